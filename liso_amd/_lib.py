@@ -1,0 +1,87 @@
+"""ctypes loader for liso_amd/libliso_hip.so (C ABI: include/*.h).
+
+The HIP library is the product.  There is no CPU fallback: if the shared object is
+missing, or a device op is called without a GPU, we raise.  PyTorch is only used
+for device memory and streams (``tensor.data_ptr()``, ``torch.cuda.current_stream()``).
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libliso_hip.so")
+
+_lib = None
+
+
+class LisoHipError(RuntimeError):
+    pass
+
+
+_ERRORS = {-1: "LISO_EINVAL (bad pointer/size)", -2: "LISO_EWORKSPACE (workspace too small)",
+           -3: "LISO_ELAUNCH (HIP launch failed)"}
+
+
+def _preload_torch_hip_runtime():
+    # torch bundles its own libamdhip64 (SONAME libamdhip64.so.7).  Our library needs the same SONAME; make
+    # sure torch's copy is the one already mapped so that both share one HIP runtime (one context, one
+    # allocator view of device pointers and streams).
+    tl = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(tl):
+        ctypes.CDLL(tl, mode=ctypes.RTLD_GLOBAL)
+
+
+def lib():
+    """Return the loaded library; raise loudly if it was never built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LisoHipError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C liso_amd/csrc`.  liso_amd has no CPU fallback for device ops.")
+        _preload_torch_hip_runtime()
+        _lib = ctypes.CDLL(LIB_PATH)
+        _declare(_lib)
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        raise LisoHipError(f"{what} failed: {_ERRORS.get(code, code)}")
+
+
+def stream_ptr(device=None):
+    """Current PyTorch HIP stream as a void* for the C ABI."""
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if not t.is_cuda:
+            raise LisoHipError("device op called with a CPU tensor; liso_amd has no CPU fallback")
+
+
+_vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+
+# symbol -> (restype, argtypes); mirrors include/*.h exactly (tests/test_abi.py parses the headers and checks)
+SIGNATURES = {
+    # include/liso_iou3d.h
+    "liso_iou3d_overlap_bev_f32": (_i, [_vp, _i, _vp, _i, _vp, _vp]),
+    "liso_iou3d_iou_bev_f32": (_i, [_vp, _i, _vp, _i, _vp, _vp]),
+    "liso_iou3d_nms_workspace_bytes": (_sz, [_i]),
+    "liso_iou3d_nms_f32": (_i, [_vp, _i, _f, _vp, _vp, _vp, _sz, _vp]),
+    "liso_iou3d_nms_normal_f32": (_i, [_vp, _i, _f, _vp, _vp, _vp, _sz, _vp]),
+    "liso_iou3d_iou_bev_cpu_f32": (_i, [_vp, _i, _vp, _i, _vp]),
+}
+
+
+def _declare(l):
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(l, name)  # AttributeError here == header/library mismatch, fail loudly
+        fn.restype = res
+        fn.argtypes = args
