@@ -356,15 +356,17 @@ __global__ __launch_bounds__(kGreedyThreads) void nms_greedy_kernel(const unsign
             if (row < n) diag = use_lds ? tile[lane * w] : mask[(size_t)row * col_blocks + b];
             const unsigned long long cur_v = remv[b];
             // wave-uniform: keep the serial chain on the scalar unit
-            unsigned long long cur = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned int)(cur_v >> 32)) << 32) |
-                                     __builtin_amdgcn_readfirstlane((unsigned int)cur_v);
+            // (readfirstlane returns int: go through unsigned int so bit 31 is not sign-extended)
+            const unsigned int cur_lo = (unsigned int)__builtin_amdgcn_readfirstlane((unsigned int)cur_v);
+            const unsigned int cur_hi = (unsigned int)__builtin_amdgcn_readfirstlane((unsigned int)(cur_v >> 32));
+            unsigned long long cur = ((unsigned long long)cur_hi << 32) | (unsigned long long)cur_lo;
             const int valid = n - rbase;  // rows >= n are never kept
             if (valid < 64) cur |= ~0ULL << valid;
             unsigned long long kept = 0ULL;
 #pragma unroll
             for (int t = 0; t < 64; t++) {
-                const unsigned int lo = __builtin_amdgcn_readlane((unsigned int)diag, t);
-                const unsigned int hi = __builtin_amdgcn_readlane((unsigned int)(diag >> 32), t);
+                const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((unsigned int)diag, t);
+                const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((unsigned int)(diag >> 32), t);
                 const unsigned long long d = ((unsigned long long)hi << 32) | lo;
                 if (!((cur >> t) & 1ULL)) {
                     kept |= 1ULL << t;
