@@ -77,7 +77,22 @@ SIGNATURES = {
     "liso_iou3d_nms_f32": (_i, [_vp, _i, _f, _vp, _vp, _vp, _sz, _vp]),
     "liso_iou3d_nms_normal_f32": (_i, [_vp, _i, _f, _vp, _vp, _vp, _sz, _vp]),
     "liso_iou3d_iou_bev_cpu_f32": (_i, [_vp, _i, _vp, _i, _vp]),
+    # include/liso_pillars.h
+    "liso_pillars_voxelize_workspace_bytes": (_sz, [_vp, _i, _i]),
+    "liso_pillars_voxelize_f32": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "liso_pfn_partials_bytes": (_sz, []),
+    "liso_pfn_bn_prepare_f32": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp,
+                                     _vp, _vp]),
+    "liso_pfn_forward_scatter": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "liso_pfn_backward": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp,
+                               _vp]),
 }
+
+
+class PillarCfg(ctypes.Structure):
+    """mirror of liso_pillar_cfg (include/liso_pillars.h)"""
+    _fields_ = [("x_min", _f), ("y_min", _f), ("z_min", _f), ("vx", _f), ("vy", _f), ("vz", _f), ("gx", _i),
+                ("gy", _i), ("max_points", _i), ("max_voxels", _i), ("n_channels", _i)]
 
 
 def _declare(l):
