@@ -95,6 +95,43 @@ class PillarCfg(ctypes.Structure):
                 ("gy", _i), ("max_points", _i), ("max_voxels", _i), ("n_channels", _i)]
 
 
+class KernelTimer:
+    """Optional HIP-event timing of individual C-ABI launches on the current PyTorch stream (used by bench.py for the
+    `roofline` object).  Disabled unless bench.py turns it on; costs two event records per timed launch."""
+
+    def __init__(self):
+        self.enabled = set()
+        self.events = {}
+
+    def enable(self, name):
+        self.enabled.add(name)
+        self.events.setdefault(name, [])
+
+    def disable_all(self):
+        self.enabled.clear()
+
+    def launch(self, name, fn):
+        if name not in self.enabled:
+            return fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        r = fn()
+        b.record()
+        self.events[name].append((a, b))
+        return r
+
+    def durations_ms(self, name):
+        torch.cuda.synchronize()
+        return [a.elapsed_time(b) for a, b in self.events.get(name, [])]
+
+    def reset(self):
+        for k in self.events:
+            self.events[k] = []
+
+
+TIMER = KernelTimer()
+
+
 def _declare(l):
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(l, name)  # AttributeError here == header/library mismatch, fail loudly

@@ -1,0 +1,71 @@
+"""CenterHead / SepHead.  Mirror of liso/networks/centerpoint/center_head.py (same ctor arguments and module names ->
+state_dict keys `shared_conv.*`, `tasks.0.{pos,dims,rot,probs}.*`)."""
+import copy
+from typing import Dict
+
+import torch
+from torch import nn
+
+from liso_amd.networks.centerpoint.rpn import conv_bn_relu
+from liso_amd.networks.centerpoint.weight_init import kaiming_init
+
+
+class SepHead(nn.Module):
+    def __init__(self, in_channels, heads, norm_cfg, head_conv=64, final_kernel=1, bn=False, **kwargs):
+        super().__init__(**kwargs)
+        self.heads = heads
+        for head in self.heads:
+            classes, num_conv = self.heads[head]
+            fc = []
+            for _ in range(num_conv - 1):  # reference :28-42
+                fc.append(nn.Conv2d(in_channels, head_conv, kernel_size=final_kernel, stride=1,
+                                    padding=final_kernel // 2, bias=True))
+                if bn:
+                    fc.append(nn.BatchNorm2d(head_conv, **norm_cfg))
+                fc.append(nn.ReLU())
+            fc.append(nn.Conv2d(head_conv, classes, kernel_size=final_kernel, stride=1, padding=final_kernel // 2,
+                                bias=True))
+            fc = nn.Sequential(*fc)
+            for m in fc.modules():
+                if isinstance(m, nn.Conv2d):
+                    kaiming_init(m)
+            self.__setattr__(head, fc)
+
+    def forward(self, x):
+        out = {}
+        for head in self.heads:
+            fc = list(self.__getattr__(head))
+            y = x
+            i = 0
+            while i < len(fc) - 1:  # conv (+BN) + ReLU groups
+                if isinstance(fc[i + 1], nn.BatchNorm2d):
+                    y = conv_bn_relu(y, fc[i], fc[i + 1])
+                    i += 3
+                else:
+                    y = torch.relu(torch.nn.functional.conv2d(y, fc[i].weight.to(y.dtype), fc[i].bias.to(y.dtype),
+                                                              padding=fc[i].padding))
+                    i += 2
+            last = fc[-1]
+            # final prediction conv: fp32 output (logits / regression targets feed an fp32 loss)
+            out[head] = torch.nn.functional.conv2d(y, last.weight.to(y.dtype), last.bias.to(y.dtype),
+                                                   padding=last.padding).float()
+        return out
+
+
+class CenterHead(nn.Module):
+    def __init__(self, common_heads: Dict, norm_cfg, in_channels=(128,), stride=1, share_conv_channel=64):
+        super().__init__()
+        self.in_channels = in_channels
+        self.num_classes = 1
+        self.shared_conv = nn.Sequential(  # reference :81-92
+            nn.Conv2d(in_channels, share_conv_channel, stride=stride, kernel_size=3, padding=1, bias=True),
+            nn.BatchNorm2d(share_conv_channel, **norm_cfg), nn.ReLU(inplace=True))
+        self.tasks = nn.ModuleList()
+        self.tasks.append(SepHead(share_conv_channel, copy.deepcopy(common_heads), norm_cfg=norm_cfg, bn=True,
+                                  final_kernel=3))
+
+    def forward(self, x, *kwargs):
+        x = conv_bn_relu(x, self.shared_conv[0], self.shared_conv[1])
+        ret = [task(x) for task in self.tasks]
+        assert len(ret) == 1, len(ret)
+        return ret[0]

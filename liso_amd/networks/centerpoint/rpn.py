@@ -1,0 +1,104 @@
+"""RPN: SECOND-style BEV backbone.  Mirror of liso/networks/centerpoint/rpn.py (same ctor, same Sequential indices ->
+same state_dict keys `blocks.{i}.{j}.*`, `deblocks.{i}.{j}.*`, including the ZeroPad2d at index 0, rpn.py:113-129).
+
+MI355X notes: tensors stay channels-last (the pillar scatter already produces NHWC storage) and in the dtype they
+arrive in (bf16 for the perf configuration, fp32 for parity); convolutions go to MIOpen's NHWC implicit-GEMM
+(MFMA) kernels, BatchNorm statistics stay fp32.  forward() is functional so ZeroPad2d+conv(pad=0) becomes one
+padded conv (identical arithmetic, one HBM round trip less per stage).
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from liso_amd.networks.centerpoint.norm import baurst_build_norm_layer as build_norm_layer
+from liso_amd.networks.centerpoint.weight_init import xavier_init
+
+
+def conv_bn_relu(x, conv, bn, stride=None, padding=None):
+    """conv (+bias) -> BatchNorm2d -> ReLU on a channels-last tensor; BN stats in fp32 whatever the conv dtype."""
+    w = conv.weight
+    if w.dtype != x.dtype:
+        w = w.to(x.dtype)
+    b = conv.bias.to(x.dtype) if conv.bias is not None else None
+    if isinstance(conv, nn.ConvTranspose2d):
+        y = F.conv_transpose2d(x, w, b, stride=conv.stride)
+    else:
+        y = F.conv2d(x, w, b, stride=conv.stride if stride is None else stride,
+                     padding=conv.padding if padding is None else padding)
+    y = F.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.training or not bn.track_running_stats,
+                     bn.momentum, bn.eps)
+    if bn.training and bn.track_running_stats:
+        bn.num_batches_tracked += 1
+    return F.relu(y, inplace=True)
+
+
+class RPN(nn.Module):
+    def __init__(self, layer_nums, ds_layer_strides, ds_num_filters, us_layer_strides, us_num_filters,
+                 num_input_features, norm_cfg=None, name="rpn", **kwargs):
+        super().__init__()
+        self._layer_strides = ds_layer_strides
+        self._num_filters = ds_num_filters
+        self._layer_nums = layer_nums
+        self._upsample_strides = us_layer_strides
+        self._num_upsample_filters = us_num_filters
+        self._num_input_features = num_input_features
+        if norm_cfg is None:
+            norm_cfg = {"type": "BN", "eps": 1e-3, "momentum": 0.01}  # reference :35-36
+        self._norm_cfg = norm_cfg
+        assert len(self._layer_strides) == len(self._layer_nums) == len(self._num_filters)
+        assert len(self._num_upsample_filters) == len(self._upsample_strides)
+        self._upsample_start_idx = len(self._layer_nums) - len(self._upsample_strides)
+        in_filters = [self._num_input_features, *self._num_filters[:-1]]
+        blocks, deblocks = [], []
+        for i, layer_num in enumerate(self._layer_nums):
+            block, num_out = self._make_layer(in_filters[i], self._num_filters[i], layer_num,
+                                              stride=self._layer_strides[i])
+            blocks.append(block)
+            if i - self._upsample_start_idx >= 0:  # reference :70-104
+                stride = self._upsample_strides[i - self._upsample_start_idx]
+                out_f = self._num_upsample_filters[i - self._upsample_start_idx]
+                if stride > 1:
+                    up = nn.ConvTranspose2d(num_out, out_f, stride, stride=stride, bias=False)
+                else:
+                    k = int(np.round(1 / stride).astype(np.int64))
+                    up = nn.Conv2d(num_out, out_f, k, stride=k, bias=False)
+                deblocks.append(nn.Sequential(up, build_norm_layer(self._norm_cfg, out_f)[1], nn.ReLU()))
+        self.blocks = nn.ModuleList(blocks)
+        self.deblocks = nn.ModuleList(deblocks)
+
+    @property
+    def downsample_factor(self):
+        factor = np.prod(self._layer_strides)
+        if len(self._upsample_strides) > 0:
+            factor /= self._upsample_strides[-1]
+        return factor
+
+    def _make_layer(self, inplanes, planes, num_blocks, stride=1):
+        """reference :113-131"""
+        layers = [nn.ZeroPad2d(1), nn.Conv2d(inplanes, planes, 3, stride=stride, bias=False),
+                  build_norm_layer(self._norm_cfg, planes)[1], nn.ReLU()]
+        for _ in range(num_blocks):
+            layers += [nn.Conv2d(planes, planes, 3, padding=1, bias=False),
+                       build_norm_layer(self._norm_cfg, planes)[1], nn.ReLU()]
+        return nn.Sequential(*layers), planes
+
+    def init_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                xavier_init(m, distribution="uniform")
+
+    def forward(self, x):
+        """reference :137-146"""
+        ups = []
+        for i, block in enumerate(self.blocks):
+            mods = list(block)
+            x = conv_bn_relu(x, mods[1], mods[2], padding=1)  # ZeroPad2d(1) + conv(pad 0) == conv(pad 1)
+            for j in range(4, len(mods), 3):
+                x = conv_bn_relu(x, mods[j], mods[j + 1])
+            if i - self._upsample_start_idx >= 0:
+                d = self.deblocks[i - self._upsample_start_idx]
+                ups.append(conv_bn_relu(x, d[0], d[1]))
+        if len(ups) > 0:
+            x = torch.cat(ups, dim=1)
+        return x

@@ -91,10 +91,10 @@ class _PillarFeatureScatter(torch.autograd.Function):
                                                 L.ptr(partials), st), "pfn_bn_prepare")
             canvas = torch.zeros((B, pcfg.gx, pcfg.gy, 64), dtype=out_dtype, device=dev)
             occupancy = torch.zeros((B, 1, pcfg.gx, pcfg.gy), dtype=torch.float32, device=dev)
-            L.check(lib.liso_pfn_forward_scatter(L.ptr(points), ctypes.byref(pcfg), B, L.ptr(coors), L.ptr(num_points),
-                                                 L.ptr(slots), L.ptr(num_voxels), L.ptr(weight), L.ptr(bn_out),
-                                                 L.ptr(canvas), int(out_dtype == torch.bfloat16), L.ptr(occupancy),
-                                                 st), "pfn_forward_scatter")
+            L.check(L.TIMER.launch("pfn_forward_scatter", lambda: lib.liso_pfn_forward_scatter(
+                L.ptr(points), ctypes.byref(pcfg), B, L.ptr(coors), L.ptr(num_points), L.ptr(slots), L.ptr(num_voxels),
+                L.ptr(weight), L.ptr(bn_out), L.ptr(canvas), int(out_dtype == torch.bfloat16), L.ptr(occupancy), st)),
+                "pfn_forward_scatter")
         ctx.save_for_backward(points, coors, num_points, slots, num_voxels, weight, gamma, bn_out, moments)
         ctx.pcfg, ctx.B, ctx.training = pcfg, B, bool(training)
         ctx.mark_non_differentiable(occupancy)

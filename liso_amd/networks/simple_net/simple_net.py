@@ -1,0 +1,59 @@
+"""BoxLearner: network selector + activations + decode.  Mirror of liso/networks/simple_net/simple_net.py:28-151
+for the CenterPoint-pillar path (the other selectable networks are out of scope)."""
+from typing import Dict, Tuple
+
+import numpy as np
+import torch
+
+from liso_amd.kabsch.output_modification import maybe_flatten_anchors_except_for, output_modification
+from liso_amd.kabsch.shape_utils import Shape
+from liso_amd.networks.simple_net.centerpoint_net import CenterPointStyleNet
+from liso_amd.networks.simple_net.simple_net_utils import allowed_activations
+from liso_amd.utils.bev_utils import get_metric_voxel_center_coords
+
+
+def get_centermaps_output_grid_size(cfg, output_grid_size):
+    """liso/datasets/torch_dataset_commons.py:106-130 (centerpoint branch)"""
+    if cfg.network.name != "centerpoint":
+        return None
+    ds = 4 if cfg.network.centerpoint.use_baseline_parameters else 8
+    if cfg.network.centerpoint.reduce_receptive_field == 1:
+        ds //= 2
+    elif cfg.network.centerpoint.reduce_receptive_field != 0:
+        raise NotImplementedError()
+    return output_grid_size // ds
+
+
+class BoxLearner(torch.nn.Module):
+    def __init__(self, cfg) -> None:
+        super().__init__()
+        self.cfg = cfg
+        self.activations = {k: allowed_activations[v] for k, v in cfg.box_prediction.activations.items()}
+        if cfg.network.name != "centerpoint":
+            raise NotImplementedError(f"{cfg.network.name}: only the centerpoint network is on the hot path")
+        self.model = CenterPointStyleNet(cfg)
+        shape = get_centermaps_output_grid_size(cfg, np.array(cfg.data.img_grid_size))
+        # a non-trainable Parameter, hence part of the state_dict (reference :59-68)
+        self.pillar_center_coors_m = torch.nn.parameter.Parameter(
+            torch.from_numpy(get_metric_voxel_center_coords(
+                bev_range_x=cfg.data.bev_range_m[0], bev_range_y=cfg.data.bev_range_m[1],
+                dataset_img_shape=shape).astype(np.float32)[..., 0:2]), requires_grad=False)
+
+    def forward(self, img_t0, pcls_t0, gt_boxes=None, centermaps_gt=None, train=True) -> Tuple[Shape, Dict]:
+        raw_box_vars, aux_outputs = self.model(img_t0, pcls_t0)
+        decoded, activated = self.apply_all_output_modifications(raw_box_vars=raw_box_vars, gt_boxes=gt_boxes,
+                                                                 centermaps_gt=centermaps_gt)
+        flat = maybe_flatten_anchors_except_for({k: v.clone() for k, v in decoded.items()}, ())
+        return Shape(**flat), decoded, activated, aux_outputs
+
+    def apply_all_output_modifications(self, *, raw_box_vars, gt_boxes=None, centermaps_gt=None):
+        """reference :111-151"""
+        activated = {k: self.activations[k](v) for k, v in raw_box_vars.items()}
+        decoded = output_modification({k: v.clone() for k, v in activated.items()}, self.cfg.box_prediction,
+                                      self.cfg.data, "boxes", self.pillar_center_coors_m)
+        return decoded, activated
+
+
+def select_network(cfg, device):
+    """reference :154-176 (centerpoint only)"""
+    return BoxLearner(cfg).to(device)

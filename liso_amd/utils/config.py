@@ -29,6 +29,7 @@ def default_cfg(grid=512, bev_range_m=100.0, use_lidar_intensity=True):
     """CenterPoint-pillar detector + SLIM settings of the reference's KITTI/nuScenes overlays."""
     return to_attr({
         "data": {
+            "shapes": {"name": "boxes"},
             "bev_range_m": (bev_range_m, bev_range_m),      # liso_config.yml:515-522
             "img_grid_size": (grid, grid),
             "z_pillar_cutoff_value": 10.0,                  # :116
@@ -46,11 +47,15 @@ def default_cfg(grid=512, bev_range_m=100.0, use_lidar_intensity=True):
         },
         "box_prediction": {
             "position_representation": {"method": "local_relative_offset", "num_box_pos_dims": 3,
-                                        "box_z_pos_prior_min": -10.0, "box_z_pos_prior_max": 10.0},
-            "rotation_representation": {"method": "vector", "norm_vector": False},           # :702-705
+                                        "box_z_pos_prior_min": -1.5, "box_z_pos_prior_max": -0.5},  # :200-201
+            "rotation_representation": {"method": "vector", "norm_vector_len": False,         # :702-705, :206
+                                        "regularization": "rot_vec_on_unit_circle", "regul_weight": 0.0001},
             "dimensions_representation": {"method": "predict_abs_size"},                      # :695-697
             "activations": {"pos": "tanh", "dims": "softplus", "rot": "none", "probs": "none"},  # :617-631
             "output_modification": {"pos": "none", "dims": "none", "rot": "none", "probs": "none"},
         },
-        "loss": {"supervised": {"centermaps": {"active": True}}},
+        "loss": {"supervised": {"centermaps": {"active": True, "confidence_target": "gaussian"},   # :179
+                                "supervised_on_clusters": {"active": True, "weight": 1.0,
+                                                           "attrs": ("pos", "dims", "rot", "probs")}}},  # :155-162
+        "optimization": {"learning_rate": 0.001, "num_training_steps": 350000},                      # :137-138
     })

@@ -1,0 +1,141 @@
+"""CPU: (1) oracle/detector.py vs fixtures from the reference's modules; (2) the product's RPN / CenterHead / decode /
+loss host modules (plain torch, device-agnostic) vs the same fixtures, including state_dict key compatibility."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import detector as OD
+
+HEADS = ("pos", "dims", "rot", "probs")
+
+
+def _fix(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def _sd(g, prefix):
+    tag = "sd_" + prefix + "__"
+    return {k[len(tag):].replace("__", "."): torch.from_numpy(g[k]).clone() for k in g.files if k.startswith(tag)}
+
+
+def _close(a, b, rel=1e-4):
+    a = a.detach().numpy() if torch.is_tensor(a) else a
+    return np.abs(a - b).max() <= rel * max(np.abs(b).max(), 1e-6)
+
+
+def test_oracle_rpn_head_matches_reference(golden_dir):
+    g = _fix(golden_dir, "detector_rpn_head.npz")
+    x = torch.from_numpy(g["x"])
+    for tag, training in (("train", True), ("eval", False)):
+        rsd, hsd = _sd(g, "rpn"), _sd(g, "head")
+        feat = OD.rpn_forward(rsd, x, [3, 5, 5], [2, 2, 2], [0.5, 1, 2], training)
+        assert _close(feat, g[f"{tag}_feat"])
+        pred = OD.center_head_forward(hsd, feat, HEADS, training)
+        for h in HEADS:
+            assert _close(pred[h], g[f"{tag}_{h}"]), (tag, h)
+
+
+def _product_modules():
+    from liso_amd.networks.centerpoint.center_head import CenterHead
+    from liso_amd.networks.centerpoint.rpn import RPN
+
+    norm = {"affine": True, "track_running_stats": True}
+    rpn = RPN(layer_nums=[3, 5, 5], ds_layer_strides=[2, 2, 2], ds_num_filters=[16, 32, 64],
+              us_layer_strides=[0.5, 1, 2], us_num_filters=[32, 32, 32], num_input_features=16, norm_cfg=norm)
+    head = CenterHead(common_heads={"pos": (3, 2), "dims": (3, 2), "rot": (2, 2), "probs": (1, 2)}, norm_cfg=norm,
+                      in_channels=96, stride=1, share_conv_channel=16)
+    return rpn, head
+
+
+def test_product_rpn_head_match_reference_and_share_its_state_dict(golden_dir):
+    g = _fix(golden_dir, "detector_rpn_head.npz")
+    x = torch.from_numpy(g["x"])
+    for tag, training in (("train", True), ("eval", False)):
+        rpn, head = _product_modules()
+        rpn.load_state_dict(_sd(g, "rpn"), strict=True)   # identical key set == drop-in checkpoints
+        head.load_state_dict(_sd(g, "head"), strict=True)
+        rpn.train(training), head.train(training)
+        xi = x.clone().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        feat = rpn(xi)
+        pred = head(feat)
+        assert _close(feat, g[f"{tag}_feat"])
+        for h in HEADS:
+            assert _close(pred[h], g[f"{tag}_{h}"]), (tag, h)
+        if training:
+            sum((v * torch.linspace(-1, 1, v.numel()).view_as(v)).sum() for v in pred.values()).backward()
+            assert _close(xi.grad, g["train_grad_x"], 1e-3)
+            assert _close(rpn.blocks[0][1].weight.grad, g["train_grad_rpn_blocks_0_1_weight"], 1e-3)
+            assert _close(rpn.deblocks[2][0].weight.grad, g["train_grad_rpn_deblocks_2_0_weight"], 1e-3)
+            assert _close(head.tasks[0].probs[3].bias.grad, g["train_grad_head_probs_3_bias"], 1e-3)
+            assert _close(rpn.blocks[0][2].running_mean, g["train_rm_after_rpn_blocks_0_2"])
+            assert int(rpn.blocks[0][2].num_batches_tracked) == 1
+
+
+def _loss_inputs(g):
+    raw = {k: torch.from_numpy(g["raw_" + k]).clone().requires_grad_(True) for k in HEADS}
+    gt = {k: torch.from_numpy(g["gt_" + k]) for k in HEADS}
+    return raw, gt, torch.from_numpy(g["center_mask"]), torch.from_numpy(g["ignore"]), torch.from_numpy(g["centers"])
+
+
+def test_oracle_decode_loss_matches_reference(golden_dir):
+    g = _fix(golden_dir, "detector_decode_loss.npz")
+    raw, gt, cm, ig, centers = _loss_inputs(g)
+    dec, act = OD.decode(raw, centers, (40.0, 40.0), -1.5, -0.5)
+    for k in HEADS:
+        assert _close(dec[k], g["dec_" + k], 1e-5), k
+    losses = OD.centerpoint_loss(dec, act, gt, cm, ig, torch.ones_like(gt["probs"]))
+    for k in HEADS:
+        assert _close(losses[k], g["loss_" + k], 1e-5), k
+    sum(losses.values()).backward()
+    for k in HEADS:
+        assert _close(raw[k].grad, g["grad_" + k], 1e-4), k
+
+
+def test_product_decode_loss_match_reference(golden_dir):
+    from liso_amd.kabsch.output_modification import output_modification
+    from liso_amd.losses.centerpoint_loss import centerpoint_loss
+    from liso_amd.networks.simple_net.simple_net_utils import allowed_activations
+    from liso_amd.utils.config import default_cfg
+
+    g = _fix(golden_dir, "detector_decode_loss.npz")
+    raw, gt, cm, ig, centers = _loss_inputs(g)
+    cfg = default_cfg(grid=64, bev_range_m=40.0)
+    act = {k: allowed_activations[cfg.box_prediction.activations[k]](v) for k, v in raw.items()}
+    dec = output_modification({k: v.clone() for k, v in act.items()}, cfg.box_prediction, cfg.data, "boxes", centers)
+    for k in HEADS:
+        assert _close(dec[k], g["dec_" + k], 1e-5), k
+    losses = centerpoint_loss(loss_cfg=cfg.loss, decoded_pred_box_maps=dec, raw_activated_pred_box_maps=act, gt_maps=gt,
+                              gt_center_mask=cm, rotation_loss_weights_map=torch.ones_like(gt["probs"]),
+                              box_prediction_cfg=cfg.box_prediction, ignore_region_is_true_mask=ig)
+    for k in HEADS:
+        assert _close(losses["loss/supervised/centermaps/" + k], g["loss_" + k], 1e-5), k
+    sum(losses.values()).backward()
+    for k in HEADS:
+        assert _close(raw[k].grad, g["grad_" + k], 1e-4), k
+    # empty positive set: every term defined and finite (the reference omits the keys instead)
+    raw2, gt2, cm2, ig2, _ = _loss_inputs(g)
+    act2 = {k: allowed_activations[cfg.box_prediction.activations[k]](v) for k, v in raw2.items()}
+    dec2 = output_modification({k: v.clone() for k, v in act2.items()}, cfg.box_prediction, cfg.data, "boxes", centers)
+    l2 = centerpoint_loss(loss_cfg=cfg.loss, decoded_pred_box_maps=dec2, raw_activated_pred_box_maps=act2, gt_maps=gt2,
+                          gt_center_mask=torch.zeros_like(cm2), rotation_loss_weights_map=torch.ones_like(gt2["probs"]),
+                          box_prediction_cfg=cfg.box_prediction, ignore_region_is_true_mask=ig2)
+    assert float(l2["loss/supervised/centermaps/rot"]) == 0.0 and torch.isfinite(l2["loss/supervised/centermaps/probs"])
+
+
+def test_shape_and_pose_helpers():
+    from liso_amd.kabsch.shape_utils import Shape
+    from liso_amd.utils.nms_iou import convert_shapes_to_dense_3d
+
+    torch.manual_seed(0)
+    s = Shape(pos=torch.randn(6, 3), dims=torch.rand(6, 3) + 1, rot=torch.randn(6, 1), probs=torch.rand(6, 1))
+    T = s.get_poses()
+    assert T.dtype == torch.float64 and T.shape == (6, 4, 4)
+    c, sn = torch.cos(s.rot[:, 0].double()), torch.sin(s.rot[:, 0].double())
+    assert torch.allclose(T[:, 0, 0], c) and torch.allclose(T[:, 0, 1], -sn) and torch.allclose(T[:, :3, 3], s.pos.double())
+    s.valid[2] = False
+    d = convert_shapes_to_dense_3d(s)
+    assert d.shape == (6, 7) and d[2].abs().sum() == 0
+    assert s.drop_padding_boxes().shape == (5,)
+    b = Shape.from_list_of_shapes([s.drop_padding_boxes(), s[:2]])
+    assert b.shape == (2, 5) and b.valid.sum() == 7

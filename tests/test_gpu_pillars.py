@@ -108,9 +108,12 @@ def test_determinism_bf16_and_edge_cases():
     b, occ_b = m([pcl])
     assert torch.equal(a, b) and torch.equal(occ_a, occ_b)  # no float atomics anywhere: bitwise reproducible
     # point order only matters through which 20 points a crowded pillar keeps: occupancy is permutation invariant
-    perm = torch.randperm(pcl.shape[0], device="cuda")
-    _, occ_p = m([pcl[perm]])
-    assert torch.equal(occ_a, occ_p)
+    # (below the 40000-voxel cap; above it the cap itself depends on point order, like the reference)
+    small = pcl[:30000]
+    _, occ_s = m([small])
+    perm = torch.randperm(small.shape[0], device="cuda")
+    _, occ_p = m([small[perm]])
+    assert torch.equal(occ_s, occ_p) and int(occ_s.sum()) < 40000
     m.out_dtype = torch.bfloat16
     c, _ = m([pcl])
     assert c.dtype == torch.bfloat16
