@@ -1,0 +1,62 @@
+/*
+ * liso_kabsch.h -- C ABI of the MI355X-native Kabsch / weighted point-cloud alignment ops.
+ *
+ * Replaces, for the reference call sites
+ *   liso/kabsch/kabsch_mask.py:149-228   render_soft_kabsch_mask_torch / get_box_pixel_weights  (soft box masks)
+ *   liso/kabsch/kabsch_mask.py:328-399   KabschDecoder.get_kabsch_trafos_from_point_flow        (fg/bg weights)
+ *   liso/kabsch/kabsch_mask.py:401-508   per_mask_trafo_from_pointwise_flows /
+ *                                        weighted_pc_alignment_for_different_batched_slotted_kabsch_weights
+ *   liso/torch_symm_ortho/__init__.py:7-87  SymmetricOrthogonalization forward (R = U Vh of an fp64 SVD) + backward
+ * The reference materialises [B,S,N,4] point-in-box coordinates and four [B,S,N,3] tensors; here one pass over the
+ * points produces all per-slot weighted moments, and a 3x3 one-sided Jacobi (no library SVD) gives U, D, Vh.
+ *
+ * All pointers are device pointers; nothing allocates or synchronises; returns LISO_OK or a negative code.
+ */
+#ifndef LISO_KABSCH_H
+#define LISO_KABSCH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LISO_KABSCH_NMOM 9 /* sum w | sum w x (2) | sum w y (2) | sum w y x^T (4), x relative to the slot's box centre */
+
+typedef struct {
+    int batch, n_points, n_slots; /* B, N (padded length), S foreground slots */
+    int point_stride;             /* floats between consecutive points of `points` (>= 3) */
+    int flow_stride;              /* floats between consecutive points of `flow` (>= 2, only x,y are read) */
+    float slope;                  /* mask_rendering.pred_sigmoid_slope (15) */
+    float scale_fg, scale_bg;     /* 1 - obj_dim_scale_buffer, 1 + obj_dim_scale_buffer (0.75, 1.25) */
+    int softness;                 /* 0 = cauchy (0.5 + atan(x)/pi), 1 = sigmoid */
+} liso_kabsch_cfg;
+
+/* scratch for liso_kabsch_trafos_f32 */
+size_t liso_kabsch_workspace_bytes(const liso_kabsch_cfg* cfg);
+
+/* points [B,N,point_stride] (padding rows may hold NaN), valid [B,N] (uint8), flow [B,N,flow_stride],
+ * box_pos [B,S,3], box_dims [B,S,3], box_rot [B,S] ->
+ *   trafos   float64 [B, S+1, 4, 4]  (foreground slots then the background slot)
+ *   cum_wts  float32 [B, S+1]
+ *   fg_weights float32 [B, S, N] or NULL (kabsch_mask.py:353-360; invalid points get weight 0, :417-419)
+ * Semantics: z of the aligned clouds is zeroed (:413), background weight = 1 - screen(fg masks at scale_bg)
+ * (:362-372), slots whose total weight is < 1e-12 fall back to uniform weights 1e-12 (:452-470),
+ * R = U Vh without reflection fix (:489-492). */
+int liso_kabsch_trafos_f32(const liso_kabsch_cfg* cfg, const float* points, const uint8_t* valid, const float* flow,
+                           const float* box_pos, const float* box_dims, const float* box_rot, double* trafos,
+                           float* cum_wts, float* fg_weights, void* workspace, size_t workspace_bytes, void* stream);
+
+/* SymmetricOrthogonalization.forward for n 3x3 matrices (row-major fp64): R = U Vh; U, Vh, D are saved for backward. */
+int liso_symm_ortho_fwd_f64(const double* a, int n, double* r, double* u, double* vh, double* d, void* stream);
+
+/* SymmetricOrthogonalization.backward (torch_symm_ortho/__init__.py:15-43): grad_A = U (W - W^T) Vh with
+ * W_kl = (U^T grad_R V)_kl / (d_k + d_l + delta_kl). */
+int liso_symm_ortho_bwd_f64(const double* grad_r, const double* u, const double* vh, const double* d, int n,
+                            double* grad_a, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LISO_KABSCH_H */

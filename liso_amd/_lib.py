@@ -86,7 +86,18 @@ SIGNATURES = {
     "liso_pfn_forward_scatter": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "liso_pfn_backward": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp,
                                _vp]),
+    # include/liso_kabsch.h
+    "liso_kabsch_workspace_bytes": (_sz, [_vp]),
+    "liso_kabsch_trafos_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "liso_symm_ortho_fwd_f64": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "liso_symm_ortho_bwd_f64": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),
 }
+
+
+class KabschCfg(ctypes.Structure):
+    """mirror of liso_kabsch_cfg (include/liso_kabsch.h)"""
+    _fields_ = [("batch", _i), ("n_points", _i), ("n_slots", _i), ("point_stride", _i), ("flow_stride", _i),
+                ("slope", _f), ("scale_fg", _f), ("scale_bg", _f), ("softness", _i)]
 
 
 class PillarCfg(ctypes.Structure):

@@ -32,7 +32,7 @@ constexpr int kOut = LISO_PFN_OUT;
 constexpr int kFP = 12;              // padded feature row in LDS (F <= 11, +1 augmented "1")
 constexpr int kMaxPts = 32;          // max_points supported by the one-wave-per-pillar mapping
 constexpr int kPfnThreads = 256;
-constexpr int kPfnGrid = 512;        // persistent grid for stats/backward (fixed => deterministic partial order)
+constexpr int kPfnGrid = 1024;       // persistent grid for stats/backward (fixed => deterministic partial order)
 
 struct BatchInfo {
     int off[LISO_PILLARS_MAX_BATCH + 1];       // point offsets
@@ -155,6 +155,9 @@ __global__ void fill_kernel(const int* __restrict__ cell_of_point, const int* __
     const int v = cell_to_voxel[cell] - 1;
     if (v < 0) return;
     int* s = slots + (size_t)v * max_points;
+    // the slot values only ever decrease: once the last slot holds a smaller index than ours we can never enter.
+    // In crowded pillars (hundreds of points near the sensor) this removes almost all of the contended atomics.
+    if (__hip_atomic_load(&s[max_points - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < i) return;
     int carry = i;
     for (int k = 0; k < max_points; k++) {
         const int old = atomicMin(&s[k], carry);
@@ -482,13 +485,25 @@ __global__ __launch_bounds__(1024) void pfn_backward_finalize_kernel(const float
                                                                      float* __restrict__ grad_beta) {
     constexpr int F = C + 6, NA = F + 2, D = F + 1;
     __shared__ double tot[NA][kOut];
-    for (int idx = threadIdx.x; idx < NA * kOut; idx += blockDim.x) {
-        const int k = idx / kOut, c = idx % kOut;
-        double s = 0.0;
-        for (int blk = 0; blk < nblocks; blk++) s += (double)partials[((size_t)blk * NA + k) * kOut + c];
-        tot[k][c] = s;
+    __shared__ double part[16][kOut];
+    {
+        // 1024 threads = 64 channels x 16 chunks of blocks; chunks are combined in fixed order (reproducible)
+        const int c = threadIdx.x & 63, chunk = threadIdx.x >> 6;
+        const int per = (nblocks + 15) / 16;
+        const int lo = chunk * per, hi = lo + per < nblocks ? lo + per : nblocks;
+        for (int k = 0; k < NA; k++) {
+            double s = 0.0;
+            for (int blk = lo; blk < hi; blk++) s += (double)partials[((size_t)blk * NA + k) * kOut + c];
+            part[chunk][c] = s;
+            __syncthreads();
+            if (chunk == 0) {
+                double t = 0.0;
+                for (int q = 0; q < 16; q++) t += part[q][c];
+                tot[k][c] = t;
+            }
+            __syncthreads();
+        }
     }
-    __syncthreads();
     if (threadIdx.x < kOut) {
         const int c = threadIdx.x;
         const double dbeta = tot[F][c], dgamma = tot[F + 1][c];

@@ -17,7 +17,7 @@ def modify_pred_pos(pred_pos, box_pred_cfg, data_cfg, pillar_center_coors_m):
         pr = box_pred_cfg.position_representation
         if pr.num_box_pos_dims == 3:
             assert pred_pos.shape[-1] == 3, pred_pos.shape
-            z = pr.box_z_pos_prior_min + 0.5 * (pred_pos[..., [-1]] + 1.0) * (pr.box_z_pos_prior_max - pr.box_z_pos_prior_min)
+            z = pr.box_z_pos_prior_min + 0.5 * (pred_pos[..., -1:] + 1.0) * (pr.box_z_pos_prior_max - pr.box_z_pos_prior_min)
             out = torch.cat([out, z], dim=-1)
         return out
     if method == "global_absolute":

@@ -57,5 +57,7 @@ def default_cfg(grid=512, bev_range_m=100.0, use_lidar_intensity=True):
         "loss": {"supervised": {"centermaps": {"active": True, "confidence_target": "gaussian"},   # :179
                                 "supervised_on_clusters": {"active": True, "weight": 1.0,
                                                            "attrs": ("pos", "dims", "rot", "probs")}}},  # :155-162
+        "mask_rendering": {"softness_fun": "cauchy", "pred_sigmoid_slope": 15.0, "obj_dim_scale_buffer": 0.25},  # :130-134
+        "svd_backend": "symm_ortho",                                                                  # :230
         "optimization": {"learning_rate": 0.001, "num_training_steps": 350000},                      # :137-138
     })

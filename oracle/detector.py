@@ -52,7 +52,7 @@ def decode(raw, pillar_centers, bev_range_m, z_min, z_max):
     (pos=tanh/local_relative_offset, dims=softplus/abs size, rot=vector, probs=none).  raw: dict of NHWC maps."""
     act = {"pos": torch.tanh(raw["pos"]), "dims": F.softplus(raw["dims"]), "rot": raw["rot"], "probs": raw["probs"]}
     H, W = raw["pos"].shape[1:3]
-    res = torch.tensor(bev_range_m) / torch.tensor([H, W])
+    res = (torch.tensor(bev_range_m) / torch.tensor([H, W])).to(raw["pos"].device)
     xy = pillar_centers[None] + res * 0.5 * act["pos"][..., :2]
     z = z_min + 0.5 * (act["pos"][..., [-1]] + 1.0) * (z_max - z_min)
     s, c = torch.split(act["rot"], 1, dim=-1)
@@ -71,8 +71,8 @@ def centerpoint_loss(dec, act, gt, center_mask, ignore_mask, rot_weights):
     out["probs"] = -(pos_l[center_mask & ~ignore_mask].sum() + neg_l[~center_mask & ~ignore_mask].sum()) / num_pos
     sel = center_mask & ~ignore_mask
     if sel.sum() > 0:
-        w = torch.maximum(rot_weights[sel], torch.tensor(0.1))
-        w = w / torch.maximum(w.sum(), torch.tensor(1.0))
+        w = torch.maximum(rot_weights[sel], torch.tensor(0.1, device=sel.device))
+        w = w / torch.maximum(w.sum(), torch.tensor(1.0, device=sel.device))
         out["rot"] = 10 * torch.sum(F.l1_loss(act["rot"][sel], gt["rot"][sel], reduction="none") * w)
         out["dims"] = F.l1_loss(dec["dims"][sel], gt["dims"][sel]).sum() / num_pos
         out["pos"] = F.l1_loss(dec["pos"][sel], gt["pos"][sel]).sum() / num_pos

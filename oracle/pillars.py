@@ -122,11 +122,11 @@ def scatter(voxel_features, coors, batch_size, ny, nx):
 
 
 def pillar_forward(pcls, weight, gamma, beta, running_mean, running_var, training, bev_range_m, img_grid_size, z_cut,
-                   max_points=20, max_voxels=40000):
+                   max_points=20, max_voxels=40000, dtype=torch.float32):
     """pcl_to_feature_grid.py:86-107 end to end -> (bev[B,64,H,W], occupancy[B,1,H,W], (voxels,num,coors,point_idx))"""
     pc_range, voxel_size = pillar_geometry(bev_range_m, img_grid_size, z_cut)
     v, n, c, pi = voxelize_batch(pcls, voxel_size, pc_range, max_points, max_voxels)
-    vt, nt, ct = torch.from_numpy(v), torch.from_numpy(n), torch.from_numpy(c)
+    vt, nt, ct = torch.from_numpy(v).to(dtype), torch.from_numpy(n), torch.from_numpy(c)
     feats = pfn_decorate(vt, nt, ct, voxel_size, pc_range)
     vf = pfn_layer(feats, weight, gamma, beta, running_mean, running_var, training)
     B = len(pcls)

@@ -25,25 +25,61 @@ def _rel(a, b):
 
 
 def test_train_step_matches_cpu_oracle_fp32():
-    from oracle.train_step import detector_forward_loss
+    """Forward (loss) within 1e-3 of the oracle.  Gradients: the backward of a freshly initialised BN/ReLU stack with
+    small BN batches is ill-conditioned in fp32 -- the oracle run in fp32 differs from the oracle run in fp64 by up to
+    ~1e-2 on some tensors -- so each gradient must be within max(1e-3, 3x the oracle's own fp32-vs-fp64 error) of the
+    fp64 oracle: never worse than the reference arithmetic's rounding noise."""
+    from oracle.train_step import detector_forward_loss, prepare_state
 
     tr, pcls, targets = _setup(128, 100.0, 2, 20000)
-    sd0 = {k: v.detach().cpu().clone() for k, v in tr.net.state_dict().items()}
+    sd0 = tr.net.state_dict()
     tr.model.train()
     total, losses, _ = tr.loss(pcls, targets)
     total.backward()
-    # oracle on the host with the same weights
-    sd = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k
-              and k != "pillar_center_coors_m" else v.clone()) for k, v in sd0.items()}
+    cpu_pcls = [p.cpu() for p in pcls]
     t_cpu = {k: v.cpu() for k, v in targets.items()}
-    ref_total, ref_raw, ref_bev = detector_forward_loss(sd, [p.cpu() for p in pcls], t_cpu, 128, 100.0)
-    ref_total.backward()
-    assert abs(float(total) - float(ref_total)) <= 1e-3 * abs(float(ref_total))
+    sd32, sd64 = prepare_state(sd0, torch.float32), prepare_state(sd0, torch.float64)
+    ref32, _, _ = detector_forward_loss(sd32, cpu_pcls, t_cpu, 128, 100.0)
+    ref32.backward()
+    ref64, _, _ = detector_forward_loss(sd64, cpu_pcls, t_cpu, 128, 100.0, dtype=torch.float64)
+    ref64.backward()
+    assert abs(float(total) - float(ref64)) <= 1e-3 * abs(float(ref64))
     names = dict(tr.net.named_parameters())
-    for k in ("model.pfn.pts_voxel_encoder.pfn_layers.0.linear.weight", "model.rpn.blocks.0.1.weight",
-              "model.rpn.blocks.2.4.weight", "model.rpn.deblocks.2.0.weight", "model.center_head.shared_conv.0.weight",
-              "model.center_head.tasks.0.probs.3.bias", "model.center_head.tasks.0.rot.3.weight"):
-        assert _rel(names[k].grad, sd[k].grad) < 2e-3, k
+    keys = [k for k, p in names.items() if p.grad is not None and sd64[k].grad is not None
+            and float(sd64[k].grad.abs().max()) >= 1e-6]  # conv biases in front of a BatchNorm: true gradient == 0
+    noise = max(_rel(sd32[k].grad, sd64[k].grad) for k in keys)  # conditioning of this backward in fp32
+    for k in keys:
+        assert _rel(names[k].grad, sd64[k].grad) <= max(1e-3, 3 * noise), (k, _rel(names[k].grad, sd64[k].grad), noise)
+    assert len(keys) > 60
+    # the last layers are well conditioned: tight
+    for k in ("model.center_head.tasks.0.rot.3.weight", "model.center_head.tasks.0.probs.3.bias"):
+        assert _rel(names[k].grad, sd64[k].grad) < 1e-3, k
+
+
+def test_eval_mode_gradients_tight():
+    """With BatchNorm in eval mode (affine maps) the backward is well conditioned: every gradient within 1e-3."""
+    from oracle.train_step import detector_forward_loss, prepare_state
+
+    tr, pcls, targets = _setup(128, 100.0, 2, 20000, seed=2)
+    with torch.no_grad():  # non-trivial running stats
+        for m in tr.net.modules():
+            if isinstance(m, (torch.nn.BatchNorm2d, torch.nn.BatchNorm1d)):
+                m.running_mean.uniform_(-0.2, 0.2)
+                m.running_var.uniform_(0.6, 1.4)
+    tr.net.eval()
+    total, _, _ = tr.loss(pcls, targets)
+    total.backward()
+    sd64 = prepare_state(tr.net.state_dict(), torch.float64)
+    ref, _, _ = detector_forward_loss(sd64, [p.cpu() for p in pcls], {k: v.cpu() for k, v in targets.items()}, 128, 100.0,
+                                      training=False, dtype=torch.float64)
+    ref.backward()
+    assert abs(float(total) - float(ref)) <= 1e-3 * abs(float(ref))
+    n = 0
+    for k, p in tr.net.named_parameters():
+        if p.grad is not None and sd64[k].grad is not None:
+            assert _rel(p.grad, sd64[k].grad) < 1e-3, (k, _rel(p.grad, sd64[k].grad))
+            n += 1
+    assert n > 80
 
 
 def test_bf16_step_runs_and_tracks_fp32():
