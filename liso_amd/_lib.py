@@ -91,6 +91,11 @@ SIGNATURES = {
     "liso_kabsch_trafos_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "liso_symm_ortho_fwd_f64": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "liso_symm_ortho_bwd_f64": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    # include/liso_flow_cluster.h
+    "liso_bev_dynamic_flow_workspace_bytes": (_sz, [_i, _i, _i]),
+    "liso_bev_dynamic_flow_f32": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "liso_fit_box_z_workspace_bytes": (_sz, [_i, _i]),
+    "liso_fit_box_z_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _vp, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
 }
 
 

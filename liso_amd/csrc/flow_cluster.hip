@@ -1,0 +1,226 @@
+// Flow -> pseudo-box helper stages for gfx950 (MI355X).  C ABI + reference lines: include/liso_flow_cluster.h.
+//
+//   bev_scatter_kernel   one thread per point: nonrigid flow in fp64, then 4 order-independent 64-bit fixed-point
+//                        atomics + 1 count atomic into the pillar grid (the cloud is read once: 12+12+8+1 B/point)
+//   bev_mean_kernel      one thread per pillar: fixed point -> fp32, divide where count > 1
+//   fit_z_kernel         lanes = boxes, every lane walks the point tile from LDS (broadcast reads) keeping count /
+//                        min / max of the in-box z in registers: no [N,K,4] fp64 tensor (192 MB at N=120k, K=50)
+//   fit_z_final_kernel   fixed-order combine of the block partials (min/max/sum are order independent)
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/liso_flow_cluster.h"
+#include "../../include/liso_iou3d.h"
+
+namespace {
+
+constexpr double kFix = 16777216.0;  // 2^24 fixed-point scale: 6e-8 m resolution, |sum| < 5e11 m fits int64
+
+__global__ void bev_scatter_kernel(const float* __restrict__ points, int ps, const uint8_t* __restrict__ valid,
+                                   const int32_t* __restrict__ coors, const float* __restrict__ flow, int fs,
+                                   const double* __restrict__ ome, int batch, int n, int h, int w,
+                                   long long* __restrict__ sums, int* __restrict__ counts) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)batch * n) return;
+    if (!valid[i]) return;  // masked_scatter_mean_2d only scatters valid rows (:63-66)
+    const int b = (int)(i / n);
+    const int r = coors[i * 2 + 0], c = coors[i * 2 + 1];
+    if (r < 0 || r >= h || c < 0 || c >= w) return;
+    const float* p = points + i * ps;
+    const float* f = flow + i * fs;
+    const double* M = ome + (size_t)b * 16;
+    const double x = p[0], y = p[1], z = p[2];
+    float nr[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        // bev_flow_utils.py:28-41: static flow = ((inv(odom) - I) [x y z 1])[:3] in fp64, cast to fp32, subtracted in fp32
+        const float stat = (float)(M[k * 4 + 0] * x + M[k * 4 + 1] * y + M[k * 4 + 2] * z + M[k * 4 + 3]);
+        nr[k] = f[k] - stat;
+    }
+    // torch.linalg.norm (fp32)
+    const float len = sqrtf(nr[0] * nr[0] + nr[1] * nr[1] + nr[2] * nr[2]);
+    const size_t cell = ((size_t)b * h + r) * w + c;
+    unsigned long long* s = (unsigned long long*)(sums + cell * 4);
+    atomicAdd(s + 0, (unsigned long long)(long long)llrint((double)len * kFix));
+    atomicAdd(s + 1, (unsigned long long)(long long)llrint((double)nr[0] * kFix));
+    atomicAdd(s + 2, (unsigned long long)(long long)llrint((double)nr[1] * kFix));
+    atomicAdd(s + 3, (unsigned long long)(long long)llrint((double)nr[2] * kFix));
+    atomicAdd(&counts[cell], 1);
+}
+
+__global__ void bev_mean_kernel(const long long* __restrict__ sums, const int* __restrict__ counts, size_t cells,
+                                float* __restrict__ dyn, float* __restrict__ nrflow) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cells) return;
+    const int cnt = counts[i];
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        v[k] = (float)((double)sums[i * 4 + k] / kFix);
+        if (cnt > 1) v[k] = v[k] / (float)cnt;  // torch_differentiable_forward_scatter.py:84-86
+    }
+    dyn[i] = v[0];
+    nrflow[i * 3 + 0] = v[1]; nrflow[i * 3 + 1] = v[2]; nrflow[i * 3 + 2] = v[3];
+}
+
+constexpr int kFitThreads = 256;
+constexpr int kFitTile = 256;
+constexpr int kFitMaxBlocks = 256;
+
+struct FitPartial {
+    int count;
+    float zmin, zmax, zmin_sensor;
+    int zmin_idx;
+};
+
+// flow_cluster_detector.py:339-384
+__global__ __launch_bounds__(kFitThreads) void fit_z_kernel(const float* __restrict__ points, int ps, int n,
+                                                            const float* __restrict__ box_pos, int pos_dims,
+                                                            const float* __restrict__ box_dims, int dims_dims,
+                                                            const float* __restrict__ box_rot, int k, float box_height,
+                                                            FitPartial* __restrict__ partials, int tiles_per_block) {
+    __shared__ float px[kFitTile], py[kFitTile], pz[kFitTile];
+    __shared__ FitPartial red[kFitThreads / 64][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int box = blockIdx.y * 64 + lane;
+    const bool has = box < k;
+    double bx = 0, by = 0, bz = 0, c = 1, s = 0;
+    float hx = 0, hy = 0, hz = 0;
+    if (has) {
+        bx = box_pos[box * pos_dims + 0]; by = box_pos[box * pos_dims + 1];
+        bz = pos_dims == 3 ? (double)box_pos[box * pos_dims + 2] : 0.0;  // shape_utils.py:280: t_z None -> 0
+        const double th = (double)box_rot[box];
+        c = cos(th); s = sin(th);
+        hx = 0.5f * box_dims[box * dims_dims + 0]; hy = 0.5f * box_dims[box * dims_dims + 1];
+        hz = 0.5f * (dims_dims == 3 ? box_dims[box * dims_dims + 2] : box_height);
+    }
+    FitPartial acc = {0, box_height, -box_height, 0.f, 0x7fffffff};
+    const int tile0 = blockIdx.x * tiles_per_block;
+    for (int t = 0; t < tiles_per_block; t++) {
+        const int base = (tile0 + t) * kFitTile;
+        if (base >= n) break;
+        {
+            const int i = base + tid;
+            if (i < n) { px[tid] = points[(size_t)i * ps]; py[tid] = points[(size_t)i * ps + 1]; pz[tid] = points[(size_t)i * ps + 2]; }
+        }
+        __syncthreads();
+        const int cntp = n - base < kFitTile ? n - base : kFitTile;
+        if (has) {
+            // every wave walks a quarter of the tile
+            for (int j = wave; j < cntp; j += kFitThreads / 64) {
+                const double dx = (double)px[j] - bx, dy = (double)py[j] - by;
+                // inverse pose applied in fp64, result cast to fp32 before the comparison (:354-360)
+                const float lx = (float)(c * dx + s * dy), ly = (float)(-s * dx + c * dy), lz = (float)((double)pz[j] - bz);
+                if (fabsf(lx) < hx && fabsf(ly) < hy && fabsf(lz) < hz) {
+                    acc.count++;
+                    acc.zmax = fmaxf(acc.zmax, lz);
+                    const int gi = base + j;
+                    if (lz < acc.zmin || (lz == acc.zmin && gi < acc.zmin_idx)) { acc.zmin = lz; acc.zmin_sensor = pz[j]; acc.zmin_idx = gi; }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    red[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && has) {
+        FitPartial r = red[0][lane];
+        for (int wv = 1; wv < kFitThreads / 64; wv++) {
+            const FitPartial o = red[wv][lane];
+            r.count += o.count;
+            r.zmax = fmaxf(r.zmax, o.zmax);
+            if (o.zmin < r.zmin || (o.zmin == r.zmin && o.zmin_idx < r.zmin_idx)) { r.zmin = o.zmin; r.zmin_sensor = o.zmin_sensor; r.zmin_idx = o.zmin_idx; }
+        }
+        partials[(size_t)blockIdx.x * k + box] = r;
+    }
+}
+
+__global__ void fit_z_final_kernel(const FitPartial* __restrict__ partials, int nblk, int k,
+                                   const float* __restrict__ points, int ps, int n, float box_height,
+                                   long long* __restrict__ num_pts, float* __restrict__ fz, float* __restrict__ fh) {
+    const int box = blockIdx.x * blockDim.x + threadIdx.x;
+    if (box >= k) return;
+    FitPartial r = {0, box_height, -box_height, 0.f, 0x7fffffff};
+    for (int b = 0; b < nblk; b++) {
+        const FitPartial o = partials[(size_t)b * k + box];
+        r.count += o.count;
+        r.zmax = fmaxf(r.zmax, o.zmax);
+        if (o.zmin < r.zmin || (o.zmin == r.zmin && o.zmin_idx < r.zmin_idx)) { r.zmin = o.zmin; r.zmin_sensor = o.zmin_sensor; r.zmin_idx = o.zmin_idx; }
+    }
+    // :367-372 height = clip(zmax - zmin, 1, 2); z = sensor z of the lowest in-box point + h/2.  An empty box has
+    // zmin == +box_height for every point, argmin == 0: the reference then takes point 0's z.
+    const float height = fminf(fmaxf(r.zmax - r.zmin, 1.0f), 2.0f);
+    const float zlow = r.count > 0 ? r.zmin_sensor : (n > 0 ? points[2] : 0.f);
+    num_pts[box] = r.count;
+    fh[box] = height;
+    fz[box] = zlow + 0.5f * height;
+}
+
+inline int check_launch() { return hipGetLastError() == hipSuccess ? LISO_OK : LISO_ELAUNCH; }
+
+inline int fit_blocks(int n) {
+    const int tiles = (n + kFitTile - 1) / kFitTile;
+    return tiles < kFitMaxBlocks ? (tiles > 0 ? tiles : 1) : kFitMaxBlocks;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t liso_bev_dynamic_flow_workspace_bytes(int batch, int h, int w) {
+    if (batch <= 0 || h <= 0 || w <= 0) return 0;
+    return (size_t)batch * h * w * (4 * sizeof(long long) + sizeof(int));
+}
+
+int liso_bev_dynamic_flow_f32(const float* points, int point_stride, const uint8_t* valid, const int32_t* pillar_coors,
+                              const float* flow, int flow_stride, const double* odom_minus_eye, int batch, int n, int h,
+                              int w, float* dynamicness, float* nonrigid_flow, void* workspace, size_t workspace_bytes,
+                              void* stream) {
+    if (batch <= 0 || n < 0 || h <= 0 || w <= 0 || point_stride < 3 || flow_stride < 3) return LISO_EINVAL;
+    if (!dynamicness || !nonrigid_flow || !workspace || !odom_minus_eye) return LISO_EINVAL;
+    if (n > 0 && (!points || !valid || !pillar_coors || !flow)) return LISO_EINVAL;
+    const size_t need = liso_bev_dynamic_flow_workspace_bytes(batch, h, w);
+    if (workspace_bytes < need) return LISO_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t cells = (size_t)batch * h * w;
+    long long* sums = (long long*)workspace;
+    int* counts = (int*)(sums + cells * 4);
+    if (hipMemsetAsync(workspace, 0, need, st) != hipSuccess) return LISO_ELAUNCH;
+    const size_t total = (size_t)batch * n;
+    if (total > 0)
+        bev_scatter_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(points, point_stride, valid, pillar_coors, flow,
+                                                                          flow_stride, odom_minus_eye, batch, n, h, w, sums,
+                                                                          counts);
+    bev_mean_kernel<<<(unsigned)((cells + 255) / 256), 256, 0, st>>>(sums, counts, cells, dynamicness, nonrigid_flow);
+    return check_launch();
+}
+
+size_t liso_fit_box_z_workspace_bytes(int n_points, int n_boxes) {
+    if (n_points < 0 || n_boxes <= 0) return 0;
+    return (size_t)fit_blocks(n_points) * n_boxes * sizeof(FitPartial);
+}
+
+int liso_fit_box_z_f32(const float* points, int point_stride, int n, const float* box_pos, int pos_dims,
+                       const float* box_dims, int dims_dims, const float* box_rot, int k, float box_height,
+                       int64_t* num_pts, float* fitted_z, float* fitted_height, void* workspace, size_t workspace_bytes,
+                       void* stream) {
+    if (n < 0 || k < 0 || point_stride < 3 || (pos_dims != 2 && pos_dims != 3) || (dims_dims != 2 && dims_dims != 3))
+        return LISO_EINVAL;
+    if (k == 0) return LISO_OK;
+    if (!box_pos || !box_dims || !box_rot || !num_pts || !fitted_z || !fitted_height || !workspace || (n > 0 && !points))
+        return LISO_EINVAL;
+    if (workspace_bytes < liso_fit_box_z_workspace_bytes(n, k)) return LISO_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = fit_blocks(n);
+    const int tiles = (n + kFitTile - 1) / kFitTile;
+    const int tpb = (tiles + nblk - 1) / nblk > 0 ? (tiles + nblk - 1) / nblk : 1;
+    fit_z_kernel<<<dim3(nblk, (k + 63) / 64), kFitThreads, 0, st>>>(points, point_stride, n, box_pos, pos_dims, box_dims,
+                                                                    dims_dims, box_rot, k, box_height,
+                                                                    (FitPartial*)workspace, tpb);
+    fit_z_final_kernel<<<(k + 63) / 64, 64, 0, st>>>((const FitPartial*)workspace, nblk, k, points, point_stride, n,
+                                                     box_height, (long long*)num_pts, fitted_z, fitted_height);
+    return check_launch();
+}
+
+}  // extern "C"
