@@ -1,0 +1,49 @@
+/*
+ * liso_slim.h -- C ABI of the MI355X-native SLIM (RAFT-on-BEV) ops.
+ *
+ * liso_corr_lookup_*: replaces CorrBlock (liso/slim/model/raft_code/corr.py:6-56) + bilinear_sampler
+ * (raft_code/utils.py:15-28).  The reference materialises the all-pairs volume fmap1^T fmap2 / sqrt(D)
+ * ([B*hw, 1, h, w] fp32: 67 MB at 512^2 BEV, 1.07 GB at 1024^2), average-pools it three times and runs four
+ * grid_sample calls per RAFT iteration.  Correlation, pooling and bilinear sampling are all linear in fmap2, so
+ *     lookup[p, level i, (a,b)] = < fmap1[p] , bilerp(avgpool^i(fmap2), coords[p]/2^i + (a-r, b-r)) > / sqrt(D)
+ * and the volume is never formed: the kernel reads the (tiny, L2-resident) pooled feature maps on the fly.
+ *
+ * Layouts (all fp32, device pointers):
+ *   fmap1      [B, h*w, D]          channels-last query features, D % 4 == 0, D <= 256
+ *   fmap2_lvl  [B, H_i, W_i, D]     channels-last pooled target features, H_i = floor(h / 2^i)
+ *   coords     [B, 2, h, w]         (x, y) in level-0 pixels (raft_mod.py: pixel_coords_t1)
+ *   out        [B, h, w, L*(2r+1)^2] channels-last; channel = i*(2r+1)^2 + a*(2r+1) + b with x offset (a-r) and
+ *                                    y offset (b-r)  (the reference's meshgrid(dy, dx) order, corr.py:31-35)
+ */
+#ifndef LISO_SLIM_H
+#define LISO_SLIM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LISO_CORR_MAX_LEVELS 4
+
+typedef struct {
+    int batch, h, w, dim; /* query grid and feature dimension */
+    int levels, radius;   /* corr_cfg.num_levels (4), corr_cfg.search_radius (3): window (2r+1)^2, r <= 3 */
+} liso_corr_cfg;
+
+int liso_corr_lookup_fwd_f32(const liso_corr_cfg* cfg, const float* fmap1, const float* const* fmap2_levels,
+                             const float* coords, float* out, void* stream);
+
+/* grad_out has the layout of `out`.  grad_fmap1 must have room for [levels+1, B, h*w, D] floats: slab 0 receives the
+ * gradient, slabs 1..levels are per-level scratch (summed in a fixed order).  grad_fmap2_levels[i] are ACCUMULATED
+ * into (the caller zero-fills them) with float atomics.  coords receive no gradient (detached per iteration,
+ * raft_mod.py:189). */
+int liso_corr_lookup_bwd_f32(const liso_corr_cfg* cfg, const float* fmap1, const float* const* fmap2_levels,
+                             const float* coords, const float* grad_out, float* grad_fmap1,
+                             float* const* grad_fmap2_levels, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LISO_SLIM_H */

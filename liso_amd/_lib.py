@@ -96,7 +96,15 @@ SIGNATURES = {
     "liso_bev_dynamic_flow_f32": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "liso_fit_box_z_workspace_bytes": (_sz, [_i, _i]),
     "liso_fit_box_z_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _vp, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
+    # include/liso_slim.h
+    "liso_corr_lookup_fwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "liso_corr_lookup_bwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
+
+
+class CorrCfg(ctypes.Structure):
+    """mirror of liso_corr_cfg (include/liso_slim.h)"""
+    _fields_ = [("batch", _i), ("h", _i), ("w", _i), ("dim", _i), ("levels", _i), ("radius", _i)]
 
 
 class KabschCfg(ctypes.Structure):

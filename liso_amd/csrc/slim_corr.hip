@@ -1,0 +1,245 @@
+// On-the-fly RAFT correlation lookup for gfx950 (MI355X).  C ABI + reference lines: include/liso_slim.h.
+//
+// One wavefront owns one (query pixel, pyramid level).  Because the 7x7 window sits at integer offsets around ONE
+// fractional centre, all 49 bilinear samples are combinations of the dot products with an 8x8 integer patch:
+//     P[u][v] = < f1 , f2_i[y0+v][x0+u] >,   x0 = floor(cx/2^i) - r,  y0 = floor(cy/2^i) - r      (0 outside the map)
+//     out[a][b] = (1-fx)(1-fy) P[a][b] + fx(1-fy) P[a+1][b] + (1-fx)fy P[a][b+1] + fx fy P[a+1][b+1]
+// Lane mapping: 32 lanes x float4 cover the D=128 channels of one patch pixel (one coalesced 512-B row read per
+// half-wave), the two half-waves stream two patch pixels at once; the 32 partial sums per lane are reduced with a
+// transposed butterfly (31 cross-lane moves for 32 values instead of 160), leaving lane l with P[2*(l&31)+(l>>5)].
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/liso_iou3d.h"
+#include "../../include/liso_slim.h"
+
+namespace {
+
+constexpr int kWavesPerBlock = 4;
+
+struct LevelPtrs {
+    const float* f2[LISO_CORR_MAX_LEVELS];
+    float* g2[LISO_CORR_MAX_LEVELS];
+};
+
+struct Patch {
+    int x0, y0, H, W;
+    float fx, fy;
+};
+
+__device__ __forceinline__ Patch patch_of(const liso_corr_cfg& c, const float* __restrict__ coords, int b, int pix, int lvl) {
+    Patch p;
+    const int hw = c.h * c.w;
+    // corr.py:37: centroid_lvl = coords / 2**i ; grid_sample(align_corners=True) maps it back to pixel units
+    const float scale = 1.0f / (float)(1 << lvl);
+    const float cx = coords[((size_t)b * 2 + 0) * hw + pix] * scale;
+    const float cy = coords[((size_t)b * 2 + 1) * hw + pix] * scale;
+    const float flx = floorf(cx), fly = floorf(cy);
+    p.fx = cx - flx; p.fy = cy - fly;
+    p.x0 = (int)flx - c.radius; p.y0 = (int)fly - c.radius;
+    p.H = c.h >> lvl; p.W = c.w >> lvl;
+    return p;
+}
+
+// sum over the 32 lanes of each half-wave of 32 per-lane values; lane g (within its half) ends with the total of acc[g]
+__device__ __forceinline__ float transpose_reduce32(float (&acc)[32], int lane) {
+#pragma unroll
+    for (int step = 0; step < 5; step++) {
+        const int mask = 16 >> step;       // lane distance
+        const int n = 16 >> step;          // values that survive this step
+        const bool upper = (lane & mask) != 0;
+#pragma unroll
+        for (int t = 0; t < n; t++) {
+            const float send = upper ? acc[t] : acc[t + n];
+            const float keep = upper ? acc[t + n] : acc[t];
+            acc[t] = keep + __shfl_xor(send, mask);
+        }
+    }
+    return acc[0];
+}
+
+template <int VEC>  // VEC float4 per lane: D = 128 * VEC
+__global__ __launch_bounds__(64 * kWavesPerBlock) void corr_lookup_fwd_kernel(liso_corr_cfg c,
+                                                                              const float* __restrict__ fmap1,
+                                                                              LevelPtrs lp, const float* __restrict__ coords,
+                                                                              float* __restrict__ out) {
+    __shared__ float P[kWavesPerBlock][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hw = c.h * c.w;
+    const long item = (long)blockIdx.x * kWavesPerBlock + wave;  // (b, pix, lvl)
+    const long total = (long)c.batch * hw * c.levels;
+    if (item >= total) return;
+    const int lvl = (int)(item % c.levels);
+    const int pix = (int)((item / c.levels) % hw);
+    const int b = (int)(item / ((long)c.levels * hw));
+    const Patch pt = patch_of(c, coords, b, pix, lvl);
+    const int g = lane & 31, half = lane >> 5;
+    const int D = c.dim;
+    float4 f1[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; k++) f1[k] = *reinterpret_cast<const float4*>(fmap1 + ((size_t)b * hw + pix) * D + (k * 32 + g) * 4);
+    const float* f2 = lp.f2[lvl] + (size_t)b * pt.H * pt.W * D;
+    float acc[32];
+#pragma unroll
+    for (int t = 0; t < 32; t++) {
+        const int q = 2 * t + half;     // patch index: u = q & 7 (x), v = q >> 3 (y)
+        const int x = pt.x0 + (q & 7), y = pt.y0 + (q >> 3);
+        float s = 0.f;
+        if (x >= 0 && x < pt.W && y >= 0 && y < pt.H) {  // zeros padding of grid_sample
+            const float* row = f2 + ((size_t)y * pt.W + x) * D;
+#pragma unroll
+            for (int k = 0; k < VEC; k++) {
+                const float4 v = *reinterpret_cast<const float4*>(row + (k * 32 + g) * 4);
+                s += f1[k].x * v.x + f1[k].y * v.y + f1[k].z * v.z + f1[k].w * v.w;
+            }
+        }
+        acc[t] = s;
+    }
+    const float tot = transpose_reduce32(acc, lane);
+    P[wave][2 * g + half] = tot;
+    __builtin_amdgcn_wave_barrier();
+    const int W7 = 2 * c.radius + 1;
+    const int a = lane / W7, bb = lane % W7;  // a: x offset index, bb: y offset index (corr.py:31-35 order)
+    if (lane < W7 * W7) {
+        const float inv = 1.0f / sqrtf((float)D);  // corr.py:56
+        const float p00 = P[wave][bb * 8 + a], p10 = P[wave][bb * 8 + a + 1];
+        const float p01 = P[wave][(bb + 1) * 8 + a], p11 = P[wave][(bb + 1) * 8 + a + 1];
+        const float v = (1.f - pt.fx) * (1.f - pt.fy) * p00 + pt.fx * (1.f - pt.fy) * p10 + (1.f - pt.fx) * pt.fy * p01 +
+                        pt.fx * pt.fy * p11;
+        const int C = c.levels * W7 * W7;
+        out[((size_t)b * hw + pix) * C + lvl * W7 * W7 + lane] = v * inv;
+    }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void corr_lookup_bwd_kernel(liso_corr_cfg c,
+                                                                              const float* __restrict__ fmap1,
+                                                                              LevelPtrs lp, const float* __restrict__ coords,
+                                                                              const float* __restrict__ grad_out,
+                                                                              float* __restrict__ grad_f1_lvl) {
+    __shared__ float G[kWavesPerBlock][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hw = c.h * c.w;
+    const long item = (long)blockIdx.x * kWavesPerBlock + wave;
+    const long total = (long)c.batch * hw * c.levels;
+    if (item >= total) return;
+    const int lvl = (int)(item % c.levels);
+    const int pix = (int)((item / c.levels) % hw);
+    const int b = (int)(item / ((long)c.levels * hw));
+    const Patch pt = patch_of(c, coords, b, pix, lvl);
+    const int D = c.dim, W7 = 2 * c.radius + 1, C = c.levels * W7 * W7;
+    // gP[u][v] = sum of the (<= 4) window outputs that read P[u][v], weighted by their bilinear factor
+    {
+        const int u = lane & 7, v = lane >> 3;
+        const float* go = grad_out + ((size_t)b * hw + pix) * C + lvl * W7 * W7;
+        const float inv = 1.0f / sqrtf((float)D);
+        float s = 0.f;
+        if (u < W7 && v < W7) s += (1.f - pt.fx) * (1.f - pt.fy) * go[u * W7 + v];
+        if (u >= 1 && u - 1 < W7 && v < W7) s += pt.fx * (1.f - pt.fy) * go[(u - 1) * W7 + v];
+        if (u < W7 && v >= 1 && v - 1 < W7) s += (1.f - pt.fx) * pt.fy * go[u * W7 + v - 1];
+        if (u >= 1 && u - 1 < W7 && v >= 1 && v - 1 < W7) s += pt.fx * pt.fy * go[(u - 1) * W7 + v - 1];
+        G[wave][lane] = s * inv;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int g = lane & 31, half = lane >> 5;
+    float4 f1[VEC], gf1[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; k++) {
+        f1[k] = *reinterpret_cast<const float4*>(fmap1 + ((size_t)b * hw + pix) * D + (k * 32 + g) * 4);
+        gf1[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float* f2 = lp.f2[lvl] + (size_t)b * pt.H * pt.W * D;
+    float* g2 = lp.g2[lvl] + (size_t)b * pt.H * pt.W * D;
+    for (int t = 0; t < 32; t++) {
+        const int q = 2 * t + half;
+        const int x = pt.x0 + (q & 7), y = pt.y0 + (q >> 3);
+        const float gp = G[wave][q];
+        if (x >= 0 && x < pt.W && y >= 0 && y < pt.H && gp != 0.f) {
+            const size_t off = ((size_t)y * pt.W + x) * D;
+#pragma unroll
+            for (int k = 0; k < VEC; k++) {
+                const float4 v = *reinterpret_cast<const float4*>(f2 + off + (k * 32 + g) * 4);
+                gf1[k].x += gp * v.x; gf1[k].y += gp * v.y; gf1[k].z += gp * v.z; gf1[k].w += gp * v.w;
+                float* dst = g2 + off + (k * 32 + g) * 4;
+                atomicAdd(dst + 0, gp * f1[k].x); atomicAdd(dst + 1, gp * f1[k].y);
+                atomicAdd(dst + 2, gp * f1[k].z); atomicAdd(dst + 3, gp * f1[k].w);
+            }
+        }
+    }
+    // the two half-waves covered different patch pixels: add them, then one row write per (pixel, level)
+#pragma unroll
+    for (int k = 0; k < VEC; k++) {
+        gf1[k].x += __shfl_xor(gf1[k].x, 32); gf1[k].y += __shfl_xor(gf1[k].y, 32);
+        gf1[k].z += __shfl_xor(gf1[k].z, 32); gf1[k].w += __shfl_xor(gf1[k].w, 32);
+        if (half == 0)
+            *reinterpret_cast<float4*>(grad_f1_lvl + (((size_t)lvl * c.batch + b) * hw + pix) * D + (k * 32 + g) * 4) = gf1[k];
+    }
+}
+
+// grad_fmap1 = sum over levels of the per-level partials (fixed order -> reproducible)
+__global__ void sum_levels_kernel(const float* __restrict__ part, size_t n, int levels, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int l = 0; l < levels; l++) s += part[(size_t)l * n + i];
+    out[i] = s;
+}
+
+inline int check_launch() { return hipGetLastError() == hipSuccess ? LISO_OK : LISO_ELAUNCH; }
+
+inline bool cfg_ok(const liso_corr_cfg* c) {
+    return c && c->batch >= 1 && c->h >= 1 && c->w >= 1 && (c->dim == 128 || c->dim == 256) && c->levels >= 1 &&
+           c->levels <= LISO_CORR_MAX_LEVELS && c->radius >= 0 && c->radius <= 3 && (c->h >> (c->levels - 1)) >= 1 &&
+           (c->w >> (c->levels - 1)) >= 1;
+}
+
+}  // namespace
+
+extern "C" {
+
+int liso_corr_lookup_fwd_f32(const liso_corr_cfg* cfg, const float* fmap1, const float* const* fmap2_levels,
+                             const float* coords, float* out, void* stream) {
+    if (!cfg_ok(cfg) || !fmap1 || !fmap2_levels || !coords || !out) return LISO_EINVAL;
+    LevelPtrs lp = {};
+    for (int i = 0; i < cfg->levels; i++) {
+        if (!fmap2_levels[i]) return LISO_EINVAL;
+        lp.f2[i] = fmap2_levels[i];
+    }
+    const long total = (long)cfg->batch * cfg->h * cfg->w * cfg->levels;
+    const unsigned grid = (unsigned)((total + kWavesPerBlock - 1) / kWavesPerBlock);
+    hipStream_t st = (hipStream_t)stream;
+    if (cfg->dim == 128)
+        corr_lookup_fwd_kernel<1><<<grid, 64 * kWavesPerBlock, 0, st>>>(*cfg, fmap1, lp, coords, out);
+    else
+        corr_lookup_fwd_kernel<2><<<grid, 64 * kWavesPerBlock, 0, st>>>(*cfg, fmap1, lp, coords, out);
+    return check_launch();
+}
+
+int liso_corr_lookup_bwd_f32(const liso_corr_cfg* cfg, const float* fmap1, const float* const* fmap2_levels,
+                             const float* coords, const float* grad_out, float* grad_fmap1,
+                             float* const* grad_fmap2_levels, void* stream) {
+    if (!cfg_ok(cfg) || !fmap1 || !fmap2_levels || !coords || !grad_out || !grad_fmap1 || !grad_fmap2_levels)
+        return LISO_EINVAL;
+    LevelPtrs lp = {};
+    for (int i = 0; i < cfg->levels; i++) {
+        if (!fmap2_levels[i] || !grad_fmap2_levels[i]) return LISO_EINVAL;
+        lp.f2[i] = fmap2_levels[i];
+        lp.g2[i] = grad_fmap2_levels[i];
+    }
+    // per-level partials of grad_fmap1 live in the tail of grad_fmap2_levels? no: the caller passes grad_fmap1 with
+    // room for `levels` slabs ([levels+1, B, hw, D]); slab 0 receives the sum.
+    const size_t n = (size_t)cfg->batch * cfg->h * cfg->w * cfg->dim;
+    float* part = grad_fmap1 + n;
+    const long total = (long)cfg->batch * cfg->h * cfg->w * cfg->levels;
+    const unsigned grid = (unsigned)((total + kWavesPerBlock - 1) / kWavesPerBlock);
+    hipStream_t st = (hipStream_t)stream;
+    if (cfg->dim == 128)
+        corr_lookup_bwd_kernel<1><<<grid, 64 * kWavesPerBlock, 0, st>>>(*cfg, fmap1, lp, coords, grad_out, part);
+    else
+        corr_lookup_bwd_kernel<2><<<grid, 64 * kWavesPerBlock, 0, st>>>(*cfg, fmap1, lp, coords, grad_out, part);
+    sum_levels_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(part, n, cfg->levels, grad_fmap1);
+    return check_launch();
+}
+
+}  // extern "C"

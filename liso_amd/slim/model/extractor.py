@@ -1,0 +1,79 @@
+"""SLIM feature encoders.  Mirror of liso/slim/model/extractor.py:5-71,211-297 (ResidualBlock, SmallEncoder; same
+constructor arguments and attribute names -> same state_dict keys).  BottleneckBlock / BasicEncoder of the reference
+are not used by SLIM's RAFT and are out of scope."""
+import torch
+import torch.nn as nn
+
+
+def _norm(norm_fn, ch, groups=None):
+    if norm_fn == "group":
+        return nn.GroupNorm(num_groups=groups, num_channels=ch)
+    if norm_fn == "batch":
+        return nn.BatchNorm2d(ch)
+    if norm_fn == "instance":
+        return nn.InstanceNorm2d(ch)
+    if norm_fn == "instance_affine":
+        return nn.InstanceNorm2d(ch, eps=1e-3, affine=True)
+    if norm_fn == "none":
+        return nn.Sequential()
+    raise ValueError(norm_fn)
+
+
+class ResidualBlock(nn.Module):
+    def __init__(self, in_filters, out_filters, dummy_in_filters, norm_fn="group", stride=1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(in_filters, out_filters, kernel_size=3, padding=1, stride=stride)
+        self.conv2 = nn.Conv2d(out_filters, out_filters, kernel_size=3, padding=1)
+        self.relu = nn.ReLU(inplace=True)
+        needs_down = not (stride == 1 and dummy_in_filters == out_filters)  # reference :19-21
+        self.norm1 = _norm(norm_fn, out_filters, out_filters // 8)
+        self.norm2 = _norm(norm_fn, out_filters, out_filters // 8)
+        if needs_down:
+            self.norm3 = _norm(norm_fn, out_filters, out_filters // 8)
+            self.downsample = nn.Sequential(nn.Conv2d(in_filters, out_filters, kernel_size=1, stride=stride), self.norm3)
+        else:
+            self.downsample = None
+
+    def forward(self, x):
+        y = self.relu(self.norm1(self.conv1(x)))
+        y = self.relu(self.norm2(self.conv2(y)))
+        if self.downsample is not None:
+            x = self.downsample(x)
+        return self.relu(x + y)
+
+
+class SmallEncoder(nn.Module):
+    """conv7x7/2 64->32, three stages of two residual blocks (32, 64 /2, 96 /2), conv1x1 -> output_dim at 1/8 res."""
+
+    def __init__(self, output_dim=128, norm_fn="batch", dropout=0.0):
+        super().__init__()
+        self.norm_fn = norm_fn
+        self.norm1 = _norm(norm_fn, 32, 8)
+        self.conv1 = nn.Conv2d(in_channels=64, out_channels=32, kernel_size=7, stride=2, padding=3)
+        self.relu1 = nn.ReLU(inplace=True)
+        self.layer1 = self._make_layer(32, 32, stride=1)
+        self.layer2 = self._make_layer(32, 64, stride=2)
+        self.layer3 = self._make_layer(64, 96, stride=2)
+        self.dropout = nn.Dropout2d(p=dropout) if dropout > 0 else None
+        self.conv2 = nn.Conv2d(96, output_dim, kernel_size=1)
+
+    def _make_layer(self, in_filters, out_filters, stride=1):
+        # reference :258-276: the second block's "dummy_in_filters" is the stage input width, so it gets a 1x1
+        # projection whenever the stage changes the width
+        return nn.Sequential(
+            ResidualBlock(in_filters, out_filters, norm_fn=self.norm_fn, dummy_in_filters=in_filters, stride=stride),
+            ResidualBlock(out_filters, out_filters, norm_fn=self.norm_fn, dummy_in_filters=in_filters, stride=1))
+
+    def forward(self, x):
+        is_list = isinstance(x, (tuple, list))
+        if is_list:
+            batch_dim = x[0].shape[0]
+            x = torch.cat(x, dim=0)
+        x = self.relu1(self.norm1(self.conv1(x)))
+        x = self.layer3(self.layer2(self.layer1(x)))
+        x = self.conv2(x)
+        if self.training and self.dropout is not None:
+            x = self.dropout(x)
+        if is_list:
+            x = torch.split(x, [batch_dim, batch_dim], dim=0)
+        return x

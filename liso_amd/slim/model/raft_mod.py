@@ -1,0 +1,97 @@
+"""RAFT-on-BEV of SLIM.  Mirror of liso/slim/model/raft_mod.py:19-266 (same constructor, sub-module names `pp_layer`,
+`fnet`, `cnet`, `update_block`, same forward signature and outputs).  The pillar encoder is the fused gfx950 pillar
+path, the correlation lookup the on-the-fly gfx950 kernel; convolutions run channels-last through MIOpen."""
+import numpy as np
+import torch
+from torch import nn
+
+from liso_amd.networks.pcl_to_feature_grid.pcl_to_feature_grid import PointsPillarFeatureNetWrapper
+from liso_amd.slim.model.extractor import SmallEncoder
+from liso_amd.slim.model.raft_code.corr import CorrBlock
+from liso_amd.slim.model.raft_code.utils import initialize_flow, upflow_n, uplogits_n
+from liso_amd.slim.model.update import SmallUpdateBlock
+
+
+def move_channel_to_last_dim(tensor):
+    return tensor.permute(0, 2, 3, 1)
+
+
+def change_flow_convention_from_raft2usfl(flow, resolution_adapter):
+    """reference :262-266 -- RAFT's (x=col, y=row) pixel flow -> (row, col) metres"""
+    return torch.flip(flow, dims=[1]) * resolution_adapter
+
+
+class RAFT(nn.Module):
+    def __init__(self, cfg, head_decoder_fw, head_decoder_bw, **kwargs):
+        super().__init__(**kwargs)
+        self.cfg = cfg
+        self.slim_cfg = cfg.SLIM
+        half = 0.5 * np.array(cfg.data.bev_range_m)
+        bev_pc_range = np.concatenate([-half, half], axis=0)
+        self.head_decoder_fw, self.head_decoder_bw = head_decoder_fw, head_decoder_bw
+        self.iters = self.slim_cfg.model.num_iters
+        fs = self.slim_cfg.model.u_net.final_scale
+        self.bev_rows_res_meters_per_fs_pixel = (bev_pc_range[2] - bev_pc_range[0]) / cfg.data.img_grid_size[0] * fs
+        self.bev_cols_res_meters_per_fs_pixel = (bev_pc_range[3] - bev_pc_range[1]) / cfg.data.img_grid_size[1] * fs
+        assert self.bev_rows_res_meters_per_fs_pixel == self.bev_cols_res_meters_per_fs_pixel
+        self.pp_layer = PointsPillarFeatureNetWrapper(cfg)
+        self.hidden_dim, self.context_dim = 96, 64
+        assert self.slim_cfg.model.corr_cfg.module == "all" and self.slim_cfg.model.feature_downsampling_factor == 8
+        self.fnet = SmallEncoder(output_dim=128, norm_fn=self.slim_cfg.model.raft_fnet_norm,
+                                 dropout=self.slim_cfg.model.dropout_rate)
+        self.cnet = SmallEncoder(output_dim=self.hidden_dim + self.context_dim, norm_fn="none",
+                                 dropout=self.slim_cfg.model.dropout_rate)
+        self.update_block = SmallUpdateBlock(cfg=self.slim_cfg, filters=self.hidden_dim)
+
+    def forward(self, pcl_t0, pcl_t1):
+        """reference :82-122"""
+        img_t0, occ_t0 = self.pp_layer(pcl_t0)
+        img_t1, occ_t1 = self.pp_layer(pcl_t1)
+        aux = {"t0": {"bev_net_input_dbg": occ_t0}, "t1": {"bev_net_input_dbg": occ_t1}}
+        fmap_t0, fmap_t1 = self.fnet(img_t0), self.fnet(img_t1)
+        fw = self.predict_single_flow_map_and_classes(img_t0, fmap_t0, fmap_t1, self.head_decoder_fw)
+        bw = self.predict_single_flow_map_and_classes(img_t1, fmap_t1, fmap_t0, self.head_decoder_bw)
+        return fw, bw, aux
+
+    def predict_single_flow_map_and_classes(self, img_t0, fmap_t0, fmap_t1, decoder):
+        """reference :124-259"""
+        m = self.slim_cfg.model
+        assert img_t0.shape[1] == m.point_pillars.nbr_point_feats, img_t0.shape
+        ds = m.feature_downsampling_factor
+        coords0 = initialize_flow(img_t0, downscale_factor=ds)
+        coords1 = initialize_flow(img_t0, downscale_factor=ds)
+        b, _, h, w = coords0.shape
+        vanilla = m.flow_maps_archi == "vanilla"
+        logits = None if vanilla else torch.zeros((b, 4, h, w), dtype=torch.float32, device=img_t0.device)
+        use_w = m.predict_weight_for_static_aggregation is not False
+        wl = torch.zeros((b, 1, h, w), dtype=torch.float32, device=img_t0.device) if use_w else None
+        correlation = CorrBlock(fmap_t0, fmap_t1, num_levels=m.corr_cfg.num_levels, radius=m.corr_cfg.search_radius)
+        cnet = self.cnet(img_t0)
+        net, inp = torch.split(cnet, [self.hidden_dim, self.context_dim], dim=1)
+        net, inp = torch.tanh(net), torch.relu(inp)
+        adapter = torch.tensor([self.bev_rows_res_meters_per_fs_pixel, self.bev_cols_res_meters_per_fs_pixel],
+                               device=inp.device, dtype=inp.dtype)[None, ..., None, None]
+        preds = []
+        for _ in range(m.num_iters):
+            coords1 = coords1.detach()
+            if not vanilla:
+                logits = logits.detach()
+            if use_w:
+                wl = wl.detach()
+            corr = correlation(coords1)
+            flow = coords1 - coords0
+            net, d_flow, d_logits, d_w = self.update_block(net, inp, corr, flow, logits, wl)
+            coords1 = coords1 + d_flow
+            if not vanilla:
+                logits = logits + d_logits
+            if use_w:
+                wl = wl + d_w
+            up_flow = change_flow_convention_from_raft2usfl(upflow_n(coords1 - coords0, n=ds), resolution_adapter=adapter)
+            if vanilla:
+                up_logits = torch.zeros((b, 4, h * ds, w * ds), dtype=torch.float32, device=img_t0.device)
+            else:
+                up_logits = uplogits_n(logits, n=ds)
+            up_w = uplogits_n(wl, n=ds) if use_w else None
+            preds.append(decoder.concat2network_output(logits=up_logits, static_flow=up_flow, dynamic_flow=up_flow,
+                                                       weight_logits_for_static_aggregation=up_w))
+        return preds

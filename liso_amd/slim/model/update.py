@@ -1,0 +1,94 @@
+"""RAFT update operator of SLIM.  Mirror of liso/slim/model/update.py:6-164 (same classes, constructor arguments and
+attribute names -> same state_dict keys)."""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+
+class FlowOrClassificationHead(nn.Module):
+    def __init__(self, input_dim=128, hidden_dim=256, out_dims=2, **kwargs):
+        super().__init__(**kwargs)
+        assert out_dims in [2, 3, 4]
+        self.conv1 = nn.Conv2d(input_dim, hidden_dim, 3, padding=1)
+        self.conv2 = nn.Conv2d(hidden_dim, out_dims, 3, padding=1)
+        self.relu = nn.ReLU(inplace=True)
+
+    def forward(self, inputs):
+        return self.conv2(self.relu(self.conv1(inputs)))
+
+
+class ConvGRU(nn.Module):
+    def __init__(self, hidden_dim=96, input_dim=304):
+        super().__init__()
+        self.convz = nn.Conv2d(input_dim, hidden_dim, 3, padding=1)
+        self.convr = nn.Conv2d(input_dim, hidden_dim, 3, padding=1)
+        self.convq = nn.Conv2d(input_dim, hidden_dim, 3, padding=1)
+
+    def forward(self, h, x):
+        """reference :29-37"""
+        hx = torch.cat([h, x], dim=1)
+        z = torch.sigmoid(self.convz(hx))
+        r = torch.sigmoid(self.convr(hx))
+        q = torch.tanh(self.convq(torch.cat([r * h, x], dim=1)))
+        return (1 - z) * h + z * q
+
+
+class SmallMotionEncoder(nn.Module):
+    def __init__(self, cfg, **kwargs):
+        super().__init__(**kwargs)
+        self.cfg = cfg
+        corr_planes = cfg.model.corr_cfg.num_levels * (2 * cfg.model.corr_cfg.search_radius + 1) ** 2
+        self.conv_stat_corr1 = nn.Conv2d(corr_planes, 96, 1, padding=0)
+        flow_ch = 3 if cfg.model.predict_weight_for_static_aggregation is not False else 2
+        self.conv_flow1 = nn.Conv2d(flow_ch, 64, 7, padding=3)
+        self.conv_flow2 = nn.Conv2d(64, 32, 3, padding=1)
+        self.predict_logits = cfg.model.flow_maps_archi != "vanilla"
+        if self.predict_logits:
+            self.conv_class1 = nn.Conv2d(4, 64, 7, padding=3)
+            self.conv_class2 = nn.Conv2d(64, 32, 3, padding=1)
+        self.conv = nn.Conv2d(128 + int(self.predict_logits) * 32, 80, 3, padding=1)
+
+    def forward(self, flow, corr, logits):
+        """reference :74-96"""
+        corr = F.relu(self.conv_stat_corr1(corr))
+        flow = F.relu(self.conv_flow2(F.relu(self.conv_flow1(flow))))
+        vals = [corr, flow]
+        if self.predict_logits:
+            logits = F.relu(self.conv_class2(F.relu(self.conv_class1(logits))))
+            vals.append(logits)
+        else:
+            assert logits is None
+        out = F.relu(self.conv(torch.cat(vals, dim=1)))
+        if self.predict_logits:
+            return torch.cat([out, logits, flow], dim=1)
+        return torch.cat([out, flow], dim=1)
+
+
+class SmallUpdateBlock(nn.Module):
+    def __init__(self, cfg, filters=96, **kwargs):
+        super().__init__(**kwargs)
+        self.cfg = cfg
+        self.filters = filters
+        self.predict_logits = cfg.model.flow_maps_archi != "vanilla"
+        self.motion_encoder = SmallMotionEncoder(cfg=cfg)
+        self.gru = ConvGRU(hidden_dim=filters, input_dim=272 + int(self.predict_logits) * 32)
+        flow_ch = 3 if cfg.model.predict_weight_for_static_aggregation is not False else 2
+        self.static_flow_head = FlowOrClassificationHead(input_dim=filters, hidden_dim=128, out_dims=flow_ch)
+        self.classification_head = (FlowOrClassificationHead(input_dim=filters, hidden_dim=128, out_dims=4)
+                                    if self.predict_logits else None)
+
+    def forward(self, net, inp, corr, flow, logits, weight_logits_for_static_aggregation):
+        """reference :130-164"""
+        if self.cfg.model.predict_weight_for_static_aggregation:
+            mf = self.motion_encoder(torch.cat([flow, weight_logits_for_static_aggregation], dim=1), corr, logits)
+        else:
+            assert weight_logits_for_static_aggregation is None
+            mf = self.motion_encoder(flow, corr, logits)
+        net = self.gru(net, torch.cat([inp, mf], dim=1))
+        if self.cfg.model.predict_weight_for_static_aggregation:
+            delta = self.static_flow_head(net)
+            delta_static_flow, delta_weights = delta[:, 0:2, ...], delta[:, -1:, ...]
+        else:
+            delta_static_flow, delta_weights = self.static_flow_head(net), None
+        delta_logits = self.classification_head(net) if self.predict_logits else None
+        return net, delta_static_flow, delta_logits, delta_weights

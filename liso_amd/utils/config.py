@@ -57,6 +57,19 @@ def default_cfg(grid=512, bev_range_m=100.0, use_lidar_intensity=True):
         "loss": {"supervised": {"centermaps": {"active": True, "confidence_target": "gaussian"},   # :179
                                 "supervised_on_clusters": {"active": True, "weight": 1.0,
                                                            "attrs": ("pos", "dims", "rot", "probs")}}},  # :155-162
+        "SLIM": {                                                                                     # :231-330
+            "optimizer": "rmsprop", "batch_size": 1,
+            "phases": {"train": {"mode": "unsupervised"}},
+            "model": {
+                "name": "raft", "dropout_rate": 0, "raft_fnet_norm": "instance_affine",              # :290-292
+                "feature_downsampling_factor": 8, "num_iters": 6, "num_pred_iters": 6,                 # :293-296
+                "flow_maps_archi": "single",                                                           # :297
+                "corr_cfg": {"module": "all", "sampler": "bilinear", "search_radius": 3, "num_levels": 4},  # :298-302
+                "predict_weight_for_static_aggregation": False, "use_static_aggr_flow_for_aggr_flow": False,  # :311-312
+                "dynamic_flow_is_non_rigid_flow": False,
+                "point_pillars": {"nbr_point_feats": 64}, "u_net": {"final_scale": 1},
+            },
+        },
         "mask_rendering": {"softness_fun": "cauchy", "pred_sigmoid_slope": 15.0, "obj_dim_scale_buffer": 0.25},  # :130-134
         "svd_backend": "symm_ortho",                                                                  # :230
         "optimization": {"learning_rate": 0.001, "num_training_steps": 350000},                      # :137-138
