@@ -51,7 +51,7 @@ def cpu_baseline(trainer, pcls, targets):
     from oracle.train_step import timed_detector_step
 
     sd = {k: v.detach().float().cpu() for k, v in trainer.net.state_dict().items()}
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     t1 = {k: v[:1].cpu() for k, v in targets.items()}
     secs, _ = timed_detector_step(sd, [pcls[0].cpu()], t1, GRID, BEV_RANGE)

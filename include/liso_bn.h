@@ -1,0 +1,44 @@
+/*
+ * liso_bn.h -- C ABI of the fused BatchNorm2d(+ReLU) for channels-last BEV feature maps (gfx950).
+ *
+ * Replaces the norm + activation pairs of the reference's BEV backbone / head
+ *   liso/networks/centerpoint/rpn.py:113-131 (`BatchNorm2d` + `ReLU` after every conv; built by norm.py:55-56)
+ *   liso/networks/centerpoint/center_head.py:36-38,81-92
+ * which PyTorch runs as 3 (forward) + 3 (backward) BatchNorm launches plus separate ReLU kernels.  Here:
+ *   forward  = stats (1 read of x) -> finalize (tiny) -> apply+ReLU (1 read, 1 write)
+ *   backward = reduce (read dy, x) -> finalize (tiny) -> dx (read dy, x; write dx), ReLU mask recomputed from x
+ * Batch statistics use block-shifted sums merged over the block means in fp64 (fixed order):
+ * no E[x^2]-E[x]^2 cancellation (MIOpen's spatial BN loses ~2e-4 relative at mean/std = 50, measured), reproducible.
+ *
+ * x, y, dy, dx: [M, C] row-major (M = N*H*W pixels, channels-last), dtype fp32 (is_bf16 = 0) or bf16 (is_bf16 = 1);
+ * C % 8 == 0, C <= 256, 256 % (C / V) == 0 with V = 4 (fp32) or 8 (bf16).  gamma/beta/running_*: fp32 [C].  stats: fp32 [4*C] = scale | shift | mean | invstd.
+ * All pointers are device pointers; nothing allocates or synchronises.
+ */
+#ifndef LISO_BN_H
+#define LISO_BN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* bytes of device scratch for the calls below (depends only on C) */
+size_t liso_bn_workspace_bytes(int c);
+
+/* training != 0: batch statistics (biased variance for normalisation, unbiased for running_var, torch semantics),
+ * running stats updated in place with `momentum`;  training == 0: running statistics.  relu != 0 fuses max(.,0). */
+int liso_bn_relu_fwd(const void* x, int is_bf16, long m, int c, const float* gamma, const float* beta,
+                     float* running_mean, float* running_var, float momentum, float eps, int training, int relu,
+                     void* y, float* stats, void* workspace, size_t workspace_bytes, void* stream);
+
+/* grad_gamma/grad_beta [C] fp32 overwritten; dx has the dtype of x. */
+int liso_bn_relu_bwd(const void* dy, const void* x, int is_bf16, long m, int c, const float* gamma, const float* stats,
+                     int training, int relu, void* dx, float* grad_gamma, float* grad_beta, void* workspace,
+                     size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LISO_BN_H */

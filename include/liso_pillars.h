@@ -67,10 +67,11 @@ int liso_pfn_bn_prepare_f32(const float* points, const liso_pillar_cfg* cfg, int
                             float momentum, float eps, int training, float* bn_out, double* moments, void* partials,
                             void* stream);
 
-/* Fused decorate + Linear + BN + ReLU + max + scatter.  canvas/occupancy must be zero-filled by the caller
- * (pillar_scatter.py:78-82 allocates zeros).  out_bf16 != 0: canvas is bfloat16, else float32. */
+/* Fused decorate + Linear + BN + ReLU + max + dense scatter.  Every cell of canvas and occupancy is written exactly
+ * once (zeros for empty cells: pillar_scatter.py:78-82 allocates zeros), so the caller need NOT pre-fill them.
+ * cell_to_voxel comes from liso_pillars_voxelize_f32.  out_bf16 != 0: canvas is bfloat16, else float32. */
 int liso_pfn_forward_scatter(const float* points, const liso_pillar_cfg* cfg, int batch, const int* coors,
-                             const int* num_points, const int* slots, const int* num_voxels, const float* weight,
+                             const int* num_points, const int* slots, const int* cell_to_voxel, const float* weight,
                              const float* bn_out, void* canvas, int out_bf16, float* occupancy, void* stream);
 
 /* Backward of the fused op w.r.t. weight, gamma, beta (inputs carry no gradient: voxelize is no_grad,

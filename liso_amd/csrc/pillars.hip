@@ -367,32 +367,67 @@ template <typename T> __device__ __forceinline__ float load_in(const T* p);
 template <> __device__ __forceinline__ float load_in<float>(const float* p) { return *p; }
 template <> __device__ __forceinline__ float load_in<__hip_bfloat16>(const __hip_bfloat16* p) { return __bfloat162float(*p); }
 
-// ---- forward: Linear(F,64, no bias) -> BN -> ReLU -> max over the 20 slots -> canvas[b, x_idx, y_idx, :] -------
+// ---- forward: Linear(F,64, no bias) -> BN -> ReLU -> max over the 20 slots -> canvas[b, x_idx, y_idx, :] ------------
+// Dense-writer form: every canvas cell is written exactly once.
+// A block owns 256 consecutive cells of the [B, gx, gy] grid.  Empty cells are zero-filled with 16-B stores (one
+// coalesced 4-KiB wave-instruction per 32 bf16 cells), occupied cells get their 64 PFN channels; no separate memset
+// pass over the 64*G^2 canvas and no double write.  HBM traffic = the canvas once + ~1 MB of cell->voxel indices.
+constexpr int kCellsPerBlock = 256;
+
 template <int C, typename OutT>
-__global__ __launch_bounds__(kPfnThreads) void pfn_forward_kernel(const float* __restrict__ pts, liso_pillar_cfg cfg,
-                                                                  int batch, const int* __restrict__ coors,
-                                                                  const int* __restrict__ num_points,
-                                                                  const int* __restrict__ slots,
-                                                                  const int* __restrict__ num_voxels,
-                                                                  const float* __restrict__ weight,
-                                                                  const float* __restrict__ bn, OutT* __restrict__ canvas,
-                                                                  float* __restrict__ occupancy) {
+__global__ __launch_bounds__(kPfnThreads) void pfn_forward_dense_kernel(const float* __restrict__ pts, liso_pillar_cfg cfg,
+                                                                        long total_cells, const int* __restrict__ coors,
+                                                                        const int* __restrict__ num_points,
+                                                                        const int* __restrict__ slots,
+                                                                        const int* __restrict__ cell_to_voxel,
+                                                                        const float* __restrict__ weight,
+                                                                        const float* __restrict__ bn,
+                                                                        OutT* __restrict__ canvas,
+                                                                        float* __restrict__ occupancy) {
     constexpr int F = C + 6;
+    constexpr int kChunks = kOut * (int)sizeof(OutT) / 16;  // 16-B chunks per cell (8 for bf16, 16 for fp32)
     __shared__ float frow[kPfnThreads / 64][kMaxPts][kFP];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ int vox[kCellsPerBlock];
+    __shared__ int list[kCellsPerBlock];
+    __shared__ int cnt;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long cell0 = (long)blockIdx.x * kCellsPerBlock;
+    if (tid == 0) cnt = 0;
+    __syncthreads();
+    {
+        const long cell = cell0 + tid;
+        int v1 = 0;
+        if (cell < total_cells) {
+            v1 = cell_to_voxel[cell];
+            occupancy[cell] = v1 > 0 ? 1.f : 0.f;
+        }
+        vox[tid] = v1;
+        if (v1 > 0) list[atomicAdd(&cnt, 1)] = tid;
+    }
+    __syncthreads();
+    // zero-fill the empty cells: consecutive threads -> consecutive 16-B chunks
+    {
+        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+        uint4* base = reinterpret_cast<uint4*>(canvas + (size_t)cell0 * kOut);
+        for (int id = tid; id < kCellsPerBlock * kChunks; id += kPfnThreads) {
+            const int cl = id / kChunks;
+            if (cell0 + cl < total_cells && vox[cl] == 0) base[id] = z;
+        }
+    }
+    const int n_occ = cnt;
+    if (n_occ == 0) return;
     const PfnGeom g = pfn_geom(cfg);
     float w[F];
 #pragma unroll
     for (int k = 0; k < F; k++) w[k] = weight[lane * F + k];
     const float scale = bn[lane], shift = bn[kOut + lane];
-    const float pad_val = fmaxf(shift, 0.f);  // a zero-padded row: Linear(0)=0 -> BN -> ReLU (utils.py:165-169)
-    const int rows = batch * cfg.max_voxels;
-    for (int v = blockIdx.x * (kPfnThreads / 64) + wave; v < rows; v += gridDim.x * (kPfnThreads / 64)) {
-        const int b = v / cfg.max_voxels;
-        if (v - b * cfg.max_voxels >= num_voxels[b]) continue;
+    const float pad_val = fmaxf(shift, 0.f);
+    for (int i = wave; i < n_occ; i += kPfnThreads / 64) {
+        const int cl = list[i];
+        const int v = vox[cl] - 1;
         const int num = build_rows<C>(pts, slots, coors, num_points, v, cfg.max_points, g, frow[wave], lane);
         __builtin_amdgcn_wave_barrier();
-        float best = num < cfg.max_points ? pad_val : 0.f;  // ReLU output is >= 0, so 0 is a neutral start
+        float best = num < cfg.max_points ? pad_val : 0.f;
         for (int s = 0; s < num; s++) {
             const float* f = frow[wave][s];
             float x = 0.f;
@@ -401,10 +436,7 @@ __global__ __launch_bounds__(kPfnThreads) void pfn_forward_kernel(const float* _
             best = fmaxf(best, fmaxf(fmaf(x, scale, shift), 0.f));
         }
         __builtin_amdgcn_wave_barrier();
-        const int xi = coors[v * 4 + 2], yi = coors[v * 4 + 3];
-        const size_t cellidx = ((size_t)b * cfg.gx + xi) * cfg.gy + yi;  // pillar_scatter.py:87: x_idx * nx + y_idx
-        store_out<OutT>(canvas + cellidx * kOut + lane, best);
-        if (lane == 0) occupancy[cellidx] = 1.f;
+        store_out<OutT>(canvas + ((size_t)cell0 + cl) * kOut + lane, best);
     }
 }
 
@@ -472,65 +504,63 @@ __global__ __launch_bounds__(kPfnThreads) void pfn_backward_kernel(const float* 
     }
 }
 
-// closed-form BN backward on the reduced sums (training) / plain scale (eval)
-template <int C>
-__global__ __launch_bounds__(1024) void pfn_backward_finalize_kernel(const float* __restrict__ partials, int nblocks,
-                                                                     const int* __restrict__ num_voxels, int batch,
-                                                                     int max_points, const float* __restrict__ weight,
-                                                                     const float* __restrict__ gamma,
-                                                                     const float* __restrict__ bn,
-                                                                     const double* __restrict__ moments, int training,
-                                                                     float* __restrict__ grad_weight,
-                                                                     float* __restrict__ grad_gamma,
-                                                                     float* __restrict__ grad_beta) {
-    constexpr int F = C + 6, NA = F + 2, D = F + 1;
-    __shared__ double tot[NA][kOut];
+// stage 1: one block per accumulator row k, 64 channels x 16 chunks of block partials, fixed combination order
+template <int NA>
+__global__ __launch_bounds__(1024) void pfn_backward_reduce_kernel(const float* __restrict__ partials, int nblocks,
+                                                                   double* __restrict__ tot) {
     __shared__ double part[16][kOut];
-    {
-        // 1024 threads = 64 channels x 16 chunks of blocks; chunks are combined in fixed order (reproducible)
-        const int c = threadIdx.x & 63, chunk = threadIdx.x >> 6;
-        const int per = (nblocks + 15) / 16;
-        const int lo = chunk * per, hi = lo + per < nblocks ? lo + per : nblocks;
-        for (int k = 0; k < NA; k++) {
-            double s = 0.0;
-            for (int blk = lo; blk < hi; blk++) s += (double)partials[((size_t)blk * NA + k) * kOut + c];
-            part[chunk][c] = s;
-            __syncthreads();
-            if (chunk == 0) {
-                double t = 0.0;
-                for (int q = 0; q < 16; q++) t += part[q][c];
-                tot[k][c] = t;
-            }
-            __syncthreads();
-        }
+    const int k = blockIdx.x, c = threadIdx.x & 63, chunk = threadIdx.x >> 6;
+    const int per = (nblocks + 15) / 16;
+    const int lo = chunk * per, hi = lo + per < nblocks ? lo + per : nblocks;
+    double s = 0.0;
+    for (int blk = lo; blk < hi; blk++) s += (double)partials[((size_t)blk * NA + k) * kOut + c];
+    part[chunk][c] = s;
+    __syncthreads();
+    if (chunk == 0) {
+        double t = 0.0;
+        for (int q = 0; q < 16; q++) t += part[q][c];
+        tot[k * kOut + c] = t;
     }
-    if (threadIdx.x < kOut) {
-        const int c = threadIdx.x;
-        const double dbeta = tot[F][c], dgamma = tot[F + 1][c];
-        grad_beta[c] = (float)dbeta;
-        grad_gamma[c] = (float)dgamma;
-        const double invstd = (double)bn[3 * kOut + c], mean = (double)bn[2 * kOut + c];
-        const double gi = (double)gamma[c] * invstd;
-        if (!training) {
-            for (int k = 0; k < F; k++) grad_weight[c * F + k] = (float)(gi * tot[k][c]);
-            return;
+}
+
+// stage 2: closed-form BN backward on the reduced sums (training) / plain scale (eval)
+template <int C>
+__global__ __launch_bounds__(64) void pfn_backward_finalize_kernel(const double* __restrict__ tot,
+                                                                   const int* __restrict__ num_voxels, int batch,
+                                                                   int max_points, const float* __restrict__ weight,
+                                                                   const float* __restrict__ gamma,
+                                                                   const float* __restrict__ bn,
+                                                                   const double* __restrict__ moments, int training,
+                                                                   float* __restrict__ grad_weight,
+                                                                   float* __restrict__ grad_gamma,
+                                                                   float* __restrict__ grad_beta) {
+    constexpr int F = C + 6, D = F + 1;
+    const int c = threadIdx.x;
+    if (c >= kOut) return;
+    const double dbeta = tot[F * kOut + c], dgamma = tot[(F + 1) * kOut + c];
+    grad_beta[c] = (float)dbeta;
+    grad_gamma[c] = (float)dgamma;
+    const double invstd = (double)bn[3 * kOut + c], mean = (double)bn[2 * kOut + c];
+    const double gi = (double)gamma[c] * invstd;
+    if (!training) {
+        for (int k = 0; k < F; k++) grad_weight[c * F + k] = (float)(gi * tot[k * kOut + c]);
+        return;
+    }
+    long long P = 0;
+    for (int b = 0; b < batch; b++) P += num_voxels[b];
+    const double M = (double)P * (double)max_points;
+    double w[F];
+    for (int k = 0; k < F; k++) w[k] = (double)weight[c * F + k];
+    for (int k = 0; k < F; k++) {
+        const double Fk = moments[pair_index(k, D - 1, D)];  // sum_rows f_k
+        double xf = 0.0;                                      // sum_rows x_c f_k = sum_j w_j FF[j][k]
+        for (int j = 0; j < F; j++) {
+            const int a = j <= k ? j : k, bb = j <= k ? k : j;
+            xf += w[j] * moments[pair_index(a, bb, D)];
         }
-        long long P = 0;
-        for (int b = 0; b < batch; b++) P += num_voxels[b];
-        const double M = (double)P * (double)max_points;
-        double w[F];
-        for (int k = 0; k < F; k++) w[k] = (double)weight[c * F + k];
-        for (int k = 0; k < F; k++) {
-            const double Fk = moments[pair_index(k, D - 1, D)];  // sum_rows f_k
-            double xf = 0.0;                                      // sum_rows x_c f_k = sum_j w_j FF[j][k]
-            for (int j = 0; j < F; j++) {
-                const int a = j <= k ? j : k, bb = j <= k ? k : j;
-                xf += w[j] * moments[pair_index(a, bb, D)];
-            }
-            const double xhat_f = invstd * (xf - mean * Fk);      // sum_rows xhat_c f_k
-            const double dw = M > 0.0 ? gi * (tot[k][c] - dbeta / M * Fk - dgamma / M * xhat_f) : 0.0;
-            grad_weight[c * F + k] = (float)dw;
-        }
+        const double xhat_f = invstd * (xf - mean * Fk);      // sum_rows xhat_c f_k
+        const double dw = M > 0.0 ? gi * (tot[k * kOut + c] - dbeta / M * Fk - dgamma / M * xhat_f) : 0.0;
+        grad_weight[c * F + k] = (float)dw;
     }
 }
 
@@ -617,7 +647,7 @@ int liso_pillars_voxelize_f32(const float* points, const int* offsets_host, int 
 
 size_t liso_pfn_partials_bytes(void) {
     const size_t stats = (size_t)kPfnGrid * LISO_PFN_STATS_DOUBLES * sizeof(double);
-    const size_t bwd = (size_t)kPfnGrid * (11 + 2) * kOut * sizeof(float);
+    const size_t bwd = (size_t)kPfnGrid * (11 + 2) * kOut * sizeof(float) + (11 + 2) * kOut * sizeof(double);
     return stats > bwd ? stats : bwd;
 }
 
@@ -644,16 +674,15 @@ int liso_pfn_bn_prepare_f32(const float* points, const liso_pillar_cfg* cfg, int
 }
 
 int liso_pfn_forward_scatter(const float* points, const liso_pillar_cfg* cfg, int batch, const int* coors,
-                             const int* num_points, const int* slots, const int* num_voxels, const float* weight,
+                             const int* num_points, const int* slots, const int* cell_to_voxel, const float* weight,
                              const float* bn_out, void* canvas, int out_bf16, float* occupancy, void* stream) {
-    if (!cfg_ok(cfg, batch) || !points || !coors || !num_points || !slots || !num_voxels || !weight || !bn_out ||
+    if (!cfg_ok(cfg, batch) || !points || !coors || !num_points || !slots || !cell_to_voxel || !weight || !bn_out ||
         !canvas || !occupancy)
         return LISO_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    const int rows = batch * cfg->max_voxels;
-    const int need = (rows + kPfnThreads / 64 - 1) / (kPfnThreads / 64);
-    const int grid = need < 4096 ? need : 4096;
-#define LISO_FWD(CC, T) pfn_forward_kernel<CC, T><<<grid, kPfnThreads, 0, st>>>(points, *cfg, batch, coors, num_points, slots, num_voxels, weight, bn_out, (T*)canvas, occupancy)
+    const long cells = (long)batch * cfg->gx * cfg->gy;
+    const unsigned grid = (unsigned)((cells + kCellsPerBlock - 1) / kCellsPerBlock);
+#define LISO_FWD(CC, T) pfn_forward_dense_kernel<CC, T><<<grid, kPfnThreads, 0, st>>>(points, *cfg, cells, coors, num_points, slots, cell_to_voxel, weight, bn_out, (T*)canvas, occupancy)
     switch (cfg->n_channels * 2 + (out_bf16 ? 1 : 0)) {
         case 6: LISO_FWD(3, float); break;
         case 7: LISO_FWD(3, __hip_bfloat16); break;
@@ -678,12 +707,15 @@ int liso_pfn_backward(const float* points, const liso_pillar_cfg* cfg, int batch
     const int grid = pfn_grid(batch * cfg->max_voxels);
 #define LISO_BWD(CC, T)                                                                                              \
     do {                                                                                                             \
+        constexpr int NA_ = CC + 8;                                                                                  \
+        double* tot_ = (double*)((float*)partials + (size_t)kPfnGrid * (11 + 2) * kOut);                             \
         pfn_backward_kernel<CC, T><<<grid, kPfnThreads, 0, st>>>(points, *cfg, batch, coors, num_points, slots,       \
                                                                  num_voxels, weight, bn_out, (const T*)grad_canvas,  \
                                                                  (float*)partials);                                  \
-        pfn_backward_finalize_kernel<CC><<<1, 1024, 0, st>>>((const float*)partials, grid, num_voxels, batch,         \
-                                                            cfg->max_points, weight, gamma, bn_out, moments,         \
-                                                            training, grad_weight, grad_gamma, grad_beta);           \
+        pfn_backward_reduce_kernel<NA_><<<NA_, 1024, 0, st>>>((const float*)partials, grid, tot_);                    \
+        pfn_backward_finalize_kernel<CC><<<1, 64, 0, st>>>(tot_, num_voxels, batch, cfg->max_points, weight, gamma,   \
+                                                           bn_out, moments, training, grad_weight, grad_gamma,       \
+                                                           grad_beta);                                               \
     } while (0)
     switch (cfg->n_channels * 2 + (grad_bf16 ? 1 : 0)) {
         case 6: LISO_BWD(3, float); break;

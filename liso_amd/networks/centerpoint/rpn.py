@@ -3,7 +3,7 @@ same state_dict keys `blocks.{i}.{j}.*`, `deblocks.{i}.{j}.*`, including the Zer
 
 MI355X notes: tensors stay channels-last (the pillar scatter already produces NHWC storage) and in the dtype they
 arrive in (bf16 for the perf configuration, fp32 for parity); convolutions go to MIOpen's NHWC implicit-GEMM
-(MFMA) kernels, BatchNorm statistics stay fp32.  forward() is functional so ZeroPad2d+conv(pad=0) becomes one
+(MFMA) kernels, BatchNorm+ReLU is the fused gfx950 kernel pair of include/liso_bn.h (fp32 statistics).  forward() is functional so ZeroPad2d+conv(pad=0) becomes one
 padded conv (identical arithmetic, one HBM round trip less per stage).
 """
 import numpy as np
@@ -11,6 +11,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from liso_amd.networks.centerpoint.fused_bn import bn_act
 from liso_amd.networks.centerpoint.norm import baurst_build_norm_layer as build_norm_layer
 from liso_amd.networks.centerpoint.weight_init import xavier_init
 
@@ -26,11 +27,7 @@ def conv_bn_relu(x, conv, bn, stride=None, padding=None):
     else:
         y = F.conv2d(x, w, b, stride=conv.stride if stride is None else stride,
                      padding=conv.padding if padding is None else padding)
-    y = F.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.training or not bn.track_running_stats,
-                     bn.momentum, bn.eps)
-    if bn.training and bn.track_running_stats:
-        bn.num_batches_tracked += 1
-    return F.relu(y, inplace=True)
+    return bn_act(y, bn, relu=True)
 
 
 class RPN(nn.Module):

@@ -89,10 +89,10 @@ class _PillarFeatureScatter(torch.autograd.Function):
                                                 L.ptr(beta), L.ptr(running_mean), L.ptr(running_var), float(momentum),
                                                 float(eps), int(training), L.ptr(bn_out), L.ptr(moments),
                                                 L.ptr(partials), st), "pfn_bn_prepare")
-            canvas = torch.zeros((B, pcfg.gx, pcfg.gy, 64), dtype=out_dtype, device=dev)
-            occupancy = torch.zeros((B, 1, pcfg.gx, pcfg.gy), dtype=torch.float32, device=dev)
+            canvas = torch.empty((B, pcfg.gx, pcfg.gy, 64), dtype=out_dtype, device=dev)  # written densely by the kernel
+            occupancy = torch.empty((B, 1, pcfg.gx, pcfg.gy), dtype=torch.float32, device=dev)
             L.check(L.TIMER.launch("pfn_forward_scatter", lambda: lib.liso_pfn_forward_scatter(
-                L.ptr(points), ctypes.byref(pcfg), B, L.ptr(coors), L.ptr(num_points), L.ptr(slots), L.ptr(num_voxels),
+                L.ptr(points), ctypes.byref(pcfg), B, L.ptr(coors), L.ptr(num_points), L.ptr(slots), L.ptr(cell_to_voxel),
                 L.ptr(weight), L.ptr(bn_out), L.ptr(canvas), int(out_dtype == torch.bfloat16), L.ptr(occupancy), st)),
                 "pfn_forward_scatter")
         ctx.save_for_backward(points, coors, num_points, slots, num_voxels, weight, gamma, bn_out, moments)

@@ -49,7 +49,7 @@ def test_train_step_matches_cpu_oracle_fp32():
             and float(sd64[k].grad.abs().max()) >= 1e-6]  # conv biases in front of a BatchNorm: true gradient == 0
     noise = max(_rel(sd32[k].grad, sd64[k].grad) for k in keys)  # conditioning of this backward in fp32
     for k in keys:
-        assert _rel(names[k].grad, sd64[k].grad) <= max(1e-3, 3 * noise), (k, _rel(names[k].grad, sd64[k].grad), noise)
+        assert _rel(names[k].grad, sd64[k].grad) <= max(2e-3, 3 * noise), (k, _rel(names[k].grad, sd64[k].grad), noise)
     assert len(keys) > 60
     # the last layers are well conditioned: tight
     for k in ("model.center_head.tasks.0.rot.3.weight", "model.center_head.tasks.0.probs.3.bias"):
