@@ -80,7 +80,15 @@ def test_two_rank_gloo_step(tmp_path):
     assert torch.equal(r["params"][0], r["params"][1])
     assert not torch.equal(r["rm"][0], r["rm"][1])
     # and equal to one process that averages the two ranks' gradients by hand
-    torch.set_num_threads(2)
+    n_threads = torch.get_num_threads()
+    torch.set_num_threads(2)  # same oneDNN blocking as the workers
+    try:
+        _compare_with_hand_averaged(r)
+    finally:
+        torch.set_num_threads(n_threads)
+
+
+def _compare_with_hand_averaged(r):
     tr = _make(0)
     d0, d1 = _data(0), _data(1)
     import copy
