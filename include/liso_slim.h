@@ -43,6 +43,32 @@ int liso_corr_lookup_bwd_f32(const liso_corr_cfg* cfg, const float* fmap1, const
                              const float* coords, const float* grad_out, float* grad_fmap1,
                              float* const* grad_fmap2_levels, void* stream);
 
+/* ---- exact 1-nearest-neighbour search (SLIM self-supervised loss) -------------------------------------------------
+ * Replaces knn_graph(x, index=ref, k=1, loop=True) (liso/slim/slim_loss/knn_graph.py:10-98), which copies both clouds
+ * to the host and queries a pynanoflann KD-tree per call (knn_wrapper.py:139-152,180-186): 12+ device->host->device
+ * round trips per training step.  Here the reference cloud is bucketed once into a uniform xy grid on the device and
+ * every query walks Chebyshev rings of cells until the best squared distance provably cannot be improved: EXACT
+ * nearest neighbour (3-D Euclidean), ties resolved towards the smaller reference index, no host involvement.
+ *
+ *   ref    float32 [n_ref, ref_stride]   (x,y,z first), all finite
+ *   query  float32 [n_query, query_stride], rows containing NaN/inf get index 0 and distance NaN
+ *   index  int64 [n_query], dist_sqr float32 [n_query] (may be NULL)
+ */
+typedef struct {
+    float x_min, y_min;  /* grid origin */
+    float cell;          /* cell edge length in metres (> 0) */
+    int nx, ny;          /* cells; reference points outside are clamped into the border cells (still exact) */
+} liso_knn_grid;
+
+size_t liso_knn_workspace_bytes(const liso_knn_grid* grid, int n_ref);
+
+/* bucket the reference cloud (counting sort by cell); the workspace then holds the index structure */
+int liso_knn_build_f32(const liso_knn_grid* grid, const float* ref, int ref_stride, int n_ref, void* workspace,
+                       size_t workspace_bytes, void* stream);
+
+int liso_knn_query_f32(const liso_knn_grid* grid, const float* ref, int ref_stride, int n_ref, const void* workspace,
+                       const float* query, int query_stride, int n_query, int64_t* index, float* dist_sqr, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

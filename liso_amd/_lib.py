@@ -103,7 +103,15 @@ SIGNATURES = {
     "liso_bn_workspace_bytes": (_sz, [_i]),
     "liso_bn_relu_fwd": (_i, [_vp, _i, ctypes.c_long, _i, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "liso_bn_relu_bwd": (_i, [_vp, _vp, _i, ctypes.c_long, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "liso_knn_workspace_bytes": (_sz, [_vp, _i]),
+    "liso_knn_build_f32": (_i, [_vp, _vp, _i, _i, _vp, _sz, _vp]),
+    "liso_knn_query_f32": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp]),
 }
+
+
+class KnnGrid(ctypes.Structure):
+    """mirror of liso_knn_grid (include/liso_slim.h)"""
+    _fields_ = [("x_min", _f), ("y_min", _f), ("cell", _f), ("nx", _i), ("ny", _i)]
 
 
 class CorrCfg(ctypes.Structure):

@@ -1,7 +1,43 @@
-"""HeadDecoder of SLIM.  Mirror of liso/slim/model/head_decoder.py (round 1: the network-output packing
-`concat2network_output`, :37-65; the per-point decoding of :67-496 lands with the SLIM loss rows)."""
+"""HeadDecoder of SLIM: network output [B,H,W,8(+1)] -> per-point flow / class predictions.
+
+Mirror of liso/slim/model/head_decoder.py (HeadDecoder.concat2network_output :37-65, apply_output_modification :67-298,
+apply_flow_to_points :300-408, forward :410-496, artificial_network_output :517-717, artificial_{flow,logit}_network_output
+:734-955, scale_gradient :720-726).  Same names, keyword arguments and returned keys; `Munch` is the attribute dict of
+liso_amd.utils.config.  In-place writes of the reference that mutate caller tensors (`coords[~valid] = 0`,
+`points_h[~mask] = 0`) are replaced by out-of-place `torch.where` with identical values.
+"""
+from typing import Dict
+
+import numpy as np
 import torch
 from torch import nn
+
+from liso_amd.slim.slim_loss.numerical_stability import normalized_sigmoid_sum
+from liso_amd.slim.slim_loss.static_aggregation import (
+    batched_grid_data_to_pointwise_data,
+    compute_batched_bev_static_aggregated_flow,
+)
+from liso_amd.utils.bev_utils import get_voxel_center_coords_m
+from liso_amd.utils.config import AttrDict as Munch
+
+
+def homogenize_coors(coors):
+    assert coors.shape[-1] == 3
+    return torch.cat([coors, torch.ones(list(coors.shape[:-1]) + [1], dtype=coors.dtype, device=coors.device)], dim=-1)
+
+
+def scale_gradient(tensor, scaling):
+    """reference :720-726"""
+    if scaling == 1.0:
+        return tensor
+    if scaling == 0.0:
+        return tensor.detach()
+    assert scaling > 0.0
+    return tensor * scaling - tensor.detach() * (scaling - 1.0)
+
+
+def castf(tensor):
+    return tensor if tensor.dtype in {torch.float32, torch.float64} else tensor.float()
 
 
 class HeadDecoder(nn.Module):
@@ -17,3 +53,245 @@ class HeadDecoder(nn.Module):
             assert weight_logits_for_static_aggregation.shape[1] == 1
             parts.append(weight_logits_for_static_aggregation)
         return torch.cat(parts, dim=1).permute(0, 2, 3, 1)
+
+    def apply_output_modification(self, network_output, dynamicness_threshold, *, pc, pointwise_voxel_coordinates_fs,
+                                  pointwise_valid_mask, filled_pillar_mask, inv_odom, per_point_cluster_idxs_gt=None,
+                                  gt_flow_bev=None, ohe_gt_stat_dyn_ground_label_bev_map=None,
+                                  dynamic_flow_is_non_rigid_flow=False,
+                                  overwrite_non_filled_pillars_with_default_flow: bool = True,
+                                  overwrite_non_filled_pillars_with_default_logits: bool = True):
+        dev = network_output.device
+        flow_dim = 2
+        assert 3 == len(filled_pillar_mask.shape) == len(network_output.shape) - 1
+        assert filled_pillar_mask.shape[-2:] == network_output.shape[-3:-1]
+        filled_pillar_mask = filled_pillar_mask[..., None]
+        nod = {}
+        if self.cfg.model.predict_weight_for_static_aggregation is not False:
+            nod["weight_logits_for_static_aggregation"] = network_output[..., -1]
+            network_output = network_output[..., :-1]
+        assert network_output.shape[-1] == 4 + 2 * flow_dim
+        nod.update({  # reference :104-113
+            "disappearing_logit": network_output[..., 0:1], "static_logit": network_output[..., 1:2],
+            "dynamic_logit": network_output[..., 2:3], "ground_logit": network_output[..., 3:4],
+            "static_flow": network_output[..., 4:4 + flow_dim],
+            "dynamic_flow": network_output[..., 4 + flow_dim:4 + 2 * flow_dim],
+        })
+        final_grid_size = network_output.shape[1:3]
+        assert pointwise_voxel_coordinates_fs.shape[-1] == 2
+        # ground-truth static flow of every BEV cell / point from the odometry (fp64 einsum, :127-157)
+        centers_np = get_voxel_center_coords_m(np.array(self.bev_extent), final_grid_size)
+        homog = torch.from_numpy(np.concatenate([centers_np, np.zeros_like(centers_np[..., :1]), np.ones_like(centers_np[..., :1])],
+                                                axis=-1)).to(inv_odom.device)
+        centers = torch.from_numpy(centers_np).to(inv_odom.device)
+        gt_static_flow = torch.einsum("bij,hwj->bhwi", inv_odom[:, :2, :] - torch.eye(2, m=4, dtype=torch.float64,
+                                                                                       device=inv_odom.device)[None],
+                                      homog).to(torch.float32)
+        gt_pointwise_static_flow = torch.einsum("bij,bnj->bni", inv_odom[:, :3, :] - torch.eye(3, m=4, dtype=torch.float64,
+                                                                                                device=inv_odom.device)[None],
+                                                homogenize_coors(pc[:, :, :3]).to(torch.float64)).to(torch.float32)
+        nod, static_aggr_trafo, not_enough_points = artificial_network_output(
+            network_output_dict=nod, dynamicness_threshold=dynamicness_threshold, cfg=self.cfg,
+            ohe_gt_stat_dyn_ground_label_bev_map=ohe_gt_stat_dyn_ground_label_bev_map, gt_flow_bev=gt_flow_bev,
+            gt_static_flow=gt_static_flow, filled_pillar_mask=filled_pillar_mask, pc=pc,
+            pointwise_voxel_coordinates_fs=pointwise_voxel_coordinates_fs.to(dev),
+            pointwise_valid_mask=pointwise_valid_mask.to(dev), voxel_center_metric_coordinates=centers,
+            overwrite_non_filled_pillars_with_default_flow=overwrite_non_filled_pillars_with_default_flow,
+            overwrite_non_filled_pillars_with_default_logits=overwrite_non_filled_pillars_with_default_logits)
+        disappearing_logit = nod["disappearing_logit"][..., 0]
+
+        def pad3(t):
+            return None if t is None else torch.cat([t, torch.zeros_like(t[..., :1])], dim=-1)
+
+        dynamic_flow, static_flow = pad3(nod["dynamic_flow"]), pad3(nod["static_flow"])
+        static_aggr_flow, masked_static_aggr_flow = pad3(nod["static_aggr_flow"]), pad3(nod["masked_static_aggr_flow"])
+        is_static, groundness = nod["is_static"], nod["groundness"]
+        static_flow_for_aggr = masked_static_aggr_flow if self.cfg.model.use_static_aggr_flow_for_aggr_flow else static_flow
+        sel = torch.tile(is_static[..., None], [1, 1, 1, static_flow_for_aggr.shape[-1]])
+        if dynamic_flow_is_non_rigid_flow:  # reference :249-267
+            aggregated_flow = torch.where(sel, static_flow_for_aggr, (static_flow_for_aggr + dynamic_flow) * (1.0 - groundness[..., None]))
+        else:
+            aggregated_flow = torch.where(sel, static_flow_for_aggr, dynamic_flow * (1.0 - groundness[..., None]))
+        modified = Munch(disappearing=torch.sigmoid(disappearing_logit), disappearing_logit=disappearing_logit,
+                         class_probs=nod["class_probs"], class_logits=nod["class_logits"], staticness=nod["staticness"],
+                         dynamicness=nod["dynamicness"], groundness=groundness, is_static=is_static,
+                         is_dynamic=nod["is_dynamic"], is_ground=nod["is_ground"], dynamic_flow=dynamic_flow,
+                         static_flow=static_flow, aggregated_flow=aggregated_flow, static_aggr_flow=static_aggr_flow)
+        return (modified, nod, gt_flow_bev, gt_static_flow, gt_pointwise_static_flow, nod["masked_gt_static_flow"],
+                masked_static_aggr_flow, nod.get("masked_weights_for_static_aggregation", None), static_aggr_trafo,
+                not_enough_points)
+
+    def apply_flow_to_points(self, *, modified_output_bev_img, pointwise_voxel_coordinates_fs, pointwise_valid_mask):
+        """reference :300-408 -- gather 3 bool + 23 float channels per point"""
+        m = modified_output_bev_img
+        bools = torch.stack([m.is_static, m.is_dynamic, m.is_ground], dim=-1)
+        flts = torch.cat([torch.stack([m.disappearing, m.disappearing_logit, m.staticness, m.dynamicness, m.groundness], dim=-1),
+                          m.class_probs, m.class_logits, m.dynamic_flow, m.static_flow, m.aggregated_flow, m.static_aggr_flow],
+                         dim=-1)
+        assert flts.shape[-1] == 23, flts.shape
+        pb = batched_grid_data_to_pointwise_data(bools, pointwise_voxel_coordinates_fs, pointwise_valid_mask, default_value=False)
+        pf = batched_grid_data_to_pointwise_data(flts, pointwise_voxel_coordinates_fs, pointwise_valid_mask, default_value=0.0)
+        return Munch(disappearing_logit=pf[..., 1], disappearing=pf[..., 0], class_logits=pf[..., 8:11], class_probs=pf[..., 5:8],
+                     staticness=pf[..., 2], dynamicness=pf[..., 3], groundness=pf[..., 4], is_static=pb[..., 0],
+                     is_dynamic=pb[..., 1], is_ground=pb[..., 2], dynamic_flow=pf[..., 11:14], static_flow=pf[..., 14:17],
+                     aggregated_flow=pf[..., 17:20], static_aggr_flow=pf[..., 20:23])
+
+    def forward(self, network_output, dynamicness_threshold, *, pc, pointwise_voxel_coordinates, pointwise_valid_mask,
+                filled_pillar_mask, odom, inv_odom, summaries, gt_flow_bev=None, per_point_cluster_idxs_gt=None,
+                ohe_gt_stat_dyn_ground_label_bev_map=None, dynamic_flow_is_non_rigid_flow=False):
+        """reference :410-496"""
+        coors_fs = torch.div(pointwise_voxel_coordinates, self.cfg.model.u_net.final_scale, rounding_mode="trunc")
+        (modified, nod, gt_flow_bev, _, _, _, _, _, static_aggr_trafo, not_enough_points) = self.apply_output_modification(
+            network_output, dynamicness_threshold, pc=pc, pointwise_voxel_coordinates_fs=coors_fs,
+            pointwise_valid_mask=pointwise_valid_mask, filled_pillar_mask=filled_pillar_mask, inv_odom=inv_odom,
+            gt_flow_bev=gt_flow_bev, ohe_gt_stat_dyn_ground_label_bev_map=ohe_gt_stat_dyn_ground_label_bev_map,
+            dynamic_flow_is_non_rigid_flow=dynamic_flow_is_non_rigid_flow, per_point_cluster_idxs_gt=per_point_cluster_idxs_gt)
+        pointwise = self.apply_flow_to_points(modified_output_bev_img=modified, pointwise_voxel_coordinates_fs=coors_fs,
+                                              pointwise_valid_mask=pointwise_valid_mask)
+        retval = Munch(**pointwise, dense_maps=Munch(aggregated_flow=modified.aggregated_flow, static_flow=modified.static_flow),
+                       modified_network_output=Munch(nod))
+        retval["static_aggr_trafo"] = static_aggr_trafo
+        retval["dynamicness_threshold"] = dynamicness_threshold
+        retval["not_enough_points"] = not_enough_points
+        return retval
+
+
+def artificial_network_output(*, network_output_dict: Dict[str, torch.Tensor], dynamicness_threshold, cfg,
+                              ohe_gt_stat_dyn_ground_label_bev_map, gt_flow_bev, gt_static_flow, filled_pillar_mask, pc,
+                              pointwise_voxel_coordinates_fs, pointwise_valid_mask, voxel_center_metric_coordinates,
+                              overwrite_non_filled_pillars_with_default_flow: bool = False,
+                              overwrite_non_filled_pillars_with_default_logits: bool = False):
+    """reference :517-717"""
+    model_cfg = cfg.model
+    om = model_cfg.output_modification
+    nod = artificial_flow_network_output(network_output_dict=network_output_dict, model_cfg=model_cfg, gt_flow_bev=gt_flow_bev,
+                                         gt_static_flow=gt_static_flow)
+    nod = artificial_logit_network_output(network_output_dict=nod, model_cfg=model_cfg,
+                                          ohe_gt_stat_dyn_ground_label_bev_map=ohe_gt_stat_dyn_ground_label_bev_map,
+                                          gt_flow_bev=gt_flow_bev, gt_static_flow=gt_static_flow)
+    defaults = {  # reference :566-574
+        "disappearing_logit": -100.0, "static_logit": -100.0 if om.static_logit is False else 0.0,
+        "dynamic_logit": 0.0 if om.dynamic_logit is True else -100.0, "ground_logit": 0.0 if om.ground_logit is True else -100.0,
+        "static_flow": 0.0, "dynamic_flow": 0.0, "static_aggr_flow": 0.0,
+    }
+    taboo = []
+    if not overwrite_non_filled_pillars_with_default_flow:
+        taboo += ["static_flow", "dynamic_flow", "static_aggr_flow"]
+    if not overwrite_non_filled_pillars_with_default_logits:
+        taboo += ["disappearing_logit", "static_logit", "dynamic_logit", "ground_logit"]
+    for k in nod:
+        if k == "weight_logits_for_static_aggregation" or k in taboo:
+            continue
+        nod[k] = torch.where(filled_pillar_mask, nod[k], defaults[k] * torch.ones_like(nod[k]))
+    nod["class_logits"] = torch.cat([nod["static_logit"], nod["dynamic_logit"], nod["ground_logit"]], dim=-1)
+    nod["class_probs"] = torch.nn.functional.softmax(nod["class_logits"], dim=-1)
+    nod["staticness"], nod["dynamicness"], nod["groundness"] = (nod["class_probs"][..., i] for i in range(3))
+    nod["is_dynamic"] = nod["dynamicness"] >= dynamicness_threshold
+    nod["is_static"] = (nod["staticness"] >= nod["groundness"]) & (~nod["is_dynamic"])
+    nod["is_ground"] = ~(nod["is_static"] | nod["is_dynamic"])
+    weight_map = nod["staticness"] * castf(filled_pillar_mask[..., 0])
+    if model_cfg.predict_weight_for_static_aggregation is not False:  # reference :627-681
+        mode = model_cfg.predict_weight_for_static_aggregation
+        assert mode in {"sigmoid", "softmax"}
+        wl = nod["weight_logits_for_static_aggregation"]
+        if mode == "softmax":
+            masked = torch.where(filled_pillar_mask[..., 0], wl, torch.ones_like(wl) * (torch.min(wl) - 1000.0))
+            shp = masked.shape
+            nod["masked_weights_for_static_aggregation"] = torch.reshape(
+                torch.nn.functional.softmax(torch.reshape(masked, (-1, shp[-1] * shp[-2])), dim=-1), (-1, *shp[-2:]))
+        else:
+            gs = filled_pillar_mask.shape[-3:-1]
+            nod["masked_weights_for_static_aggregation"] = torch.reshape(
+                normalized_sigmoid_sum(logits=torch.reshape(wl, [-1, gs[0] * gs[1]]),
+                                       mask=torch.reshape(filled_pillar_mask[..., 0], [-1, gs[0] * gs[1]])), [-1, *gs])
+        weight_map = weight_map * nod["masked_weights_for_static_aggregation"]
+    nod["static_aggr_flow"], static_aggr_trafo, not_enough_points = compute_batched_bev_static_aggregated_flow(
+        pc, pointwise_voxel_coordinates_fs, pointwise_valid_mask, nod["static_flow"], weight_map,
+        voxel_center_metric_coordinates,
+        use_eps_for_weighted_pc_alignment=cfg.losses.unsupervised.use_epsilon_for_weighted_pc_alignment)
+    nod["masked_static_aggr_flow"] = torch.where(filled_pillar_mask, nod["static_aggr_flow"], torch.zeros_like(nod["static_aggr_flow"]))
+    nod["masked_gt_static_flow"] = torch.where(filled_pillar_mask, gt_static_flow, torch.zeros_like(nod["masked_static_aggr_flow"]))
+    return nod, static_aggr_trafo, not_enough_points
+
+
+def artificial_flow_network_output(*, network_output_dict, model_cfg, gt_flow_bev, gt_static_flow):
+    """reference :734-776"""
+    om = model_cfg.output_modification
+    nod = network_output_dict
+    if om.static_flow == "gt":
+        nod["static_flow"] = gt_static_flow
+    elif om.static_flow == "zero":
+        nod["static_flow"] = torch.zeros_like(nod["static_flow"])
+    elif om.static_flow != "net":
+        raise ValueError("unknown output mode: %s" % str(om.static_flow))
+    if om.dynamic_flow == "gt":
+        nod["dynamic_flow"] = gt_flow_bev
+        if model_cfg.dynamic_flow_is_non_rigid_flow:
+            nod["dynamic_flow"] = nod["dynamic_flow"] - nod["static_flow"]
+    elif om.dynamic_flow == "zero":
+        nod["dynamic_flow"] = torch.zeros_like(nod["dynamic_flow"])
+    elif om.dynamic_flow != "net":
+        raise ValueError("unknown output mode: %s" % str(om.dynamic_flow))
+    nod["dynamic_flow"] = scale_gradient(nod["dynamic_flow"], om.dynamic_flow_grad_scale)
+    return nod
+
+
+def _extreme(a, b, fn):
+    return fn(torch.cat([a, b], dim=0)).detach()
+
+
+def artificial_logit_network_output(*, network_output_dict, model_cfg, ohe_gt_stat_dyn_ground_label_bev_map, gt_flow_bev,
+                                    gt_static_flow):
+    """reference :779-955 (the `net` / on / off modes; the gt_label_based / gt_flow_based modes need dataset labels and
+    are reproduced as well)."""
+    om = model_cfg.output_modification
+    nod = network_output_dict
+    ones = torch.ones_like(nod["static_logit"])
+    ohe = ohe_gt_stat_dyn_ground_label_bev_map
+    if om.disappearing_logit is True:
+        nod["disappearing_logit"] = 0 * ones
+    elif om.disappearing_logit is False:
+        nod["disappearing_logit"] = -100 * ones
+    elif om.disappearing_logit != "net":
+        raise ValueError("unknown output mode: %s" % str(om.disappearing_logit))
+    # static
+    if om.static_logit == "gt_label_based":
+        assert om.dynamic_logit == "gt_label_based"
+        if om.ground_logit is False:
+            nod["static_logit"] = 100.0 * (castf(ohe[..., 0:1] | ohe[..., 2:3]) - 1.0)
+        else:
+            assert om.ground_logit == "gt_label_based"
+            nod["static_logit"] = 100.0 * (castf(ohe[..., 0:1]) - 1.0)
+    elif om.static_logit == "gt_flow_based":
+        assert om.dynamic_logit == "gt_flow_based" and om.ground_logit is False
+        is_static = castf(torch.linalg.norm(gt_flow_bev - gt_static_flow, dim=-1, keepdim=True) <= 0.05)
+        nod["static_logit"] = 100.0 * (is_static - 1.0)
+    elif om.static_logit is True:
+        assert om.dynamic_logit is False and om.ground_logit is False
+        nod["static_logit"] = _extreme(nod["dynamic_logit"], nod["ground_logit"], torch.max) + 100.0 * ones
+    elif om.static_logit is False:
+        assert om.dynamic_logit is not False or om.ground_logit is not False
+        nod["static_logit"] = _extreme(nod["dynamic_logit"], nod["ground_logit"], torch.max) - 100.0 * ones
+    elif om.static_logit != "net":
+        raise ValueError("unknown output mode: %s" % str(om.static_logit))
+    # dynamic
+    if om.dynamic_logit == "gt_label_based":
+        nod["dynamic_logit"] = 100.0 * (castf(ohe[..., 1:2]) - 1.0)
+    elif om.dynamic_logit == "gt_flow_based":
+        nod["dynamic_logit"] = 100.0 - nod["static_logit"]
+    elif om.dynamic_logit is True:
+        nod["dynamic_logit"] = _extreme(nod["static_logit"], nod["ground_logit"], torch.max) + 100.0 * ones
+    elif om.dynamic_logit is False:
+        nod["dynamic_logit"] = _extreme(nod["static_logit"], nod["ground_logit"], torch.min) - 100.0 * ones
+    elif om.dynamic_logit != "net":
+        raise ValueError("unknown output mode: %s" % str(om.dynamic_logit))
+    # ground
+    if om.ground_logit == "gt_label_based":
+        nod["ground_logit"] = 100.0 * (castf(ohe[..., 2:3]) - 1.0)
+    elif om.ground_logit is True:
+        assert om.static_logit is False and om.dynamic_logit is False
+        nod["ground_logit"] = _extreme(nod["static_logit"], nod["dynamic_logit"], torch.max) + 100.0 * ones
+    elif om.ground_logit is False:
+        nod["ground_logit"] = _extreme(nod["static_logit"], nod["dynamic_logit"], torch.min) - 100.0 * ones
+    elif om.ground_logit != "net":
+        raise ValueError("unknown output mode: %s" % str(om.ground_logit))
+    return nod

@@ -1,0 +1,61 @@
+"""SLIM = RAFT on BEV pillars + per-direction HeadDecoder.  Mirror of liso/slim/model/slim.py:10-156 (same
+constructor, sub-module names `head_decoder_fw/bw`, `moving_dynamicness_threshold`, `raft_network`, same forward
+signature and outputs).  The hard-coded `"cuda"` placements of the reference (:56,:62) become "the module's device"."""
+import numpy as np
+import torch
+from torch import nn
+
+from liso_amd.slim.model.head_decoder import HeadDecoder
+from liso_amd.slim.model.raft_mod import RAFT
+from liso_amd.slim.slim_loss.movavg_cls_threshold import MovingAverageThreshold
+
+
+def get_network_input_pcls(cfg, sample_data, time_key: str, to_device=None):
+    """liso/kabsch/main_utils.py:247-261"""
+    key = f"pcl_full_w_ground_{time_key}" if cfg.data.use_ground_for_network else f"pcl_full_no_ground_{time_key}"
+    return [el.to(to_device) for el in sample_data[key]] if to_device else sample_data[key]
+
+
+class SLIM(nn.Module):
+    def __init__(self, cfg, num_train_samples, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.cfg, self.slim_cfg = cfg, cfg.SLIM
+        half = 0.5 * np.array(cfg.data.bev_range_m)
+        bev_pc_range = np.concatenate([-half, half], axis=0)
+        self.head_decoder_fw = HeadDecoder(self.slim_cfg, bev_extent=bev_pc_range, name="head_decoder_forward")
+        self.head_decoder_bw = HeadDecoder(self.slim_cfg, bev_extent=bev_pc_range, name="head_decoder_backward")
+        assert self.slim_cfg.phases.train.mode in ["supervised", "unsupervised"]
+        if self.slim_cfg.phases.train.mode == "unsupervised":
+            num_still = None
+        else:
+            num_still = self.slim_cfg.data.train.num_still_points * self.slim_cfg.model.num_iters
+        self.moving_dynamicness_threshold = MovingAverageThreshold(num_train_samples=num_train_samples,
+                                                                   num_moving=621013971, num_still=num_still)
+        self.raft_network = RAFT(cfg=cfg, head_decoder_fw=self.head_decoder_fw, head_decoder_bw=self.head_decoder_bw)
+
+    def forward(self, sample_data_t0, sample_data_t1, summaries=None):
+        dev = next(self.raft_network.parameters()).device
+        out_fw, out_bw, aux = self.raft_network(get_network_input_pcls(self.cfg, sample_data_t0, "ta", to_device=dev),
+                                                get_network_input_pcls(self.cfg, sample_data_t1, "ta", to_device=dev))
+        filled0 = torch.squeeze(aux["t0"]["bev_net_input_dbg"] > 0.5, dim=1)
+        filled1 = torch.squeeze(aux["t1"]["bev_net_input_dbg"] > 0.5, dim=1)
+        thr = self.moving_dynamicness_threshold.value()
+        nri = self.slim_cfg.model.dynamic_flow_is_non_rigid_flow
+        preds_fw, preds_bw = [], []
+        for o01, o10 in zip(out_fw, out_bw):
+            kw0 = dict(dynamicness_threshold=thr, pointwise_valid_mask=sample_data_t0["pcl_ta"]["pcl_is_valid"].to(dev),
+                       pointwise_voxel_coordinates=sample_data_t0["pcl_ta"]["pillar_coors"].to(dev),
+                       pc=sample_data_t0["pcl_ta"]["pcl"].to(dev), filled_pillar_mask=filled0,
+                       odom=sample_data_t0["gt"]["odom_ta_tb"].to(dev), inv_odom=sample_data_t1["gt"]["odom_ta_tb"].to(dev),
+                       summaries=summaries, gt_flow_bev=None, ohe_gt_stat_dyn_ground_label_bev_map=None,
+                       dynamic_flow_is_non_rigid_flow=nri)
+            kw1 = dict(dynamicness_threshold=thr, pointwise_valid_mask=sample_data_t1["pcl_ta"]["pcl_is_valid"].to(dev),
+                       pointwise_voxel_coordinates=sample_data_t1["pcl_ta"]["pillar_coors"].to(dev),
+                       pc=sample_data_t1["pcl_ta"]["pcl"].to(dev), filled_pillar_mask=filled1,
+                       odom=sample_data_t1["gt"]["odom_ta_tb"].to(dev), inv_odom=sample_data_t0["gt"]["odom_ta_tb"].to(dev),
+                       summaries=summaries, gt_flow_bev=None, ohe_gt_stat_dyn_ground_label_bev_map=None,
+                       dynamic_flow_is_non_rigid_flow=nri)
+            preds_fw.append(self.head_decoder_fw(o01, **kw0))
+            preds_bw.append(self.head_decoder_bw(o10, **kw1))
+        self.predictions_fw, self.predictions_bw = preds_fw, preds_bw
+        return preds_fw, preds_bw

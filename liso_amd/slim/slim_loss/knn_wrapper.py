@@ -1,0 +1,83 @@
+"""Nearest-point flow loss.  Mirror of liso/slim/slim_loss/knn_wrapper.py:11-217 (same functions and semantics)."""
+import functools as ft
+
+import torch
+
+from liso_amd.slim.slim_loss.knn_graph import KnnIndex, knn_graph
+from liso_amd.utils.config import AttrDict as Munch
+
+
+def huber_delta(*, err=None, err_sqr=None, delta: float, mode: str = "large_grad_1"):
+    """reference :11-49"""
+    assert mode in {"large_grad_1", "small_err_sqr"}
+    if delta == 0.0:
+        assert mode == "large_grad_1" and err is None and err_sqr is not None
+        nz = ~(err_sqr == 0.0)  # gradient-safe sqrt
+        return torch.where(nz, err_sqr, torch.ones_like(err_sqr)).sqrt() * nz.to(torch.float)
+    assert delta > 0.0
+    if err is not None:
+        assert err_sqr is None
+        err_sqr = err.square()
+    if mode == "large_grad_1":
+        return torch.clamp(err_sqr, max=delta ** 2) / (2.0 * delta) + torch.clamp(err_sqr, min=delta ** 2).sqrt() - delta
+    return torch.clamp(err_sqr, max=delta ** 2) + torch.clamp(err_sqr, min=delta ** 2).sqrt() * (2 * delta) - 2 * delta ** 2
+
+
+def squared_sum(delta, dim: int = -1):
+    return delta.square().sum(dim=dim)
+
+
+class NearestPointLoss:
+    """reference :58-135"""
+
+    def __init__(self, *args, bev_extent, L1_delta: float, drop_outliers__perc: float, fov_mode: str = "ignore_out_fov", **kwargs):
+        assert 0.0 <= drop_outliers__perc < 100.0
+        assert fov_mode in {"none", "ignore_out_fov", "use_nearest", "mask_close_fov"}
+        self.bev_extent = bev_extent
+        self.drop_outliers__perc = drop_outliers__perc
+        self.huber_loss = ft.partial(huber_delta, delta=L1_delta, mode="large_grad_1")
+        self.fov_mode = fov_mode
+
+    def __call__(self, *, cloud_b__a, nearest_cloud_b__a, nearest_dist_sqr_b__a):
+        e = self.bev_extent
+        min_fov = torch.min(torch.stack([cloud_b__a[..., 0] - e[0], cloud_b__a[..., 1] - e[1], e[2] - cloud_b__a[..., 0],
+                                         e[3] - cloud_b__a[..., 1]], dim=-1), dim=-1)[0]
+        weights = None
+        if self.fov_mode == "ignore_out_fov":
+            weights = (min_fov > 0.0).to(torch.float)
+        elif self.fov_mode == "use_nearest":
+            nearest_dist_sqr_b__a = torch.min(nearest_dist_sqr_b__a, min_fov.square())
+        elif self.fov_mode == "mask_close_fov":
+            weights = (min_fov > 0.0).to(torch.float) * (nearest_dist_sqr_b__a < min_fov.square())
+        loss = self.huber_loss(err_sqr=nearest_dist_sqr_b__a)
+        if weights is not None:
+            loss = loss * weights
+        if self.drop_outliers__perc > 0.0:  # reference :120-133
+            keep = 1.0 - self.drop_outliers__perc / 100.0
+            bs = loss.size(0)
+            kth = int(round(loss.numel() / bs * keep))
+            thr = torch.stack([torch.kthvalue(loss[b], kth)[0] for b in range(bs)], dim=0)
+            loss = torch.where(loss <= thr[(slice(None),) + tuple([None] * (loss.ndim - 1))], loss, torch.zeros_like(loss))
+        return loss
+
+
+@torch.no_grad()
+def get_idx_dists_for_knn(ref_pts, query_pts, num_neighbors: int = 1):
+    """reference :138-152"""
+    assert query_pts.ndim == 2
+    return knn_graph(query_pts, index=ref_pts, k=num_neighbors, loop=True)
+
+
+def compute_flow_loss_a_to_b(cloud_a, cloud_b, flow_a_to_b, loss_function, nearest_dist_mode: str = "point", knn_indices=None):
+    """reference :155-217.  `knn_indices` (optional list of KnnIndex, one per batch row of cloud_b) lets the caller reuse
+    the device index of a reference cloud across RAFT iterations / flow types."""
+    assert nearest_dist_mode == "point"
+    assert cloud_a.ndim == 3 and cloud_b.ndim == 3 and flow_a_to_b.ndim == 3
+    cloud_b__a = cloud_a + flow_a_to_b
+    bs = cloud_b.size(0)
+    idx = torch.stack([get_idx_dists_for_knn(knn_indices[b] if knn_indices is not None else cloud_b[b], cloud_b__a[b], 1)
+                       for b in range(bs)], dim=0)
+    nearest = torch.gather(cloud_b, 1, idx.repeat(1, 1, 3))
+    d2 = squared_sum(nearest - cloud_b__a, dim=-1)
+    loss = loss_function(cloud_b__a=cloud_b__a, nearest_cloud_b__a=nearest, nearest_dist_sqr_b__a=d2)
+    return loss, Munch(nearest_dist_sqr=d2, nearest_dist=d2.sqrt())

@@ -1,0 +1,64 @@
+"""MovingAverageThreshold.  Mirror of liso/slim/slim_loss/movavg_cls_threshold.py:9-157 (same buffers -> same
+state_dict keys: start_value, update_weight, [moving_counter, still_counter], bias_counter, moving_average_importance)."""
+from typing import Tuple
+
+import torch
+from torch import nn
+
+
+class MovingAverageThreshold(nn.Module):
+    def __init__(self, num_train_samples: int, num_moving: int, num_still=None, resolution: int = 100000,
+                 start_value: float = 0.5, value_range: Tuple[float, float] = (0.0, 1.0), *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.value_range = (value_range[0], value_range[1] - value_range[0])
+        self.resolution, self.num_moving, self.num_still = resolution, num_moving, num_still
+        self.register_buffer("start_value", torch.tensor(start_value, dtype=torch.float))
+        self.total = num_moving + (num_still if num_still is not None else 0)
+        assert num_train_samples > 0, num_train_samples
+        update_weight = 1.0 / min(2.0 * self.total, 5_000.0 * self.total / num_train_samples)
+        self.register_buffer("update_weight", torch.tensor(update_weight, dtype=torch.double))
+        if num_still is not None:
+            self.register_buffer("moving_counter", torch.tensor(self.num_moving, dtype=torch.long))
+            self.register_buffer("still_counter", torch.tensor(self.num_still, dtype=torch.long))
+        self.register_buffer("bias_counter", torch.zeros((), dtype=torch.double))
+        self.register_buffer("moving_average_importance", torch.zeros((self.resolution,), dtype=torch.float))
+
+    def value(self):
+        return self._compute_optimal_score_threshold() if self.bias_counter > 0.0 else self.start_value
+
+    def _compute_bin_idxs(self, scores):
+        idxs = ((scores - self.value_range[0]) * self.resolution / self.value_range[1]).to(torch.int)
+        return torch.clamp(idxs, max=self.resolution - 1)
+
+    def _compute_improvements(self, epes_stat_flow, epes_dyn_flow, moving_mask):
+        if self.num_still is None:
+            assert moving_mask is None
+            return epes_stat_flow - epes_dyn_flow
+        w = 1.0 / torch.where(moving_mask, self.moving_counter, self.still_counter).to(torch.float)
+        return (epes_stat_flow - epes_dyn_flow) * w
+
+    def _compute_optimal_score_threshold(self):
+        z = torch.zeros((1,), dtype=self.moving_average_importance.dtype, device=self.moving_average_importance.device)
+        improv = torch.cat([z, torch.cumsum(self.moving_average_importance, 0)], dim=0)
+        avg_idx = torch.mean(torch.where(torch.min(improv) == improv)[0].to(torch.float))
+        return self.value_range[0] + avg_idx * self.value_range[1] / self.resolution
+
+    def _update_values(self, cur_value, cur_weight):
+        w = (1.0 - self.update_weight) ** cur_weight
+        self.moving_average_importance *= w.to(torch.float)
+        self.moving_average_importance += (1.0 - w.to(torch.float)) * cur_value
+        self.bias_counter *= w
+        self.bias_counter += 1.0 - w
+
+    def update(self, epes_stat_flow, epes_dyn_flow, moving_mask, dynamicness_scores, training):
+        assert isinstance(training, bool)
+        if training:
+            e_s, e_d, sc = epes_stat_flow.detach(), epes_dyn_flow.detach(), dynamicness_scores.detach()
+            imp = self._compute_improvements(e_s, e_d, moving_mask)
+            cur = torch.zeros((self.resolution,), dtype=imp.dtype, device=imp.device).scatter_add_(
+                0, self._compute_bin_idxs(sc).to(torch.long), imp)
+            self._update_values(cur, e_s.numel())
+            if self.num_still is not None:
+                self.moving_counter += torch.count_nonzero(moving_mask)
+                self.still_counter += torch.count_nonzero(~moving_mask)
+        return self.value()

@@ -1,0 +1,114 @@
+"""Self-supervised SLIM loss.  Mirror of liso/slim/slim_loss/slim_loss_adaptor.py:9-348 (same function names and
+keyword arguments; `total_loss` starts on the inputs' device instead of a hard-coded `.cuda()`, :145)."""
+from typing import Any, Dict
+
+import torch
+
+from liso_amd.slim.slim_loss.artificial_labels_pytorch import compute_artificial_label_loss
+from liso_amd.slim.slim_loss.knn_loss import compute_knn_loss_components
+from liso_amd.utils.torch_transformation import homogenize_pcl
+
+
+def trafo_distance(delta_trafos, points, mask):
+    """reference :9-33 -- mean squared displacement of the points under (T - I)"""
+    points = points.detach()
+    count = mask.sum(dim=-1)
+    ph = torch.cat([points, torch.ones_like(points[..., :1])], dim=-1)
+    ph = torch.where(mask[..., None], ph, torch.zeros_like(ph))
+    d = torch.einsum("b...ij,bkj->b...ki", delta_trafos[..., :3, :], ph.double()).float()
+    return torch.sum(torch.sum(d ** 2, dim=-1), dim=-1) / count
+
+
+def weighted_mse_loss(input_tensor, target, weight):
+    return (weight * (input_tensor - target) ** 2).mean(dim=-1)
+
+
+def static_points_loss(pc, valid_mask, flow, weights, trafo):
+    """reference :55-91"""
+    pc_valid = torch.where(valid_mask[..., None], pc, torch.tensor(0.0, dtype=pc.dtype, device=pc.device))
+    pc_hom = homogenize_pcl(pc_valid[..., :3])
+    moved = torch.sum(pc_hom[:, :, None, :].double() * trafo.detach()[:, None, :, :], dim=-1)
+    est = (moved[..., :3] - pc_valid[..., :3].double()).float()
+    return weighted_mse_loss(est, flow, weights[..., None])
+
+
+def symmetric_static_points_loss(pc0, valid_mask_pc0, static_flow_fw, static_aggr_trafo_fw, staticness_fw, pc1=None,
+                                 valid_mask_pc1=None, static_aggr_trafo_bw=None):
+    """reference :94-120"""
+    assert (pc1 is None) == (static_aggr_trafo_bw is None)
+    loss0 = static_points_loss(pc0, valid_mask_pc0, static_flow_fw, staticness_fw, static_aggr_trafo_fw)
+    if pc1 is None:
+        return loss0
+    fb = torch.einsum("boc,bcx->box", static_aggr_trafo_bw, static_aggr_trafo_fw)
+    fb_loss = trafo_distance(fb - torch.eye(4, device=fb.device), torch.cat([pc0[..., :3], pc1[..., :3]], dim=1),
+                             mask=torch.cat([valid_mask_pc0, valid_mask_pc1], dim=1)).mean()
+    return loss0, fb_loss
+
+
+def _masked_mean(x, mask):
+    return x[mask].mean()
+
+
+def selfsupervisedSlimSingleScaleLoss(pc1, valid_mask_pc1, pc2, valid_mask_pc2, pred_fw, pred_bw, moving_thresh_module, *,
+                                      loss_cfg, model_cfg, bev_extent, metrics_collector: Dict[str, Any], training=True,
+                                      knn_index_pc1=None, knn_index_pc2=None):
+    """reference :123-348.  knn_index_pc{1,2}: optional per-batch lists of device KnnIndex built once per cloud."""
+    total = torch.zeros(1, device=pc1.device)
+    sfp, fbp = loss_cfg.static_flow_penalty_factor != 0.0, loss_cfg.fw_bw_static_trafo_penalty_factor != 0.0
+    if sfp or fbp:
+        det = loss_cfg.artificial_labels.cross_entropy_penalty > 0.0
+        st_fw = pred_fw.staticness.detach() if det else pred_fw.staticness
+        st_bw = pred_bw.staticness.detach() if det else pred_bw.staticness
+        l_fw, fb = symmetric_static_points_loss(pc0=pc1, valid_mask_pc0=valid_mask_pc1, static_flow_fw=pred_fw.static_flow,
+                                                static_aggr_trafo_fw=pred_fw.static_aggr_trafo, staticness_fw=st_fw, pc1=pc2,
+                                                valid_mask_pc1=valid_mask_pc2, static_aggr_trafo_bw=pred_bw.static_aggr_trafo)
+        l_bw = symmetric_static_points_loss(pc0=pc2, valid_mask_pc0=valid_mask_pc2, static_flow_fw=pred_bw.static_flow,
+                                            static_aggr_trafo_fw=pred_bw.static_aggr_trafo, staticness_fw=st_bw)
+        static_flow_loss = 0.5 * (_masked_mean(l_fw, valid_mask_pc1) + _masked_mean(l_bw, valid_mask_pc2))
+        metrics_collector["static_flow_loss"] = static_flow_loss.detach()
+        metrics_collector["for_back_static_trafo_loss"] = fb.detach()
+        if sfp:
+            total = total + static_flow_loss * loss_cfg.static_flow_penalty_factor
+        if fbp:
+            total = total + fb * loss_cfg.fw_bw_static_trafo_penalty_factor
+    kw = dict(loss_cfg=loss_cfg, model_cfg=model_cfg, bev_extent=bev_extent)
+    knn_fw = compute_knn_loss_components(pc1[..., :3], valid_mask_pc1, pc2[..., :3], valid_mask_pc2, prediction=pred_fw,
+                                         knn_indices=knn_index_pc2, **kw)
+    knn_bw = compute_knn_loss_components(pc2[..., :3], valid_mask_pc2, pc1[..., :3], valid_mask_pc1, prediction=pred_bw,
+                                         knn_indices=knn_index_pc1, **kw)
+    ce = loss_cfg.artificial_labels.cross_entropy_penalty > 0.0
+    if ce:
+        ce_fw = _masked_mean(compute_artificial_label_loss(prediction={"staticness": pred_fw.staticness}, knn_results=knn_fw,
+                                                           loss_cfg=loss_cfg), valid_mask_pc1)
+        ce_bw = _masked_mean(compute_artificial_label_loss(prediction={"staticness": pred_bw.staticness}, knn_results=knn_bw,
+                                                           loss_cfg=loss_cfg), valid_mask_pc2)
+    assert loss_cfg.knn_loss.range_based_weights.weight_slope == 0.0, "range-based kNN weights are not on the hot path"
+    w1, w2 = torch.ones_like(pc1[..., 0]), torch.ones_like(pc2[..., 0])
+    flow_loss = 0.5 * (_masked_mean(w2 * knn_bw["aggregated"]["loss"], valid_mask_pc2)
+                       + _masked_mean(w1 * knn_fw["aggregated"]["loss"], valid_mask_pc1))
+    if loss_cfg.knn_loss_penalty_factor != 0.0:
+        total = total + flow_loss * loss_cfg.knn_loss_penalty_factor
+    if loss_cfg.knn_on_dynamic_penalty != 0.0:
+        dyn = 0.5 * (_masked_mean(w2 * knn_bw["dynamic"]["loss"], valid_mask_pc2)
+                     + _masked_mean(w1 * knn_fw["dynamic"]["loss"], valid_mask_pc1))
+        metrics_collector["dynamic_flow_loss"] = dyn.detach()
+        total = total + dyn * loss_cfg.knn_on_dynamic_penalty
+    if loss_cfg.knn_on_static_penalty != 0.0:
+        assert loss_cfg.knn_on_static_penalty == 1.0 and model_cfg.use_static_aggr_flow_for_aggr_flow
+        st = 0.5 * (_masked_mean(w2 * knn_bw["static_aggr"]["loss"], valid_mask_pc2)
+                    + _masked_mean(w1 * knn_fw["static_aggr"]["loss"], valid_mask_pc1))
+        metrics_collector["static_flow_loss"] = st.detach()
+        total = total + st * loss_cfg.knn_on_static_penalty
+    assert loss_cfg.opposite_flow_penalty_factor == 0.0
+    if model_cfg.use_static_aggr_flow_for_aggr_flow:  # reference :294-335: update the dynamicness threshold
+        es, ed, sc = [], [], []
+        for res, pred, m in ((knn_fw, pred_fw, valid_mask_pc1), (knn_bw, pred_bw, valid_mask_pc2)):
+            es.append(res["static_aggr"]["knn"]["nearest_dist"][m].flatten())
+            ed.append(res["dynamic"]["knn"]["nearest_dist"][m].flatten())
+            sc.append(pred.dynamicness[m].flatten())
+        moving_thresh_module.update(epes_stat_flow=torch.cat(es), epes_dyn_flow=torch.cat(ed), moving_mask=None,
+                                    dynamicness_scores=torch.cat(sc), training=training)
+    if ce:
+        total = total + 0.5 * (ce_fw + ce_bw) * loss_cfg.artificial_labels.cross_entropy_penalty
+    metrics_collector["total_loss"] = total.detach()
+    return total

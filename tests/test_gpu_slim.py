@@ -111,3 +111,72 @@ def test_raft_loop_matches_reference():
     assert _rel(ub.gru.convz.weight.grad[:, ::8], g["raft_g_gru_convz"]) < 5e-3
     assert _rel(ub.static_flow_head.conv2.weight.grad, g["raft_g_flow_head"]) < 5e-3
     assert _rel(ub.motion_encoder.conv_stat_corr1.weight.grad[..., 0, 0], g["raft_g_corr_conv"]) < 5e-3
+
+
+# ---- SLIM decoder + self-supervised loss (E6/E7) -------------------------------------------------------------------------
+@pytest.mark.parametrize("nq,nr,spread", [(120000, 120000, 50.0), (5000, 300, 10.0), (10, 1, 1.0), (1000, 50000, 200.0)])
+def test_knn_exact_vs_bruteforce(nq, nr, spread):
+    from liso_amd.slim.slim_loss.knn_graph import KnnIndex, knn_graph
+
+    g = torch.Generator().manual_seed(nq + nr)
+    ref = torch.cat([torch.rand(nr, 2, generator=g) * 2 * spread - spread, torch.rand(nr, 1, generator=g) * 3 - 2], -1).cuda()
+    qry = torch.cat([torch.rand(nq, 2, generator=g) * 2.4 * spread - 1.2 * spread, torch.rand(nq, 1, generator=g) * 3 - 2], -1).cuda()
+    idx, d2 = KnnIndex(ref).query(qry, return_dist_sqr=True)
+    best = torch.full((nq,), float("inf"), device="cuda")
+    for s in range(0, nq, 4096):  # brute force in chunks
+        best[s:s + 4096] = torch.cdist(qry[s:s + 4096].double(), ref.double()).min(dim=1).values.float() ** 2
+    got = ((ref[idx] - qry) ** 2).sum(-1)
+    assert torch.allclose(got, best, rtol=1e-5, atol=1e-7)       # exact nearest neighbour (distance-wise)
+    assert torch.allclose(d2, got, rtol=1e-5, atol=1e-7)
+    assert knn_graph(qry, index=ref, k=1, loop=True).shape == (nq, 1)
+
+
+def _slim_cfg(tag):
+    from liso_amd.utils.config import apply_slim_simple_knn_training, default_cfg
+
+    cfg = default_cfg(grid=32, bev_range_m=20.0)
+    return apply_slim_simple_knn_training(cfg) if tag == "simple_knn" else cfg
+
+
+@pytest.mark.parametrize("tag", ["default", "simple_knn"])
+def test_head_decoder_and_loss_match_reference(tag):
+    from liso_amd.slim.model.head_decoder import HeadDecoder
+    from liso_amd.slim.slim_loss.movavg_cls_threshold import MovingAverageThreshold
+    from liso_amd.slim.slim_loss.slim_loss_adaptor import selfsupervisedSlimSingleScaleLoss
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "slim_loss_reference.npz"))
+    cfg = _slim_cfg(tag)
+    R, G = 20.0, 32
+    ext = np.array([-R / 2, -R / 2, R / 2, R / 2])
+    pc1, pc2 = torch.from_numpy(g["pc1"]).cuda(), torch.from_numpy(g["pc2"]).cuda()
+    odom = torch.from_numpy(g["odom"]).cuda()
+    inv_odom = torch.linalg.inv(odom)
+    valid = torch.ones(pc1.shape[:2], dtype=torch.bool, device="cuda")
+    coors = lambda pc: ((pc[..., :2] + R / 2) / R * G).to(torch.int32)
+
+    def filled(c):
+        m = torch.zeros(1, G, G, dtype=torch.bool, device="cuda")
+        m[0, c[0, :, 0].long(), c[0, :, 1].long()] = True
+        return m
+
+    net_fw = torch.from_numpy(g[f"{tag}_net_fw"]).cuda().requires_grad_(True)
+    net_bw = torch.from_numpy(g[f"{tag}_net_bw"]).cuda().requires_grad_(True)
+    thr = MovingAverageThreshold(num_train_samples=100, num_moving=621013971, num_still=None).cuda()
+    dec_fw, dec_bw = HeadDecoder(cfg.SLIM, "fw", ext), HeadDecoder(cfg.SLIM, "bw", ext)
+    common = dict(summaries=None, gt_flow_bev=None, ohe_gt_stat_dyn_ground_label_bev_map=None, dynamic_flow_is_non_rigid_flow=False)
+    pfw = dec_fw(net_fw, thr.value(), pc=pc1, pointwise_voxel_coordinates=coors(pc1), pointwise_valid_mask=valid,
+                 filled_pillar_mask=filled(coors(pc1)), odom=odom, inv_odom=inv_odom, **common)
+    pbw = dec_bw(net_bw, thr.value(), pc=pc2, pointwise_voxel_coordinates=coors(pc2), pointwise_valid_mask=valid,
+                 filled_pillar_mask=filled(coors(pc2)), odom=inv_odom, inv_odom=odom, **common)
+    assert _rel(pfw.aggregated_flow, g[f"{tag}_agg_flow_fw"]) < REL
+    assert _rel(pfw.staticness, g[f"{tag}_staticness_fw"]) < REL
+    assert _rel(pfw.static_aggr_flow, g[f"{tag}_static_aggr_flow_fw"]) < REL
+    assert _rel(pfw.static_aggr_trafo, g[f"{tag}_T_fw"]) < REL
+    assert np.array_equal(pfw.is_static.cpu().numpy(), g[f"{tag}_is_static_fw"])
+    assert _rel(pfw.dense_maps.aggregated_flow, g[f"{tag}_dense_agg_fw"]) < REL
+    loss = selfsupervisedSlimSingleScaleLoss(pc1=pc1, valid_mask_pc1=valid, pc2=pc2, valid_mask_pc2=valid, pred_fw=pfw, pred_bw=pbw,
+                                             moving_thresh_module=thr, loss_cfg=cfg.SLIM.losses.unsupervised,
+                                             model_cfg=cfg.SLIM.model, bev_extent=ext, metrics_collector={})
+    assert abs(float(loss) - float(g[f"{tag}_loss"])) <= REL * abs(float(g[f"{tag}_loss"]))
+    loss.backward()
+    assert _rel(net_fw.grad, g[f"{tag}_g_fw"]) < 5e-3 and _rel(net_bw.grad, g[f"{tag}_g_bw"]) < 5e-3
