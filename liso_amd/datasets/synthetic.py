@@ -107,3 +107,52 @@ def detector_batch(seed, batch, device, n_points=120000, grid=512, bev_range_m=1
     t = render_center_targets(torch.stack(P), torch.stack(D), torch.stack(Rt), torch.stack(V), (out, out),
                               (bev_range_m, bev_range_m))
     return pcls, t
+
+
+def _se2(dx, dy, dth, device):
+    T = torch.eye(4, dtype=torch.float64, device=device)
+    c, s = math.cos(dth), math.sin(dth)
+    T[0, 0], T[0, 1], T[1, 0], T[1, 1], T[0, 3], T[1, 3] = c, -s, s, c, dx, dy
+    return T
+
+
+def _loss_cloud(cloud, n_points, grid, bev_range_m, gen):
+    """ground removed by a z threshold, in BEV range, exactly n_points rows"""
+    half = bev_range_m / 2
+    keep = (cloud[:, 2] > -1.45) & (cloud[:, :2].abs().amax(dim=1) < half - 1e-3)
+    c = cloud[keep]
+    n = c.shape[0]
+    if n >= n_points:
+        c = c[torch.randperm(n, generator=gen)[:n_points].to(c.device)]
+    else:
+        idx = torch.randint(0, n, (n_points - n,), generator=gen).to(c.device)
+        c = torch.cat([c, c[idx] + torch.randn(n_points - n, 4, generator=gen).to(c.device) * torch.tensor([0.02, 0.02, 0.01, 0.0], device=c.device)])
+        c[:, :2] = c[:, :2].clamp(-half + 1e-3, half - 1e-3)
+    return c.contiguous()
+
+
+def slim_pair(seed, device, n_points=120000, grid=512, bev_range_m=100.0):
+    """Two consecutive KITTI-shaped sweeps for the SLIM step in the reference's sample layout
+    (liso/datasets/torch_dataset_commons.py:380-431,975-987): `pcl_full_no_ground_ta` (network input, list of [N,4]),
+    `pcl_ta` = {pcl [1,N,4], pcl_is_valid [1,N], pillar_coors [1,N,2] int32 by truncation (analyse_boxes.py:11-17)},
+    `gt.odom_ta_tb` [1,4,4] fp64.  Returns (sample_t0, sample_t1); sample_t1 is the time-reversed view."""
+    gen = torch.Generator(device="cpu").manual_seed(seed + 77)
+    boxes0, speed, ego = make_scene(seed, device, n_boxes=30)
+    boxes1 = move_scene(boxes0, speed, ego)
+    # denser ray fan than the 64x1875 detector input so that 120k non-ground points remain (rendered twice, merged)
+    clouds = []
+    for bx, sd in ((boxes0, seed), (boxes1, seed + 1)):
+        a, _ = render(bx, device, sd, n_points=120000)
+        b, _ = render(bx, device, sd + 1000, n_points=120000, noise=0.03)
+        b[:, :2] += 0.011  # decorrelate the two fans
+        clouds.append(_loss_cloud(torch.cat([a, b]), n_points, grid, bev_range_m, gen))
+    T01 = _se2(float(ego[0]), float(ego[1]), float(ego[2]), device)
+
+    def sample(cloud, odom):
+        coors = ((cloud[:, :2] + bev_range_m / 2) / bev_range_m * grid).to(torch.int32)
+        return {"pcl_full_no_ground_ta": [cloud],
+                "pcl_ta": {"pcl": cloud[None], "pcl_is_valid": torch.ones(1, cloud.shape[0], dtype=torch.bool, device=device),
+                           "pillar_coors": coors[None]},
+                "gt": {"odom_ta_tb": odom[None]}}
+
+    return sample(clouds[0], T01), sample(clouds[1], torch.linalg.inv(T01))

@@ -66,3 +66,57 @@ class DetectorTrainer:
         self.optimizer.step()
         self.lr_scheduler.step()
         return total.detach()
+
+
+class SlimTrainer:
+    """SLIM self-supervised train step, mirror of liso/slim/experiment.py:834-919 (`train_one_step`) with the optimizer /
+    schedule factory of :200-219: RMSprop(lr 1e-4) + linear warm-up (2000) then linear decay to 5 %; the loss is the
+    un-weighted sum over the 6 RAFT iterations.  The reference cloud of every kNN query is bucketed on the device once
+    per step (the reference rebuilds a host KD-tree for each of the 12+ queries)."""
+
+    def __init__(self, cfg, device, num_train_samples=1000):
+        from liso_amd.slim.model.slim import SLIM
+        from liso_amd.utils.learning_rate import get_polynomial_decay_schedule_with_warmup
+
+        self.cfg, self.slim_cfg, self.device = cfg, cfg.SLIM, device
+        self.net = SLIM(cfg, num_train_samples=num_train_samples).to(device)
+        self.model = self.net
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            self.model = torch.nn.parallel.DistributedDataParallel(
+                self.net, device_ids=[device.index] if device.type == "cuda" else None, bucket_cap_mb=64,
+                broadcast_buffers=False, gradient_as_bucket_view=True)
+        assert self.slim_cfg.optimizer == "rmsprop"
+        self.optimizer = torch.optim.RMSprop(self.net.parameters(), lr=self.slim_cfg.learning_rate.initial)
+        self.lr_scheduler = get_polynomial_decay_schedule_with_warmup(
+            optimizer=self.optimizer, num_warmup_steps=self.slim_cfg.learning_rate.warm_up.step_length,
+            num_training_steps=self.slim_cfg.iterations.train, lr_end=self.slim_cfg.learning_rate.initial * 0.05)
+        half = 0.5 * torch.tensor(cfg.data.bev_range_m).numpy()
+        import numpy as np
+        self.bev_extent = np.concatenate([-half, half], axis=0)
+
+    def loss(self, sample_t0, sample_t1):
+        from liso_amd.slim.slim_loss.knn_graph import KnnIndex
+        from liso_amd.slim.slim_loss.slim_loss_adaptor import selfsupervisedSlimSingleScaleLoss
+
+        preds_fw, preds_bw = self.model(sample_t0, sample_t1, None)
+        pc1, m1 = sample_t0["pcl_ta"]["pcl"].to(self.device), sample_t0["pcl_ta"]["pcl_is_valid"].to(self.device)
+        pc2, m2 = sample_t1["pcl_ta"]["pcl"].to(self.device), sample_t1["pcl_ta"]["pcl_is_valid"].to(self.device)
+        idx1 = [KnnIndex(pc1[b][m1[b]][:, :3]) for b in range(pc1.shape[0])] if bool(m1.all()) else None
+        idx2 = [KnnIndex(pc2[b][m2[b]][:, :3]) for b in range(pc2.shape[0])] if bool(m2.all()) else None
+        total = torch.zeros(1, device=self.device)
+        for pfw, pbw in zip(preds_fw, preds_bw):
+            total = total + selfsupervisedSlimSingleScaleLoss(
+                pc1=pc1, valid_mask_pc1=m1, pc2=pc2, valid_mask_pc2=m2, pred_fw=pfw, pred_bw=pbw,
+                moving_thresh_module=self.net.moving_dynamicness_threshold, loss_cfg=self.slim_cfg.losses.unsupervised,
+                model_cfg=self.slim_cfg.model, bev_extent=self.bev_extent, metrics_collector={},
+                knn_index_pc1=idx1, knn_index_pc2=idx2)
+        return total, preds_fw, preds_bw
+
+    def step(self, sample_t0, sample_t1):
+        self.model.train()
+        total, _, _ = self.loss(sample_t0, sample_t1)
+        self.optimizer.zero_grad(set_to_none=True)
+        total.backward()
+        self.optimizer.step()
+        self.lr_scheduler.step()
+        return total.detach()
