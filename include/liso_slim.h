@@ -57,7 +57,7 @@ int liso_corr_lookup_bwd_f32(const liso_corr_cfg* cfg, const float* fmap1, const
 typedef struct {
     float x_min, y_min;  /* grid origin */
     float cell;          /* cell edge length in metres (> 0) */
-    int nx, ny;          /* cells; reference points outside are clamped into the border cells (still exact) */
+    int nx, ny;          /* cells (nx*ny <= 2^20); reference points outside are clamped into the border cells (still exact) */
 } liso_knn_grid;
 
 size_t liso_knn_workspace_bytes(const liso_knn_grid* grid, int n_ref);
@@ -66,8 +66,13 @@ size_t liso_knn_workspace_bytes(const liso_knn_grid* grid, int n_ref);
 int liso_knn_build_f32(const liso_knn_grid* grid, const float* ref, int ref_stride, int n_ref, void* workspace,
                        size_t workspace_bytes, void* stream);
 
+/* max_rings < 0: search until proven exact.  max_rings >= 0: stop after that many rings and mark queries whose result
+ * is not yet proven with index -1 (nothing else written for them).  only_unresolved != 0: process only rows whose
+ * index is -1 (second pass on a coarser grid: a fine grid answers the dense near field in 1-2 rings, a coarse grid the
+ * few queries that land in empty space, so no query walks thousands of empty cells). */
 int liso_knn_query_f32(const liso_knn_grid* grid, const float* ref, int ref_stride, int n_ref, const void* workspace,
-                       const float* query, int query_stride, int n_query, int64_t* index, float* dist_sqr, void* stream);
+                       const float* query, int query_stride, int n_query, int64_t* index, float* dist_sqr, int max_rings,
+                       int only_unresolved, void* stream);
 
 #ifdef __cplusplus
 }

@@ -35,25 +35,48 @@ __global__ void knn_count_kernel(liso_knn_grid g, const float* __restrict__ ref,
     atomicAdd(&count[c], 1);
 }
 
-__global__ __launch_bounds__(1024) void knn_scan_kernel(const int* __restrict__ count, int cells, int* __restrict__ start) {
-    __shared__ int part[1024];
-    const int tid = threadIdx.x;
-    const int per = (cells + 1023) / 1024;
-    const int lo = tid * per, hi = lo + per < cells ? lo + per : cells;
-    int s = 0;
-    for (int i = lo; i < hi; i++) s += count[i];
-    part[tid] = s;
-    __syncthreads();
-    // Hillis-Steele inclusive scan over the 1024 partials
-    for (int off = 1; off < 1024; off <<= 1) {
-        const int v = tid >= off ? part[tid - off] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
+// exclusive scan of the cell counts in three short launches: per-1024-cell block scan, scan of the block totals, add
+__global__ __launch_bounds__(1024) void knn_scan_block_kernel(const int* __restrict__ count, int cells, int* __restrict__ start,
+                                                              int* __restrict__ block_tot) {
+    __shared__ int wsum[16];
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int v = i < cells ? count[i] : 0;
+    int incl = v;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
     }
-    int run = tid == 0 ? 0 : part[tid - 1];
-    for (int i = lo; i < hi; i++) { start[i] = run; run += count[i]; }
-    if (tid == 1023) start[cells] = part[1023];
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; w++) base += wsum[w];
+    if (i < cells) start[i] = base + incl - v;
+    if (threadIdx.x == 1023) block_tot[blockIdx.x] = base + incl;
+}
+
+__global__ __launch_bounds__(1024) void knn_scan_tot_kernel(int* __restrict__ block_tot, int nblocks) {
+    __shared__ int wsum[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int v = (int)threadIdx.x < nblocks ? block_tot[threadIdx.x] : 0;
+    int incl = v;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; w++) base += wsum[w];
+    if ((int)threadIdx.x < nblocks) block_tot[threadIdx.x] = base + incl - v;  // exclusive
+    if ((int)threadIdx.x == nblocks - 1) block_tot[nblocks] = base + incl;     // grand total
+}
+
+__global__ __launch_bounds__(1024) void knn_scan_add_kernel(int* __restrict__ start, int cells, const int* __restrict__ block_tot,
+                                                            int nblocks) {
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    if (i < cells) start[i] += block_tot[blockIdx.x];
+    if (i == 0) start[cells] = block_tot[nblocks];
 }
 
 __global__ void knn_fill_kernel(const float* __restrict__ ref, int stride, int n, const int* __restrict__ cell_of_pt,
@@ -66,57 +89,80 @@ __global__ void knn_fill_kernel(const float* __restrict__ ref, int stride, int n
                                 __int_as_float(i));
 }
 
-__global__ void knn_query_kernel(liso_knn_grid g, const int* __restrict__ start, const float4* __restrict__ bucketed,
-                                 int n_ref, const float* __restrict__ query, int qstride, int nq,
-                                 long long* __restrict__ index, float* __restrict__ dist_sqr) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nq) return;
-    const float qx = query[(size_t)i * qstride], qy = query[(size_t)i * qstride + 1], qz = query[(size_t)i * qstride + 2];
+// 16 lanes cooperate on one query: the cells of a ring are spread over the lanes (independent loads in flight instead
+// of one thread chasing start[c] -> points serially), then a 4-step butterfly picks the group's best (distance, index).
+constexpr int kGroup = 16;
+
+__device__ __forceinline__ void scan_cell(const int* __restrict__ start, const float4* __restrict__ bucketed, int c, float qx,
+                                          float qy, float qz, float& best, int& best_i) {
+    const int s = start[c], e = start[c + 1];
+    for (int k = s; k < e; k++) {
+        const float4 p = bucketed[k];
+        const float dx = p.x - qx, dy = p.y - qy, dz = p.z - qz;
+        const float d = dx * dx + dy * dy + dz * dz;
+        const int pi = __float_as_int(p.w);
+        if (d < best || (d == best && pi < best_i)) { best = d; best_i = pi; }
+    }
+}
+
+__global__ __launch_bounds__(256) void knn_query_kernel(liso_knn_grid g, const int* __restrict__ start,
+                                                        const float4* __restrict__ bucketed, int n_ref,
+                                                        const float* __restrict__ query, int qstride, int nq,
+                                                        long long* __restrict__ index, float* __restrict__ dist_sqr,
+                                                        int max_rings, int only_unresolved) {
+    const int gid = (blockIdx.x * blockDim.x + threadIdx.x) / kGroup;  // query handled by this 16-lane group
+    const int sub = threadIdx.x & (kGroup - 1);
+    if (gid >= nq) return;
+    if (only_unresolved && index[gid] >= 0) return;  // second (coarse-grid) pass: only rows the fine pass gave up on
+    const float qx = query[(size_t)gid * qstride], qy = query[(size_t)gid * qstride + 1], qz = query[(size_t)gid * qstride + 2];
     if (!(isfinite(qx) && isfinite(qy) && isfinite(qz)) || n_ref == 0) {
-        index[i] = 0;
-        if (dist_sqr) dist_sqr[i] = nanf("");
+        if (sub == 0) { index[gid] = 0; if (dist_sqr) dist_sqr[gid] = nanf(""); }
         return;
     }
     int cx, cy;
     cell_of(g, qx, qy, &cx, &cy);
-    // distance from the query to the edges of its (clamped) cell; a query outside the grid has a negative margin on that
-    // side, which only makes the stopping bound more conservative (still exact)
     const float ox = qx - (g.x_min + cx * g.cell), oy = qy - (g.y_min + cy * g.cell);
     const float margin = fminf(fminf(ox, g.cell - ox), fminf(oy, g.cell - oy));
     float best = INFINITY;
     int best_i = 0x7fffffff;
-    const int rmax = max(max(cx, g.nx - 1 - cx), max(cy, g.ny - 1 - cy));
+    int rmax = max(max(cx, g.nx - 1 - cx), max(cy, g.ny - 1 - cy));
+    bool resolved = true;
+    if (max_rings >= 0 && rmax > max_rings) { rmax = max_rings; resolved = false; }
     for (int r = 0; r <= rmax; r++) {
+        const int ncell = r == 0 ? 1 : 8 * r;
         const int x0 = cx - r, x1 = cx + r, y0 = cy - r, y1 = cy + r;
-        for (int x = max(x0, 0); x <= min(x1, g.nx - 1); x++) {
-            const bool edge_col = (x == x0 || x == x1);
-            // on the ring: the full column for the two edge columns, else only the two end cells
-            const int step = edge_col ? 1 : (y1 - y0 > 0 ? y1 - y0 : 1);
-            for (int y = y0; y <= y1; y += step) {
-                if (y < 0 || y >= g.ny) continue;
-                const int c = x * g.ny + y;
-                const int s = start[c], e = start[c + 1];
-                for (int k = s; k < e; k++) {
-                    const float4 p = bucketed[k];
-                    const float dx = p.x - qx, dy = p.y - qy, dz = p.z - qz;
-                    const float d = dx * dx + dy * dy + dz * dz;
-                    const int pi = __float_as_int(p.w);
-                    if (d < best || (d == best && pi < best_i)) { best = d; best_i = pi; }
-                }
+        for (int t = sub; t < ncell; t += kGroup) {
+            int x = cx, y = cy;
+            if (r > 0) {
+                const int side = t / (2 * r), k = t - side * 2 * r;
+                x = side == 0 ? x0 + k : (side == 1 ? x1 : (side == 2 ? x1 - k : x0));
+                y = side == 0 ? y0 : (side == 1 ? y0 + k : (side == 2 ? y1 : y1 - k));
             }
+            if (x >= 0 && x < g.nx && y >= 0 && y < g.ny) scan_cell(start, bucketed, x * g.ny + y, qx, qy, qz, best, best_i);
+        }
+        // group-wide best (ties -> smaller index)
+#pragma unroll
+        for (int o = 1; o < kGroup; o <<= 1) {
+            const float ob = __shfl_xor(best, o);
+            const int oi = __shfl_xor(best_i, o);
+            if (ob < best || (ob == best && oi < best_i)) { best = ob; best_i = oi; }
         }
         const float bound = r * g.cell + margin;  // every unvisited point is at least this far (xy distance)
-        if (bound > 0.f && best <= bound * bound) break;
+        if (bound > 0.f && best <= bound * bound) { resolved = true; break; }
+        if (r == rmax && rmax == max(max(cx, g.nx - 1 - cx), max(cy, g.ny - 1 - cy))) resolved = true;  // grid exhausted
     }
-    index[i] = best_i == 0x7fffffff ? 0 : best_i;
-    if (dist_sqr) dist_sqr[i] = best;
+    if (sub != 0) return;
+    if (!resolved) { index[gid] = -1; return; }  // left to the coarse-grid pass
+    index[gid] = best_i == 0x7fffffff ? 0 : best_i;
+    if (dist_sqr) dist_sqr[gid] = best;
 }
 
 inline int check_launch() { return hipGetLastError() == hipSuccess ? LISO_OK : LISO_ELAUNCH; }
 inline bool grid_ok(const liso_knn_grid* g) {
     return g && g->cell > 0.f && g->nx >= 1 && g->ny >= 1 && (long)g->nx * g->ny <= (1L << 20);
 }
-// workspace: count[cells] | cursor[cells] | start[cells+1] | cell_of_pt[n] | (pad to 16 B) bucketed[n] float4
+// workspace: count[cells] | cursor[cells] | start[cells+1] | block_tot[1026] | cell_of_pt[n] | (pad to 16 B) bucketed[n] float4
+constexpr int kTotSlots = 1026;
 inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
 
 }  // namespace
@@ -126,7 +172,7 @@ extern "C" {
 size_t liso_knn_workspace_bytes(const liso_knn_grid* grid, int n_ref) {
     if (!grid_ok(grid) || n_ref < 0) return 0;
     const size_t cells = (size_t)grid->nx * grid->ny;
-    return align16((3 * cells + 1 + (size_t)n_ref) * sizeof(int)) + (size_t)n_ref * sizeof(float4) + 16;
+    return align16((3 * cells + 1 + kTotSlots + (size_t)n_ref) * sizeof(int)) + (size_t)n_ref * sizeof(float4) + 16;
 }
 
 int liso_knn_build_f32(const liso_knn_grid* grid, const float* ref, int ref_stride, int n_ref, void* workspace,
@@ -138,26 +184,32 @@ int liso_knn_build_f32(const liso_knn_grid* grid, const float* ref, int ref_stri
     int* count = (int*)workspace;
     int* cursor = count + cells;
     int* start = cursor + cells;
-    int* cell_of_pt = start + cells + 1;
-    float4* bucketed = (float4*)((char*)workspace + align16((3 * (size_t)cells + 1 + (size_t)n_ref) * sizeof(int)));
+    int* block_tot = start + cells + 1;
+    int* cell_of_pt = block_tot + kTotSlots;
+    float4* bucketed = (float4*)((char*)workspace + align16((3 * (size_t)cells + 1 + kTotSlots + (size_t)n_ref) * sizeof(int)));
     if (hipMemsetAsync(count, 0, 2 * (size_t)cells * sizeof(int), st) != hipSuccess) return LISO_ELAUNCH;
     if (n_ref > 0) knn_count_kernel<<<(n_ref + 255) / 256, 256, 0, st>>>(*grid, ref, ref_stride, n_ref, count, cell_of_pt);
-    knn_scan_kernel<<<1, 1024, 0, st>>>(count, cells, start);
+    const int nsb = (cells + 1023) / 1024;
+    knn_scan_block_kernel<<<nsb, 1024, 0, st>>>(count, cells, start, block_tot);
+    knn_scan_tot_kernel<<<1, 1024, 0, st>>>(block_tot, nsb);
+    knn_scan_add_kernel<<<nsb, 1024, 0, st>>>(start, cells, block_tot, nsb);
     if (n_ref > 0) knn_fill_kernel<<<(n_ref + 255) / 256, 256, 0, st>>>(ref, ref_stride, n_ref, cell_of_pt, start, cursor, bucketed);
     return check_launch();
 }
 
 int liso_knn_query_f32(const liso_knn_grid* grid, const float* ref, int ref_stride, int n_ref, const void* workspace,
-                       const float* query, int query_stride, int n_query, int64_t* index, float* dist_sqr, void* stream) {
+                       const float* query, int query_stride, int n_query, int64_t* index, float* dist_sqr, int max_rings,
+                       int only_unresolved, void* stream) {
     (void)ref; (void)ref_stride;
     if (!grid_ok(grid) || n_ref < 0 || n_query < 0 || query_stride < 3 || !workspace) return LISO_EINVAL;
     if (n_query == 0) return LISO_OK;
     if (!query || !index) return LISO_EINVAL;
     const int cells = grid->nx * grid->ny;
     const int* start = (const int*)workspace + 2 * (size_t)cells;
-    const float4* bucketed = (const float4*)((const char*)workspace + align16((3 * (size_t)cells + 1 + (size_t)n_ref) * sizeof(int)));
-    knn_query_kernel<<<(n_query + 127) / 128, 128, 0, (hipStream_t)stream>>>(*grid, start, bucketed, n_ref, query, query_stride,
-                                                                            n_query, (long long*)index, dist_sqr);
+    const float4* bucketed = (const float4*)((const char*)workspace + align16((3 * (size_t)cells + 1 + kTotSlots + (size_t)n_ref) * sizeof(int)));
+    knn_query_kernel<<<(unsigned)(((long)n_query * kGroup + 255) / 256), 256, 0, (hipStream_t)stream>>>(*grid, start, bucketed, n_ref, query, query_stride,
+                                                                            n_query, (long long*)index, dist_sqr, max_rings,
+                                                                            only_unresolved);
     return check_launch();
 }
 

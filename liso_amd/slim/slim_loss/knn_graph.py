@@ -12,41 +12,64 @@ import torch
 from liso_amd import _lib as L
 
 
-class KnnIndex:
-    """Device-resident uniform-grid index over one reference cloud; reusable across queries."""
+class _Grid:
+    def __init__(self, ref, lo, hi, cell, max_cells_per_side):
+        ext = max(hi[0] - lo[0], hi[1] - lo[1], 1e-3)
+        cell = max(cell, ext / max_cells_per_side)
+        nx = max(1, int((hi[0] - lo[0]) / cell) + 1)
+        ny = max(1, int((hi[1] - lo[1]) / cell) + 1)
+        self.grid = L.KnnGrid(lo[0], lo[1], cell, nx, ny)
+        lib = L.lib()
+        n = ref.shape[0]
+        nbytes = lib.liso_knn_workspace_bytes(ctypes.byref(self.grid), n)
+        self.ws = torch.empty(nbytes, dtype=torch.uint8, device=ref.device)
+        L.check(lib.liso_knn_build_f32(ctypes.byref(self.grid), L.ptr(ref), ref.shape[1], n, L.ptr(self.ws), nbytes,
+                                       L.stream_ptr()), "knn_build")
 
-    def __init__(self, ref: torch.Tensor, cell: float = 0.5, max_cells_per_side: int = 1000):
+
+class KnnIndex:
+    """Device-resident two-level uniform-grid index over one reference cloud; reusable across queries.
+    fine grid (0.2 m cells): dense near field resolved in 1-2 rings; coarse grid (2 m cells): the few queries that land in
+    empty space.  Both passes are exact; the coarse pass only touches rows the fine pass could not prove."""
+
+    FINE_RINGS = 6
+
+    def __init__(self, ref: torch.Tensor, cell: float = 0.2, coarse_cell: float = 2.0, extent=None):
         assert ref.ndim == 2 and ref.shape[1] >= 3
         L.require_cuda(ref)
         self.ref = ref.detach().float().contiguous()
         n = self.ref.shape[0]
-        if n > 0:
-            lo = self.ref[:, :2].amin(dim=0)
-            hi = self.ref[:, :2].amax(dim=0)
-            lo_h, hi_h = lo.tolist(), hi.tolist()  # one small sync per index build (twice per training step)
+        if extent is not None:  # (x_min, y_min, x_max, y_max) known up front (the BEV range): no host sync at all;
+            lo, hi = [float(extent[0]), float(extent[1])], [float(extent[2]), float(extent[3])]  # outliers are clamped
+        elif n > 0:
+            lo = self.ref[:, :2].amin(dim=0).tolist()  # one small sync per index build
+            hi = self.ref[:, :2].amax(dim=0).tolist()
         else:
-            lo_h, hi_h = [0.0, 0.0], [1.0, 1.0]
-        ext = max(hi_h[0] - lo_h[0], hi_h[1] - lo_h[1], 1e-3)
-        cell = max(cell, ext / max_cells_per_side)
-        nx = max(1, int((hi_h[0] - lo_h[0]) / cell) + 1)
-        ny = max(1, int((hi_h[1] - lo_h[1]) / cell) + 1)
-        self.grid = L.KnnGrid(lo_h[0], lo_h[1], cell, nx, ny)
-        lib = L.lib()
-        nbytes = lib.liso_knn_workspace_bytes(ctypes.byref(self.grid), n)
-        self.ws = torch.empty(nbytes, dtype=torch.uint8, device=ref.device)
+            lo, hi = [0.0, 0.0], [1.0, 1.0]
         with torch.cuda.device(ref.device):
-            L.check(lib.liso_knn_build_f32(ctypes.byref(self.grid), L.ptr(self.ref), self.ref.shape[1], n, L.ptr(self.ws),
-                                           nbytes, L.stream_ptr()), "knn_build")
+            self.fine = _Grid(self.ref, lo, hi, cell, 1000)
+            self.coarse = _Grid(self.ref, lo, hi, coarse_cell, 1000)
 
     def query(self, x: torch.Tensor, return_dist_sqr=False):
         q = x.detach().float().contiguous()
         nq = q.shape[0]
         idx = torch.empty(nq, dtype=torch.int64, device=q.device)
         d2 = torch.empty(nq, dtype=torch.float32, device=q.device) if return_dist_sqr else None
+        lib = L.lib()
+        n = self.ref.shape[0]
+
+        def run():
+            rc = lib.liso_knn_query_f32(ctypes.byref(self.fine.grid), L.ptr(self.ref), self.ref.shape[1], n, L.ptr(self.fine.ws),
+                                        L.ptr(q), q.shape[1], nq, L.ptr(idx), L.ptr(d2) if d2 is not None else None,
+                                        self.FINE_RINGS, 0, L.stream_ptr())
+            if rc:
+                return rc
+            return lib.liso_knn_query_f32(ctypes.byref(self.coarse.grid), L.ptr(self.ref), self.ref.shape[1], n,
+                                          L.ptr(self.coarse.ws), L.ptr(q), q.shape[1], nq, L.ptr(idx),
+                                          L.ptr(d2) if d2 is not None else None, -1, 1, L.stream_ptr())
+
         with torch.cuda.device(q.device):
-            L.check(L.TIMER.launch("knn_query", lambda: L.lib().liso_knn_query_f32(
-                ctypes.byref(self.grid), L.ptr(self.ref), self.ref.shape[1], self.ref.shape[0], L.ptr(self.ws), L.ptr(q),
-                q.shape[1], nq, L.ptr(idx), L.ptr(d2) if d2 is not None else None, L.stream_ptr())), "knn_query")
+            L.check(L.TIMER.launch("knn_query", run), "knn_query")
         return (idx, d2) if return_dist_sqr else idx
 
 

@@ -31,7 +31,11 @@ def compute_batched_bev_static_aggregated_flow(pc, pointwise_voxel_coordinates_f
         m = pointwise_valid_mask[b]
         T, nep = weighted_pc_alignment(pc[b][m][..., :3], (pc[b][..., :3] + pw_flow[b])[m], pw_static[b][m],
                                        use_epsilon_on_weights=use_eps_for_weighted_pc_alignment)
-        flows.append(torch.einsum("ij,hwj->hwi", T - torch.eye(4, dtype=torch.float64, device=T.device), grid_h)[..., 0:2].float())
+        # (T - I) applied to every cell centre as fp64 broadcast multiply-adds; the reference's einsum (:88-99) is a
+        # [4x4]x[4xHW] DGEMM that rocBLAS runs with a 128x128 tile: 28 ms per call at 512^2 (measured), 12 calls per step
+        D = T - torch.eye(4, dtype=torch.float64, device=T.device)
+        flows.append((D[:2, 0] * grid_h[..., 0:1] + D[:2, 1] * grid_h[..., 1:2] + D[:2, 2] * grid_h[..., 2:3]
+                      + D[:2, 3] * grid_h[..., 3:4]).float())
         Ts.append(T)
         neps.append(nep)
     return torch.stack(flows, dim=0), torch.stack(Ts, dim=0), torch.stack(neps, dim=0)

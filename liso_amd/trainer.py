@@ -101,8 +101,9 @@ class SlimTrainer:
         preds_fw, preds_bw = self.model(sample_t0, sample_t1, None)
         pc1, m1 = sample_t0["pcl_ta"]["pcl"].to(self.device), sample_t0["pcl_ta"]["pcl_is_valid"].to(self.device)
         pc2, m2 = sample_t1["pcl_ta"]["pcl"].to(self.device), sample_t1["pcl_ta"]["pcl_is_valid"].to(self.device)
-        idx1 = [KnnIndex(pc1[b][m1[b]][:, :3]) for b in range(pc1.shape[0])] if bool(m1.all()) else None
-        idx2 = [KnnIndex(pc2[b][m2[b]][:, :3]) for b in range(pc2.shape[0])] if bool(m2.all()) else None
+        ext = [float(v) for v in self.bev_extent]
+        idx1 = [KnnIndex(pc1[b][m1[b]][:, :3], extent=ext) for b in range(pc1.shape[0])] if bool(m1.all()) else None
+        idx2 = [KnnIndex(pc2[b][m2[b]][:, :3], extent=ext) for b in range(pc2.shape[0])] if bool(m2.all()) else None
         total = torch.zeros(1, device=self.device)
         for pfw, pbw in zip(preds_fw, preds_bw):
             total = total + selfsupervisedSlimSingleScaleLoss(
