@@ -4,11 +4,15 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A "step" = one CenterPoint-pillar detector TRAIN step (voxelise -> fused PFN/scatter -> BEV backbone -> CenterHead ->
-decode -> loss -> backward -> [RCCL gradient all-reduce] -> AdamW -> OneCycleLR) over one batch of synthetic
-KITTI-shaped 120k-point clouds already resident in HBM (BASELINE.json configs[2]; see DESIGN.md "Measurement" for
-why this is the N=1 workload of this round).  Weak scaling: per-GPU batch fixed, samples sharded across ranks, the
-only collective is the gradient all-reduce.  Rank 0 prints ONE JSON line.
+Default workload (`--workload slim`, BASELINE.json configs[1], the configuration the metric is quoted on): a "step" =
+one SLIM self-supervised TRAIN step (pillar-encode both clouds -> RAFT fwd+bw, 6 iterations each -> flow/class
+decoder with weighted Kabsch -> kNN loss over all 6 iterations -> backward -> [RCCL gradient all-reduce] -> RMSprop)
+on one pair of synthetic KITTI-shaped 120k-point clouds already resident in HBM, B=1 per GPU as in the reference's
+`slim_RAFT batch_size_one`; a step consumes 2 frames.
+`--workload detector` (configs[2]): one CenterPoint-pillar detector train step (voxelise -> fused PFN/scatter -> BEV
+backbone -> CenterHead -> decode -> loss -> backward -> [all-reduce] -> AdamW -> OneCycleLR), B=4 clouds per GPU.
+Weak scaling: per-GPU work fixed, samples sharded across ranks by seed, the only collective is the gradient
+all-reduce.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -34,29 +38,58 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU)
+    ap.add_argument("--workload", default="slim", choices=["slim", "detector"])
+    ap.add_argument("--batch", type=int, default=None, help="detector workload: clouds per GPU (default 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
 
 def pfn_algorithmic_bytes(batch, n_points, grid, out_bytes):
     """SURVEY.md 8(d), pillar path: read the points once (N*C*4 B) + write the dense canvas once (64*G^2*s B) +
-    occupancy (G^2*4 B), per sample.  The launch timed here is the fused PFN+scatter kernel; the canvas zero-fill
-    that precedes it is part of the same algorithmic write and is NOT counted twice."""
+    occupancy (G^2*4 B), per sample."""
     return batch * (n_points * 4 * 4 + 64 * grid * grid * out_bytes + grid * grid * 4)
 
 
-def cpu_baseline(trainer, pcls, targets):
+def slim_algorithmic_bytes(batch, n_points, grid, levels=4, radius=3):
+    """SURVEY.md 8(d), SLIM rows, per launch:
+    corr lookup (fwd, and its adjoint bwd): levels * hw * (2r+1)^2 bilinear reads of 4 taps * 4 B + the
+      [hw, levels*(2r+1)^2] fp32 output, hw = (G/8)^2;
+    1-NN query: (N_q + N_ref) * 12 B in + N_q * 8 B out."""
+    hw = (grid // 8) ** 2
+    w2 = (2 * radius + 1) ** 2
+    lookup = batch * (levels * hw * w2 * 4 * 4 + hw * levels * w2 * 4)
+    return {"corr_lookup_fwd": lookup, "corr_lookup_bwd": lookup, "knn_query": 2 * n_points * 12 + n_points * 8}
+
+
+SLIM_KERNELS = {
+    "corr_lookup_fwd": "corr_lookup_fwd_kernel (on-the-fly 4-level correlation + bilinear lookup)",
+    "corr_lookup_bwd": "corr_lookup_bwd_kernel (adjoint of the lookup into fmap1 / pooled fmap2 gradients)",
+    "knn_query": "knn_query_kernel (exact 1-NN, two-level bucket grid, 16 lanes per query)",
+}
+
+
+def cpu_baseline_detector(trainer, pcls, targets):
     """The oracle port of the same train step (fwd+bwd) on the host cores, ONE frame (bounded sample)."""
     from oracle.train_step import timed_detector_step
 
     sd = {k: v.detach().float().cpu() for k, v in trainer.net.state_dict().items()}
-    cores = min(os.cpu_count() or 1, 32)
-    torch.set_num_threads(cores)
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
     t1 = {k: v[:1].cpu() for k, v in targets.items()}
     secs, _ = timed_detector_step(sd, [pcls[0].cpu()], t1, GRID, BEV_RANGE)
     return {"value": 1.0 / secs, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"1 frame ({N_POINTS} pts, {GRID}x{GRID} BEV) fwd+bwd, fp32, torch-CPU oracle, {secs:.2f} s"}
+
+
+def cpu_baseline_slim(cfg, trainer, s0, s1):
+    """The CPU port of the same SLIM step (oracle/slim_step.py) on the host cores: ONE pair = 2 frames."""
+    from oracle.slim_step import timed_slim_step
+
+    sd = {k: v.detach().cpu() for k, v in trainer.net.state_dict().items()}
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    secs, _ = timed_slim_step(cfg, sd, s0, s1)
+    return {"value": 2.0 / secs, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 pair = 2 frames ({N_POINTS} pts each, {GRID}x{GRID} BEV), 1 SLIM train step fwd+bwd+RMSprop, "
+                      f"fp32, torch-CPU port with explicit correlation volume + cKDTree, {secs:.2f} s"}
 
 
 def main():
@@ -72,29 +105,46 @@ def main():
         dist.init_process_group(backend="nccl", device_id=dev)
 
     from liso_amd import _lib as L
-    from liso_amd.datasets.synthetic import detector_batch
-    from liso_amd.trainer import DetectorTrainer
-    from liso_amd.utils.config import default_cfg
+    from liso_amd.utils.config import apply_slim_simple_knn_training, default_cfg
 
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     cfg = default_cfg(grid=GRID, bev_range_m=BEV_RANGE)
     torch.manual_seed(0)  # identical initial weights on every rank (DDP also broadcasts them)
-    trainer = DetectorTrainer(cfg, dev, compute_dtype=dtype, total_steps=args.steps + args.warmup + 8)
-    # each rank owns different samples (DistributedSampler-style sharding by seed), resident in HBM
-    pcls, targets = detector_batch(seed=1 + rank, batch=args.batch, device=dev, n_points=N_POINTS, grid=GRID,
-                                   bev_range_m=BEV_RANGE)
+    if args.workload == "slim":
+        from liso_amd.datasets.synthetic import slim_pair
+        from liso_amd.trainer import SlimTrainer
+
+        args.dtype = "fp32"  # the reference trains SLIM in fp32 (no autocast in slim/experiment.py)
+        batch = 1  # one pair per GPU, as in the reference's `slim_RAFT batch_size_one`
+        cfg = apply_slim_simple_knn_training(cfg)
+        trainer = SlimTrainer(cfg, dev)
+        # each rank owns different pairs (DistributedSampler-style sharding by seed), resident in HBM
+        s0, s1 = slim_pair(2 + rank, dev, n_points=N_POINTS, grid=GRID, bev_range_m=BEV_RANGE)
+        step = lambda: trainer.step(s0, s1)  # noqa: E731
+        frames_per_step, timed = 2 * batch, list(SLIM_KERNELS)
+    else:
+        from liso_amd.datasets.synthetic import detector_batch
+        from liso_amd.trainer import DetectorTrainer
+
+        batch = args.batch or BATCH_PER_GPU
+        dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+        trainer = DetectorTrainer(cfg, dev, compute_dtype=dtype, total_steps=args.steps + args.warmup + 8)
+        pcls, targets = detector_batch(seed=1 + rank, batch=batch, device=dev, n_points=N_POINTS, grid=GRID,
+                                       bev_range_m=BEV_RANGE)
+        step = lambda: trainer.step(pcls, targets)  # noqa: E731
+        frames_per_step, timed = batch, ["pfn_forward_scatter"]
 
     for _ in range(args.warmup):
-        trainer.step(pcls, targets)
+        step()
 
-    L.TIMER.enable("pfn_forward_scatter")
+    for k in timed:
+        L.TIMER.enable(k)
     L.TIMER.reset()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = trainer.step(pcls, targets)
+        loss = step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -106,15 +156,24 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
-        frames = args.batch * world * args.steps
-        durs = L.TIMER.durations_ms("pfn_forward_scatter")
-        avg_ms = sum(durs) / max(len(durs), 1)
-        out_bytes = 2 if dtype == torch.bfloat16 else 4
-        alg = pfn_algorithmic_bytes(args.batch, N_POINTS, GRID, out_bytes)
+        durs = {k: L.TIMER.durations_ms(k) for k in timed}
+        if args.workload == "slim":
+            alg_all = slim_algorithmic_bytes(batch, N_POINTS, GRID)
+            key = max(durs, key=lambda k: sum(durs[k]))  # the hand-written kernel with the largest share of the step
+            alg, kname = alg_all[key], SLIM_KERNELS[key]
+            workload = ("SLIM scene-flow train step (BASELINE configs[1]): two 120k-pt KITTI-shaped clouds, 512x512 BEV "
+                        "pillars, RAFT 6 iterations fwd+bw flow, kNN loss, fwd+bwd+RMSprop")
+        else:
+            key = "pfn_forward_scatter"
+            alg = pfn_algorithmic_bytes(batch, N_POINTS, GRID, 2 if args.dtype == "bf16" else 4)
+            kname = "pfn_forward_dense_kernel (fused decorate+Linear+BN+ReLU+max+scatter)"
+            workload = ("CenterPoint-pillar detector train step (BASELINE configs[2]): 120k-pt KITTI-shaped clouds, "
+                        "512x512 BEV pillars, fwd+bwd+AdamW")
+        avg_ms = sum(durs[key]) / max(len(durs[key]), 1)
         achieved = alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         line = {
             "metric": "LISO train-step frames/sec (120k-pt clouds)",
-            "value": frames / elapsed,
+            "value": frames_per_step * world * args.steps / elapsed,
             "unit": "frames/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -125,17 +184,19 @@ def main():
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic",
-            "config": {"workload": "CenterPoint-pillar detector train step (BASELINE configs[2]): 120k-pt KITTI-shaped "
-                                   "clouds, 512x512 BEV pillars, fwd+bwd+AdamW",
-                       "points_per_cloud": N_POINTS, "bev_grid": GRID, "batch_per_gpu": args.batch,
-                       "global_batch": args.batch * world, "parallelism": f"dp{world}"},
+            "config": {"workload": workload, "points_per_cloud": N_POINTS, "bev_grid": GRID, "batch_per_gpu": batch,
+                       "frames_per_step_per_gpu": frames_per_step, "parallelism": f"dp{world}"},
             "final_loss": float(loss),
-            "roofline": {"kernel": "pfn_forward_kernel (fused decorate+Linear+BN+ReLU+max+scatter)", "bound": "hbm",
-                         "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": None, "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg},
+            "roofline": {"kernel": kname, "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                         "frac": achieved / 8000.0, "traffic": None, "avg_launch_ms": avg_ms,
+                         "launches_per_step": len(durs[key]) / max(args.steps, 1), "algorithmic_bytes_per_launch": alg,
+                         "timed_kernels_ms_per_step": {k: sum(v) / max(args.steps, 1) for k, v in durs.items()}},
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(trainer, pcls, targets)
+            if args.workload == "slim":
+                line["cpu_baseline"] = cpu_baseline_slim(cfg, trainer, s0, s1)
+            else:
+                line["cpu_baseline"] = cpu_baseline_detector(trainer, pcls, targets)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -35,13 +35,16 @@ typedef struct {
 int liso_corr_lookup_fwd_f32(const liso_corr_cfg* cfg, const float* fmap1, const float* const* fmap2_levels,
                              const float* coords, float* out, void* stream);
 
-/* grad_out has the layout of `out`.  grad_fmap1 must have room for [levels+1, B, h*w, D] floats: slab 0 receives the
- * gradient, slabs 1..levels are per-level scratch (summed in a fixed order).  grad_fmap2_levels[i] are ACCUMULATED
- * into (the caller zero-fills them) with float atomics.  coords receive no gradient (detached per iteration,
- * raft_mod.py:189). */
-int liso_corr_lookup_bwd_f32(const liso_corr_cfg* cfg, const float* fmap1, const float* const* fmap2_levels,
-                             const float* coords, const float* grad_out, float* grad_fmap1,
-                             float* const* grad_fmap2_levels, void* stream);
+/* Backward, step 1 of 2.  grad_out has the layout of `out`.  dvol_levels[i] is a dense fp32 matrix
+ * [B, h*w, H_i*W_i] (zero-filled by the caller before the first call): the gradient with respect to the pooled
+ * correlation volume of level i, into which this call ADDS the adjoint of its bilinear 7x7 windows (<= 64 entries per
+ * row and level).  Every entry is owned by one lane, so the update is a plain read-modify-write: no atomics, bit
+ * reproducible; calls for the RAFT iterations of one direction accumulate into the same matrices (they share fmap1 and
+ * fmap2).  Step 2 is two plain GEMMs per level, run once per direction by the host:
+ *     grad_fmap1 = sum_i dvol_i @ fmap2_i        grad_fmap2_i = dvol_i^T @ fmap1
+ * (liso_amd/slim/model/raft_code/corr.py).  coords receive no gradient (detached per iteration, raft_mod.py:189). */
+int liso_corr_lookup_bwd_dvol_f32(const liso_corr_cfg* cfg, const float* coords, const float* grad_out,
+                                  float* const* dvol_levels, void* stream);
 
 /* ---- exact 1-nearest-neighbour search (SLIM self-supervised loss) -------------------------------------------------
  * Replaces knn_graph(x, index=ref, k=1, loop=True) (liso/slim/slim_loss/knn_graph.py:10-98), which copies both clouds

@@ -98,7 +98,7 @@ SIGNATURES = {
     "liso_fit_box_z_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _vp, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
     # include/liso_slim.h
     "liso_corr_lookup_fwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
-    "liso_corr_lookup_bwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "liso_corr_lookup_bwd_dvol_f32": (_i, [_vp, _vp, _vp, _vp, _vp]),
     # include/liso_bn.h
     "liso_bn_workspace_bytes": (_sz, [_i]),
     "liso_bn_relu_fwd": (_i, [_vp, _i, ctypes.c_long, _i, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _vp, _vp, _vp, _sz, _vp]),

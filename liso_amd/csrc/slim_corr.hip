@@ -112,13 +112,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void corr_lookup_fwd_kernel(li
     }
 }
 
-template <int VEC>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void corr_lookup_bwd_kernel(liso_corr_cfg c,
-                                                                              const float* __restrict__ fmap1,
-                                                                              LevelPtrs lp, const float* __restrict__ coords,
-                                                                              const float* __restrict__ grad_out,
-                                                                              float* __restrict__ grad_f1_lvl) {
-    __shared__ float G[kWavesPerBlock][64];
+// Backward of the lookup, step 1: the adjoint of (bilinear weights x 7x7 window) for one (query pixel, level) is an 8x8
+// patch of coefficients gP[u][v] on the integer grid of that level.  They are ADDED into the dense per-level matrix
+//     dvol_i[b, p, y*W_i + x]    ( == d loss / d (pooled correlation volume of level i) )
+// One lane per patch entry; each (p, x, y) is owned by exactly one lane of one launch, so a plain read-modify-write is
+// race free and the 6 RAFT iterations of one direction accumulate into the same matrices launch after launch.
+// Step 2 (host, once per direction): grad_fmap1 = sum_i dvol_i @ f2_i, grad_f2_i = dvol_i^T @ fmap1 -- plain GEMMs.
+__global__ __launch_bounds__(64 * kWavesPerBlock) void corr_lookup_bwd_dvol_kernel(liso_corr_cfg c, const float* __restrict__ coords,
+                                                                                   const float* __restrict__ grad_out,
+                                                                                   LevelPtrs lp) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int hw = c.h * c.w;
     const long item = (long)blockIdx.x * kWavesPerBlock + wave;
@@ -128,62 +130,19 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void corr_lookup_bwd_kernel(li
     const int pix = (int)((item / c.levels) % hw);
     const int b = (int)(item / ((long)c.levels * hw));
     const Patch pt = patch_of(c, coords, b, pix, lvl);
-    const int D = c.dim, W7 = 2 * c.radius + 1, C = c.levels * W7 * W7;
-    // gP[u][v] = sum of the (<= 4) window outputs that read P[u][v], weighted by their bilinear factor
-    {
-        const int u = lane & 7, v = lane >> 3;
-        const float* go = grad_out + ((size_t)b * hw + pix) * C + lvl * W7 * W7;
-        const float inv = 1.0f / sqrtf((float)D);
-        float s = 0.f;
-        if (u < W7 && v < W7) s += (1.f - pt.fx) * (1.f - pt.fy) * go[u * W7 + v];
-        if (u >= 1 && u - 1 < W7 && v < W7) s += pt.fx * (1.f - pt.fy) * go[(u - 1) * W7 + v];
-        if (u < W7 && v >= 1 && v - 1 < W7) s += (1.f - pt.fx) * pt.fy * go[u * W7 + v - 1];
-        if (u >= 1 && u - 1 < W7 && v >= 1 && v - 1 < W7) s += pt.fx * pt.fy * go[(u - 1) * W7 + v - 1];
-        G[wave][lane] = s * inv;
-    }
-    __builtin_amdgcn_wave_barrier();
-    const int g = lane & 31, half = lane >> 5;
-    float4 f1[VEC], gf1[VEC];
-#pragma unroll
-    for (int k = 0; k < VEC; k++) {
-        f1[k] = *reinterpret_cast<const float4*>(fmap1 + ((size_t)b * hw + pix) * D + (k * 32 + g) * 4);
-        gf1[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    const float* f2 = lp.f2[lvl] + (size_t)b * pt.H * pt.W * D;
-    float* g2 = lp.g2[lvl] + (size_t)b * pt.H * pt.W * D;
-    for (int t = 0; t < 32; t++) {
-        const int q = 2 * t + half;
-        const int x = pt.x0 + (q & 7), y = pt.y0 + (q >> 3);
-        const float gp = G[wave][q];
-        if (x >= 0 && x < pt.W && y >= 0 && y < pt.H && gp != 0.f) {
-            const size_t off = ((size_t)y * pt.W + x) * D;
-#pragma unroll
-            for (int k = 0; k < VEC; k++) {
-                const float4 v = *reinterpret_cast<const float4*>(f2 + off + (k * 32 + g) * 4);
-                gf1[k].x += gp * v.x; gf1[k].y += gp * v.y; gf1[k].z += gp * v.z; gf1[k].w += gp * v.w;
-                float* dst = g2 + off + (k * 32 + g) * 4;
-                atomicAdd(dst + 0, gp * f1[k].x); atomicAdd(dst + 1, gp * f1[k].y);
-                atomicAdd(dst + 2, gp * f1[k].z); atomicAdd(dst + 3, gp * f1[k].w);
-            }
-        }
-    }
-    // the two half-waves covered different patch pixels: add them, then one row write per (pixel, level)
-#pragma unroll
-    for (int k = 0; k < VEC; k++) {
-        gf1[k].x += __shfl_xor(gf1[k].x, 32); gf1[k].y += __shfl_xor(gf1[k].y, 32);
-        gf1[k].z += __shfl_xor(gf1[k].z, 32); gf1[k].w += __shfl_xor(gf1[k].w, 32);
-        if (half == 0)
-            *reinterpret_cast<float4*>(grad_f1_lvl + (((size_t)lvl * c.batch + b) * hw + pix) * D + (k * 32 + g) * 4) = gf1[k];
-    }
-}
-
-// grad_fmap1 = sum over levels of the per-level partials (fixed order -> reproducible)
-__global__ void sum_levels_kernel(const float* __restrict__ part, size_t n, int levels, float* __restrict__ out) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    const int W7 = 2 * c.radius + 1, C = c.levels * W7 * W7;
+    const int u = lane & 7, v = lane >> 3;
+    const int x = pt.x0 + u, y = pt.y0 + v;
+    if (x < 0 || x >= pt.W || y < 0 || y >= pt.H) return;  // zeros padding of grid_sample: no gradient outside
+    const float* go = grad_out + ((size_t)b * hw + pix) * C + lvl * W7 * W7;
     float s = 0.f;
-    for (int l = 0; l < levels; l++) s += part[(size_t)l * n + i];
-    out[i] = s;
+    if (u < W7 && v < W7) s += (1.f - pt.fx) * (1.f - pt.fy) * go[u * W7 + v];
+    if (u >= 1 && u - 1 < W7 && v < W7) s += pt.fx * (1.f - pt.fy) * go[(u - 1) * W7 + v];
+    if (u < W7 && v >= 1 && v - 1 < W7) s += (1.f - pt.fx) * pt.fy * go[u * W7 + v - 1];
+    if (u >= 1 && u - 1 < W7 && v >= 1 && v - 1 < W7) s += pt.fx * pt.fy * go[(u - 1) * W7 + v - 1];
+    if (s == 0.f) return;
+    float* dst = lp.g2[lvl] + ((size_t)b * hw + pix) * ((size_t)pt.H * pt.W) + (size_t)y * pt.W + x;
+    *dst += s * (1.0f / sqrtf((float)c.dim));
 }
 
 inline int check_launch() { return hipGetLastError() == hipSuccess ? LISO_OK : LISO_ELAUNCH; }
@@ -216,29 +175,17 @@ int liso_corr_lookup_fwd_f32(const liso_corr_cfg* cfg, const float* fmap1, const
     return check_launch();
 }
 
-int liso_corr_lookup_bwd_f32(const liso_corr_cfg* cfg, const float* fmap1, const float* const* fmap2_levels,
-                             const float* coords, const float* grad_out, float* grad_fmap1,
-                             float* const* grad_fmap2_levels, void* stream) {
-    if (!cfg_ok(cfg) || !fmap1 || !fmap2_levels || !coords || !grad_out || !grad_fmap1 || !grad_fmap2_levels)
-        return LISO_EINVAL;
+int liso_corr_lookup_bwd_dvol_f32(const liso_corr_cfg* cfg, const float* coords, const float* grad_out,
+                                  float* const* dvol_levels, void* stream) {
+    if (!cfg_ok(cfg) || !coords || !grad_out || !dvol_levels) return LISO_EINVAL;
     LevelPtrs lp = {};
     for (int i = 0; i < cfg->levels; i++) {
-        if (!fmap2_levels[i] || !grad_fmap2_levels[i]) return LISO_EINVAL;
-        lp.f2[i] = fmap2_levels[i];
-        lp.g2[i] = grad_fmap2_levels[i];
+        if (!dvol_levels[i]) return LISO_EINVAL;
+        lp.g2[i] = dvol_levels[i];
     }
-    // per-level partials of grad_fmap1 live in the tail of grad_fmap2_levels? no: the caller passes grad_fmap1 with
-    // room for `levels` slabs ([levels+1, B, hw, D]); slab 0 receives the sum.
-    const size_t n = (size_t)cfg->batch * cfg->h * cfg->w * cfg->dim;
-    float* part = grad_fmap1 + n;
     const long total = (long)cfg->batch * cfg->h * cfg->w * cfg->levels;
     const unsigned grid = (unsigned)((total + kWavesPerBlock - 1) / kWavesPerBlock);
-    hipStream_t st = (hipStream_t)stream;
-    if (cfg->dim == 128)
-        corr_lookup_bwd_kernel<1><<<grid, 64 * kWavesPerBlock, 0, st>>>(*cfg, fmap1, lp, coords, grad_out, part);
-    else
-        corr_lookup_bwd_kernel<2><<<grid, 64 * kWavesPerBlock, 0, st>>>(*cfg, fmap1, lp, coords, grad_out, part);
-    sum_levels_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(part, n, cfg->levels, grad_fmap1);
+    corr_lookup_bwd_dvol_kernel<<<grid, 64 * kWavesPerBlock, 0, (hipStream_t)stream>>>(*cfg, coords, grad_out, lp);
     return check_launch();
 }
 

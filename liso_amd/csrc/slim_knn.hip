@@ -4,7 +4,7 @@
 //   knn_scan     one 1024-thread block: exclusive scan of the cell counts (<= 1M cells)
 //   knn_fill     one thread per reference point: position = start[cell] + atomicAdd(cursor[cell]); writes the point
 //                (x, y, z, original index) into the bucketed array -> queries read 16 contiguous bytes per candidate
-//   knn_query    one thread per query: ring 0, 1, 2, ... of cells around the query's cell; after ring r every
+//   knn_query    16 lanes per query: ring 0, 1, 2, ... of cells around the query's cell; after ring r every
 //                unvisited point is at least r*cell + (distance to the own cell's nearest edge) away, so the search
 //                stops as soon as best <= that bound (exact), or when the rings cover the whole grid.
 // LiDAR clouds are thin in z, so a 2-D grid with the full 3-D distance test is both exact and compact.
@@ -89,21 +89,11 @@ __global__ void knn_fill_kernel(const float* __restrict__ ref, int stride, int n
                                 __int_as_float(i));
 }
 
-// 16 lanes cooperate on one query: the cells of a ring are spread over the lanes (independent loads in flight instead
-// of one thread chasing start[c] -> points serially), then a 4-step butterfly picks the group's best (distance, index).
+// 16 lanes cooperate on one query: each lane fetches the [start, end) range of one cell of the ring (independent loads
+// in flight), then the group walks every non-empty range together, 16 consecutive float4 per step (256 coalesced
+// bytes) -- vertical structures put hundreds of points into one xy cell, so points, not cells, are the unit of work.
+// A 4-step butterfly picks the group's best (distance, index) once per ring.
 constexpr int kGroup = 16;
-
-__device__ __forceinline__ void scan_cell(const int* __restrict__ start, const float4* __restrict__ bucketed, int c, float qx,
-                                          float qy, float qz, float& best, int& best_i) {
-    const int s = start[c], e = start[c + 1];
-    for (int k = s; k < e; k++) {
-        const float4 p = bucketed[k];
-        const float dx = p.x - qx, dy = p.y - qy, dz = p.z - qz;
-        const float d = dx * dx + dy * dy + dz * dz;
-        const int pi = __float_as_int(p.w);
-        if (d < best || (d == best && pi < best_i)) { best = d; best_i = pi; }
-    }
-}
 
 __global__ __launch_bounds__(256) void knn_query_kernel(liso_knn_grid g, const int* __restrict__ start,
                                                         const float4* __restrict__ bucketed, int n_ref,
@@ -112,6 +102,7 @@ __global__ __launch_bounds__(256) void knn_query_kernel(liso_knn_grid g, const i
                                                         int max_rings, int only_unresolved) {
     const int gid = (blockIdx.x * blockDim.x + threadIdx.x) / kGroup;  // query handled by this 16-lane group
     const int sub = threadIdx.x & (kGroup - 1);
+    const int group_shift = (threadIdx.x & 63) & ~(kGroup - 1);  // first lane of this group inside the wavefront
     if (gid >= nq) return;
     if (only_unresolved && index[gid] >= 0) return;  // second (coarse-grid) pass: only rows the fine pass gave up on
     const float qx = query[(size_t)gid * qstride], qy = query[(size_t)gid * qstride + 1], qz = query[(size_t)gid * qstride + 2];
@@ -131,14 +122,31 @@ __global__ __launch_bounds__(256) void knn_query_kernel(liso_knn_grid g, const i
     for (int r = 0; r <= rmax; r++) {
         const int ncell = r == 0 ? 1 : 8 * r;
         const int x0 = cx - r, x1 = cx + r, y0 = cy - r, y1 = cy + r;
-        for (int t = sub; t < ncell; t += kGroup) {
-            int x = cx, y = cy;
-            if (r > 0) {
-                const int side = t / (2 * r), k = t - side * 2 * r;
-                x = side == 0 ? x0 + k : (side == 1 ? x1 : (side == 2 ? x1 - k : x0));
-                y = side == 0 ? y0 : (side == 1 ? y0 + k : (side == 2 ? y1 : y1 - k));
+        for (int t0 = 0; t0 < ncell; t0 += kGroup) {
+            const int t = t0 + sub;
+            int s = 0, e = 0;
+            if (t < ncell) {
+                int x = cx, y = cy;
+                if (r > 0) {
+                    const int side = t / (2 * r), k = t - side * 2 * r;
+                    x = side == 0 ? x0 + k : (side == 1 ? x1 : (side == 2 ? x1 - k : x0));
+                    y = side == 0 ? y0 : (side == 1 ? y0 + k : (side == 2 ? y1 : y1 - k));
+                }
+                if (x >= 0 && x < g.nx && y >= 0 && y < g.ny) { s = start[x * g.ny + y]; e = start[x * g.ny + y + 1]; }
             }
-            if (x >= 0 && x < g.nx && y >= 0 && y < g.ny) scan_cell(start, bucketed, x * g.ny + y, qx, qy, qz, best, best_i);
+            unsigned nonempty = (unsigned)(__ballot(e > s) >> group_shift) & 0xffffu;
+            while (nonempty) {
+                const int j = __ffs(nonempty) - 1;
+                nonempty &= nonempty - 1;
+                const int sj = __shfl(s, j, kGroup), ej = __shfl(e, j, kGroup);
+                for (int k = sj + sub; k < ej; k += kGroup) {
+                    const float4 p = bucketed[k];
+                    const float dx = p.x - qx, dy = p.y - qy, dz = p.z - qz;
+                    const float d = dx * dx + dy * dy + dz * dz;
+                    const int pi = __float_as_int(p.w);
+                    if (d < best || (d == best && pi < best_i)) { best = d; best_i = pi; }
+                }
+            }
         }
         // group-wide best (ties -> smaller index)
 #pragma unroll

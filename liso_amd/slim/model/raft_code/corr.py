@@ -4,7 +4,9 @@ __call__ signature, same output [B, L*(2r+1)^2, h, w] fp32 and channel order).
 The reference builds the all-pairs volume (67 MB at 512^2 BEV, 1.07 GB at 1024^2) plus three pooled copies and calls
 grid_sample four times per RAFT iteration.  Correlation, average pooling and bilinear sampling are linear in fmap2,
 so the same numbers are obtained from the pooled *feature maps* (2.8 MB, L2 resident) by the on-the-fly gfx950
-kernel of include/liso_slim.h; nothing of size (hw)^2 is ever stored, forward or backward.
+kernel of include/liso_slim.h: the forward never stores anything of size (hw)^2.  The backward accumulates the window
+gradients of all RAFT iterations into ONE dense volume-gradient per level (no float atomics, reproducible) and turns it
+into feature gradients with two GEMMs per level, once per CorrBlock instead of once per iteration.
 """
 import ctypes
 
@@ -18,9 +20,43 @@ def _ptr_array(tensors):
     return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
 
+class _VolumeGradState:
+    """d loss / d (pooled correlation volumes) of one CorrBlock, accumulated over all lookups that used it"""
+
+    def __init__(self):
+        self.dvol = None
+
+
+class _CorrFeatures(torch.autograd.Function):
+    """Ties fmap1 / pooled fmap2 into the graph through a 1-element token.  Its backward runs exactly once, after the
+    backward of every lookup of this CorrBlock has added its window gradients to `state.dvol` (autograd's dependency
+    count on the token guarantees the order), and turns them into feature gradients with two GEMMs per level."""
+
+    @staticmethod
+    def forward(ctx, state, fmap1, *levels):
+        ctx.state = state
+        ctx.save_for_backward(fmap1, *levels)
+        return fmap1.new_zeros(1)
+
+    @staticmethod
+    def backward(ctx, _grad_token):
+        fmap1, *levels = ctx.saved_tensors
+        dvol, ctx.state.dvol = ctx.state.dvol, None
+        if dvol is None:
+            return (None, torch.zeros_like(fmap1)) + tuple(torch.zeros_like(l) for l in levels)
+        B, hw, D = fmap1.shape
+        g1 = None
+        g2 = []
+        for dv, f2 in zip(dvol, levels):
+            f2m = f2.reshape(B, -1, D)
+            g1 = torch.bmm(dv, f2m) if g1 is None else torch.baddbmm(g1, dv, f2m)
+            g2.append(torch.bmm(dv.transpose(1, 2), fmap1).view_as(f2))
+        return (None, g1) + tuple(g2)
+
+
 class _CorrLookup(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, coords, radius, fmap1, *fmap2_levels):
+    def forward(ctx, coords, radius, state, token, fmap1, *fmap2_levels):
         L.require_cuda(fmap1, coords)
         B, hw, D = fmap1.shape
         _, _, h, w = coords.shape
@@ -32,22 +68,22 @@ class _CorrLookup(torch.autograd.Function):
             L.check(L.TIMER.launch("corr_lookup_fwd", lambda: L.lib().liso_corr_lookup_fwd_f32(
                 ctypes.byref(cfg), L.ptr(fmap1), _ptr_array(fmap2_levels), L.ptr(coords), L.ptr(out), L.stream_ptr())),
                 "corr_lookup_fwd")
-        ctx.save_for_backward(coords, fmap1, *fmap2_levels)
-        ctx.cfg = cfg
+        ctx.save_for_backward(coords)
+        ctx.cfg, ctx.state = cfg, state
+        ctx.level_hw = [l.shape[1] * l.shape[2] for l in fmap2_levels]
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        coords, fmap1, *levels = ctx.saved_tensors
-        cfg = ctx.cfg
+        (coords,) = ctx.saved_tensors
+        cfg, st = ctx.cfg, ctx.state
         g = grad_out.float().contiguous()
-        g1 = torch.empty((cfg.levels + 1,) + tuple(fmap1.shape), dtype=torch.float32, device=fmap1.device)
-        g2 = [torch.zeros_like(l) for l in levels]
-        with torch.cuda.device(fmap1.device):
-            L.check(L.TIMER.launch("corr_lookup_bwd", lambda: L.lib().liso_corr_lookup_bwd_f32(
-                ctypes.byref(cfg), L.ptr(fmap1), _ptr_array(levels), L.ptr(coords), L.ptr(g), L.ptr(g1), _ptr_array(g2),
-                L.stream_ptr())), "corr_lookup_bwd")
-        return (None, None, g1[0]) + tuple(g2)
+        if st.dvol is None:
+            st.dvol = [torch.zeros((cfg.batch, cfg.h * cfg.w, n), dtype=torch.float32, device=g.device) for n in ctx.level_hw]
+        with torch.cuda.device(g.device):
+            L.check(L.TIMER.launch("corr_lookup_bwd", lambda: L.lib().liso_corr_lookup_bwd_dvol_f32(
+                ctypes.byref(cfg), L.ptr(coords), L.ptr(g), _ptr_array(st.dvol), L.stream_ptr())), "corr_lookup_bwd")
+        return (None, None, None, g.new_zeros(1)) + (None,) * (1 + cfg.levels)
 
 
 class CorrBlock:
@@ -64,9 +100,14 @@ class CorrBlock:
             if i > 0:
                 f2 = F.avg_pool2d(f2, 2, stride=2)
             self.levels.append(f2.permute(0, 2, 3, 1).contiguous())
+        self._state = _VolumeGradState()
+        needs_grad = torch.is_grad_enabled() and (self.fmap1.requires_grad or any(l.requires_grad for l in self.levels))
+        self._token = _CorrFeatures.apply(self._state, self.fmap1, *self.levels) if needs_grad else self.fmap1.new_zeros(1)
+        self._fmap1_d = self.fmap1.detach()
+        self._levels_d = [l.detach() for l in self.levels]
 
     def __call__(self, coords):
-        out = _CorrLookup.apply(coords, self.radius, self.fmap1, *self.levels)  # [B,h,w,C] storage
+        out = _CorrLookup.apply(coords, self.radius, self._state, self._token, self._fmap1_d, *self._levels_d)  # [B,h,w,C]
         return out.permute(0, 3, 1, 2)  # logical [B,C,h,w] like the reference (:46), channels-last memory
 
     @staticmethod

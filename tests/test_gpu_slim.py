@@ -58,6 +58,45 @@ def test_corr_lookup_vs_explicit_volume(h, w, B):
     assert _rel(out, ref.cpu().numpy()) < 1e-4
 
 
+def test_corr_lookup_backward_accumulates_over_lookups():
+    """three lookups (RAFT iterations) through ONE CorrBlock: the deferred dense-volume backward must equal autograd
+    through the reference's explicit volume + avg_pool2d + grid_sample path (corr.py:6-46), and be bit reproducible"""
+    import torch.nn.functional as F
+
+    from liso_amd.slim.model.raft_code.corr import CorrBlock
+    from liso_amd.slim.model.raft_code.utils import bilinear_sampler, coords_grid
+
+    B, h, w = 2, 24, 40
+    torch.manual_seed(5)
+    f1 = torch.randn(B, 128, h, w, device="cuda", requires_grad=True)
+    f2 = torch.randn(B, 128, h, w, device="cuda", requires_grad=True)
+    coords = [coords_grid(B, h, w, "cuda") + torch.randn(B, 2, h, w, device="cuda") * s for s in (0.5, 3.0, 20.0)]
+    gos = [torch.randn(B, 196, h, w, device="cuda") for _ in coords]
+
+    def ours():
+        cb = CorrBlock(f1, f2, 4, 3)
+        loss = sum((cb(c) * go).sum() for c, go in zip(coords, gos))
+        return torch.autograd.grad(loss, [f1, f2])
+
+    def explicit():
+        vol = CorrBlock.corr(f1, f2).reshape(B * h * w, 1, h, w)
+        pyr = [vol]
+        for _ in range(3):
+            pyr.append(F.avg_pool2d(pyr[-1], 2, stride=2))
+        d = torch.linspace(-3, 3, 7, device="cuda")
+        delta = torch.stack(torch.meshgrid(d, d, indexing="ij"), dim=-1).view(1, 7, 7, 2)
+        loss = 0.0
+        for c, go in zip(coords, gos):
+            cc = c.permute(0, 2, 3, 1).reshape(B * h * w, 1, 1, 2)
+            out = torch.cat([bilinear_sampler(v, cc / 2 ** i + delta).view(B, h, w, -1) for i, v in enumerate(pyr)], dim=-1)
+            loss = loss + (out.permute(0, 3, 1, 2) * go).sum()
+        return torch.autograd.grad(loss, [f1, f2])
+
+    (a1, a2), (b1, b2), (e1, e2) = ours(), ours(), explicit()
+    assert torch.equal(a1, b1) and torch.equal(a2, b2)  # no float atomics anywhere
+    assert _rel(a1, e1.cpu().numpy()) < 1e-4 and _rel(a2, e2.cpu().numpy()) < 1e-4
+
+
 def _build(seed=1234):
     from liso_amd.slim.model.extractor import SmallEncoder
     from liso_amd.slim.model.head_decoder import HeadDecoder
