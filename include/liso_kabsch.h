@@ -56,6 +56,22 @@ int liso_symm_ortho_fwd_f64(const double* a, int n, double* r, double* u, double
 int liso_symm_ortho_bwd_f64(const double* grad_r, const double* u, const double* vh, const double* d, int n,
                             double* grad_a, void* stream);
 
+/* ---- weighted moments of a differentiable weighted Kabsch fit ------------------------------------------------------
+ * Replaces the torch reductions of weighted_pc_alignment (liso/slim/slim_loss/weighted_pc_alignment.py:36-47; same
+ * code in liso/weighted_pc_alignment/weighted_pc_alignment.py:80-110): two weighted means, two centred clouds and the
+ * 3xN . Nx3 product -- 12 launches forward, ~25 backward and a skinny GEMM per call, 12 calls per SLIM step.  Here
+ * the clouds are read once and 16 fp64 sums come back:
+ *     out[0]      = sum_i w_i                out[1..3] = sum_i w_i x_i         out[4..6] = sum_i w_i y_i
+ *     out[7+3a+b] = sum_i w_i y_i[a] x_i[b]
+ * from which the host forms  m_x = S_x/S, m_y = S_y/S, S_xy = (S_yx - S m_y m_x^T)/S  (== the reference's centred
+ * product) with differentiable 3x3 fp64 algebra.  x, y: float32 [n,3] (finite); w: float32 [n] (rows to ignore: 0).
+ * Backward: grad_out float64 [16] -> grad_x/grad_y [n,3], grad_w [n] (any of them may be NULL). */
+size_t liso_weighted_moments_workspace_bytes(void);
+int liso_weighted_moments_fwd_f32(const float* x, const float* y, const float* w, long n, double* out, void* workspace,
+                                  size_t workspace_bytes, void* stream);
+int liso_weighted_moments_bwd_f32(const float* x, const float* y, const float* w, long n, const double* grad_out, float* grad_x,
+                                  float* grad_y, float* grad_w, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -53,7 +53,7 @@ int liso_corr_lookup_bwd_dvol_f32(const liso_corr_cfg* cfg, const float* coords,
  * every query walks Chebyshev rings of cells until the best squared distance provably cannot be improved: EXACT
  * nearest neighbour (3-D Euclidean), ties resolved towards the smaller reference index, no host involvement.
  *
- *   ref    float32 [n_ref, ref_stride]   (x,y,z first), all finite
+ *   ref    float32 [n_ref, ref_stride]   (x,y,z first); rows containing NaN/inf (padding) are never returned
  *   query  float32 [n_query, query_stride], rows containing NaN/inf get index 0 and distance NaN
  *   index  int64 [n_query], dist_sqr float32 [n_query] (may be NULL)
  */
@@ -76,6 +76,25 @@ int liso_knn_build_f32(const liso_knn_grid* grid, const float* ref, int ref_stri
 int liso_knn_query_f32(const liso_knn_grid* grid, const float* ref, int ref_stride, int n_ref, const void* workspace,
                        const float* query, int query_stride, int n_query, int64_t* index, float* dist_sqr, int max_rings,
                        int only_unresolved, void* stream);
+
+/* ---- BEV grid -> per-point gather (decoder) and its adjoint ---------------------------------------------------------
+ * Replaces batched_grid_data_to_pointwise_data (liso/slim/slim_loss/static_aggregation.py:8-31; used by
+ * head_decoder.py:300-408 to pull 26 channels per point out of the decoded BEV maps).  PyTorch's advanced-index backward
+ * sorts the 120k indices and runs a serial-per-segment accumulate on every call (3 x 0.3 ms per decode, 12 decodes per
+ * step, measured); here the points are sorted by cell once per cloud and every backward is one segmented-sum launch.
+ *
+ *   grid        float32 [cells_total, c]  channels-last BEV maps of the whole batch flattened (cells_total = B*H*W)
+ *   lin         int32 [n_rows]            flattened cell of every point (b*H*W + row*W + col), < 0: invalid point
+ *   out         float32 [n_rows, c]       invalid rows receive `default_value`
+ *   sorted_lin  int32 [n_rows] ascending  (lin sorted), order int32 [n_rows] = the permutation that sorts lin,
+ *   seg_rank    int32 [n_rows]            position of the sorted row inside its run of equal cells (0 = first)
+ *   partial     float32 [n_rows, c]       scratch
+ *   grad_grid   float32 [cells_total, c]  ZERO-FILLED by the caller; rows of cells holding >= 1 point are overwritten
+ */
+int liso_bev_gather_fwd_f32(const float* grid, const int* lin, long n_rows, int c, float default_value, float* out,
+                            void* stream);
+int liso_bev_gather_bwd_f32(const float* grad_out, const int* sorted_lin, const int* order, const int* seg_rank, long n_rows,
+                            int c, float* partial, float* grad_grid, void* stream);
 
 #ifdef __cplusplus
 }

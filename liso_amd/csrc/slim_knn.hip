@@ -30,7 +30,9 @@ __global__ void knn_count_kernel(liso_knn_grid g, const float* __restrict__ ref,
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int cx, cy;
-    const int c = cell_of(g, ref[(size_t)i * stride], ref[(size_t)i * stride + 1], &cx, &cy);
+    const float x = ref[(size_t)i * stride], y = ref[(size_t)i * stride + 1], z = ref[(size_t)i * stride + 2];
+    if (!(isfinite(x) && isfinite(y) && isfinite(z))) { cell_of_pt[i] = -1; return; }  // padding rows (NaN) are never neighbours
+    const int c = cell_of(g, x, y, &cx, &cy);
     cell_of_pt[i] = c;
     atomicAdd(&count[c], 1);
 }
@@ -84,6 +86,7 @@ __global__ void knn_fill_kernel(const float* __restrict__ ref, int stride, int n
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int c = cell_of_pt[i];
+    if (c < 0) return;
     const int pos = start[c] + atomicAdd(&cursor[c], 1);
     bucketed[pos] = make_float4(ref[(size_t)i * stride], ref[(size_t)i * stride + 1], ref[(size_t)i * stride + 2],
                                 __int_as_float(i));

@@ -14,6 +14,7 @@ from torch import nn
 
 from liso_amd.slim.slim_loss.numerical_stability import normalized_sigmoid_sum
 from liso_amd.slim.slim_loss.static_aggregation import (
+    BevGatherPlan,
     batched_grid_data_to_pointwise_data,
     compute_batched_bev_static_aggregated_flow,
 )
@@ -44,6 +45,15 @@ class HeadDecoder(nn.Module):
     def __init__(self, cfg, name, bev_extent, *args, **kwargs):
         super().__init__(*args, **kwargs)
         self.cfg, self.name, self.bev_extent = cfg, name, bev_extent
+        self._centers = {}  # (grid size, device) -> ([H,W,2] fp64 cell centres, [H,W,4] homogeneous), uploaded once
+
+    def _cell_centers(self, final_grid_size, device):
+        key = (tuple(int(v) for v in final_grid_size), str(device))
+        if key not in self._centers:
+            centers_np = get_voxel_center_coords_m(np.array(self.bev_extent), final_grid_size)
+            homog = np.concatenate([centers_np, np.zeros_like(centers_np[..., :1]), np.ones_like(centers_np[..., :1])], axis=-1)
+            self._centers[key] = (torch.from_numpy(centers_np).to(device), torch.from_numpy(homog).to(device))
+        return self._centers[key]
 
     def concat2network_output(self, *, logits, static_flow, dynamic_flow, weight_logits_for_static_aggregation=None):
         assert logits.shape[1] == 4 and static_flow.shape[1] == 2 and dynamic_flow.shape[1] == 2
@@ -59,7 +69,7 @@ class HeadDecoder(nn.Module):
                                   gt_flow_bev=None, ohe_gt_stat_dyn_ground_label_bev_map=None,
                                   dynamic_flow_is_non_rigid_flow=False,
                                   overwrite_non_filled_pillars_with_default_flow: bool = True,
-                                  overwrite_non_filled_pillars_with_default_logits: bool = True):
+                                  overwrite_non_filled_pillars_with_default_logits: bool = True, gather_plan=None):
         dev = network_output.device
         flow_dim = 2
         assert 3 == len(filled_pillar_mask.shape) == len(network_output.shape) - 1
@@ -79,10 +89,7 @@ class HeadDecoder(nn.Module):
         final_grid_size = network_output.shape[1:3]
         assert pointwise_voxel_coordinates_fs.shape[-1] == 2
         # ground-truth static flow of every BEV cell / point from the odometry (fp64 einsum, :127-157)
-        centers_np = get_voxel_center_coords_m(np.array(self.bev_extent), final_grid_size)
-        homog = torch.from_numpy(np.concatenate([centers_np, np.zeros_like(centers_np[..., :1]), np.ones_like(centers_np[..., :1])],
-                                                axis=-1)).to(inv_odom.device)
-        centers = torch.from_numpy(centers_np).to(inv_odom.device)
+        centers, homog = self._cell_centers(final_grid_size, inv_odom.device)
         # (inv_odom - I) applied to cell centres / points: written as broadcast multiply-adds in fp64.  The reference's
         # einsum (:139-157) is a [3x4]x[4xN] fp64 GEMM, which rocBLAS runs with a 128x128 DGEMM tile (28 ms per call at
         # N = 120k, measured) -- 70 % of the whole SLIM step for a quantity forward() then discards.
@@ -100,7 +107,8 @@ class HeadDecoder(nn.Module):
             pointwise_voxel_coordinates_fs=pointwise_voxel_coordinates_fs.to(dev),
             pointwise_valid_mask=pointwise_valid_mask.to(dev), voxel_center_metric_coordinates=centers,
             overwrite_non_filled_pillars_with_default_flow=overwrite_non_filled_pillars_with_default_flow,
-            overwrite_non_filled_pillars_with_default_logits=overwrite_non_filled_pillars_with_default_logits)
+            overwrite_non_filled_pillars_with_default_logits=overwrite_non_filled_pillars_with_default_logits,
+            gather_plan=gather_plan)
         disappearing_logit = nod["disappearing_logit"][..., 0]
 
         def pad3(t):
@@ -124,16 +132,18 @@ class HeadDecoder(nn.Module):
                 masked_static_aggr_flow, nod.get("masked_weights_for_static_aggregation", None), static_aggr_trafo,
                 not_enough_points)
 
-    def apply_flow_to_points(self, *, modified_output_bev_img, pointwise_voxel_coordinates_fs, pointwise_valid_mask):
-        """reference :300-408 -- gather 3 bool + 23 float channels per point"""
+    def apply_flow_to_points(self, *, modified_output_bev_img, pointwise_voxel_coordinates_fs, pointwise_valid_mask,
+                             gather_plan=None):
+        """reference :300-408 -- gather 3 bool + 23 float channels per point (one 26-channel gather: the booleans ride
+        along as 0/1 floats, default 0 == False)"""
         m = modified_output_bev_img
-        bools = torch.stack([m.is_static, m.is_dynamic, m.is_ground], dim=-1)
         flts = torch.cat([torch.stack([m.disappearing, m.disappearing_logit, m.staticness, m.dynamicness, m.groundness], dim=-1),
-                          m.class_probs, m.class_logits, m.dynamic_flow, m.static_flow, m.aggregated_flow, m.static_aggr_flow],
-                         dim=-1)
-        assert flts.shape[-1] == 23, flts.shape
-        pb = batched_grid_data_to_pointwise_data(bools, pointwise_voxel_coordinates_fs, pointwise_valid_mask, default_value=False)
-        pf = batched_grid_data_to_pointwise_data(flts, pointwise_voxel_coordinates_fs, pointwise_valid_mask, default_value=0.0)
+                          m.class_probs, m.class_logits, m.dynamic_flow, m.static_flow, m.aggregated_flow, m.static_aggr_flow,
+                          torch.stack([m.is_static, m.is_dynamic, m.is_ground], dim=-1).to(m.staticness.dtype)], dim=-1)
+        assert flts.shape[-1] == 26, flts.shape
+        pf = batched_grid_data_to_pointwise_data(flts, pointwise_voxel_coordinates_fs, pointwise_valid_mask, default_value=0.0,
+                                                 plan=gather_plan)
+        pb = pf[..., 23:26].detach() > 0.5
         return Munch(disappearing_logit=pf[..., 1], disappearing=pf[..., 0], class_logits=pf[..., 8:11], class_probs=pf[..., 5:8],
                      staticness=pf[..., 2], dynamicness=pf[..., 3], groundness=pf[..., 4], is_static=pb[..., 0],
                      is_dynamic=pb[..., 1], is_ground=pb[..., 2], dynamic_flow=pf[..., 11:14], static_flow=pf[..., 14:17],
@@ -141,16 +151,20 @@ class HeadDecoder(nn.Module):
 
     def forward(self, network_output, dynamicness_threshold, *, pc, pointwise_voxel_coordinates, pointwise_valid_mask,
                 filled_pillar_mask, odom, inv_odom, summaries, gt_flow_bev=None, per_point_cluster_idxs_gt=None,
-                ohe_gt_stat_dyn_ground_label_bev_map=None, dynamic_flow_is_non_rigid_flow=False):
-        """reference :410-496"""
+                ohe_gt_stat_dyn_ground_label_bev_map=None, dynamic_flow_is_non_rigid_flow=False, gather_plan=None):
+        """reference :410-496.  `gather_plan` (extension): a BevGatherPlan of (pointwise_voxel_coordinates // final_scale,
+        pointwise_valid_mask) to reuse across the RAFT iterations of one cloud; built here when absent."""
         coors_fs = torch.div(pointwise_voxel_coordinates, self.cfg.model.u_net.final_scale, rounding_mode="trunc")
+        if gather_plan is None:
+            gather_plan = BevGatherPlan(coors_fs, pointwise_valid_mask, network_output.shape[1:3])
         (modified, nod, gt_flow_bev, _, _, _, _, _, static_aggr_trafo, not_enough_points) = self.apply_output_modification(
             network_output, dynamicness_threshold, pc=pc, pointwise_voxel_coordinates_fs=coors_fs,
             pointwise_valid_mask=pointwise_valid_mask, filled_pillar_mask=filled_pillar_mask, inv_odom=inv_odom,
             gt_flow_bev=gt_flow_bev, ohe_gt_stat_dyn_ground_label_bev_map=ohe_gt_stat_dyn_ground_label_bev_map,
-            dynamic_flow_is_non_rigid_flow=dynamic_flow_is_non_rigid_flow, per_point_cluster_idxs_gt=per_point_cluster_idxs_gt)
+            dynamic_flow_is_non_rigid_flow=dynamic_flow_is_non_rigid_flow, per_point_cluster_idxs_gt=per_point_cluster_idxs_gt,
+            gather_plan=gather_plan)
         pointwise = self.apply_flow_to_points(modified_output_bev_img=modified, pointwise_voxel_coordinates_fs=coors_fs,
-                                              pointwise_valid_mask=pointwise_valid_mask)
+                                              pointwise_valid_mask=pointwise_valid_mask, gather_plan=gather_plan)
         retval = Munch(**pointwise, dense_maps=Munch(aggregated_flow=modified.aggregated_flow, static_flow=modified.static_flow),
                        modified_network_output=Munch(nod))
         retval["static_aggr_trafo"] = static_aggr_trafo
@@ -163,7 +177,7 @@ def artificial_network_output(*, network_output_dict: Dict[str, torch.Tensor], d
                               ohe_gt_stat_dyn_ground_label_bev_map, gt_flow_bev, gt_static_flow, filled_pillar_mask, pc,
                               pointwise_voxel_coordinates_fs, pointwise_valid_mask, voxel_center_metric_coordinates,
                               overwrite_non_filled_pillars_with_default_flow: bool = False,
-                              overwrite_non_filled_pillars_with_default_logits: bool = False):
+                              overwrite_non_filled_pillars_with_default_logits: bool = False, gather_plan=None):
     """reference :517-717"""
     model_cfg = cfg.model
     om = model_cfg.output_modification
@@ -211,7 +225,7 @@ def artificial_network_output(*, network_output_dict: Dict[str, torch.Tensor], d
     nod["static_aggr_flow"], static_aggr_trafo, not_enough_points = compute_batched_bev_static_aggregated_flow(
         pc, pointwise_voxel_coordinates_fs, pointwise_valid_mask, nod["static_flow"], weight_map,
         voxel_center_metric_coordinates,
-        use_eps_for_weighted_pc_alignment=cfg.losses.unsupervised.use_epsilon_for_weighted_pc_alignment)
+        use_eps_for_weighted_pc_alignment=cfg.losses.unsupervised.use_epsilon_for_weighted_pc_alignment, plan=gather_plan)
     nod["masked_static_aggr_flow"] = torch.where(filled_pillar_mask, nod["static_aggr_flow"], torch.zeros_like(nod["static_aggr_flow"]))
     nod["masked_gt_static_flow"] = torch.where(filled_pillar_mask, gt_static_flow, torch.zeros_like(nod["masked_static_aggr_flow"]))
     return nod, static_aggr_trafo, not_enough_points

@@ -8,6 +8,7 @@ from torch import nn
 from liso_amd.slim.model.head_decoder import HeadDecoder
 from liso_amd.slim.model.raft_mod import RAFT
 from liso_amd.slim.slim_loss.movavg_cls_threshold import MovingAverageThreshold
+from liso_amd.slim.slim_loss.static_aggregation import BevGatherPlan
 
 
 def get_network_input_pcls(cfg, sample_data, time_key: str, to_device=None):
@@ -42,19 +43,23 @@ class SLIM(nn.Module):
         thr = self.moving_dynamicness_threshold.value()
         nri = self.slim_cfg.model.dynamic_flow_is_non_rigid_flow
         preds_fw, preds_bw = [], []
+        fs = self.slim_cfg.model.u_net.final_scale
+        plans = [BevGatherPlan(torch.div(sd["pcl_ta"]["pillar_coors"].to(dev), fs, rounding_mode="trunc"),
+                               sd["pcl_ta"]["pcl_is_valid"].to(dev), out_fw[0].shape[1:3])
+                 for sd in (sample_data_t0, sample_data_t1)]  # point -> cell lists, shared by all RAFT iterations
         for o01, o10 in zip(out_fw, out_bw):
             kw0 = dict(dynamicness_threshold=thr, pointwise_valid_mask=sample_data_t0["pcl_ta"]["pcl_is_valid"].to(dev),
                        pointwise_voxel_coordinates=sample_data_t0["pcl_ta"]["pillar_coors"].to(dev),
                        pc=sample_data_t0["pcl_ta"]["pcl"].to(dev), filled_pillar_mask=filled0,
                        odom=sample_data_t0["gt"]["odom_ta_tb"].to(dev), inv_odom=sample_data_t1["gt"]["odom_ta_tb"].to(dev),
                        summaries=summaries, gt_flow_bev=None, ohe_gt_stat_dyn_ground_label_bev_map=None,
-                       dynamic_flow_is_non_rigid_flow=nri)
+                       dynamic_flow_is_non_rigid_flow=nri, gather_plan=plans[0])
             kw1 = dict(dynamicness_threshold=thr, pointwise_valid_mask=sample_data_t1["pcl_ta"]["pcl_is_valid"].to(dev),
                        pointwise_voxel_coordinates=sample_data_t1["pcl_ta"]["pillar_coors"].to(dev),
                        pc=sample_data_t1["pcl_ta"]["pcl"].to(dev), filled_pillar_mask=filled1,
                        odom=sample_data_t1["gt"]["odom_ta_tb"].to(dev), inv_odom=sample_data_t0["gt"]["odom_ta_tb"].to(dev),
                        summaries=summaries, gt_flow_bev=None, ohe_gt_stat_dyn_ground_label_bev_map=None,
-                       dynamic_flow_is_non_rigid_flow=nri)
+                       dynamic_flow_is_non_rigid_flow=nri, gather_plan=plans[1])
             preds_fw.append(self.head_decoder_fw(o01, **kw0))
             preds_bw.append(self.head_decoder_bw(o10, **kw1))
         self.predictions_fw, self.predictions_bw = preds_fw, preds_bw

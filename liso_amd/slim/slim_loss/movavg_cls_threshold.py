@@ -24,7 +24,8 @@ class MovingAverageThreshold(nn.Module):
         self.register_buffer("moving_average_importance", torch.zeros((self.resolution,), dtype=torch.float))
 
     def value(self):
-        return self._compute_optimal_score_threshold() if self.bias_counter > 0.0 else self.start_value
+        """reference :56-60; the `if bias_counter > 0` branch is a torch.where (no device->host sync)"""
+        return torch.where(self.bias_counter > 0.0, self._compute_optimal_score_threshold(), self.start_value)
 
     def _compute_bin_idxs(self, scores):
         idxs = ((scores - self.value_range[0]) * self.resolution / self.value_range[1]).to(torch.int)
@@ -40,7 +41,8 @@ class MovingAverageThreshold(nn.Module):
     def _compute_optimal_score_threshold(self):
         z = torch.zeros((1,), dtype=self.moving_average_importance.dtype, device=self.moving_average_importance.device)
         improv = torch.cat([z, torch.cumsum(self.moving_average_importance, 0)], dim=0)
-        avg_idx = torch.mean(torch.where(torch.min(improv) == improv)[0].to(torch.float))
+        is_min = torch.min(improv) == improv  # mean index of the minima, without nonzero()
+        avg_idx = (torch.arange(improv.numel(), device=improv.device, dtype=torch.float) * is_min).sum() / is_min.sum()
         return self.value_range[0] + avg_idx * self.value_range[1] / self.resolution
 
     def _update_values(self, cur_value, cur_weight):
@@ -50,15 +52,25 @@ class MovingAverageThreshold(nn.Module):
         self.bias_counter *= w
         self.bias_counter += 1.0 - w
 
-    def update(self, epes_stat_flow, epes_dyn_flow, moving_mask, dynamicness_scores, training):
+    def update(self, epes_stat_flow, epes_dyn_flow, moving_mask, dynamicness_scores, training, valid_mask=None,
+               compute_value=True):
+        """reference :118-157.  Extensions: `valid_mask` -- rows to ignore (instead of the caller compacting the arrays
+        with boolean indexing); `compute_value=False` skips evaluating the returned threshold."""
         assert isinstance(training, bool)
         if training:
             e_s, e_d, sc = epes_stat_flow.detach(), epes_dyn_flow.detach(), dynamicness_scores.detach()
             imp = self._compute_improvements(e_s, e_d, moving_mask)
-            cur = torch.zeros((self.resolution,), dtype=imp.dtype, device=imp.device).scatter_add_(
-                0, self._compute_bin_idxs(sc).to(torch.long), imp)
-            self._update_values(cur, e_s.numel())
+            bins = self._compute_bin_idxs(sc).to(torch.long)
+            count = e_s.numel()
+            if valid_mask is not None:
+                imp = torch.where(valid_mask, imp, 0.0)
+                bins = torch.where(valid_mask, bins, 0).clamp(min=0)
+                count = valid_mask.sum()
+            cur = torch.zeros((self.resolution,), dtype=imp.dtype, device=imp.device).scatter_add_(0, bins, imp)
+            self._update_values(cur, count)
             if self.num_still is not None:
-                self.moving_counter += torch.count_nonzero(moving_mask)
-                self.still_counter += torch.count_nonzero(~moving_mask)
-        return self.value()
+                mm = moving_mask if valid_mask is None else moving_mask & valid_mask
+                sm = ~moving_mask if valid_mask is None else (~moving_mask) & valid_mask
+                self.moving_counter += torch.count_nonzero(mm)
+                self.still_counter += torch.count_nonzero(sm)
+        return self.value() if compute_value else None

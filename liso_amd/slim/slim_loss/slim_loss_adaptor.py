@@ -25,7 +25,7 @@ def weighted_mse_loss(input_tensor, target, weight):
 
 def static_points_loss(pc, valid_mask, flow, weights, trafo):
     """reference :55-91"""
-    pc_valid = torch.where(valid_mask[..., None], pc, torch.tensor(0.0, dtype=pc.dtype, device=pc.device))
+    pc_valid = torch.where(valid_mask[..., None], pc, 0.0)
     pc_hom = homogenize_pcl(pc_valid[..., :3])
     moved = torch.sum(pc_hom[:, :, None, :].double() * trafo.detach()[:, None, :, :], dim=-1)
     est = (moved[..., :3] - pc_valid[..., :3].double()).float()
@@ -46,7 +46,8 @@ def symmetric_static_points_loss(pc0, valid_mask_pc0, static_flow_fw, static_agg
 
 
 def _masked_mean(x, mask):
-    return x[mask].mean()
+    """x[mask].mean() without the boolean-index compaction (a device->host sync per call)"""
+    return torch.where(mask, x, 0.0).sum() / mask.sum()
 
 
 def selfsupervisedSlimSingleScaleLoss(pc1, valid_mask_pc1, pc2, valid_mask_pc2, pred_fw, pred_bw, moving_thresh_module, *,
@@ -101,13 +102,17 @@ def selfsupervisedSlimSingleScaleLoss(pc1, valid_mask_pc1, pc2, valid_mask_pc2, 
         total = total + st * loss_cfg.knn_on_static_penalty
     assert loss_cfg.opposite_flow_penalty_factor == 0.0
     if model_cfg.use_static_aggr_flow_for_aggr_flow:  # reference :294-335: update the dynamicness threshold
-        es, ed, sc = [], [], []
+        es, ed, sc, vm = [], [], [], []
         for res, pred, m in ((knn_fw, pred_fw, valid_mask_pc1), (knn_bw, pred_bw, valid_mask_pc2)):
-            es.append(res["static_aggr"]["knn"]["nearest_dist"][m].flatten())
-            ed.append(res["dynamic"]["knn"]["nearest_dist"][m].flatten())
-            sc.append(pred.dynamicness[m].flatten())
+            es.append(res["static_aggr"]["knn"]["nearest_dist"].flatten())
+            ed.append(res["dynamic"]["knn"]["nearest_dist"].flatten())
+            sc.append(pred.dynamicness.flatten())
+            vm.append(m.flatten())
+        # the reference compacts the three arrays with `[mask]` (:300-320); the histogram update ignores rows through
+        # `valid_mask` instead, and the returned threshold (unused here) is not evaluated
         moving_thresh_module.update(epes_stat_flow=torch.cat(es), epes_dyn_flow=torch.cat(ed), moving_mask=None,
-                                    dynamicness_scores=torch.cat(sc), training=training)
+                                    dynamicness_scores=torch.cat(sc), training=training, valid_mask=torch.cat(vm),
+                                    compute_value=False)
     if ce:
         total = total + 0.5 * (ce_fw + ce_bw) * loss_cfg.artificial_labels.cross_entropy_penalty
     metrics_collector["total_loss"] = total.detach()

@@ -1,41 +1,100 @@
 """Static-flow aggregation.  Mirror of liso/slim/slim_loss/static_aggregation.py:8-110."""
 import torch
 
+from liso_amd import _lib as L
 from liso_amd.slim.slim_loss.weighted_pc_alignment import weighted_pc_alignment
 
 
-def batched_grid_data_to_pointwise_data(grid_data, pointwise_voxel_coordinates_fs, pointwise_valid_mask, default_value):
-    """reference :8-31 -- gather [B,H,W,C] at each point's pillar (invalid rows -> default), out of place"""
+class BevGatherPlan:
+    """The cell of every point of a batch of clouds, flattened over (b, row, col), and the same list sorted by cell.
+    Built once per cloud and reused by every BEV->point gather (forward) and its segmented-sum adjoint (backward) of a
+    training step: 6 RAFT iterations x 3 gathers per direction."""
+
+    def __init__(self, pointwise_voxel_coordinates_fs, pointwise_valid_mask, grid_hw):
+        H, W = int(grid_hw[0]), int(grid_hw[1])
+        B, N = pointwise_valid_mask.shape
+        c = pointwise_voxel_coordinates_fs.long()
+        b = torch.arange(B, device=c.device)[:, None]
+        lin = (b * H + c[..., 0]) * W + c[..., 1]
+        self.lin = torch.where(pointwise_valid_mask, lin, -1).to(torch.int32).reshape(-1).contiguous()
+        sorted_lin, order = torch.sort(self.lin, stable=True)
+        self.sorted_lin, self.order = sorted_lin.contiguous(), order.to(torch.int32).contiguous()
+        pos = torch.arange(sorted_lin.numel(), device=c.device, dtype=torch.int32)
+        is_head = torch.ones_like(sorted_lin, dtype=torch.bool)
+        is_head[1:] = sorted_lin[1:] != sorted_lin[:-1]
+        self.seg_rank = (pos - torch.cummax(torch.where(is_head, pos, 0), dim=0).values).contiguous()
+        self.shape = (B, N, H, W)
+
+    def matches(self, grid_data, mask):
+        B, N, H, W = self.shape
+        return tuple(grid_data.shape[:3]) == (B, H, W) and tuple(mask.shape) == (B, N)
+
+
+class _BevGather(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, grid_data, plan, default_value):
+        L.require_cuda(grid_data)
+        B, N, H, W = plan.shape
+        C = grid_data.shape[-1]
+        g = grid_data.float().contiguous()
+        out = torch.empty((B, N, C), dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            L.check(L.lib().liso_bev_gather_fwd_f32(L.ptr(g), L.ptr(plan.lin), B * N, C, float(default_value), L.ptr(out),
+                                                    L.stream_ptr()), "bev_gather_fwd")
+        ctx.plan, ctx.C = plan, C
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        plan, C = ctx.plan, ctx.C
+        B, N, H, W = plan.shape
+        go = grad_out.float().contiguous()
+        gg = torch.zeros((B, H, W, C), dtype=torch.float32, device=go.device)
+        partial = torch.empty((B * N, C), dtype=torch.float32, device=go.device)
+        with torch.cuda.device(go.device):
+            L.check(L.lib().liso_bev_gather_bwd_f32(L.ptr(go), L.ptr(plan.sorted_lin), L.ptr(plan.order), L.ptr(plan.seg_rank),
+                                                    B * N, C, L.ptr(partial), L.ptr(gg), L.stream_ptr()), "bev_gather_bwd")
+        return gg, None, None
+
+
+def batched_grid_data_to_pointwise_data(grid_data, pointwise_voxel_coordinates_fs, pointwise_valid_mask, default_value, plan=None):
+    """reference :8-31 -- gather [B,H,W,C] at each point's pillar (invalid rows -> default), out of place.
+    Float maps go through the gfx950 gather of include/liso_slim.h (`plan`: reusable BevGatherPlan); other dtypes use
+    torch indexing (they carry no gradient)."""
     assert len(grid_data.shape) == 4, grid_data.shape
+    if grid_data.dtype == torch.float32:
+        if plan is None or not plan.matches(grid_data, pointwise_valid_mask):
+            plan = BevGatherPlan(pointwise_voxel_coordinates_fs, pointwise_valid_mask, grid_data.shape[1:3])
+        return _BevGather.apply(grid_data, plan, default_value)
     coors = torch.where(pointwise_valid_mask[..., None], pointwise_voxel_coordinates_fs,
                         torch.zeros_like(pointwise_voxel_coordinates_fs)).long()
     b = torch.arange(pointwise_valid_mask.shape[0], device=grid_data.device)[:, None].expand(-1, pointwise_valid_mask.shape[1])
     data = grid_data[b, coors[..., 0], coors[..., 1]]
-    return torch.where(pointwise_valid_mask[..., None], data, torch.as_tensor(default_value, dtype=data.dtype, device=data.device))
+    return torch.where(pointwise_valid_mask[..., None], data, default_value)
 
 
 def compute_batched_bev_static_aggregated_flow(pc, pointwise_voxel_coordinates_fs, pointwise_valid_mask, static_flow_bev,
                                                staticness_weights, voxel_center_metric_coordinates_bev,
-                                               use_eps_for_weighted_pc_alignment: bool = False):
+                                               use_eps_for_weighted_pc_alignment: bool = False, plan=None):
     """reference :34-110 -- per sample: Kabsch of (points, points + static flow) weighted by staticness, then the rigid
-    flow field (T - I) applied to every BEV cell centre."""
+    flow field (T - I) applied to every BEV cell centre.  Invalid (padding) points enter the weighted moments with
+    weight 0 instead of being removed by boolean indexing (same sums, no device->host sync)."""
     assert len(static_flow_bev.shape) == 4 and static_flow_bev.shape[-1] == 2
-    flow3 = torch.cat([static_flow_bev, torch.zeros_like(static_flow_bev[..., :1])], dim=-1)
-    pw_flow = batched_grid_data_to_pointwise_data(flow3, pointwise_voxel_coordinates_fs, pointwise_valid_mask, 0.0)
-    pw_static = batched_grid_data_to_pointwise_data(staticness_weights[..., None], pointwise_voxel_coordinates_fs,
-                                                    pointwise_valid_mask, 0.0)[..., 0]
+    both = torch.cat([static_flow_bev, staticness_weights[..., None]], dim=-1)  # one gather for flow + weight
+    pw = batched_grid_data_to_pointwise_data(both, pointwise_voxel_coordinates_fs, pointwise_valid_mask, 0.0, plan=plan)
+    pw_flow = torch.cat([pw[..., :2], torch.zeros_like(pw[..., :1])], dim=-1)
+    pw_static = pw[..., 2]
     centers = voxel_center_metric_coordinates_bev
-    grid_h = torch.cat([centers, torch.zeros_like(centers[..., :1]), torch.ones_like(centers[..., :1])], dim=-1)
     flows, Ts, neps = [], [], []
     for b in range(staticness_weights.shape[0]):
         m = pointwise_valid_mask[b]
-        T, nep = weighted_pc_alignment(pc[b][m][..., :3], (pc[b][..., :3] + pw_flow[b])[m], pw_static[b][m],
-                                       use_epsilon_on_weights=use_eps_for_weighted_pc_alignment)
-        # (T - I) applied to every cell centre as fp64 broadcast multiply-adds; the reference's einsum (:88-99) is a
-        # [4x4]x[4xHW] DGEMM that rocBLAS runs with a 128x128 tile: 28 ms per call at 512^2 (measured), 12 calls per step
+        p0 = torch.where(m[:, None], pc[b][..., :3], 0.0)
+        T, nep = weighted_pc_alignment(p0, p0 + pw_flow[b], pw_static[b],
+                                       use_epsilon_on_weights=use_eps_for_weighted_pc_alignment, valid_mask=m)
+        # (T - I) applied to every cell centre (z = 0, w = 1) as fp64 broadcast multiply-adds; the reference's einsum
+        # (:88-99) is a [4x4]x[4xHW] DGEMM that rocBLAS runs with a 128x128 tile: 28 ms per call at 512^2 (measured)
         D = T - torch.eye(4, dtype=torch.float64, device=T.device)
-        flows.append((D[:2, 0] * grid_h[..., 0:1] + D[:2, 1] * grid_h[..., 1:2] + D[:2, 2] * grid_h[..., 2:3]
-                      + D[:2, 3] * grid_h[..., 3:4]).float())
+        flows.append((D[:2, 0] * centers[..., 0:1] + D[:2, 1] * centers[..., 1:2] + D[:2, 3]).float())
         Ts.append(T)
         neps.append(nep)
     return torch.stack(flows, dim=0), torch.stack(Ts, dim=0), torch.stack(neps, dim=0)

@@ -1,33 +1,74 @@
 """weighted_pc_alignment: weighted Kabsch between two clouds -> T[4,4] fp64.
 
 Mirror of liso/slim/slim_loss/weighted_pc_alignment.py:10-80 (same signature and return values; the duplicate module
-liso/weighted_pc_alignment/weighted_pc_alignment.py:54-141 is aliased in liso_amd/weighted_pc_alignment).  The moments
-stay differentiable torch reductions (gradients flow to weights and clouds in the SLIM loss); the 3x3 solve is the
-gfx950 symmetric_orthogonalization kernel.  The debugging try/except of the reference (:49-70) is not reproduced.
+liso/weighted_pc_alignment/weighted_pc_alignment.py:54-141 is aliased in liso_amd/weighted_pc_alignment).  The weighted
+moments come from one fused, differentiable gfx950 reduction (fp64 sums; the reference reduces in fp32), the 3x3
+solve is the gfx950 symmetric_orthogonalization kernel.  The debugging try/except of the reference (:49-70) is not reproduced.
 """
 import torch
 
+from liso_amd import _lib as L
 from liso_amd.torch_symm_ortho import symmetric_orthogonalization
+
+
+class _WeightedMoments(torch.autograd.Function):
+    """16 fp64 sums (include/liso_kabsch.h) of two [N,3] clouds and their weights, differentiable in all three"""
+
+    @staticmethod
+    def forward(ctx, x, y, w):
+        L.require_cuda(x, y, w)
+        x, y, w = x.float().contiguous(), y.float().contiguous(), w.float().contiguous()
+        lib = L.lib()
+        out = torch.empty(16, dtype=torch.float64, device=x.device)
+        nbytes = lib.liso_weighted_moments_workspace_bytes()
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        with torch.cuda.device(x.device):
+            L.check(lib.liso_weighted_moments_fwd_f32(L.ptr(x), L.ptr(y), L.ptr(w), x.shape[0], L.ptr(out), L.ptr(ws), nbytes,
+                                                      L.stream_ptr()), "weighted_moments_fwd")
+        ctx.save_for_backward(x, y, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y, w = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        gx = torch.empty_like(x) if need[0] else None
+        gy = torch.empty_like(y) if need[1] else None
+        gw = torch.empty_like(w) if need[2] else None
+        g = g.double().contiguous()
+        with torch.cuda.device(x.device):
+            L.check(L.lib().liso_weighted_moments_bwd_f32(L.ptr(x), L.ptr(y), L.ptr(w), x.shape[0], L.ptr(g),
+                                                          L.ptr(gx) if gx is not None else None,
+                                                          L.ptr(gy) if gy is not None else None,
+                                                          L.ptr(gw) if gw is not None else None, L.stream_ptr()),
+                    "weighted_moments_bwd")
+        return gx, gy, gw
 
 EPSILON = 1e-7
 
 
-def weighted_pc_alignment(cloud_t0, cloud_t1, weights, use_epsilon_on_weights=False):
+def weighted_pc_alignment(cloud_t0, cloud_t1, weights, use_epsilon_on_weights=False, valid_mask=None):
+    """`valid_mask` (extension): rows to ignore stay in the arrays with weight exactly 0 (and finite coordinates)
+    instead of being removed by the caller with boolean indexing -- same moments, no device->host sync."""
     assert cloud_t0.shape[1:] == (3,) and cloud_t1.shape[1:] == (3,), (cloud_t0.shape, cloud_t1.shape)
     assert len(weights.shape) == 1
+    if valid_mask is not None:
+        weights = torch.where(valid_mask, weights, 0.0)
     if use_epsilon_on_weights:  # reference :26-34
         weights = weights + EPSILON
+        if valid_mask is not None:
+            weights = torch.where(valid_mask, weights, 0.0)
         not_enough_points = (weights > 0).sum() < 3
     else:
         not_enough_points = (weights > 0).sum() < 3
         # `if not_enough_points: weights += EPSILON` without a host sync
-        weights = weights + EPSILON * not_enough_points.to(weights.dtype)
-    cum_wts = weights.sum(dim=-1)
-    mx_wtd = (cloud_t0 * weights[..., None]).sum(dim=0) / cum_wts
-    my_wtd = (cloud_t1 * weights[..., None]).sum(dim=0) / cum_wts
-    Xc = cloud_t0 - mx_wtd[None, :]
-    Yc = cloud_t1 - my_wtd[None, :]
-    Sxy_wtd = (Yc * weights[..., None]).T @ Xc / cum_wts
+        eps = EPSILON * not_enough_points.to(weights.dtype)
+        weights = weights + (eps if valid_mask is None else eps * valid_mask.to(weights.dtype))
+    # reference :36-47 (weighted means, centred clouds, (Yc * w)^T Xc / sum w) from one pass over the points
+    mom = _WeightedMoments.apply(cloud_t0, cloud_t1, weights)
+    cum_wts = mom[0]
+    mx_wtd, my_wtd = mom[1:4] / cum_wts, mom[4:7] / cum_wts
+    Sxy_wtd = (mom[7:16].view(3, 3) - cum_wts * my_wtd[:, None] * mx_wtd[None, :]) / cum_wts
     R = symmetric_orthogonalization(Sxy_wtd.to(torch.double))
     t = my_wtd.to(torch.double) - R @ mx_wtd.to(torch.double)
     R = torch.cat([R, torch.zeros((1, 3), dtype=R.dtype, device=R.device)], dim=0)

@@ -98,12 +98,14 @@ class SlimTrainer:
         from liso_amd.slim.slim_loss.knn_graph import KnnIndex
         from liso_amd.slim.slim_loss.slim_loss_adaptor import selfsupervisedSlimSingleScaleLoss
 
-        preds_fw, preds_bw = self.model(sample_t0, sample_t1, None)
         pc1, m1 = sample_t0["pcl_ta"]["pcl"].to(self.device), sample_t0["pcl_ta"]["pcl_is_valid"].to(self.device)
         pc2, m2 = sample_t1["pcl_ta"]["pcl"].to(self.device), sample_t1["pcl_ta"]["pcl_is_valid"].to(self.device)
         ext = [float(v) for v in self.bev_extent]
-        idx1 = [KnnIndex(pc1[b][m1[b]][:, :3], extent=ext) for b in range(pc1.shape[0])] if bool(m1.all()) else None
-        idx2 = [KnnIndex(pc2[b][m2[b]][:, :3], extent=ext) for b in range(pc2.shape[0])] if bool(m2.all()) else None
+        # bucket both clouds before the network runs: the `all valid` test is the step's only device->host sync and
+        # costs nothing while the queue is still empty
+        idx1 = [KnnIndex(pc1[b][:, :3], extent=ext) for b in range(pc1.shape[0])] if bool(m1.all()) else None
+        idx2 = [KnnIndex(pc2[b][:, :3], extent=ext) for b in range(pc2.shape[0])] if bool(m2.all()) else None
+        preds_fw, preds_bw = self.model(sample_t0, sample_t1, None)
         total = torch.zeros(1, device=self.device)
         for pfw, pbw in zip(preds_fw, preds_bw):
             total = total + selfsupervisedSlimSingleScaleLoss(

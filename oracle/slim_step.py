@@ -1,11 +1,12 @@
 """TEST INFRASTRUCTURE ONLY: the SLIM train step on the host CPU, for bench.py's cpu_baseline leg ("kind": "port").
 
-The product's SLIM host modules are plain torch except for four HIP-backed ops.  `cpu_port()` temporarily swaps those
-four for CPU implementations that follow the reference's own formulation:
+The product's SLIM host modules are plain torch except for five HIP-backed ops.  `cpu_port()` temporarily swaps those
+for CPU implementations that follow the reference's own formulation:
   pillar encoder      -> oracle/pillars.py              (mmdet3d voxel_generator + PillarFeatureNet + scatter)
   correlation lookup  -> explicit all-pairs volume + avg_pool2d + grid_sample   (liso/slim/model/raft_code/corr.py:6-46)
   symmetric orthogonalisation -> torch.linalg.svd (fp64)                         (liso/torch_symm_ortho/__init__.py:63)
   1-nearest neighbour -> scipy.spatial.cKDTree (exact; stands in for pynanoflann, knn_graph.py:57-70)
+  BEV -> point gather -> torch advanced indexing                                 (slim_loss/static_aggregation.py:8-31)
 This is a *timing* port of the step, not a parity oracle: SLIM parity is pinned by fixtures generated from the
 reference (tests/golden/make_slim*_golden.py).
 """
@@ -72,15 +73,27 @@ def _cpu_knn_graph(x, *, index=None, k, loop=False, **kw):
     return idx[:, None]
 
 
+def _cpu_grid_to_points(grid_data, pointwise_voxel_coordinates_fs, pointwise_valid_mask, default_value, plan=None):
+    coors = torch.where(pointwise_valid_mask[..., None], pointwise_voxel_coordinates_fs,
+                        torch.zeros_like(pointwise_voxel_coordinates_fs)).long()
+    b = torch.arange(pointwise_valid_mask.shape[0])[:, None].expand(-1, pointwise_valid_mask.shape[1])
+    data = grid_data[b, coors[..., 0], coors[..., 1]]
+    return torch.where(pointwise_valid_mask[..., None], data, default_value)
+
+
 @contextlib.contextmanager
 def cpu_port():
     import liso_amd.networks.pcl_to_feature_grid.pcl_to_feature_grid as pp
+    import liso_amd.slim.model.head_decoder as hd
     import liso_amd.slim.model.raft_mod as rm
+    import liso_amd.slim.slim_loss.static_aggregation as sa
     import liso_amd.slim.slim_loss.knn_graph as kg
     import liso_amd.slim.slim_loss.knn_wrapper as kw
     import liso_amd.slim.slim_loss.weighted_pc_alignment as wpa
 
     saved = (pp.PointsPillarFeatureNetWrapper.forward, rm.CorrBlock, wpa.symmetric_orthogonalization, kw.knn_graph, kg.KnnIndex)
+    saved_gather = (hd.batched_grid_data_to_pointwise_data, sa.batched_grid_data_to_pointwise_data)
+    hd.batched_grid_data_to_pointwise_data = sa.batched_grid_data_to_pointwise_data = _cpu_grid_to_points
     pp.PointsPillarFeatureNetWrapper.forward = _cpu_pillar_forward
     rm.CorrBlock = _CpuCorrBlock
     wpa.symmetric_orthogonalization = OK.symm_ortho
@@ -90,6 +103,7 @@ def cpu_port():
         yield
     finally:
         (pp.PointsPillarFeatureNetWrapper.forward, rm.CorrBlock, wpa.symmetric_orthogonalization, kw.knn_graph, kg.KnnIndex) = saved
+        hd.batched_grid_data_to_pointwise_data, sa.batched_grid_data_to_pointwise_data = saved_gather
 
 
 def timed_slim_step(cfg, state_dict, sample_t0, sample_t1):
