@@ -43,6 +43,44 @@ int liso_fit_box_z_f32(const float* points, int point_stride, int n, const float
                        int64_t* num_pts, float* fitted_z, float* fitted_height, void* workspace, size_t workspace_bytes,
                        void* stream);
 
+/* ---- clustering block (flow_cluster_detector.py:151-189) --------------------------------------------------------------
+ * sklearn.cluster.DBSCAN(eps=1.0, min_samples=5, metric="euclidean") on the dynamic pillars' 5-D features
+ * (x, y, w*fx, w*fy, w*fz), w = flow_similarity_importance = 2, then skimage.measure.regionprops of the label image
+ * (.centroid, .orientation, .axis_major_length, .axis_minor_length) -- both third-party, both on the host in the
+ * reference (pins: scikit-learn 0.24.2, scikit-image 0.19.2).  Here the dense BEV grid is the neighbour structure:
+ * eps-neighbours of a pillar lie inside a (2*window+1)^2 window, labels are produced on the device with sklearn's
+ * numbering (components of the core graph ordered by their first member in row-major order; border pillars take the
+ * smallest adjacent cluster), and the region moments are exact integer sums.
+ *
+ *   dynamic_mask uint8 [B,gx,gy]; row_coords float32 [gx], col_coords float32 [gy] (metric pillar centres: x of a row,
+ *   y of a column -- the float32 values of `pcl_bev_center_coords_homog`); flow float32 [B,gx,gy,3] (bev_nonrigid_flow)
+ */
+typedef struct {
+    int batch, gx, gy;
+    int window;        /* >= ceil(eps / pillar size): pillars further apart than this in a row or column cannot be neighbours */
+    int min_samples;   /* 5 */
+    float eps;         /* 1.0 */
+    float flow_weight; /* 2.0 (flow_cluster_detector.py:154-160) */
+} liso_dbscan_cfg;
+
+/* step 1: core flags uint8 [B,gx,gy], union-find parents int32 [B,gx,gy] (per-sample cell index, -1 for non-core) and
+ * is_root int32 [B,gx,gy] (1 where a core pillar is the smallest member of its component). */
+int liso_dbscan_components(const liso_dbscan_cfg* cfg, const uint8_t* dynamic_mask, const float* row_coords,
+                           const float* col_coords, const float* flow, uint8_t* core, int32_t* parent, int32_t* is_root,
+                           void* stream);
+
+/* step 2: root_rank int32 [B,gx,gy] = per-sample inclusive scan of is_root (the caller's scan; 1-based label of a root)
+ * -> labels int32 [B,gx,gy]: 0 = background / noise, k >= 1 = sklearn label k-1 (flow_cluster_detector.py:169-172). */
+int liso_dbscan_labels(const liso_dbscan_cfg* cfg, const uint8_t* dynamic_mask, const float* row_coords, const float* col_coords,
+                       const float* flow, const uint8_t* core, const int32_t* parent, const int32_t* root_rank,
+                       int32_t* labels, void* stream);
+
+/* regionprops of a label image: moments uint64 [B,max_labels,6] scratch (n, sum r, sum c, sum r^2, sum c^2, sum rc) ->
+ * props float64 [B,max_labels,5] = (centroid_row, centroid_col, orientation, axis_major_length, axis_minor_length);
+ * labels above max_labels are ignored, absent labels give zeros. */
+int liso_region_props(const int32_t* labels, int batch, int gx, int gy, int max_labels, uint64_t* moments, double* props,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif

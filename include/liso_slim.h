@@ -49,8 +49,9 @@ int liso_corr_lookup_bwd_dvol_f32(const liso_corr_cfg* cfg, const float* coords,
 /* ---- exact 1-nearest-neighbour search (SLIM self-supervised loss) -------------------------------------------------
  * Replaces knn_graph(x, index=ref, k=1, loop=True) (liso/slim/slim_loss/knn_graph.py:10-98), which copies both clouds
  * to the host and queries a pynanoflann KD-tree per call (knn_wrapper.py:139-152,180-186): 12+ device->host->device
- * round trips per training step.  Here the reference cloud is bucketed once into a uniform xy grid on the device and
- * every query walks Chebyshev rings of cells until the best squared distance provably cannot be improved: EXACT
+ * round trips per training step.  Here the reference cloud is bucketed once into a uniform xy grid (with z bins inside
+ * every cell) on the device and every query walks Chebyshev rings of cells, reading only the z bins that can still
+ * hold a closer point, until the best squared distance provably cannot be improved: EXACT
  * nearest neighbour (3-D Euclidean), ties resolved towards the smaller reference index, no host involvement.
  *
  *   ref    float32 [n_ref, ref_stride]   (x,y,z first); rows containing NaN/inf (padding) are never returned
@@ -59,8 +60,10 @@ int liso_corr_lookup_bwd_dvol_f32(const liso_corr_cfg* cfg, const float* coords,
  */
 typedef struct {
     float x_min, y_min;  /* grid origin */
-    float cell;          /* cell edge length in metres (> 0) */
-    int nx, ny;          /* cells (nx*ny <= 2^20); reference points outside are clamped into the border cells (still exact) */
+    float cell;          /* xy cell edge length in metres (> 0) */
+    int nx, ny;          /* xy cells; reference points outside are clamped into the border cells (still exact) */
+    float z_min, z_cell; /* z bins inside every xy cell: bin = clamp(floor((z - z_min) / z_cell), 0, nz-1) */
+    int nz;              /* >= 1; nx*ny*nz <= 2^24.  Bins only prune candidates: any nz gives the exact answer */
 } liso_knn_grid;
 
 size_t liso_knn_workspace_bytes(const liso_knn_grid* grid, int n_ref);

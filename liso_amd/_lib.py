@@ -99,6 +99,9 @@ SIGNATURES = {
     "liso_bev_dynamic_flow_f32": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "liso_fit_box_z_workspace_bytes": (_sz, [_i, _i]),
     "liso_fit_box_z_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _vp, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "liso_dbscan_components": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "liso_dbscan_labels": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "liso_region_props": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     # include/liso_slim.h
     "liso_corr_lookup_fwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "liso_corr_lookup_bwd_dvol_f32": (_i, [_vp, _vp, _vp, _vp, _vp]),
@@ -116,7 +119,12 @@ SIGNATURES = {
 
 class KnnGrid(ctypes.Structure):
     """mirror of liso_knn_grid (include/liso_slim.h)"""
-    _fields_ = [("x_min", _f), ("y_min", _f), ("cell", _f), ("nx", _i), ("ny", _i)]
+    _fields_ = [("x_min", _f), ("y_min", _f), ("cell", _f), ("nx", _i), ("ny", _i), ("z_min", _f), ("z_cell", _f), ("nz", _i)]
+
+
+class DbscanCfg(ctypes.Structure):
+    """mirror of liso_dbscan_cfg (include/liso_flow_cluster.h)"""
+    _fields_ = [("batch", _i), ("gx", _i), ("gy", _i), ("window", _i), ("min_samples", _i), ("eps", _f), ("flow_weight", _f)]
 
 
 class CorrCfg(ctypes.Structure):

@@ -1,0 +1,253 @@
+// DBSCAN over the dynamic BEV pillars + region moments, on the device, for gfx950.  C ABI + reference lines:
+// include/liso_flow_cluster.h.
+//
+// The reference clusters the M dynamic pillars in the 5-D space (x, y, 2 fx, 2 fy, 2 fz) with sklearn's DBSCAN
+// (eps 1 m, min_samples 5) on the host.  eps bounds the BEV distance, so every eps-neighbour of a pillar lies inside a
+// (2R+1)^2 window of the dense grid (R = 6 at 0.195 m pillars): no neighbour lists, no KD-tree, no M^2 pairs.
+//
+//   dbscan_core     one thread per cell: counts eps-neighbours in the window (self included) -> core flag
+//   dbscan_union    one thread per core cell: lock-free union-find (always link the larger root under the smaller:
+//                   atomicMin on the parent) with every core eps-neighbour of smaller index
+//   dbscan_flatten  one thread per core cell: is_root flag (the root is the smallest cell index of its component)
+//   dbscan_label    one thread per dynamic cell: core -> rank of its root; border -> smallest rank among its core
+//                   eps-neighbours; no core neighbour -> 0 (noise).  rank = 1-based position of the root among all
+//                   roots in row-major order (an inclusive scan of the root flags, done by the caller).
+// Why this equals sklearn's labelling: sklearn visits points in input (row-major) order, starts cluster k at the k-th
+// still unlabelled core point and grows it completely (depth-first over core points, labelling every neighbour) before
+// it moves on -- so clusters are the connected components of the core graph numbered by their smallest member, and a
+// border point reachable from several clusters keeps the first one that reached it, i.e. the smallest number.
+//
+//   region_moments  one thread per labelled cell: 6 exact integer moments (n, sum r, sum c, sum r^2, sum c^2, sum rc)
+//                   by 64-bit integer atomics (order independent)
+//   region_props    one thread per label: centroid, orientation, axis lengths from the second central moments
+//                   (skimage.measure.regionprops formulas, fp64)
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/liso_flow_cluster.h"
+#include "../../include/liso_iou3d.h"
+
+namespace {
+
+struct Cfg {
+    int batch, gx, gy, win, min_samples;
+    double eps_sqr;
+    float flow_weight;
+};
+
+// squared 5-D distance exactly as the host code builds it: float32 features (centre coordinates, flow_weight * flow)
+// promoted to float64, differences squared and summed in feature order
+__device__ __forceinline__ double dist_sqr(const float* __restrict__ xs, const float* __restrict__ ys,
+                                           const float* __restrict__ flow, float fw, int r0, int c0, size_t i0, int r1, int c1,
+                                           size_t i1) {
+    const double d0 = (double)xs[r0] - (double)xs[r1];
+    const double d1 = (double)ys[c0] - (double)ys[c1];
+    const double d2 = (double)(fw * flow[3 * i0 + 0]) - (double)(fw * flow[3 * i1 + 0]);
+    const double d3 = (double)(fw * flow[3 * i0 + 1]) - (double)(fw * flow[3 * i1 + 1]);
+    const double d4 = (double)(fw * flow[3 * i0 + 2]) - (double)(fw * flow[3 * i1 + 2]);
+    return d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3 + d4 * d4;
+}
+
+template <typename F>
+__device__ __forceinline__ void for_each_neighbour(const Cfg& c, const uint8_t* __restrict__ dyn, const float* __restrict__ xs,
+                                                   const float* __restrict__ ys, const float* __restrict__ flow, int b, int r,
+                                                   int col, F&& f) {
+    const size_t base = (size_t)b * c.gx * c.gy;
+    const size_t me = base + (size_t)r * c.gy + col;
+    const int r_lo = max(r - c.win, 0), r_hi = min(r + c.win, c.gx - 1);
+    const int c_lo = max(col - c.win, 0), c_hi = min(col + c.win, c.gy - 1);
+    for (int rr = r_lo; rr <= r_hi; rr++)
+        for (int cc = c_lo; cc <= c_hi; cc++) {
+            const size_t nb = base + (size_t)rr * c.gy + cc;
+            if (!dyn[nb]) continue;
+            if (dist_sqr(xs, ys, flow, c.flow_weight, r, col, me, rr, cc, nb) <= c.eps_sqr) f(nb);
+        }
+}
+
+__global__ void dbscan_core_kernel(Cfg c, const uint8_t* __restrict__ dyn, const float* __restrict__ xs,
+                                   const float* __restrict__ ys, const float* __restrict__ flow, uint8_t* __restrict__ core,
+                                   int* __restrict__ parent) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t per = (size_t)c.gx * c.gy;
+    if (i >= per * c.batch) return;
+    int is_core = 0;
+    if (dyn[i]) {
+        const int b = (int)(i / per), r = (int)((i % per) / c.gy), col = (int)(i % c.gy);
+        int count = 0;
+        for_each_neighbour(c, dyn, xs, ys, flow, b, r, col, [&](size_t) { count++; });
+        is_core = count >= c.min_samples;
+    }
+    core[i] = (uint8_t)is_core;
+    parent[i] = is_core ? (int)(i % per) : -1;  // per-sample cell index
+}
+
+// parents only ever move to smaller indices; device-scope loads keep concurrent hooks visible (fewer retries)
+__device__ __forceinline__ int find_root(const int* parent, int x) {
+    int p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (p != x) { x = p; p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    return x;
+}
+
+__global__ void dbscan_union_kernel(Cfg c, const uint8_t* __restrict__ dyn, const uint8_t* __restrict__ core,
+                                    const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ flow,
+                                    int* __restrict__ parent) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t per = (size_t)c.gx * c.gy;
+    if (i >= per * c.batch || !core[i]) return;
+    const int b = (int)(i / per), r = (int)((i % per) / c.gy), col = (int)(i % c.gy);
+    int* par = parent + (size_t)b * per;
+    const int me = (int)(i % per);
+    for_each_neighbour(c, dyn, xs, ys, flow, b, r, col, [&](size_t nb) {
+        if (!core[nb]) return;
+        const int other = (int)(nb % per);
+        if (other >= me) return;  // every undirected edge once
+        int x = me, y = other;
+        while (true) {
+            x = find_root(par, x);
+            y = find_root(par, y);
+            if (x == y) break;
+            if (x < y) { const int t = x; x = y; y = t; }  // x: larger root, linked under y
+            const int old = atomicMin(&par[x], y);
+            if (old == x) break;  // x was still a root: linked
+            x = old;              // somebody re-parented x meanwhile: retry from there
+        }
+    });
+}
+
+__global__ void dbscan_flatten_kernel(Cfg c, const uint8_t* __restrict__ core, int* __restrict__ parent,
+                                      int* __restrict__ is_root) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t per = (size_t)c.gx * c.gy;
+    if (i >= per * c.batch) return;
+    int root_flag = 0;
+    if (core[i]) {
+        const int* par = parent + (i / per) * per;
+        const int root = find_root(par, (int)(i % per));
+        root_flag = root == (int)(i % per);  // no path compression: the label pass walks the (short) chains again
+    }
+    is_root[i] = root_flag;
+}
+
+__global__ void dbscan_label_kernel(Cfg c, const uint8_t* __restrict__ dyn, const uint8_t* __restrict__ core,
+                                    const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ flow,
+                                    const int* __restrict__ parent, const int* __restrict__ root_rank, int* __restrict__ labels) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t per = (size_t)c.gx * c.gy;
+    if (i >= per * c.batch) return;
+    int label = 0;
+    if (dyn[i]) {
+        const int b = (int)(i / per), r = (int)((i % per) / c.gy), col = (int)(i % c.gy);
+        const int* par = parent + (size_t)b * per;
+        const int* rank = root_rank + (size_t)b * per;
+        if (core[i]) {
+            label = rank[find_root(par, (int)(i % per))];
+        } else {
+            int best = 0x7fffffff;
+            for_each_neighbour(c, dyn, xs, ys, flow, b, r, col, [&](size_t nb) {
+                if (core[nb]) best = min(best, rank[find_root(par, (int)(nb % per))]);
+            });
+            label = best == 0x7fffffff ? 0 : best;
+        }
+    }
+    labels[i] = label;
+}
+
+__global__ void region_moments_kernel(const int* __restrict__ labels, int batch, int gx, int gy, int max_labels,
+                                      unsigned long long* __restrict__ mom) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t per = (size_t)gx * gy;
+    if (i >= per * batch) return;
+    const int l = labels[i];
+    if (l <= 0 || l > max_labels) return;
+    const unsigned long long r = (i % per) / gy, col = i % gy;
+    unsigned long long* m = mom + ((size_t)(i / per) * max_labels + (l - 1)) * 6;
+    atomicAdd(m + 0, 1ull);
+    atomicAdd(m + 1, r);
+    atomicAdd(m + 2, col);
+    atomicAdd(m + 3, r * r);
+    atomicAdd(m + 4, col * col);
+    atomicAdd(m + 5, r * col);
+}
+
+__global__ void region_props_kernel(const unsigned long long* __restrict__ mom, long n_regions, double* __restrict__ props) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_regions) return;
+    const unsigned long long* m = mom + (size_t)i * 6;
+    double* p = props + (size_t)i * 5;
+    const double n = (double)m[0];
+    if (m[0] == 0) { p[0] = p[1] = p[2] = p[3] = p[4] = 0.0; return; }
+    const double sr = (double)m[1], sc = (double)m[2];
+    const double cr = sr / n, cc = sc / n;  // centroid (row, col)
+    // central second moments, normalised by the area (skimage: inertia_tensor = [[mu02, -mu11], [-mu11, mu20]] / mu00)
+    const double mu20 = ((double)m[3] - sr * sr / n) / n;  // rows
+    const double mu02 = ((double)m[4] - sc * sc / n) / n;  // cols
+    const double mu11 = ((double)m[5] - sr * sc / n) / n;
+    const double a = mu02, b = -mu11, c = mu20;
+    double orientation;
+    if (a - c == 0.0)
+        orientation = b < 0.0 ? -M_PI / 4.0 : M_PI / 4.0;
+    else
+        orientation = 0.5 * atan2(-2.0 * b, c - a);
+    const double tr = a + c, disc = sqrt((a - c) * (a - c) + 4.0 * b * b);
+    const double l1 = fmax(0.5 * (tr + disc), 0.0), l2 = fmax(0.5 * (tr - disc), 0.0);
+    p[0] = cr; p[1] = cc; p[2] = orientation; p[3] = 4.0 * sqrt(l1); p[4] = 4.0 * sqrt(l2);
+}
+
+inline int check_launch() { return hipGetLastError() == hipSuccess ? LISO_OK : LISO_ELAUNCH; }
+inline bool cfg_ok(const liso_dbscan_cfg* c) {
+    return c && c->batch >= 1 && c->gx >= 1 && c->gy >= 1 && c->window >= 0 && c->min_samples >= 1 && c->eps > 0.f &&
+           (long)c->gx * c->gy < (1L << 31);
+}
+inline Cfg to_cfg(const liso_dbscan_cfg* c) {
+    Cfg k;
+    k.batch = c->batch; k.gx = c->gx; k.gy = c->gy; k.win = c->window; k.min_samples = c->min_samples;
+    k.eps_sqr = (double)c->eps * (double)c->eps;
+    k.flow_weight = c->flow_weight;
+    return k;
+}
+
+}  // namespace
+
+extern "C" {
+
+int liso_dbscan_components(const liso_dbscan_cfg* cfg, const uint8_t* dynamic_mask, const float* row_coords,
+                           const float* col_coords, const float* flow, uint8_t* core, int32_t* parent, int32_t* is_root,
+                           void* stream) {
+    if (!cfg_ok(cfg) || !dynamic_mask || !row_coords || !col_coords || !flow || !core || !parent || !is_root) return LISO_EINVAL;
+    const Cfg c = to_cfg(cfg);
+    const size_t total = (size_t)c.batch * c.gx * c.gy;
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    hipStream_t st = (hipStream_t)stream;
+    dbscan_core_kernel<<<blocks, 256, 0, st>>>(c, dynamic_mask, row_coords, col_coords, flow, core, parent);
+    dbscan_union_kernel<<<blocks, 256, 0, st>>>(c, dynamic_mask, core, row_coords, col_coords, flow, parent);
+    dbscan_flatten_kernel<<<blocks, 256, 0, st>>>(c, core, parent, is_root);
+    return check_launch();
+}
+
+int liso_dbscan_labels(const liso_dbscan_cfg* cfg, const uint8_t* dynamic_mask, const float* row_coords, const float* col_coords,
+                       const float* flow, const uint8_t* core, const int32_t* parent, const int32_t* root_rank,
+                       int32_t* labels, void* stream) {
+    if (!cfg_ok(cfg) || !dynamic_mask || !row_coords || !col_coords || !flow || !core || !parent || !root_rank || !labels)
+        return LISO_EINVAL;
+    const Cfg c = to_cfg(cfg);
+    const size_t total = (size_t)c.batch * c.gx * c.gy;
+    dbscan_label_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(c, dynamic_mask, core, row_coords,
+                                                                                       col_coords, flow, parent, root_rank, labels);
+    return check_launch();
+}
+
+int liso_region_props(const int32_t* labels, int batch, int gx, int gy, int max_labels, uint64_t* moments, double* props,
+                      void* stream) {
+    if (!labels || batch < 1 || gx < 1 || gy < 1 || max_labels < 1 || !moments || !props) return LISO_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t total = (size_t)batch * gx * gy;
+    const long regions = (long)batch * max_labels;
+    if (hipMemsetAsync(moments, 0, (size_t)regions * 6 * sizeof(uint64_t), st) != hipSuccess) return LISO_ELAUNCH;
+    region_moments_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(labels, batch, gx, gy, max_labels,
+                                                                          (unsigned long long*)moments);
+    region_props_kernel<<<(unsigned)((regions + 255) / 256), 256, 0, st>>>((const unsigned long long*)moments, regions, props);
+    return check_launch();
+}
+
+}  // extern "C"

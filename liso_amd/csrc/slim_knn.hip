@@ -1,13 +1,17 @@
-// Exact 1-nearest-neighbour search on a uniform xy grid for gfx950.  C ABI + reference lines: include/liso_slim.h.
+// Exact 1-nearest-neighbour search on a uniform grid for gfx950.  C ABI + reference lines: include/liso_slim.h.
 //
-//   knn_count    one thread per reference point: cell id, atomicAdd(count[cell])
-//   knn_scan     one 1024-thread block: exclusive scan of the cell counts (<= 1M cells)
-//   knn_fill     one thread per reference point: position = start[cell] + atomicAdd(cursor[cell]); writes the point
+// Bucket key = (xy cell, z bin): the reference points are counting-sorted by key, so the points of one xy cell are
+// contiguous AND ordered by z bin.  LiDAR clouds are thin in z but full of vertical structure (a wall stacks hundreds of
+// returns into one pillar), so the search walks rings of xy cells and, inside every cell, only reads the z bins that
+// can still hold a closer point than the best found so far.
+//
+//   knn_count    one thread per reference point: key, atomicAdd(count[key])
+//   knn_scan_*   exclusive scan of the key counts (per-1024 block scan, scan of the block totals, add)
+//   knn_fill     one thread per reference point: position = start[key] + atomicAdd(cursor[key]); writes the point
 //                (x, y, z, original index) into the bucketed array -> queries read 16 contiguous bytes per candidate
 //   knn_query    16 lanes per query: ring 0, 1, 2, ... of cells around the query's cell; after ring r every
 //                unvisited point is at least r*cell + (distance to the own cell's nearest edge) away, so the search
 //                stops as soon as best <= that bound (exact), or when the rings cover the whole grid.
-// LiDAR clouds are thin in z, so a 2-D grid with the full 3-D distance test is both exact and compact.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -25,6 +29,11 @@ __device__ __forceinline__ int cell_of(const liso_knn_grid& g, float x, float y,
     return *cx * g.ny + *cy;
 }
 
+// z bin, clamped: points below / above the binned range live in the first / last bin
+__device__ __forceinline__ int zbin_of(const liso_knn_grid& g, float z) {
+    return clampi((int)floorf((z - g.z_min) / g.z_cell), 0, g.nz - 1);
+}
+
 __global__ void knn_count_kernel(liso_knn_grid g, const float* __restrict__ ref, int stride, int n, int* __restrict__ count,
                                  int* __restrict__ cell_of_pt) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -32,7 +41,7 @@ __global__ void knn_count_kernel(liso_knn_grid g, const float* __restrict__ ref,
     int cx, cy;
     const float x = ref[(size_t)i * stride], y = ref[(size_t)i * stride + 1], z = ref[(size_t)i * stride + 2];
     if (!(isfinite(x) && isfinite(y) && isfinite(z))) { cell_of_pt[i] = -1; return; }  // padding rows (NaN) are never neighbours
-    const int c = cell_of(g, x, y, &cx, &cy);
+    const int c = cell_of(g, x, y, &cx, &cy) * g.nz + zbin_of(g, z);
     cell_of_pt[i] = c;
     atomicAdd(&count[c], 1);
 }
@@ -59,19 +68,28 @@ __global__ __launch_bounds__(1024) void knn_scan_block_kernel(const int* __restr
 
 __global__ __launch_bounds__(1024) void knn_scan_tot_kernel(int* __restrict__ block_tot, int nblocks) {
     __shared__ int wsum[16];
+    __shared__ int carry;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int v = (int)threadIdx.x < nblocks ? block_tot[threadIdx.x] : 0;
-    int incl = v;
-    for (int off = 1; off < 64; off <<= 1) {
-        const int t = __shfl_up(incl, off);
-        if (lane >= off) incl += t;
-    }
-    if (lane == 63) wsum[wave] = incl;
+    if (threadIdx.x == 0) carry = 0;
     __syncthreads();
-    int base = 0;
-    for (int w = 0; w < wave; w++) base += wsum[w];
-    if ((int)threadIdx.x < nblocks) block_tot[threadIdx.x] = base + incl - v;  // exclusive
-    if ((int)threadIdx.x == nblocks - 1) block_tot[nblocks] = base + incl;     // grand total
+    for (int c0 = 0; c0 < nblocks; c0 += 1024) {  // chunks of 1024 block totals, running carry
+        const int i = c0 + (int)threadIdx.x;
+        const int v = i < nblocks ? block_tot[i] : 0;
+        int incl = v;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int base = carry;
+        for (int w = 0; w < wave; w++) base += wsum[w];
+        if (i < nblocks) block_tot[i] = base + incl - v;  // exclusive
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = base + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) block_tot[nblocks] = carry;  // grand total
 }
 
 __global__ __launch_bounds__(1024) void knn_scan_add_kernel(int* __restrict__ start, int cells, const int* __restrict__ block_tot,
@@ -125,6 +143,10 @@ __global__ __launch_bounds__(256) void knn_query_kernel(liso_knn_grid g, const i
     for (int r = 0; r <= rmax; r++) {
         const int ncell = r == 0 ? 1 : 8 * r;
         const int x0 = cx - r, x1 = cx + r, y0 = cy - r, y1 = cy + r;
+        // only z bins that can hold a point closer than the best so far (|dz| <= sqrt(best)); everything on ring 0
+        const float dzmax = sqrtf(best) * 1.0001f + 1e-6f;  // inf before the first hit; padded against sqrt rounding
+        const int zlo = best == INFINITY ? 0 : zbin_of(g, qz - dzmax);
+        const int zhi = best == INFINITY ? g.nz - 1 : zbin_of(g, qz + dzmax);
         for (int t0 = 0; t0 < ncell; t0 += kGroup) {
             const int t = t0 + sub;
             int s = 0, e = 0;
@@ -135,7 +157,11 @@ __global__ __launch_bounds__(256) void knn_query_kernel(liso_knn_grid g, const i
                     x = side == 0 ? x0 + k : (side == 1 ? x1 : (side == 2 ? x1 - k : x0));
                     y = side == 0 ? y0 : (side == 1 ? y0 + k : (side == 2 ? y1 : y1 - k));
                 }
-                if (x >= 0 && x < g.nx && y >= 0 && y < g.ny) { s = start[x * g.ny + y]; e = start[x * g.ny + y + 1]; }
+                if (x >= 0 && x < g.nx && y >= 0 && y < g.ny) {
+                    const int c = (x * g.ny + y) * g.nz;
+                    s = start[c + zlo];
+                    e = start[c + zhi + 1];
+                }
             }
             unsigned nonempty = (unsigned)(__ballot(e > s) >> group_shift) & 0xffffu;
             while (nonempty) {
@@ -170,10 +196,12 @@ __global__ __launch_bounds__(256) void knn_query_kernel(liso_knn_grid g, const i
 
 inline int check_launch() { return hipGetLastError() == hipSuccess ? LISO_OK : LISO_ELAUNCH; }
 inline bool grid_ok(const liso_knn_grid* g) {
-    return g && g->cell > 0.f && g->nx >= 1 && g->ny >= 1 && (long)g->nx * g->ny <= (1L << 20);
+    return g && g->cell > 0.f && g->z_cell > 0.f && g->nx >= 1 && g->ny >= 1 && g->nz >= 1 &&
+           (long)g->nx * g->ny * g->nz <= (1L << 24);
 }
-// workspace: count[cells] | cursor[cells] | start[cells+1] | block_tot[1026] | cell_of_pt[n] | (pad to 16 B) bucketed[n] float4
-constexpr int kTotSlots = 1026;
+inline int n_keys(const liso_knn_grid* g) { return g->nx * g->ny * g->nz; }
+// workspace: count[keys] | cursor[keys] | start[keys+1] | block_tot[kTotSlots] | key_of_pt[n] | (pad to 16 B) bucketed[n] float4
+constexpr int kTotSlots = (1 << 14) + 2;  // 2^24 keys / 1024 per scan block, + grand total
 inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
 
 }  // namespace
@@ -182,7 +210,7 @@ extern "C" {
 
 size_t liso_knn_workspace_bytes(const liso_knn_grid* grid, int n_ref) {
     if (!grid_ok(grid) || n_ref < 0) return 0;
-    const size_t cells = (size_t)grid->nx * grid->ny;
+    const size_t cells = (size_t)n_keys(grid);
     return align16((3 * cells + 1 + kTotSlots + (size_t)n_ref) * sizeof(int)) + (size_t)n_ref * sizeof(float4) + 16;
 }
 
@@ -191,7 +219,7 @@ int liso_knn_build_f32(const liso_knn_grid* grid, const float* ref, int ref_stri
     if (!grid_ok(grid) || n_ref < 0 || ref_stride < 3 || !workspace || (n_ref > 0 && !ref)) return LISO_EINVAL;
     if (workspace_bytes < liso_knn_workspace_bytes(grid, n_ref)) return LISO_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    const int cells = grid->nx * grid->ny;
+    const int cells = n_keys(grid);
     int* count = (int*)workspace;
     int* cursor = count + cells;
     int* start = cursor + cells;
@@ -215,7 +243,7 @@ int liso_knn_query_f32(const liso_knn_grid* grid, const float* ref, int ref_stri
     if (!grid_ok(grid) || n_ref < 0 || n_query < 0 || query_stride < 3 || !workspace) return LISO_EINVAL;
     if (n_query == 0) return LISO_OK;
     if (!query || !index) return LISO_EINVAL;
-    const int cells = grid->nx * grid->ny;
+    const int cells = n_keys(grid);
     const int* start = (const int*)workspace + 2 * (size_t)cells;
     const float4* bucketed = (const float4*)((const char*)workspace + align16((3 * (size_t)cells + 1 + kTotSlots + (size_t)n_ref) * sizeof(int)));
     knn_query_kernel<<<(unsigned)(((long)n_query * kGroup + 255) / 256), 256, 0, (hipStream_t)stream>>>(*grid, start, bucketed, n_ref, query, query_stride,

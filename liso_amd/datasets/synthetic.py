@@ -156,3 +156,39 @@ def slim_pair(seed, device, n_points=120000, grid=512, bev_range_m=100.0):
                 "gt": {"odom_ta_tb": odom[None]}}
 
     return sample(clouds[0], T01), sample(clouds[1], torch.linalg.inv(T01))
+
+
+def cluster_sample(seed, device, batch=1, n_points=120000, grid=512, bev_range_m=100.0, time_delta_s=0.1):
+    """A batch for FlowClusterDetector.forward in the reference's sample layout (flow_cluster_detector.py:94-103):
+    `pcl_ta` = {pcl [B,N,4] without ground, pcl_is_valid, pillar_coors}, `pcl_full_w_ground_ta` [B,M,4],
+    `gt` = {flow_ta_tb [B,N,3] true per-point flow, odom_ta_tb [B,4,4] fp64}, `src_trgt_time_delta_s` [B].
+    Also returns the scene boxes at t0 and their per-sweep displacement for checking the mined boxes."""
+    gen = torch.Generator(device="cpu").manual_seed(seed + 177)
+    half = bev_range_m / 2
+    pcls, flows, odoms, full, scenes = [], [], [], [], []
+    for b in range(batch):
+        boxes, speed, ego = make_scene(seed * 100 + b, device, n_boxes=30)
+        cloud, obj = render(boxes, device, seed * 100 + b, n_points=120000)
+        T01 = _se2(float(ego[0]), float(ego[1]), float(ego[2]), device)
+        disp = torch.zeros(cloud.shape[0], 3, device=device)
+        on = obj >= 0
+        k = obj.clamp(min=0)
+        disp[:, 0] = torch.where(on, speed[k] * torch.cos(boxes[k, 6]), torch.zeros_like(disp[:, 0]))
+        disp[:, 1] = torch.where(on, speed[k] * torch.sin(boxes[k, 6]), torch.zeros_like(disp[:, 1]))
+        moved = torch.cat([cloud[:, :3] + disp, torch.ones_like(cloud[:, :1])], dim=-1).double()
+        flow = ((torch.linalg.inv(T01) @ moved.T).T[:, :3] - cloud[:, :3].double()).float()
+        keep = (cloud[:, 2] > -1.45) & (cloud[:, :2].abs().amax(dim=1) < half - 1e-3)
+        c, f = cloud[keep], flow[keep]
+        n = c.shape[0]
+        idx = torch.randperm(n, generator=gen)[:n_points].to(device) if n >= n_points else \
+            torch.cat([torch.arange(n), torch.randint(0, n, (n_points - n,), generator=gen)]).to(device)
+        pcls.append(c[idx].contiguous()), flows.append(f[idx].contiguous()), odoms.append(T01), full.append(cloud)
+        scenes.append((boxes, speed))
+    pcl = torch.stack(pcls)
+    coors = ((pcl[..., :2] + half) / bev_range_m * grid).to(torch.int32)
+    sample = {"pcl_ta": {"pcl": pcl, "pcl_is_valid": torch.ones(pcl.shape[:2], dtype=torch.bool, device=device),
+                         "pillar_coors": coors},
+              "pcl_full_w_ground_ta": torch.stack(full),
+              "gt": {"flow_ta_tb": torch.stack(flows), "odom_ta_tb": torch.stack(odoms)},
+              "src_trgt_time_delta_s": torch.full((batch,), time_delta_s, device=device)}
+    return sample, scenes

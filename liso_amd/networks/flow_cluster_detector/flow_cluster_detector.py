@@ -1,10 +1,13 @@
-"""Flow -> pseudo-boxes.  Mirror of liso/networks/flow_cluster_detector/flow_cluster_detector.py
-(`fit_bev_box_z_and_height_using_points_in_box` now; the detector class is assembled in this module as its stages
-land: BEV dynamicness (D1), clustering (D2), z-fit (D3), Kabsch heading/velocity (D4-D6))."""
+"""Flow -> pseudo-boxes.  Mirror of liso/networks/flow_cluster_detector/flow_cluster_detector.py: `FlowClusterDetector`
+(:14-336) and `fit_bev_box_z_and_height_using_points_in_box` (:339-384), built from the device stages BEV dynamicness
+(D1), clustering + region moments (D2), z-fit (D3), Kabsch heading/velocity (D4-D6).  TensorBoard image logging
+(:250-309) is not part of the path."""
+import numpy as np
 import torch
 
 from liso_amd import _lib as L
-from liso_amd.kabsch.shape_utils import Shape
+from liso_amd.kabsch.shape_utils import Shape, extract_motion_in_pred_box_coordinates
+from liso_amd.utils.bev_flow_utils import get_bev_dynamic_flow_map_from_pcl_flow_and_odom
 
 
 @torch.no_grad()
@@ -31,3 +34,164 @@ def fit_bev_box_z_and_height_using_points_in_box(pcl, boxes: Shape, box_height=1
             L.ptr(pts), pts.shape[-1], pts.shape[0], L.ptr(pos), pos.shape[-1], L.ptr(dims), dims.shape[-1], L.ptr(rot), K,
             float(box_height), L.ptr(num), L.ptr(fz), L.ptr(fh), L.ptr(ws), nbytes, L.stream_ptr())), "fit_box_z")
     return num, fz, fh
+
+
+# ---- clustering block (reference :139-189) ---------------------------------------------------------------------------
+@torch.no_grad()
+def cluster_dynamic_pillars(dynamic_mask, bev_nonrigid_flow, row_coords_m, col_coords_m, eps=1.0, min_samples=5,
+                            flow_similarity_importance=2.0):
+    """DBSCAN(eps, min_samples) of the dynamic pillars in (x, y, w fx, w fy, w fz) -- reference :151-172, on the device.
+    dynamic_mask [B,gx,gy] bool, bev_nonrigid_flow [B,gx,gy,3] -> (labels int32 [B,gx,gy] with 0 = background/noise and
+    k = sklearn label k-1, num_labels int64 [B])."""
+    L.require_cuda(dynamic_mask, bev_nonrigid_flow)
+    B, gx, gy = dynamic_mask.shape
+    dev = dynamic_mask.device
+    dyn = dynamic_mask.to(torch.uint8).contiguous()
+    flow = bev_nonrigid_flow.float().contiguous()
+    assert flow.shape == (B, gx, gy, 3), flow.shape
+    xs, ys = row_coords_m.float().contiguous(), col_coords_m.float().contiguous()
+    pitch = min(float(xs[1] - xs[0]) if gx > 1 else eps, float(ys[1] - ys[0]) if gy > 1 else eps)
+    cfg = L.DbscanCfg(B, gx, gy, int(eps / pitch) + 1, int(min_samples), float(eps), float(flow_similarity_importance))
+    core = torch.empty((B, gx, gy), dtype=torch.uint8, device=dev)
+    parent = torch.empty((B, gx, gy), dtype=torch.int32, device=dev)
+    is_root = torch.empty((B, gx, gy), dtype=torch.int32, device=dev)
+    labels = torch.empty((B, gx, gy), dtype=torch.int32, device=dev)
+    lib = L.lib()
+    import ctypes
+    with torch.cuda.device(dev):
+        L.check(L.TIMER.launch("dbscan_components", lambda: lib.liso_dbscan_components(
+            ctypes.byref(cfg), L.ptr(dyn), L.ptr(xs), L.ptr(ys), L.ptr(flow), L.ptr(core), L.ptr(parent), L.ptr(is_root),
+            L.stream_ptr())), "dbscan_components")
+        rank = torch.cumsum(is_root.view(B, -1), dim=1, dtype=torch.int32).view(B, gx, gy).contiguous()
+        L.check(L.TIMER.launch("dbscan_labels", lambda: lib.liso_dbscan_labels(
+            ctypes.byref(cfg), L.ptr(dyn), L.ptr(xs), L.ptr(ys), L.ptr(flow), L.ptr(core), L.ptr(parent), L.ptr(rank),
+            L.ptr(labels), L.stream_ptr())), "dbscan_labels")
+    return labels, rank.view(B, -1)[:, -1].long()
+
+
+@torch.no_grad()
+def label_region_props(labels, max_labels):
+    """skimage.measure.regionprops(label_img) for labels 1..max_labels (reference :175-189) ->
+    float64 [B,max_labels,5] = (centroid_row, centroid_col, orientation, axis_major_length, axis_minor_length)"""
+    L.require_cuda(labels)
+    B, gx, gy = labels.shape
+    lab = labels.to(torch.int32).contiguous()
+    mom = torch.empty((B, max_labels, 6), dtype=torch.int64, device=lab.device)
+    props = torch.empty((B, max_labels, 5), dtype=torch.float64, device=lab.device)
+    with torch.cuda.device(lab.device):
+        L.check(L.TIMER.launch("region_props", lambda: L.lib().liso_region_props(
+            L.ptr(lab), B, gx, gy, max_labels, L.ptr(mom), L.ptr(props), L.stream_ptr())), "region_props")
+    return props
+
+
+class FlowClusterDetector(torch.nn.Module):
+    """reference :14-336 -- point flow -> dynamic BEV pillars -> DBSCAN clusters -> one box per cluster (moments),
+    z/height from the points inside, plausibility filters, heading/velocity from a per-box Kabsch fit.
+    Every stage runs on the device; the only host round trips are the two box counts (clusters, surviving boxes) that
+    size the padded `Shape`."""
+
+    def __init__(self, cfg, min_num_pts_per_box=10, max_box_len_m=7.0, aspect_ratio_max=4.0, min_box_area_m2=0.35,
+                 min_box_volume_m3=0.5) -> None:
+        super().__init__()
+        from liso_amd.kabsch.kabsch_mask import KabschDecoder
+        from liso_amd.utils.bev_utils import get_bev_setup_params
+
+        tcfg = cfg.data.tracking_cfg
+        if getattr(tcfg, "flow_cluster_detector_ignore_min_box_size_limits", False):  # reference :24-35
+            min_box_area_m2, min_box_volume_m3 = 0.0, 0.0
+        if getattr(tcfg, "flow_cluster_detector_ignore_max_box_size_limits", False):  # reference :36-46
+            aspect_ratio_max, max_box_len_m = 1000.0, 1000.0
+        self.min_box_area_m2, self.min_box_volume_m3 = min_box_area_m2, min_box_volume_m3
+        self.min_num_pts_per_box, self.aspect_ratio_max, self.max_box_len_m = min_num_pts_per_box, aspect_ratio_max, max_box_len_m
+        self.cfg = cfg
+        (self.bev_range_m_np, self.img_grid_size_np, self.bev_pixel_per_meter_res_np, self.pcl_bev_center_coords_homog_np,
+         torch_params) = get_bev_setup_params(cfg)
+        for name, param in torch_params.items():
+            self.register_parameter(name, torch.nn.Parameter(param, requires_grad=False))
+        self.min_residual_flow_thresh_mps = 1.0  # 0.1 m displacement in 100 ms (reference :70)
+        self.bev_img_grid_size = np.array(self.cfg.data.img_grid_size)
+        self.kabsch_decoder = KabschDecoder(cfg)
+
+    @torch.no_grad()
+    def forward(self, sample_data_ta, writer=None, writer_prefix: str = "", global_step: int = None, is_batched=True) -> Shape:
+        pcl = sample_data_ta["pcl_ta"]["pcl"]
+        pcl_w_ground = sample_data_ta["pcl_full_w_ground_ta"]
+        pillar_coors = sample_data_ta["pcl_ta"]["pillar_coors"]
+        point_flow = sample_data_ta[self.cfg.data.flow_source]["flow_ta_tb"]
+        odom_ta_tb = sample_data_ta[self.cfg.data.odom_source]["odom_ta_tb"]
+        thresh = sample_data_ta["src_trgt_time_delta_s"] * self.min_residual_flow_thresh_mps
+        if is_batched:
+            pcl_is_valid = sample_data_ta["pcl_ta"]["pcl_is_valid"]
+        else:  # reference :105-112
+            pcl_is_valid = torch.ones_like(pcl[:, 0], dtype=torch.bool)[None]
+            pcl, pcl_w_ground, pillar_coors = pcl[None], pcl_w_ground[None], pillar_coors[None]
+            point_flow, odom_ta_tb, thresh = point_flow[None], odom_ta_tb[None], thresh[None]
+        dev = pcl.device
+        bev_dynamicness, bev_nonrigid_flow = get_bev_dynamic_flow_map_from_pcl_flow_and_odom(
+            pcl_is_valid=pcl_is_valid, pcl=pcl, pillar_coors=pillar_coors, point_flow=point_flow, odom_ta_tb=odom_ta_tb,
+            target_shape=self.bev_img_grid_size, return_nonrigid_bev_flow=True)
+        dynamic_mask = torch.squeeze(bev_dynamicness, dim=-1) > thresh.to(dev)[..., None, None]
+        centers = self.pcl_bev_center_coords_homog  # [gx,gy,4] float32; x depends on the row only, y on the column only
+        labels, num_labels = cluster_dynamic_pillars(dynamic_mask, bev_nonrigid_flow, centers[:, 0, 0], centers[0, :, 1])
+        self.last_bev_labels = labels
+        B = labels.shape[0]
+        k_max = int(num_labels.max()) if B > 0 else 0  # host round trip 1: sizes the padded box arrays
+        if k_max == 0:
+            boxes = Shape.from_list_of_shapes([Shape.createEmpty().to_tensor().to(dev) for _ in range(B)], numeric_padding_value=0.0)
+            return boxes if is_batched else boxes[0]
+        props = label_region_props(labels, k_max)  # [B,K,5] float64
+        exists = torch.arange(k_max, device=dev)[None, :] < num_labels[:, None]
+        gx, gy = centers.shape[:2]
+        # reference :176-180: centroid -> int (truncation), clipped, then the centre of THAT pillar
+        pix = props[..., 0:2].to(torch.int64).clamp(min=0, max=min(gx, gy) - 1)
+        box_center_m = centers[pix[..., 0], pix[..., 1], 0:2]                                   # float32 [B,K,2]
+        rot = props[..., 2:3]                                                                    # float64 [B,K,1]
+        box_dims = props[..., 3:5] * 1.0 / self.bev_pixel_per_meter_resolution.to(dev)          # float64 [B,K,2]
+        assert box_dims.shape[-1] == 2, "otherwise box fitting will use bad box size from clustering!"
+        num_pts, fit_z, fit_h = [], [], []
+        for b in range(B):
+            pb = Shape(pos=box_center_m[b], dims=box_dims[b], rot=rot[b], probs=torch.ones_like(rot[b]))
+            n, z, h = fit_bev_box_z_and_height_using_points_in_box(pcl_w_ground[b][:, :3], pb, box_height=1000.0)
+            num_pts.append(n), fit_z.append(z), fit_h.append(h)
+        num_pts, fit_z, fit_h = torch.stack(num_pts), torch.stack(fit_z), torch.stack(fit_h)
+        # plausibility filters, reference :208-237
+        enough_points = num_pts >= self.min_num_pts_per_box
+        aspect_ratio = box_dims[..., 0] / torch.max(box_dims[..., 1], 0.001 * torch.ones_like(box_dims[..., 1]))
+        aspect_ok = aspect_ratio <= self.aspect_ratio_max
+        not_too_large = box_dims[..., 0] <= self.max_box_len_m
+        footprint_ok = torch.prod(box_dims[..., :2], dim=-1) > self.min_box_area_m2
+        dims3 = torch.cat([box_dims, fit_h[..., None].to(box_dims.dtype)], dim=-1)
+        pos3 = torch.cat([box_center_m, fit_z[..., None].to(box_center_m.dtype)], dim=-1)
+        volume_ok = torch.prod(dims3, dim=-1) > self.min_box_volume_m3
+        valid = exists & enough_points & aspect_ok & not_too_large & footprint_ok & volume_ok
+        # reference :239-248,311: drop the rejected boxes of every sample, pad the batch with zeros
+        counts = valid.sum(dim=1)
+        order = torch.argsort((~valid).to(torch.uint8), dim=1, stable=True)  # survivors first, label order kept
+        s_max = int(counts.max())  # host round trip 2
+        order = order[:, :s_max]
+        keep = torch.arange(s_max, device=dev)[None, :] < counts[:, None]
+
+        def take(t, pad):
+            g = torch.gather(t, 1, order[..., None].expand(-1, -1, t.shape[-1]))
+            return torch.where(keep[..., None], g, torch.as_tensor(pad, dtype=t.dtype, device=dev))
+
+        from liso_amd.kabsch.shape_utils import INVALID_CLASS_ID, UNKNOWN_CLASS_ID
+        probs = torch.ones_like(rot)
+        boxes = Shape(pos=take(pos3, 0.0), dims=take(dims3, 0.0), rot=take(rot, 0.0), probs=take(probs, 0.0),
+                      velo=torch.zeros((B, s_max, 1), dtype=probs.dtype, device=dev), valid=keep,
+                      class_id=torch.where(keep[..., None], UNKNOWN_CLASS_ID, INVALID_CLASS_ID).to(torch.int32),
+                      difficulty=torch.where(keep[..., None], 1, INVALID_CLASS_ID).to(torch.int32))
+        if s_max > 0:
+            # adapt the rotation of the box to the direction of the flow (reference :312-331)
+            fg_trafos, _, _, bg_trafo, _ = self.kabsch_decoder.get_kabsch_trafos_from_point_flow(
+                point_cloud_ta=pcl[..., :3], valid_mask_ta=pcl_is_valid, pointwise_flow_ta_tb=point_flow, pred_boxes_ta=boxes)
+            box_translation, _ = extract_motion_in_pred_box_coordinates(boxes, fg_trafos, bg_trafo)
+            delta_angle = torch.atan2(box_translation[..., [1]], box_translation[..., [0]])
+            box_velo = torch.zeros_like(boxes.probs)
+            box_velo[..., 0] = torch.linalg.norm(box_translation, dim=-1)
+            boxes.rot = boxes.rot + delta_angle
+            boxes.velo = box_velo
+        if not is_batched:
+            boxes = boxes[0]
+            assert len(boxes.shape) == 1, boxes.shape
+        return boxes

@@ -13,12 +13,12 @@ from liso_amd import _lib as L
 
 
 class _Grid:
-    def __init__(self, ref, lo, hi, cell, max_cells_per_side):
+    def __init__(self, ref, lo, hi, cell, max_cells_per_side, z_min, z_cell, nz):
         ext = max(hi[0] - lo[0], hi[1] - lo[1], 1e-3)
         cell = max(cell, ext / max_cells_per_side)
         nx = max(1, int((hi[0] - lo[0]) / cell) + 1)
         ny = max(1, int((hi[1] - lo[1]) / cell) + 1)
-        self.grid = L.KnnGrid(lo[0], lo[1], cell, nx, ny)
+        self.grid = L.KnnGrid(lo[0], lo[1], cell, nx, ny, z_min, z_cell, nz)
         lib = L.lib()
         n = ref.shape[0]
         nbytes = lib.liso_knn_workspace_bytes(ctypes.byref(self.grid), n)
@@ -30,7 +30,8 @@ class _Grid:
 class KnnIndex:
     """Device-resident two-level uniform-grid index over one reference cloud; reusable across queries.
     fine grid (0.2 m cells): dense near field resolved in 1-2 rings; coarse grid (2 m cells): the few queries that land in
-    empty space.  Both passes are exact; the coarse pass only touches rows the fine pass could not prove."""
+    empty space.  Both passes are exact; the coarse pass only touches rows the fine pass could not prove.  Inside every
+    xy cell the points are ordered by z bin, so a query next to a wall reads only the slice of the stack it can reach."""
 
     FINE_RINGS = 6
 
@@ -47,8 +48,9 @@ class KnnIndex:
         else:
             lo, hi = [0.0, 0.0], [1.0, 1.0]
         with torch.cuda.device(ref.device):
-            self.fine = _Grid(self.ref, lo, hi, cell, 1000)
-            self.coarse = _Grid(self.ref, lo, hi, coarse_cell, 1000)
+            # z bins over [-4 m, 4 m) (clamped outside): 0.25 m inside the fine cells, 2 m inside the coarse ones
+            self.fine = _Grid(self.ref, lo, hi, cell, 700, -4.0, 0.25, 32)
+            self.coarse = _Grid(self.ref, lo, hi, coarse_cell, 700, -4.0, 2.0, 4)
 
     def query(self, x: torch.Tensor, return_dist_sqr=False):
         q = x.detach().float().contiguous()

@@ -49,6 +49,9 @@ def default_cfg(grid=512, bev_range_m=100.0, use_lidar_intensity=True):
             "use_lidar_intensity": use_lidar_intensity,     # :47
             "limit_pillar_height": True,                    # :115
             "pillar_height_range_m": (-2.0, 1.0),           # :117-119
+            "flow_source": "gt", "odom_source": "gt",       # :111-112
+            "tracking_cfg": {"min_points_in_box": 20, "max_num_boxes_after_nms": 100, "max_num_boxes_before_nms": 1000,  # :21-34
+                             "flow_cluster_detector_min_obj_speed_mps": 1.0},
         },
         "network": {
             "name": "centerpoint",
