@@ -11,6 +11,8 @@ on one pair of synthetic KITTI-shaped 120k-point clouds already resident in HBM,
 `slim_RAFT batch_size_one`; a step consumes 2 frames.
 `--workload detector` (configs[2]): one CenterPoint-pillar detector train step (voxelise -> fused PFN/scatter -> BEV
 backbone -> CenterHead -> decode -> loss -> backward -> [all-reduce] -> AdamW -> OneCycleLR), B=4 clouds per GPU.
+`--workload loop` (configs[3]): the fused LISO iteration -- SLIM forward (no_grad) -> flow clusters (DBSCAN) -> NMS ->
+target maps -> detector train step, one sweep pair per GPU.
 Weak scaling: per-GPU work fixed, samples sharded across ranks by seed, the only collective is the gradient
 all-reduce.  Rank 0 prints ONE JSON line.
 """
@@ -38,7 +40,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--workload", default="slim", choices=["slim", "detector"])
+    ap.add_argument("--workload", default="slim", choices=["slim", "detector", "loop"])
     ap.add_argument("--batch", type=int, default=None, help="detector workload: clouds per GPU (default 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
@@ -65,6 +67,18 @@ SLIM_KERNELS = {
     "corr_lookup_fwd": "corr_lookup_fwd_kernel (on-the-fly 4-level correlation + bilinear lookup)",
     "corr_lookup_bwd": "corr_lookup_bwd_kernel (adjoint of the lookup into fmap1 / pooled fmap2 gradients)",
     "knn_query": "knn_query_kernel (exact 1-NN, two-level bucket grid, 16 lanes per query)",
+}
+
+
+LOOP_KERNELS = {  # name -> (description, algorithmic bytes per launch at B=1, N=120k, G=512)
+    "pfn_forward_scatter": ("pfn_forward_dense_kernel (fused decorate+Linear+BN+ReLU+max+scatter)", None),
+    "corr_lookup_fwd": (SLIM_KERNELS["corr_lookup_fwd"], None),
+    "bev_dynamic_flow": ("bev_scatter_kernel + bev_mean_kernel (non-rigid flow, fixed-point scatter-mean)",
+                         N_POINTS * (12 + 12 + 8 + 1) + GRID * GRID * 16),
+    "dbscan_components": ("dbscan core/union/flatten kernels (grid-window DBSCAN)", GRID * GRID * (1 + 12 + 1 + 4 + 4)),
+    "dbscan_labels": ("dbscan_label_kernel", GRID * GRID * (1 + 12 + 1 + 4 + 4 + 4)),
+    "kabsch_trafos": ("kabsch_moments_kernel + kabsch_solve_kernel (soft masks + weighted Kabsch)", N_POINTS * (12 + 8 + 1)),
+    "fit_box_z": ("fit_z_kernel (points-in-box z extent)", N_POINTS * 12),
 }
 
 
@@ -121,6 +135,17 @@ def main():
         s0, s1 = slim_pair(2 + rank, dev, n_points=N_POINTS, grid=GRID, bev_range_m=BEV_RANGE)
         step = lambda: trainer.step(s0, s1)  # noqa: E731
         frames_per_step, timed = 2 * batch, list(SLIM_KERNELS)
+    elif args.workload == "loop":
+        from liso_amd.datasets.synthetic import slim_pair
+        from liso_amd.trainer import LisoLoopTrainer
+
+        batch = 1
+        dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+        cfg = apply_slim_simple_knn_training(cfg)
+        trainer = LisoLoopTrainer(cfg, dev, compute_dtype=dtype, total_steps=args.steps + args.warmup + 8)
+        s0, s1 = slim_pair(2 + rank, dev, n_points=N_POINTS, grid=GRID, bev_range_m=BEV_RANGE)
+        step = lambda: trainer.step(s0, s1)  # noqa: E731
+        frames_per_step, timed = 2, list(LOOP_KERNELS)
     else:
         from liso_amd.datasets.synthetic import detector_batch
         from liso_amd.trainer import DetectorTrainer
@@ -157,7 +182,15 @@ def main():
 
     if rank == 0:
         durs = {k: L.TIMER.durations_ms(k) for k in timed}
-        if args.workload == "slim":
+        if args.workload == "loop":
+            key = max(durs, key=lambda k: sum(durs[k]))
+            alg_all = dict(slim_algorithmic_bytes(1, N_POINTS, GRID))
+            alg_all["pfn_forward_scatter"] = pfn_algorithmic_bytes(1, N_POINTS, GRID, 4)
+            alg = LOOP_KERNELS[key][1] or alg_all[key]
+            kname = LOOP_KERNELS[key][0]
+            workload = ("fused LISO iteration (BASELINE configs[3]): SLIM fwd (no_grad) -> FlowClusterDetector (DBSCAN) -> NMS "
+                        "-> target maps -> CenterPoint-pillar train step, one 120k-pt sweep pair per GPU, 512x512 BEV")
+        elif args.workload == "slim":
             alg_all = slim_algorithmic_bytes(batch, N_POINTS, GRID)
             key = max(durs, key=lambda k: sum(durs[k]))  # the hand-written kernel with the largest share of the step
             alg, kname = alg_all[key], SLIM_KERNELS[key]
@@ -195,8 +228,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             if args.workload == "slim":
                 line["cpu_baseline"] = cpu_baseline_slim(cfg, trainer, s0, s1)
-            else:
+            elif args.workload == "detector":
                 line["cpu_baseline"] = cpu_baseline_detector(trainer, pcls, targets)
+        if args.workload == "loop":
+            line["mined_boxes_last_step"] = int(trainer.last_boxes.valid.sum())
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

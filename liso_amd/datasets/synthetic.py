@@ -140,22 +140,23 @@ def slim_pair(seed, device, n_points=120000, grid=512, bev_range_m=100.0):
     boxes0, speed, ego = make_scene(seed, device, n_boxes=30)
     boxes1 = move_scene(boxes0, speed, ego)
     # denser ray fan than the 64x1875 detector input so that 120k non-ground points remain (rendered twice, merged)
-    clouds = []
+    clouds, with_ground = [], []
     for bx, sd in ((boxes0, seed), (boxes1, seed + 1)):
         a, _ = render(bx, device, sd, n_points=120000)
         b, _ = render(bx, device, sd + 1000, n_points=120000, noise=0.03)
         b[:, :2] += 0.011  # decorrelate the two fans
         clouds.append(_loss_cloud(torch.cat([a, b]), n_points, grid, bev_range_m, gen))
+        with_ground.append(a)
     T01 = _se2(float(ego[0]), float(ego[1]), float(ego[2]), device)
 
-    def sample(cloud, odom):
+    def sample(cloud, full, odom):
         coors = ((cloud[:, :2] + bev_range_m / 2) / bev_range_m * grid).to(torch.int32)
-        return {"pcl_full_no_ground_ta": [cloud],
+        return {"pcl_full_no_ground_ta": [cloud], "pcl_full_w_ground_ta": full[None],
                 "pcl_ta": {"pcl": cloud[None], "pcl_is_valid": torch.ones(1, cloud.shape[0], dtype=torch.bool, device=device),
                            "pillar_coors": coors[None]},
-                "gt": {"odom_ta_tb": odom[None]}}
+                "gt": {"odom_ta_tb": odom[None]}, "src_trgt_time_delta_s": torch.full((1,), 0.1, device=device)}
 
-    return sample(clouds[0], T01), sample(clouds[1], torch.linalg.inv(T01))
+    return sample(clouds[0], with_ground[0], T01), sample(clouds[1], with_ground[1], torch.linalg.inv(T01))
 
 
 def cluster_sample(seed, device, batch=1, n_points=120000, grid=512, bev_range_m=100.0, time_delta_s=0.1):

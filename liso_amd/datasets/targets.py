@@ -42,8 +42,8 @@ def render_center_targets(boxes_pos, boxes_dims, boxes_rot, boxes_valid, grid_si
     res = torch.tensor([H / bev_range_m[0], W / bev_range_m[1]], device=dev)
     ij = ((boxes_pos[..., :2] + torch.tensor(bev_range_m, device=dev) / 2) * res).long()
     ok = boxes_valid & (ij[..., 0] >= 0) & (ij[..., 0] < H) & (ij[..., 1] >= 0) & (ij[..., 1] < W)
-    mask = torch.zeros((B, H * W), dtype=torch.bool, device=dev)
+    hits = torch.zeros((B, H * W), dtype=torch.int32, device=dev)
     lin = (ij[..., 0].clamp(0, H - 1) * W + ij[..., 1].clamp(0, W - 1))
-    mask.scatter_(1, lin, ok)
-    maps["center_bool_mask"] = mask.view(B, H, W)
+    hits.scatter_add_(1, lin, ok.to(torch.int32))  # padded slots add 0: never clear a valid box's cell
+    maps["center_bool_mask"] = (hits > 0).view(B, H, W)
     return maps

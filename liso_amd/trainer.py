@@ -123,3 +123,58 @@ class SlimTrainer:
         self.optimizer.step()
         self.lr_scheduler.step()
         return total.detach()
+
+
+class LisoLoopTrainer:
+    """One fused LISO iteration per sample pair: SLIM forward (no_grad) -> per-point flow ->
+    FlowClusterDetector (BEV dynamicness, DBSCAN, region moments, z-fit, filters, Kabsch heading/velocity) -> rotated NMS
+    (pre 1000 / post 100 / IoU 0.1, liso_config.yml:4,27-28) -> CenterPoint target maps -> detector train step.
+    The reference runs these stages as separate jobs that exchange files (flow export: slim/experiment.py:363-471;
+    box mining + box DB: tracker/; training: liso_cli.py); here the tensors stay in HBM from the sweep to the gradient.
+    Box-DB augmentation and tracking between the stages are outside this loop."""
+
+    def __init__(self, cfg, device, compute_dtype=torch.float32, total_steps=None, slim_state_dict=None):
+        from liso_amd.networks.flow_cluster_detector.flow_cluster_detector import FlowClusterDetector
+        from liso_amd.slim.model.slim import SLIM
+
+        self.cfg, self.device = cfg, device
+        self.slim = SLIM(cfg, num_train_samples=1000).to(device)
+        if slim_state_dict is not None:
+            self.slim.load_state_dict(slim_state_dict)
+        self.slim.eval()
+        self.cluster_detector = FlowClusterDetector(cfg).to(device)
+        self.detector = DetectorTrainer(cfg, device, compute_dtype=compute_dtype, total_steps=total_steps)
+        tc = cfg.data.tracking_cfg
+        self.pre_nms, self.post_nms = tc.max_num_boxes_before_nms, tc.max_num_boxes_after_nms
+        self.nms_iou = cfg.setdefault("nms_iou_threshold", 0.1)
+
+    @torch.no_grad()
+    def mine_boxes(self, sample_t0, sample_t1):
+        """-> (Shape [B,K] after NMS, padded with zeros; point flow [B,N,3])"""
+        from liso_amd.utils.nms_iou import perform_nms_on_shapes
+
+        preds_fw, _ = self.slim(sample_t0, sample_t1, None)
+        flow = preds_fw[-1].aggregated_flow
+        sample = dict(sample_t0)
+        sample[self.cfg.data.flow_source] = {**sample_t0.get(self.cfg.data.flow_source, {}), "flow_ta_tb": flow}
+        boxes = self.cluster_detector(sample, global_step=1)
+        if boxes.shape[1] > 0:
+            boxes = perform_nms_on_shapes(boxes, max_num_boxes=self.post_nms, overlap_threshold=self.nms_iou,
+                                          pre_nms_max_num_boxes=self.pre_nms)
+            boxes.set_padding_val_to(0.0)
+        return boxes, flow
+
+    def step(self, sample_t0, sample_t1):
+        from liso_amd.datasets.targets import render_center_targets
+
+        boxes, _ = self.mine_boxes(sample_t0, sample_t1)
+        B = boxes.shape[0]
+        if boxes.shape[1] == 0:  # nothing moved: an all-background target (one padded slot)
+            z = torch.zeros((B, 1, 3), device=self.device)
+            pos, dims, rot, valid = z, z + 1.0, z[..., :1], torch.zeros((B, 1), dtype=torch.bool, device=self.device)
+        else:
+            pos, dims, rot, valid = boxes.pos.float(), boxes.dims.float().clamp(min=1e-3), boxes.rot.float(), boxes.valid
+        out = tuple(int(g) // 4 for g in self.cfg.data.img_grid_size)
+        targets = render_center_targets(pos, dims, rot, valid, out, tuple(self.cfg.data.bev_range_m))
+        self.last_boxes = boxes
+        return self.detector.step(sample_t0["pcl_full_no_ground_ta"], targets)
