@@ -3,6 +3,7 @@ state_dict keys: start_value, update_weight, [moving_counter, still_counter], bi
 from typing import Tuple
 
 import torch
+import torch.distributed as dist
 from torch import nn
 
 
@@ -67,6 +68,12 @@ class MovingAverageThreshold(nn.Module):
                 bins = torch.where(valid_mask, bins, 0).clamp(min=0)
                 count = valid_mask.sum()
             cur = torch.zeros((self.resolution,), dtype=imp.dtype, device=imp.device).scatter_add_(0, bins, imp)
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                # data parallel: every rank applies the histogram increment of the GLOBAL batch (400 KB all-reduce), so
+                # the threshold buffers stay identical on all replicas
+                count = torch.as_tensor(count, dtype=torch.long, device=imp.device).clone()
+                dist.all_reduce(cur)
+                dist.all_reduce(count)
             self._update_values(cur, count)
             if self.num_still is not None:
                 mm = moving_mask if valid_mask is None else moving_mask & valid_mask

@@ -1,12 +1,13 @@
 """TEST INFRASTRUCTURE ONLY: the SLIM train step on the host CPU, for bench.py's cpu_baseline leg ("kind": "port").
 
-The product's SLIM host modules are plain torch except for five HIP-backed ops.  `cpu_port()` temporarily swaps those
+The product's SLIM host modules are plain torch except for six HIP-backed ops.  `cpu_port()` temporarily swaps those
 for CPU implementations that follow the reference's own formulation:
   pillar encoder      -> oracle/pillars.py              (mmdet3d voxel_generator + PillarFeatureNet + scatter)
   correlation lookup  -> explicit all-pairs volume + avg_pool2d + grid_sample   (liso/slim/model/raft_code/corr.py:6-46)
   symmetric orthogonalisation -> torch.linalg.svd (fp64)                         (liso/torch_symm_ortho/__init__.py:63)
   1-nearest neighbour -> scipy.spatial.cKDTree (exact; stands in for pynanoflann, knn_graph.py:57-70)
   BEV -> point gather -> torch advanced indexing                                 (slim_loss/static_aggregation.py:8-31)
+  weighted moments    -> torch reductions                                         (slim_loss/weighted_pc_alignment.py:36-47)
 This is a *timing* port of the step, not a parity oracle: SLIM parity is pinned by fixtures generated from the
 reference (tests/golden/make_slim*_golden.py).
 """
@@ -73,6 +74,16 @@ def _cpu_knn_graph(x, *, index=None, k, loop=False, **kw):
     return idx[:, None]
 
 
+class _CpuWeightedMoments:
+    """the 16 weighted sums of weighted_pc_alignment.py:36-47 with differentiable torch ops"""
+
+    @staticmethod
+    def apply(x, y, w):
+        xd, yd, wd = x.double(), y.double(), w.double()
+        return torch.cat([wd.sum()[None], (wd[:, None] * xd).sum(0), (wd[:, None] * yd).sum(0),
+                          ((yd * wd[:, None]).T @ xd).reshape(-1)])
+
+
 def _cpu_grid_to_points(grid_data, pointwise_voxel_coordinates_fs, pointwise_valid_mask, default_value, plan=None):
     coors = torch.where(pointwise_valid_mask[..., None], pointwise_voxel_coordinates_fs,
                         torch.zeros_like(pointwise_voxel_coordinates_fs)).long()
@@ -94,6 +105,7 @@ def cpu_port():
     saved = (pp.PointsPillarFeatureNetWrapper.forward, rm.CorrBlock, wpa.symmetric_orthogonalization, kw.knn_graph, kg.KnnIndex)
     saved_gather = (hd.batched_grid_data_to_pointwise_data, sa.batched_grid_data_to_pointwise_data)
     hd.batched_grid_data_to_pointwise_data = sa.batched_grid_data_to_pointwise_data = _cpu_grid_to_points
+    saved_mom, wpa._WeightedMoments = wpa._WeightedMoments, _CpuWeightedMoments
     pp.PointsPillarFeatureNetWrapper.forward = _cpu_pillar_forward
     rm.CorrBlock = _CpuCorrBlock
     wpa.symmetric_orthogonalization = OK.symm_ortho
@@ -104,6 +116,7 @@ def cpu_port():
     finally:
         (pp.PointsPillarFeatureNetWrapper.forward, rm.CorrBlock, wpa.symmetric_orthogonalization, kw.knn_graph, kg.KnnIndex) = saved
         hd.batched_grid_data_to_pointwise_data, sa.batched_grid_data_to_pointwise_data = saved_gather
+        wpa._WeightedMoments = saved_mom
 
 
 def timed_slim_step(cfg, state_dict, sample_t0, sample_t1):

@@ -112,3 +112,68 @@ def _compare_with_hand_averaged(r):
     flat = torch.cat([p.detach().flatten() for p in tr.net.parameters()])
     # BN running stats do not enter the training-mode forward, so hand-averaging reproduces DDP up to fp32 summation order
     assert torch.allclose(flat, r["params"][0], rtol=2e-4, atol=2e-6)
+
+
+# ---- SLIM trainer under DDP (gloo, 2 ranks).  The six HIP-backed ops are swapped for the CPU port of oracle/slim_step.py
+# (test infrastructure); model, decoder, loss, DDP wiring, optimizer and the threshold all-reduce are the product.
+def _slim_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(2)
+    try:
+        from liso_amd.datasets.synthetic import slim_pair
+        from liso_amd.trainer import SlimTrainer
+        from liso_amd.utils.config import apply_slim_simple_knn_training, default_cfg
+        from oracle.slim_step import cpu_port
+
+        cfg = apply_slim_simple_knn_training(default_cfg(grid=128, bev_range_m=40.0))
+        cfg.SLIM.model.num_iters = 2
+        torch.manual_seed(0)
+        with cpu_port():
+            tr = SlimTrainer(cfg, torch.device("cpu"))
+            assert isinstance(tr.model, torch.nn.parallel.DistributedDataParallel)
+            s0, s1 = slim_pair(30 + rank, torch.device("cpu"), n_points=4000, grid=128, bev_range_m=40.0)
+            losses = [float(tr.step(s0, s1)) for _ in range(2)]
+        flat = torch.cat([p.detach().flatten() for p in tr.net.parameters()])
+        # the dynamicness-threshold histogram: every rank feeds its own points, all ranks must end with the update of
+        # the global batch (movavg_cls_threshold.py:118-157 + the all-reduce of SURVEY.md 8e)
+        from liso_amd.slim.slim_loss.movavg_cls_threshold import MovingAverageThreshold
+        g = torch.Generator().manual_seed(100 + rank)
+        thr = MovingAverageThreshold(num_train_samples=100, num_moving=1000)
+        es, ed, sc = torch.rand(500, generator=g), torch.rand(500, generator=g), torch.rand(500, generator=g)
+        thr.update(es, ed, None, sc, True, valid_mask=torch.rand(500, generator=g) > 0.2)
+        hist = thr.moving_average_importance.clone()
+        bias = thr.bias_counter.clone().reshape(1)
+        g_flat = [torch.zeros_like(flat) for _ in range(world)]
+        g_hist = [torch.zeros_like(hist) for _ in range(world)]
+        g_bias = [torch.zeros_like(bias) for _ in range(world)]
+        dist.all_gather(g_flat, flat), dist.all_gather(g_hist, hist), dist.all_gather(g_bias, bias)
+        if rank == 0:
+            torch.save({"params": g_flat, "hist": g_hist, "bias": g_bias, "losses": losses}, out)
+    finally:
+        torch.set_num_threads(threads)
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_gloo_slim_step(tmp_path):
+    out = str(tmp_path / "ddp_slim.pt")
+    mp.spawn(_slim_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r = torch.load(out)
+    assert all(l == l for l in r["losses"])  # finite
+    assert torch.equal(r["params"][0], r["params"][1])          # replicas identical after two steps
+    assert torch.equal(r["hist"][0], r["hist"][1]) and float(r["hist"][0].abs().sum()) > 0.0  # global histogram update
+    assert torch.equal(r["bias"][0], r["bias"][1])
+    # ... and equal to ONE process seeing both ranks' points
+    from liso_amd.slim.slim_loss.movavg_cls_threshold import MovingAverageThreshold
+    parts = []
+    for rank in range(2):
+        g = torch.Generator().manual_seed(100 + rank)
+        parts.append((torch.rand(500, generator=g), torch.rand(500, generator=g), torch.rand(500, generator=g),
+                      torch.rand(500, generator=g) > 0.2))
+    one = MovingAverageThreshold(num_train_samples=100, num_moving=1000)
+    one.update(*[torch.cat([p[i] for p in parts]) for i in (0, 1)], None, torch.cat([p[2] for p in parts]), True,
+               valid_mask=torch.cat([p[3] for p in parts]))
+    assert torch.allclose(one.moving_average_importance, r["hist"][0], rtol=1e-5, atol=1e-9)
+    assert torch.allclose(one.bias_counter, r["bias"][0][0])
