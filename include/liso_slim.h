@@ -72,13 +72,14 @@ size_t liso_knn_workspace_bytes(const liso_knn_grid* grid, int n_ref);
 int liso_knn_build_f32(const liso_knn_grid* grid, const float* ref, int ref_stride, int n_ref, void* workspace,
                        size_t workspace_bytes, void* stream);
 
-/* max_rings < 0: search until proven exact.  max_rings >= 0: stop after that many rings and mark queries whose result
- * is not yet proven with index -1 (nothing else written for them).  only_unresolved != 0: process only rows whose
- * index is -1 (second pass on a coarser grid: a fine grid answers the dense near field in 1-2 rings, a coarse grid the
- * few queries that land in empty space, so no query walks thousands of empty cells). */
-int liso_knn_query_f32(const liso_knn_grid* grid, const float* ref, int ref_stride, int n_ref, const void* workspace,
-                       const float* query, int query_stride, int n_query, int64_t* index, float* dist_sqr, int max_rings,
-                       int only_unresolved, void* stream);
+/* One launch answers all queries.  `grid`/`workspace`: the (fine) index.  `coarse_grid`/`coarse_workspace` (both NULL or
+ * both set): a second index of the SAME reference cloud with larger cells -- a query whose answer is not proven exact
+ * after `fine_max_rings` rings of the fine grid continues on the coarse one (the fine grid answers the dense near field
+ * in 1-2 rings, the coarse grid the few queries that land in empty space, so no query walks thousands of empty cells).
+ * Without a coarse index the fine search runs until proven exact (fine_max_rings ignored). */
+int liso_knn_query_f32(const liso_knn_grid* grid, const void* workspace, const liso_knn_grid* coarse_grid,
+                       const void* coarse_workspace, int n_ref, const float* query, int query_stride, int n_query,
+                       int64_t* index, float* dist_sqr, int fine_max_rings, void* stream);
 
 /* ---- BEV grid -> per-point gather (decoder) and its adjoint ---------------------------------------------------------
  * Replaces batched_grid_data_to_pointwise_data (liso/slim/slim_loss/static_aggregation.py:8-31; used by

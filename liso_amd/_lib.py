@@ -113,7 +113,7 @@ SIGNATURES = {
     "liso_bn_relu_bwd": (_i, [_vp, _vp, _i, ctypes.c_long, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "liso_knn_workspace_bytes": (_sz, [_vp, _i]),
     "liso_knn_build_f32": (_i, [_vp, _vp, _i, _i, _vp, _sz, _vp]),
-    "liso_knn_query_f32": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp]),
+    "liso_knn_query_f32": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _i, _vp]),
 }
 
 
@@ -159,7 +159,8 @@ class KernelTimer:
     def disable_all(self):
         self.enabled.clear()
 
-    def launch(self, name, fn):
+    def launch(self, name, fn, units=None):
+        """`units`: how many work items (queries, points ...) this launch processes, for per-launch algorithmic bytes"""
         if name not in self.enabled:
             return fn()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -167,7 +168,13 @@ class KernelTimer:
         r = fn()
         b.record()
         self.events[name].append((a, b))
+        if units is not None:
+            self.units.setdefault(name, []).append(units)
         return r
+
+    def mean_units(self, name):
+        u = self.units.get(name, [])
+        return sum(u) / len(u) if u else None
 
     def durations_ms(self, name):
         torch.cuda.synchronize()
@@ -176,6 +183,7 @@ class KernelTimer:
     def reset(self):
         for k in self.events:
             self.events[k] = []
+        self.units = {}
 
 
 TIMER = KernelTimer()

@@ -116,35 +116,28 @@ __global__ void knn_fill_kernel(const float* __restrict__ ref, int stride, int n
 // A 4-step butterfly picks the group's best (distance, index) once per ring.
 constexpr int kGroup = 16;
 
-__global__ __launch_bounds__(256) void knn_query_kernel(liso_knn_grid g, const int* __restrict__ start,
-                                                        const float4* __restrict__ bucketed, int n_ref,
-                                                        const float* __restrict__ query, int qstride, int nq,
-                                                        long long* __restrict__ index, float* __restrict__ dist_sqr,
-                                                        int max_rings, int only_unresolved) {
-    const int gid = (blockIdx.x * blockDim.x + threadIdx.x) / kGroup;  // query handled by this 16-lane group
-    const int sub = threadIdx.x & (kGroup - 1);
-    const int group_shift = (threadIdx.x & 63) & ~(kGroup - 1);  // first lane of this group inside the wavefront
-    if (gid >= nq) return;
-    if (only_unresolved && index[gid] >= 0) return;  // second (coarse-grid) pass: only rows the fine pass gave up on
-    const float qx = query[(size_t)gid * qstride], qy = query[(size_t)gid * qstride + 1], qz = query[(size_t)gid * qstride + 2];
-    if (!(isfinite(qx) && isfinite(qy) && isfinite(qz)) || n_ref == 0) {
-        if (sub == 0) { index[gid] = 0; if (dist_sqr) dist_sqr[gid] = nanf(""); }
-        return;
-    }
+struct Level {
+    liso_knn_grid g;
+    const int* start;
+    const float4* bucketed;
+};
+
+// ring search on one grid level; (best, best_i) carry over between levels (a candidate found on the fine level is a real
+// point, so it only tightens the coarse search).  Returns true when the answer is proven exact.
+__device__ __forceinline__ bool ring_search(const Level& L, float qx, float qy, float qz, int max_rings, int sub, int group_shift,
+                                            float& best, int& best_i) {
+    const liso_knn_grid& g = L.g;
     int cx, cy;
     cell_of(g, qx, qy, &cx, &cy);
     const float ox = qx - (g.x_min + cx * g.cell), oy = qy - (g.y_min + cy * g.cell);
     const float margin = fminf(fminf(ox, g.cell - ox), fminf(oy, g.cell - oy));
-    float best = INFINITY;
-    int best_i = 0x7fffffff;
-    int rmax = max(max(cx, g.nx - 1 - cx), max(cy, g.ny - 1 - cy));
-    bool resolved = true;
-    if (max_rings >= 0 && rmax > max_rings) { rmax = max_rings; resolved = false; }
+    const int rfull = max(max(cx, g.nx - 1 - cx), max(cy, g.ny - 1 - cy));
+    const int rmax = (max_rings >= 0 && rfull > max_rings) ? max_rings : rfull;
     for (int r = 0; r <= rmax; r++) {
         const int ncell = r == 0 ? 1 : 8 * r;
         const int x0 = cx - r, x1 = cx + r, y0 = cy - r, y1 = cy + r;
-        // only z bins that can hold a point closer than the best so far (|dz| <= sqrt(best)); everything on ring 0
-        const float dzmax = sqrtf(best) * 1.0001f + 1e-6f;  // inf before the first hit; padded against sqrt rounding
+        // only z bins that can hold a point closer than the best so far (|dz| <= sqrt(best)); everything before a first hit
+        const float dzmax = sqrtf(best) * 1.0001f + 1e-6f;  // padded against sqrt rounding
         const int zlo = best == INFINITY ? 0 : zbin_of(g, qz - dzmax);
         const int zhi = best == INFINITY ? g.nz - 1 : zbin_of(g, qz + dzmax);
         for (int t0 = 0; t0 < ncell; t0 += kGroup) {
@@ -159,8 +152,8 @@ __global__ __launch_bounds__(256) void knn_query_kernel(liso_knn_grid g, const i
                 }
                 if (x >= 0 && x < g.nx && y >= 0 && y < g.ny) {
                     const int c = (x * g.ny + y) * g.nz;
-                    s = start[c + zlo];
-                    e = start[c + zhi + 1];
+                    s = L.start[c + zlo];
+                    e = L.start[c + zhi + 1];
                 }
             }
             unsigned nonempty = (unsigned)(__ballot(e > s) >> group_shift) & 0xffffu;
@@ -169,7 +162,7 @@ __global__ __launch_bounds__(256) void knn_query_kernel(liso_knn_grid g, const i
                 nonempty &= nonempty - 1;
                 const int sj = __shfl(s, j, kGroup), ej = __shfl(e, j, kGroup);
                 for (int k = sj + sub; k < ej; k += kGroup) {
-                    const float4 p = bucketed[k];
+                    const float4 p = L.bucketed[k];
                     const float dx = p.x - qx, dy = p.y - qy, dz = p.z - qz;
                     const float d = dx * dx + dy * dy + dz * dz;
                     const int pi = __float_as_int(p.w);
@@ -185,11 +178,31 @@ __global__ __launch_bounds__(256) void knn_query_kernel(liso_knn_grid g, const i
             if (ob < best || (ob == best && oi < best_i)) { best = ob; best_i = oi; }
         }
         const float bound = r * g.cell + margin;  // every unvisited point is at least this far (xy distance)
-        if (bound > 0.f && best <= bound * bound) { resolved = true; break; }
-        if (r == rmax && rmax == max(max(cx, g.nx - 1 - cx), max(cy, g.ny - 1 - cy))) resolved = true;  // grid exhausted
+        if (bound > 0.f && best <= bound * bound) return true;
     }
+    return rmax == rfull;  // grid exhausted
+}
+
+// One launch answers every query: the fine level resolves the dense near field in a few rings; a group whose answer is
+// not proven after `fine_max_rings` continues on the coarse level (no second launch, no pass over resolved rows).
+__global__ __launch_bounds__(256) void knn_query_kernel(Level fine, Level coarse, int has_coarse, int n_ref,
+                                                        const float* __restrict__ query, int qstride, int nq,
+                                                        long long* __restrict__ index, float* __restrict__ dist_sqr,
+                                                        int fine_max_rings) {
+    const int gid = (blockIdx.x * blockDim.x + threadIdx.x) / kGroup;  // query handled by this 16-lane group
+    const int sub = threadIdx.x & (kGroup - 1);
+    const int group_shift = (threadIdx.x & 63) & ~(kGroup - 1);  // first lane of this group inside the wavefront
+    if (gid >= nq) return;
+    const float qx = query[(size_t)gid * qstride], qy = query[(size_t)gid * qstride + 1], qz = query[(size_t)gid * qstride + 2];
+    if (!(isfinite(qx) && isfinite(qy) && isfinite(qz)) || n_ref == 0) {
+        if (sub == 0) { index[gid] = 0; if (dist_sqr) dist_sqr[gid] = nanf(""); }
+        return;
+    }
+    float best = INFINITY;
+    int best_i = 0x7fffffff;
+    if (!ring_search(fine, qx, qy, qz, has_coarse ? fine_max_rings : -1, sub, group_shift, best, best_i))
+        ring_search(coarse, qx, qy, qz, -1, sub, group_shift, best, best_i);
     if (sub != 0) return;
-    if (!resolved) { index[gid] = -1; return; }  // left to the coarse-grid pass
     index[gid] = best_i == 0x7fffffff ? 0 : best_i;
     if (dist_sqr) dist_sqr[gid] = best;
 }
@@ -236,19 +249,27 @@ int liso_knn_build_f32(const liso_knn_grid* grid, const float* ref, int ref_stri
     return check_launch();
 }
 
-int liso_knn_query_f32(const liso_knn_grid* grid, const float* ref, int ref_stride, int n_ref, const void* workspace,
-                       const float* query, int query_stride, int n_query, int64_t* index, float* dist_sqr, int max_rings,
-                       int only_unresolved, void* stream) {
-    (void)ref; (void)ref_stride;
+static Level make_level(const liso_knn_grid* grid, const void* workspace, int n_ref) {
+    Level l;
+    l.g = *grid;
+    const int cells = n_keys(grid);
+    l.start = (const int*)workspace + 2 * (size_t)cells;
+    l.bucketed = (const float4*)((const char*)workspace + align16((3 * (size_t)cells + 1 + kTotSlots + (size_t)n_ref) * sizeof(int)));
+    return l;
+}
+
+int liso_knn_query_f32(const liso_knn_grid* grid, const void* workspace, const liso_knn_grid* coarse_grid,
+                       const void* coarse_workspace, int n_ref, const float* query, int query_stride, int n_query,
+                       int64_t* index, float* dist_sqr, int fine_max_rings, void* stream) {
     if (!grid_ok(grid) || n_ref < 0 || n_query < 0 || query_stride < 3 || !workspace) return LISO_EINVAL;
+    if ((coarse_grid != nullptr) != (coarse_workspace != nullptr) || (coarse_grid && !grid_ok(coarse_grid))) return LISO_EINVAL;
+    if (coarse_grid && fine_max_rings < 0) return LISO_EINVAL;
     if (n_query == 0) return LISO_OK;
     if (!query || !index) return LISO_EINVAL;
-    const int cells = n_keys(grid);
-    const int* start = (const int*)workspace + 2 * (size_t)cells;
-    const float4* bucketed = (const float4*)((const char*)workspace + align16((3 * (size_t)cells + 1 + kTotSlots + (size_t)n_ref) * sizeof(int)));
-    knn_query_kernel<<<(unsigned)(((long)n_query * kGroup + 255) / 256), 256, 0, (hipStream_t)stream>>>(*grid, start, bucketed, n_ref, query, query_stride,
-                                                                            n_query, (long long*)index, dist_sqr, max_rings,
-                                                                            only_unresolved);
+    const Level fine = make_level(grid, workspace, n_ref);
+    const Level coarse = coarse_grid ? make_level(coarse_grid, coarse_workspace, n_ref) : fine;
+    knn_query_kernel<<<(unsigned)(((long)n_query * kGroup + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+        fine, coarse, coarse_grid != nullptr, n_ref, query, query_stride, n_query, (long long*)index, dist_sqr, fine_max_rings);
     return check_launch();
 }
 

@@ -60,18 +60,11 @@ class KnnIndex:
         lib = L.lib()
         n = self.ref.shape[0]
 
-        def run():
-            rc = lib.liso_knn_query_f32(ctypes.byref(self.fine.grid), L.ptr(self.ref), self.ref.shape[1], n, L.ptr(self.fine.ws),
-                                        L.ptr(q), q.shape[1], nq, L.ptr(idx), L.ptr(d2) if d2 is not None else None,
-                                        self.FINE_RINGS, 0, L.stream_ptr())
-            if rc:
-                return rc
-            return lib.liso_knn_query_f32(ctypes.byref(self.coarse.grid), L.ptr(self.ref), self.ref.shape[1], n,
-                                          L.ptr(self.coarse.ws), L.ptr(q), q.shape[1], nq, L.ptr(idx),
-                                          L.ptr(d2) if d2 is not None else None, -1, 1, L.stream_ptr())
-
         with torch.cuda.device(q.device):
-            L.check(L.TIMER.launch("knn_query", run), "knn_query")
+            L.check(L.TIMER.launch("knn_query", lambda: lib.liso_knn_query_f32(
+                ctypes.byref(self.fine.grid), L.ptr(self.fine.ws), ctypes.byref(self.coarse.grid), L.ptr(self.coarse.ws), n,
+                L.ptr(q), q.shape[1], nq, L.ptr(idx), L.ptr(d2) if d2 is not None else None, self.FINE_RINGS,
+                L.stream_ptr()), units=nq), "knn_query")
         return (idx, d2) if return_dist_sqr else idx
 
 
