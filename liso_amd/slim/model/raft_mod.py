@@ -69,8 +69,9 @@ class RAFT(nn.Module):
         cnet = self.cnet(img_t0)
         net, inp = torch.split(cnet, [self.hidden_dim, self.context_dim], dim=1)
         net, inp = torch.tanh(net), torch.relu(inp)
-        adapter = torch.tensor([self.bev_rows_res_meters_per_fs_pixel, self.bev_cols_res_meters_per_fs_pixel],
-                               device=inp.device, dtype=inp.dtype)[None, ..., None, None]
+        # (rows, cols) metres per pixel; equal (asserted in __init__), so a python scalar does the job of the reference's
+        # [1,2,1,1] tensor (:171-176) without a host->device copy per call
+        adapter = float(self.bev_rows_res_meters_per_fs_pixel)
         preds = []
         for _ in range(m.num_iters):
             coords1 = coords1.detach()

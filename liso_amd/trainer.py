@@ -72,16 +72,23 @@ class SlimTrainer:
     """SLIM self-supervised train step, mirror of liso/slim/experiment.py:834-919 (`train_one_step`) with the optimizer /
     schedule factory of :200-219: RMSprop(lr 1e-4) + linear warm-up (2000) then linear decay to 5 %; the loss is the
     un-weighted sum over the 6 RAFT iterations.  The reference cloud of every kNN query is bucketed on the device once
-    per step (the reference rebuilds a host KD-tree for each of the 12+ queries)."""
+    per step (the reference rebuilds a host KD-tree for each of the 12+ queries).
 
-    def __init__(self, cfg, device, num_train_samples=1000):
+    `use_graph=True`: forward + loss + backward of one step (≈7 800 kernel launches, no device->host sync) are captured
+    once per input shape into a hipGraph and replayed; new sweeps are copied into the captured input buffers.  Gradients
+    live in one flat buffer: data parallelism is one RCCL all-reduce of that buffer after the replay (no DDP wrapper),
+    then the eager RMSprop step."""
+
+    def __init__(self, cfg, device, num_train_samples=1000, use_graph=False):
         from liso_amd.slim.model.slim import SLIM
         from liso_amd.utils.learning_rate import get_polynomial_decay_schedule_with_warmup
 
         self.cfg, self.slim_cfg, self.device = cfg, cfg.SLIM, device
         self.net = SLIM(cfg, num_train_samples=num_train_samples).to(device)
         self.model = self.net
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        self.use_graph = bool(use_graph) and device.type == "cuda"
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        if self.world > 1 and not self.use_graph:
             self.model = torch.nn.parallel.DistributedDataParallel(
                 self.net, device_ids=[device.index] if device.type == "cuda" else None, bucket_cap_mb=64,
                 broadcast_buffers=False, gradient_as_bucket_view=True)
@@ -90,21 +97,39 @@ class SlimTrainer:
         self.lr_scheduler = get_polynomial_decay_schedule_with_warmup(
             optimizer=self.optimizer, num_warmup_steps=self.slim_cfg.learning_rate.warm_up.step_length,
             num_training_steps=self.slim_cfg.iterations.train, lr_end=self.slim_cfg.learning_rate.initial * 0.05)
-        half = 0.5 * torch.tensor(cfg.data.bev_range_m).numpy()
         import numpy as np
+        half = 0.5 * np.array(cfg.data.bev_range_m, dtype=np.float32)
         self.bev_extent = np.concatenate([-half, half], axis=0)
+        self._graph, self._graph_sig = None, None
+        if self.use_graph:
+            params = [p for p in self.net.parameters() if p.requires_grad]
+            self._flat_grad = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=device)
+            off = 0
+            for p in params:  # gradients are views into one flat buffer: one memset, one all-reduce
+                p.grad = self._flat_grad[off:off + p.numel()].view_as(p)
+                off += p.numel()
+            if self.world > 1:  # replicas start identical (what the DDP constructor would do)
+                for t in list(self.net.parameters()) + list(self.net.buffers()):
+                    dist.broadcast(t.data, src=0)
 
-    def loss(self, sample_t0, sample_t1):
+    def _inputs(self, sample_t0, sample_t1):
+        pc1, m1 = sample_t0["pcl_ta"]["pcl"].to(self.device), sample_t0["pcl_ta"]["pcl_is_valid"].to(self.device)
+        pc2, m2 = sample_t1["pcl_ta"]["pcl"].to(self.device), sample_t1["pcl_ta"]["pcl_is_valid"].to(self.device)
+        return pc1, m1, pc2, m2
+
+    def loss(self, sample_t0, sample_t1, all_valid=None):
+        """`all_valid` = (bool, bool): whether every row of the two loss clouds is a real point; evaluated here (the step's
+        only device->host sync, before any work is queued) unless the caller already knows."""
         from liso_amd.slim.slim_loss.knn_graph import KnnIndex
         from liso_amd.slim.slim_loss.slim_loss_adaptor import selfsupervisedSlimSingleScaleLoss
 
-        pc1, m1 = sample_t0["pcl_ta"]["pcl"].to(self.device), sample_t0["pcl_ta"]["pcl_is_valid"].to(self.device)
-        pc2, m2 = sample_t1["pcl_ta"]["pcl"].to(self.device), sample_t1["pcl_ta"]["pcl_is_valid"].to(self.device)
+        pc1, m1, pc2, m2 = self._inputs(sample_t0, sample_t1)
+        if all_valid is None:
+            all_valid = (bool(m1.all()), bool(m2.all()))
         ext = [float(v) for v in self.bev_extent]
-        # bucket both clouds before the network runs: the `all valid` test is the step's only device->host sync and
-        # costs nothing while the queue is still empty
-        idx1 = [KnnIndex(pc1[b][:, :3], extent=ext) for b in range(pc1.shape[0])] if bool(m1.all()) else None
-        idx2 = [KnnIndex(pc2[b][:, :3], extent=ext) for b in range(pc2.shape[0])] if bool(m2.all()) else None
+        # bucket both clouds before the network runs
+        idx1 = [KnnIndex(pc1[b][:, :3], extent=ext) for b in range(pc1.shape[0])] if all_valid[0] else None
+        idx2 = [KnnIndex(pc2[b][:, :3], extent=ext) for b in range(pc2.shape[0])] if all_valid[1] else None
         preds_fw, preds_bw = self.model(sample_t0, sample_t1, None)
         total = torch.zeros(1, device=self.device)
         for pfw, pbw in zip(preds_fw, preds_bw):
@@ -115,14 +140,93 @@ class SlimTrainer:
                 knn_index_pc1=idx1, knn_index_pc2=idx2)
         return total, preds_fw, preds_bw
 
-    def step(self, sample_t0, sample_t1):
+    def step(self, sample_t0, sample_t1, eager=False):
         self.model.train()
+        if self.use_graph and not eager:
+            return self._graph_step(sample_t0, sample_t1)
         total, _, _ = self.loss(sample_t0, sample_t1)
-        self.optimizer.zero_grad(set_to_none=True)
+        if self.use_graph:
+            self._flat_grad.zero_()
+        else:
+            self.optimizer.zero_grad(set_to_none=True)
         total.backward()
+        self._reduce_and_update()
+        return total.detach()
+
+    def _reduce_and_update(self):
+        if self.use_graph and self.world > 1:
+            dist.all_reduce(self._flat_grad)
+            self._flat_grad.div_(self.world)
         self.optimizer.step()
         self.lr_scheduler.step()
-        return total.detach()
+
+    # ---- hipGraph path ----------------------------------------------------------------------------------------------
+    @staticmethod
+    def _map_tensors(obj, fn):
+        if torch.is_tensor(obj):
+            return fn(obj)
+        if isinstance(obj, dict):
+            return {k: SlimTrainer._map_tensors(v, fn) for k, v in obj.items()}
+        if isinstance(obj, (list, tuple)):
+            return type(obj)(SlimTrainer._map_tensors(v, fn) for v in obj)
+        return obj
+
+    @staticmethod
+    def _copy_tensors(dst, src):
+        if torch.is_tensor(dst):
+            dst.copy_(src, non_blocking=True)
+        elif isinstance(dst, dict):
+            for k in dst:
+                SlimTrainer._copy_tensors(dst[k], src[k])
+        elif isinstance(dst, (list, tuple)):
+            for d, s in zip(dst, src):
+                SlimTrainer._copy_tensors(d, s)
+
+    def _signature(self, sample_t0, sample_t1, all_valid):
+        shapes = []
+        self._map_tensors((sample_t0, sample_t1), lambda t: shapes.append((tuple(t.shape), t.dtype)) or t)
+        return (tuple(shapes), all_valid)
+
+    def _capture(self, sample_t0, sample_t1, all_valid):
+        dev = self.device
+        self._static = self._map_tensors((sample_t0, sample_t1), lambda t: t.to(dev).clone())
+        s0, s1 = self._static
+        buffers = {k: v.clone() for k, v in self.net.state_dict().items() if v.is_floating_point() or v.dtype == torch.long}
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):  # warm-up off the capture: MIOpen / rocBLAS pick their kernels, caches fill
+            for _ in range(2):
+                self._flat_grad.zero_()
+                total, _, _ = self.loss(s0, s1, all_valid)
+                total.backward()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        with torch.no_grad():  # the warm-up passes must not count as training steps (BN / threshold statistics)
+            for k, v in self.net.state_dict().items():
+                if k in buffers:
+                    v.copy_(buffers[k])
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._flat_grad.zero_()
+            total, _, _ = self.loss(s0, s1, all_valid)
+            total.backward()
+            self._static_loss = total.detach()
+        with torch.no_grad():  # capture does not execute, but restore anyway in case the backend ran eagerly
+            for k, v in self.net.state_dict().items():
+                if k in buffers:
+                    v.copy_(buffers[k])
+
+    def _graph_step(self, sample_t0, sample_t1):
+        _, m1, _, m2 = self._inputs(sample_t0, sample_t1)
+        all_valid = (bool(m1.all()), bool(m2.all()))
+        sig = self._signature(sample_t0, sample_t1, all_valid)
+        if self._graph is None or sig != self._graph_sig:
+            self._capture(sample_t0, sample_t1, all_valid)
+            self._graph_sig = sig
+        else:
+            self._copy_tensors(self._static, (sample_t0, sample_t1))
+        self._graph.replay()
+        self._reduce_and_update()
+        return self._static_loss
 
 
 class LisoLoopTrainer:
