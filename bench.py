@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=None, help="detector workload: clouds per GPU (default 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="slim workload: eager launches instead of hipGraph replay")
+    ap.add_argument("--nhwc", action="store_true", help="slim workload: conv filters in channels-last memory format (slower)")
     return ap.parse_args()
 
 
@@ -131,7 +132,7 @@ def main():
         args.dtype = "fp32"  # the reference trains SLIM in fp32 (no autocast in slim/experiment.py)
         batch = 1  # one pair per GPU, as in the reference's `slim_RAFT batch_size_one`
         cfg = apply_slim_simple_knn_training(cfg)
-        trainer = SlimTrainer(cfg, dev, use_graph=not args.no_graph)
+        trainer = SlimTrainer(cfg, dev, use_graph=not args.no_graph, channels_last=args.nhwc)
         # each rank owns different pairs (DistributedSampler-style sharding by seed), resident in HBM
         s0, s1 = slim_pair(2 + rank, dev, n_points=N_POINTS, grid=GRID, bev_range_m=BEV_RANGE)
         step = lambda: trainer.step(s0, s1)  # noqa: E731

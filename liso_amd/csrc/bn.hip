@@ -121,8 +121,19 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
     const int per = (nblk + chunks - 1) / chunks;
     const int lo = chunk * per, hi = (chunk < chunks) ? (lo + per < nblk ? lo + per : nblk) : lo;
     const double last_n = (double)(m - (long)(nblk - 1) * rows_per_block);
+    // the partial rows are read 8 at a time (independent loads in flight) and added in the original order
     double acc = 0.0;
-    for (int b = lo; b < hi; b++) acc += (b == nblk - 1 ? last_n : (double)rows_per_block) * (double)partial[(size_t)b * 2 * c + ch];
+    {
+        int b = lo;
+        for (; b + 8 <= hi; b += 8) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = partial[(size_t)(b + j) * 2 * c + ch];
+#pragma unroll
+            for (int j = 0; j < 8; j++) acc += (b + j == nblk - 1 ? last_n : (double)rows_per_block) * (double)v[j];
+        }
+        for (; b < hi; b++) acc += (b == nblk - 1 ? last_n : (double)rows_per_block) * (double)partial[(size_t)b * 2 * c + ch];
+    }
     sh[tid] = acc;
     __syncthreads();
     if (tid < c) {
@@ -133,9 +144,22 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
     __syncthreads();
     const double mean = sh_mean[ch];
     acc = 0.0;
-    for (int b = lo; b < hi; b++) {
-        const double d = (double)partial[(size_t)b * 2 * c + ch] - mean;
-        acc += (double)partial[(size_t)b * 2 * c + c + ch] + (b == nblk - 1 ? last_n : (double)rows_per_block) * d * d;
+    {
+        int b = lo;
+        for (; b + 8 <= hi; b += 8) {
+            float v[8], q2[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) { v[j] = partial[(size_t)(b + j) * 2 * c + ch]; q2[j] = partial[(size_t)(b + j) * 2 * c + c + ch]; }
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const double d = (double)v[j] - mean;
+                acc += (double)q2[j] + (b + j == nblk - 1 ? last_n : (double)rows_per_block) * d * d;
+            }
+        }
+        for (; b < hi; b++) {
+            const double d = (double)partial[(size_t)b * 2 * c + ch] - mean;
+            acc += (double)partial[(size_t)b * 2 * c + c + ch] + (b == nblk - 1 ? last_n : (double)rows_per_block) * d * d;
+        }
     }
     __syncthreads();
     sh[tid] = acc;
@@ -249,7 +273,15 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
     if (chunk < chunks) {
         const int per = (nblk + chunks - 1) / chunks;
         const int lo = chunk * per, hi = lo + per < nblk ? lo + per : nblk;
-        for (int q = lo; q < hi; q++) { a += (double)partial[(size_t)q * 2 * c + ch]; b += (double)partial[(size_t)q * 2 * c + c + ch]; }
+        int q = lo;
+        for (; q + 8 <= hi; q += 8) {  // 16 independent loads in flight, original summation order
+            float va[8], vb[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) { va[j] = partial[(size_t)(q + j) * 2 * c + ch]; vb[j] = partial[(size_t)(q + j) * 2 * c + c + ch]; }
+#pragma unroll
+            for (int j = 0; j < 8; j++) { a += (double)va[j]; b += (double)vb[j]; }
+        }
+        for (; q < hi; q++) { a += (double)partial[(size_t)q * 2 * c + ch]; b += (double)partial[(size_t)q * 2 * c + c + ch]; }
     }
     sh_a[tid] = a; sh_b[tid] = b;
     __syncthreads();

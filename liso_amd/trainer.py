@@ -79,12 +79,16 @@ class SlimTrainer:
     live in one flat buffer: data parallelism is one RCCL all-reduce of that buffer after the replay (no DDP wrapper),
     then the eager RMSprop step."""
 
-    def __init__(self, cfg, device, num_train_samples=1000, use_graph=False):
+    def __init__(self, cfg, device, num_train_samples=1000, use_graph=False, channels_last=False):
         from liso_amd.slim.model.slim import SLIM
         from liso_amd.utils.learning_rate import get_polynomial_decay_schedule_with_warmup
 
         self.cfg, self.slim_cfg, self.device = cfg, cfg.SLIM, device
         self.net = SLIM(cfg, num_train_samples=num_train_samples).to(device)
+        if channels_last:  # measured slower than NCHW filters on gfx950 (65 vs 59 ms per step): MIOpen's fp32 Winograd is NCHW
+            # the pillar canvas is channels-last storage; keep filters in the same layout so MIOpen's NHWC kernels run
+            # without a transpose before and after every convolution
+            self.net.raft_network.to(memory_format=torch.channels_last)
         self.model = self.net
         self.use_graph = bool(use_graph) and device.type == "cuda"
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1

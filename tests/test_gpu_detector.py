@@ -25,10 +25,14 @@ def _rel(a, b):
 
 
 def test_train_step_matches_cpu_oracle_fp32():
-    """Forward (loss) within 1e-3 of the oracle.  Gradients: the backward of a freshly initialised BN/ReLU stack with
-    small BN batches is ill-conditioned in fp32 -- the oracle run in fp32 differs from the oracle run in fp64 by up to
-    ~1e-2 on some tensors -- so each gradient must be within max(1e-3, 3x the oracle's own fp32-vs-fp64 error) of the
-    fp64 oracle: never worse than the reference arithmetic's rounding noise."""
+    """Forward (loss) within 1e-3 of the fp64 oracle.  Gradients: the loss is piecewise smooth -- 28 ReLU layers with
+    ~10^7 activations, a handful of which sit within fp32 rounding of their kink; whether such an activation counts as
+    positive decides if the (possibly large) upstream gradient of that pixel enters every parameter gradient upstream.
+    Measured: the GPU's inputs to `center_head.shared_conv` and the gradient arriving at its output agree with the
+    oracle to 3e-6 / 1e-6, the block's own backward agrees with an fp64 replay to 3e-7, yet its bias gradient differs by
+    2.5e-2 because of flipped kinks (scripts/debug_head.py).  The tolerance is therefore the oracle's OWN sensitivity:
+    the fp64 oracle is re-run with every parameter perturbed by the relative size of the measured forward mismatch
+    (3e-6), and each GPU gradient must be within max(1e-3, 3x the largest change that perturbation causes)."""
     from oracle.train_step import detector_forward_loss, prepare_state
 
     tr, pcls, targets = _setup(128, 100.0, 2, 20000)
@@ -38,20 +42,29 @@ def test_train_step_matches_cpu_oracle_fp32():
     total.backward()
     cpu_pcls = [p.cpu() for p in pcls]
     t_cpu = {k: v.cpu() for k, v in targets.items()}
-    sd32, sd64 = prepare_state(sd0, torch.float32), prepare_state(sd0, torch.float64)
-    ref32, _, _ = detector_forward_loss(sd32, cpu_pcls, t_cpu, 128, 100.0)
-    ref32.backward()
+    sd64 = prepare_state(sd0, torch.float64)
     ref64, _, _ = detector_forward_loss(sd64, cpu_pcls, t_cpu, 128, 100.0, dtype=torch.float64)
     ref64.backward()
     assert abs(float(total) - float(ref64)) <= 1e-3 * abs(float(ref64))
     names = dict(tr.net.named_parameters())
     keys = [k for k, p in names.items() if p.grad is not None and sd64[k].grad is not None
             and float(sd64[k].grad.abs().max()) >= 1e-6]  # conv biases in front of a BatchNorm: true gradient == 0
-    noise = max(_rel(sd32[k].grad, sd64[k].grad) for k in keys)  # conditioning of this backward in fp32
+    noise = 0.0
+    gen = torch.Generator().manual_seed(1)
+    for _ in range(4):  # kink sensitivity of the reference arithmetic itself
+        sdp = prepare_state(sd0, torch.float64)
+        with torch.no_grad():
+            for k in keys:
+                sdp[k].mul_(1.0 + 3e-6 * torch.randn(sdp[k].shape, generator=gen, dtype=torch.float64))
+        refp, _, _ = detector_forward_loss(sdp, cpu_pcls, t_cpu, 128, 100.0, dtype=torch.float64)
+        refp.backward()
+        noise = max(noise, max(_rel(sdp[k].grad, sd64[k].grad) for k in keys))
+    worst = max(_rel(names[k].grad, sd64[k].grad) for k in keys)
+    print(f"worst gradient error {worst:.2e}; oracle sensitivity to a 3e-6 perturbation {noise:.2e}")
     for k in keys:
-        assert _rel(names[k].grad, sd64[k].grad) <= max(2e-3, 3 * noise), (k, _rel(names[k].grad, sd64[k].grad), noise)
+        assert _rel(names[k].grad, sd64[k].grad) <= max(1e-3, 3 * noise), (k, _rel(names[k].grad, sd64[k].grad), noise)
     assert len(keys) > 60
-    # the last layers are well conditioned: tight
+    # the last layers see no kinks downstream except their own head: tight
     for k in ("model.center_head.tasks.0.rot.3.weight", "model.center_head.tasks.0.probs.3.bias"):
         assert _rel(names[k].grad, sd64[k].grad) < 1e-3, k
 
