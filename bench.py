@@ -73,7 +73,7 @@ SLIM_KERNELS = {
 
 
 LOOP_KERNELS = {  # name -> (description, algorithmic bytes per launch at B=1, N=120k, G=512)
-    "pfn_forward_scatter": ("pfn_forward_dense_kernel (fused decorate+Linear+BN+ReLU+max+scatter)", None),
+    "pfn_forward_scatter": ("pfn_forward_kernel (Linear+BN+ReLU+max + dense scatter from CSR feature rows)", None),
     "corr_lookup_fwd": (SLIM_KERNELS["corr_lookup_fwd"], None),
     "bev_dynamic_flow": ("bev_scatter_kernel + bev_mean_kernel (non-rigid flow, fixed-point scatter-mean)",
                          N_POINTS * (12 + 12 + 8 + 1) + GRID * GRID * 16),
@@ -158,7 +158,7 @@ def main():
         pcls, targets = detector_batch(seed=1 + rank, batch=batch, device=dev, n_points=N_POINTS, grid=GRID,
                                        bev_range_m=BEV_RANGE)
         step = lambda: trainer.step(pcls, targets)  # noqa: E731
-        frames_per_step, timed = batch, ["pfn_forward_scatter"]
+        frames_per_step, timed = batch, ["pfn_decorate", "pfn_forward_scatter"]
 
     for _ in range(args.warmup):
         step()
@@ -220,10 +220,13 @@ def main():
         else:
             key = "pfn_forward_scatter"
             alg = pfn_algorithmic_bytes(batch, N_POINTS, GRID, 2 if args.dtype == "bf16" else 4)
-            kname = "pfn_forward_dense_kernel (fused decorate+Linear+BN+ReLU+max+scatter)"
+            kname = ("pfn_decorate_kernel (+3 scan kernels) then pfn_forward_kernel: decorate -> Linear+BN+ReLU+max -> dense "
+                     "scatter; the two launches are timed together")
             workload = ("CenterPoint-pillar detector train step (BASELINE configs[2]): 120k-pt KITTI-shaped clouds, "
                         "512x512 BEV pillars, fwd+bwd+AdamW")
         avg_ms = sum(durs[key]) / max(len(durs[key]), 1)
+        if args.workload == "detector":  # the pillar pass is two launches (decorate, forward): time them as one unit
+            avg_ms += sum(durs["pfn_decorate"]) / max(len(durs["pfn_decorate"]), 1)
         achieved = alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         line = {
             "metric": "LISO train-step frames/sec (120k-pt clouds)",

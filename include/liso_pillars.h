@@ -54,34 +54,44 @@ int liso_pillars_voxelize_f32(const float* points, const int* offsets_host, int 
                               int* coors, int* num_points, int* slots, int* num_voxels, int* cell_to_voxel,
                               void* workspace, size_t workspace_bytes, void* stream);
 
+/* Decorated feature rows in pillar order (CSR).  Walks the count -> slot indices -> points chain of every pillar once
+ * (pillar_encoder.py:109-146: cluster-centre and voxel-centre offsets, legacy aliasing) and writes, for every kept point,
+ * a 12-float row [f_0 .. f_{C+5}, 1, 0 pad]; the rows of pillar row v are feat[pt_off[v] .. pt_off[v+1]).
+ *   pt_off     int32 [B*max_voxels + 1]   (rows of a sample beyond its num_voxels are empty)
+ *   feat       float32 [>= total points, 12]  (16-B aligned)
+ *   voxel_cell int32 [B*max_voxels]       flattened canvas cell (b*gx + x_idx)*gy + y_idx of the pillar, -1 if unused
+ * Everything downstream (statistics, forward, backward) streams these rows; the point cloud is not read again. */
+size_t liso_pfn_decorate_workspace_bytes(int batch, int max_voxels);
+int liso_pfn_decorate_f32(const float* points, const liso_pillar_cfg* cfg, int batch, const int* coors, const int* num_points,
+                          const int* slots, const int* num_voxels, int* pt_off, float* feat, int* voxel_cell, void* workspace,
+                          size_t workspace_bytes, void* stream);
+
 /* Batch statistics of the PFN linear output for BatchNorm1d in training mode, then scale/shift.
  *   weight [64, C+6] row-major, gamma/beta/running_mean/running_var [64] (running_* updated in place when
  *   training != 0 with `momentum`; unbiased variance, as torch.nn.BatchNorm1d).
  *   bn_out float32 [4*64] = scale | shift | mean | invstd ;  moments float64 [LISO_PFN_STATS_DOUBLES] (for backward)
  *   partials: device scratch of liso_pfn_partials_bytes() bytes.
- * training == 0: scale/shift from running stats, nothing else is touched. */
+ * training == 0: scale/shift from running stats, nothing else is touched (feat / pt_off may be NULL). */
 size_t liso_pfn_partials_bytes(void);
-int liso_pfn_bn_prepare_f32(const float* points, const liso_pillar_cfg* cfg, int batch, const int* coors,
-                            const int* num_points, const int* slots, const int* num_voxels, const float* weight,
-                            const float* gamma, const float* beta, float* running_mean, float* running_var,
-                            float momentum, float eps, int training, float* bn_out, double* moments, void* partials,
-                            void* stream);
+int liso_pfn_bn_prepare_f32(const float* feat, const int* pt_off, const liso_pillar_cfg* cfg, int batch, const int* num_voxels,
+                            const float* weight, const float* gamma, const float* beta, float* running_mean,
+                            float* running_var, float momentum, float eps, int training, float* bn_out, double* moments,
+                            void* partials, void* stream);
 
-/* Fused decorate + Linear + BN + ReLU + max + dense scatter.  Every cell of canvas and occupancy is written exactly
- * once (zeros for empty cells: pillar_scatter.py:78-82 allocates zeros), so the caller need NOT pre-fill them.
+/* Fused Linear + BN + ReLU + max + dense scatter.  Every cell of canvas and occupancy is written exactly once (zeros
+ * for empty cells: pillar_scatter.py:78-82 allocates zeros), so the caller need NOT pre-fill them.
  * cell_to_voxel comes from liso_pillars_voxelize_f32.  out_bf16 != 0: canvas is bfloat16, else float32. */
-int liso_pfn_forward_scatter(const float* points, const liso_pillar_cfg* cfg, int batch, const int* coors,
-                             const int* num_points, const int* slots, const int* cell_to_voxel, const float* weight,
-                             const float* bn_out, void* canvas, int out_bf16, float* occupancy, void* stream);
+int liso_pfn_forward_scatter(const float* feat, const int* pt_off, const int* voxel_cell, const liso_pillar_cfg* cfg, int batch,
+                             const int* cell_to_voxel, const float* weight, const float* bn_out, void* canvas, int out_bf16,
+                             float* occupancy, void* stream);
 
 /* Backward of the fused op w.r.t. weight, gamma, beta (inputs carry no gradient: voxelize is no_grad,
  * pcl_to_feature_grid.py:56).  grad_canvas has the canvas layout/dtype.  grad_weight [64, C+6],
  * grad_gamma/grad_beta [64] are overwritten.  partials: liso_pfn_partials_bytes() bytes of scratch. */
-int liso_pfn_backward(const float* points, const liso_pillar_cfg* cfg, int batch, const int* coors,
-                      const int* num_points, const int* slots, const int* num_voxels, const float* weight,
-                      const float* gamma, const float* bn_out, const double* moments, int training,
-                      const void* grad_canvas, int grad_bf16, float* grad_weight, float* grad_gamma,
-                      float* grad_beta, void* partials, void* stream);
+int liso_pfn_backward(const float* feat, const int* pt_off, const int* voxel_cell, const liso_pillar_cfg* cfg, int batch,
+                      const int* num_voxels, const float* weight, const float* gamma, const float* bn_out,
+                      const double* moments, int training, const void* grad_canvas, int grad_bf16, float* grad_weight,
+                      float* grad_gamma, float* grad_beta, void* partials, void* stream);
 
 #ifdef __cplusplus
 }

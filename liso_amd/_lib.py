@@ -81,11 +81,11 @@ SIGNATURES = {
     "liso_pillars_voxelize_workspace_bytes": (_sz, [_vp, _i, _i]),
     "liso_pillars_voxelize_f32": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "liso_pfn_partials_bytes": (_sz, []),
-    "liso_pfn_bn_prepare_f32": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp,
-                                     _vp, _vp]),
-    "liso_pfn_forward_scatter": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
-    "liso_pfn_backward": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp,
-                               _vp]),
+    "liso_pfn_decorate_workspace_bytes": (_sz, [_i, _i]),
+    "liso_pfn_decorate_f32": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "liso_pfn_bn_prepare_f32": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp]),
+    "liso_pfn_forward_scatter": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "liso_pfn_backward": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     # include/liso_kabsch.h
     "liso_kabsch_workspace_bytes": (_sz, [_vp]),
     "liso_kabsch_trafos_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -167,7 +167,12 @@ __global__ void fill_kernel(const int* __restrict__ cell_of_point, const int* __
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// PFN: shared row builder.  One wave per pillar; lane s < num owns point s.
+// PFN.  The voxeliser leaves, per pillar, up to 20 point indices in first-come order (`slots`): reading a pillar is a
+// chain of three dependent loads (count -> indices -> points).  `pfn_decorate` walks that chain ONCE, massively
+// parallel (32 lanes per pillar, every pillar of the batch in flight), and writes the decorated feature rows
+// [f_0..f_{F-1}, 1, pad] (12 floats) of all kept points contiguously in pillar order (CSR: pt_off[v] .. pt_off[v+1]).
+// The three consumers -- BN statistics, forward, backward -- then stream rows: a wave stages the rows of kGroup
+// consecutive pillars into LDS with coalesced 16-B loads and computes with lanes = 64 output channels.
 // ---------------------------------------------------------------------------------------------------------
 struct PfnGeom {
     float vx, vy, x_off, y_off, z_off;  // pillar_encoder.py:86-91 (offsets = v/2 + range_min)
@@ -182,89 +187,156 @@ __device__ __forceinline__ PfnGeom pfn_geom(const liso_pillar_cfg& c) {
     return g;
 }
 
-// Builds the decorated rows of pillar v into frow[s][0..F) (and frow[s][F] = 1), returns num.
-// Channel order (pillar_encoder.py:109-146 with legacy aliasing, :129-139): the in-place f_center update
+constexpr int kGroup = 4;                       // pillars staged per wave step
+constexpr int kStage = kGroup * kMaxPts;        // rows of LDS per wave (worst case)
+
+// exclusive scan of the kept-point counts of all pillar rows (rows of samples beyond num_voxels count 0)
+__device__ __forceinline__ int kept_points(const int* __restrict__ num_points, const int* __restrict__ num_voxels, int max_voxels,
+                                           int rows, int v) {
+    if (v >= rows) return 0;
+    const int b = v / max_voxels;
+    return (v - b * max_voxels) < num_voxels[b] ? num_points[v] : 0;
+}
+
+__global__ __launch_bounds__(1024) void pfn_scan_block_kernel(const int* __restrict__ num_points, const int* __restrict__ num_voxels,
+                                                              int max_voxels, int rows, int* __restrict__ pt_off,
+                                                              int* __restrict__ block_tot) {
+    __shared__ int wsum[16];
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int v = kept_points(num_points, num_voxels, max_voxels, rows, i);
+    int incl = v;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; w++) base += wsum[w];
+    if (i < rows) pt_off[i] = base + incl - v;
+    if (threadIdx.x == 1023) block_tot[blockIdx.x] = base + incl;
+}
+
+__global__ __launch_bounds__(1024) void pfn_scan_tot_kernel(int* __restrict__ block_tot, int nblocks) {
+    __shared__ int wsum[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int v = (int)threadIdx.x < nblocks ? block_tot[threadIdx.x] : 0;
+    int incl = v;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; w++) base += wsum[w];
+    if ((int)threadIdx.x < nblocks) block_tot[threadIdx.x] = base + incl - v;
+    if ((int)threadIdx.x == nblocks - 1) block_tot[nblocks] = base + incl;
+}
+
+__global__ __launch_bounds__(1024) void pfn_scan_add_kernel(int* __restrict__ pt_off, int rows, const int* __restrict__ block_tot,
+                                                            int nblocks) {
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    if (i < rows) pt_off[i] += block_tot[blockIdx.x];
+    if (i == 0) pt_off[rows] = block_tot[nblocks];
+}
+
+// Decorated rows.  Channel order (pillar_encoder.py:109-146 with legacy aliasing, :129-139): the in-place f_center update
 // overwrites xyz of `features` itself, so the 10 inputs are [fc(3), extras(C-3), cluster(3), fc(3)], and because
 // of the x/y swap at pcl_to_feature_grid.py:73, fc_x uses the *y index* and fc_y the *x index*.
 template <int C>
-__device__ __forceinline__ int build_rows(const float* __restrict__ pts, const int* __restrict__ slots,
-                                          const int* __restrict__ coors, const int* __restrict__ num_points, int v,
-                                          int max_points, const PfnGeom& g, float (*frow)[kFP], int lane) {
+__global__ __launch_bounds__(256) void pfn_decorate_kernel(const float* __restrict__ pts, liso_pillar_cfg cfg, int rows,
+                                                           const int* __restrict__ coors, const int* __restrict__ num_points,
+                                                           const int* __restrict__ slots, const int* __restrict__ num_voxels,
+                                                           const int* __restrict__ pt_off, float* __restrict__ feat,
+                                                           int* __restrict__ voxel_cell) {
 #pragma clang fp contract(off)
     constexpr int F = C + 6;
-    const int num = num_points[v];
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int v = (int)(t >> 5), s = (int)(t & 31);  // 32 lanes per pillar (max_points <= 32)
+    if (v >= rows) return;
+    const int num = kept_points(num_points, num_voxels, cfg.max_voxels, rows, v);
     const int xi = coors[v * 4 + 2], yi = coors[v * 4 + 3];
+    if (s == 0) voxel_cell[v] = num > 0 ? ((v / cfg.max_voxels) * cfg.gx + xi) * cfg.gy + yi : -1;
     float p[C];
 #pragma unroll
     for (int k = 0; k < C; k++) p[k] = 0.f;
-    if (lane < num) {
-        const int idx = slots[(size_t)v * max_points + lane];
+    if (s < num) {
+        const int idx = slots[(size_t)v * cfg.max_points + s];
         const float* q = pts + (size_t)idx * C;
         if constexpr (C == 4) {
-            const float4 t = *reinterpret_cast<const float4*>(q);
-            p[0] = t.x; p[1] = t.y; p[2] = t.z; p[3] = t.w;
+            const float4 tt = *reinterpret_cast<const float4*>(q);
+            p[0] = tt.x; p[1] = tt.y; p[2] = tt.z; p[3] = tt.w;
         } else {
 #pragma unroll
             for (int k = 0; k < C; k++) p[k] = q[k];
         }
     }
-    // points_mean = sum over the (zero padded) slots / num_points, pillar_encoder.py:112-115
+    // points_mean = sum over the (zero padded) slots / num_points, pillar_encoder.py:112-115; the butterfly offsets
+    // stay inside the 32-lane half that holds this pillar
     float sx = p[0], sy = p[1], sz = p[2];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
+    for (int o = 16; o > 0; o >>= 1) {
         sx += __shfl_xor(sx, o);
         sy += __shfl_xor(sy, o);
         sz += __shfl_xor(sz, o);
     }
+    if (s >= num) return;
+    const PfnGeom g = pfn_geom(cfg);
     const float fn = (float)num;
     const float mx = sx / fn, my = sy / fn, mz = sz / fn;
-    if (lane < num) {
-        const float fcx = p[0] - ((float)yi * g.vx + g.x_off);  // coors[:,3] (= y index) * vx, :130-132
-        const float fcy = p[1] - ((float)xi * g.vy + g.y_off);  // coors[:,2] (= x index) * vy, :133-135
-        const float fcz = p[2] - (0.f + g.z_off);               // coors[:,1] == 0,              :136-138
-        float* f = frow[lane];
-        f[0] = fcx; f[1] = fcy; f[2] = fcz;
+    const float fcx = p[0] - ((float)yi * g.vx + g.x_off);  // coors[:,3] (= y index) * vx, :130-132
+    const float fcy = p[1] - ((float)xi * g.vy + g.y_off);  // coors[:,2] (= x index) * vy, :133-135
+    const float fcz = p[2] - (0.f + g.z_off);               // coors[:,1] == 0,              :136-138
+    float f[kFP];
 #pragma unroll
-        for (int k = 3; k < C; k++) f[k] = p[k];
-        f[C + 0] = p[0] - mx; f[C + 1] = p[1] - my; f[C + 2] = p[2] - mz;
-        f[C + 3] = fcx; f[C + 4] = fcy; f[C + 5] = fcz;
-        f[F] = 1.f;
-    }
-    return num;
+    for (int k = 0; k < kFP; k++) f[k] = 0.f;
+    f[0] = fcx; f[1] = fcy; f[2] = fcz;
+#pragma unroll
+    for (int k = 3; k < C; k++) f[k] = p[k];
+    f[C + 0] = p[0] - mx; f[C + 1] = p[1] - my; f[C + 2] = p[2] - mz;
+    f[C + 3] = fcx; f[C + 4] = fcy; f[C + 5] = fcz;
+    f[F] = 1.f;
+    float4* row = reinterpret_cast<float4*>(feat + ((size_t)pt_off[v] + s) * kFP);
+    row[0] = make_float4(f[0], f[1], f[2], f[3]);
+    row[1] = make_float4(f[4], f[5], f[6], f[7]);
+    row[2] = make_float4(f[8], f[9], f[10], f[11]);
 }
 
-// ---- stats: second moments of the augmented feature vector [f, 1] over all valid rows ----------------------
+// ---- stats: second moments of the augmented feature vector [f, 1] over all kept rows ------------------------
+// Rows are independent: every block takes a contiguous chunk, a wave stages 64 rows at a time, lanes = moment pairs.
 template <int C>
-__global__ __launch_bounds__(kPfnThreads) void pfn_stats_kernel(const float* __restrict__ pts, liso_pillar_cfg cfg,
-                                                                int batch, const int* __restrict__ coors,
-                                                                const int* __restrict__ num_points,
-                                                                const int* __restrict__ slots,
-                                                                const int* __restrict__ num_voxels,
-                                                                double* __restrict__ partials) {
+__global__ __launch_bounds__(kPfnThreads) void pfn_stats_kernel(const float* __restrict__ feat, const int* __restrict__ pt_off,
+                                                                int rows, double* __restrict__ partials) {
     constexpr int F = C + 6, D = F + 1, NP = D * (D + 1) / 2;
-    __shared__ float frow[kPfnThreads / 64][kMaxPts][kFP];
+    __shared__ __attribute__((aligned(16))) float tile[kPfnThreads / 64][64][kFP];
     __shared__ double red[kPfnThreads / 64][LISO_PFN_STATS_DOUBLES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const PfnGeom g = pfn_geom(cfg);
     // lane -> up to two (j,k) pairs of the upper triangle
     int pj[2] = {0, 0}, pk[2] = {0, 0};
     {
-        int e = 0;
+        int idx = 0;
         for (int j = 0; j < D; j++)
-            for (int k = j; k < D; k++, e++) {
-                if (e == lane) { pj[0] = j; pk[0] = k; }
-                if (e == lane + 64) { pj[1] = j; pk[1] = k; }
+            for (int k = j; k < D; k++, idx++) {
+                if (idx == lane) { pj[0] = j; pk[0] = k; }
+                if (idx == lane + 64) { pj[1] = j; pk[1] = k; }
             }
     }
+    const long n = pt_off[rows];
+    const long waves = (long)gridDim.x * (kPfnThreads / 64);
+    const long per = ((n + waves - 1) / waves + 63) / 64 * 64;  // rows per wave, multiple of the 64-row tile
+    const long w_id = (long)blockIdx.x * (kPfnThreads / 64) + wave;
+    const long r0 = w_id * per, r1 = r0 + per < n ? r0 + per : n;
     double acc0 = 0.0, acc1 = 0.0;
-    const int rows = batch * cfg.max_voxels;
-    for (int v = blockIdx.x * (kPfnThreads / 64) + wave; v < rows; v += gridDim.x * (kPfnThreads / 64)) {
-        const int b = v / cfg.max_voxels;
-        if (v - b * cfg.max_voxels >= num_voxels[b]) continue;
-        const int num = build_rows<C>(pts, slots, coors, num_points, v, cfg.max_points, g, frow[wave], lane);
+    for (long base = r0; base < r1; base += 64) {
+        const int cnt = (int)(r1 - base < 64 ? r1 - base : 64);
+        const float4* src = reinterpret_cast<const float4*>(feat + (size_t)base * kFP);
+        float4* dst = reinterpret_cast<float4*>(&tile[wave][0][0]);
+        for (int i = lane; i < cnt * 3; i += 64) dst[i] = src[i];
         __builtin_amdgcn_wave_barrier();
-        for (int s = 0; s < num; s++) {
-            const float* f = frow[wave][s];
+        for (int s = 0; s < cnt; s++) {
+            const float* f = tile[wave][s];
             acc0 += (double)f[pj[0]] * (double)f[pk[0]];
             if (lane + 64 < NP) acc1 += (double)f[pj[1]] * (double)f[pk[1]];
         }
@@ -367,34 +439,42 @@ template <typename T> __device__ __forceinline__ float load_in(const T* p);
 template <> __device__ __forceinline__ float load_in<float>(const float* p) { return *p; }
 template <> __device__ __forceinline__ float load_in<__hip_bfloat16>(const __hip_bfloat16* p) { return __bfloat162float(*p); }
 
+// stage the rows of pillars [v0, v0 + kGroup) of one wave step: returns the group's first row offset, fills off[] (lane
+// g holds pt_off[v0+g] for g <= kGroup) and copies the rows into `frow` with 16-B loads
+__device__ __forceinline__ void stage_rows(const float* __restrict__ feat, const int* __restrict__ pt_off, int rows, int v0, int lane,
+                                           float (*frow)[kFP], int (&off)[kGroup + 1]) {
+    int o = 0;
+    if (lane <= kGroup) { const int v = v0 + lane; o = pt_off[v < rows ? v : rows]; }
+#pragma unroll
+    for (int g = 0; g <= kGroup; g++) off[g] = __shfl(o, g);
+    const int total = off[kGroup] - off[0];
+    const float4* src = reinterpret_cast<const float4*>(feat + (size_t)off[0] * kFP);
+    float4* dst = reinterpret_cast<float4*>(&frow[0][0]);
+    for (int i = lane; i < total * 3; i += 64) dst[i] = src[i];
+}
+
 // ---- forward: Linear(F,64, no bias) -> BN -> ReLU -> max over the 20 slots -> canvas[b, x_idx, y_idx, :] ------------
-// Dense-writer form: every canvas cell is written exactly once.
-// A block owns 256 consecutive cells of the [B, gx, gy] grid.  Empty cells are zero-filled with 16-B stores (one
-// coalesced 4-KiB wave-instruction per 32 bf16 cells), occupied cells get their 64 PFN channels; no separate memset
-// pass over the 64*G^2 canvas and no double write.  HBM traffic = the canvas once + ~1 MB of cell->voxel indices.
+// One launch, two kinds of blocks, every canvas cell written exactly once (no memset pass, no double write):
+//   blocks [0, zero_blocks): 256 consecutive cells each; empty cells are zero-filled with 16-B stores (consecutive
+//                            threads -> consecutive chunks), the occupancy map is written;
+//   the other blocks:        pillars in voxel order, kGroup per wave step, rows streamed from the CSR feature array,
+//                            one 128-B (bf16) / 256-B (fp32) row store per pillar.
 constexpr int kCellsPerBlock = 256;
 
 template <int C, typename OutT>
-__global__ __launch_bounds__(kPfnThreads) void pfn_forward_dense_kernel(const float* __restrict__ pts, liso_pillar_cfg cfg,
-                                                                        long total_cells, const int* __restrict__ coors,
-                                                                        const int* __restrict__ num_points,
-                                                                        const int* __restrict__ slots,
-                                                                        const int* __restrict__ cell_to_voxel,
-                                                                        const float* __restrict__ weight,
-                                                                        const float* __restrict__ bn,
-                                                                        OutT* __restrict__ canvas,
-                                                                        float* __restrict__ occupancy) {
+__global__ __launch_bounds__(kPfnThreads) void pfn_forward_kernel(const float* __restrict__ feat, const int* __restrict__ pt_off,
+                                                                  const int* __restrict__ voxel_cell, int rows, int max_points,
+                                                                  long total_cells, int zero_blocks,
+                                                                  const int* __restrict__ cell_to_voxel,
+                                                                  const float* __restrict__ weight, const float* __restrict__ bn,
+                                                                  OutT* __restrict__ canvas, float* __restrict__ occupancy) {
     constexpr int F = C + 6;
     constexpr int kChunks = kOut * (int)sizeof(OutT) / 16;  // 16-B chunks per cell (8 for bf16, 16 for fp32)
-    __shared__ float frow[kPfnThreads / 64][kMaxPts][kFP];
+    __shared__ __attribute__((aligned(16))) float frow[kPfnThreads / 64][kStage][kFP];
     __shared__ int vox[kCellsPerBlock];
-    __shared__ int list[kCellsPerBlock];
-    __shared__ int cnt;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long cell0 = (long)blockIdx.x * kCellsPerBlock;
-    if (tid == 0) cnt = 0;
-    __syncthreads();
-    {
+    if ((int)blockIdx.x < zero_blocks) {
+        const long cell0 = (long)blockIdx.x * kCellsPerBlock;
         const long cell = cell0 + tid;
         int v1 = 0;
         if (cell < total_cells) {
@@ -402,60 +482,61 @@ __global__ __launch_bounds__(kPfnThreads) void pfn_forward_dense_kernel(const fl
             occupancy[cell] = v1 > 0 ? 1.f : 0.f;
         }
         vox[tid] = v1;
-        if (v1 > 0) list[atomicAdd(&cnt, 1)] = tid;
-    }
-    __syncthreads();
-    // zero-fill the empty cells: consecutive threads -> consecutive 16-B chunks
-    {
+        __syncthreads();
         const uint4 z = make_uint4(0u, 0u, 0u, 0u);
         uint4* base = reinterpret_cast<uint4*>(canvas + (size_t)cell0 * kOut);
         for (int id = tid; id < kCellsPerBlock * kChunks; id += kPfnThreads) {
             const int cl = id / kChunks;
             if (cell0 + cl < total_cells && vox[cl] == 0) base[id] = z;
         }
+        return;
     }
-    const int n_occ = cnt;
-    if (n_occ == 0) return;
-    const PfnGeom g = pfn_geom(cfg);
     float w[F];
 #pragma unroll
     for (int k = 0; k < F; k++) w[k] = weight[lane * F + k];
     const float scale = bn[lane], shift = bn[kOut + lane];
     const float pad_val = fmaxf(shift, 0.f);
-    for (int i = wave; i < n_occ; i += kPfnThreads / 64) {
-        const int cl = list[i];
-        const int v = vox[cl] - 1;
-        const int num = build_rows<C>(pts, slots, coors, num_points, v, cfg.max_points, g, frow[wave], lane);
+    const int wave_id = ((int)blockIdx.x - zero_blocks) * (kPfnThreads / 64) + wave;
+    const int n_waves = ((int)gridDim.x - zero_blocks) * (kPfnThreads / 64);
+    for (int v0 = wave_id * kGroup; v0 < rows; v0 += n_waves * kGroup) {
+        int off[kGroup + 1];
+        stage_rows(feat, pt_off, rows, v0, lane, frow[wave], off);
+        int cell_l = -1;
+        if (lane < kGroup && v0 + lane < rows) cell_l = voxel_cell[v0 + lane];
         __builtin_amdgcn_wave_barrier();
-        float best = num < cfg.max_points ? pad_val : 0.f;
-        for (int s = 0; s < num; s++) {
-            const float* f = frow[wave][s];
-            float x = 0.f;
 #pragma unroll
-            for (int k = 0; k < F; k++) x = fmaf(w[k], f[k], x);
-            best = fmaxf(best, fmaxf(fmaf(x, scale, shift), 0.f));
+        for (int g = 0; g < kGroup; g++) {
+            const int num = off[g + 1] - off[g];
+            const int cell = __shfl(cell_l, g);
+            if (num <= 0 || cell < 0) continue;
+            float best = num < max_points ? pad_val : 0.f;
+            const int r0 = off[g] - off[0];
+            for (int s = 0; s < num; s++) {
+                const float4* f4 = reinterpret_cast<const float4*>(frow[wave][r0 + s]);
+                const float4 a = f4[0], b = f4[1], c4 = f4[2];
+                const float f[kFP] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c4.x, c4.y, c4.z, c4.w};
+                float x = 0.f;
+#pragma unroll
+                for (int k = 0; k < F; k++) x = fmaf(w[k], f[k], x);
+                best = fmaxf(best, fmaxf(fmaf(x, scale, shift), 0.f));
+            }
+            store_out<OutT>(canvas + (size_t)cell * kOut + lane, best);
         }
         __builtin_amdgcn_wave_barrier();
-        store_out<OutT>(canvas + ((size_t)cell0 + cl) * kOut + lane, best);
     }
 }
 
 // ---- backward: per-block partial sums of  A[c][k] = sum dz*f,  dbeta[c] = sum dz,  dgamma[c] = sum dz*xhat ------
 template <int C, typename GT>
-__global__ __launch_bounds__(kPfnThreads) void pfn_backward_kernel(const float* __restrict__ pts, liso_pillar_cfg cfg,
-                                                                   int batch, const int* __restrict__ coors,
-                                                                   const int* __restrict__ num_points,
-                                                                   const int* __restrict__ slots,
-                                                                   const int* __restrict__ num_voxels,
-                                                                   const float* __restrict__ weight,
-                                                                   const float* __restrict__ bn,
+__global__ __launch_bounds__(kPfnThreads) void pfn_backward_kernel(const float* __restrict__ feat, const int* __restrict__ pt_off,
+                                                                   const int* __restrict__ voxel_cell, int rows, int max_points,
+                                                                   const float* __restrict__ weight, const float* __restrict__ bn,
                                                                    const GT* __restrict__ grad_canvas,
                                                                    float* __restrict__ partials) {
     constexpr int F = C + 6, NA = F + 2;
-    __shared__ float frow[kPfnThreads / 64][kMaxPts][kFP];
+    __shared__ __attribute__((aligned(16))) float frow[kPfnThreads / 64][kStage][kFP];
     __shared__ float red[kPfnThreads / 64][NA][kOut];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const PfnGeom g = pfn_geom(cfg);
     float w[F], acc[NA];
 #pragma unroll
     for (int k = 0; k < F; k++) w[k] = weight[lane * F + k];
@@ -463,34 +544,41 @@ __global__ __launch_bounds__(kPfnThreads) void pfn_backward_kernel(const float* 
     for (int k = 0; k < NA; k++) acc[k] = 0.f;
     const float scale = bn[lane], shift = bn[kOut + lane], mean = bn[2 * kOut + lane], invstd = bn[3 * kOut + lane];
     const float pad_val = fmaxf(shift, 0.f);
-    const int rows = batch * cfg.max_voxels;
-    for (int v = blockIdx.x * (kPfnThreads / 64) + wave; v < rows; v += gridDim.x * (kPfnThreads / 64)) {
-        const int b = v / cfg.max_voxels;
-        if (v - b * cfg.max_voxels >= num_voxels[b]) continue;
-        const int num = build_rows<C>(pts, slots, coors, num_points, v, cfg.max_points, g, frow[wave], lane);
+    const int wave_id = (int)blockIdx.x * (kPfnThreads / 64) + wave;
+    const int n_waves = (int)gridDim.x * (kPfnThreads / 64);
+    for (int v0 = wave_id * kGroup; v0 < rows; v0 += n_waves * kGroup) {
+        int off[kGroup + 1];
+        stage_rows(feat, pt_off, rows, v0, lane, frow[wave], off);
+        int cell_l = -1;
+        if (lane < kGroup && v0 + lane < rows) cell_l = voxel_cell[v0 + lane];
         __builtin_amdgcn_wave_barrier();
-        float best = -1.f, best_x = 0.f;
-        int best_s = -1;
-        for (int s = 0; s < num; s++) {
-            const float* f = frow[wave][s];
-            float x = 0.f;
 #pragma unroll
-            for (int k = 0; k < F; k++) x = fmaf(w[k], f[k], x);
-            const float y = fmaxf(fmaf(x, scale, shift), 0.f);
-            if (y > best) { best = y; best_s = s; best_x = x; }
-        }
-        if (num < cfg.max_points && pad_val > best) { best = pad_val; best_s = -1; best_x = 0.f; }
-        const int xi = coors[v * 4 + 2], yi = coors[v * 4 + 3];
-        const size_t cellidx = ((size_t)b * cfg.gx + xi) * cfg.gy + yi;
-        const float gy = load_in<GT>(grad_canvas + cellidx * kOut + lane);
-        const float dz = best > 0.f ? gy : 0.f;  // ReLU gate; the max routes the gradient to one row
-        if (best_s >= 0) {
-            const float* f = frow[wave][best_s];
+        for (int g = 0; g < kGroup; g++) {
+            const int num = off[g + 1] - off[g];
+            const int cell = __shfl(cell_l, g);
+            if (num <= 0 || cell < 0) continue;
+            const int r0 = off[g] - off[0];
+            float best = -1.f, best_x = 0.f;
+            int best_s = -1;
+            for (int s = 0; s < num; s++) {
+                const float* f = frow[wave][r0 + s];
+                float x = 0.f;
 #pragma unroll
-            for (int k = 0; k < F; k++) acc[k] = fmaf(dz, f[k], acc[k]);
+                for (int k = 0; k < F; k++) x = fmaf(w[k], f[k], x);
+                const float y = fmaxf(fmaf(x, scale, shift), 0.f);
+                if (y > best) { best = y; best_s = s; best_x = x; }
+            }
+            if (num < max_points && pad_val > best) { best = pad_val; best_s = -1; best_x = 0.f; }
+            const float gy = load_in<GT>(grad_canvas + (size_t)cell * kOut + lane);
+            const float dz = best > 0.f ? gy : 0.f;  // ReLU gate; the max routes the gradient to one row
+            if (best_s >= 0) {
+                const float* f = frow[wave][r0 + best_s];
+#pragma unroll
+                for (int k = 0; k < F; k++) acc[k] = fmaf(dz, f[k], acc[k]);
+            }
+            acc[F] += dz;
+            acc[F + 1] = fmaf(dz, (best_x - mean) * invstd, acc[F + 1]);
         }
-        acc[F] += dz;
-        acc[F + 1] = fmaf(dz, (best_x - mean) * invstd, acc[F + 1]);
         __builtin_amdgcn_wave_barrier();
     }
 #pragma unroll
@@ -587,16 +675,6 @@ inline int pfn_grid(int rows) {
     return need < kPfnGrid ? (need > 0 ? need : 1) : kPfnGrid;
 }
 
-template <int C>
-void launch_bn_prepare(const float* points, const liso_pillar_cfg* cfg, int batch, const int* coors,
-                       const int* num_points, const int* slots, const int* num_voxels, const float* weight,
-                       const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
-                       float eps, float* bn_out, double* moments, double* partials, int grid, hipStream_t st) {
-    pfn_stats_kernel<C><<<grid, kPfnThreads, 0, st>>>(points, *cfg, batch, coors, num_points, slots, num_voxels, partials);
-    pfn_bn_finalize_kernel<C><<<1, 1024, 0, st>>>(partials, grid, num_voxels, batch, cfg->max_points, weight, gamma, beta,
-                                                  running_mean, running_var, momentum, eps, bn_out, moments);
-}
-
 }  // namespace
 
 extern "C" {
@@ -651,38 +729,78 @@ size_t liso_pfn_partials_bytes(void) {
     return stats > bwd ? stats : bwd;
 }
 
-int liso_pfn_bn_prepare_f32(const float* points, const liso_pillar_cfg* cfg, int batch, const int* coors,
-                            const int* num_points, const int* slots, const int* num_voxels, const float* weight,
-                            const float* gamma, const float* beta, float* running_mean, float* running_var,
-                            float momentum, float eps, int training, float* bn_out, double* moments, void* partials,
-                            void* stream) {
+size_t liso_pfn_decorate_workspace_bytes(int batch, int max_voxels) {
+    if (batch < 1 || max_voxels < 1) return 0;
+    return ((size_t)(batch * (long)max_voxels + 1023) / 1024 + 2) * sizeof(int);
+}
+
+int liso_pfn_decorate_f32(const float* points, const liso_pillar_cfg* cfg, int batch, const int* coors, const int* num_points,
+                          const int* slots, const int* num_voxels, int* pt_off, float* feat, int* voxel_cell, void* workspace,
+                          size_t workspace_bytes, void* stream) {
+    if (!cfg_ok(cfg, batch) || !points || !coors || !num_points || !slots || !num_voxels || !pt_off || !feat || !voxel_cell ||
+        !workspace)
+        return LISO_EINVAL;
+    if (workspace_bytes < liso_pfn_decorate_workspace_bytes(batch, cfg->max_voxels)) return LISO_EWORKSPACE;
+    const int rows = batch * cfg->max_voxels;
+    const int nsb = (rows + 1023) / 1024;
+    if (nsb > 1024) return LISO_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    int* block_tot = (int*)workspace;
+    pfn_scan_block_kernel<<<nsb, 1024, 0, st>>>(num_points, num_voxels, cfg->max_voxels, rows, pt_off, block_tot);
+    pfn_scan_tot_kernel<<<1, 1024, 0, st>>>(block_tot, nsb);
+    pfn_scan_add_kernel<<<nsb, 1024, 0, st>>>(pt_off, rows, block_tot, nsb);
+    const unsigned grid = (unsigned)(((long)rows * 32 + 255) / 256);
+    switch (cfg->n_channels) {
+        case 3: pfn_decorate_kernel<3><<<grid, 256, 0, st>>>(points, *cfg, rows, coors, num_points, slots, num_voxels, pt_off, feat, voxel_cell); break;
+        case 4: pfn_decorate_kernel<4><<<grid, 256, 0, st>>>(points, *cfg, rows, coors, num_points, slots, num_voxels, pt_off, feat, voxel_cell); break;
+        default: pfn_decorate_kernel<5><<<grid, 256, 0, st>>>(points, *cfg, rows, coors, num_points, slots, num_voxels, pt_off, feat, voxel_cell); break;
+    }
+    return check_launch();
+}
+
+int liso_pfn_bn_prepare_f32(const float* feat, const int* pt_off, const liso_pillar_cfg* cfg, int batch, const int* num_voxels,
+                            const float* weight, const float* gamma, const float* beta, float* running_mean,
+                            float* running_var, float momentum, float eps, int training, float* bn_out, double* moments,
+                            void* partials, void* stream) {
     if (!cfg_ok(cfg, batch) || !gamma || !beta || !running_mean || !running_var || !bn_out) return LISO_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     if (!training) {
         pfn_bn_eval_kernel<<<1, 64, 0, st>>>(gamma, beta, running_mean, running_var, eps, bn_out);
         return check_launch();
     }
-    if (!points || !coors || !num_points || !slots || !num_voxels || !weight || !moments || !partials)
-        return LISO_EINVAL;
-    const int grid = pfn_grid(batch * cfg->max_voxels);
+    if (!feat || !pt_off || !num_voxels || !weight || !moments || !partials) return LISO_EINVAL;
+    const int rows = batch * cfg->max_voxels;
+    const int grid = kPfnGrid;
+#define LISO_PREP(CC)                                                                                                     \
+    do {                                                                                                                  \
+        pfn_stats_kernel<CC><<<grid, kPfnThreads, 0, st>>>(feat, pt_off, rows, (double*)partials);                           \
+        pfn_bn_finalize_kernel<CC><<<1, 1024, 0, st>>>((const double*)partials, grid, num_voxels, batch, cfg->max_points,    \
+                                                      weight, gamma, beta, running_mean, running_var, momentum, eps, bn_out, \
+                                                      moments);                                                           \
+    } while (0)
     switch (cfg->n_channels) {
-        case 3: launch_bn_prepare<3>(points, cfg, batch, coors, num_points, slots, num_voxels, weight, gamma, beta, running_mean, running_var, momentum, eps, bn_out, moments, (double*)partials, grid, st); break;
-        case 4: launch_bn_prepare<4>(points, cfg, batch, coors, num_points, slots, num_voxels, weight, gamma, beta, running_mean, running_var, momentum, eps, bn_out, moments, (double*)partials, grid, st); break;
-        default: launch_bn_prepare<5>(points, cfg, batch, coors, num_points, slots, num_voxels, weight, gamma, beta, running_mean, running_var, momentum, eps, bn_out, moments, (double*)partials, grid, st); break;
+        case 3: LISO_PREP(3); break;
+        case 4: LISO_PREP(4); break;
+        default: LISO_PREP(5); break;
     }
+#undef LISO_PREP
     return check_launch();
 }
 
-int liso_pfn_forward_scatter(const float* points, const liso_pillar_cfg* cfg, int batch, const int* coors,
-                             const int* num_points, const int* slots, const int* cell_to_voxel, const float* weight,
-                             const float* bn_out, void* canvas, int out_bf16, float* occupancy, void* stream) {
-    if (!cfg_ok(cfg, batch) || !points || !coors || !num_points || !slots || !cell_to_voxel || !weight || !bn_out ||
-        !canvas || !occupancy)
+int liso_pfn_forward_scatter(const float* feat, const int* pt_off, const int* voxel_cell, const liso_pillar_cfg* cfg, int batch,
+                             const int* cell_to_voxel, const float* weight, const float* bn_out, void* canvas, int out_bf16,
+                             float* occupancy, void* stream) {
+    if (!cfg_ok(cfg, batch) || !feat || !pt_off || !voxel_cell || !cell_to_voxel || !weight || !bn_out || !canvas || !occupancy)
         return LISO_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const long cells = (long)batch * cfg->gx * cfg->gy;
-    const unsigned grid = (unsigned)((cells + kCellsPerBlock - 1) / kCellsPerBlock);
-#define LISO_FWD(CC, T) pfn_forward_dense_kernel<CC, T><<<grid, kPfnThreads, 0, st>>>(points, *cfg, cells, coors, num_points, slots, cell_to_voxel, weight, bn_out, (T*)canvas, occupancy)
+    const int rows = batch * cfg->max_voxels;
+    const int zero_blocks = (int)((cells + kCellsPerBlock - 1) / kCellsPerBlock);
+    const int groups = (rows + kGroup - 1) / kGroup;
+    int pfn_blocks = (groups + kPfnThreads / 64 - 1) / (kPfnThreads / 64);
+    if (pfn_blocks > 4096) pfn_blocks = 4096;
+    const unsigned grid = (unsigned)(zero_blocks + pfn_blocks);
+#define LISO_FWD(CC, T) pfn_forward_kernel<CC, T><<<grid, kPfnThreads, 0, st>>>(feat, pt_off, voxel_cell, rows, cfg->max_points, cells, zero_blocks, cell_to_voxel, weight, bn_out, (T*)canvas, occupancy)
     switch (cfg->n_channels * 2 + (out_bf16 ? 1 : 0)) {
         case 6: LISO_FWD(3, float); break;
         case 7: LISO_FWD(3, __hip_bfloat16); break;
@@ -695,22 +813,22 @@ int liso_pfn_forward_scatter(const float* points, const liso_pillar_cfg* cfg, in
     return check_launch();
 }
 
-int liso_pfn_backward(const float* points, const liso_pillar_cfg* cfg, int batch, const int* coors,
-                      const int* num_points, const int* slots, const int* num_voxels, const float* weight,
-                      const float* gamma, const float* bn_out, const double* moments, int training,
-                      const void* grad_canvas, int grad_bf16, float* grad_weight, float* grad_gamma,
-                      float* grad_beta, void* partials, void* stream) {
-    if (!cfg_ok(cfg, batch) || !points || !coors || !num_points || !slots || !num_voxels || !weight || !gamma ||
-        !bn_out || !grad_canvas || !grad_weight || !grad_gamma || !grad_beta || !partials || (training && !moments))
+int liso_pfn_backward(const float* feat, const int* pt_off, const int* voxel_cell, const liso_pillar_cfg* cfg, int batch,
+                      const int* num_voxels, const float* weight, const float* gamma, const float* bn_out,
+                      const double* moments, int training, const void* grad_canvas, int grad_bf16, float* grad_weight,
+                      float* grad_gamma, float* grad_beta, void* partials, void* stream) {
+    if (!cfg_ok(cfg, batch) || !feat || !pt_off || !voxel_cell || !num_voxels || !weight || !gamma || !bn_out || !grad_canvas ||
+        !grad_weight || !grad_gamma || !grad_beta || !partials || (training && !moments))
         return LISO_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    const int grid = pfn_grid(batch * cfg->max_voxels);
+    const int rows = batch * cfg->max_voxels;
+    const int grid = pfn_grid((rows + kGroup - 1) / kGroup);
 #define LISO_BWD(CC, T)                                                                                              \
     do {                                                                                                             \
         constexpr int NA_ = CC + 8;                                                                                  \
         double* tot_ = (double*)((float*)partials + (size_t)kPfnGrid * (11 + 2) * kOut);                             \
-        pfn_backward_kernel<CC, T><<<grid, kPfnThreads, 0, st>>>(points, *cfg, batch, coors, num_points, slots,       \
-                                                                 num_voxels, weight, bn_out, (const T*)grad_canvas,  \
+        pfn_backward_kernel<CC, T><<<grid, kPfnThreads, 0, st>>>(feat, pt_off, voxel_cell, rows, cfg->max_points,     \
+                                                                 weight, bn_out, (const T*)grad_canvas,             \
                                                                  (float*)partials);                                  \
         pfn_backward_reduce_kernel<NA_><<<NA_, 1024, 0, st>>>((const float*)partials, grid, tot_);                    \
         pfn_backward_finalize_kernel<CC><<<1, 64, 0, st>>>(tot_, num_voxels, batch, cfg->max_points, weight, gamma,   \

@@ -67,6 +67,24 @@ def voxelize_raw(points, offsets, pcfg):
     return coors, num_points, slots, num_voxels, cell_to_voxel
 
 
+def decorate_rows(points, pcfg, B, coors, num_points, slots, num_voxels):
+    """CSR feature rows of all kept points in pillar order (include/liso_pillars.h: liso_pfn_decorate_f32) ->
+    (pt_off int32 [B*maxV+1], feat float32 [N,12], voxel_cell int32 [B*maxV])"""
+    lib = L.lib()
+    dev = points.device
+    rows = B * pcfg.max_voxels
+    pt_off = torch.empty(rows + 1, dtype=torch.int32, device=dev)
+    feat = torch.empty((max(points.shape[0], 1), 12), dtype=torch.float32, device=dev)
+    voxel_cell = torch.empty(rows, dtype=torch.int32, device=dev)
+    nbytes = lib.liso_pfn_decorate_workspace_bytes(B, pcfg.max_voxels)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        L.check(L.TIMER.launch("pfn_decorate", lambda: lib.liso_pfn_decorate_f32(
+            L.ptr(points), ctypes.byref(pcfg), B, L.ptr(coors), L.ptr(num_points), L.ptr(slots), L.ptr(num_voxels), L.ptr(pt_off),
+            L.ptr(feat), L.ptr(voxel_cell), L.ptr(ws), nbytes, L.stream_ptr())), "pfn_decorate")
+    return pt_off, feat, voxel_cell
+
+
 class _PillarFeatureScatter(torch.autograd.Function):
     """voxelise (no grad) + fused PFN + scatter; differentiable w.r.t. linear.weight, norm.weight, norm.bias."""
 
@@ -78,33 +96,33 @@ class _PillarFeatureScatter(torch.autograd.Function):
         dev = points.device
         B = len(offsets) - 1
         coors, num_points, slots, num_voxels, cell_to_voxel = voxelize_raw(points, offsets, pcfg)
+        pt_off, feat, voxel_cell = decorate_rows(points, pcfg, B, coors, num_points, slots, num_voxels)
         weight = weight.contiguous().float()
         with torch.cuda.device(dev):
             st = L.stream_ptr()
             bn_out = torch.empty(4 * 64, dtype=torch.float32, device=dev)
             moments = torch.empty(80, dtype=torch.float64, device=dev)
             partials = torch.empty(lib.liso_pfn_partials_bytes(), dtype=torch.uint8, device=dev)
-            L.check(lib.liso_pfn_bn_prepare_f32(L.ptr(points), ctypes.byref(pcfg), B, L.ptr(coors), L.ptr(num_points),
-                                                L.ptr(slots), L.ptr(num_voxels), L.ptr(weight), L.ptr(gamma),
-                                                L.ptr(beta), L.ptr(running_mean), L.ptr(running_var), float(momentum),
-                                                float(eps), int(training), L.ptr(bn_out), L.ptr(moments),
-                                                L.ptr(partials), st), "pfn_bn_prepare")
+            L.check(lib.liso_pfn_bn_prepare_f32(L.ptr(feat), L.ptr(pt_off), ctypes.byref(pcfg), B, L.ptr(num_voxels),
+                                                L.ptr(weight), L.ptr(gamma), L.ptr(beta), L.ptr(running_mean),
+                                                L.ptr(running_var), float(momentum), float(eps), int(training),
+                                                L.ptr(bn_out), L.ptr(moments), L.ptr(partials), st), "pfn_bn_prepare")
             canvas = torch.empty((B, pcfg.gx, pcfg.gy, 64), dtype=out_dtype, device=dev)  # written densely by the kernel
             occupancy = torch.empty((B, 1, pcfg.gx, pcfg.gy), dtype=torch.float32, device=dev)
             L.check(L.TIMER.launch("pfn_forward_scatter", lambda: lib.liso_pfn_forward_scatter(
-                L.ptr(points), ctypes.byref(pcfg), B, L.ptr(coors), L.ptr(num_points), L.ptr(slots), L.ptr(cell_to_voxel),
-                L.ptr(weight), L.ptr(bn_out), L.ptr(canvas), int(out_dtype == torch.bfloat16), L.ptr(occupancy), st)),
+                L.ptr(feat), L.ptr(pt_off), L.ptr(voxel_cell), ctypes.byref(pcfg), B, L.ptr(cell_to_voxel), L.ptr(weight),
+                L.ptr(bn_out), L.ptr(canvas), int(out_dtype == torch.bfloat16), L.ptr(occupancy), st)),
                 "pfn_forward_scatter")
-        ctx.save_for_backward(points, coors, num_points, slots, num_voxels, weight, gamma, bn_out, moments)
+        ctx.save_for_backward(feat, pt_off, voxel_cell, num_voxels, weight, gamma, bn_out, moments)
         ctx.pcfg, ctx.B, ctx.training = pcfg, B, bool(training)
         ctx.mark_non_differentiable(occupancy)
         return canvas.permute(0, 3, 1, 2), occupancy
 
     @staticmethod
     def backward(ctx, grad_canvas, _grad_occ):
-        points, coors, num_points, slots, num_voxels, weight, gamma, bn_out, moments = ctx.saved_tensors
+        feat, pt_off, voxel_cell, num_voxels, weight, gamma, bn_out, moments = ctx.saved_tensors
         lib = L.lib()
-        dev = points.device
+        dev = feat.device
         g = grad_canvas.permute(0, 2, 3, 1)
         if g.dtype not in (torch.float32, torch.bfloat16):
             g = g.float()
@@ -115,11 +133,10 @@ class _PillarFeatureScatter(torch.autograd.Function):
         gb = torch.empty(64, dtype=torch.float32, device=dev)
         partials = torch.empty(lib.liso_pfn_partials_bytes(), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
-            L.check(lib.liso_pfn_backward(L.ptr(points), ctypes.byref(ctx.pcfg), ctx.B, L.ptr(coors), L.ptr(num_points),
-                                          L.ptr(slots), L.ptr(num_voxels), L.ptr(weight), L.ptr(gamma), L.ptr(bn_out),
-                                          L.ptr(moments), int(ctx.training), L.ptr(g),
-                                          int(g.dtype == torch.bfloat16), L.ptr(gw), L.ptr(gg), L.ptr(gb),
-                                          L.ptr(partials), L.stream_ptr()), "pfn_backward")
+            L.check(lib.liso_pfn_backward(L.ptr(feat), L.ptr(pt_off), L.ptr(voxel_cell), ctypes.byref(ctx.pcfg), ctx.B,
+                                          L.ptr(num_voxels), L.ptr(weight), L.ptr(gamma), L.ptr(bn_out), L.ptr(moments),
+                                          int(ctx.training), L.ptr(g), int(g.dtype == torch.bfloat16), L.ptr(gw), L.ptr(gg),
+                                          L.ptr(gb), L.ptr(partials), L.stream_ptr()), "pfn_backward")
         return gw, gg, gb, None, None, None, None, None, None, None, None, None
 
 

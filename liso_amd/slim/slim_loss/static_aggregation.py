@@ -20,9 +20,8 @@ class BevGatherPlan:
         sorted_lin, order = torch.sort(self.lin, stable=True)
         self.sorted_lin, self.order = sorted_lin.contiguous(), order.to(torch.int32).contiguous()
         pos = torch.arange(sorted_lin.numel(), device=c.device, dtype=torch.int32)
-        is_head = torch.ones_like(sorted_lin, dtype=torch.bool)
-        is_head[1:] = sorted_lin[1:] != sorted_lin[:-1]
-        self.seg_rank = (pos - torch.cummax(torch.where(is_head, pos, 0), dim=0).values).contiguous()
+        # first row of every run of equal cells = lower bound of the value in the sorted list itself
+        self.seg_rank = (pos - torch.searchsorted(sorted_lin, sorted_lin, right=False).to(torch.int32)).contiguous()
         self.shape = (B, N, H, W)
 
     def matches(self, grid_data, mask):
