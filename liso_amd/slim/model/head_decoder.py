@@ -47,6 +47,24 @@ class HeadDecoder(nn.Module):
         self.cfg, self.name, self.bev_extent = cfg, name, bev_extent
         self._centers = {}  # (grid size, device) -> ([H,W,2] fp64 cell centres, [H,W,4] homogeneous), uploaded once
 
+    def _gt_static_flows(self, inv_odom, pc, homog):
+        """reference :127-157 -- the odometry's static flow of every BEV cell and point, (inv_odom - I) applied as fp64
+        broadcast multiply-adds.  (The reference's einsum is a [3x4]x[4xN] fp64 GEMM, which rocBLAS runs with a 128x128
+        DGEMM tile: 28 ms per call at N = 120k, measured -- 70 % of the first SLIM step for a quantity forward() then
+        discards.)  It depends on the sweep only, so the 6 RAFT iterations of a step share one evaluation."""
+        key = (inv_odom, pc, inv_odom._version, pc._version, homog)
+        c = getattr(self, "_gt_cache", None)
+        if c is not None and all(a is b for a, b in zip(c[0], key) if torch.is_tensor(a)) and c[0][2:4] == key[2:4]:
+            return c[1]
+        M = inv_odom.double() - torch.eye(4, dtype=torch.float64, device=inv_odom.device)[None]
+        gt_static_flow = (M[:, None, None, :2, 0] * homog[None, ..., 0:1] + M[:, None, None, :2, 1] * homog[None, ..., 1:2]
+                          + M[:, None, None, :2, 3]).to(torch.float32)  # cell centres have z = 0, w = 1
+        p64 = pc[:, :, :3].to(torch.float64)
+        gt_pointwise_static_flow = (M[:, None, :3, 0] * p64[..., 0:1] + M[:, None, :3, 1] * p64[..., 1:2]
+                                    + M[:, None, :3, 2] * p64[..., 2:3] + M[:, None, :3, 3]).to(torch.float32)
+        self._gt_cache = (key, (gt_static_flow, gt_pointwise_static_flow))
+        return self._gt_cache[1]
+
     def _cell_centers(self, final_grid_size, device):
         key = (tuple(int(v) for v in final_grid_size), str(device))
         if key not in self._centers:
@@ -90,16 +108,7 @@ class HeadDecoder(nn.Module):
         assert pointwise_voxel_coordinates_fs.shape[-1] == 2
         # ground-truth static flow of every BEV cell / point from the odometry (fp64 einsum, :127-157)
         centers, homog = self._cell_centers(final_grid_size, inv_odom.device)
-        # (inv_odom - I) applied to cell centres / points: written as broadcast multiply-adds in fp64.  The reference's
-        # einsum (:139-157) is a [3x4]x[4xN] fp64 GEMM, which rocBLAS runs with a 128x128 DGEMM tile (28 ms per call at
-        # N = 120k, measured) -- 70 % of the whole SLIM step for a quantity forward() then discards.
-        M = inv_odom.double() - torch.eye(4, dtype=torch.float64, device=inv_odom.device)[None]
-        gt_static_flow = (M[:, None, None, :2, 0] * homog[None, ..., 0:1] + M[:, None, None, :2, 1] * homog[None, ..., 1:2]
-                          + M[:, None, None, :2, 2] * homog[None, ..., 2:3] + M[:, None, None, :2, 3] * homog[None, ..., 3:4]
-                          ).to(torch.float32)
-        p64 = pc[:, :, :3].to(torch.float64)
-        gt_pointwise_static_flow = (M[:, None, :3, 0] * p64[..., 0:1] + M[:, None, :3, 1] * p64[..., 1:2]
-                                    + M[:, None, :3, 2] * p64[..., 2:3] + M[:, None, :3, 3]).to(torch.float32)
+        gt_static_flow, gt_pointwise_static_flow = self._gt_static_flows(inv_odom, pc, homog)
         nod, static_aggr_trafo, not_enough_points = artificial_network_output(
             network_output_dict=nod, dynamicness_threshold=dynamicness_threshold, cfg=self.cfg,
             ohe_gt_stat_dyn_ground_label_bev_map=ohe_gt_stat_dyn_ground_label_bev_map, gt_flow_bev=gt_flow_bev,
@@ -110,44 +119,53 @@ class HeadDecoder(nn.Module):
             overwrite_non_filled_pillars_with_default_logits=overwrite_non_filled_pillars_with_default_logits,
             gather_plan=gather_plan)
         disappearing_logit = nod["disappearing_logit"][..., 0]
-
-        def pad3(t):
-            return None if t is None else torch.cat([t, torch.zeros_like(t[..., :1])], dim=-1)
-
-        dynamic_flow, static_flow = pad3(nod["dynamic_flow"]), pad3(nod["static_flow"])
-        static_aggr_flow, masked_static_aggr_flow = pad3(nod["static_aggr_flow"]), pad3(nod["masked_static_aggr_flow"])
         is_static, groundness = nod["is_static"], nod["groundness"]
-        static_flow_for_aggr = masked_static_aggr_flow if self.cfg.model.use_static_aggr_flow_for_aggr_flow else static_flow
-        sel = torch.tile(is_static[..., None], [1, 1, 1, static_flow_for_aggr.shape[-1]])
+        masked_static_aggr_flow = nod["masked_static_aggr_flow"]
+        static2 = masked_static_aggr_flow if self.cfg.model.use_static_aggr_flow_for_aggr_flow else nod["static_flow"]
+        dyn2 = nod["dynamic_flow"] * (1.0 - groundness[..., None])
         if dynamic_flow_is_non_rigid_flow:  # reference :249-267
-            aggregated_flow = torch.where(sel, static_flow_for_aggr, (static_flow_for_aggr + dynamic_flow) * (1.0 - groundness[..., None]))
-        else:
-            aggregated_flow = torch.where(sel, static_flow_for_aggr, dynamic_flow * (1.0 - groundness[..., None]))
-        modified = Munch(disappearing=torch.sigmoid(disappearing_logit), disappearing_logit=disappearing_logit,
+            dyn2 = static2 * (1.0 - groundness[..., None]) + dyn2
+        aggregated2 = torch.where(is_static[..., None], static2, dyn2)
+        # every map the per-point gather needs, packed once (2-D flows get their zero z column here; the 3-D flow maps
+        # of the reference's Munch are views into this tensor):
+        #   0 disappearing | 1 disappearing_logit | 2:5 class_probs | 5:8 class_logits | 8:11 dynamic_flow |
+        #   11:14 static_flow | 14:17 aggregated_flow | 17:20 static_aggr_flow | 20:23 is_static, is_dynamic, is_ground
+        z1 = torch.zeros_like(disappearing_logit)[..., None]
+        flags = torch.stack([is_static, nod["is_dynamic"], nod["is_ground"]], dim=-1)
+        packed = torch.cat([torch.sigmoid(nod["disappearing_logit"]), nod["disappearing_logit"], nod["class_probs"],
+                            nod["class_logits"], nod["dynamic_flow"], z1, nod["static_flow"], z1, aggregated2, z1,
+                            nod["static_aggr_flow"], z1, flags.to(z1.dtype)], dim=-1)
+        modified = Munch(disappearing=packed[..., 0], disappearing_logit=disappearing_logit,
                          class_probs=nod["class_probs"], class_logits=nod["class_logits"], staticness=nod["staticness"],
                          dynamicness=nod["dynamicness"], groundness=groundness, is_static=is_static,
-                         is_dynamic=nod["is_dynamic"], is_ground=nod["is_ground"], dynamic_flow=dynamic_flow,
-                         static_flow=static_flow, aggregated_flow=aggregated_flow, static_aggr_flow=static_aggr_flow)
+                         is_dynamic=nod["is_dynamic"], is_ground=nod["is_ground"], dynamic_flow=packed[..., 8:11],
+                         static_flow=packed[..., 11:14], aggregated_flow=packed[..., 14:17],
+                         static_aggr_flow=packed[..., 17:20], packed=packed)
+        masked_static_aggr_flow3 = torch.cat([masked_static_aggr_flow, z1], dim=-1)
         return (modified, nod, gt_flow_bev, gt_static_flow, gt_pointwise_static_flow, nod["masked_gt_static_flow"],
-                masked_static_aggr_flow, nod.get("masked_weights_for_static_aggregation", None), static_aggr_trafo,
+                masked_static_aggr_flow3, nod.get("masked_weights_for_static_aggregation", None), static_aggr_trafo,
                 not_enough_points)
 
     def apply_flow_to_points(self, *, modified_output_bev_img, pointwise_voxel_coordinates_fs, pointwise_valid_mask,
                              gather_plan=None):
-        """reference :300-408 -- gather 3 bool + 23 float channels per point (one 26-channel gather: the booleans ride
-        along as 0/1 floats, default 0 == False)"""
+        """reference :300-408 -- gather 3 bool + 20 distinct float channels per point (one 23-channel gather: the booleans
+        ride along as 0/1 floats, default 0 == False)"""
         m = modified_output_bev_img
-        flts = torch.cat([torch.stack([m.disappearing, m.disappearing_logit, m.staticness, m.dynamicness, m.groundness], dim=-1),
-                          m.class_probs, m.class_logits, m.dynamic_flow, m.static_flow, m.aggregated_flow, m.static_aggr_flow,
-                          torch.stack([m.is_static, m.is_dynamic, m.is_ground], dim=-1).to(m.staticness.dtype)], dim=-1)
-        assert flts.shape[-1] == 26, flts.shape
+        if "packed" in m:
+            flts = m.packed
+        else:  # a caller-built Munch without the packed tensor: same channel layout
+            flts = torch.cat([torch.stack([m.disappearing, m.disappearing_logit], dim=-1), m.class_probs, m.class_logits,
+                              m.dynamic_flow, m.static_flow, m.aggregated_flow, m.static_aggr_flow,
+                              torch.stack([m.is_static, m.is_dynamic, m.is_ground], dim=-1).to(m.staticness.dtype)], dim=-1)
+        assert flts.shape[-1] == 23, flts.shape
         pf = batched_grid_data_to_pointwise_data(flts, pointwise_voxel_coordinates_fs, pointwise_valid_mask, default_value=0.0,
                                                  plan=gather_plan)
-        pb = pf[..., 23:26].detach() > 0.5
-        return Munch(disappearing_logit=pf[..., 1], disappearing=pf[..., 0], class_logits=pf[..., 8:11], class_probs=pf[..., 5:8],
-                     staticness=pf[..., 2], dynamicness=pf[..., 3], groundness=pf[..., 4], is_static=pb[..., 0],
-                     is_dynamic=pb[..., 1], is_ground=pb[..., 2], dynamic_flow=pf[..., 11:14], static_flow=pf[..., 14:17],
-                     aggregated_flow=pf[..., 17:20], static_aggr_flow=pf[..., 20:23])
+        dis, dis_l, probs, logits, dyn, stat, agg, saf, flg = torch.split(pf, [1, 1, 3, 3, 3, 3, 3, 3, 3], dim=-1)
+        pb = flg.detach() > 0.5
+        st, dy, gr = torch.unbind(probs, dim=-1)
+        return Munch(disappearing_logit=dis_l[..., 0], disappearing=dis[..., 0], class_logits=logits, class_probs=probs,
+                     staticness=st, dynamicness=dy, groundness=gr, is_static=pb[..., 0], is_dynamic=pb[..., 1],
+                     is_ground=pb[..., 2], dynamic_flow=dyn, static_flow=stat, aggregated_flow=agg, static_aggr_flow=saf)
 
     def forward(self, network_output, dynamicness_threshold, *, pc, pointwise_voxel_coordinates, pointwise_valid_mask,
                 filled_pillar_mask, odom, inv_odom, summaries, gt_flow_bev=None, per_point_cluster_idxs_gt=None,
@@ -196,11 +214,18 @@ def artificial_network_output(*, network_output_dict: Dict[str, torch.Tensor], d
         taboo += ["static_flow", "dynamic_flow", "static_aggr_flow"]
     if not overwrite_non_filled_pillars_with_default_logits:
         taboo += ["disappearing_logit", "static_logit", "dynamic_logit", "ground_logit"]
-    for k in nod:
-        if k == "weight_logits_for_static_aggregation" or k in taboo:
-            continue
-        nod[k] = torch.where(filled_pillar_mask, nod[k], defaults[k] * torch.ones_like(nod[k]))
-    nod["class_logits"] = torch.cat([nod["static_logit"], nod["dynamic_logit"], nod["ground_logit"]], dim=-1)
+    # one masked select over the 8 packed channels instead of one per key (reference :576-590)
+    order = ["disappearing_logit", "static_logit", "dynamic_logit", "ground_logit", "static_flow", "dynamic_flow"]
+    vals = torch.cat([nod[k] for k in order], dim=-1)
+    dvec = []
+    for k in order:
+        dvec += [float("nan") if k in taboo else defaults[k]] * nod[k].shape[-1]
+    dvec_t = _cached_vector(tuple(dvec), vals.device, vals.dtype)
+    keep = filled_pillar_mask if not taboo else (filled_pillar_mask | torch.isnan(dvec_t))
+    vals = torch.where(keep, vals, dvec_t)
+    for k, piece in zip(order, torch.split(vals, [nod[k].shape[-1] for k in order], dim=-1)):
+        nod[k] = piece  # one split: its backward is a single cat
+    nod["class_logits"] = vals[..., 1:4]  # static | dynamic | ground: adjacent channels of the packed tensor
     nod["class_probs"] = torch.nn.functional.softmax(nod["class_logits"], dim=-1)
     nod["staticness"], nod["dynamicness"], nod["groundness"] = (nod["class_probs"][..., i] for i in range(3))
     nod["is_dynamic"] = nod["dynamicness"] >= dynamicness_threshold
@@ -231,6 +256,17 @@ def artificial_network_output(*, network_output_dict: Dict[str, torch.Tensor], d
     return nod, static_aggr_trafo, not_enough_points
 
 
+_VECTOR_CACHE = {}
+
+
+def _cached_vector(values, device, dtype):
+    """small constant vectors (per-channel defaults) uploaded once per (values, device)"""
+    key = (values, str(device), dtype)
+    if key not in _VECTOR_CACHE:
+        _VECTOR_CACHE[key] = torch.tensor(values, dtype=dtype, device=device)
+    return _VECTOR_CACHE[key]
+
+
 def artificial_flow_network_output(*, network_output_dict, model_cfg, gt_flow_bev, gt_static_flow):
     """reference :734-776"""
     om = model_cfg.output_modification
@@ -238,7 +274,7 @@ def artificial_flow_network_output(*, network_output_dict, model_cfg, gt_flow_be
     if om.static_flow == "gt":
         nod["static_flow"] = gt_static_flow
     elif om.static_flow == "zero":
-        nod["static_flow"] = torch.zeros_like(nod["static_flow"])
+        nod["static_flow"] = _const_like(nod["static_flow"], 0.0)
     elif om.static_flow != "net":
         raise ValueError("unknown output mode: %s" % str(om.static_flow))
     if om.dynamic_flow == "gt":
@@ -246,7 +282,7 @@ def artificial_flow_network_output(*, network_output_dict, model_cfg, gt_flow_be
         if model_cfg.dynamic_flow_is_non_rigid_flow:
             nod["dynamic_flow"] = nod["dynamic_flow"] - nod["static_flow"]
     elif om.dynamic_flow == "zero":
-        nod["dynamic_flow"] = torch.zeros_like(nod["dynamic_flow"])
+        nod["dynamic_flow"] = _const_like(nod["dynamic_flow"], 0.0)
     elif om.dynamic_flow != "net":
         raise ValueError("unknown output mode: %s" % str(om.dynamic_flow))
     nod["dynamic_flow"] = scale_gradient(nod["dynamic_flow"], om.dynamic_flow_grad_scale)
@@ -254,7 +290,16 @@ def artificial_flow_network_output(*, network_output_dict, model_cfg, gt_flow_be
 
 
 def _extreme(a, b, fn):
-    return fn(torch.cat([a, b], dim=0)).detach()
+    """global max / min over two maps (reference: fn(torch.cat([a, b], 0)).detach())"""
+    return (torch.maximum(a.detach().amax(), b.detach().amax()) if fn is torch.max
+            else torch.minimum(a.detach().amin(), b.detach().amin()))
+
+
+def _const_like(ref, value):
+    """`value * ones_like(ref)` as an expanded view (value: python scalar or 0-d tensor)"""
+    if torch.is_tensor(value):
+        return value.to(ref.dtype).expand(ref.shape)
+    return ref.new_full((), value).expand(ref.shape)
 
 
 def artificial_logit_network_output(*, network_output_dict, model_cfg, ohe_gt_stat_dyn_ground_label_bev_map, gt_flow_bev,
@@ -263,12 +308,12 @@ def artificial_logit_network_output(*, network_output_dict, model_cfg, ohe_gt_st
     are reproduced as well)."""
     om = model_cfg.output_modification
     nod = network_output_dict
-    ones = torch.ones_like(nod["static_logit"])
+    ref = nod["static_logit"]
     ohe = ohe_gt_stat_dyn_ground_label_bev_map
     if om.disappearing_logit is True:
-        nod["disappearing_logit"] = 0 * ones
+        nod["disappearing_logit"] = _const_like(ref, 0.0)
     elif om.disappearing_logit is False:
-        nod["disappearing_logit"] = -100 * ones
+        nod["disappearing_logit"] = _const_like(ref, -100.0)
     elif om.disappearing_logit != "net":
         raise ValueError("unknown output mode: %s" % str(om.disappearing_logit))
     # static
@@ -285,10 +330,10 @@ def artificial_logit_network_output(*, network_output_dict, model_cfg, ohe_gt_st
         nod["static_logit"] = 100.0 * (is_static - 1.0)
     elif om.static_logit is True:
         assert om.dynamic_logit is False and om.ground_logit is False
-        nod["static_logit"] = _extreme(nod["dynamic_logit"], nod["ground_logit"], torch.max) + 100.0 * ones
+        nod["static_logit"] = _const_like(ref, _extreme(nod["dynamic_logit"], nod["ground_logit"], torch.max) + 100.0)
     elif om.static_logit is False:
         assert om.dynamic_logit is not False or om.ground_logit is not False
-        nod["static_logit"] = _extreme(nod["dynamic_logit"], nod["ground_logit"], torch.max) - 100.0 * ones
+        nod["static_logit"] = _const_like(ref, _extreme(nod["dynamic_logit"], nod["ground_logit"], torch.max) - 100.0)
     elif om.static_logit != "net":
         raise ValueError("unknown output mode: %s" % str(om.static_logit))
     # dynamic
@@ -297,9 +342,9 @@ def artificial_logit_network_output(*, network_output_dict, model_cfg, ohe_gt_st
     elif om.dynamic_logit == "gt_flow_based":
         nod["dynamic_logit"] = 100.0 - nod["static_logit"]
     elif om.dynamic_logit is True:
-        nod["dynamic_logit"] = _extreme(nod["static_logit"], nod["ground_logit"], torch.max) + 100.0 * ones
+        nod["dynamic_logit"] = _const_like(ref, _extreme(nod["static_logit"], nod["ground_logit"], torch.max) + 100.0)
     elif om.dynamic_logit is False:
-        nod["dynamic_logit"] = _extreme(nod["static_logit"], nod["ground_logit"], torch.min) - 100.0 * ones
+        nod["dynamic_logit"] = _const_like(ref, _extreme(nod["static_logit"], nod["ground_logit"], torch.min) - 100.0)
     elif om.dynamic_logit != "net":
         raise ValueError("unknown output mode: %s" % str(om.dynamic_logit))
     # ground
@@ -307,9 +352,9 @@ def artificial_logit_network_output(*, network_output_dict, model_cfg, ohe_gt_st
         nod["ground_logit"] = 100.0 * (castf(ohe[..., 2:3]) - 1.0)
     elif om.ground_logit is True:
         assert om.static_logit is False and om.dynamic_logit is False
-        nod["ground_logit"] = _extreme(nod["static_logit"], nod["dynamic_logit"], torch.max) + 100.0 * ones
+        nod["ground_logit"] = _const_like(ref, _extreme(nod["static_logit"], nod["dynamic_logit"], torch.max) + 100.0)
     elif om.ground_logit is False:
-        nod["ground_logit"] = _extreme(nod["static_logit"], nod["dynamic_logit"], torch.min) - 100.0 * ones
+        nod["ground_logit"] = _const_like(ref, _extreme(nod["static_logit"], nod["dynamic_logit"], torch.min) - 100.0)
     elif om.ground_logit != "net":
         raise ValueError("unknown output mode: %s" % str(om.ground_logit))
     return nod
