@@ -160,8 +160,21 @@ def main():
         step = lambda: trainer.step(pcls, targets)  # noqa: E731
         frames_per_step, timed = batch, ["pfn_decorate", "pfn_forward_scatter"]
 
-    for _ in range(args.warmup):
-        step()
+    graph_note = None
+    for i in range(args.warmup):
+        if i == 0 and args.workload == "slim" and not args.no_graph:
+            try:
+                step()
+            except Exception as e:  # capture refused by the runtime: same kernels, launched eagerly
+                graph_note = f"hipGraph capture failed ({type(e).__name__}: {str(e)[:120]}); eager launches"
+                print(graph_note, file=sys.stderr, flush=True)
+                args.no_graph = True
+                torch.manual_seed(0)
+                trainer = SlimTrainer(cfg, dev, use_graph=False, channels_last=args.nhwc)
+                step = lambda: trainer.step(s0, s1)  # noqa: E731
+                step()
+        else:
+            step()
 
     graphed = args.workload == "slim" and not args.no_graph
     if not graphed:  # per-launch HIP events on the launch stream, inside the timed region
@@ -258,6 +271,8 @@ def main():
                 line["cpu_baseline"] = cpu_baseline_detector(trainer, pcls, targets)
         if args.workload == "loop":
             line["mined_boxes_last_step"] = int(trainer.last_boxes.valid.sum())
+        if graph_note:
+            line["config"]["launch"] = graph_note
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -146,7 +146,8 @@ class SlimTrainer:
 
     def step(self, sample_t0, sample_t1, eager=False):
         self.model.train()
-        if self.use_graph and not eager:
+        if self.use_graph and not eager and not (self.world > 1 and self.slim_cfg.model.use_static_aggr_flow_for_aggr_flow):
+            # (with several ranks the dynamicness-threshold update all-reduces inside the loss: keep that step eager)
             return self._graph_step(sample_t0, sample_t1)
         total, _, _ = self.loss(sample_t0, sample_t1)
         if self.use_graph:
