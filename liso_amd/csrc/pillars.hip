@@ -793,8 +793,8 @@ size_t liso_pfn_decorate_workspace_bytes(int batch, int max_voxels) {
 int liso_pfn_decorate_f32(const float* points, const liso_pillar_cfg* cfg, int batch, const int* coors, const int* num_points,
                           const int* slots, const int* num_voxels, int* pt_off, float* feat, int* voxel_cell, void* workspace,
                           size_t workspace_bytes, void* stream) {
-    if (!cfg_ok(cfg, batch) || !points || !coors || !num_points || !slots || !num_voxels || !pt_off || !feat || !voxel_cell ||
-        !workspace)
+    // `points` is only dereferenced for kept points: it may be NULL when the batch holds no point at all
+    if (!cfg_ok(cfg, batch) || !coors || !num_points || !slots || !num_voxels || !pt_off || !feat || !voxel_cell || !workspace)
         return LISO_EINVAL;
     if (workspace_bytes < liso_pfn_decorate_workspace_bytes(batch, cfg->max_voxels)) return LISO_EWORKSPACE;
     const int rows = batch * cfg->max_voxels;

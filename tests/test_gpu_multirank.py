@@ -1,0 +1,57 @@
+"""Two ranks on ONE GPU (gloo carries the collectives, both processes compute on cuda:0): the data-parallel wiring of the
+hipGraph SLIM step -- parameter broadcast at start, flat gradient buffer all-reduced after every replay -- that the RCCL
+runs of bench.py use with one GPU per rank."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from liso_amd.datasets.synthetic import slim_pair
+        from liso_amd.trainer import SlimTrainer
+        from liso_amd.utils.config import apply_slim_simple_knn_training, default_cfg
+
+        dev = torch.device("cuda:0")
+        cfg = apply_slim_simple_knn_training(default_cfg(grid=128, bev_range_m=40.0))
+        torch.manual_seed(rank)  # different initial weights on purpose: the constructor must broadcast rank 0's
+        tr = SlimTrainer(cfg, dev, use_graph=True)
+        assert tr.model is tr.net  # no DDP wrapper in graph mode
+        s0, s1 = slim_pair(50 + rank, dev, n_points=8000, grid=128, bev_range_m=40.0)
+        for g in tr.optimizer.param_groups:  # leave the lr = 0 start of the warm-up schedule
+            g["lr"] = 1e-3
+        tr.lr_scheduler = torch.optim.lr_scheduler.LambdaLR(tr.optimizer, lambda s: 1.0)
+        losses = [float(tr.step(s0, s1)) for _ in range(3)]
+        flat = torch.cat([p.detach().flatten() for p in tr.net.parameters()]).cpu()
+        gathered = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+        if rank == 0:
+            torch.save({"params": gathered, "losses": losses}, out)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_two_ranks_hipgraph_slim_step_keeps_replicas_identical(tmp_path):
+    out = str(tmp_path / "mr.pt")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r = torch.load(out)
+    assert all(l == l for l in r["losses"])
+    assert torch.equal(r["params"][0], r["params"][1])
+    assert r["losses"][2] != r["losses"][0]  # the weights moved
