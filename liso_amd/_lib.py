@@ -107,6 +107,10 @@ SIGNATURES = {
     "liso_corr_lookup_bwd_dvol_f32": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "liso_bev_gather_fwd_f32": (_i, [_vp, _vp, ctypes.c_long, _i, ctypes.c_float, _vp, _vp]),
     "liso_bev_gather_bwd_f32": (_i, [_vp, _vp, _vp, _vp, ctypes.c_long, _i, _vp, _vp, _vp]),
+    # include/liso_detector.h
+    "liso_centerloss_workspace_bytes": (_sz, [_vp]),
+    "liso_centerloss_fwd_f32": (_i, [_vp] * 17 + [_sz, _vp]),
+    "liso_centerloss_bwd_f32": (_i, [_vp] * 21),
     # include/liso_bn.h
     "liso_bn_workspace_bytes": (_sz, [_i]),
     "liso_bn_relu_fwd": (_i, [_vp, _i, ctypes.c_long, _i, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _vp, _vp, _vp, _sz, _vp]),
@@ -120,6 +124,12 @@ SIGNATURES = {
 class KnnGrid(ctypes.Structure):
     """mirror of liso_knn_grid (include/liso_slim.h)"""
     _fields_ = [("x_min", _f), ("y_min", _f), ("cell", _f), ("nx", _i), ("ny", _i), ("z_min", _f), ("z_cell", _f), ("nz", _i)]
+
+
+class CenterLossCfg(ctypes.Structure):
+    """mirror of liso_centerloss_cfg (include/liso_detector.h)"""
+    _fields_ = [("batch", _i), ("h", _i), ("w", _i), ("res_x", _f), ("res_y", _f), ("z_min", _f), ("z_max", _f),
+                ("sup_weight", _f), ("rot_reg_weight", _f)]
 
 
 class DbscanCfg(ctypes.Structure):

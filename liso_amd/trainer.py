@@ -23,8 +23,14 @@ def get_optimizer_scheduler(cfg, box_predictor, total_steps=None):
 
 
 class DetectorTrainer:
-    def __init__(self, cfg, device, compute_dtype=torch.float32, total_steps=None):
+    def __init__(self, cfg, device, compute_dtype=torch.float32, total_steps=None, fused_loss=None):
+        """`fused_loss`: activations + decode + CenterPoint loss in one HIP pass (include/liso_detector.h) instead of
+        ~140 torch launches; default = whenever the configuration is the overlay the kernel implements and the
+        network runs on the GPU."""
+        from liso_amd.losses import fused_centerpoint
+
         self.cfg, self.device = cfg, device
+        self.fused_loss = (fused_centerpoint.supports(cfg) and device.type == "cuda") if fused_loss is None else fused_loss
         self.net = BoxLearner(cfg).to(device)
         self.net.model.set_compute_dtype(compute_dtype)
         if compute_dtype != torch.float32:
@@ -41,10 +47,19 @@ class DetectorTrainer:
     def loss(self, pcls, targets):
         """liso_cli.py:452-614"""
         cfg = self.cfg
-        pred_boxes, decoded, activated, aux = self.model(None, pcls, None, centermaps_gt=None)
         sup = cfg.loss.supervised.supervised_on_clusters
         gt_maps = {a: targets[a] for a in sup.attrs}
         mask = targets["center_bool_mask"]
+        if self.fused_loss:
+            from liso_amd.losses.fused_centerpoint import fused_centerpoint_loss
+
+            _, _, raw, _ = self.model(None, pcls, None, centermaps_gt=None, decode=False)
+            total, losses = fused_centerpoint_loss(
+                cfg=cfg, raw_box_maps=raw, gt_maps=gt_maps, gt_center_mask=mask,
+                ignore_region_is_true_mask=targets.get("ignore_region_is_true_mask", None),
+                pillar_center_coors_m=self.net.pillar_center_coors_m)
+            return total, losses, None
+        pred_boxes, decoded, activated, aux = self.model(None, pcls, None, centermaps_gt=None)
         ignore = targets.get("ignore_region_is_true_mask", torch.zeros_like(mask))
         losses = centerpoint_loss(loss_cfg=cfg.loss, raw_activated_pred_box_maps=activated, decoded_pred_box_maps=decoded,
                                   gt_maps=gt_maps, gt_center_mask=mask,

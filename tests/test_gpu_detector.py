@@ -114,10 +114,55 @@ def test_full_size_step_properties():
     we only require closeness there)."""
     tr, pcls, targets = _setup(512, 100.0, 2, 120000, torch.bfloat16, seed=7)
     tr.model.train()
-    total, losses, boxes = tr.loss(pcls, targets)
+    total, losses, _ = tr.loss(pcls, targets)
     total.backward()
     assert torch.isfinite(total)
+    with torch.no_grad():  # the decoded dense predictions (inference path of BoxLearner.forward, simple_net.py:70-109)
+        boxes, _, _, _ = tr.net(None, pcls, None)
     assert boxes.pos.shape == (2, 128 * 128, 3)
     for n, p in tr.net.named_parameters():
         if p.requires_grad:
             assert p.grad is not None and torch.isfinite(p.grad).all(), n
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fused_decode_loss_equals_torch_op_path(dtype):
+    """include/liso_detector.h: activations + decode + CenterPoint loss + rotation regulariser in one pass must equal
+    the torch-op mirrors of simple_net.py:111-151 / centerpoint_loss.py:13-136 / main_utils.py:51-58 -- every loss term,
+    the total, and the gradients of all four raw network maps (NCHW fp32 and channels-last bf16-network layouts),
+    with an ignore region and non-trivial rotation weights."""
+    from liso_amd.losses.fused_centerpoint import fused_centerpoint_loss, supports
+
+    tr, pcls, targets = _setup(128, 100.0, 2, 20000, dtype, seed=11)
+    assert supports(tr.cfg) and tr.fused_loss
+    tr.model.train()
+    g = torch.Generator().manual_seed(3)
+    ignore = (torch.rand(targets["center_bool_mask"].shape, generator=g) < 0.1).cuda()
+    rot_w = (torch.rand(targets["probs"].shape, generator=g) * 2).cuda()
+    _, _, raw, _ = tr.net(None, pcls, None, decode=False)
+    raw = {k: (v.detach() * 3.0).requires_grad_(True) for k, v in raw.items()}  # spread the activations out
+    gt_maps = {a: targets[a] for a in ("pos", "dims", "rot", "probs")}
+    total, losses = fused_centerpoint_loss(cfg=tr.cfg, raw_box_maps=raw, gt_maps=gt_maps, gt_center_mask=targets["center_bool_mask"],
+                                           ignore_region_is_true_mask=ignore, rotation_loss_weights_map=rot_w,
+                                           pillar_center_coors_m=tr.net.pillar_center_coors_m)
+    grads = torch.autograd.grad(total * 1.7, [raw[k] for k in ("pos", "dims", "rot", "probs")])
+    # torch-op path on the same raw maps (fp64 for a clean comparison)
+    from liso_amd.losses.centerpoint_loss import centerpoint_loss, rotation_vec_on_unit_circle
+    raw64 = {k: v.detach().double().requires_grad_(True) for k, v in raw.items()}
+    act = {k: tr.net.activations[k](v) for k, v in raw64.items()}
+    from liso_amd.kabsch.output_modification import output_modification
+    dec = output_modification({k: v.clone() for k, v in act.items()}, tr.cfg.box_prediction, tr.cfg.data, "boxes",
+                              tr.net.pillar_center_coors_m.double())
+    ref_losses = centerpoint_loss(loss_cfg=tr.cfg.loss, raw_activated_pred_box_maps=act, decoded_pred_box_maps=dec,
+                                  gt_maps={k: v.double() for k, v in gt_maps.items()}, gt_center_mask=targets["center_bool_mask"],
+                                  rotation_loss_weights_map=rot_w.double(), box_prediction_cfg=tr.cfg.box_prediction,
+                                  ignore_region_is_true_mask=ignore)
+    ref_total = sum(ref_losses.values()) * tr.cfg.loss.supervised.supervised_on_clusters.weight \
+        + rotation_vec_on_unit_circle(act) * tr.cfg.box_prediction.rotation_representation.regul_weight
+    ref_grads = torch.autograd.grad(ref_total * 1.7, [raw64[k] for k in ("pos", "dims", "rot", "probs")])
+    for k, v in ref_losses.items():
+        assert abs(float(losses[k]) - float(v)) <= 1e-5 * max(abs(float(v)), 1e-3), (k, float(losses[k]), float(v))
+    assert abs(float(total) - float(ref_total)) <= 1e-5 * abs(float(ref_total))
+    for name, a, b in zip(("pos", "dims", "rot", "probs"), grads, ref_grads):
+        assert a.stride() == raw[name].stride()
+        assert _rel(a, b) < 1e-5, (name, _rel(a, b))
