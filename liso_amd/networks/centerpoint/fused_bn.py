@@ -66,9 +66,25 @@ class _BnAct(torch.autograd.Function):
 def bn_act(x, bn, relu=True):
     """y = ReLU?(BatchNorm2d(x)) with `bn`'s parameters; updates running stats / num_batches_tracked like the module."""
     training = bn.training or not bn.track_running_stats
-    if bn.training and bn.track_running_stats:
-        bn.num_batches_tracked += 1
+    if bn.training and bn.track_running_stats and not getattr(bn, "_liso_counter_deferred", False):
+        bn.num_batches_tracked += 1  # (a trainer may take over: one fused increment for all layers, see defer_batch_counters)
     if x.is_cuda and _supported(x.shape[1], x.dtype) and bn.affine and bn.track_running_stats:
         return _BnAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, training, relu)
     y = F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, training, bn.momentum, bn.eps)
     return F.relu(y, inplace=True) if relu else y
+
+
+def defer_batch_counters(module):
+    """Let the caller bump `num_batches_tracked` of every BatchNorm2d under `module` with ONE fused launch per step
+    (`step_batch_counters`) instead of one tiny kernel per layer and forward (24 in the CenterPoint backbone)."""
+    counters = []
+    for m in module.modules():
+        if isinstance(m, torch.nn.BatchNorm2d) and m.track_running_stats:
+            m._liso_counter_deferred = True
+            counters.append(m.num_batches_tracked)
+    return counters
+
+
+def step_batch_counters(counters):
+    if counters:
+        torch._foreach_add_(counters, 1)

@@ -43,9 +43,14 @@ class DetectorTrainer:
                 self.net, device_ids=[device.index] if device.type == "cuda" else None, bucket_cap_mb=64,
                 broadcast_buffers=False, gradient_as_bucket_view=True)
         self.optimizer, self.lr_scheduler = get_optimizer_scheduler(cfg, self.net, total_steps)
+        from liso_amd.networks.centerpoint.fused_bn import defer_batch_counters
+        self._bn_counters = defer_batch_counters(self.net.model.rpn) + defer_batch_counters(self.net.model.center_head)
 
     def loss(self, pcls, targets):
         """liso_cli.py:452-614"""
+        if self.model.training:
+            from liso_amd.networks.centerpoint.fused_bn import step_batch_counters
+            step_batch_counters(self._bn_counters)
         cfg = self.cfg
         sup = cfg.loss.supervised.supervised_on_clusters
         gt_maps = {a: targets[a] for a in sup.attrs}
