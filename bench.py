@@ -25,6 +25,26 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+
+def _seed_miopen_user_db():
+    """MIOpen keeps the solver picks / tuning parameters it finds in a per-user database; a fresh machine starts from
+    heuristics (detector step 8.9 ms) and only reaches the tuned state (6.0-6.6 ms) after several processes have run.
+    liso_amd/miopen_db/ holds that database as harvested on an MI355X with this ROCm image; every process works on a
+    private copy (MIOpen appends to it).  Must run before MIOpen initialises; no effect if the files do not match the
+    installed MIOpen version."""
+    src = os.path.join(ROOT, "liso_amd", "miopen_db")
+    if "MIOPEN_USER_DB_PATH" in os.environ or not os.path.isdir(src) or "--no-miopen-db" in sys.argv:
+        return
+    import shutil
+    import tempfile
+    dst = tempfile.mkdtemp(prefix="liso_miopen_db_")
+    for f in os.listdir(src):
+        shutil.copy(os.path.join(src, f), dst)
+    os.environ["MIOPEN_USER_DB_PATH"] = dst
+
+
+_seed_miopen_user_db()
+
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -44,6 +64,10 @@ def parse():
     ap.add_argument("--batch", type=int, default=None, help="detector workload: clouds per GPU (default 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="slim workload: eager launches instead of hipGraph replay")
+    ap.add_argument("--conv-benchmark", action="store_true",
+                    help="torch.backends.cudnn.benchmark = True: MIOpen re-times its solvers in this process (run-to-run "
+                         "variation of the picks: 540-620 frames/s on the detector); default: the picks of the seeded database")
+    ap.add_argument("--no-miopen-db", action="store_true", help="do not seed MIOpen's user database from liso_amd/miopen_db/")
     ap.add_argument("--nhwc", action="store_true", help="slim workload: conv filters in channels-last memory format (slower)")
     return ap.parse_args()
 
@@ -122,6 +146,8 @@ def main():
 
     from liso_amd import _lib as L
     from liso_amd.utils.config import apply_slim_simple_knn_training, default_cfg
+
+    torch.backends.cudnn.benchmark = bool(args.conv_benchmark)
 
     cfg = default_cfg(grid=GRID, bev_range_m=BEV_RANGE)
     torch.manual_seed(0)  # identical initial weights on every rank (DDP also broadcasts them)
@@ -256,7 +282,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": workload, "points_per_cloud": N_POINTS, "bev_grid": GRID, "batch_per_gpu": batch,
                        "frames_per_step_per_gpu": frames_per_step, "parallelism": f"dp{world}",
-                       "launch": "hipGraph replay of fwd+loss+bwd, eager RMSprop" if graphed else "eager"},
+                       "launch": "hipGraph replay of fwd+loss+bwd, eager RMSprop" if graphed else "eager",
+                       "miopen_solver_selection": ("timed in-process (cudnn.benchmark)" if args.conv_benchmark else
+                                                   "MIOpen defaults" if args.no_miopen_db else "seeded user database liso_amd/miopen_db")},
             "final_loss": float(loss),
             "roofline": {"kernel": kname, "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": None, "avg_launch_ms": avg_ms,
