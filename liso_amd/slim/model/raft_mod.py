@@ -44,14 +44,22 @@ class RAFT(nn.Module):
         self.update_block = SmallUpdateBlock(cfg=self.slim_cfg, filters=self.hidden_dim)
 
     def forward(self, pcl_t0, pcl_t1):
-        """reference :82-122"""
+        """reference :82-122.  The forward (t0->t1) and backward (t1->t0) flow estimates share every weight and never
+        interact inside the network (instance norm in `fnet`, no norm elsewhere), so they run as ONE batch of 2B samples
+        through the encoders, the correlation lookup and the 6 update iterations: per-sample results are those of the
+        reference's two sequential calls, with half the launches and twice the work per convolution (the 64x64 update
+        maps of a single sample cannot fill 256 CUs).  The pillar encoder stays per sweep: its BatchNorm1d statistics are
+        per call in the reference."""
         img_t0, occ_t0 = self.pp_layer(pcl_t0)
         img_t1, occ_t1 = self.pp_layer(pcl_t1)
         aux = {"t0": {"bev_net_input_dbg": occ_t0}, "t1": {"bev_net_input_dbg": occ_t1}}
-        fmap_t0, fmap_t1 = self.fnet(img_t0), self.fnet(img_t1)
-        fw = self.predict_single_flow_map_and_classes(img_t0, fmap_t0, fmap_t1, self.head_decoder_fw)
-        bw = self.predict_single_flow_map_and_classes(img_t1, fmap_t1, fmap_t0, self.head_decoder_bw)
-        return fw, bw, aux
+        B = img_t0.shape[0]
+        imgs = torch.cat([img_t0, img_t1], dim=0)
+        fmap = self.fnet(imgs)
+        fmap_swapped = torch.cat([fmap[B:], fmap[:B]], dim=0)
+        both = self.predict_single_flow_map_and_classes(imgs, fmap, fmap_swapped, self.head_decoder_fw)
+        aux["fw_bw_batched"] = both  # per iteration [2B,H,W,8]: samples [:B] = forward flow, [B:] = backward flow
+        return [p[:B] for p in both], [p[B:] for p in both], aux
 
     def predict_single_flow_map_and_classes(self, img_t0, fmap_t0, fmap_t1, decoder):
         """reference :124-259"""

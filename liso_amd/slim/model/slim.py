@@ -17,6 +17,20 @@ def get_network_input_pcls(cfg, sample_data, time_key: str, to_device=None):
     return [el.to(to_device) for el in sample_data[key]] if to_device else sample_data[key]
 
 
+def _slice_prediction(pred, sl):
+    """the samples `sl` of a batched HeadDecoder result (tensors with a leading batch dimension are sliced, 0-d tensors and
+    other values are shared)"""
+    out = type(pred)()
+    for k, v in pred.items():
+        if isinstance(v, dict):
+            out[k] = _slice_prediction(v, sl)
+        elif torch.is_tensor(v) and v.ndim >= 1:
+            out[k] = v[sl]
+        else:
+            out[k] = v
+    return out
+
+
 class SLIM(nn.Module):
     def __init__(self, cfg, num_train_samples, *args, **kwargs):
         super().__init__(*args, **kwargs)
@@ -44,23 +58,39 @@ class SLIM(nn.Module):
         nri = self.slim_cfg.model.dynamic_flow_is_non_rigid_flow
         preds_fw, preds_bw = [], []
         fs = self.slim_cfg.model.u_net.final_scale
-        plans = [BevGatherPlan(torch.div(sd["pcl_ta"]["pillar_coors"].to(dev), fs, rounding_mode="trunc"),
-                               sd["pcl_ta"]["pcl_is_valid"].to(dev), out_fw[0].shape[1:3])
-                 for sd in (sample_data_t0, sample_data_t1)]  # point -> cell lists, shared by all RAFT iterations
-        for o01, o10 in zip(out_fw, out_bw):
-            kw0 = dict(dynamicness_threshold=thr, pointwise_valid_mask=sample_data_t0["pcl_ta"]["pcl_is_valid"].to(dev),
-                       pointwise_voxel_coordinates=sample_data_t0["pcl_ta"]["pillar_coors"].to(dev),
-                       pc=sample_data_t0["pcl_ta"]["pcl"].to(dev), filled_pillar_mask=filled0,
-                       odom=sample_data_t0["gt"]["odom_ta_tb"].to(dev), inv_odom=sample_data_t1["gt"]["odom_ta_tb"].to(dev),
-                       summaries=summaries, gt_flow_bev=None, ohe_gt_stat_dyn_ground_label_bev_map=None,
-                       dynamic_flow_is_non_rigid_flow=nri, gather_plan=plans[0])
-            kw1 = dict(dynamicness_threshold=thr, pointwise_valid_mask=sample_data_t1["pcl_ta"]["pcl_is_valid"].to(dev),
-                       pointwise_voxel_coordinates=sample_data_t1["pcl_ta"]["pillar_coors"].to(dev),
-                       pc=sample_data_t1["pcl_ta"]["pcl"].to(dev), filled_pillar_mask=filled1,
-                       odom=sample_data_t1["gt"]["odom_ta_tb"].to(dev), inv_odom=sample_data_t0["gt"]["odom_ta_tb"].to(dev),
-                       summaries=summaries, gt_flow_bev=None, ohe_gt_stat_dyn_ground_label_bev_map=None,
-                       dynamic_flow_is_non_rigid_flow=nri, gather_plan=plans[1])
-            preds_fw.append(self.head_decoder_fw(o01, **kw0))
-            preds_bw.append(self.head_decoder_bw(o10, **kw1))
+        pa, pb = sample_data_t0["pcl_ta"], sample_data_t1["pcl_ta"]
+        common = dict(dynamicness_threshold=thr, summaries=summaries, gt_flow_bev=None, ohe_gt_stat_dyn_ground_label_bev_map=None,
+                      dynamic_flow_is_non_rigid_flow=nri)
+        if pa["pcl"].shape == pb["pcl"].shape:
+            # both directions through ONE decoder call per RAFT iteration (batch = [forward samples; backward samples]):
+            # the decoder has no parameters and treats samples independently (its only batch-wide quantities are the global
+            # logit extrema of the `True`/`False` output modes, head_decoder.py:779-955, which the reference also takes over
+            # whatever batch it is given; they only offset logits by +-100 and leave the class probabilities unchanged)
+            B = pa["pcl"].shape[0]
+            cat = lambda a, b: torch.cat([a.to(dev), b.to(dev)], dim=0)  # noqa: E731
+            pc, valid, coors = cat(pa["pcl"], pb["pcl"]), cat(pa["pcl_is_valid"], pb["pcl_is_valid"]), cat(pa["pillar_coors"], pb["pillar_coors"])
+            odom = cat(sample_data_t0["gt"]["odom_ta_tb"], sample_data_t1["gt"]["odom_ta_tb"])
+            inv_odom = cat(sample_data_t1["gt"]["odom_ta_tb"], sample_data_t0["gt"]["odom_ta_tb"])
+            filled = torch.cat([filled0, filled1], dim=0)
+            plan = BevGatherPlan(torch.div(coors, fs, rounding_mode="trunc"), valid, out_fw[0].shape[1:3])
+            batched = aux.get("fw_bw_batched") or [torch.cat([o01, o10], dim=0) for o01, o10 in zip(out_fw, out_bw)]
+            for net_out in batched:
+                both = self.head_decoder_fw(net_out, pointwise_valid_mask=valid, pointwise_voxel_coordinates=coors,
+                                            pc=pc, filled_pillar_mask=filled, odom=odom, inv_odom=inv_odom, gather_plan=plan, **common)
+                preds_fw.append(_slice_prediction(both, slice(0, B)))
+                preds_bw.append(_slice_prediction(both, slice(B, 2 * B)))
+        else:
+            plans = [BevGatherPlan(torch.div(sd["pcl_ta"]["pillar_coors"].to(dev), fs, rounding_mode="trunc"),
+                                   sd["pcl_ta"]["pcl_is_valid"].to(dev), out_fw[0].shape[1:3])
+                     for sd in (sample_data_t0, sample_data_t1)]  # point -> cell lists, shared by all RAFT iterations
+            for o01, o10 in zip(out_fw, out_bw):
+                kw0 = dict(pointwise_valid_mask=pa["pcl_is_valid"].to(dev), pointwise_voxel_coordinates=pa["pillar_coors"].to(dev),
+                           pc=pa["pcl"].to(dev), filled_pillar_mask=filled0, odom=sample_data_t0["gt"]["odom_ta_tb"].to(dev),
+                           inv_odom=sample_data_t1["gt"]["odom_ta_tb"].to(dev), gather_plan=plans[0], **common)
+                kw1 = dict(pointwise_valid_mask=pb["pcl_is_valid"].to(dev), pointwise_voxel_coordinates=pb["pillar_coors"].to(dev),
+                           pc=pb["pcl"].to(dev), filled_pillar_mask=filled1, odom=sample_data_t1["gt"]["odom_ta_tb"].to(dev),
+                           inv_odom=sample_data_t0["gt"]["odom_ta_tb"].to(dev), gather_plan=plans[1], **common)
+                preds_fw.append(self.head_decoder_fw(o01, **kw0))
+                preds_bw.append(self.head_decoder_bw(o10, **kw1))
         self.predictions_fw, self.predictions_bw = preds_fw, preds_bw
         return preds_fw, preds_bw
