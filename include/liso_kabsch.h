@@ -64,13 +64,14 @@ int liso_symm_ortho_bwd_f64(const double* grad_r, const double* u, const double*
  *     out[0]      = sum_i w_i                out[1..3] = sum_i w_i x_i         out[4..6] = sum_i w_i y_i
  *     out[7+3a+b] = sum_i w_i y_i[a] x_i[b]
  * from which the host forms  m_x = S_x/S, m_y = S_y/S, S_xy = (S_yx - S m_y m_x^T)/S  (== the reference's centred
- * product) with differentiable 3x3 fp64 algebra.  x, y: float32 [n,3] (finite); w: float32 [n] (rows to ignore: 0).
- * Backward: grad_out float64 [16] -> grad_x/grad_y [n,3], grad_w [n] (any of them may be NULL). */
-size_t liso_weighted_moments_workspace_bytes(void);
-int liso_weighted_moments_fwd_f32(const float* x, const float* y, const float* w, long n, double* out, void* workspace,
+ * product) with differentiable 3x3 fp64 algebra.  Batched over `batch` independent fits of the same length:
+ * x, y: float32 [batch,n,3] (finite); w: float32 [batch,n] (rows to ignore: 0); out float64 [batch,16].
+ * Backward: grad_out float64 [batch,16] -> grad_x/grad_y [batch,n,3], grad_w [batch,n] (any of them may be NULL). */
+size_t liso_weighted_moments_workspace_bytes(int batch);
+int liso_weighted_moments_fwd_f32(const float* x, const float* y, const float* w, int batch, long n, double* out, void* workspace,
                                   size_t workspace_bytes, void* stream);
-int liso_weighted_moments_bwd_f32(const float* x, const float* y, const float* w, long n, const double* grad_out, float* grad_x,
-                                  float* grad_y, float* grad_w, void* stream);
+int liso_weighted_moments_bwd_f32(const float* x, const float* y, const float* w, int batch, long n, const double* grad_out,
+                                  float* grad_x, float* grad_y, float* grad_w, void* stream);
 
 #ifdef __cplusplus
 }

@@ -91,9 +91,9 @@ SIGNATURES = {
     "liso_kabsch_trafos_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "liso_symm_ortho_fwd_f64": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "liso_symm_ortho_bwd_f64": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),
-    "liso_weighted_moments_workspace_bytes": (_sz, []),
-    "liso_weighted_moments_fwd_f32": (_i, [_vp, _vp, _vp, ctypes.c_long, _vp, _vp, _sz, _vp]),
-    "liso_weighted_moments_bwd_f32": (_i, [_vp, _vp, _vp, ctypes.c_long, _vp, _vp, _vp, _vp, _vp]),
+    "liso_weighted_moments_workspace_bytes": (_sz, [_i]),
+    "liso_weighted_moments_fwd_f32": (_i, [_vp, _vp, _vp, _i, ctypes.c_long, _vp, _vp, _sz, _vp]),
+    "liso_weighted_moments_bwd_f32": (_i, [_vp, _vp, _vp, _i, ctypes.c_long, _vp, _vp, _vp, _vp, _vp]),
     # include/liso_flow_cluster.h
     "liso_bev_dynamic_flow_workspace_bytes": (_sz, [_i, _i, _i]),
     "liso_bev_dynamic_flow_f32": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),

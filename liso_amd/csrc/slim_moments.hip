@@ -26,6 +26,9 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int m) {
 __global__ __launch_bounds__(kThreads) void moments_partial_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                                    const float* __restrict__ w, long n,
                                                                    double* __restrict__ partials) {
+    // blockIdx.y = sample of the batch: x, y [B, n, 3], w [B, n], partials [B, kBlocks, 16]
+    x += (size_t)blockIdx.y * n * 3; y += (size_t)blockIdx.y * n * 3; w += (size_t)blockIdx.y * n;
+    partials += (size_t)blockIdx.y * kBlocks * 16;
     double acc[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) acc[k] = 0.0;
@@ -61,9 +64,16 @@ __global__ __launch_bounds__(kThreads) void moments_partial_kernel(const float* 
 
 __global__ void moments_final_kernel(const double* __restrict__ partials, double* __restrict__ out) {
     if (threadIdx.x >= 16) return;
+    partials += (size_t)blockIdx.x * kBlocks * 16;
     double v = 0.0;
-    for (int b = 0; b < kBlocks; b++) v += partials[(size_t)b * 16 + threadIdx.x];
-    out[threadIdx.x] = v;
+    for (int b = 0; b < kBlocks; b += 8) {  // 8 loads in flight, fixed summation order
+        double t[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) t[j] = partials[(size_t)(b + j) * 16 + threadIdx.x];
+#pragma unroll
+        for (int j = 0; j < 8; j++) v += t[j];
+    }
+    out[(size_t)blockIdx.x * 16 + threadIdx.x] = v;
 }
 
 __global__ void moments_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ w, long n,
@@ -71,6 +81,13 @@ __global__ void moments_bwd_kernel(const float* __restrict__ x, const float* __r
                                    float* __restrict__ gw) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    {   // blockIdx.y = sample
+        const size_t o = (size_t)blockIdx.y * n;
+        x += o * 3; y += o * 3; w += o; g += (size_t)blockIdx.y * 16;
+        if (gx) gx += o * 3;
+        if (gy) gy += o * 3;
+        if (gw) gw += o;
+    }
     const double wi = (double)w[i];
     const double xs[3] = {(double)x[3 * i], (double)x[3 * i + 1], (double)x[3 * i + 2]};
     const double ys[3] = {(double)y[3 * i], (double)y[3 * i + 1], (double)y[3 * i + 2]};
@@ -101,23 +118,24 @@ inline int check_launch() { return hipGetLastError() == hipSuccess ? LISO_OK : L
 
 extern "C" {
 
-size_t liso_weighted_moments_workspace_bytes(void) { return (size_t)kBlocks * 16 * sizeof(double); }
+size_t liso_weighted_moments_workspace_bytes(int batch) { return (size_t)(batch > 0 ? batch : 0) * kBlocks * 16 * sizeof(double); }
 
-int liso_weighted_moments_fwd_f32(const float* x, const float* y, const float* w, long n, double* out, void* workspace,
+int liso_weighted_moments_fwd_f32(const float* x, const float* y, const float* w, int batch, long n, double* out, void* workspace,
                                   size_t workspace_bytes, void* stream) {
-    if (n < 0 || !out || !workspace || (n > 0 && (!x || !y || !w))) return LISO_EINVAL;
-    if (workspace_bytes < liso_weighted_moments_workspace_bytes()) return LISO_EWORKSPACE;
+    if (batch < 1 || n < 0 || !out || !workspace || (n > 0 && (!x || !y || !w))) return LISO_EINVAL;
+    if (workspace_bytes < liso_weighted_moments_workspace_bytes(batch)) return LISO_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    moments_partial_kernel<<<kBlocks, kThreads, 0, st>>>(x, y, w, n, (double*)workspace);
-    moments_final_kernel<<<1, 64, 0, st>>>((const double*)workspace, out);
+    moments_partial_kernel<<<dim3(kBlocks, batch), kThreads, 0, st>>>(x, y, w, n, (double*)workspace);
+    moments_final_kernel<<<batch, 64, 0, st>>>((const double*)workspace, out);
     return check_launch();
 }
 
-int liso_weighted_moments_bwd_f32(const float* x, const float* y, const float* w, long n, const double* grad_out, float* grad_x,
-                                  float* grad_y, float* grad_w, void* stream) {
-    if (n < 0 || !grad_out || (n > 0 && (!x || !y || !w))) return LISO_EINVAL;
+int liso_weighted_moments_bwd_f32(const float* x, const float* y, const float* w, int batch, long n, const double* grad_out,
+                                  float* grad_x, float* grad_y, float* grad_w, void* stream) {
+    if (batch < 1 || n < 0 || !grad_out || (n > 0 && (!x || !y || !w))) return LISO_EINVAL;
     if (n == 0) return LISO_OK;
-    moments_bwd_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, y, w, n, grad_out, grad_x, grad_y, grad_w);
+    moments_bwd_kernel<<<dim3((unsigned)((n + 255) / 256), batch), 256, 0, (hipStream_t)stream>>>(x, y, w, n, grad_out, grad_x, grad_y,
+                                                                                                 grad_w);
     return check_launch();
 }
 

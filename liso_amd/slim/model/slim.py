@@ -57,6 +57,7 @@ class SLIM(nn.Module):
         thr = self.moving_dynamicness_threshold.value()
         nri = self.slim_cfg.model.dynamic_flow_is_non_rigid_flow
         preds_fw, preds_bw = [], []
+        self.stacked_predictions = None
         fs = self.slim_cfg.model.u_net.final_scale
         pa, pb = sample_data_t0["pcl_ta"], sample_data_t1["pcl_ta"]
         common = dict(dynamicness_threshold=thr, summaries=summaries, gt_flow_bev=None, ohe_gt_stat_dyn_ground_label_bev_map=None,
@@ -72,13 +73,23 @@ class SLIM(nn.Module):
             odom = cat(sample_data_t0["gt"]["odom_ta_tb"], sample_data_t1["gt"]["odom_ta_tb"])
             inv_odom = cat(sample_data_t1["gt"]["odom_ta_tb"], sample_data_t0["gt"]["odom_ta_tb"])
             filled = torch.cat([filled0, filled1], dim=0)
-            plan = BevGatherPlan(torch.div(coors, fs, rounding_mode="trunc"), valid, out_fw[0].shape[1:3])
             batched = aux.get("fw_bw_batched") or [torch.cat([o01, o10], dim=0) for o01, o10 in zip(out_fw, out_bw)]
-            for net_out in batched:
-                both = self.head_decoder_fw(net_out, pointwise_valid_mask=valid, pointwise_voxel_coordinates=coors,
-                                            pc=pc, filled_pillar_mask=filled, odom=odom, inv_odom=inv_odom, gather_plan=plan, **common)
-                preds_fw.append(_slice_prediction(both, slice(0, B)))
-                preds_bw.append(_slice_prediction(both, slice(B, 2 * B)))
+            # ... and all RAFT iterations at once: the decoder output of iteration i feeds nothing but the loss, so the
+            # 6 x 2B network outputs are decoded as one batch ordered [fw it0..it5 | bw it0..it5]
+            n_it = len(batched)
+            net_all = torch.cat([p[:B] for p in batched] + [p[B:] for p in batched], dim=0)
+            tile = lambda t: torch.cat([t[:B]] * n_it + [t[B:]] * n_it, dim=0)  # noqa: E731
+            pc_all, valid_all, coors_all = tile(pc), tile(valid), tile(coors)
+            plan = BevGatherPlan(torch.div(coors_all, fs, rounding_mode="trunc"), valid_all, out_fw[0].shape[1:3])
+            out_all = self.head_decoder_fw(net_all, pointwise_valid_mask=valid_all, pointwise_voxel_coordinates=coors_all, pc=pc_all,
+                                           filled_pillar_mask=tile(filled), odom=tile(odom), inv_odom=tile(inv_odom),
+                                           gather_plan=plan, **common)
+            for i in range(n_it):
+                preds_fw.append(_slice_prediction(out_all, slice(i * B, (i + 1) * B)))
+                preds_bw.append(_slice_prediction(out_all, slice((n_it + i) * B, (n_it + i + 1) * B)))
+            # the same predictions stacked over the iterations, for a single evaluation of the per-iteration loss
+            self.stacked_predictions = (_slice_prediction(out_all, slice(0, n_it * B)),
+                                        _slice_prediction(out_all, slice(n_it * B, 2 * n_it * B)), n_it)
         else:
             plans = [BevGatherPlan(torch.div(sd["pcl_ta"]["pillar_coors"].to(dev), fs, rounding_mode="trunc"),
                                    sd["pcl_ta"]["pcl_is_valid"].to(dev), out_fw[0].shape[1:3])

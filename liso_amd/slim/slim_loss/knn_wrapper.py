@@ -75,8 +75,27 @@ def compute_flow_loss_a_to_b(cloud_a, cloud_b, flow_a_to_b, loss_function, neare
     assert cloud_a.ndim == 3 and cloud_b.ndim == 3 and flow_a_to_b.ndim == 3
     cloud_b__a = cloud_a + flow_a_to_b
     bs = cloud_b.size(0)
-    idx = torch.stack([get_idx_dists_for_knn(knn_indices[b] if knn_indices is not None else cloud_b[b], cloud_b__a[b], 1)
-                       for b in range(bs)], dim=0)
+    if knn_indices is not None:
+        # rows that query the SAME reference index (flow types / RAFT iterations stacked along the batch axis) go through
+        # one launch: the queries are independent
+        groups = {}
+        for b in range(bs):
+            groups.setdefault(id(knn_indices[b]), []).append(b)
+        idx = torch.empty((bs, cloud_b__a.shape[1], 1), dtype=torch.int64, device=cloud_b__a.device)
+        for rows in groups.values():
+            contiguous = rows == list(range(rows[0], rows[-1] + 1))
+            if contiguous:  # plain slices: no index tensor (a host->device copy, which a hipGraph capture refuses)
+                q = cloud_b__a[rows[0]:rows[-1] + 1].reshape(-1, cloud_b__a.shape[-1])
+            else:
+                q = torch.cat([cloud_b__a[b] for b in rows], dim=0)
+            res = get_idx_dists_for_knn(knn_indices[rows[0]], q, 1).view(len(rows), -1, 1)
+            if contiguous:
+                idx[rows[0]:rows[-1] + 1] = res
+            else:
+                for j, b in enumerate(rows):
+                    idx[b] = res[j]
+    else:
+        idx = torch.stack([get_idx_dists_for_knn(cloud_b[b], cloud_b__a[b], 1) for b in range(bs)], dim=0)
     nearest = torch.gather(cloud_b, 1, idx.repeat(1, 1, 3))
     d2 = squared_sum(nearest - cloud_b__a, dim=-1)
     loss = loss_function(cloud_b__a=cloud_b__a, nearest_cloud_b__a=nearest, nearest_dist_sqr_b__a=d2)

@@ -2,7 +2,7 @@
 import torch
 
 from liso_amd import _lib as L
-from liso_amd.slim.slim_loss.weighted_pc_alignment import weighted_pc_alignment
+from liso_amd.slim.slim_loss.weighted_pc_alignment import batched_weighted_pc_alignment, weighted_pc_alignment  # noqa: F401
 
 
 class BevGatherPlan:
@@ -84,16 +84,13 @@ def compute_batched_bev_static_aggregated_flow(pc, pointwise_voxel_coordinates_f
     pw_flow = torch.cat([pw[..., :2], torch.zeros_like(pw[..., :1])], dim=-1)
     pw_static = pw[..., 2]
     centers = voxel_center_metric_coordinates_bev
-    flows, Ts, neps = [], [], []
-    for b in range(staticness_weights.shape[0]):
-        m = pointwise_valid_mask[b]
-        p0 = torch.where(m[:, None], pc[b][..., :3], 0.0)
-        T, nep = weighted_pc_alignment(p0, p0 + pw_flow[b], pw_static[b],
-                                       use_epsilon_on_weights=use_eps_for_weighted_pc_alignment, valid_mask=m)
-        # (T - I) applied to every cell centre (z = 0, w = 1) as fp64 broadcast multiply-adds; the reference's einsum
-        # (:88-99) is a [4x4]x[4xHW] DGEMM that rocBLAS runs with a 128x128 tile: 28 ms per call at 512^2 (measured)
-        D = T - torch.eye(4, dtype=torch.float64, device=T.device)
-        flows.append((D[:2, 0] * centers[..., 0:1] + D[:2, 1] * centers[..., 1:2] + D[:2, 3]).float())
-        Ts.append(T)
-        neps.append(nep)
-    return torch.stack(flows, dim=0), torch.stack(Ts, dim=0), torch.stack(neps, dim=0)
+    # all samples of the batch in one set of launches (the reference loops over the batch, :60-106)
+    p0 = torch.where(pointwise_valid_mask[..., None], pc[..., :3], 0.0)
+    T, nep = batched_weighted_pc_alignment(p0, p0 + pw_flow, pw_static, pointwise_valid_mask,
+                                           use_epsilon_on_weights=use_eps_for_weighted_pc_alignment)
+    # (T - I) applied to every cell centre (z = 0, w = 1) as fp64 broadcast multiply-adds; the reference's einsum
+    # (:88-99) is a [4x4]x[4xHW] DGEMM that rocBLAS runs with a 128x128 tile: 28 ms per call at 512^2 (measured)
+    D = T - torch.eye(4, dtype=torch.float64, device=T.device)
+    flows = (D[:, None, None, :2, 0] * centers[None, ..., 0:1] + D[:, None, None, :2, 1] * centers[None, ..., 1:2]
+             + D[:, None, None, :2, 3]).float()
+    return flows, T, nep

@@ -155,13 +155,24 @@ class SlimTrainer:
         idx1 = [KnnIndex(pc1[b][:, :3], extent=ext) for b in range(pc1.shape[0])] if all_valid[0] else None
         idx2 = [KnnIndex(pc2[b][:, :3], extent=ext) for b in range(pc2.shape[0])] if all_valid[1] else None
         preds_fw, preds_bw = self.model(sample_t0, sample_t1, None)
+        kw = dict(moving_thresh_module=self.net.moving_dynamicness_threshold, loss_cfg=self.slim_cfg.losses.unsupervised,
+                  model_cfg=self.slim_cfg.model, bev_extent=self.bev_extent, metrics_collector={})
+        stacked = getattr(self.net, "stacked_predictions", None)
+        if stacked is not None and not self.slim_cfg.model.use_static_aggr_flow_for_aggr_flow:
+            # experiment.py:834-919 sums the loss over the RAFT iterations.  Every term of it is a mean over the points /
+            # samples of one iteration, so with the iterations stacked along the batch axis (same clouds, same masks) ONE
+            # evaluation gives exactly sum_i loss_i / n_it.  (Not used when the loss also updates the dynamicness
+            # threshold: that update is sequential in the iterations.)
+            sfw, sbw, n_it = stacked
+            rep = lambda t: t.repeat(n_it, *([1] * (t.dim() - 1)))  # noqa: E731
+            total = n_it * selfsupervisedSlimSingleScaleLoss(
+                pc1=rep(pc1), valid_mask_pc1=rep(m1), pc2=rep(pc2), valid_mask_pc2=rep(m2), pred_fw=sfw, pred_bw=sbw,
+                knn_index_pc1=None if idx1 is None else idx1 * n_it, knn_index_pc2=None if idx2 is None else idx2 * n_it, **kw)
+            return total, preds_fw, preds_bw
         total = torch.zeros(1, device=self.device)
         for pfw, pbw in zip(preds_fw, preds_bw):
-            total = total + selfsupervisedSlimSingleScaleLoss(
-                pc1=pc1, valid_mask_pc1=m1, pc2=pc2, valid_mask_pc2=m2, pred_fw=pfw, pred_bw=pbw,
-                moving_thresh_module=self.net.moving_dynamicness_threshold, loss_cfg=self.slim_cfg.losses.unsupervised,
-                model_cfg=self.slim_cfg.model, bev_extent=self.bev_extent, metrics_collector={},
-                knn_index_pc1=idx1, knn_index_pc2=idx2)
+            total = total + selfsupervisedSlimSingleScaleLoss(pc1=pc1, valid_mask_pc1=m1, pc2=pc2, valid_mask_pc2=m2, pred_fw=pfw,
+                                                              pred_bw=pbw, knn_index_pc1=idx1, knn_index_pc2=idx2, **kw)
         return total, preds_fw, preds_bw
 
     def step(self, sample_t0, sample_t1, eager=False):

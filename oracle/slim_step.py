@@ -80,8 +80,11 @@ class _CpuWeightedMoments:
     @staticmethod
     def apply(x, y, w):
         xd, yd, wd = x.double(), y.double(), w.double()
-        return torch.cat([wd.sum()[None], (wd[:, None] * xd).sum(0), (wd[:, None] * yd).sum(0),
-                          ((yd * wd[:, None]).T @ xd).reshape(-1)])
+        if xd.dim() == 2:
+            return torch.cat([wd.sum()[None], (wd[:, None] * xd).sum(0), (wd[:, None] * yd).sum(0),
+                              ((yd * wd[:, None]).T @ xd).reshape(-1)])
+        return torch.cat([wd.sum(1, keepdim=True), (wd[..., None] * xd).sum(1), (wd[..., None] * yd).sum(1),
+                          torch.einsum("bn,bni,bnj->bij", wd, yd, xd).reshape(xd.shape[0], 9)], dim=1)
 
 
 def _cpu_grid_to_points(grid_data, pointwise_voxel_coordinates_fs, pointwise_valid_mask, default_value, plan=None):
