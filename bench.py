@@ -80,12 +80,13 @@ def pfn_algorithmic_bytes(batch, n_points, grid, out_bytes):
 
 def slim_algorithmic_bytes(batch, n_points, grid, levels=4, radius=3):
     """SURVEY.md 8(d), SLIM rows, per launch:
-    corr lookup (fwd, and its adjoint bwd): levels * hw * (2r+1)^2 bilinear reads of 4 taps * 4 B + the
+    corr lookup (fwd, and its adjoint bwd), per sample: levels * hw * (2r+1)^2 bilinear reads of 4 taps * 4 B + the
       [hw, levels*(2r+1)^2] fp32 output, hw = (G/8)^2;
     1-NN query: (N_q + N_ref) * 12 B in + N_q * 8 B out."""
     hw = (grid // 8) ** 2
     w2 = (2 * radius + 1) ** 2
-    lookup = batch * (levels * hw * w2 * 4 * 4 + hw * levels * w2 * 4)
+    # the forward and the backward flow direction of every pair share one launch: 2 * batch samples per lookup
+    lookup = 2 * batch * (levels * hw * w2 * 4 * 4 + hw * levels * w2 * 4)
     return {"corr_lookup_fwd": lookup, "corr_lookup_bwd": lookup, "knn_query": 2 * n_points * 12 + n_points * 8}
 
 
