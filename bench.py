@@ -188,20 +188,26 @@ def main():
         frames_per_step, timed = batch, ["pfn_decorate", "pfn_forward_scatter"]
 
     graph_note = None
-    for i in range(args.warmup):
-        if i == 0 and args.workload == "slim" and not args.no_graph:
-            try:
-                step()
-            except Exception as e:  # capture refused by the runtime: same kernels, launched eagerly
-                graph_note = f"hipGraph capture failed ({type(e).__name__}: {str(e)[:120]}); eager launches"
-                print(graph_note, file=sys.stderr, flush=True)
-                args.no_graph = True
-                torch.manual_seed(0)
-                trainer = SlimTrainer(cfg, dev, use_graph=False, channels_last=args.nhwc)
-                step = lambda: trainer.step(s0, s1)  # noqa: E731
-                step()
-        else:
-            step()
+    if args.workload == "slim" and not args.no_graph:
+        # capture before the first step and let all ranks agree on the outcome (capture issues no collective)
+        ok, err = 1, ""
+        try:
+            trainer.capture(s0, s1)
+        except Exception as e:  # capture refused by the runtime: same kernels, launched eagerly
+            ok, err = 0, f"{type(e).__name__}: {str(e)[:120]}"
+        if world > 1:
+            flag = torch.tensor([ok], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag.item())
+        if not ok:
+            graph_note = f"hipGraph capture failed on some rank ({err}); eager launches"
+            print(graph_note, file=sys.stderr, flush=True)
+            args.no_graph = True
+            torch.manual_seed(0)
+            trainer = SlimTrainer(cfg, dev, use_graph=False, channels_last=args.nhwc)
+            step = lambda: trainer.step(s0, s1)  # noqa: E731
+    for _ in range(args.warmup):
+        step()
 
     graphed = args.workload == "slim" and not args.no_graph
     if not graphed:  # per-launch HIP events on the launch stream, inside the timed region

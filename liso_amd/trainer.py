@@ -228,6 +228,9 @@ class SlimTrainer:
         self._static = self._map_tensors((sample_t0, sample_t1), lambda t: t.to(dev).clone())
         s0, s1 = self._static
         buffers = {k: v.clone() for k, v in self.net.state_dict().items() if v.is_floating_point() or v.dtype == torch.long}
+        if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
+            # the flat gradient views are created on the default stream, warm-up and capture run on side streams
+            torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):  # warm-up off the capture: MIOpen / rocBLAS pick their kernels, caches fill
@@ -251,14 +254,21 @@ class SlimTrainer:
                 if k in buffers:
                     v.copy_(buffers[k])
 
-    def _graph_step(self, sample_t0, sample_t1):
+    def capture(self, sample_t0, sample_t1):
+        """Capture the graph for inputs shaped like these (no collective is issued: callers running several ranks can
+        agree on the outcome before the first step).  Raises whatever the runtime raises if capture is refused."""
         _, m1, _, m2 = self._inputs(sample_t0, sample_t1)
         all_valid = (bool(m1.all()), bool(m2.all()))
         sig = self._signature(sample_t0, sample_t1, all_valid)
         if self._graph is None or sig != self._graph_sig:
+            self._graph = None
             self._capture(sample_t0, sample_t1, all_valid)
             self._graph_sig = sig
-        else:
+            return True
+        return False
+
+    def _graph_step(self, sample_t0, sample_t1):
+        if not self.capture(sample_t0, sample_t1):
             self._copy_tensors(self._static, (sample_t0, sample_t1))
         self._graph.replay()
         self._reduce_and_update()
