@@ -53,6 +53,11 @@ class RAFT(nn.Module):
         img_t0, occ_t0 = self.pp_layer(pcl_t0)
         img_t1, occ_t1 = self.pp_layer(pcl_t1)
         aux = {"t0": {"bev_net_input_dbg": occ_t0}, "t1": {"bev_net_input_dbg": occ_t1}}
+        if not getattr(self, "batch_directions", True):  # the reference's schedule: two sequential passes (:95-121)
+            fmap_t0, fmap_t1 = self.fnet(img_t0), self.fnet(img_t1)
+            fw = self.predict_single_flow_map_and_classes(img_t0, fmap_t0, fmap_t1, self.head_decoder_fw)
+            bw = self.predict_single_flow_map_and_classes(img_t1, fmap_t1, fmap_t0, self.head_decoder_bw)
+            return fw, bw, aux
         B = img_t0.shape[0]
         imgs = torch.cat([img_t0, img_t1], dim=0)
         fmap = self.fnet(imgs)

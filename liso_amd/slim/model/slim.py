@@ -62,7 +62,7 @@ class SLIM(nn.Module):
         pa, pb = sample_data_t0["pcl_ta"], sample_data_t1["pcl_ta"]
         common = dict(dynamicness_threshold=thr, summaries=summaries, gt_flow_bev=None, ohe_gt_stat_dyn_ground_label_bev_map=None,
                       dynamic_flow_is_non_rigid_flow=nri)
-        if pa["pcl"].shape == pb["pcl"].shape:
+        if pa["pcl"].shape == pb["pcl"].shape and getattr(self, "batch_decoding", True):
             # both directions through ONE decoder call per RAFT iteration (batch = [forward samples; backward samples]):
             # the decoder has no parameters and treats samples independently (its only batch-wide quantities are the global
             # logit extrema of the `True`/`False` output modes, head_decoder.py:779-955, which the reference also takes over
