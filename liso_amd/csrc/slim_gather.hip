@@ -28,36 +28,37 @@ __global__ void bev_gather_fwd_kernel(const float* __restrict__ grid, const int*
 // up its chunk heads (<= len / kChunk steps) and write the cell's gradient row.  Fixed order, no atomics.
 constexpr int kChunk = 16;
 
-__global__ void bev_gather_bwd_chunk_kernel(const float* __restrict__ grad_out, const int* __restrict__ sorted_lin,
-                                            const int* __restrict__ order, const int* __restrict__ seg_rank, long n_rows, int c,
-                                            float* __restrict__ partial) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_rows * c) return;
-    const long s = i / c;
-    const int ch = (int)(i - s * c);
+// 32 lanes per sorted row: the row's cell / rank are read once per half-wave (not once per channel), lanes = channels.
+__global__ __launch_bounds__(256) void bev_gather_bwd_chunk_kernel(const float* __restrict__ grad_out, const int* __restrict__ sorted_lin,
+                                                                   const int* __restrict__ order, const int* __restrict__ seg_rank,
+                                                                   long n_rows, int c, float* __restrict__ partial) {
+    const long s = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    const int lane = threadIdx.x & 31;
+    if (s >= n_rows) return;
     const int cell = sorted_lin[s];
     if (cell < 0 || (seg_rank[s] % kChunk) != 0) return;
-    float acc = 0.f;
-#pragma unroll 4
-    for (int k = 0; k < kChunk; k++) {
-        const long j = s + k;
-        if (j >= n_rows || sorted_lin[j] != cell) break;
-        acc += grad_out[(size_t)order[j] * c + ch];
+    int rows = 0;  // rows of this chunk: consecutive sorted rows of the same cell, at most kChunk
+    while (rows < kChunk && s + rows < n_rows && sorted_lin[s + rows] == cell) rows++;
+    for (int ch = lane; ch < c; ch += 32) {
+        float acc = 0.f;
+        for (int k = 0; k < rows; k++) acc += grad_out[(size_t)order[s + k] * c + ch];
+        partial[(size_t)s * c + ch] = acc;
     }
-    partial[i] = acc;
 }
 
-__global__ void bev_gather_bwd_segment_kernel(const float* __restrict__ partial, const int* __restrict__ sorted_lin,
-                                              const int* __restrict__ seg_rank, long n_rows, int c, float* __restrict__ grad_grid) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_rows * c) return;
-    const long s = i / c;
-    const int ch = (int)(i - s * c);
+__global__ __launch_bounds__(256) void bev_gather_bwd_segment_kernel(const float* __restrict__ partial, const int* __restrict__ sorted_lin,
+                                                                     const int* __restrict__ seg_rank, long n_rows, int c,
+                                                                     float* __restrict__ grad_grid) {
+    const long s = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    const int lane = threadIdx.x & 31;
+    if (s >= n_rows) return;
     const int cell = sorted_lin[s];
     if (cell < 0 || seg_rank[s] != 0) return;
-    float acc = 0.f;
-    for (long j = s; j < n_rows && sorted_lin[j] == cell; j += kChunk) acc += partial[(size_t)j * c + ch];
-    grad_grid[(size_t)cell * c + ch] = acc;
+    for (int ch = lane; ch < c; ch += 32) {
+        float acc = 0.f;
+        for (long j = s; j < n_rows && sorted_lin[j] == cell; j += kChunk) acc += partial[(size_t)j * c + ch];
+        grad_grid[(size_t)cell * c + ch] = acc;
+    }
 }
 
 inline int check_launch() { return hipGetLastError() == hipSuccess ? LISO_OK : LISO_ELAUNCH; }
@@ -81,8 +82,7 @@ int liso_bev_gather_bwd_f32(const float* grad_out, const int* sorted_lin, const 
     if (n_rows < 0 || c < 1) return LISO_EINVAL;
     if (n_rows == 0) return LISO_OK;
     if (!grad_out || !sorted_lin || !order || !seg_rank || !partial || !grad_grid) return LISO_EINVAL;
-    const long total = n_rows * c;
-    const unsigned blocks = (unsigned)((total + 255) / 256);
+    const unsigned blocks = (unsigned)((n_rows * 32 + 255) / 256);
     hipStream_t st = (hipStream_t)stream;
     bev_gather_bwd_chunk_kernel<<<blocks, 256, 0, st>>>(grad_out, sorted_lin, order, seg_rank, n_rows, c, partial);
     bev_gather_bwd_segment_kernel<<<blocks, 256, 0, st>>>(partial, sorted_lin, seg_rank, n_rows, c, grad_grid);
