@@ -66,8 +66,21 @@ class RAFT(nn.Module):
         aux["fw_bw_batched"] = both  # per iteration [2B,H,W,8]: samples [:B] = forward flow, [B:] = backward flow
         return [p[:B] for p in both], [p[B:] for p in both], aux
 
-    def predict_single_flow_map_and_classes(self, img_t0, fmap_t0, fmap_t1, decoder):
-        """reference :124-259"""
+    @torch.no_grad()
+    def infer_forward_direction(self, pcl_t0, pcl_t1):
+        """Inference for consumers of the t0 -> t1 flow only (the box miner): one direction, last iteration.
+        -> ([B,H,W,8(+1)] network output, aux)"""
+        img_t0, occ_t0 = self.pp_layer(pcl_t0)
+        img_t1, occ_t1 = self.pp_layer(pcl_t1)
+        aux = {"t0": {"bev_net_input_dbg": occ_t0}, "t1": {"bev_net_input_dbg": occ_t1}}
+        B = img_t0.shape[0]
+        fmap = self.fnet(torch.cat([img_t0, img_t1], dim=0))
+        out = self.predict_single_flow_map_and_classes(img_t0, fmap[:B], fmap[B:], self.head_decoder_fw, only_last=True)
+        return out[-1], aux
+
+    def predict_single_flow_map_and_classes(self, img_t0, fmap_t0, fmap_t1, decoder, only_last=False):
+        """reference :124-259.  `only_last` (extension, inference): upsample / assemble the network output of the last
+        iteration only -- the intermediate ones exist for the training loss."""
         m = self.slim_cfg.model
         assert img_t0.shape[1] == m.point_pillars.nbr_point_feats, img_t0.shape
         ds = m.feature_downsampling_factor
@@ -86,7 +99,7 @@ class RAFT(nn.Module):
         # [1,2,1,1] tensor (:171-176) without a host->device copy per call
         adapter = float(self.bev_rows_res_meters_per_fs_pixel)
         preds = []
-        for _ in range(m.num_iters):
+        for it in range(m.num_iters):
             coords1 = coords1.detach()
             if not vanilla:
                 logits = logits.detach()
@@ -100,6 +113,8 @@ class RAFT(nn.Module):
                 logits = logits + d_logits
             if use_w:
                 wl = wl + d_w
+            if only_last and it + 1 < m.num_iters:
+                continue
             up_flow = change_flow_convention_from_raft2usfl(upflow_n(coords1 - coords0, n=ds), resolution_adapter=adapter)
             if vanilla:
                 up_logits = torch.zeros((b, 4, h * ds, w * ds), dtype=torch.float32, device=img_t0.device)

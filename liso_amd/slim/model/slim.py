@@ -48,6 +48,23 @@ class SLIM(nn.Module):
                                                                    num_moving=621013971, num_still=num_still)
         self.raft_network = RAFT(cfg=cfg, head_decoder_fw=self.head_decoder_fw, head_decoder_bw=self.head_decoder_bw)
 
+    @torch.no_grad()
+    def infer_point_flow_t0_t1(self, sample_data_t0, sample_data_t1):
+        """Per-point flow t0 -> t1 of the sweep at t0 (`aggregated_flow` of the last RAFT iteration, [B,N,3]): what
+        FlowClusterDetector consumes.  One flow direction, one decode -- the training forward produces 12."""
+        dev = next(self.raft_network.parameters()).device
+        net_out, aux = self.raft_network.infer_forward_direction(
+            get_network_input_pcls(self.cfg, sample_data_t0, "ta", to_device=dev),
+            get_network_input_pcls(self.cfg, sample_data_t1, "ta", to_device=dev))
+        pa = sample_data_t0["pcl_ta"]
+        pred = self.head_decoder_fw(
+            net_out, self.moving_dynamicness_threshold.value(), pc=pa["pcl"].to(dev),
+            pointwise_voxel_coordinates=pa["pillar_coors"].to(dev), pointwise_valid_mask=pa["pcl_is_valid"].to(dev),
+            filled_pillar_mask=torch.squeeze(aux["t0"]["bev_net_input_dbg"] > 0.5, dim=1),
+            odom=sample_data_t0["gt"]["odom_ta_tb"].to(dev), inv_odom=sample_data_t1["gt"]["odom_ta_tb"].to(dev), summaries=None,
+            dynamic_flow_is_non_rigid_flow=self.slim_cfg.model.dynamic_flow_is_non_rigid_flow)
+        return pred.aggregated_flow
+
     def forward(self, sample_data_t0, sample_data_t1, summaries=None):
         dev = next(self.raft_network.parameters()).device
         out_fw, out_bw, aux = self.raft_network(get_network_input_pcls(self.cfg, sample_data_t0, "ta", to_device=dev),

@@ -303,8 +303,7 @@ class LisoLoopTrainer:
         """-> (Shape [B,K] after NMS, padded with zeros; point flow [B,N,3])"""
         from liso_amd.utils.nms_iou import perform_nms_on_shapes
 
-        preds_fw, _ = self.slim(sample_t0, sample_t1, None)
-        flow = preds_fw[-1].aggregated_flow
+        flow = self.slim.infer_point_flow_t0_t1(sample_t0, sample_t1)  # one direction, last RAFT iteration
         sample = dict(sample_t0)
         sample[self.cfg.data.flow_source] = {**sample_t0.get(self.cfg.data.flow_source, {}), "flow_ta_tb": flow}
         boxes = self.cluster_detector(sample, global_step=1)

@@ -32,3 +32,22 @@ def test_liso_loop_runs_and_trains_on_mined_boxes():
     assert changed > 0.0  # the detector stepped
     # the SLIM network is frozen in this loop
     assert all(p.grad is None for p in tr.slim.parameters())
+
+
+def test_inference_flow_equals_the_training_forward():
+    """SLIM.infer_point_flow_t0_t1 (one direction, last iteration only) returns the same per-point flow as the full
+    forward's preds_fw[-1].aggregated_flow"""
+    from liso_amd.datasets.synthetic import slim_pair
+    from liso_amd.slim.model.slim import SLIM
+    from liso_amd.utils.config import default_cfg
+
+    dev = torch.device("cuda")
+    torch.manual_seed(1)
+    net = SLIM(default_cfg(grid=256, bev_range_m=50.0), 100).to(dev).eval()
+    s0, s1 = slim_pair(11, dev, n_points=30000, grid=256, bev_range_m=50.0)
+    with torch.no_grad():
+        full, _ = net(s0, s1, None)
+        fast = net.infer_point_flow_t0_t1(s0, s1)
+    a, b = full[-1].aggregated_flow, fast
+    assert a.shape == b.shape == (1, 30000, 3)
+    assert float((a - b).abs().max()) <= 1e-4 * max(float(a.abs().max()), 1e-6)
