@@ -301,15 +301,15 @@ class LisoLoopTrainer:
     @torch.no_grad()
     def mine_boxes(self, sample_t0, sample_t1):
         """-> (Shape [B,K] after NMS, padded with zeros; point flow [B,N,3])"""
-        from liso_amd.utils.nms_iou import perform_nms_on_shapes
+        from liso_amd.utils.nms_iou import perform_nms_on_shapes_padded
 
         flow = self.slim.infer_point_flow_t0_t1(sample_t0, sample_t1)  # one direction, last RAFT iteration
         sample = dict(sample_t0)
         sample[self.cfg.data.flow_source] = {**sample_t0.get(self.cfg.data.flow_source, {}), "flow_ta_tb": flow}
         boxes = self.cluster_detector(sample, global_step=1)
         if boxes.shape[1] > 0:
-            boxes = perform_nms_on_shapes(boxes, max_num_boxes=self.post_nms, overlap_threshold=self.nms_iou,
-                                          pre_nms_max_num_boxes=self.pre_nms)
+            boxes = perform_nms_on_shapes_padded(boxes, max_num_boxes=self.post_nms, overlap_threshold=self.nms_iou,
+                                                 pre_nms_max_num_boxes=self.pre_nms)
             boxes.set_padding_val_to(0.0)
         return boxes, flow
 

@@ -120,3 +120,41 @@ def rotate_nms_pcdet(boxes, scores, thresh, pre_maxsize=None, post_max_size=None
     if post_max_size is not None:
         selected = selected[:post_max_size]
     return selected
+
+
+@torch.no_grad()
+def perform_nms_on_shapes_padded(boxes: Shape, max_num_boxes: int, overlap_threshold: float, pre_nms_max_num_boxes=-1):
+    """`perform_nms_on_shapes` (reference :23-66) without leaving the device: the same survivors -- per sample: boxes by
+    descending confidence (stable), at most `pre_nms_max_num_boxes` into rotated NMS, the first `max_num_boxes` survivors
+    kept -- returned in that order inside a padded Shape [B,K] whose `valid` flags mark them (the reference compacts each
+    sample on the host: 4+ device->host syncs per sample).  Invalid input slots never suppress anything."""
+    B, K = boxes.valid.shape
+    if K == 0:
+        return boxes
+    dev = boxes.pos.device
+    score = torch.where(boxes.valid, boxes.probs[..., 0].float(), torch.full_like(boxes.probs[..., 0].float(), -float("inf")))
+    order = torch.argsort(score, dim=1, descending=True, stable=True)
+
+    def take(t):
+        return torch.gather(t, 1, order.reshape(B, K, *([1] * (t.dim() - 2))).expand(-1, -1, *t.shape[2:]))
+
+    sorted_boxes = Shape(**{k: (take(v) if v is not None else None) for k, v in boxes.__dict__.items()})
+    valid = sorted_boxes.valid
+    pos = torch.arange(K, device=dev)
+    if pre_nms_max_num_boxes > 0:
+        valid = valid & (pos[None, :] < pre_nms_max_num_boxes)
+    dense = convert_shapes_to_dense_3d(Shape(**{**sorted_boxes.__dict__, "valid": valid})).float()
+    # invalid slots: far away, tiny, disjoint -> they overlap nothing
+    far = torch.stack([1e6 + 10.0 * pos.float(), torch.full((K,), 1e6, device=dev), torch.zeros(K, device=dev),
+                       torch.full((K,), 1e-3, device=dev), torch.full((K,), 1e-3, device=dev), torch.full((K,), 1e-3, device=dev),
+                       torch.zeros(K, device=dev)], dim=-1)
+    dense = torch.where(valid[..., None], dense, far[None])
+    hits = torch.zeros((B, K), dtype=torch.int32, device=dev)
+    for b in range(B):
+        keep_dev, num_dev = iou3d_nms_cuda.nms_gpu_device(dense[b].contiguous(), overlap_threshold)
+        is_kept = (pos < num_dev.to(torch.int64)).to(torch.int32)  # the first num entries of keep_dev are the survivors
+        hits[b].scatter_add_(0, keep_dev.clamp(0, K - 1), is_kept)   # (entries beyond num are unspecified: they add 0)
+    kept = (hits > 0) & valid
+    rank = torch.cumsum(kept.to(torch.int32), dim=1)
+    sorted_boxes.valid = kept & (rank <= max_num_boxes)
+    return sorted_boxes

@@ -51,3 +51,28 @@ def test_inference_flow_equals_the_training_forward():
     a, b = full[-1].aggregated_flow, fast
     assert a.shape == b.shape == (1, 30000, 3)
     assert float((a - b).abs().max()) <= 1e-4 * max(float(a.abs().max()), 1e-6)
+
+
+def test_padded_device_nms_keeps_the_same_boxes_as_the_reference_schedule():
+    """perform_nms_on_shapes_padded (no host round trips) vs perform_nms_on_shapes (nms_iou.py:23-66): same survivors per
+    sample, in the same order"""
+    from liso_amd.kabsch.shape_utils import Shape
+    from liso_amd.utils.nms_iou import perform_nms_on_shapes, perform_nms_on_shapes_padded
+
+    g = torch.Generator().manual_seed(0)
+    B, K = 3, 300
+    pos = torch.cat([torch.rand(B, K, 2, generator=g) * 40 - 20, torch.zeros(B, K, 1)], -1)
+    dims = torch.stack([torch.rand(B, K, generator=g) * 3 + 2, torch.rand(B, K, generator=g) + 1.5, torch.full((B, K), 1.5)], -1)
+    rot = (torch.rand(B, K, 1, generator=g) * 2 - 1) * 3.14159
+    probs = torch.rand(B, K, 1, generator=g)
+    valid = torch.rand(B, K, generator=g) > 0.2
+    valid[2] = False  # a sample without boxes
+    boxes = Shape(pos=pos.cuda(), dims=dims.cuda(), rot=rot.cuda(), probs=probs.cuda(), valid=valid.cuda())
+    ref = perform_nms_on_shapes(boxes.clone(), max_num_boxes=40, overlap_threshold=0.1, pre_nms_max_num_boxes=200)
+    got = perform_nms_on_shapes_padded(boxes.clone(), max_num_boxes=40, overlap_threshold=0.1, pre_nms_max_num_boxes=200)
+    assert got.valid.shape == (B, K)
+    for b in range(B):
+        r, o = ref[b].drop_padding_boxes(), got[b].drop_padding_boxes()
+        assert r.shape == o.shape, (b, r.shape, o.shape)
+        assert torch.equal(r.pos, o.pos) and torch.equal(r.probs, o.probs) and torch.equal(r.rot, o.rot)
+    assert int(got.valid[2].sum()) == 0 and int(got.valid[0].sum()) > 5
