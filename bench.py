@@ -78,15 +78,16 @@ def pfn_algorithmic_bytes(batch, n_points, grid, out_bytes):
     return batch * (n_points * 4 * 4 + 64 * grid * grid * out_bytes + grid * grid * 4)
 
 
-def slim_algorithmic_bytes(batch, n_points, grid, levels=4, radius=3):
+def slim_algorithmic_bytes(batch, n_points, grid, levels=4, radius=3, directions=2):
     """SURVEY.md 8(d), SLIM rows, per launch:
     corr lookup (fwd, and its adjoint bwd), per sample: levels * hw * (2r+1)^2 bilinear reads of 4 taps * 4 B + the
       [hw, levels*(2r+1)^2] fp32 output, hw = (G/8)^2;
     1-NN query: (N_q + N_ref) * 12 B in + N_q * 8 B out."""
     hw = (grid // 8) ** 2
     w2 = (2 * radius + 1) ** 2
-    # the forward and the backward flow direction of every pair share one launch: 2 * batch samples per lookup
-    lookup = 2 * batch * (levels * hw * w2 * 4 * 4 + hw * levels * w2 * 4)
+    # training: the forward and the backward flow direction of every pair share one launch (2 * batch samples per lookup);
+    # the box miner of the loop workload runs the forward direction only
+    lookup = directions * batch * (levels * hw * w2 * 4 * 4 + hw * levels * w2 * 4)
     return {"corr_lookup_fwd": lookup, "corr_lookup_bwd": lookup, "knn_query": 2 * n_points * 12 + n_points * 8}
 
 
@@ -248,7 +249,7 @@ def main():
         event_steps = n_event_steps if graphed else args.steps
         if args.workload == "loop":
             key = max(durs, key=lambda k: sum(durs[k]))
-            alg_all = dict(slim_algorithmic_bytes(1, N_POINTS, GRID))
+            alg_all = dict(slim_algorithmic_bytes(1, N_POINTS, GRID, directions=1))
             alg_all["pfn_forward_scatter"] = pfn_algorithmic_bytes(1, N_POINTS, GRID, 4)
             alg = LOOP_KERNELS[key][1] or alg_all[key]
             kname = LOOP_KERNELS[key][0]
