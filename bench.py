@@ -110,6 +110,26 @@ LOOP_KERNELS = {  # name -> (description, algorithmic bytes per launch at B=1, N
 }
 
 
+def pmc_traffic(workload, patterns):
+    """HBM bytes per launch of the roofline kernel(s) from the committed rocprofv3 PMC passes of this bench command
+    (profiles/r01_<workload>_pmc_{FETCH,WRITE}_SIZE.csv; counters cannot be collected from inside the timed process).
+    MI355X_MICROARCH.md: both counters are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of wide streaming
+    reads, so reads are doubled (an upper bracket for the narrow / scattered reads of these kernels)."""
+    import csv
+
+    total = 0.0
+    for pat in patterns:
+        for kind, factor in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
+            path = os.path.join(ROOT, "profiles", f"r01_{workload}_pmc_{kind}.csv")
+            if not os.path.exists(path):
+                return None
+            vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path)) if pat in r["Kernel_Name"]]
+            if not vals:
+                return None
+            total += factor * 1024.0 * sum(vals) / len(vals)
+    return total
+
+
 def cpu_baseline_detector(trainer, pcls, targets):
     """The oracle port of the same train step (fwd+bwd) on the host cores, ONE frame (bounded sample)."""
     from oracle.train_step import timed_detector_step
@@ -271,6 +291,10 @@ def main():
                      "scatter; the two launches are timed together")
             workload = ("CenterPoint-pillar detector train step (BASELINE configs[2]): 120k-pt KITTI-shaped clouds, "
                         "512x512 BEV pillars, fwd+bwd+AdamW")
+        pmc_patterns = {"slim": {"knn_query": ["knn_query_kernel"], "corr_lookup_fwd": ["corr_lookup_fwd_kernel"]}.get(key),
+                        "detector": ["pfn_decorate_kernel", "pfn_forward_kernel"],
+                        "loop": {"corr_lookup_fwd": ["corr_lookup_fwd_kernel"]}.get(key)}[args.workload]
+        traffic = pmc_traffic(args.workload, pmc_patterns) if pmc_patterns else None
         avg_ms = sum(durs[key]) / max(len(durs[key]), 1)
         if args.workload == "detector":  # the pillar pass is two launches (decorate, forward): time them as one unit
             avg_ms += sum(durs["pfn_decorate"]) / max(len(durs["pfn_decorate"]), 1)
@@ -295,7 +319,10 @@ def main():
                                                    "MIOpen defaults" if args.no_miopen_db else "seeded user database liso_amd/miopen_db")},
             "final_loss": float(loss),
             "roofline": {"kernel": kname, "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": None, "avg_launch_ms": avg_ms,
+                         "frac": achieved / 8000.0, "traffic": traffic,
+                         "traffic_source": None if traffic is None else f"profiles/r01_{args.workload}_pmc_*.csv (separate rocprofv3 --pmc "
+                                                                        "passes of this command; 2 x FETCH_SIZE + WRITE_SIZE, KiB)",
+                         "avg_launch_ms": avg_ms,
                          "launches_per_step": len(durs[key]) / max(event_steps, 1), "algorithmic_bytes_per_launch": alg,
                          "timed_in": timed_in,
                          "timed_kernels_ms_per_step": {k: sum(v) / max(event_steps, 1) for k, v in durs.items()}},
