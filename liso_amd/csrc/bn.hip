@@ -332,8 +332,8 @@ inline bool geom(int c, int v, long m, Geom* g, int* nblk) {
     if (cg > kThreads || (kThreads % cg) != 0) return false;
     g->cg = cg;
     g->rl = kThreads / cg;
-    // ~512 blocks (2 per CU) keeps the single-block finalize short; never fewer than kRowsPerBlock rows per block
-    long rpb = (m + 511) / 512;
+    // ~256 blocks (1 per CU) keeps the single-block finalize short; never fewer than kRowsPerBlock rows per block
+    long rpb = (m + 255) / 256;
     if (rpb < kRowsPerBlock) rpb = kRowsPerBlock;
     long nb = (m + rpb - 1) / rpb;
     if (nb > kMaxBlocks) { rpb = (m + kMaxBlocks - 1) / kMaxBlocks; nb = (m + rpb - 1) / rpb; }
