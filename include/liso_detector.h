@@ -55,6 +55,24 @@ int liso_centerloss_bwd_f32(const liso_centerloss_cfg* cfg, const float* pos, co
                             const float* rot_weights, const float* pillar_centers, const double* sums,
                             const float* grad_total, float* g_pos, float* g_dims, float* g_rot, float* g_probs, void* stream);
 
+/* ---- CenterPoint target maps from boxes ---------------------------------------------------------
+ * draw_heat_regression_maps (liso/datasets/torch_dataset_commons.py:190-339) with the gaussians of
+ * batched_render_gaussian_kabsch_mask (liso/kabsch/kabsch_mask.py:56-116): per box a rotated gaussian with variances
+ * 0.15 * (length, width), normalised by its own maximum over the grid (clamped at 1e-5); per cell the hottest box wins
+ * (ties add up) where its heat exceeds 0.01.  The reference renders this per sample in DataLoader workers with numpy
+ * (a [K,H,W] tensor per sample); here one launch finds the per-box maxima and one renders every cell.
+ *   box_pos [B,K,3], box_dims [B,K,3], box_rot [B,K] float32, box_valid uint8 [B,K] (padding slots: 0)
+ *   -> probs [B,H,W,1], dims [B,H,W,3], pos [B,H,W,3], rot [B,H,W,2] = (sin, cos), center_mask uint8 [B,H,W]
+ *   box_max: float32 [B,K] scratch. */
+typedef struct {
+    int batch, n_boxes, h, w;
+    float range_x, range_y; /* bev_range_m */
+} liso_targets_cfg;
+
+int liso_render_center_targets_f32(const liso_targets_cfg* cfg, const float* box_pos, const float* box_dims, const float* box_rot,
+                                   const uint8_t* box_valid, float* box_max, float* probs, float* dims, float* pos, float* rot,
+                                   uint8_t* center_mask, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -111,6 +111,7 @@ SIGNATURES = {
     "liso_centerloss_workspace_bytes": (_sz, [_vp]),
     "liso_centerloss_fwd_f32": (_i, [_vp] * 17 + [_sz, _vp]),
     "liso_centerloss_bwd_f32": (_i, [_vp] * 21),
+    "liso_render_center_targets_f32": (_i, [_vp] * 12),
     # include/liso_bn.h
     "liso_bn_workspace_bytes": (_sz, [_i]),
     "liso_bn_relu_fwd": (_i, [_vp, _i, ctypes.c_long, _i, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _vp, _vp, _vp, _sz, _vp]),
@@ -130,6 +131,11 @@ class CenterLossCfg(ctypes.Structure):
     """mirror of liso_centerloss_cfg (include/liso_detector.h)"""
     _fields_ = [("batch", _i), ("h", _i), ("w", _i), ("res_x", _f), ("res_y", _f), ("z_min", _f), ("z_max", _f),
                 ("sup_weight", _f), ("rot_reg_weight", _f)]
+
+
+class TargetsCfg(ctypes.Structure):
+    """mirror of liso_targets_cfg (include/liso_detector.h)"""
+    _fields_ = [("batch", _i), ("n_boxes", _i), ("h", _i), ("w", _i), ("range_x", _f), ("range_y", _f)]
 
 
 class DbscanCfg(ctypes.Structure):

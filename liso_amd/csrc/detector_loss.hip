@@ -191,6 +191,85 @@ __global__ __launch_bounds__(kThreads) void centerloss_bwd_kernel(liso_centerlos
     }
 }
 
+// ---- target rendering ----------------------------------------------------------------------------------------------------
+// cell centres: get_voxel_center_coords_m (liso/utils/bev_utils.py:24-40): ((i + 0.5) / H) * range - range / 2, in fp64 then fp32
+__device__ __forceinline__ float cell_center(int i, int n, float range) {
+    return (float)((((double)i + 0.5) / (double)n) * (double)range - 0.5 * (double)range);
+}
+
+__device__ __forceinline__ float box_heat(float cx, float cy, float bx, float by, float c, float s, float len, float wid) {
+    const float dx = cx - bx, dy = cy - by;
+    const float u = dx * c + dy * s, v = -dx * s + dy * c;
+    const float fac = u * u / (0.15f * len) + v * v / (0.15f * wid);  // kabsch_mask.py:93-102
+    return expf(-fac / 2.0f);
+}
+
+__global__ __launch_bounds__(256) void targets_box_max_kernel(liso_targets_cfg c, const float* __restrict__ box_pos,
+                                                              const float* __restrict__ box_dims, const float* __restrict__ box_rot,
+                                                              float* __restrict__ box_max) {
+    const int bk = blockIdx.x;  // one block per (sample, box)
+    const float bx = box_pos[3 * bk], by = box_pos[3 * bk + 1], len = box_dims[3 * bk], wid = box_dims[3 * bk + 1];
+    const float cs = cosf(box_rot[bk]), sn = sinf(box_rot[bk]);
+    float m = 0.f;
+    for (int i = threadIdx.x; i < c.h * c.w; i += 256) {
+        const int y = i / c.w, x = i - y * c.w;
+        m = fmaxf(m, box_heat(cell_center(y, c.h, c.range_x), cell_center(x, c.w, c.range_y), bx, by, cs, sn, len, wid));
+    }
+    __shared__ float red[4];
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) box_max[bk] = fmaxf(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), 1e-5f);  // :111-115
+}
+
+__global__ __launch_bounds__(256) void targets_render_kernel(liso_targets_cfg c, const float* __restrict__ box_pos,
+                                                             const float* __restrict__ box_dims, const float* __restrict__ box_rot,
+                                                             const uint8_t* __restrict__ box_valid, const float* __restrict__ box_max,
+                                                             float* __restrict__ probs, float* __restrict__ dims,
+                                                             float* __restrict__ pos, float* __restrict__ rot,
+                                                             uint8_t* __restrict__ center_mask) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long n = (long)c.batch * c.h * c.w;
+    if (i >= n) return;
+    const int b = (int)(i / ((long)c.h * c.w));
+    const int rem = (int)(i - (long)b * c.h * c.w);
+    const int y = rem / c.w, x = rem - y * c.w;
+    const float cx = cell_center(y, c.h, c.range_x), cy = cell_center(x, c.w, c.range_y);
+    const float* P = box_pos + (size_t)b * c.n_boxes * 3;
+    const float* D = box_dims + (size_t)b * c.n_boxes * 3;
+    const float* R = box_rot + (size_t)b * c.n_boxes;
+    const uint8_t* V = box_valid + (size_t)b * c.n_boxes;
+    const float* M = box_max + (size_t)b * c.n_boxes;
+    float best = 0.f;
+    int center = 0;
+    for (int k = 0; k < c.n_boxes; k++) {
+        if (!V[k]) continue;
+        const float h = box_heat(cx, cy, P[3 * k], P[3 * k + 1], cosf(R[k]), sinf(R[k]), D[3 * k], D[3 * k + 1]) / M[k];
+        best = fmaxf(best, h);
+        // the cell that contains the box centre (create_occupancy_pcl_image of the centres, :309-314)
+        const int iy = (int)((P[3 * k] + 0.5f * c.range_x) * ((float)c.h / c.range_x));
+        const int ix = (int)((P[3 * k + 1] + 0.5f * c.range_y) * ((float)c.w / c.range_y));
+        center |= (iy == y && ix == x && P[3 * k] + 0.5f * c.range_x >= 0.f && P[3 * k + 1] + 0.5f * c.range_y >= 0.f);
+    }
+    float ad[3] = {0.f, 0.f, 0.f}, ap[3] = {0.f, 0.f, 0.f}, ar[2] = {0.f, 0.f};
+    if (best > 0.01f) {  // occupancy threshold, :212-215; the hottest box(es) of the cell give it their attributes
+        for (int k = 0; k < c.n_boxes; k++) {
+            if (!V[k]) continue;
+            const float h = box_heat(cx, cy, P[3 * k], P[3 * k + 1], cosf(R[k]), sinf(R[k]), D[3 * k], D[3 * k + 1]) / M[k];
+            if (h == best) {
+#pragma unroll
+                for (int j = 0; j < 3; j++) { ad[j] += D[3 * k + j]; ap[j] += P[3 * k + j]; }
+                ar[0] += sinf(R[k]); ar[1] += cosf(R[k]);
+            }
+        }
+    }
+    probs[i] = best;
+#pragma unroll
+    for (int j = 0; j < 3; j++) { dims[3 * i + j] = ad[j]; pos[3 * i + j] = ap[j]; }
+    rot[2 * i] = ar[0]; rot[2 * i + 1] = ar[1];
+    center_mask[i] = (uint8_t)center;
+}
+
 inline int check_launch() { return hipGetLastError() == hipSuccess ? LISO_OK : LISO_ELAUNCH; }
 inline int n_blocks(const liso_centerloss_cfg* c) {
     const long n = (long)c->batch * c->h * c->w;
@@ -243,6 +322,21 @@ int liso_centerloss_bwd_f32(const liso_centerloss_cfg* cfg, const float* pos, co
     centerloss_bwd_kernel<<<(unsigned)((n + kThreads - 1) / kThreads), kThreads, 0, (hipStream_t)stream>>>(
         *cfg, make_maps(pos, dims, rot, probs, strides), gt_probs, gt_dims, gt_pos, gt_rot, center_mask, ignore_mask, rot_weights,
         pillar_centers, sums, grad_total, g_pos, g_dims, g_rot, g_probs);
+    return check_launch();
+}
+
+int liso_render_center_targets_f32(const liso_targets_cfg* cfg, const float* box_pos, const float* box_dims, const float* box_rot,
+                                   const uint8_t* box_valid, float* box_max, float* probs, float* dims, float* pos, float* rot,
+                                   uint8_t* center_mask, void* stream) {
+    if (!cfg || cfg->batch < 1 || cfg->n_boxes < 0 || cfg->h < 1 || cfg->w < 1 || !probs || !dims || !pos || !rot || !center_mask)
+        return LISO_EINVAL;
+    if (cfg->n_boxes > 0 && (!box_pos || !box_dims || !box_rot || !box_valid || !box_max)) return LISO_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (cfg->n_boxes > 0)
+        targets_box_max_kernel<<<cfg->batch * cfg->n_boxes, 256, 0, st>>>(*cfg, box_pos, box_dims, box_rot, box_max);
+    const long n = (long)cfg->batch * cfg->h * cfg->w;
+    targets_render_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(*cfg, box_pos, box_dims, box_rot, box_valid, box_max, probs,
+                                                                      dims, pos, rot, center_mask);
     return check_launch();
 }
 

@@ -12,7 +12,41 @@ from liso_amd.utils.bev_utils import get_metric_voxel_center_coords
 
 def render_center_targets(boxes_pos, boxes_dims, boxes_rot, boxes_valid, grid_size, bev_range_m):
     """boxes_*: [B,K,3],[B,K,3],[B,K,1],[B,K] (padded) -> dict(probs[B,H,W,1], dims[..3], pos[..3], rot[..2],
-    center_bool_mask[B,H,W]) with rot = (sin, cos) (torch_dataset_commons.py:225-228)."""
+    center_bool_mask[B,H,W]) with rot = (sin, cos) (torch_dataset_commons.py:225-228).
+    Device tensors go through the two-launch gfx950 kernel of include/liso_detector.h; host tensors (and the reference
+    fixture test) through the torch formulation below, which materialises [B,K,H,W]."""
+    if boxes_pos.is_cuda:
+        return _render_center_targets_hip(boxes_pos, boxes_dims, boxes_rot, boxes_valid, grid_size, bev_range_m)
+    return render_center_targets_torch(boxes_pos, boxes_dims, boxes_rot, boxes_valid, grid_size, bev_range_m)
+
+
+def _render_center_targets_hip(boxes_pos, boxes_dims, boxes_rot, boxes_valid, grid_size, bev_range_m):
+    import ctypes
+
+    from liso_amd import _lib as L
+
+    dev = boxes_pos.device
+    B, K = boxes_valid.shape
+    H, W = int(grid_size[0]), int(grid_size[1])
+    cfg = L.TargetsCfg(B, K, H, W, float(bev_range_m[0]), float(bev_range_m[1]))
+    pos, dims = boxes_pos.float().contiguous(), boxes_dims.float().contiguous()
+    rot, val = boxes_rot[..., 0].float().contiguous(), boxes_valid.to(torch.uint8).contiguous()
+    box_max = torch.empty((B, max(K, 1)), dtype=torch.float32, device=dev)
+    out = {"probs": torch.empty((B, H, W, 1), dtype=torch.float32, device=dev),
+           "dims": torch.empty((B, H, W, 3), dtype=torch.float32, device=dev),
+           "pos": torch.empty((B, H, W, 3), dtype=torch.float32, device=dev),
+           "rot": torch.empty((B, H, W, 2), dtype=torch.float32, device=dev)}
+    mask = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        L.check(L.TIMER.launch("render_center_targets", lambda: L.lib().liso_render_center_targets_f32(
+            ctypes.byref(cfg), L.ptr(pos), L.ptr(dims), L.ptr(rot), L.ptr(val), L.ptr(box_max), L.ptr(out["probs"]),
+            L.ptr(out["dims"]), L.ptr(out["pos"]), L.ptr(out["rot"]), L.ptr(mask), L.stream_ptr())), "render_center_targets")
+    out["center_bool_mask"] = mask.bool()
+    return out
+
+
+def render_center_targets_torch(boxes_pos, boxes_dims, boxes_rot, boxes_valid, grid_size, bev_range_m):
+    """the torch formulation (checked against the reference fixture in tests/test_targets.py)"""
     dev = boxes_pos.device
     B, K = boxes_valid.shape
     H, W = int(grid_size[0]), int(grid_size[1])
