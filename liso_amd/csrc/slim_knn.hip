@@ -120,7 +120,20 @@ struct Level {
     liso_knn_grid g;
     const int* start;
     const float4* bucketed;
+    const unsigned* occ;  // one bit per xy cell: does the cell hold any point (any z bin)?
 };
+
+// after the scan the `count` array is dead: its first nx*ny/32 words become the occupancy bitmap (31 KB for a 500x500
+// grid: cache resident), so that a ring walk reads the 8-byte [start, end) pair only for the few cells that hold points
+__global__ void knn_occupancy_kernel(liso_knn_grid g, const int* __restrict__ start, unsigned* __restrict__ occ) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;  // xy cell; blockDim is a multiple of 64
+    const int n = g.nx * g.ny;
+    const bool full = c < n && start[(size_t)(c + 1) * g.nz] > start[(size_t)c * g.nz];
+    const unsigned long long m = __ballot(full);
+    const int lane = threadIdx.x & 63;
+    if (lane == 0 && c < n) occ[c >> 5] = (unsigned)m;
+    if (lane == 32 && c < n) occ[c >> 5] = (unsigned)(m >> 32);
+}
 
 // ring search on one grid level; (best, best_i) carry over between levels (a candidate found on the fine level is a real
 // point, so it only tightens the coarse search).  Returns true when the answer is proven exact.
@@ -151,9 +164,11 @@ __device__ __forceinline__ bool ring_search(const Level& L, float qx, float qy, 
                     y = side == 0 ? y0 : (side == 1 ? y0 + k : (side == 2 ? y1 : y1 - k));
                 }
                 if (x >= 0 && x < g.nx && y >= 0 && y < g.ny) {
-                    const int c = (x * g.ny + y) * g.nz;
-                    s = L.start[c + zlo];
-                    e = L.start[c + zhi + 1];
+                    const int cxy = x * g.ny + y;
+                    if ((L.occ[cxy >> 5] >> (cxy & 31)) & 1u) {
+                        s = L.start[cxy * g.nz + zlo];
+                        e = L.start[cxy * g.nz + zhi + 1];
+                    }
                 }
             }
             unsigned nonempty = (unsigned)(__ballot(e > s) >> group_shift) & 0xffffu;
@@ -246,6 +261,7 @@ int liso_knn_build_f32(const liso_knn_grid* grid, const float* ref, int ref_stri
     knn_scan_tot_kernel<<<1, 1024, 0, st>>>(block_tot, nsb);
     knn_scan_add_kernel<<<nsb, 1024, 0, st>>>(start, cells, block_tot, nsb);
     if (n_ref > 0) knn_fill_kernel<<<(n_ref + 255) / 256, 256, 0, st>>>(ref, ref_stride, n_ref, cell_of_pt, start, cursor, bucketed);
+    knn_occupancy_kernel<<<(grid->nx * grid->ny + 255) / 256, 256, 0, st>>>(*grid, start, (unsigned*)count);
     return check_launch();
 }
 
@@ -254,6 +270,7 @@ static Level make_level(const liso_knn_grid* grid, const void* workspace, int n_
     l.g = *grid;
     const int cells = n_keys(grid);
     l.start = (const int*)workspace + 2 * (size_t)cells;
+    l.occ = (const unsigned*)workspace;
     l.bucketed = (const float4*)((const char*)workspace + align16((3 * (size_t)cells + 1 + kTotSlots + (size_t)n_ref) * sizeof(int)));
     return l;
 }
