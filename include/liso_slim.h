@@ -81,6 +81,27 @@ int liso_knn_query_f32(const liso_knn_grid* grid, const void* workspace, const l
                        const void* coarse_workspace, int n_ref, const float* query, int query_stride, int n_query,
                        int64_t* index, float* dist_sqr, int fine_max_rings, void* stream);
 
+/* ---- nearest-point flow loss ---------------------------------------------------------------------------------------
+ * compute_flow_loss_a_to_b + NearestPointLoss + huber_delta (liso/slim/slim_loss/knn_wrapper.py:11-49,58-135,155-217) after
+ * the 1-NN indices are known: q = cloud_a + flow, nn = cloud_b[b, index], d2 = |nn - q|^2, field-of-view weight from the
+ * BEV extent, loss = huber(d2) * weight.  ~30 torch launches forward and ~40 backward per call become one each.
+ *   cloud_a, flow float32 [B,n,3] (padding rows NaN -> loss/d2 NaN, gradient 0); cloud_b float32 [B,n_b,3];
+ *   index int64 [B,n]; loss, dist_sqr float32 [B,n].
+ * Backward: grad_loss [B,n] (and optionally grad_dist_sqr [B,n], may be NULL) -> grad_flow [B,n,3] (== grad cloud_a). */
+typedef struct {
+    int batch;
+    long n, n_b;
+    float ext[4];   /* bev extent x_min, y_min, x_max, y_max */
+    int fov_mode;   /* 0 none, 1 ignore_out_fov, 2 mask_close_fov  ("use_nearest" is not covered: torch path) */
+    float delta;    /* L1_delta of huber_delta(mode "large_grad_1"); 0 = plain (gradient-safe) norm */
+} liso_nploss_cfg;
+
+int liso_nearest_point_loss_fwd_f32(const liso_nploss_cfg* cfg, const float* cloud_a, const float* flow, const float* cloud_b,
+                                    const int64_t* index, float* loss, float* dist_sqr, void* stream);
+int liso_nearest_point_loss_bwd_f32(const liso_nploss_cfg* cfg, const float* cloud_a, const float* flow, const float* cloud_b,
+                                    const int64_t* index, const float* grad_loss, const float* grad_dist_sqr, float* grad_flow,
+                                    void* stream);
+
 /* ---- BEV grid -> per-point gather (decoder) and its adjoint ---------------------------------------------------------
  * Replaces batched_grid_data_to_pointwise_data (liso/slim/slim_loss/static_aggregation.py:8-31; used by
  * head_decoder.py:300-408 to pull 26 channels per point out of the decoded BEV maps).  PyTorch's advanced-index backward

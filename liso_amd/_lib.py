@@ -105,6 +105,8 @@ SIGNATURES = {
     # include/liso_slim.h
     "liso_corr_lookup_fwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "liso_corr_lookup_bwd_dvol_f32": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "liso_nearest_point_loss_fwd_f32": (_i, [_vp] * 8),
+    "liso_nearest_point_loss_bwd_f32": (_i, [_vp] * 9),
     "liso_bev_gather_fwd_f32": (_i, [_vp, _vp, ctypes.c_long, _i, ctypes.c_float, _vp, _vp]),
     "liso_bev_gather_bwd_f32": (_i, [_vp, _vp, _vp, _vp, ctypes.c_long, _i, _vp, _vp, _vp]),
     # include/liso_detector.h
@@ -131,6 +133,11 @@ class CenterLossCfg(ctypes.Structure):
     """mirror of liso_centerloss_cfg (include/liso_detector.h)"""
     _fields_ = [("batch", _i), ("h", _i), ("w", _i), ("res_x", _f), ("res_y", _f), ("z_min", _f), ("z_max", _f),
                 ("sup_weight", _f), ("rot_reg_weight", _f)]
+
+
+class NpLossCfg(ctypes.Structure):
+    """mirror of liso_nploss_cfg (include/liso_slim.h)"""
+    _fields_ = [("batch", _i), ("n", ctypes.c_long), ("n_b", ctypes.c_long), ("ext", _f * 4), ("fov_mode", _i), ("delta", _f)]
 
 
 class TargetsCfg(ctypes.Structure):

@@ -1,7 +1,10 @@
 """Nearest-point flow loss.  Mirror of liso/slim/slim_loss/knn_wrapper.py:11-217 (same functions and semantics)."""
+import ctypes
 import functools as ft
 
 import torch
+
+from liso_amd import _lib as L
 
 from liso_amd.slim.slim_loss.knn_graph import KnnIndex, knn_graph
 from liso_amd.utils.config import AttrDict as Munch
@@ -27,13 +30,46 @@ def squared_sum(delta, dim: int = -1):
     return delta.square().sum(dim=dim)
 
 
+class _NearestPointLossFused(torch.autograd.Function):
+    """gather + squared distance + field-of-view weight + huber norm in one launch (include/liso_slim.h)"""
+
+    @staticmethod
+    def forward(ctx, cloud_a, flow, cloud_b, idx, cfg):
+        a, f, b = cloud_a.float().contiguous(), flow.float().contiguous(), cloud_b.float().contiguous()
+        i = idx.reshape(idx.shape[0], idx.shape[1]).contiguous()
+        loss = torch.empty(a.shape[:2], dtype=torch.float32, device=a.device)
+        d2 = torch.empty_like(loss)
+        with torch.cuda.device(a.device):
+            L.check(L.TIMER.launch("nearest_point_loss_fwd", lambda: L.lib().liso_nearest_point_loss_fwd_f32(
+                ctypes.byref(cfg), L.ptr(a), L.ptr(f), L.ptr(b), L.ptr(i), L.ptr(loss), L.ptr(d2), L.stream_ptr())),
+                "nearest_point_loss_fwd")
+        ctx.save_for_backward(a, f, b, i)
+        ctx.cfg = cfg
+        return loss, d2
+
+    @staticmethod
+    def backward(ctx, g_loss, g_d2):
+        a, f, b, i = ctx.saved_tensors
+        gl = g_loss.float().contiguous()
+        gd = None if g_d2 is None else g_d2.float().contiguous()
+        gf = torch.empty_like(f)
+        with torch.cuda.device(a.device):
+            L.check(L.lib().liso_nearest_point_loss_bwd_f32(ctypes.byref(ctx.cfg), L.ptr(a), L.ptr(f), L.ptr(b), L.ptr(i), L.ptr(gl),
+                                                            L.ptr(gd) if gd is not None else None, L.ptr(gf), L.stream_ptr()),
+                    "nearest_point_loss_bwd")
+        return (gf if ctx.needs_input_grad[0] else None), gf, None, None, None
+
+
 class NearestPointLoss:
     """reference :58-135"""
+
+    FOV_MODES = {"none": 0, "ignore_out_fov": 1, "mask_close_fov": 2}
 
     def __init__(self, *args, bev_extent, L1_delta: float, drop_outliers__perc: float, fov_mode: str = "ignore_out_fov", **kwargs):
         assert 0.0 <= drop_outliers__perc < 100.0
         assert fov_mode in {"none", "ignore_out_fov", "use_nearest", "mask_close_fov"}
         self.bev_extent = bev_extent
+        self.L1_delta = L1_delta
         self.drop_outliers__perc = drop_outliers__perc
         self.huber_loss = ft.partial(huber_delta, delta=L1_delta, mode="large_grad_1")
         self.fov_mode = fov_mode
@@ -96,6 +132,13 @@ def compute_flow_loss_a_to_b(cloud_a, cloud_b, flow_a_to_b, loss_function, neare
                     idx[b] = res[j]
     else:
         idx = torch.stack([get_idx_dists_for_knn(cloud_b[b], cloud_b__a[b], 1) for b in range(bs)], dim=0)
+    if (cloud_a.is_cuda and isinstance(loss_function, NearestPointLoss) and loss_function.drop_outliers__perc == 0.0
+            and loss_function.fov_mode in NearestPointLoss.FOV_MODES):
+        e = [float(v) for v in loss_function.bev_extent]
+        cfg = L.NpLossCfg(bs, cloud_a.shape[1], cloud_b.shape[1], (ctypes.c_float * 4)(*e),
+                          NearestPointLoss.FOV_MODES[loss_function.fov_mode], float(loss_function.L1_delta))
+        loss, d2 = _NearestPointLossFused.apply(cloud_a, flow_a_to_b, cloud_b, idx, cfg)
+        return loss, Munch(nearest_dist_sqr=d2, nearest_dist=d2.sqrt())
     nearest = torch.gather(cloud_b, 1, idx.repeat(1, 1, 3))
     d2 = squared_sum(nearest - cloud_b__a, dim=-1)
     loss = loss_function(cloud_b__a=cloud_b__a, nearest_cloud_b__a=nearest, nearest_dist_sqr_b__a=d2)

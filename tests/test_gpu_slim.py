@@ -326,3 +326,39 @@ def test_batched_directions_and_iterations_equal_the_sequential_schedule():
         # library convolutions is 3e-6); batching the directions changes MIOpen's solver picks (B=2 instead of B=1
         # convolutions, fp32 Winograd): up to 2e-3 on a few convolution weights
         assert worst < 5e-3, (tag, worst)
+
+
+@pytest.mark.parametrize("fov_mode,delta", [("mask_close_fov", 0.0), ("ignore_out_fov", 0.0), ("none", 0.3), ("mask_close_fov", 0.1)])
+def test_fused_nearest_point_loss_equals_torch_ops(fov_mode, delta):
+    """include/liso_slim.h liso_nearest_point_loss_*: loss, distances and flow gradients against the torch-op formulation
+    of knn_wrapper.py:58-135,155-217 (NearestPointLoss + huber_delta), incl. NaN padding rows and out-of-FoV points"""
+    import liso_amd.slim.slim_loss.knn_wrapper as KW
+
+    g = torch.Generator().manual_seed(7)
+    B, N = 3, 20000
+    ext = np.array([-20.0, -20.0, 20.0, 20.0])
+    a = (torch.rand(B, N, 3, generator=g) * torch.tensor([44.0, 44.0, 3.0]) - torch.tensor([22.0, 22.0, 1.5])).cuda()
+    b = (torch.rand(B, N, 3, generator=g) * torch.tensor([40.0, 40.0, 3.0]) - torch.tensor([20.0, 20.0, 1.5])).cuda()
+    a[:, ::37] = float("nan")
+    flow = (torch.randn(B, N, 3, generator=g) * 0.3).cuda().requires_grad_(True)
+    lf = KW.NearestPointLoss(bev_extent=ext, L1_delta=delta, drop_outliers__perc=0.0, fov_mode=fov_mode)
+    idx = [KW.KnnIndex(b[i]) for i in range(B)]
+    loss, knn = KW.compute_flow_loss_a_to_b(a, b, flow, lf, knn_indices=idx)
+    w = torch.rand(B, N, generator=g).cuda()
+    valid = torch.isfinite(a).all(-1)
+    (gf,) = torch.autograd.grad((torch.where(valid, loss, 0.0) * w).sum() + 0.1 * torch.where(valid, knn.nearest_dist_sqr, 0.0).sum(), flow)
+    # torch-op path: same indices, reference formulation
+    flow2 = flow.detach().clone().requires_grad_(True)
+    q = a + flow2
+    with torch.no_grad():
+        ii = torch.stack([idx[i].query(q[i].detach()) for i in range(B)])[..., None]
+    nearest = torch.gather(b, 1, ii.repeat(1, 1, 3))
+    d2 = KW.squared_sum(nearest - q, dim=-1)
+    ref = lf(cloud_b__a=q, nearest_cloud_b__a=nearest, nearest_dist_sqr_b__a=d2)
+    (gr,) = torch.autograd.grad((torch.where(valid, ref, 0.0) * w).sum() + 0.1 * torch.where(valid, d2, 0.0).sum(), flow2)
+    assert torch.allclose(loss[valid], ref[valid], rtol=1e-5, atol=1e-6)
+    assert torch.allclose(knn.nearest_dist_sqr[valid], d2[valid], rtol=1e-5, atol=1e-6)
+    assert bool(torch.isnan(loss[~valid]).all())
+    # padding rows: the torch ops hand back 0 * NaN = NaN there (masked out upstream by the NaN-marking `where`,
+    # knn_loss.py:44-45); the kernel writes zeros
+    assert torch.allclose(gf[valid], gr[valid], rtol=1e-4, atol=1e-6) and bool(torch.isfinite(gf).all())
