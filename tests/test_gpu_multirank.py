@@ -1,6 +1,7 @@
 """Two ranks on ONE GPU (gloo carries the collectives, both processes compute on cuda:0): the data-parallel wiring of the
-hipGraph SLIM step -- parameter broadcast at start, flat gradient buffer all-reduced after every replay -- that the RCCL
-runs of bench.py use with one GPU per rank."""
+SLIM step that the RCCL runs of bench.py use with one GPU per rank -- the eager step under DistributedDataParallel
+(bench.py's default) and the hipGraph step (`--graph`: parameter broadcast at start, flat gradient buffer all-reduced after
+every replay)."""
 import os
 import socket
 
@@ -20,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, use_graph):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -31,8 +32,8 @@ def _worker(rank, world, port, out):
         dev = torch.device("cuda:0")
         cfg = apply_slim_simple_knn_training(default_cfg(grid=128, bev_range_m=40.0))
         torch.manual_seed(rank)  # different initial weights on purpose: the constructor must broadcast rank 0's
-        tr = SlimTrainer(cfg, dev, use_graph=True)
-        assert tr.model is tr.net  # no DDP wrapper in graph mode
+        tr = SlimTrainer(cfg, dev, use_graph=use_graph)
+        assert (tr.model is tr.net) == use_graph  # no DDP wrapper in graph mode
         s0, s1 = slim_pair(50 + rank, dev, n_points=8000, grid=128, bev_range_m=40.0)
         for g in tr.optimizer.param_groups:  # leave the lr = 0 start of the warm-up schedule
             g["lr"] = 1e-3
@@ -48,9 +49,10 @@ def _worker(rank, world, port, out):
 
 
 @pytest.mark.timeout(900)
-def test_two_ranks_hipgraph_slim_step_keeps_replicas_identical(tmp_path):
+@pytest.mark.parametrize("use_graph", [False, True], ids=["eager_ddp", "hipgraph"])
+def test_two_ranks_slim_step_keeps_replicas_identical(tmp_path, use_graph):
     out = str(tmp_path / "mr.pt")
-    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), out, use_graph), nprocs=2, join=True)
     r = torch.load(out)
     assert all(l == l for l in r["losses"])
     assert torch.equal(r["params"][0], r["params"][1])
