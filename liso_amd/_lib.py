@@ -121,6 +121,10 @@ SIGNATURES = {
     "liso_knn_workspace_bytes": (_sz, [_vp, _i]),
     "liso_knn_build_f32": (_i, [_vp, _vp, _i, _i, _vp, _sz, _vp]),
     "liso_knn_query_f32": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _i, _vp]),
+    # include/liso_tracking.h
+    "liso_points_in_boxes_workspace_bytes": (_sz, [_vp]),
+    "liso_points_in_boxes_f32": (_i, [_vp] * 9 + [_sz, _vp]),
+    "liso_match_greedy_f32": (_i, [_vp, ctypes.c_long, ctypes.c_long, _i, _i, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 
 
@@ -138,6 +142,11 @@ class CenterLossCfg(ctypes.Structure):
 class NpLossCfg(ctypes.Structure):
     """mirror of liso_nploss_cfg (include/liso_slim.h)"""
     _fields_ = [("batch", _i), ("n", ctypes.c_long), ("n_b", ctypes.c_long), ("ext", _f * 4), ("fov_mode", _i), ("delta", _f)]
+
+
+class BoxPtsCfg(ctypes.Structure):
+    """mirror of liso_boxpts_cfg (include/liso_tracking.h)"""
+    _fields_ = [("batch", _i), ("n", ctypes.c_long), ("k", _i), ("point_stride", _i), ("precision", _i), ("dims_bloat", _f)]
 
 
 class TargetsCfg(ctypes.Structure):

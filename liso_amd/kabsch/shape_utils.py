@@ -198,10 +198,18 @@ class Shape:
 
     @torch.no_grad()
     def get_points_in_box_bool_mask(self, pcl, box_dims_bloat_factor=1.0, return_points_in_box_coords=False):
-        """reference :488-538 -- [.., N, K] inside test in box coordinates (plain torch; the fused HIP version that
-        never materialises [N,K,4] is liso_amd.networks.flow_cluster_detector's z-fit kernel)."""
+        """reference :488-538 -- [.., N, K] inside test in box coordinates.  Device tensors go through
+        liso_points_in_boxes_f32 (include/liso_tracking.h), which never materialises [N,K,4]; host arrays (the reference's
+        data-loader use) and `return_points_in_box_coords` keep the reference's formulation."""
         assert pcl.shape[-1] == 3, pcl.shape
         assert len(self.shape) == len(pcl.shape) - 1, (self.shape, pcl.shape)
+        if _is_t(pcl) and pcl.is_cuda and not return_points_in_box_coords and self.dims.shape[-1] == 3 and self.pos.shape[-1] == 3:
+            from liso_amd.tracker.box_points import FP32_PRODUCT, dense_boxes, points_in_boxes
+            unb = len(self.shape) == 1
+            boxes7 = dense_boxes(self)
+            res = points_in_boxes(boxes7[None] if unb else boxes7, pcl[None] if unb else pcl, want_mask=True, want_count=False,
+                                  precision=FP32_PRODUCT, dims_bloat=box_dims_bloat_factor)
+            return res["mask"][0] if unb else res["mask"]
         sensor_T_box = self.get_poses()
         homog = homogenize_pcl(pcl[..., :3])
         dims = box_dims_bloat_factor * self.dims

@@ -1,0 +1,227 @@
+"""Mining / tracking / validation inner loops on the device (include/liso_tracking.h) against the reference fixture
+(tests/golden/tracking_reference.npz), the numpy oracle (oracle/tracking.py) and size-independent properties."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _shape(pos, dims, rot, probs=None):
+    from liso_amd.kabsch.shape_utils import Shape
+
+    t = lambda a: torch.as_tensor(a).float().cuda()  # noqa: E731
+    k = pos.shape[-2]
+    lead = tuple(pos.shape[:-1])
+    return Shape(pos=t(pos), dims=t(dims), rot=t(rot), probs=t(np.ones(lead + (1,)) if probs is None else probs),
+                 valid=torch.ones(lead, dtype=torch.bool, device="cuda")), k
+
+
+def _unpack(bits, n):
+    return np.unpackbits(bits, axis=0)[:n].astype(bool)
+
+
+def _scene(seed, K, N, R=100.0):
+    g = np.random.default_rng(seed)
+    pos = np.concatenate([g.uniform(-0.45 * R, 0.45 * R, (K, 2)), g.uniform(-1.2, -0.6, (K, 1))], -1).astype(np.float32)
+    dims = np.stack([g.uniform(3.0, 5.5, K), g.uniform(1.5, 2.4, K), g.uniform(1.4, 2.0, K)], -1).astype(np.float32)
+    rot = g.uniform(-np.pi, np.pi, (K, 1)).astype(np.float32)
+    near = pos[g.integers(0, max(K, 1), N // 2)] + g.normal(0.0, 1.2, (N // 2, 3)) if K else g.normal(0, 1, (N // 2, 3))
+    far = np.concatenate([g.uniform(-0.5 * R, 0.5 * R, (N - N // 2, 2)), g.uniform(-2.0, 1.0, (N - N // 2, 1))], -1)
+    pts = np.concatenate([near, far], 0).astype(np.float32)
+    g.shuffle(pts, axis=0)
+    flow = (g.normal(0.0, 0.5, (N, 3)) + np.array([1.0, -0.5, 0.0])).astype(np.float32)
+    valid = g.uniform(size=N) > 0.1
+    return pos, dims, rot, pts, flow, valid
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_point_masks_match_reference_fixture(golden_dir, tag):
+    from liso_amd.datasets.torch_dataset_commons import get_points_in_boxes_mask
+
+    g = np.load(f"{golden_dir}/tracking_reference.npz")
+    boxes, _ = _shape(g[f"{tag}_pos"], g[f"{tag}_dims"], g[f"{tag}_rot"])
+    pts = torch.from_numpy(g[f"{tag}_pts"]).cuda()
+    n = pts.shape[0]
+    homog = torch.cat([pts, torch.ones_like(pts[:, :1])], -1)
+    m64 = get_points_in_boxes_mask(boxes, homog).cpu().numpy()
+    assert m64.shape == (n, boxes.shape[0]) and m64.dtype == bool
+    assert np.array_equal(m64, _unpack(g[f"{tag}_mask64"], n))  # fp64 transform: bit exact
+    for key, bloat in (("mask32", 1.0), ("mask32_bloat", 1.25)):
+        m32 = boxes.get_points_in_box_bool_mask(pts, box_dims_bloat_factor=bloat).cpu().numpy()
+        # fp32 transform: the reference's product rounds in its BLAS's order; only a point within an ulp of a face can differ
+        assert (m32 != _unpack(g[f"{tag}_{key}"], n)).sum() <= 1
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_flow_propagation_matches_reference_fixture(golden_dir, tag):
+    from liso_amd.tracker.tracking import mean_flow_per_box, propagate_boxes_forward_using_flow
+
+    g = np.load(f"{golden_dir}/tracking_reference.npz")
+    boxes, _ = _shape(g[f"{tag}_pos"][None], g[f"{tag}_dims"][None], g[f"{tag}_rot"][None])
+    pts, flow = torch.from_numpy(g[f"{tag}_pts"]).cuda()[None], torch.from_numpy(g[f"{tag}_flow"]).cuda()[None]
+    valid = torch.from_numpy(g[f"{tag}_valid"]).cuda()[None]
+    odom = torch.from_numpy(g[f"{tag}_odom"]).cuda()
+    fg, od, bg, warped, st1 = propagate_boxes_forward_using_flow(boxes, pts, valid, flow, odom, "cuda")
+    tol = 5e-6  # metres; the reference sums fp32 products over the points, the kernel 2^-24 m fixed point
+    assert fg.dtype == torch.float64 and not warped.is_cuda
+    np.testing.assert_allclose(fg.cpu().numpy(), g[f"{tag}_fg"], atol=tol)
+    np.testing.assert_allclose(bg.cpu().numpy(), g[f"{tag}_bg"], atol=1e-12)
+    np.testing.assert_allclose(warped.numpy(), g[f"{tag}_warped"], atol=tol)
+    np.testing.assert_allclose(st1.cpu().numpy(), g[f"{tag}_st1"], atol=tol)
+    # the tracker's second call (-flow, inverse odometry) can reuse the means
+    mean, _ = mean_flow_per_box(boxes, pts, valid, flow)
+    a = propagate_boxes_forward_using_flow(boxes, pts, valid, -flow, torch.linalg.inv(odom), "cuda")
+    b = propagate_boxes_forward_using_flow(boxes, pts, valid, -flow, torch.linalg.inv(odom), "cuda", mean_flow=-mean)
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+
+
+@pytest.mark.parametrize("K,N,B", [(100, 120000, 1), (37, 5000, 3), (300, 20000, 2), (5, 1000, 1), (1000, 120000, 1)])
+def test_points_in_boxes_equals_oracle(K, N, B):
+    from liso_amd.tracker.box_points import FP32_PRODUCT, FP64_PRODUCT, points_in_boxes
+    from oracle import tracking as O
+
+    scenes = [_scene(11 * K + b, K, N) for b in range(B)]
+    boxes7 = torch.from_numpy(np.stack([np.concatenate([s[0], s[1], s[2]], -1) for s in scenes])).cuda()
+    pts = torch.from_numpy(np.stack([np.concatenate([s[3], np.full((N, 1), 0.5, np.float32)], -1) for s in scenes])).cuda()  # stride 4
+    flow = torch.from_numpy(np.stack([s[4] for s in scenes])).cuda()
+    valid = torch.from_numpy(np.stack([s[5] for s in scenes])).cuda()
+    r64 = points_in_boxes(boxes7, pts, want_mask=True, precision=FP64_PRODUCT)
+    r32 = points_in_boxes(boxes7, pts, point_valid=valid, flow=flow, want_mask=True, precision=FP32_PRODUCT)
+    assert torch.equal(r64["mask"].sum(1).int(), r64["count"]) and torch.equal(r32["mask"].sum(1).int(), r32["count"])
+    small = N * K <= 20000 * 300  # the oracle materialises [N,K,4] in fp64
+    for b, s in enumerate(scenes if small else scenes[:0]):
+        assert np.array_equal(r64["mask"][b].cpu().numpy(), O.points_in_boxes_mask(s[0], s[1], s[2], s[3]))
+        want = O.points_in_box_bool_mask(s[0], s[1], s[2], s[3])
+        assert (r32["mask"][b].cpu().numpy() != want).sum() <= 1
+        np.testing.assert_allclose(r32["mean_flow"][b].cpu().numpy(), O.mean_flow_per_box(s[0], s[1], s[2], s[3], s[5], s[4]),
+                                   atol=5e-6)
+    assert int(r64["count"].sum()) > 0
+    # order independence: fixed-point sums do not depend on which block finishes first, nor on the order of the points
+    perm = torch.randperm(N, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+    rp = points_in_boxes(boxes7, pts[:, perm], point_valid=valid[:, perm], flow=flow[:, perm], precision=FP32_PRODUCT)
+    assert torch.equal(rp["count"], r32["count"]) and torch.equal(rp["mean_flow"], r32["mean_flow"])
+    # the per-box mean equals the masked mean of the flow (up to fp32 summation)
+    m = r32["mask"].float()
+    want = torch.einsum("bnk,bnc->bkc", m * valid[..., None].float(), flow) / m.sum(1).clamp(min=1.0)[..., None]
+    assert float((r32["mean_flow"] - want).abs().max()) < 2e-4
+
+
+def test_points_in_boxes_edge_cases():
+    from liso_amd.tracker.box_points import points_in_boxes
+
+    pos, dims, rot, pts, flow, valid = _scene(5, 6, 2000)
+    boxes7 = torch.from_numpy(np.concatenate([pos, dims, rot], -1))[None].cuda()
+    p, f = torch.from_numpy(pts)[None].cuda(), torch.from_numpy(flow)[None].cuda()
+    ref = points_in_boxes(boxes7, p, flow=f, want_mask=True)
+    # NaN box rows (padding) hold no point; the other rows are unaffected
+    nb = boxes7.clone()
+    nb[0, 2] = float("nan")
+    r = points_in_boxes(nb, p, flow=f, want_mask=True)
+    keep = [0, 1, 3, 4, 5]
+    assert int(r["count"][0, 2]) == 0 and float(r["mean_flow"][0, 2].abs().sum()) == 0.0 and not bool(r["mask"][0, :, 2].any())
+    assert torch.equal(r["count"][0, keep], ref["count"][0, keep]) and torch.equal(r["mean_flow"][0, keep], ref["mean_flow"][0, keep])
+    # NaN / inf points lie in no box
+    pp = p.clone()
+    inside_rows = ref["mask"][0].any(-1).nonzero()[:10, 0]
+    pp[0, inside_rows[:5]] = float("nan")
+    pp[0, inside_rows[5:], 2] = float("inf")
+    r = points_in_boxes(boxes7, pp, want_mask=True)
+    assert not bool(r["mask"][0, inside_rows].any())
+    assert int(r["count"].sum()) == int(ref["count"].sum()) - int(ref["mask"][0, inside_rows].sum())
+    # zero-size boxes (padding zeroed by set_padding_val_to) hold no point
+    zb = boxes7.clone()
+    zb[0, 1] = 0.0
+    assert int(points_in_boxes(zb, p)["count"][0, 1]) == 0
+    # no boxes / no points
+    assert points_in_boxes(boxes7[:, :0], p, flow=f, want_mask=True)["mask"].shape == (1, 2000, 0)
+    r = points_in_boxes(boxes7, p[:, :0], flow=f[:, :0], want_mask=True)
+    assert int(r["count"].sum()) == 0 and float(r["mean_flow"].abs().sum()) == 0.0 and r["mask"].shape == (1, 0, 6)
+
+
+def test_min_points_filter_matches_reference_semantics():
+    from liso_amd.tracker.tracking import count_points_in_boxes, drop_boxes_with_too_few_points
+    from oracle import tracking as O
+
+    pos, dims, rot, pts, _, _ = _scene(9, 40, 30000)
+    boxes, _ = _shape(pos[:, :2], dims[:, :2], rot)  # BEV boxes: dummy z = -1, height 2 (tracking.py:771-792)
+    pcl = torch.from_numpy(pts).cuda()
+    num = count_points_in_boxes(boxes, pcl).cpu().numpy()
+    pos3 = np.concatenate([pos[:, :2], -np.ones((40, 1), np.float32)], -1)
+    dims3 = np.concatenate([dims[:, :2], 2 * np.ones((40, 1), np.float32)], -1)
+    want = O.points_in_boxes_mask(pos3, dims3, rot, pts).sum(0)
+    assert np.array_equal(num, want)
+    kept = drop_boxes_with_too_few_points(boxes, pcl, 130)
+    assert kept.shape[0] == int((want >= 130).sum()) and 0 < kept.shape[0] < 40
+    assert torch.equal(kept.pos.cpu(), boxes.pos.cpu()[torch.from_numpy(want >= 130)])
+
+
+@pytest.mark.parametrize("tag", ["m0", "m1", "m2", "m3", "m4"])
+@pytest.mark.parametrize("thr", [0.3, 0.5])
+def test_greedy_matching_matches_reference_fixture(golden_dir, tag, thr):
+    from liso_amd.kabsch.box_groundtruth_matching_iou import greedy_match_iou_matrix
+
+    g = np.load(f"{golden_dir}/tracking_reference.npz")
+    iou = torch.from_numpy(g[f"{tag}_iou"]).cuda()
+    order = torch.from_numpy(np.argsort(-g[f"{tag}_conf"].reshape(-1), kind="stable")).cuda()
+    ig, ip, d, num, pm, gm = greedy_match_iou_matrix(iou, order, thr)
+    m = int(num)
+    assert np.array_equal(ig[:m].cpu().numpy(), g[f"{tag}_{thr}_idx_gt"]) and np.array_equal(ip[:m].cpu().numpy(), g[f"{tag}_{thr}_idx_pred"])
+    assert np.array_equal(d[:m].cpu().numpy(), g[f"{tag}_{thr}_dists"])
+    assert np.array_equal(pm.cpu().numpy(), g[f"{tag}_{thr}_pred_mask"]) and np.array_equal(gm.cpu().numpy(), g[f"{tag}_{thr}_gt_mask"])
+
+
+@pytest.mark.parametrize("n_gt,n_pred", [(300, 1000), (1000, 300), (64, 64), (65, 1), (0, 5), (5, 0)])
+def test_greedy_matching_equals_oracle(n_gt, n_pred):
+    from liso_amd.kabsch.box_groundtruth_matching_iou import greedy_match_iou_matrix
+    from oracle import tracking as O
+
+    g = np.random.default_rng(n_gt * 7 + n_pred)
+    iou = g.uniform(0, 1, (n_gt, n_pred)).astype(np.float32)
+    iou[g.uniform(size=iou.shape) < 0.9] = 0.0
+    if n_gt > 10 and n_pred > 10:
+        iou[5] = iou[4]
+        iou[7, 3] = np.nan
+    order = g.permutation(n_pred)
+    want = O.match_greedy_ordered(iou, order, 0.25)
+    ig, ip, d, num, pm, gm = greedy_match_iou_matrix(torch.from_numpy(iou).cuda().view(n_gt, n_pred), torch.from_numpy(order).cuda(), 0.25)
+    m = int(num)
+    assert m == len(want[0])
+    for got, w in zip((ig[:m], ip[:m], d[:m], pm, gm), want):
+        assert np.array_equal(got.cpu().numpy(), w)
+    # every ground-truth box and every prediction is matched at most once
+    assert len(set(ig[:m].tolist())) == m and len(set(ip[:m].tolist())) == m
+
+
+def test_match_boxes_end_to_end_against_oracle_iou():
+    from liso_amd.kabsch.box_groundtruth_matching_iou import match_boxes_by_descending_confidence_iou
+    from oracle import iou3d as OI
+    from oracle import tracking as O
+
+    pos, dims, rot, _, _, _ = _scene(21, 60, 10, R=60.0)
+    g = np.random.default_rng(4)
+    gt, _ = _shape(pos, dims, rot)
+    keep = g.uniform(size=60) > 0.3  # detections: most ground-truth boxes, jittered, plus clutter
+    ppos = np.concatenate([pos[keep] + g.normal(0, 0.3, (keep.sum(), 3)).astype(np.float32), _scene(22, 25, 10, R=60.0)[0]], 0)
+    pdims = np.concatenate([dims[keep] * g.uniform(0.9, 1.1, (keep.sum(), 3)).astype(np.float32), _scene(22, 25, 10)[1]], 0)
+    prot = np.concatenate([rot[keep] + g.normal(0, 0.05, (keep.sum(), 1)).astype(np.float32), _scene(22, 25, 10)[2]], 0)
+    conf = g.uniform(0.05, 1.0, (ppos.shape[0], 1)).astype(np.float32)
+    pred, _ = _shape(ppos, pdims, prot, probs=conf)
+    for mode in ("iou_bev", "iou_3d"):
+        got = match_boxes_by_descending_confidence_iou(gt, pred, 0.3, iou_mode=mode)
+        a7, b7 = np.concatenate([pos, dims, rot], -1), np.concatenate([ppos, pdims, prot], -1)
+        if mode == "iou_bev":
+            iou = OI.boxes_iou_bev(a7, b7)
+        else:  # nms_iou.py:124-207: BEV overlap x height overlap / union volume
+            ov = OI.boxes_overlap_bev(a7, b7)
+            lo = np.maximum((pos[:, 2] - 0.5 * dims[:, 2])[:, None], (ppos[:, 2] - 0.5 * pdims[:, 2])[None])
+            hi = np.minimum((pos[:, 2] + 0.5 * dims[:, 2])[:, None], (ppos[:, 2] + 0.5 * pdims[:, 2])[None])
+            inter = np.where(hi - lo > 0, ov * (hi - lo), 0.0)
+            iou = inter / np.clip(dims.prod(-1)[:, None] + pdims.prod(-1)[None] - inter, np.finfo(np.float32).eps, None)
+        want = O.match_greedy(iou.astype(np.float32), conf, 0.3)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and len(got[0]) > 10
+        np.testing.assert_allclose(got[2], want[2], atol=1e-5)
+        assert np.array_equal(got[3], want[3]) and np.array_equal(got[4], want[4])
+        assert all(isinstance(x, np.ndarray) for x in got)
+    with pytest.raises(NotImplementedError):
+        match_boxes_by_descending_confidence_iou(gt, pred, 0.3, matching_mode="hungarian")
