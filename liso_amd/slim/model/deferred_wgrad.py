@@ -1,0 +1,111 @@
+"""Weight gradients of the RAFT update block, computed once per step instead of once per iteration.
+
+The update block (liso/slim/model/update.py:98-164) runs its 13 convolutions `num_iters` (6) times with the same weights.
+Autograd then launches 6 weight-gradient convolutions, 6 bias reductions and 5 gradient accumulations per parameter
+(78 + 78 + 130 launches per direction batch; the 64x64 maps leave most of the 256 CUs idle in each).  The weight gradient is
+a sum over samples, so here every convolution's backward only computes the data gradient and stashes (input, grad_output);
+when the backward of the first iteration is through, ONE weight-gradient convolution per layer runs over the stashed pairs
+concatenated along the batch axis.  Same arithmetic, other summation order (fp32 sums over 6x the samples in one kernel).
+
+Ordering: a 1-element token is threaded through the convolutions in forward order (each consumes the previous token and
+emits the next), so autograd runs their backwards in exactly the reverse order and the gate that owns the parameters last.
+"""
+import contextlib
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+_ACTIVE = None
+
+
+class _State:
+    def __init__(self, layers):
+        self.layers = layers
+        self.index = {id(m): i for i, m in enumerate(layers)}
+        self.stash = [[] for _ in layers]
+        self.token = None
+
+
+def _pair(v):
+    return [int(v[0]), int(v[1])] if isinstance(v, (tuple, list)) else [int(v), int(v)]
+
+
+class _ParamGate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, state, *params):
+        ctx.state = state
+        ctx.save_for_backward(*params)
+        return params[0].new_zeros(1)
+
+    @staticmethod
+    def backward(ctx, _token_grad):
+        params = ctx.saved_tensors
+        st = ctx.state
+        grads = []
+        for li, layer in enumerate(st.layers):
+            w, b = params[2 * li], params[2 * li + 1]
+            items, st.stash[li] = st.stash[li], []
+            if not items:
+                grads += [torch.zeros_like(w), torch.zeros_like(b)]
+                continue
+            x = items[0][0] if len(items) == 1 else torch.cat([i[0] for i in items], dim=0)
+            gy = items[0][1] if len(items) == 1 else torch.cat([i[1] for i in items], dim=0)
+            _, gw, gb = torch.ops.aten.convolution_backward(gy, x, w, [b.numel()], _pair(layer.stride), _pair(layer.padding),
+                                                            _pair(layer.dilation), False, [0, 0], 1, [False, True, True])
+            grads += [gw, gb]
+        return (None, *grads)
+
+
+class _ConvDeferred(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, token, w, b, state, li):
+        layer = state.layers[li]
+        ctx.state, ctx.li = state, li
+        ctx.save_for_backward(x, w)
+        ctx.set_materialize_grads(False)
+        return F.conv2d(x, w, b, layer.stride, layer.padding, layer.dilation), token.view_as(token)  # alias: no launch
+
+    @staticmethod
+    def backward(ctx, gy, token_grad):
+        x, w = ctx.saved_tensors
+        st, li = ctx.state, ctx.li
+        layer = st.layers[li]
+        gx = None
+        if gy is not None:
+            if ctx.needs_input_grad[0]:
+                gx = torch.ops.aten.convolution_backward(gy, x, w, None, _pair(layer.stride), _pair(layer.padding),
+                                                         _pair(layer.dilation), False, [0, 0], 1, [True, False, False])[0]
+            st.stash[li].append((x, gy))
+        if token_grad is None:  # the last convolution of the chain: nothing consumed its token
+            token_grad = st.zero
+        return gx, token_grad, None, None, None, None
+
+
+@contextlib.contextmanager
+def deferred_weight_gradients(module: nn.Module, enabled=True):
+    """Inside the context, `conv2d(layer, x)` of any Conv2d of `module` (groups == 1, with bias) defers its weight gradient."""
+    global _ACTIVE
+    layers = [m for m in module.modules() if isinstance(m, nn.Conv2d)]
+    ok = (enabled and torch.is_grad_enabled() and layers and all(m.groups == 1 and m.bias is not None and m.weight.requires_grad
+                                                                  and m.bias.requires_grad and m.padding_mode == "zeros"
+                                                                  for m in layers))
+    if not ok or _ACTIVE is not None:
+        yield None
+        return
+    st = _State(layers)
+    st.token = _ParamGate.apply(st, *[p for m in layers for p in (m.weight, m.bias)])
+    st.zero = st.token.detach()
+    _ACTIVE = st
+    try:
+        yield st
+    finally:
+        _ACTIVE = None
+
+
+def conv2d(layer: nn.Conv2d, x):
+    st = _ACTIVE
+    if st is None or id(layer) not in st.index:
+        return layer(x)
+    y, st.token = _ConvDeferred.apply(x, st.token, layer.weight.detach(), layer.bias.detach(), st, st.index[id(layer)])
+    return y

@@ -4,6 +4,8 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from liso_amd.slim.model.deferred_wgrad import conv2d
+
 
 class FlowOrClassificationHead(nn.Module):
     def __init__(self, input_dim=128, hidden_dim=256, out_dims=2, **kwargs):
@@ -14,7 +16,7 @@ class FlowOrClassificationHead(nn.Module):
         self.relu = nn.ReLU(inplace=True)
 
     def forward(self, inputs):
-        return self.conv2(self.relu(self.conv1(inputs)))
+        return conv2d(self.conv2, self.relu(conv2d(self.conv1, inputs)))
 
 
 class ConvGRU(nn.Module):
@@ -27,9 +29,9 @@ class ConvGRU(nn.Module):
     def forward(self, h, x):
         """reference :29-37"""
         hx = torch.cat([h, x], dim=1)
-        z = torch.sigmoid(self.convz(hx))
-        r = torch.sigmoid(self.convr(hx))
-        q = torch.tanh(self.convq(torch.cat([r * h, x], dim=1)))
+        z = torch.sigmoid(conv2d(self.convz, hx))
+        r = torch.sigmoid(conv2d(self.convr, hx))
+        q = torch.tanh(conv2d(self.convq, torch.cat([r * h, x], dim=1)))
         return (1 - z) * h + z * q
 
 
@@ -50,15 +52,15 @@ class SmallMotionEncoder(nn.Module):
 
     def forward(self, flow, corr, logits):
         """reference :74-96"""
-        corr = F.relu(self.conv_stat_corr1(corr))
-        flow = F.relu(self.conv_flow2(F.relu(self.conv_flow1(flow))))
+        corr = F.relu(conv2d(self.conv_stat_corr1, corr))
+        flow = F.relu(conv2d(self.conv_flow2, F.relu(conv2d(self.conv_flow1, flow))))
         vals = [corr, flow]
         if self.predict_logits:
-            logits = F.relu(self.conv_class2(F.relu(self.conv_class1(logits))))
+            logits = F.relu(conv2d(self.conv_class2, F.relu(conv2d(self.conv_class1, logits))))
             vals.append(logits)
         else:
             assert logits is None
-        out = F.relu(self.conv(torch.cat(vals, dim=1)))
+        out = F.relu(conv2d(self.conv, torch.cat(vals, dim=1)))
         if self.predict_logits:
             return torch.cat([out, logits, flow], dim=1)
         return torch.cat([out, flow], dim=1)

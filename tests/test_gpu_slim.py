@@ -288,7 +288,9 @@ def test_slim_trainer_hipgraph_step_equals_eager_step():
     assert np.allclose(l0, l1, rtol=1e-5, atol=1e-6), (l0, l1)
     for k in s0:
         a, b = s0[k].double(), s1[k].double()
-        assert torch.allclose(a, b, rtol=1e-4, atol=1e-6), (k, float((a - b).abs().max()))
+        # MIOpen's split-K weight-gradient kernels (igemm_wrw ..._gkgs) accumulate with float atomics: two runs of the same
+        # step differ in the last bits of the gradients, which RMSprop's g / sqrt(v) turns into ~1e-6 weight differences
+        assert torch.allclose(a, b, rtol=1e-4, atol=5e-6), (k, float((a - b).abs().max()))
 
 
 def test_batched_directions_and_iterations_equal_the_sequential_schedule():
@@ -362,3 +364,43 @@ def test_fused_nearest_point_loss_equals_torch_ops(fov_mode, delta):
     # padding rows: the torch ops hand back 0 * NaN = NaN there (masked out upstream by the NaN-marking `where`,
     # knn_loss.py:44-45); the kernel writes zeros
     assert torch.allclose(gf[valid], gr[valid], rtol=1e-4, atol=1e-6) and bool(torch.isfinite(gf).all())
+
+
+def test_deferred_update_block_weight_gradients_equal_per_iteration_ones():
+    """RAFT(defer_update_block_wgrad): one weight-gradient convolution per update-block layer over all iterations
+    (liso_amd/slim/model/deferred_wgrad.py) vs autograd's per-iteration ones -- same loss, same gradients up to fp32
+    summation order"""
+    from liso_amd.slim.model.deferred_wgrad import deferred_weight_gradients
+    from liso_amd.slim.model.update import SmallUpdateBlock
+    from liso_amd.utils.config import default_cfg
+
+    torch.manual_seed(0)
+    ub = SmallUpdateBlock(default_cfg(grid=128).SLIM).cuda()
+    B, h, w, n_it = 2, 32, 32, 6
+    net0, inp = torch.randn(B, 96, h, w, device="cuda"), torch.randn(B, 64, h, w, device="cuda")
+    corrs = [torch.randn(B, 196, h, w, device="cuda") for _ in range(n_it)]
+
+    def run(defer):
+        for p in ub.parameters():
+            p.grad = None
+        net = net0.clone().requires_grad_(True)
+        flow, logits = torch.zeros(B, 2, h, w, device="cuda"), torch.zeros(B, 4, h, w, device="cuda")
+        loss, n = 0.0, net
+        with deferred_weight_gradients(ub, enabled=defer) as st:
+            assert (st is not None) == defer
+            for it in range(n_it):
+                n, df, dl, _ = ub(n, inp, corrs[it], flow.detach(), logits.detach(), None)
+                flow, logits = flow.detach() + df, logits.detach() + dl
+                loss = loss + flow.square().mean() + 0.5 * logits.square().mean()
+        loss.backward()
+        return float(loss), [p.grad.clone() for p in ub.parameters()], net.grad.clone()
+
+    l0, g0, n0 = run(False)
+    l1, g1, n1 = run(True)
+    assert abs(l0 - l1) <= 1e-5 * abs(l0)  # MIOpen may pick another forward solver on the second pass over the same shapes
+    assert float((n0 - n1).abs().max()) <= 1e-5 * float(n0.abs().max())
+    for a, b in zip(g0, g1):
+        assert float((a - b).abs().max()) <= 1e-4 * max(float(a.abs().max()), 1e-6), float((a - b).abs().max())
+    with torch.no_grad():  # inference: plain convolutions
+        with deferred_weight_gradients(ub) as st:
+            assert st is None
