@@ -90,13 +90,18 @@ def slim_algorithmic_bytes(batch, n_points, grid, levels=4, radius=3, directions
     # training: the forward and the backward flow direction of every pair share one launch (2 * batch samples per lookup);
     # the box miner of the loop workload runs the forward direction only
     lookup = directions * batch * (levels * hw * w2 * 4 * 4 + hw * levels * w2 * 4)
-    return {"corr_lookup_fwd": lookup, "corr_lookup_bwd": lookup, "knn_query": 2 * n_points * 12 + n_points * 8}
+    # RAFT output assembly: [6 iterations x directions x batch, G, G, 8] fp32 written (fwd) / read (bwd) once + the low-res maps
+    outputs = 6 * directions * batch * (grid * grid * 8 * 4 + hw * 6 * 4)
+    return {"corr_lookup_fwd": lookup, "corr_lookup_bwd": lookup, "knn_query": 2 * n_points * 12 + n_points * 8,
+            "raft_outputs_fwd": outputs, "raft_outputs_bwd": outputs}
 
 
 SLIM_KERNELS = {
     "corr_lookup_fwd": "corr_lookup_fwd_kernel (on-the-fly 4-level correlation + bilinear lookup)",
     "corr_lookup_bwd": "corr_lookup_bwd_kernel (adjoint of the lookup into fmap1 / pooled fmap2 gradients)",
     "knn_query": "knn_query_kernel (exact 1-NN, two-level bucket grid with z bins, 16 lanes per query, one launch)",
+    "raft_outputs_fwd": "upsample_fwd_kernel (x8 bilinear upsampling + flow convention + concat of all RAFT iterations)",
+    "raft_outputs_bwd": "upsample_bwd_x/y kernels (adjoint of the output assembly, two gather passes)",
 }
 
 

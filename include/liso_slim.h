@@ -121,6 +121,35 @@ int liso_bev_gather_fwd_f32(const float* grid, const int* lin, long n_rows, int 
 int liso_bev_gather_bwd_f32(const float* grad_out, const int* sorted_lin, const int* order, const int* seg_rank, long n_rows,
                             int c, float* partial, float* grad_grid, void* stream);
 
+/* ---- RAFT output assembly -------------------------------------------------------------------------------------------
+ * Replaces, for all update iterations of a step at once, upflow_n / uplogits_n (liso/slim/model/raft_code/utils.py:5-12:
+ * x`factor` bilinear F.interpolate, align_corners=True), change_flow_convention_from_raft2usfl (raft_mod.py:262-266),
+ * HeadDecoder.concat2network_output (head_decoder.py:37-65) and the channels-last permute (raft_mod.py:244-258): per
+ * iteration the reference runs 2 upsamplings, a flip, 2 scalings and a concat over 512x512 maps (and autograd their six
+ * adjoints); here one launch writes the [S, H, W, 8] network outputs of all iterations, two launches form the adjoint.
+ *
+ *   flow_lr    float32 [n_it, batch2, 2, h, w]   coords1 - coords0 per iteration, RAFT convention (x = col, y = row), pixels
+ *   logits_lr  float32 [n_it, batch2, 4, h, w]
+ *   out        float32 [n_it*batch2, H, W, 8], H = h*factor: channels 0:4 logits, 4:6 static flow (row, col) in metres,
+ *              6:8 dynamic flow (the same values).  Sample order: output sample dir*(n_it*B) + it*B + b holds input sample
+ *              (it, dir*B + b), B = batch2/dirs -- with dirs = 2 the forward-flow samples of all iterations come first,
+ *              then the backward-flow ones (the order the stacked loss consumes); dirs = 1 keeps (it, b) order.
+ *   flow_scale = factor * metres per low-resolution pixel
+ * Bilinear taps follow ATen's upsample_bilinear2d (align_corners=True) arithmetic. */
+typedef struct {
+    int n_it, batch2, dirs;
+    int h, w, factor;
+    float flow_scale;
+} liso_upsample_cfg;
+
+size_t liso_raft_upsample_scratch_bytes(const liso_upsample_cfg* cfg);
+int liso_raft_upsample_outputs_fwd_f32(const liso_upsample_cfg* cfg, const float* flow_lr, const float* logits_lr, float* out,
+                                       void* stream);
+/* grad_out [S,H,W,8] -> grad_flow_lr [n_it,batch2,2,h,w], grad_logits_lr [n_it,batch2,4,h,w] (overwritten); two gather
+ * passes (along x, then y) through `scratch`: no atomics, bit reproducible. */
+int liso_raft_upsample_outputs_bwd_f32(const liso_upsample_cfg* cfg, const float* grad_out, void* scratch, size_t scratch_bytes,
+                                       float* grad_flow_lr, float* grad_logits_lr, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -109,6 +109,9 @@ SIGNATURES = {
     "liso_nearest_point_loss_bwd_f32": (_i, [_vp] * 9),
     "liso_bev_gather_fwd_f32": (_i, [_vp, _vp, ctypes.c_long, _i, ctypes.c_float, _vp, _vp]),
     "liso_bev_gather_bwd_f32": (_i, [_vp, _vp, _vp, _vp, ctypes.c_long, _i, _vp, _vp, _vp]),
+    "liso_raft_upsample_scratch_bytes": (_sz, [_vp]),
+    "liso_raft_upsample_outputs_fwd_f32": (_i, [_vp] * 5),
+    "liso_raft_upsample_outputs_bwd_f32": (_i, [_vp, _vp, _vp, _sz, _vp, _vp, _vp]),
     # include/liso_detector.h
     "liso_centerloss_workspace_bytes": (_sz, [_vp]),
     "liso_centerloss_fwd_f32": (_i, [_vp] * 17 + [_sz, _vp]),
@@ -147,6 +150,11 @@ class NpLossCfg(ctypes.Structure):
 class BoxPtsCfg(ctypes.Structure):
     """mirror of liso_boxpts_cfg (include/liso_tracking.h)"""
     _fields_ = [("batch", _i), ("n", ctypes.c_long), ("k", _i), ("point_stride", _i), ("precision", _i), ("dims_bloat", _f)]
+
+
+class UpsampleCfg(ctypes.Structure):
+    """mirror of liso_upsample_cfg (include/liso_slim.h)"""
+    _fields_ = [("n_it", _i), ("batch2", _i), ("dirs", _i), ("h", _i), ("w", _i), ("factor", _i), ("flow_scale", _f)]
 
 
 class TargetsCfg(ctypes.Structure):

@@ -9,6 +9,7 @@ from liso_amd.networks.pcl_to_feature_grid.pcl_to_feature_grid import PointsPill
 from liso_amd.slim.model.extractor import SmallEncoder
 from liso_amd.slim.model.raft_code.corr import CorrBlock
 from liso_amd.slim.model.deferred_wgrad import deferred_weight_gradients
+from liso_amd.slim.model.raft_outputs import raft_network_outputs
 from liso_amd.slim.model.raft_code.utils import initialize_flow, upflow_n, uplogits_n
 from liso_amd.slim.model.update import SmallUpdateBlock
 
@@ -63,7 +64,13 @@ class RAFT(nn.Module):
         imgs = torch.cat([img_t0, img_t1], dim=0)
         fmap = self.fnet(imgs)
         fmap_swapped = torch.cat([fmap[B:], fmap[:B]], dim=0)
-        both = self.predict_single_flow_map_and_classes(imgs, fmap, fmap_swapped, self.head_decoder_fw)
+        both = self.predict_single_flow_map_and_classes(imgs, fmap, fmap_swapped, self.head_decoder_fw,
+                                                        fused_dirs=2 if getattr(self, "fused_outputs", True) else None)
+        if torch.is_tensor(both):  # all iterations assembled by one launch: [fw it0..itN | bw it0..itN] x B samples
+            n_it = both.shape[0] // (2 * B)
+            aux["net_all"] = both
+            return ([both[i * B:(i + 1) * B] for i in range(n_it)],
+                    [both[(n_it + i) * B:(n_it + i + 1) * B] for i in range(n_it)], aux)
         aux["fw_bw_batched"] = both  # per iteration [2B,H,W,8]: samples [:B] = forward flow, [B:] = backward flow
         return [p[:B] for p in both], [p[B:] for p in both], aux
 
@@ -79,9 +86,11 @@ class RAFT(nn.Module):
         out = self.predict_single_flow_map_and_classes(img_t0, fmap[:B], fmap[B:], self.head_decoder_fw, only_last=True)
         return out[-1], aux
 
-    def predict_single_flow_map_and_classes(self, img_t0, fmap_t0, fmap_t1, decoder, only_last=False):
+    def predict_single_flow_map_and_classes(self, img_t0, fmap_t0, fmap_t1, decoder, only_last=False, fused_dirs=None):
         """reference :124-259.  `only_last` (extension, inference): upsample / assemble the network output of the last
-        iteration only -- the intermediate ones exist for the training loss."""
+        iteration only -- the intermediate ones exist for the training loss.  `fused_dirs` (extension): the batch holds
+        `fused_dirs` flow directions x B samples; the outputs of all iterations are then assembled by one launch
+        (raft_outputs.py) and returned as ONE tensor [fused_dirs * n_it * B, H, W, 8] instead of a list."""
         m = self.slim_cfg.model
         assert img_t0.shape[1] == m.point_pillars.nbr_point_feats, img_t0.shape
         ds = m.feature_downsampling_factor
@@ -100,6 +109,9 @@ class RAFT(nn.Module):
         # [1,2,1,1] tensor (:171-176) without a host->device copy per call
         adapter = float(self.bev_rows_res_meters_per_fs_pixel)
         preds = []
+        fuse = (fused_dirs is not None and not vanilla and not use_w and not only_last and img_t0.is_cuda
+                and b % fused_dirs == 0)
+        lowres_flows, lowres_logits = [], []
         # weight gradients of the update block: one convolution per layer over all iterations (deferred_wgrad.py)
         defer = self.training and getattr(self, "defer_update_block_wgrad", True)
         with deferred_weight_gradients(self.update_block, enabled=defer):
@@ -119,6 +131,10 @@ class RAFT(nn.Module):
                     wl = wl + d_w
                 if only_last and it + 1 < m.num_iters:
                     continue
+                if fuse:
+                    lowres_flows.append(coords1 - coords0)
+                    lowres_logits.append(logits)
+                    continue
                 up_flow = change_flow_convention_from_raft2usfl(upflow_n(coords1 - coords0, n=ds), resolution_adapter=adapter)
                 if vanilla:
                     up_logits = torch.zeros((b, 4, h * ds, w * ds), dtype=torch.float32, device=img_t0.device)
@@ -127,4 +143,6 @@ class RAFT(nn.Module):
                 up_w = uplogits_n(wl, n=ds) if use_w else None
                 preds.append(decoder.concat2network_output(logits=up_logits, static_flow=up_flow, dynamic_flow=up_flow,
                                                            weight_logits_for_static_aggregation=up_w))
+        if fuse:
+            return raft_network_outputs(lowres_flows, lowres_logits, dirs=fused_dirs, factor=ds, resolution_adapter=adapter)
         return preds

@@ -90,11 +90,14 @@ class SLIM(nn.Module):
             odom = cat(sample_data_t0["gt"]["odom_ta_tb"], sample_data_t1["gt"]["odom_ta_tb"])
             inv_odom = cat(sample_data_t1["gt"]["odom_ta_tb"], sample_data_t0["gt"]["odom_ta_tb"])
             filled = torch.cat([filled0, filled1], dim=0)
-            batched = aux.get("fw_bw_batched") or [torch.cat([o01, o10], dim=0) for o01, o10 in zip(out_fw, out_bw)]
             # ... and all RAFT iterations at once: the decoder output of iteration i feeds nothing but the loss, so the
             # 6 x 2B network outputs are decoded as one batch ordered [fw it0..it5 | bw it0..it5]
-            n_it = len(batched)
-            net_all = torch.cat([p[:B] for p in batched] + [p[B:] for p in batched], dim=0)
+            n_it = len(out_fw)
+            if "net_all" in aux:  # already assembled in that order by one launch (raft_outputs.py)
+                net_all = aux["net_all"]
+            else:
+                batched = aux.get("fw_bw_batched") or [torch.cat([o01, o10], dim=0) for o01, o10 in zip(out_fw, out_bw)]
+                net_all = torch.cat([p[:B] for p in batched] + [p[B:] for p in batched], dim=0)
             tile = lambda t: torch.cat([t[:B]] * n_it + [t[B:]] * n_it, dim=0)  # noqa: E731
             pc_all, valid_all, coors_all = tile(pc), tile(valid), tile(coors)
             plan = BevGatherPlan(torch.div(coors_all, fs, rounding_mode="trunc"), valid_all, out_fw[0].shape[1:3])

@@ -404,3 +404,46 @@ def test_deferred_update_block_weight_gradients_equal_per_iteration_ones():
     with torch.no_grad():  # inference: plain convolutions
         with deferred_weight_gradients(ub) as st:
             assert st is None
+
+
+@pytest.mark.parametrize("n_it,B,dirs,h,w", [(6, 1, 2, 64, 64), (3, 2, 2, 16, 24), (2, 3, 1, 8, 8), (1, 1, 1, 5, 7)])
+def test_raft_output_assembly_equals_reference_ops(n_it, B, dirs, h, w):
+    """liso_raft_upsample_outputs_*: all iterations' network outputs in one launch vs upflow_n / uplogits_n /
+    change_flow_convention_from_raft2usfl / concat2network_output per iteration (raft_mod.py:244-266), forward and adjoint"""
+    from liso_amd.slim.model.raft_code.utils import upflow_n, uplogits_n
+    from liso_amd.slim.model.raft_mod import change_flow_convention_from_raft2usfl
+    from liso_amd.slim.model.raft_outputs import raft_network_outputs
+
+    g = torch.Generator().manual_seed(n_it * 100 + h)
+    b2, adapter = dirs * B, 0.1953125
+    flows = [torch.randn(b2, 2, h, w, generator=g).cuda().requires_grad_(True) for _ in range(n_it)]
+    logits = [torch.randn(b2, 4, h, w, generator=g).cuda().requires_grad_(True) for _ in range(n_it)]
+    out = raft_network_outputs(flows, logits, dirs=dirs, factor=8, resolution_adapter=adapter)
+    assert out.shape == (n_it * b2, 8 * h, 8 * w, 8) and out.is_contiguous()
+    def reference(dtype):  # the per-iteration ops of raft_mod.py:244-266, output sample order [direction][iteration][sample]
+        ref = []
+        for f, lg in zip(flows, logits):
+            up = change_flow_convention_from_raft2usfl(upflow_n(f.to(dtype), n=8), resolution_adapter=adapter)
+            ref.append(torch.cat([uplogits_n(lg.to(dtype), n=8), up, up], dim=1).permute(0, 2, 3, 1))
+        return torch.cat([ref[it][d * B:(d + 1) * B] for d in range(dirs) for it in range(n_it)], dim=0)
+
+    def grads(loss):
+        for t in flows + logits:
+            t.grad = None
+        loss.backward()
+        return [t.grad.clone() for t in flows + logits]
+
+    wgt = torch.randn(out.shape, generator=g).cuda()
+    got = grads((out * wgt).sum())
+    # fp32 bilinear taps carry the rounding of scale * dst (half an ulp of 63 = 1.9e-6 on the weight): ATen's fp32 kernel
+    # is itself 2.3e-5 / 1.4e-4 (fwd / bwd, 64 -> 512) away from the fp64 evaluation, this kernel 6e-6 / 5e-5.  Checked
+    # against both: tight against fp64, within ATen's own error against ATen.
+    for dtype, tol in ((torch.float64, 2e-6), (torch.float32, 6e-6)):
+        want = reference(dtype)
+        assert float((out - want).abs().max()) <= tol * max(float(want.abs().max()), 1.0), (dtype, float((out - want).abs().max()))
+        ref_g = grads((want * wgt.to(dtype)).sum())
+        gmax = max(float(r.abs().max()) for r in ref_g)
+        assert max(float((a - r).abs().max()) for a, r in zip(got, ref_g)) <= tol * gmax, dtype
+    # gather adjoint: bit reproducible
+    out2 = raft_network_outputs(flows, logits, dirs=dirs, factor=8, resolution_adapter=adapter)
+    assert torch.equal(out, out2) and all(torch.equal(a, b) for a, b in zip(got, grads((out2 * wgt).sum())))
