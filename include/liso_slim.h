@@ -72,6 +72,11 @@ size_t liso_knn_workspace_bytes(const liso_knn_grid* grid, int n_ref);
 int liso_knn_build_f32(const liso_knn_grid* grid, const float* ref, int ref_stride, int n_ref, void* workspace,
                        size_t workspace_bytes, void* stream);
 
+/* The reference rows in bucket order (cell-major, z bin inside the cell): ids[0 .. n_ref) int64.  Only meaningful when every
+ * reference row was finite (rows with NaN/inf are not bucketed: the tail of `ids` is then undefined).  Use: a spatially
+ * coherent processing order for queries that start at this cloud's points (liso_amd/slim/slim_loss/knn_wrapper.py). */
+int liso_knn_sorted_ids(const liso_knn_grid* grid, const void* workspace, int n_ref, int64_t* ids, void* stream);
+
 /* One launch answers all queries.  `grid`/`workspace`: the (fine) index.  `coarse_grid`/`coarse_workspace` (both NULL or
  * both set): a second index of the SAME reference cloud with larger cells -- a query whose answer is not proven exact
  * after `fine_max_rings` rings of the fine grid continues on the coarse one (the fine grid answers the dense near field

@@ -123,6 +123,7 @@ SIGNATURES = {
     "liso_bn_relu_bwd": (_i, [_vp, _vp, _i, ctypes.c_long, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "liso_knn_workspace_bytes": (_sz, [_vp, _i]),
     "liso_knn_build_f32": (_i, [_vp, _vp, _i, _i, _vp, _sz, _vp]),
+    "liso_knn_sorted_ids": (_i, [_vp, _vp, _i, _vp, _vp]),
     "liso_knn_query_f32": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _i, _vp]),
     # include/liso_tracking.h
     "liso_points_in_boxes_workspace_bytes": (_sz, [_vp]),

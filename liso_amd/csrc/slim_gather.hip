@@ -36,12 +36,27 @@ __global__ __launch_bounds__(256) void bev_gather_bwd_chunk_kernel(const float* 
     const int lane = threadIdx.x & 31;
     if (s >= n_rows) return;
     const int cell = sorted_lin[s];
-    if (cell < 0 || (seg_rank[s] % kChunk) != 0) return;
-    int rows = 0;  // rows of this chunk: consecutive sorted rows of the same cell, at most kChunk
-    while (rows < kChunk && s + rows < n_rows && sorted_lin[s + rows] == cell) rows++;
+    const int rank0 = seg_rank[s];
+    if (cell < 0 || (rank0 % kChunk) != 0) return;
+    // rows of this chunk: consecutive sorted rows of the same cell, at most kChunk.  Row s + k belongs to it iff its rank
+    // inside the cell's run is rank0 + k: all kChunk ranks and source rows are fetched up front (independent loads), so
+    // the chunk costs two memory round trips instead of two per row.
+    int src[kChunk];
+    int rows = kChunk;
+#pragma unroll
+    for (int k = 0; k < kChunk; k++) {
+        const bool in_range = s + k < n_rows;
+        const int rk = in_range ? seg_rank[s + k] : -1;
+        src[k] = in_range ? order[s + k] : 0;
+        if (rows == kChunk && rk != rank0 + k) rows = k;
+    }
     for (int ch = lane; ch < c; ch += 32) {
+        float v[kChunk];
+#pragma unroll
+        for (int k = 0; k < kChunk; k++) v[k] = k < rows ? grad_out[(size_t)src[k] * c + ch] : 0.f;
         float acc = 0.f;
-        for (int k = 0; k < rows; k++) acc += grad_out[(size_t)order[s + k] * c + ch];
+#pragma unroll
+        for (int k = 0; k < kChunk; k++) acc += v[k];  // fixed order; rows beyond the chunk add exact zeros
         partial[(size_t)s * c + ch] = acc;
     }
 }

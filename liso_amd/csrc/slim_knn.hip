@@ -110,6 +110,11 @@ __global__ void knn_fill_kernel(const float* __restrict__ ref, int stride, int n
                                 __int_as_float(i));
 }
 
+__global__ void knn_sorted_ids_kernel(const float4* __restrict__ bucketed, int n, long long* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = __float_as_int(bucketed[i].w);
+}
+
 // 16 lanes cooperate on one query: each lane fetches the [start, end) range of one cell of the ring (independent loads
 // in flight), then the group walks every non-empty range together, 16 consecutive float4 per step (256 coalesced
 // bytes) -- vertical structures put hundreds of points into one xy cell, so points, not cells, are the unit of work.
@@ -273,6 +278,14 @@ static Level make_level(const liso_knn_grid* grid, const void* workspace, int n_
     l.occ = (const unsigned*)workspace;
     l.bucketed = (const float4*)((const char*)workspace + align16((3 * (size_t)cells + 1 + kTotSlots + (size_t)n_ref) * sizeof(int)));
     return l;
+}
+
+int liso_knn_sorted_ids(const liso_knn_grid* grid, const void* workspace, int n_ref, int64_t* ids, void* stream) {
+    if (!grid_ok(grid) || n_ref < 0 || !workspace || (n_ref > 0 && !ids)) return LISO_EINVAL;
+    if (n_ref == 0) return LISO_OK;
+    const Level l = make_level(grid, workspace, n_ref);
+    knn_sorted_ids_kernel<<<(n_ref + 255) / 256, 256, 0, (hipStream_t)stream>>>(l.bucketed, n_ref, (long long*)ids);
+    return hipGetLastError() == hipSuccess ? LISO_OK : LISO_ELAUNCH;
 }
 
 int liso_knn_query_f32(const liso_knn_grid* grid, const void* workspace, const liso_knn_grid* coarse_grid,

@@ -35,9 +35,11 @@ class KnnIndex:
 
     FINE_RINGS = 6
 
-    def __init__(self, ref: torch.Tensor, cell: float = 0.2, coarse_cell: float = 2.0, extent=None):
+    def __init__(self, ref: torch.Tensor, cell: float = 0.2, coarse_cell: float = 2.0, extent=None, all_rows_finite=False):
+        """`all_rows_finite`: the caller knows that no row of `ref` holds NaN / inf (enables `sorted_ids`)"""
         assert ref.ndim == 2 and ref.shape[1] >= 3
         L.require_cuda(ref)
+        self.all_rows_finite, self._sorted_ids = bool(all_rows_finite), None
         self.ref = ref.detach().float().contiguous()
         n = self.ref.shape[0]
         if extent is not None:  # (x_min, y_min, x_max, y_max) known up front (the BEV range): no host sync at all;
@@ -51,6 +53,20 @@ class KnnIndex:
             # z bins over [-4 m, 4 m) (clamped outside): 0.25 m inside the fine cells, 2 m inside the coarse ones
             self.fine = _Grid(self.ref, lo, hi, cell, 700, -4.0, 0.25, 32)
             self.coarse = _Grid(self.ref, lo, hi, coarse_cell, 700, -4.0, 2.0, 4)
+
+    def sorted_ids(self):
+        """int64 [n]: this cloud's rows in (fine) bucket order -- a spatially coherent visiting order for queries that start
+        at this cloud's points; None unless the index was built with all_rows_finite=True"""
+        if not self.all_rows_finite:
+            return None
+        if self._sorted_ids is None:
+            n = self.ref.shape[0]
+            ids = torch.empty(n, dtype=torch.int64, device=self.ref.device)
+            with torch.cuda.device(self.ref.device):
+                L.check(L.lib().liso_knn_sorted_ids(ctypes.byref(self.fine.grid), L.ptr(self.fine.ws), n, L.ptr(ids), L.stream_ptr()),
+                        "knn_sorted_ids")
+            self._sorted_ids = ids
+        return self._sorted_ids
 
     def query(self, x: torch.Tensor, return_dist_sqr=False):
         q = x.detach().float().contiguous()

@@ -6,7 +6,7 @@ from liso_amd.utils.config import AttrDict as Munch
 
 
 def compute_knn_loss_components(pcl_t0, valid_mask_t0, pcl_t1, valid_mask_t1, *, prediction, loss_cfg, model_cfg, bev_extent,
-                                knn_indices=None):
+                                knn_indices=None, query_order_indices=None):
     assert pcl_t0.ndim == 3 and pcl_t0.size(2) == 3 and pcl_t1.ndim == 3 and pcl_t1.size(2) == 3
     assert prediction.static_flow.ndim == 3 and prediction.static_flow.size(2) == 3
     types = {"aggregated"}  # reference :27-43
@@ -27,6 +27,7 @@ def compute_knn_loss_components(pcl_t0, valid_mask_t0, pcl_t1, valid_mask_t1, *,
     loss, knn = compute_flow_loss_a_to_b(torch.cat([pcl_t0] * n, 0), torch.cat([pcl_t1] * n, 0), torch.cat(flows, 0),
                                          loss_function=NearestPointLoss(bev_extent=bev_extent, **loss_cfg.knn_loss),
                                          nearest_dist_mode=loss_cfg.knn_dist_measure,
-                                         knn_indices=None if knn_indices is None else list(knn_indices) * n)
+                                         knn_indices=None if knn_indices is None else list(knn_indices) * n,
+                                         query_order_indices=None if query_order_indices is None else list(query_order_indices) * n)
     return {t: {"loss": loss[i * bs:(i + 1) * bs], "knn": Munch(**{k: v[i * bs:(i + 1) * bs] for k, v in knn.items()})}
             for i, t in enumerate(types)}

@@ -104,9 +104,13 @@ def get_idx_dists_for_knn(ref_pts, query_pts, num_neighbors: int = 1):
     return knn_graph(query_pts, index=ref_pts, k=num_neighbors, loop=True)
 
 
-def compute_flow_loss_a_to_b(cloud_a, cloud_b, flow_a_to_b, loss_function, nearest_dist_mode: str = "point", knn_indices=None):
+def compute_flow_loss_a_to_b(cloud_a, cloud_b, flow_a_to_b, loss_function, nearest_dist_mode: str = "point", knn_indices=None,
+                             query_order_indices=None):
     """reference :155-217.  `knn_indices` (optional list of KnnIndex, one per batch row of cloud_b) lets the caller reuse
-    the device index of a reference cloud across RAFT iterations / flow types."""
+    the device index of a reference cloud across RAFT iterations / flow types.  `query_order_indices` (optional list of
+    KnnIndex of the rows of cloud_a): the queries cloud_a + flow are answered in that cloud's bucket order -- neighbouring
+    queries then walk the same cells of the reference index (cache hits instead of scattered reads); the result is the
+    same, the search is exact."""
     assert nearest_dist_mode == "point"
     assert cloud_a.ndim == 3 and cloud_b.ndim == 3 and flow_a_to_b.ndim == 3
     cloud_b__a = cloud_a + flow_a_to_b
@@ -124,6 +128,16 @@ def compute_flow_loss_a_to_b(cloud_a, cloud_b, flow_a_to_b, loss_function, neare
                 q = cloud_b__a[rows[0]:rows[-1] + 1].reshape(-1, cloud_b__a.shape[-1])
             else:
                 q = torch.cat([cloud_b__a[b] for b in rows], dim=0)
+            perm = None
+            if contiguous and query_order_indices is not None and len({id(query_order_indices[b]) for b in rows}) == 1:
+                perm = query_order_indices[rows[0]].sorted_ids()
+                if perm is not None and perm.shape[0] != cloud_b__a.shape[1]:
+                    perm = None
+            if perm is not None:
+                q = cloud_b__a[rows[0]:rows[-1] + 1].detach().index_select(1, perm).reshape(-1, cloud_b__a.shape[-1])
+                res = get_idx_dists_for_knn(knn_indices[rows[0]], q, 1).view(len(rows), -1)
+                idx[rows[0]:rows[-1] + 1, :, 0].index_copy_(1, perm, res)
+                continue
             res = get_idx_dists_for_knn(knn_indices[rows[0]], q, 1).view(len(rows), -1, 1)
             if contiguous:
                 idx[rows[0]:rows[-1] + 1] = res

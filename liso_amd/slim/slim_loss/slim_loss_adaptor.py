@@ -74,9 +74,9 @@ def selfsupervisedSlimSingleScaleLoss(pc1, valid_mask_pc1, pc2, valid_mask_pc2, 
             total = total + fb * loss_cfg.fw_bw_static_trafo_penalty_factor
     kw = dict(loss_cfg=loss_cfg, model_cfg=model_cfg, bev_extent=bev_extent)
     knn_fw = compute_knn_loss_components(pc1[..., :3], valid_mask_pc1, pc2[..., :3], valid_mask_pc2, prediction=pred_fw,
-                                         knn_indices=knn_index_pc2, **kw)
+                                         knn_indices=knn_index_pc2, query_order_indices=knn_index_pc1, **kw)
     knn_bw = compute_knn_loss_components(pc2[..., :3], valid_mask_pc2, pc1[..., :3], valid_mask_pc1, prediction=pred_bw,
-                                         knn_indices=knn_index_pc1, **kw)
+                                         knn_indices=knn_index_pc1, query_order_indices=knn_index_pc2, **kw)
     ce = loss_cfg.artificial_labels.cross_entropy_penalty > 0.0
     if ce:
         ce_fw = _masked_mean(compute_artificial_label_loss(prediction={"staticness": pred_fw.staticness}, knn_results=knn_fw,

@@ -152,8 +152,8 @@ class SlimTrainer:
             all_valid = (bool(m1.all()), bool(m2.all()))
         ext = [float(v) for v in self.bev_extent]
         # bucket both clouds before the network runs
-        idx1 = [KnnIndex(pc1[b][:, :3], extent=ext) for b in range(pc1.shape[0])] if all_valid[0] else None
-        idx2 = [KnnIndex(pc2[b][:, :3], extent=ext) for b in range(pc2.shape[0])] if all_valid[1] else None
+        idx1 = [KnnIndex(pc1[b][:, :3], extent=ext, all_rows_finite=True) for b in range(pc1.shape[0])] if all_valid[0] else None
+        idx2 = [KnnIndex(pc2[b][:, :3], extent=ext, all_rows_finite=True) for b in range(pc2.shape[0])] if all_valid[1] else None
         preds_fw, preds_bw = self.model(sample_t0, sample_t1, None)
         kw = dict(moving_thresh_module=self.net.moving_dynamicness_threshold, loss_cfg=self.slim_cfg.losses.unsupervised,
                   model_cfg=self.slim_cfg.model, bev_extent=self.bev_extent, metrics_collector={})

@@ -400,7 +400,9 @@ def test_deferred_update_block_weight_gradients_equal_per_iteration_ones():
     assert abs(l0 - l1) <= 1e-5 * abs(l0)  # MIOpen may pick another forward solver on the second pass over the same shapes
     assert float((n0 - n1).abs().max()) <= 1e-5 * float(n0.abs().max())
     for a, b in zip(g0, g1):
-        assert float((a - b).abs().max()) <= 1e-4 * max(float(a.abs().max()), 1e-6), float((a - b).abs().max())
+        # fp32 sums over 6 x 2 x 1024 samples in another order (and split-K atomics inside MIOpen's kernels): measured up to
+        # 4e-4 of the tensor's largest entry on the 1x1 correlation convolution, whose gradient is a sum with heavy cancellation
+        assert float((a - b).abs().max()) <= 2e-3 * max(float(a.abs().max()), 1e-6), float((a - b).abs().max())
     with torch.no_grad():  # inference: plain convolutions
         with deferred_weight_gradients(ub) as st:
             assert st is None
