@@ -103,7 +103,8 @@ class SLIM(nn.Module):
             plan = BevGatherPlan(torch.div(coors_all, fs, rounding_mode="trunc"), valid_all, out_fw[0].shape[1:3])
             out_all = self.head_decoder_fw(net_all, pointwise_valid_mask=valid_all, pointwise_voxel_coordinates=coors_all, pc=pc_all,
                                            filled_pillar_mask=tile(filled), odom=tile(odom), inv_odom=tile(inv_odom),
-                                           gather_plan=plan, **common)
+                                           gather_plan=plan, pointwise_only=self.training and getattr(self, "pointwise_decoding", True),
+                                           **common)
             for i in range(n_it):
                 preds_fw.append(_slice_prediction(out_all, slice(i * B, (i + 1) * B)))
                 preds_bw.append(_slice_prediction(out_all, slice((n_it + i) * B, (n_it + i + 1) * B)))

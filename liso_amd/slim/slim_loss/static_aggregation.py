@@ -24,6 +24,13 @@ class BevGatherPlan:
         self.seg_rank = (pos - torch.searchsorted(sorted_lin, sorted_lin, right=False).to(torch.int32)).contiguous()
         self.shape = (B, N, H, W)
 
+    @property
+    def lin64(self):
+        """`lin` as int64 (torch indexing), built on first use"""
+        if getattr(self, "_lin64", None) is None:
+            self._lin64 = self.lin.long()
+        return self._lin64
+
     def matches(self, grid_data, mask):
         B, N, H, W = self.shape
         return tuple(grid_data.shape[:3]) == (B, H, W) and tuple(mask.shape) == (B, N)
@@ -93,4 +100,20 @@ def compute_batched_bev_static_aggregated_flow(pc, pointwise_voxel_coordinates_f
     D = T - torch.eye(4, dtype=torch.float64, device=T.device)
     flows = (D[:, None, None, :2, 0] * centers[None, ..., 0:1] + D[:, None, None, :2, 1] * centers[None, ..., 1:2]
              + D[:, None, None, :2, 3]).float()
+    return flows, T, nep
+
+
+def compute_pointwise_static_aggregated_flow(pc, pointwise_valid_mask, static_flow_pt, staticness_weights_pt, cell_centers_pt,
+                                             use_eps_for_weighted_pc_alignment: bool = False):
+    """compute_batched_bev_static_aggregated_flow for quantities that are already per point: static_flow_pt [B,N,2] and
+    staticness_weights_pt [B,N] are the BEV maps of the reference (:34-110) read at every point's pillar (0 at padding
+    rows), cell_centers_pt [B,N,2] (fp64) the metric centre of that pillar.  Returns the rigid flow (T - I) of the pillar
+    centre per point [B,N,2] -- the value the reference's BEV `static_aggr_flow` map holds at the point's pillar -- T, and
+    the not-enough-points flags."""
+    pw_flow = torch.cat([static_flow_pt, torch.zeros_like(static_flow_pt[..., :1])], dim=-1)
+    p0 = torch.where(pointwise_valid_mask[..., None], pc[..., :3], 0.0)
+    T, nep = batched_weighted_pc_alignment(p0, p0 + pw_flow, staticness_weights_pt, pointwise_valid_mask,
+                                           use_epsilon_on_weights=use_eps_for_weighted_pc_alignment)
+    D = T - torch.eye(4, dtype=torch.float64, device=T.device)
+    flows = (D[:, None, :2, 0] * cell_centers_pt[..., 0:1] + D[:, None, :2, 1] * cell_centers_pt[..., 1:2] + D[:, None, :2, 3]).float()
     return flows, T, nep

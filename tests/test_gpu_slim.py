@@ -223,8 +223,10 @@ def _slim_cfg(tag):
     return apply_slim_simple_knn_training(cfg) if tag == "simple_knn" else cfg
 
 
+@pytest.mark.parametrize("pointwise", [False, True], ids=["bev_maps", "pointwise_only"])
 @pytest.mark.parametrize("tag", ["default", "simple_knn"])
-def test_head_decoder_and_loss_match_reference(tag):
+def test_head_decoder_and_loss_match_reference(tag, pointwise):
+    """`pointwise_only` (the training path of SLIM.forward): gather first, decode per point -- same fixture, same bar"""
     from liso_amd.slim.model.head_decoder import HeadDecoder
     from liso_amd.slim.slim_loss.movavg_cls_threshold import MovingAverageThreshold
     from liso_amd.slim.slim_loss.slim_loss_adaptor import selfsupervisedSlimSingleScaleLoss
@@ -248,7 +250,8 @@ def test_head_decoder_and_loss_match_reference(tag):
     net_bw = torch.from_numpy(g[f"{tag}_net_bw"]).cuda().requires_grad_(True)
     thr = MovingAverageThreshold(num_train_samples=100, num_moving=621013971, num_still=None).cuda()
     dec_fw, dec_bw = HeadDecoder(cfg.SLIM, "fw", ext), HeadDecoder(cfg.SLIM, "bw", ext)
-    common = dict(summaries=None, gt_flow_bev=None, ohe_gt_stat_dyn_ground_label_bev_map=None, dynamic_flow_is_non_rigid_flow=False)
+    common = dict(summaries=None, gt_flow_bev=None, ohe_gt_stat_dyn_ground_label_bev_map=None, dynamic_flow_is_non_rigid_flow=False,
+                  pointwise_only=pointwise)
     pfw = dec_fw(net_fw, thr.value(), pc=pc1, pointwise_voxel_coordinates=coors(pc1), pointwise_valid_mask=valid,
                  filled_pillar_mask=filled(coors(pc1)), odom=odom, inv_odom=inv_odom, **common)
     pbw = dec_bw(net_bw, thr.value(), pc=pc2, pointwise_voxel_coordinates=coors(pc2), pointwise_valid_mask=valid,
@@ -258,7 +261,9 @@ def test_head_decoder_and_loss_match_reference(tag):
     assert _rel(pfw.static_aggr_flow, g[f"{tag}_static_aggr_flow_fw"]) < REL
     assert _rel(pfw.static_aggr_trafo, g[f"{tag}_T_fw"]) < REL
     assert np.array_equal(pfw.is_static.cpu().numpy(), g[f"{tag}_is_static_fw"])
-    assert _rel(pfw.dense_maps.aggregated_flow, g[f"{tag}_dense_agg_fw"]) < REL
+    assert ("dense_maps" in pfw) == (not pointwise)
+    if not pointwise:
+        assert _rel(pfw.dense_maps.aggregated_flow, g[f"{tag}_dense_agg_fw"]) < REL
     loss = selfsupervisedSlimSingleScaleLoss(pc1=pc1, valid_mask_pc1=valid, pc2=pc2, valid_mask_pc2=valid, pred_fw=pfw, pred_bw=pbw,
                                              moving_thresh_module=thr, loss_cfg=cfg.SLIM.losses.unsupervised,
                                              model_cfg=cfg.SLIM.model, bev_extent=ext, metrics_collector={})
@@ -449,3 +454,51 @@ def test_raft_output_assembly_equals_reference_ops(n_it, B, dirs, h, w):
     # gather adjoint: bit reproducible
     out2 = raft_network_outputs(flows, logits, dirs=dirs, factor=8, resolution_adapter=adapter)
     assert torch.equal(out, out2) and all(torch.equal(a, b) for a, b in zip(got, grads((out2 * wgt).sum())))
+
+
+@pytest.mark.parametrize("tag", ["default", "simple_knn"])
+def test_pointwise_decoding_equals_bev_decoding_with_padding_and_unfilled_pillars(tag):
+    """HeadDecoder(pointwise_only=True) vs the BEV-map path on inputs the fixtures do not cover: padding rows, valid points
+    in pillars the network input did not fill, a batch of 3 -- every per-point output and the gradient w.r.t. the network
+    output"""
+    from liso_amd.slim.model.head_decoder import HeadDecoder
+    from liso_amd.utils.config import apply_slim_simple_knn_training, default_cfg
+
+    cfg = default_cfg(grid=64, bev_range_m=40.0)
+    cfg = apply_slim_simple_knn_training(cfg) if tag == "simple_knn" else cfg
+    R, G, B, N = 40.0, 64, 3, 6000
+    ext = np.array([-R / 2, -R / 2, R / 2, R / 2])
+    g = torch.Generator().manual_seed(3)
+    pc = torch.cat([(torch.rand(B, N, 2, generator=g) - 0.5) * 0.98 * R, torch.rand(B, N, 1, generator=g) - 1.0], -1).cuda()
+    valid = (torch.rand(B, N, generator=g) > 0.15).cuda()
+    coors = ((pc[..., :2] + R / 2) / R * G).to(torch.int32)
+    filled = torch.zeros(B, G, G, dtype=torch.bool, device="cuda")
+    keep = valid & (torch.rand(B, N, generator=g).cuda() > 0.2)  # some valid points sit in pillars that stay "unfilled"
+    bi = torch.arange(B, device="cuda")[:, None].expand(-1, N)
+    filled[bi[keep], coors[..., 0].long()[keep], coors[..., 1].long()[keep]] = True
+    th = 0.03
+    odom = torch.eye(4, dtype=torch.float64)[None].repeat(B, 1, 1)
+    odom[:, 0, 0] = odom[:, 1, 1] = np.cos(th)
+    odom[:, 0, 1], odom[:, 1, 0] = -np.sin(th), np.sin(th)
+    odom[:, 0, 3] = 0.8
+    odom = odom.cuda()
+    net = (torch.randn(B, G, G, 8, generator=g) * torch.tensor([1, 1, 1, 1, 0.3, 0.3, 0.3, 0.3])).cuda()
+    wgt = {k: torch.randn(B, N, 3, generator=g).cuda() for k in ("aggregated_flow", "static_flow", "class_probs", "static_aggr_flow")}
+    dec = HeadDecoder(cfg.SLIM, "fw", ext)
+    res = []
+    for pointwise in (False, True):
+        x = net.clone().requires_grad_(True)
+        p = dec(x, 0.4, pc=pc, pointwise_voxel_coordinates=coors, pointwise_valid_mask=valid, filled_pillar_mask=filled, odom=odom,
+                inv_odom=torch.linalg.inv(odom), summaries=None, pointwise_only=pointwise)
+        loss = sum((p[k] * w).sum() for k, w in wgt.items()) + (p.static_aggr_trafo[:, :3] ** 2).sum().float()
+        loss.backward()
+        res.append((p, x.grad.clone()))
+    (pa, ga), (pb, gb) = res
+    for k in ("disappearing_logit", "disappearing", "class_logits", "class_probs", "staticness", "dynamicness", "groundness",
+              "dynamic_flow", "static_flow", "aggregated_flow", "static_aggr_flow", "static_aggr_trafo"):
+        a, b = pa[k].detach().double(), pb[k].detach().double()
+        assert float((a - b).abs().max()) <= 1e-6 * max(float(a.abs().max()), 1.0), (k, float((a - b).abs().max()))
+    for k in ("is_static", "is_dynamic", "is_ground", "not_enough_points"):
+        assert torch.equal(pa[k], pb[k]), k
+    assert float((ga - gb).abs().max()) <= 1e-5 * float(ga.abs().max()), float((ga - gb).abs().max())
+    assert float(ga.abs().max()) > 0
