@@ -67,6 +67,14 @@ class HeadDecoder(nn.Module):
         self._gt_cache = (key, (gt_static_flow, gt_pointwise_static_flow))
         return self._gt_cache[1]
 
+    def _extent_vectors(self, device):
+        key = str(device)
+        c = getattr(self, "_extent_cache", None)
+        if c is None or c[0] != key:
+            e = np.asarray(self.bev_extent, dtype=np.float64)
+            self._extent_cache = (key, torch.from_numpy(e[:2].copy()).to(device), torch.from_numpy((e[2:] - e[:2]).copy()).to(device))
+        return self._extent_cache[1], self._extent_cache[2]
+
     def _cell_centers(self, final_grid_size, device):
         key = (tuple(int(v) for v in final_grid_size), str(device))
         if key not in self._centers:
@@ -230,8 +238,11 @@ class HeadDecoder(nn.Module):
         if any(v is True or v is False for v in (om.static_logit, om.dynamic_logit, om.ground_logit)):
             lg = network_output[..., :4].detach()
             extremes = (lg.amax(dim=(0, 1, 2)), lg.amin(dim=(0, 1, 2)))
-        centers, _ = self._cell_centers((H, W), inv_odom.device)
-        centers_pt = centers.view(H * W, 2)[safe % (H * W)].view(S, N, 1, 2)
+        # metric centre of every point's pillar: get_voxel_center_coords_m's fp64 arithmetic (bev_utils.py:24-40) on the
+        # point's own (row, col) -- bit-identical to reading the [H,W,2] centre map, without a 16-byte-row gather
+        lo, span = self._extent_vectors(inv_odom.device)
+        shape = _cached_vector((float(H), float(W)), inv_odom.device, torch.float64)
+        centers_pt = (((coors_fs.to(torch.float64) + 0.5) / shape) * span + lo).view(S, N, 1, 2)
         homog_pt = torch.cat([centers_pt, torch.zeros_like(centers_pt[..., :1]), torch.ones_like(centers_pt[..., :1])], dim=-1)
         (modified, _, _, _, _, _, _, _, static_aggr_trafo, not_enough_points) = self.apply_output_modification(
             raw.view(S, N, 1, raw.shape[-1]), dynamicness_threshold, pc=pc, pointwise_voxel_coordinates_fs=coors_fs,
