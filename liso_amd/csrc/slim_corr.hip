@@ -17,6 +17,7 @@
 namespace {
 
 constexpr int kWavesPerBlock = 4;
+constexpr int kTransposeStride = 36;  // floats per lane row in the LDS transpose (32 + 4: 16-B aligned, conflict-free columns)
 
 struct LevelPtrs {
     const float* f2[LISO_CORR_MAX_LEVELS];
@@ -42,32 +43,22 @@ __device__ __forceinline__ Patch patch_of(const liso_corr_cfg& c, const float* _
     return p;
 }
 
-// sum over the 32 lanes of each half-wave of 32 per-lane values; lane g (within its half) ends with the total of acc[g]
-__device__ __forceinline__ float transpose_reduce32(float (&acc)[32], int lane) {
-#pragma unroll
-    for (int step = 0; step < 5; step++) {
-        const int mask = 16 >> step;       // lane distance
-        const int n = 16 >> step;          // values that survive this step
-        const bool upper = (lane & mask) != 0;
-#pragma unroll
-        for (int t = 0; t < n; t++) {
-            const float send = upper ? acc[t] : acc[t + n];
-            const float keep = upper ? acc[t + n] : acc[t];
-            acc[t] = keep + __shfl_xor(send, mask);
-        }
-    }
-    return acc[0];
-}
-
 template <int VEC>  // VEC float4 per lane: D = 128 * VEC
 __global__ __launch_bounds__(64 * kWavesPerBlock) void corr_lookup_fwd_kernel(liso_corr_cfg c,
                                                                               const float* __restrict__ fmap1,
                                                                               LevelPtrs lp, const float* __restrict__ coords,
                                                                               float* __restrict__ out) {
     __shared__ float P[kWavesPerBlock][64];
+    __shared__ float T[kWavesPerBlock][64][kTransposeStride];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int hw = c.h * c.w;
-    const long item = (long)blockIdx.x * kWavesPerBlock + wave;  // (b, pix, lvl)
+    // XCD-aware block order: the hardware deals consecutive workgroups round-robin to the 8 XCDs, each with its own 4 MB
+    // L2.  Logical block = (physical % 8) * (blocks / 8) + physical / 8 gives every XCD one contiguous eighth of the
+    // (sample, pixel) range: its level-0 working set is then ~1/4 of one sample's feature map (0.5 MB + halo) instead of
+    // all 5.3 MB of both samples' pyramids, i.e. L2 resident.  (gridDim.x is a multiple of 8.)
+    const long per_xcd = gridDim.x / 8;
+    const long block = (long)(blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    const long item = block * kWavesPerBlock + wave;  // (b, pix, lvl)
     const long total = (long)c.batch * hw * c.levels;
     if (item >= total) return;
     const int lvl = (int)(item % c.levels);
@@ -81,22 +72,44 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void corr_lookup_fwd_kernel(li
     for (int k = 0; k < VEC; k++) f1[k] = *reinterpret_cast<const float4*>(fmap1 + ((size_t)b * hw + pix) * D + (k * 32 + g) * 4);
     const float* f2 = lp.f2[lvl] + (size_t)b * pt.H * pt.W * D;
     float acc[32];
+    // Loads are unconditional (coordinates clamped into the map, the result masked afterwards) and issued 8 patch pixels
+    // at a time: a branch around each load would serialise 32 dependent L2 round trips per wavefront.
+    constexpr int kBatch = 8;
 #pragma unroll
-    for (int t = 0; t < 32; t++) {
-        const int q = 2 * t + half;     // patch index: u = q & 7 (x), v = q >> 3 (y)
-        const int x = pt.x0 + (q & 7), y = pt.y0 + (q >> 3);
-        float s = 0.f;
-        if (x >= 0 && x < pt.W && y >= 0 && y < pt.H) {  // zeros padding of grid_sample
-            const float* row = f2 + ((size_t)y * pt.W + x) * D;
+    for (int t0 = 0; t0 < 32; t0 += kBatch) {
+        float4 v[kBatch][VEC];
+        bool inside[kBatch];
 #pragma unroll
-            for (int k = 0; k < VEC; k++) {
-                const float4 v = *reinterpret_cast<const float4*>(row + (k * 32 + g) * 4);
-                s += f1[k].x * v.x + f1[k].y * v.y + f1[k].z * v.z + f1[k].w * v.w;
-            }
+        for (int j = 0; j < kBatch; j++) {
+            const int q = 2 * (t0 + j) + half;  // patch index: u = q & 7 (x), v = q >> 3 (y)
+            const int x = pt.x0 + (q & 7), y = pt.y0 + (q >> 3);
+            inside[j] = x >= 0 && x < pt.W && y >= 0 && y < pt.H;  // zeros padding of grid_sample
+            const int xc = min(max(x, 0), pt.W - 1), yc = min(max(y, 0), pt.H - 1);
+            const float* row = f2 + ((size_t)yc * pt.W + xc) * D;
+#pragma unroll
+            for (int k = 0; k < VEC; k++) v[j][k] = *reinterpret_cast<const float4*>(row + (k * 32 + g) * 4);
         }
-        acc[t] = s;
+#pragma unroll
+        for (int j = 0; j < kBatch; j++) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < VEC; k++)
+                s += f1[k].x * v[j][k].x + f1[k].y * v[j][k].y + f1[k].z * v[j][k].z + f1[k].w * v[j][k].w;
+            acc[t0 + j] = inside[j] ? s : 0.f;
+        }
     }
-    const float tot = transpose_reduce32(acc, lane);
+    // Sum over the 32 lanes of each half-wave of 32 per-lane values, lane g keeping the total of acc[g]: a transpose through
+    // LDS (8 x 16-B writes per lane, then 32 conflict-free 4-B reads down a column; rows padded to 36 floats).  The
+    // 31-shuffle butterfly this replaces (ds_bpermute) took 97 of the kernel's 123 us: measured 26 us without it.
+    {
+        float4* wrow = reinterpret_cast<float4*>(&T[wave][lane][0]);
+#pragma unroll
+        for (int k = 0; k < 8; k++) wrow[k] = make_float4(acc[4 * k], acc[4 * k + 1], acc[4 * k + 2], acc[4 * k + 3]);
+    }
+    __builtin_amdgcn_wave_barrier();
+    float tot = 0.f;
+#pragma unroll
+    for (int j = 0; j < 32; j++) tot += T[wave][half * 32 + j][g];  // fixed order: bit reproducible
     P[wave][2 * g + half] = tot;
     __builtin_amdgcn_wave_barrier();
     const int W7 = 2 * c.radius + 1;
@@ -166,7 +179,7 @@ int liso_corr_lookup_fwd_f32(const liso_corr_cfg* cfg, const float* fmap1, const
         lp.f2[i] = fmap2_levels[i];
     }
     const long total = (long)cfg->batch * cfg->h * cfg->w * cfg->levels;
-    const unsigned grid = (unsigned)((total + kWavesPerBlock - 1) / kWavesPerBlock);
+    const unsigned grid = (unsigned)(((total + kWavesPerBlock - 1) / kWavesPerBlock + 7) / 8 * 8);  // XCD-aware order
     hipStream_t st = (hipStream_t)stream;
     if (cfg->dim == 128)
         corr_lookup_fwd_kernel<1><<<grid, 64 * kWavesPerBlock, 0, st>>>(*cfg, fmap1, lp, coords, out);

@@ -190,13 +190,21 @@ __device__ __forceinline__ bool ring_search(const Level& L, float qx, float qy, 
                 }
             }
         }
-        // group-wide best (ties -> smaller index)
-#pragma unroll
-        for (int o = 1; o < kGroup; o <<= 1) {
-            const float ob = __shfl_xor(best, o);
-            const int oi = __shfl_xor(best_i, o);
-            if (ob < best || (ob == best && oi < best_i)) { best = ob; best_i = oi; }
+        // group-wide best (ties -> smaller index).  The 16-lane group is one DPP row: quad_perm [1,0,3,2], quad_perm
+        // [2,3,0,1], row_ror:4, row_ror:8 leave every lane with the row minimum -- VALU-rate moves instead of 8 ds_bpermute
+        // round trips through the LDS crossbar per ring (min over (distance, index) is order independent).
+        static_assert(kGroup == 16, "the DPP reduction below assumes one 16-lane row per query");
+#define LISO_KNN_DPP_STEP(CTRL)                                                                                     \
+        {                                                                                                           \
+            const float ob = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(best), CTRL, 0xf, 0xf, false)); \
+            const int oi = __builtin_amdgcn_mov_dpp(best_i, CTRL, 0xf, 0xf, false);                                 \
+            if (ob < best || (ob == best && oi < best_i)) { best = ob; best_i = oi; }                              \
         }
+        LISO_KNN_DPP_STEP(0xB1)
+        LISO_KNN_DPP_STEP(0x4E)
+        LISO_KNN_DPP_STEP(0x124)
+        LISO_KNN_DPP_STEP(0x128)
+#undef LISO_KNN_DPP_STEP
         const float bound = r * g.cell + margin;  // every unvisited point is at least this far (xy distance)
         if (bound > 0.f && best <= bound * bound) return true;
     }
