@@ -130,7 +130,8 @@ def compute_flow_loss_a_to_b(cloud_a, cloud_b, flow_a_to_b, loss_function, neare
                 q = torch.cat([cloud_b__a[b] for b in rows], dim=0)
             perm = None
             if contiguous and query_order_indices is not None and len({id(query_order_indices[b]) for b in rows}) == 1:
-                perm = query_order_indices[rows[0]].sorted_ids()
+                sorted_ids = getattr(query_order_indices[rows[0]], "sorted_ids", None)  # device KnnIndex only
+                perm = sorted_ids() if sorted_ids is not None else None
                 if perm is not None and perm.shape[0] != cloud_b__a.shape[1]:
                     perm = None
             if perm is not None:
