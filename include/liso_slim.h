@@ -155,6 +155,29 @@ int liso_raft_upsample_outputs_fwd_f32(const liso_upsample_cfg* cfg, const float
 int liso_raft_upsample_outputs_bwd_f32(const liso_upsample_cfg* cfg, const float* grad_out, void* scratch, size_t scratch_bytes,
                                        float* grad_flow_lr, float* grad_logits_lr, void* stream);
 
+/* ---- ConvGRU gates of the update block ---------------------------------------------------------------------------------
+ * Replaces the elementwise part of ConvGRU.forward (liso/slim/model/update.py:29-37) between its three convolutions:
+ *     z = sigmoid(convz(hx)); r = sigmoid(convr(hx)); q = tanh(convq(cat([r*h, x]))); h' = (1-z)*h + z*q
+ * 10 ATen launches forward and ~15 backward per RAFT iteration become 2 + 2.  All maps NCHW fp32 (hw = H*W):
+ *   cz, cr  [B,ch,hw]   pre-activations; `zr_batch_stride` (elements) lets them be the channel halves of ONE merged
+ *                       convolution output [B,2ch,hw] (convz and convr read the same input)
+ *   h [B,ch,hw], x [B,cx,hw];  z [B,ch,hw] (saved for the output gate);  rhx [B,ch+cx,hw] = cat([r*h, x]) for convq
+ * in_bwd: g_rhx [B,ch+cx,hw] (+ g_z [B,ch,hw] or NULL) -> g_cz, g_cr (batch stride `gzr_batch_stride`), g_h [B,ch,hw];
+ *         the gradient of x is the tail of g_rhx.   out_fwd/out_bwd: n = B*ch*hw contiguous elements. */
+typedef struct {
+    int batch, ch, cx;
+    long hw;
+} liso_gru_cfg;
+
+int liso_gru_in_fwd_f32(const liso_gru_cfg* cfg, const float* cz, const float* cr, long zr_batch_stride, const float* h,
+                        const float* x, float* z, float* rhx, void* stream);
+int liso_gru_in_bwd_f32(const liso_gru_cfg* cfg, const float* cr, long zr_batch_stride, const float* h, const float* z,
+                        const float* g_z, const float* g_rhx, float* g_cz, float* g_cr, long gzr_batch_stride, float* g_h,
+                        void* stream);
+int liso_gru_out_fwd_f32(long n, const float* cq, const float* z, const float* h, float* out, void* stream);
+int liso_gru_out_bwd_f32(long n, const float* cq, const float* z, const float* h, const float* g_out, float* g_cq, float* g_z,
+                         float* g_h, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -109,6 +109,10 @@ SIGNATURES = {
     "liso_nearest_point_loss_bwd_f32": (_i, [_vp] * 9),
     "liso_bev_gather_fwd_f32": (_i, [_vp, _vp, ctypes.c_long, _i, ctypes.c_float, _vp, _vp]),
     "liso_bev_gather_bwd_f32": (_i, [_vp, _vp, _vp, _vp, ctypes.c_long, _i, _vp, _vp, _vp]),
+    "liso_gru_in_fwd_f32": (_i, [_vp, _vp, _vp, ctypes.c_long, _vp, _vp, _vp, _vp, _vp]),
+    "liso_gru_in_bwd_f32": (_i, [_vp, _vp, ctypes.c_long, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_long, _vp, _vp]),
+    "liso_gru_out_fwd_f32": (_i, [ctypes.c_long, _vp, _vp, _vp, _vp, _vp]),
+    "liso_gru_out_bwd_f32": (_i, [ctypes.c_long, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "liso_raft_upsample_scratch_bytes": (_sz, [_vp]),
     "liso_raft_upsample_outputs_fwd_f32": (_i, [_vp] * 5),
     "liso_raft_upsample_outputs_bwd_f32": (_i, [_vp, _vp, _vp, _sz, _vp, _vp, _vp]),
@@ -151,6 +155,11 @@ class NpLossCfg(ctypes.Structure):
 class BoxPtsCfg(ctypes.Structure):
     """mirror of liso_boxpts_cfg (include/liso_tracking.h)"""
     _fields_ = [("batch", _i), ("n", ctypes.c_long), ("k", _i), ("point_stride", _i), ("precision", _i), ("dims_bloat", _f)]
+
+
+class GruCfg(ctypes.Structure):
+    """mirror of liso_gru_cfg (include/liso_slim.h)"""
+    _fields_ = [("batch", _i), ("ch", _i), ("cx", _i), ("hw", ctypes.c_long)]
 
 
 class UpsampleCfg(ctypes.Structure):

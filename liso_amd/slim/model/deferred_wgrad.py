@@ -20,11 +20,24 @@ _ACTIVE = None
 
 
 class _State:
-    def __init__(self, layers):
-        self.layers = layers
-        self.index = {id(m): i for i, m in enumerate(layers)}
-        self.stash = [[] for _ in layers]
+    """`ops`: tuples of 1 or 2 Conv2d.  A pair shares its input and geometry (ConvGRU's convz / convr): it runs as ONE
+    convolution with the weights concatenated along the output channels."""
+
+    def __init__(self, ops):
+        self.ops = ops
+        self.layers = [op[0] for op in ops]  # geometry (stride / padding / dilation) of every op
+        self.index = {tuple(id(m) for m in op): i for i, op in enumerate(ops)}
+        self.stash = [[] for _ in ops]
+        self.merged = {}  # op index -> (weight, bias) concatenated once per step
         self.token = None
+
+    def weights(self, li):
+        op = self.ops[li]
+        if len(op) == 1:
+            return op[0].weight.detach(), op[0].bias.detach()
+        if li not in self.merged:
+            self.merged[li] = (torch.cat([m.weight.detach() for m in op], dim=0), torch.cat([m.bias.detach() for m in op], dim=0))
+        return self.merged[li]
 
 
 def _pair(v):
@@ -43,17 +56,27 @@ class _ParamGate(torch.autograd.Function):
         params = ctx.saved_tensors
         st = ctx.state
         grads = []
-        for li, layer in enumerate(st.layers):
-            w, b = params[2 * li], params[2 * li + 1]
+        pi = 0
+        for li, op in enumerate(st.ops):
+            mine = params[pi:pi + 2 * len(op)]  # (w, b) of every layer of the op
+            pi += 2 * len(op)
             items, st.stash[li] = st.stash[li], []
             if not items:
-                grads += [torch.zeros_like(w), torch.zeros_like(b)]
+                grads += [torch.zeros_like(p) for p in mine]
                 continue
+            layer = op[0]
+            w, b = st.weights(li)
             x = items[0][0] if len(items) == 1 else torch.cat([i[0] for i in items], dim=0)
             gy = items[0][1] if len(items) == 1 else torch.cat([i[1] for i in items], dim=0)
             _, gw, gb = torch.ops.aten.convolution_backward(gy, x, w, [b.numel()], _pair(layer.stride), _pair(layer.padding),
                                                             _pair(layer.dilation), False, [0, 0], 1, [False, True, True])
-            grads += [gw, gb]
+            if len(op) == 1:
+                grads += [gw, gb]
+            else:
+                sizes = [m.weight.shape[0] for m in op]
+                for gwi, gbi in zip(torch.split(gw, sizes, dim=0), torch.split(gb, sizes, dim=0)):
+                    grads += [gwi, gbi]
+        st.merged.clear()
         return (None, *grads)
 
 
@@ -93,8 +116,11 @@ def deferred_weight_gradients(module: nn.Module, enabled=True):
     if not ok or _ACTIVE is not None:
         yield None
         return
-    st = _State(layers)
-    st.token = _ParamGate.apply(st, *[p for m in layers for p in (m.weight, m.bias)])
+    pairs = [tuple(p) for m in module.modules() for p in getattr(m, "merged_convs", ())]
+    paired = {id(l) for p in pairs for l in p}
+    ops = pairs + [(m,) for m in layers if id(m) not in paired]
+    st = _State(ops)
+    st.token = _ParamGate.apply(st, *[p for op in ops for m in op for p in (m.weight, m.bias)])
     st.zero = st.token.detach()
     _ACTIVE = st
     try:
@@ -105,7 +131,21 @@ def deferred_weight_gradients(module: nn.Module, enabled=True):
 
 def conv2d(layer: nn.Conv2d, x):
     st = _ACTIVE
-    if st is None or id(layer) not in st.index:
+    if st is None or (id(layer),) not in st.index:
         return layer(x)
-    y, st.token = _ConvDeferred.apply(x, st.token, layer.weight.detach(), layer.bias.detach(), st, st.index[id(layer)])
+    li = st.index[(id(layer),)]
+    y, st.token = _ConvDeferred.apply(x, st.token, *st.weights(li), st, li)
+    return y
+
+
+def conv2d_pair(layer_a: nn.Conv2d, layer_b: nn.Conv2d, x):
+    """cat([layer_a(x), layer_b(x)], dim=1) as one convolution (same input, same geometry)"""
+    st = _ACTIVE
+    key = (id(layer_a), id(layer_b))
+    if st is None or key not in st.index:
+        w = torch.cat([layer_a.weight, layer_b.weight], dim=0)
+        b = torch.cat([layer_a.bias, layer_b.bias], dim=0)
+        return F.conv2d(x, w, b, layer_a.stride, layer_a.padding, layer_a.dilation)
+    li = st.index[key]
+    y, st.token = _ConvDeferred.apply(x, st.token, *st.weights(li), st, li)
     return y

@@ -4,7 +4,8 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from liso_amd.slim.model.deferred_wgrad import conv2d
+from liso_amd.slim.model.deferred_wgrad import conv2d, conv2d_pair
+from liso_amd.slim.model.gru_gates import gru_in, gru_out
 
 
 class FlowOrClassificationHead(nn.Module):
@@ -25,10 +26,16 @@ class ConvGRU(nn.Module):
         self.convz = nn.Conv2d(input_dim, hidden_dim, 3, padding=1)
         self.convr = nn.Conv2d(input_dim, hidden_dim, 3, padding=1)
         self.convq = nn.Conv2d(input_dim, hidden_dim, 3, padding=1)
+        self.merged_convs = [(self.convz, self.convr)]  # same input: one convolution with 2 x hidden_dim outputs
+        self.fused_gates = True
 
     def forward(self, h, x):
-        """reference :29-37"""
+        """reference :29-37.  On the GPU (fp32): convz and convr as one convolution, the gate arithmetic in two fused
+        launches (gru_gates.py); otherwise the reference's op sequence."""
         hx = torch.cat([h, x], dim=1)
+        if self.fused_gates and h.is_cuda and h.dtype == torch.float32:
+            z, rhx = gru_in(conv2d_pair(self.convz, self.convr, hx), h, x)
+            return gru_out(conv2d(self.convq, rhx), z, h)
         z = torch.sigmoid(conv2d(self.convz, hx))
         r = torch.sigmoid(conv2d(self.convr, hx))
         q = torch.tanh(conv2d(self.convq, torch.cat([r * h, x], dim=1)))

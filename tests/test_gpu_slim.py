@@ -502,3 +502,36 @@ def test_pointwise_decoding_equals_bev_decoding_with_padding_and_unfilled_pillar
         assert torch.equal(pa[k], pb[k]), k
     assert float((ga - gb).abs().max()) <= 1e-5 * float(ga.abs().max()), float((ga - gb).abs().max())
     assert float(ga.abs().max()) > 0
+
+
+@pytest.mark.parametrize("defer", [False, True], ids=["autograd_wgrad", "deferred_wgrad"])
+def test_fused_conv_gru_equals_reference_op_sequence(defer):
+    """ConvGRU on the GPU: convz | convr as one convolution + liso_gru_{in,out}_* gate kernels vs update.py:29-37's ops
+    (sigmoid, sigmoid, mul, cat, tanh, (1-z)*h + z*q), values and every gradient, over 3 chained steps"""
+    from liso_amd.slim.model.deferred_wgrad import deferred_weight_gradients
+    from liso_amd.slim.model.update import ConvGRU
+
+    torch.manual_seed(1)
+    gru = ConvGRU(hidden_dim=96, input_dim=96 + 146).cuda()
+    B, H, W = 2, 24, 40
+    h0 = torch.randn(B, 96, H, W, device="cuda")
+    xs = [torch.randn(B, 146, H, W, device="cuda") for _ in range(3)]
+    wgt = torch.randn(B, 96, H, W, device="cuda")
+    res = []
+    for fused in (False, True):
+        gru.fused_gates = fused
+        for p in gru.parameters():
+            p.grad = None
+        h = h0.clone().requires_grad_(True)
+        xi = [x.clone().requires_grad_(True) for x in xs]
+        with deferred_weight_gradients(gru, enabled=defer and fused):
+            cur = h
+            for x in xi:
+                cur = gru(cur, x)
+        (cur * wgt).sum().backward()
+        res.append((cur.detach(), h.grad.clone(), [x.grad.clone() for x in xi], [p.grad.clone() for p in gru.parameters()]))
+    (oa, ha, xa, pa), (ob, hb, xb, pb) = res
+    rel = lambda a, b: float((a - b).abs().max()) / max(float(a.abs().max()), 1e-12)  # noqa: E731
+    assert rel(oa, ob) < 1e-5 and rel(ha, hb) < 1e-4
+    assert all(rel(a, b) < 1e-4 for a, b in zip(xa, xb))
+    assert all(rel(a, b) < 1e-3 for a, b in zip(pa, pb)), [rel(a, b) for a, b in zip(pa, pb)]
