@@ -164,7 +164,8 @@ __device__ __forceinline__ bool ring_search(const Level& L, float qx, float qy, 
             if (t < ncell) {
                 int x = cx, y = cy;
                 if (r > 0) {
-                    const int side = t / (2 * r), k = t - side * 2 * r;
+                    const int two_r = 2 * r;  // side = t / (2r) in {0,1,2,3} without an integer division
+                    const int side = (t >= two_r) + (t >= 2 * two_r) + (t >= 3 * two_r), k = t - side * two_r;
                     x = side == 0 ? x0 + k : (side == 1 ? x1 : (side == 2 ? x1 - k : x0));
                     y = side == 0 ? y0 : (side == 1 ? y0 + k : (side == 2 ? y1 : y1 - k));
                 }
