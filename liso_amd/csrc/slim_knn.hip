@@ -119,7 +119,7 @@ __global__ void knn_sorted_ids_kernel(const float4* __restrict__ bucketed, int n
 // in flight), then the group walks every non-empty range together, 16 consecutive float4 per step (256 coalesced
 // bytes) -- vertical structures put hundreds of points into one xy cell, so points, not cells, are the unit of work.
 // A 4-step butterfly picks the group's best (distance, index) once per ring.
-constexpr int kGroup = 16;
+constexpr int kGroup = 16;  // lanes per query (measured: 8 lanes per query -> 1.24 ms per step instead of 1.02: more divergence, more batches)
 
 struct Level {
     liso_knn_grid g;
@@ -177,7 +177,7 @@ __device__ __forceinline__ bool ring_search(const Level& L, float qx, float qy, 
                     }
                 }
             }
-            unsigned nonempty = (unsigned)(__ballot(e > s) >> group_shift) & 0xffffu;
+            unsigned nonempty = (unsigned)(__ballot(e > s) >> group_shift) & ((1u << kGroup) - 1u);
             while (nonempty) {
                 const int j = __ffs(nonempty) - 1;
                 nonempty &= nonempty - 1;
@@ -194,17 +194,21 @@ __device__ __forceinline__ bool ring_search(const Level& L, float qx, float qy, 
         // group-wide best (ties -> smaller index).  The 16-lane group is one DPP row: quad_perm [1,0,3,2], quad_perm
         // [2,3,0,1], row_ror:4, row_ror:8 leave every lane with the row minimum -- VALU-rate moves instead of 8 ds_bpermute
         // round trips through the LDS crossbar per ring (min over (distance, index) is order independent).
-        static_assert(kGroup == 16, "the DPP reduction below assumes one 16-lane row per query");
+        static_assert(kGroup == 8 || kGroup == 16, "the DPP reduction below assumes 8- or 16-lane groups inside one DPP row");
 #define LISO_KNN_DPP_STEP(CTRL)                                                                                     \
         {                                                                                                           \
             const float ob = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(best), CTRL, 0xf, 0xf, false)); \
             const int oi = __builtin_amdgcn_mov_dpp(best_i, CTRL, 0xf, 0xf, false);                                 \
             if (ob < best || (ob == best && oi < best_i)) { best = ob; best_i = oi; }                              \
         }
-        LISO_KNN_DPP_STEP(0xB1)
-        LISO_KNN_DPP_STEP(0x4E)
-        LISO_KNN_DPP_STEP(0x124)
-        LISO_KNN_DPP_STEP(0x128)
+        LISO_KNN_DPP_STEP(0xB1)   // quad_perm [1,0,3,2]
+        LISO_KNN_DPP_STEP(0x4E)   // quad_perm [2,3,0,1]: every quad now holds its minimum in all four lanes
+        if (kGroup == 8) {
+            LISO_KNN_DPP_STEP(0x141)  // row_half_mirror: the other quad of the same 8 lanes
+        } else {
+            LISO_KNN_DPP_STEP(0x124)  // row_ror:4
+            LISO_KNN_DPP_STEP(0x128)  // row_ror:8
+        }
 #undef LISO_KNN_DPP_STEP
         const float bound = r * g.cell + margin;  // every unvisited point is at least this far (xy distance)
         if (bound > 0.f && best <= bound * bound) return true;
