@@ -55,7 +55,11 @@ class HeadDecoder(nn.Module):
         discards.)  It depends on the sweep only, so the 6 RAFT iterations of a step share one evaluation."""
         key = (inv_odom, pc, inv_odom._version, pc._version, homog)
         c = getattr(self, "_gt_cache", None)
-        if c is not None and all(a is b for a, b in zip(c[0], key) if torch.is_tensor(a)) and c[0][2:4] == key[2:4]:
+        # (never while a hipGraph is being captured: a hit would leave the computation out of the graph and every replay
+        # would keep the values of the capture-time inputs)
+        capturing = inv_odom.is_cuda and torch.cuda.is_current_stream_capturing()
+        if (not capturing and c is not None and all(a is b for a, b in zip(c[0], key) if torch.is_tensor(a))
+                and c[0][2:4] == key[2:4]):
             return c[1]
         M = inv_odom.double() - torch.eye(4, dtype=torch.float64, device=inv_odom.device)[None]
         hb = homog if homog.dim() == 4 else homog[None]  # [B,N,1,4] (per point, pointwise decoding) or the shared [H,W,4]
@@ -64,6 +68,8 @@ class HeadDecoder(nn.Module):
         p64 = pc[:, :, :3].to(torch.float64)
         gt_pointwise_static_flow = (M[:, None, :3, 0] * p64[..., 0:1] + M[:, None, :3, 1] * p64[..., 1:2]
                                     + M[:, None, :3, 2] * p64[..., 2:3] + M[:, None, :3, 3]).to(torch.float32)
+        if capturing:
+            return gt_static_flow, gt_pointwise_static_flow
         self._gt_cache = (key, (gt_static_flow, gt_pointwise_static_flow))
         return self._gt_cache[1]
 
