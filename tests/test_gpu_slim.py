@@ -272,7 +272,8 @@ def test_head_decoder_and_loss_match_reference(tag, pointwise):
     assert _rel(net_fw.grad, g[f"{tag}_g_fw"]) < 5e-3 and _rel(net_bw.grad, g[f"{tag}_g_bw"]) < 5e-3
 
 
-def test_slim_trainer_hipgraph_step_equals_eager_step():
+@pytest.mark.parametrize("grid,rng,n_points", [(256, 50.0, 30000), (128, 40.0, 10000)])
+def test_slim_trainer_hipgraph_step_equals_eager_step(grid, rng, n_points):
     """SlimTrainer(use_graph=True): forward+loss+backward replayed from a hipGraph (inputs copied into the captured
     buffers, flat gradient buffer) must train exactly like the eager step: same losses, same weights, same BatchNorm /
     threshold buffers after 3 steps on 2 different sweep pairs"""
@@ -281,10 +282,10 @@ def test_slim_trainer_hipgraph_step_equals_eager_step():
     from liso_amd.utils.config import apply_slim_simple_knn_training, default_cfg
 
     dev = torch.device("cuda")
-    pairs = [slim_pair(40 + i, dev, n_points=30000, grid=256, bev_range_m=50.0) for i in range(2)]
+    pairs = [slim_pair(40 + i, dev, n_points=n_points, grid=grid, bev_range_m=rng) for i in range(2)]
     out = []
     for use_graph in (False, True):
-        cfg = apply_slim_simple_knn_training(default_cfg(grid=256, bev_range_m=50.0))
+        cfg = apply_slim_simple_knn_training(default_cfg(grid=grid, bev_range_m=rng))
         torch.manual_seed(0)
         tr = SlimTrainer(cfg, dev, use_graph=use_graph)
         losses = [float(tr.step(*pairs[i % 2])) for i in range(3)]
