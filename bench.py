@@ -301,7 +301,8 @@ def main():
                         "512x512 BEV pillars, fwd+bwd+AdamW")
         pmc_patterns = {"slim": {"knn_query": ["knn_query_kernel"], "corr_lookup_fwd": ["corr_lookup_fwd_kernel"]}.get(key),
                         "detector": ["pfn_decorate_kernel", "pfn_forward_kernel"],
-                        "loop": {"corr_lookup_fwd": ["corr_lookup_fwd_kernel"]}.get(key)}[args.workload]
+                        "loop": {"corr_lookup_fwd": ["corr_lookup_fwd_kernel"],
+                                 "dbscan_components": ["dbscan_core_kernel", "dbscan_union_kernel", "dbscan_flatten_kernel"]}.get(key)}[args.workload]
         traffic = pmc_traffic(args.workload, pmc_patterns) if pmc_patterns else None
         avg_ms = sum(durs[key]) / max(len(durs[key]), 1)
         if args.workload == "detector":  # the pillar pass is two launches (decorate, forward): time them as one unit
