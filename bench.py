@@ -64,7 +64,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=None, help="detector workload: clouds per GPU (default 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true",
-                    help="slim workload: replay forward+loss+backward from a hipGraph (immune to host jitter: a steady 26 ms per "
+                    help="slim workload: replay forward+loss+backward from a hipGraph (immune to host jitter: a steady 24.5 ms per "
                          "step; eager launches are 22-23 ms on an idle host and up to 30 ms on a busy one, and only eager steps "
                          "can carry the per-kernel HIP events inside the timed region, so eager is the default)")
     ap.add_argument("--conv-benchmark", action="store_true",

@@ -30,6 +30,8 @@ class _State:
         self.stash = [[] for _ in ops]
         self.merged = {}  # op index -> (weight, bias) concatenated once per step
         self.token = None
+        self.direct_accumulate = False
+        self.params = []
 
     def weights(self, li):
         op = self.ops[li]
@@ -77,6 +79,17 @@ class _ParamGate(torch.autograd.Function):
                 for gwi, gbi in zip(torch.split(gw, sizes, dim=0), torch.split(gb, sizes, dim=0)):
                     grads += [gwi, gbi]
         st.merged.clear()
+        if st.direct_accumulate:
+            # hipGraph capture: add into the (pre-existing) .grad buffers here, on the capturing stream.  Handing the gradients
+            # to autograd's AccumulateGrad nodes would run them on the stream those nodes were created on (the warm-up's), a
+            # cross-stream hop that a capture cannot contain: wrong values / a crash, depending on the sizes (measured).
+            with torch.no_grad():
+                for src, g in zip(st.params, grads):
+                    if src.grad is None:
+                        src.grad = g.clone()
+                    else:
+                        src.grad.add_(g)
+            return (None,) * (1 + len(params))
         return (None, *grads)
 
 
@@ -106,8 +119,10 @@ class _ConvDeferred(torch.autograd.Function):
 
 
 @contextlib.contextmanager
-def deferred_weight_gradients(module: nn.Module, enabled=True):
-    """Inside the context, `conv2d(layer, x)` of any Conv2d of `module` (groups == 1, with bias) defers its weight gradient."""
+def deferred_weight_gradients(module: nn.Module, enabled=True, direct_accumulate=False):
+    """Inside the context, `conv2d(layer, x)` of any Conv2d of `module` (groups == 1, with bias) defers its weight gradient.
+    `direct_accumulate`: the gate adds the weight gradients into `param.grad` itself instead of returning them to autograd
+    (for hipGraph capture; bypasses gradient hooks, so not for DistributedDataParallel)."""
     global _ACTIVE
     layers = [m for m in module.modules() if isinstance(m, nn.Conv2d)]
     ok = (enabled and torch.is_grad_enabled() and layers and all(m.groups == 1 and m.bias is not None and m.weight.requires_grad
@@ -120,7 +135,9 @@ def deferred_weight_gradients(module: nn.Module, enabled=True):
     paired = {id(l) for p in pairs for l in p}
     ops = pairs + [(m,) for m in layers if id(m) not in paired]
     st = _State(ops)
-    st.token = _ParamGate.apply(st, *[p for op in ops for m in op for p in (m.weight, m.bias)])
+    st.direct_accumulate = bool(direct_accumulate)
+    st.params = [p for op in ops for m in op for p in (m.weight, m.bias)]
+    st.token = _ParamGate.apply(st, *st.params)
     st.zero = st.token.detach()
     _ACTIVE = st
     try:

@@ -113,8 +113,8 @@ class RAFT(nn.Module):
                 and b % fused_dirs == 0)
         lowres_flows, lowres_logits = [], []
         # weight gradients of the update block: one convolution per layer over all iterations (deferred_wgrad.py)
-        defer = self.training and getattr(self, "defer_update_block_wgrad", True)
-        with deferred_weight_gradients(self.update_block, enabled=defer):
+        mode = getattr(self, "defer_update_block_wgrad", True)  # True | False | "direct" (hipGraph capture, see trainer.py)
+        with deferred_weight_gradients(self.update_block, enabled=self.training and bool(mode), direct_accumulate=mode == "direct"):
             for it in range(m.num_iters):
                 coords1 = coords1.detach()
                 if not vanilla:

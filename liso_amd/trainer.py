@@ -126,10 +126,10 @@ class SlimTrainer:
         self.bev_extent = np.concatenate([-half, half], axis=0)
         self._graph, self._graph_sig = None, None
         if self.use_graph:
-            # the once-per-step weight gradients of the update block (deferred_wgrad.py) are an eager-mode optimisation: captured
-            # into a hipGraph they produced wrong losses at some sizes (smoke config: 4.02 instead of 3.56) -- not tracked down,
-            # so the graph path keeps autograd's per-iteration weight gradients
-            self.net.raft_network.defer_update_block_wgrad = False
+            # once-per-step weight gradients of the update block (deferred_wgrad.py): inside a captured graph the gate adds them
+            # into the flat gradient buffer itself ("direct"); returned to autograd they would go through AccumulateGrad nodes
+            # bound to the warm-up's stream -- a cross-stream hop the capture cannot contain (wrong losses / crashes, measured)
+            self.net.raft_network.defer_update_block_wgrad = "direct"
             params = [p for p in self.net.parameters() if p.requires_grad]
             self._flat_grad = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=device)
             off = 0
