@@ -4,21 +4,24 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-Default workload (`--workload slim`, BASELINE.json configs[1], the configuration the metric is quoted on): a "step" =
-one SLIM self-supervised TRAIN step (pillar-encode both clouds -> RAFT fwd+bw, 6 iterations each -> flow/class
-decoder with weighted Kabsch -> kNN loss over all 6 iterations -> backward -> [RCCL gradient all-reduce] -> RMSprop)
-on one pair of synthetic KITTI-shaped 120k-point clouds already resident in HBM, B=1 per GPU as in the reference's
-`slim_RAFT batch_size_one`; a step consumes 2 frames.
-`--workload detector` (configs[2]): one CenterPoint-pillar detector train step (voxelise -> fused PFN/scatter -> BEV
-backbone -> CenterHead -> decode -> loss -> backward -> [all-reduce] -> AdamW -> OneCycleLR), B=4 clouds per GPU.
-`--workload loop` (configs[3]): the fused LISO iteration -- SLIM forward (no_grad) -> flow clusters (DBSCAN) -> NMS ->
-target maps -> detector train step, one sweep pair per GPU.
+Default workload (`--workload loop`, BASELINE.json configs[3] at N GPUs, the workload north_star's "Target" sentence
+defines the metric on): a "step" = one fused LISO iteration per GPU -- SLIM forward (no_grad) on a pair of 120k-point
+sweeps -> per-point flow -> FlowClusterDetector (BEV dynamicness, DBSCAN, region moments, z fit, Kabsch heading) ->
+rotated NMS -> CenterPoint target maps -> CenterPoint-pillar detector train step (fwd + bwd + [RCCL gradient all-reduce]
++ AdamW + OneCycleLR), inputs resident in HBM; a step consumes 2 frames.  The same JSON line carries `iou3d_nms`
+(boxes/s of the NMS entry point incl. the device greedy sweep, pairs/s of the IoU matrix; the second half of
+BASELINE.json's metric), `roofline` (the hand-written kernel family with the largest share of the step's GPU time,
+HIP events on the launch stream) and `cpu_baseline` (the oracle port of the same iteration on the host cores).
+`--workload slim` (configs[1]): one SLIM self-supervised TRAIN step on one pair, B=1 per GPU as in the reference's
+`slim_RAFT batch_size_one`.  `--workload detector` (configs[2]): one detector train step, B=4 clouds per GPU, bf16.
+`--workload iou3d`: only the iou3d_nms section.
 Weak scaling: per-GPU work fixed, samples sharded across ranks by seed, the only collective is the gradient
-all-reduce.  Rank 0 prints ONE JSON line.
+all-reduce.  Rank 0 prints ONE JSON line.  `python bench.py --gpus N` without a launcher starts the N ranks itself.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -28,10 +31,9 @@ sys.path.insert(0, ROOT)
 
 def _seed_miopen_user_db():
     """MIOpen keeps the solver picks / tuning parameters it finds in a per-user database; a fresh machine starts from
-    heuristics (detector step 8.9 ms) and only reaches the tuned state (6.0-6.6 ms) after several processes have run.
-    liso_amd/miopen_db/ holds that database as harvested on an MI355X with this ROCm image; every process works on a
-    private copy (MIOpen appends to it).  Must run before MIOpen initialises; no effect if the files do not match the
-    installed MIOpen version."""
+    heuristics and only reaches the tuned state after several processes have run.  liso_amd/miopen_db/ holds that
+    database as harvested on an MI355X with this ROCm image (for the layers that still go through MIOpen); every
+    process works on a private copy.  Must run before MIOpen initialises."""
     src = os.path.join(ROOT, "liso_amd", "miopen_db")
     if "MIOPEN_USER_DB_PATH" in os.environ or not os.path.isdir(src) or "--no-miopen-db" in sys.argv:
         return
@@ -43,15 +45,13 @@ def _seed_miopen_user_db():
     os.environ["MIOPEN_USER_DB_PATH"] = dst
 
 
-_seed_miopen_user_db()
-
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 N_POINTS = 120000
 GRID = 512
 BEV_RANGE = 100.0
 BATCH_PER_GPU = 4
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+MFMA_PEAK_BF16_TF = 2500.0  # dense bf16 MFMA
+VALU_PEAK_F32_TF = 157.3    # fp32 vector peak
 
 
 def parse():
@@ -60,86 +60,129 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--workload", default="slim", choices=["slim", "detector", "loop"])
+    ap.add_argument("--workload", default="loop", choices=["loop", "slim", "detector", "iou3d"])
     ap.add_argument("--batch", type=int, default=None, help="detector workload: clouds per GPU (default 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-iou3d", action="store_true", help="skip the iou3d_nms section of the line")
     ap.add_argument("--graph", action="store_true",
-                    help="slim workload: replay forward+loss+backward from a hipGraph (immune to host jitter: a steady 24.5 ms per "
-                         "step; eager launches are 22-23 ms on an idle host and up to 30 ms on a busy one, and only eager steps "
-                         "can carry the per-kernel HIP events inside the timed region, so eager is the default)")
-    ap.add_argument("--conv-benchmark", action="store_true",
-                    help="torch.backends.cudnn.benchmark = True: MIOpen re-times its solvers in this process (run-to-run "
-                         "variation of the picks: 540-620 frames/s on the detector); default: the picks of the seeded database")
+                    help="slim workload: replay forward+loss+backward from a hipGraph (host-independent step time)")
+    ap.add_argument("--conv-benchmark", action="store_true", help="torch.backends.cudnn.benchmark = True (MIOpen layers only)")
     ap.add_argument("--no-miopen-db", action="store_true", help="do not seed MIOpen's user database from liso_amd/miopen_db/")
-    ap.add_argument("--nhwc", action="store_true", help="slim workload: conv filters in channels-last memory format (slower)")
+    ap.add_argument("--miopen-convs", action="store_true",
+                    help="route every convolution through MIOpen instead of the own MFMA kernels (comparison runs)")
     return ap.parse_args()
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` (no launcher): start N ranks as child processes BEFORE anything touches the GPU in this
+    process (never exec from a process that has initialised HIP) and exit with the worst of their codes."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    codes = [p.wait() for p in procs]
+    sys.exit(max(abs(c) for c in codes))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# algorithmic bytes / flops per launch of the timed kernel families (SURVEY.md 8d); conv families report flops at the
+# call site (units = 2 * M * N * K of the implicit GEMM)
 def pfn_algorithmic_bytes(batch, n_points, grid, out_bytes):
-    """SURVEY.md 8(d), pillar path: read the points once (N*C*4 B) + write the dense canvas once (64*G^2*s B) +
-    occupancy (G^2*4 B), per sample."""
+    """pillar path: read the points once (N*C*4 B) + write the dense canvas once (64*G^2*s B) + occupancy (G^2*4 B)"""
     return batch * (n_points * 4 * 4 + 64 * grid * grid * out_bytes + grid * grid * 4)
 
 
 def slim_algorithmic_bytes(batch, n_points, grid, levels=4, radius=3, directions=2):
-    """SURVEY.md 8(d), SLIM rows, per launch:
-    corr lookup (fwd, and its adjoint bwd), per sample: levels * hw * (2r+1)^2 bilinear reads of 4 taps * 4 B + the
-      [hw, levels*(2r+1)^2] fp32 output, hw = (G/8)^2;
-    1-NN query: (N_q + N_ref) * 12 B in + N_q * 8 B out."""
     hw = (grid // 8) ** 2
     w2 = (2 * radius + 1) ** 2
-    # training: the forward and the backward flow direction of every pair share one launch (2 * batch samples per lookup);
-    # the box miner of the loop workload runs the forward direction only
     lookup = directions * batch * (levels * hw * w2 * 4 * 4 + hw * levels * w2 * 4)
-    # RAFT output assembly: [6 iterations x directions x batch, G, G, 8] fp32 written (fwd) / read (bwd) once + the low-res maps
     outputs = 6 * directions * batch * (grid * grid * 8 * 4 + hw * 6 * 4)
     return {"corr_lookup_fwd": lookup, "corr_lookup_bwd": lookup, "knn_query": 2 * n_points * 12 + n_points * 8,
             "raft_outputs_fwd": outputs, "raft_outputs_bwd": outputs}
 
 
-SLIM_KERNELS = {
-    "corr_lookup_fwd": "corr_lookup_fwd_kernel (on-the-fly 4-level correlation + bilinear lookup)",
-    "corr_lookup_bwd": "corr_lookup_bwd_kernel (adjoint of the lookup into fmap1 / pooled fmap2 gradients)",
-    "knn_query": "knn_query_kernel (exact 1-NN, two-level bucket grid with z bins, 16 lanes per query, one launch)",
-    "raft_outputs_fwd": "upsample_fwd_kernel (x8 bilinear upsampling + flow convention + concat of all RAFT iterations)",
-    "raft_outputs_bwd": "upsample_bwd_x/y kernels (adjoint of the output assembly, two gather passes)",
+KERNELS = {  # timer name -> (kernel description, bound, unit of `units`)
+    "conv_bf16_fwd": ("conv_igemm_kernel<bf16> forward (NHWC implicit GEMM on v_mfma_f32_32x32x16_bf16, fused BN-apply "
+                      "prologue / bias+ReLU+BN-statistics epilogue)", "mfma", "flop"),
+    "conv_bf16_dgrad": ("conv_igemm_kernel<bf16> data gradient", "mfma", "flop"),
+    "conv_bf16_wgrad": ("conv_wgrad_kernel<bf16> weight gradient (transposed LDS reads, split over pixels)", "mfma", "flop"),
+    "conv_f32x3_fwd": ("conv_igemm_kernel<bf16x3> forward (fp32 tensors, hi/lo bf16 split, 3 MFMAs per product)", "mfma", "flop"),
+    "conv_f32x3_dgrad": ("conv_igemm_kernel<bf16x3> data gradient", "mfma", "flop"),
+    "conv_f32x3_wgrad": ("conv_wgrad_kernel<bf16x3> weight gradient", "mfma", "flop"),
+    "pfn_forward_scatter": ("pfn_forward_kernel (Linear+BN+ReLU+max + dense scatter from CSR feature rows)", "hbm", "bytes"),
+    "pfn_decorate": ("pfn_decorate_kernel (+3 scan kernels)", "hbm", "bytes"),
+    "corr_lookup_fwd": ("corr_lookup_fwd_kernel (on-the-fly 4-level correlation + bilinear lookup)", "hbm", "bytes"),
+    "corr_lookup_bwd": ("corr_lookup_bwd_kernel (adjoint of the lookup into the dense volume gradient)", "hbm", "bytes"),
+    "knn_query": ("knn_query_kernel (exact 1-NN, two-level bucket grid with z bins, 16 lanes per query)", "hbm", "bytes"),
+    "raft_outputs_fwd": ("upsample_fwd_kernel (x8 bilinear upsampling + flow convention + concat of all RAFT iterations)", "hbm", "bytes"),
+    "raft_outputs_bwd": ("upsample_bwd_x/y kernels (adjoint of the output assembly)", "hbm", "bytes"),
+    "bev_dynamic_flow": ("bev_scatter_kernel + bev_mean_kernel (non-rigid flow, fixed-point scatter-mean)", "hbm", "bytes"),
+    "dbscan_components": ("dbscan core/union/flatten kernels (grid-window DBSCAN)", "hbm", "bytes"),
+    "dbscan_labels": ("dbscan_label_kernel", "hbm", "bytes"),
+    "region_props": ("region_moments_kernel + region_props_kernel", "hbm", "bytes"),
+    "kabsch_trafos": ("kabsch_moments_kernel + kabsch_solve_kernel (soft masks + weighted Kabsch)", "hbm", "bytes"),
+    "fit_box_z": ("fit_z_kernel (points-in-box z extent)", "hbm", "bytes"),
+    "bn_fwd": ("bn_stats/finalize/apply kernels (BatchNorm2d+ReLU forward)", "hbm", "bytes"),
+    "bn_bwd": ("bn_bwd_reduce/finalize/dx kernels (BatchNorm2d+ReLU backward)", "hbm", "bytes"),
 }
 
 
-LOOP_KERNELS = {  # name -> (description, algorithmic bytes per launch at B=1, N=120k, G=512; SURVEY.md 8d)
-    "pfn_forward_scatter": ("pfn_forward_kernel (Linear+BN+ReLU+max + dense scatter from CSR feature rows)", None),
-    "corr_lookup_fwd": (SLIM_KERNELS["corr_lookup_fwd"], None),
-    "bev_dynamic_flow": ("bev_scatter_kernel + bev_mean_kernel (non-rigid flow, fixed-point scatter-mean)",
-                         N_POINTS * (12 + 12 + 8 + 1) + GRID * GRID * 16),
-    "dbscan_components": ("dbscan core/union/flatten kernels (grid-window DBSCAN)", GRID * GRID * (1 + 12 + 1 + 4 + 4)),
-    "dbscan_labels": ("dbscan_label_kernel", GRID * GRID * (1 + 12 + 1 + 4 + 4 + 4)),
-    "kabsch_trafos": ("kabsch_moments_kernel + kabsch_solve_kernel (soft masks + weighted Kabsch)", N_POINTS * (12 + 8 + 1)),
-    "fit_box_z": ("fit_z_kernel (points-in-box z extent)", N_POINTS * 12),
-}
+def static_algorithmic_bytes(workload, batch, dtype_bytes):
+    """bytes per launch for the families whose call sites do not report units (B = 1 in the loop)"""
+    a = dict(slim_algorithmic_bytes(batch, N_POINTS, GRID, directions=1 if workload == "loop" else 2))
+    a["pfn_forward_scatter"] = pfn_algorithmic_bytes(batch, N_POINTS, GRID, dtype_bytes)
+    a["pfn_decorate"] = batch * N_POINTS * (16 + 48)
+    a["bev_dynamic_flow"] = batch * (N_POINTS * (12 + 12 + 8 + 1) + GRID * GRID * 16)
+    a["dbscan_components"] = batch * GRID * GRID * (1 + 12 + 1 + 4 + 4)
+    a["dbscan_labels"] = batch * GRID * GRID * (1 + 12 + 1 + 4 + 4 + 4)
+    a["region_props"] = batch * GRID * GRID * 4
+    a["kabsch_trafos"] = batch * N_POINTS * (12 + 8 + 1)
+    a["fit_box_z"] = batch * N_POINTS * 12
+    return a
 
 
 def pmc_traffic(workload, patterns):
     """HBM bytes per launch of the roofline kernel(s) from the committed rocprofv3 PMC passes of this bench command
-    (profiles/r01_<workload>_pmc_{FETCH,WRITE}_SIZE.csv; counters cannot be collected from inside the timed process).
-    MI355X_MICROARCH.md: both counters are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of wide streaming
-    reads, so reads are doubled (an upper bracket for the narrow / scattered reads of these kernels)."""
+    (profiles/r0N_<workload>_pmc_{FETCH,WRITE}_SIZE.csv, newest round first; counters cannot be collected from inside the
+    timed process).  MI355X_MICROARCH.md: both counters are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of
+    wide streaming reads, so reads are doubled."""
     import csv
+    import glob
 
-    total = 0.0
-    for pat in patterns:
-        for kind, factor in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
-            path = os.path.join(ROOT, "profiles", f"r01_{workload}_pmc_{kind}.csv")
-            if not os.path.exists(path):
-                return None
-            vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path)) if pat in r["Kernel_Name"]]
-            if not vals:
-                return None
-            total += factor * 1024.0 * sum(vals) / len(vals)
-    return total
+    for rnd in sorted({os.path.basename(p)[:3] for p in glob.glob(os.path.join(ROOT, "profiles", f"r*_{workload}_pmc_*.csv"))},
+                      reverse=True):
+        total, ok = 0.0, True
+        for pat in patterns:
+            for kind, factor in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
+                path = os.path.join(ROOT, "profiles", f"{rnd}_{workload}_pmc_{kind}.csv")
+                vals = ([float(r["Counter_Value"]) for r in csv.DictReader(open(path)) if pat in r["Kernel_Name"]]
+                        if os.path.exists(path) else [])
+                if not vals:
+                    ok = False
+                    break
+                total += factor * 1024.0 * sum(vals) / len(vals)
+            if not ok:
+                break
+        if ok:
+            return total, f"profiles/{rnd}_{workload}_pmc_*.csv (separate rocprofv3 --pmc passes of this command; 2 x FETCH_SIZE + WRITE_SIZE, KiB)"
+    return None, None
 
 
-def cpu_baseline_detector(trainer, pcls, targets):
-    """The oracle port of the same train step (fwd+bwd) on the host cores, ONE frame (bounded sample)."""
+PMC_PATTERNS = {"conv_bf16_fwd": ["conv_igemm_kernel"], "conv_bf16_dgrad": ["conv_igemm_kernel"], "conv_bf16_wgrad": ["conv_wgrad_kernel"],
+                "conv_f32x3_fwd": ["conv_igemm_kernel"], "conv_f32x3_dgrad": ["conv_igemm_kernel"], "conv_f32x3_wgrad": ["conv_wgrad_kernel"],
+                "knn_query": ["knn_query_kernel"], "corr_lookup_fwd": ["corr_lookup_fwd_kernel"],
+                "pfn_forward_scatter": ["pfn_forward_kernel"],
+                "dbscan_components": ["dbscan_core_kernel", "dbscan_union_kernel", "dbscan_flatten_kernel"]}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def cpu_baseline_detector(trainer, pcls, targets, torch):
     from oracle.train_step import timed_detector_step
 
     sd = {k: v.detach().float().cpu() for k, v in trainer.net.state_dict().items()}
@@ -150,8 +193,7 @@ def cpu_baseline_detector(trainer, pcls, targets):
             "sample": f"1 frame ({N_POINTS} pts, {GRID}x{GRID} BEV) fwd+bwd, fp32, torch-CPU oracle, {secs:.2f} s"}
 
 
-def cpu_baseline_slim(cfg, trainer, s0, s1):
-    """The CPU port of the same SLIM step (oracle/slim_step.py) on the host cores: ONE pair = 2 frames."""
+def cpu_baseline_slim(cfg, trainer, s0, s1, torch):
     from oracle.slim_step import timed_slim_step
 
     sd = {k: v.detach().cpu() for k, v in trainer.net.state_dict().items()}
@@ -162,9 +204,89 @@ def cpu_baseline_slim(cfg, trainer, s0, s1):
                       f"fp32, torch-CPU port with explicit correlation volume + cKDTree, {secs:.2f} s"}
 
 
+def cpu_baseline_loop(cfg, trainer, s0, s1, torch):
+    """oracle/liso_loop.py: the same fused iteration on the host cores, ONE sweep pair (bounded sample)"""
+    from oracle.liso_loop import timed_loop_step
+
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    secs, stages, n = timed_loop_step(cfg, {k: v.detach().float().cpu() for k, v in trainer.slim.state_dict().items()},
+                                      trainer.detector.net.state_dict(), s0, s1, GRID, BEV_RANGE)
+    return {"value": 2.0 / secs, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 sweep pair = 2 frames ({N_POINTS} pts each, {GRID}x{GRID} BEV), one fused LISO iteration (SLIM fwd, "
+                      f"sklearn DBSCAN + moments + Kabsch, NMS, targets, detector fwd+bwd), fp32 torch-CPU port, {secs:.2f} s, "
+                      f"{n} mined boxes", "stage_seconds": {k: round(v, 4) for k, v in stages.items()}}
+
+
+def bench_iou3d(dev, torch, with_cpu=True):
+    """BASELINE.json metric, second half (SURVEY.md 8d ii): boxes/s of one nms_gpu-equivalent call INCLUDING the device
+    greedy sweep, pairs/s of the rotated IoU matrix, at N in {256, 1000, 4096}; random car-like boxes (the oracle's
+    generator, xy in +-50 m), sorted by score; HIP events on the launch stream, inputs resident in HBM.  VALU fraction at
+    SURVEY's fixed 600 flop per pair vs the 157.3 TFLOP/s fp32 vector peak; the C oracle (single thread, like the
+    reference's serial boxes_iou_bev_cpu + greedy loop) timed beside it."""
+    import numpy as np
+
+    from liso_amd import iou3d_nms_cuda as M
+    from oracle import iou3d as O
+
+    out = {"flop_per_pair": 600, "valu_peak_tflops": VALU_PEAK_F32_TF, "thresh": 0.1, "sizes": {}}
+    for n in (256, 1000, 4096):
+        b, s = O.random_boxes(n, 1, 50.0)
+        b = b[np.argsort(-s, kind="stable")]
+        tb = torch.from_numpy(b).to(dev)
+        iou = torch.zeros(n, n, device=dev)
+        reps = 50 if n <= 1000 else 20
+
+        def timed(fn):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            e = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+            for a, z in e:
+                a.record()
+                fn()
+                z.record()
+            torch.cuda.synchronize()
+            t = sorted(a.elapsed_time(z) for a, z in e)
+            return t[len(t) // 2] * 1e-3
+
+        t_nms = timed(lambda: M.nms_gpu_device(tb, 0.1))
+        t_iou = timed(lambda: M.boxes_iou_bev_gpu(tb, tb, iou))
+        keep = torch.zeros(n, dtype=torch.int64)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            M.nms_gpu(tb, keep, 0.1)
+        t_api = (time.perf_counter() - t0) / 5
+        row = {"nms_boxes_per_s": n / t_nms, "nms_ms": 1e3 * t_nms, "nms_host_api_ms": 1e3 * t_api,
+               "nms_pairs_per_s": n * (n - 1) / 2 / t_nms,
+               "iou_matrix_pairs_per_s": n * n / t_iou, "iou_matrix_ms": 1e3 * t_iou,
+               "iou_matrix_valu_frac": 600.0 * n * n / t_iou / (VALU_PEAK_F32_TF * 1e12)}
+        if with_cpu:
+            t0 = time.perf_counter()
+            ref_keep = O.nms(b, 0.1)
+            t_cpu_nms = time.perf_counter() - t0
+            m = min(n, 1000)  # bounded sample of the matrix for the serial CPU code
+            t0 = time.perf_counter()
+            O.boxes_iou_bev(b[:m], b[:m])
+            t_cpu_iou = time.perf_counter() - t0
+            num = M.nms_gpu(tb, keep, 0.1)
+            row.update({"cpu_oracle_nms_boxes_per_s": n / t_cpu_nms, "cpu_oracle_iou_pairs_per_s": m * m / t_cpu_iou,
+                        "cpu_cores": 1, "keep_identical_to_oracle": bool(np.array_equal(keep[:num].numpy(), ref_keep))})
+        out["sizes"][str(n)] = row
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with matching values")
+    _seed_miopen_user_db()
+    import torch
+    import torch.distributed as dist
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback for the HIP path)"
@@ -178,21 +300,36 @@ def main():
     from liso_amd.utils.config import apply_slim_simple_knn_training, default_cfg
 
     torch.backends.cudnn.benchmark = bool(args.conv_benchmark)
+    if args.miopen_convs:
+        os.environ["LISO_CONV_BACKEND"] = "miopen"
+
+    if args.workload == "iou3d":
+        if rank == 0:
+            r = bench_iou3d(dev, torch, with_cpu=not args.no_cpu_baseline)
+            n = "1000"
+            print(json.dumps({"metric": "iou3d_nms boxes/s", "value": r["sizes"][n]["nms_boxes_per_s"], "unit": "boxes/s",
+                              "n_gpus": 1, "steps": 50, "warmup": 3, "ms_per_step": r["sizes"][n]["nms_ms"],
+                              "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                              "config": {"workload": "iou3d_nms: rotated NMS incl. device greedy sweep, 1000 random boxes, IoU 0.1"},
+                              "iou3d_nms": r}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     cfg = default_cfg(grid=GRID, bev_range_m=BEV_RANGE)
     torch.manual_seed(0)  # identical initial weights on every rank (DDP also broadcasts them)
+    s0 = s1 = pcls = targets = None
     if args.workload == "slim":
         from liso_amd.datasets.synthetic import slim_pair
         from liso_amd.trainer import SlimTrainer
 
         args.dtype = "fp32"  # the reference trains SLIM in fp32 (no autocast in slim/experiment.py)
-        batch = 1  # one pair per GPU, as in the reference's `slim_RAFT batch_size_one`
+        batch = 1
         cfg = apply_slim_simple_knn_training(cfg)
-        trainer = SlimTrainer(cfg, dev, use_graph=args.graph, channels_last=args.nhwc)
-        # each rank owns different pairs (DistributedSampler-style sharding by seed), resident in HBM
+        trainer = SlimTrainer(cfg, dev, use_graph=args.graph)
         s0, s1 = slim_pair(2 + rank, dev, n_points=N_POINTS, grid=GRID, bev_range_m=BEV_RANGE)
         step = lambda: trainer.step(s0, s1)  # noqa: E731
-        frames_per_step, timed = 2 * batch, list(SLIM_KERNELS)
+        frames_per_step = 2 * batch
     elif args.workload == "loop":
         from liso_amd.datasets.synthetic import slim_pair
         from liso_amd.trainer import LisoLoopTrainer
@@ -203,7 +340,7 @@ def main():
         trainer = LisoLoopTrainer(cfg, dev, compute_dtype=dtype, total_steps=args.steps + args.warmup + 8)
         s0, s1 = slim_pair(2 + rank, dev, n_points=N_POINTS, grid=GRID, bev_range_m=BEV_RANGE)
         step = lambda: trainer.step(s0, s1)  # noqa: E731
-        frames_per_step, timed = 2, list(LOOP_KERNELS)
+        frames_per_step = 2
     else:
         from liso_amd.datasets.synthetic import detector_batch
         from liso_amd.trainer import DetectorTrainer
@@ -214,11 +351,10 @@ def main():
         pcls, targets = detector_batch(seed=1 + rank, batch=batch, device=dev, n_points=N_POINTS, grid=GRID,
                                        bev_range_m=BEV_RANGE)
         step = lambda: trainer.step(pcls, targets)  # noqa: E731
-        frames_per_step, timed = batch, ["pfn_decorate", "pfn_forward_scatter"]
+        frames_per_step = batch
 
     graph_note = None
     if args.workload == "slim" and args.graph:
-        # capture before the first step and let all ranks agree on the outcome (capture issues no collective)
         ok, err = 1, ""
         try:
             trainer.capture(s0, s1)
@@ -233,15 +369,14 @@ def main():
             print(graph_note, file=sys.stderr, flush=True)
             args.graph = False
             torch.manual_seed(0)
-            trainer = SlimTrainer(cfg, dev, use_graph=False, channels_last=args.nhwc)
+            trainer = SlimTrainer(cfg, dev, use_graph=False)
             step = lambda: trainer.step(s0, s1)  # noqa: E731
     for _ in range(args.warmup):
         step()
 
     graphed = args.workload == "slim" and args.graph
     if not graphed:  # per-launch HIP events on the launch stream, inside the timed region
-        for k in timed:
-            L.TIMER.enable(k)
+        L.TIMER.enable_all()
     L.TIMER.reset()
     if world > 1:
         dist.barrier()
@@ -253,19 +388,18 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    timed_in = "the timed steps"
-    if graphed and rank == 0:
-        # the timed steps replay a hipGraph, inside which per-kernel events cannot be recorded: the same kernels are
-        # timed over two eager steps on the same inputs right after the timed region (rocprof of the graph replays
-        # agrees, profiles/)
-        for k in timed:
-            L.TIMER.enable(k)
+    timed_in, event_steps = "the timed steps", args.steps
+    if graphed:
+        # the timed steps replay a hipGraph, inside which per-kernel events cannot be recorded: the same kernels are timed
+        # over two eager forward+backward passes right after the timed region.  EVERY rank runs them and they issue no
+        # collective and no optimizer update (update=False), so the ranks stay in lock step for the MAX reduction below.
+        L.TIMER.enable_all()
         L.TIMER.reset()
-        n_event_steps = 2
-        for _ in range(n_event_steps):
-            trainer.step(s0, s1, eager=True)
+        event_steps = 2
+        for _ in range(event_steps):
+            trainer.step(s0, s1, eager=True, update=False)
         torch.cuda.synchronize()
-        timed_in = f"{n_event_steps} eager steps after the timed region (the timed steps replay a hipGraph)"
+        timed_in = f"{event_steps} eager fwd+bwd passes after the timed region (the timed steps replay a hipGraph)"
     L.TIMER.disable_all()
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -273,41 +407,40 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
-        durs = {k: L.TIMER.durations_ms(k) for k in timed}
-        event_steps = n_event_steps if graphed else args.steps
-        if args.workload == "loop":
-            key = max(durs, key=lambda k: sum(durs[k]))
-            alg_all = dict(slim_algorithmic_bytes(1, N_POINTS, GRID, directions=1))
-            alg_all["pfn_forward_scatter"] = pfn_algorithmic_bytes(1, N_POINTS, GRID, 4)
-            alg = LOOP_KERNELS[key][1] or alg_all[key]
-            kname = LOOP_KERNELS[key][0]
-            workload = ("fused LISO iteration (BASELINE configs[3]): SLIM fwd (no_grad) -> FlowClusterDetector (DBSCAN) -> NMS "
-                        "-> target maps -> CenterPoint-pillar train step, one 120k-pt sweep pair per GPU, 512x512 BEV")
-        elif args.workload == "slim":
-            alg_all = slim_algorithmic_bytes(batch, N_POINTS, GRID)
-            key = max(durs, key=lambda k: sum(durs[k]))  # the hand-written kernel with the largest share of the step
-            alg, kname = alg_all[key], SLIM_KERNELS[key]
-            if key == "knn_query":  # queries per launch as counted at the call site
-                nq = L.TIMER.mean_units("knn_query") or N_POINTS
-                alg = int((nq + N_POINTS) * 12 + nq * 8)
-            workload = ("SLIM scene-flow train step (BASELINE configs[1]): two 120k-pt KITTI-shaped clouds, 512x512 BEV "
-                        "pillars, RAFT 6 iterations fwd+bw flow, kNN loss, fwd+bwd+RMSprop")
-        else:
+        durs = {k: L.TIMER.durations_ms(k) for k in list(L.TIMER.events) if L.TIMER.events[k]}
+        totals = {k: sum(v) for k, v in durs.items()}
+        static_bytes = static_algorithmic_bytes(args.workload, batch, 2 if args.dtype == "bf16" else 4)
+        key = max(totals, key=totals.get)  # the hand-written kernel family with the largest share of the step
+        if args.workload == "detector" and key.startswith("pfn"):
             key = "pfn_forward_scatter"
-            alg = pfn_algorithmic_bytes(batch, N_POINTS, GRID, 2 if args.dtype == "bf16" else 4)
-            kname = ("pfn_decorate_kernel (+3 scan kernels) then pfn_forward_kernel: decorate -> Linear+BN+ReLU+max -> dense "
-                     "scatter; the two launches are timed together")
-            workload = ("CenterPoint-pillar detector train step (BASELINE configs[2]): 120k-pt KITTI-shaped clouds, "
-                        "512x512 BEV pillars, fwd+bwd+AdamW")
-        pmc_patterns = {"slim": {"knn_query": ["knn_query_kernel"], "corr_lookup_fwd": ["corr_lookup_fwd_kernel"]}.get(key),
-                        "detector": ["pfn_decorate_kernel", "pfn_forward_kernel"],
-                        "loop": {"corr_lookup_fwd": ["corr_lookup_fwd_kernel"],
-                                 "dbscan_components": ["dbscan_core_kernel", "dbscan_union_kernel", "dbscan_flatten_kernel"]}.get(key)}[args.workload]
-        traffic = pmc_traffic(args.workload, pmc_patterns) if pmc_patterns else None
-        avg_ms = sum(durs[key]) / max(len(durs[key]), 1)
-        if args.workload == "detector":  # the pillar pass is two launches (decorate, forward): time them as one unit
-            avg_ms += sum(durs["pfn_decorate"]) / max(len(durs["pfn_decorate"]), 1)
-        achieved = alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        kname, bound, unit = KERNELS.get(key, (key, "hbm", "bytes"))
+        n_launch = max(len(durs[key]), 1)
+        units = L.TIMER.units.get(key, [])
+        if key == "knn_query" and units:  # queries per launch as counted at the call site
+            nq = sum(units) / len(units)
+            alg_total = n_launch * ((nq + N_POINTS) * 12 + nq * 8)
+        elif units and len(units) == len(durs[key]):
+            alg_total = float(sum(units))
+        else:
+            alg_total = float(static_bytes.get(key, 0)) * n_launch
+        t_total = totals[key] * 1e-3
+        if key == "pfn_forward_scatter" and "pfn_decorate" in totals:  # the pillar pass is two launches: one unit
+            t_total += totals["pfn_decorate"] * 1e-3
+        if bound == "mfma":
+            achieved = alg_total / t_total / 1e12 if t_total > 0 else 0.0
+            peak, runit = (MFMA_PEAK_BF16_TF / 3.0 if "f32x3" in key else MFMA_PEAK_BF16_TF), "TFLOP/s"
+        else:
+            achieved = alg_total / t_total / 1e9 if t_total > 0 else 0.0
+            peak, runit = HBM_PEAK_GBS, "GB/s"
+        traffic, traffic_src = pmc_traffic(args.workload, PMC_PATTERNS[key]) if key in PMC_PATTERNS else (None, None)
+        workload = {
+            "loop": ("fused LISO iteration (BASELINE configs[3]): SLIM fwd (no_grad) -> FlowClusterDetector (DBSCAN) -> NMS "
+                     "-> target maps -> CenterPoint-pillar train step, one 120k-pt sweep pair per GPU, 512x512 BEV"),
+            "slim": ("SLIM scene-flow train step (BASELINE configs[1]): two 120k-pt KITTI-shaped clouds, 512x512 BEV "
+                     "pillars, RAFT 6 iterations fwd+bw flow, kNN loss, fwd+bwd+RMSprop"),
+            "detector": ("CenterPoint-pillar detector train step (BASELINE configs[2]): 120k-pt KITTI-shaped clouds, "
+                         "512x512 BEV pillars, fwd+bwd+AdamW"),
+        }[args.workload]
         line = {
             "metric": "LISO train-step frames/sec (120k-pt clouds)",
             "value": frames_per_step * world * args.steps / elapsed,
@@ -319,28 +452,34 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": args.dtype,
+            "dtype": "bf16 (detector) + f32 via bf16x3 MFMA (SLIM)" if args.workload == "loop" and args.dtype == "bf16" else args.dtype,
             "data": "synthetic",
             "config": {"workload": workload, "points_per_cloud": N_POINTS, "bev_grid": GRID, "batch_per_gpu": batch,
                        "frames_per_step_per_gpu": frames_per_step, "parallelism": f"dp{world}",
                        "launch": "hipGraph replay of fwd+loss+bwd, eager RMSprop" if graphed else "eager",
-                       "miopen_solver_selection": ("timed in-process (cudnn.benchmark)" if args.conv_benchmark else
-                                                   "MIOpen defaults" if args.no_miopen_db else "seeded user database liso_amd/miopen_db")},
+                       "convolutions": "MIOpen (--miopen-convs)" if args.miopen_convs else "own MFMA implicit-GEMM kernels"},
             "final_loss": float(loss),
-            "roofline": {"kernel": kname, "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": traffic,
-                         "traffic_source": None if traffic is None else f"profiles/r01_{args.workload}_pmc_*.csv (separate rocprofv3 --pmc "
-                                                                        "passes of this command; 2 x FETCH_SIZE + WRITE_SIZE, KiB)",
-                         "avg_launch_ms": avg_ms,
-                         "launches_per_step": len(durs[key]) / max(event_steps, 1), "algorithmic_bytes_per_launch": alg,
+            "roofline": {"kernel": kname, "bound": bound, "achieved": achieved, "peak": peak, "unit": runit,
+                         "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
+                         "avg_launch_ms": 1e3 * t_total / n_launch, "launches_per_step": n_launch / max(event_steps, 1),
+                         ("algorithmic_flop_per_launch" if bound == "mfma" else "algorithmic_bytes_per_launch"): alg_total / n_launch,
+                         "share_of_step": 1e3 * t_total / max(event_steps, 1) / (1e3 * elapsed / args.steps),
                          "timed_in": timed_in,
-                         "timed_kernels_ms_per_step": {k: sum(v) / max(event_steps, 1) for k, v in durs.items()}},
+                         "timed_kernels_ms_per_step": {k: round(v / max(event_steps, 1), 4) for k, v in
+                                                       sorted(totals.items(), key=lambda kv: -kv[1])}},
         }
+        if bound == "mfma" and "f32x3" in key:
+            line["roofline"]["peak_note"] = ("fp32 tensors computed as 3 bf16 MFMAs per product (hi*hi + hi*lo + lo*hi): peak = dense "
+                                             "bf16 MFMA / 3 in algorithmic fp32 flops (native f32 MFMA peak: 157.3 TFLOP/s)")
+        if world == 1 and not args.no_iou3d:
+            line["iou3d_nms"] = bench_iou3d(dev, torch, with_cpu=not args.no_cpu_baseline)
         if world == 1 and not args.no_cpu_baseline:
             if args.workload == "slim":
-                line["cpu_baseline"] = cpu_baseline_slim(cfg, trainer, s0, s1)
+                line["cpu_baseline"] = cpu_baseline_slim(cfg, trainer, s0, s1, torch)
             elif args.workload == "detector":
-                line["cpu_baseline"] = cpu_baseline_detector(trainer, pcls, targets)
+                line["cpu_baseline"] = cpu_baseline_detector(trainer, pcls, targets, torch)
+            else:
+                line["cpu_baseline"] = cpu_baseline_loop(cfg, trainer, s0, s1, torch)
         if args.workload == "loop":
             line["mined_boxes_last_step"] = int(trainer.last_boxes.valid.sum())
         if graph_note:

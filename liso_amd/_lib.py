@@ -194,6 +194,11 @@ class PillarCfg(ctypes.Structure):
                 ("gy", _i), ("max_points", _i), ("max_voxels", _i), ("n_channels", _i)]
 
 
+class _Everything:
+    def __contains__(self, name):
+        return True
+
+
 class KernelTimer:
     """Optional HIP-event timing of individual C-ABI launches on the current PyTorch stream (used by bench.py for the
     `roofline` object).  Disabled unless bench.py turns it on; costs two event records per timed launch."""
@@ -201,13 +206,18 @@ class KernelTimer:
     def __init__(self):
         self.enabled = set()
         self.events = {}
+        self.units = {}
 
     def enable(self, name):
         self.enabled.add(name)
         self.events.setdefault(name, [])
 
+    def enable_all(self):
+        """time every `launch()` whatever its name (bench.py: find the kernel family with the largest share of a step)"""
+        self.enabled = _Everything()
+
     def disable_all(self):
-        self.enabled.clear()
+        self.enabled = set()
 
     def launch(self, name, fn, units=None):
         """`units`: how many work items (queries, points ...) this launch processes, for per-launch algorithmic bytes"""
@@ -217,7 +227,7 @@ class KernelTimer:
         a.record()
         r = fn()
         b.record()
-        self.events[name].append((a, b))
+        self.events.setdefault(name, []).append((a, b))
         if units is not None:
             self.units.setdefault(name, []).append(units)
         return r

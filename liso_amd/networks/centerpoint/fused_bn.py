@@ -33,10 +33,10 @@ class _BnAct(torch.autograd.Function):
         nbytes = lib.liso_bn_workspace_bytes(C)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
         with torch.cuda.device(x.device):
-            L.check(lib.liso_bn_relu_fwd(L.ptr(xc), int(x.dtype == torch.bfloat16), M, C, L.ptr(gamma), L.ptr(beta),
-                                         L.ptr(running_mean), L.ptr(running_var), float(momentum), float(eps),
-                                         int(training), int(relu), L.ptr(y), L.ptr(stats), L.ptr(ws), nbytes,
-                                         L.stream_ptr()), "bn_relu_fwd")
+            L.check(L.TIMER.launch("bn_fwd", lambda: lib.liso_bn_relu_fwd(
+                L.ptr(xc), int(x.dtype == torch.bfloat16), M, C, L.ptr(gamma), L.ptr(beta), L.ptr(running_mean),
+                L.ptr(running_var), float(momentum), float(eps), int(training), int(relu), L.ptr(y), L.ptr(stats), L.ptr(ws),
+                nbytes, L.stream_ptr()), units=3 * M * C * xc.element_size()), "bn_relu_fwd")
         ctx.save_for_backward(xc, gamma, stats)
         ctx.cfg = (M, C, bool(training), bool(relu))
         return y.permute(0, 3, 1, 2)
@@ -57,9 +57,10 @@ class _BnAct(torch.autograd.Function):
         nbytes = lib.liso_bn_workspace_bytes(C)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=xc.device)
         with torch.cuda.device(xc.device):
-            L.check(lib.liso_bn_relu_bwd(L.ptr(g), L.ptr(xc), int(xc.dtype == torch.bfloat16), M, C, L.ptr(gamma),
-                                         L.ptr(stats), int(training), int(relu), L.ptr(dx), L.ptr(gg), L.ptr(gb),
-                                         L.ptr(ws), nbytes, L.stream_ptr()), "bn_relu_bwd")
+            L.check(L.TIMER.launch("bn_bwd", lambda: lib.liso_bn_relu_bwd(
+                L.ptr(g), L.ptr(xc), int(xc.dtype == torch.bfloat16), M, C, L.ptr(gamma), L.ptr(stats), int(training),
+                int(relu), L.ptr(dx), L.ptr(gg), L.ptr(gb), L.ptr(ws), nbytes, L.stream_ptr()),
+                units=5 * M * C * xc.element_size()), "bn_relu_bwd")
         return dx.permute(0, 3, 1, 2), gg, gb, None, None, None, None, None, None
 
 

@@ -78,6 +78,13 @@ class MovingAverageThreshold(nn.Module):
             if self.num_still is not None:
                 mm = moving_mask if valid_mask is None else moving_mask & valid_mask
                 sm = ~moving_mask if valid_mask is None else (~moving_mask) & valid_mask
-                self.moving_counter += torch.count_nonzero(mm)
-                self.still_counter += torch.count_nonzero(sm)
+                n_mov, n_still = torch.count_nonzero(mm), torch.count_nonzero(sm)
+                if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                    # the counters weight the next step's improvements (_compute_improvements): like the histogram they
+                    # must count the GLOBAL batch or the threshold buffers drift apart across replicas
+                    both = torch.stack([n_mov, n_still])
+                    dist.all_reduce(both)
+                    n_mov, n_still = both[0], both[1]
+                self.moving_counter += n_mov
+                self.still_counter += n_still
         return self.value() if compute_value else None

@@ -6,6 +6,8 @@ optimizer factory liso_cli.py:792-823).  The reference is single-GPU; data paral
 gradient all-reduce over RCCL/xGMI in a single flat bucket overlapped with backward, per-rank BatchNorm) is the
 only addition.
 """
+import contextlib
+
 import torch
 import torch.distributed as dist
 
@@ -179,7 +181,9 @@ class SlimTrainer:
                                                               pred_bw=pbw, knn_index_pc1=idx1, knn_index_pc2=idx2, **kw)
         return total, preds_fw, preds_bw
 
-    def step(self, sample_t0, sample_t1, eager=False):
+    def step(self, sample_t0, sample_t1, eager=False, update=True):
+        """`update=False` (with `eager=True`): forward + loss + backward only -- no collective, no optimizer / scheduler step
+        (bench.py times individual kernels this way after a graph-replayed region; every rank may call it independently)."""
         self.model.train()
         if self.use_graph and not eager and not (self.world > 1 and self.slim_cfg.model.use_static_aggr_flow_for_aggr_flow):
             # (with several ranks the dynamicness-threshold update all-reduces inside the loss: keep that step eager)
@@ -189,6 +193,10 @@ class SlimTrainer:
             self._flat_grad.zero_()
         else:
             self.optimizer.zero_grad(set_to_none=True)
+        if not update:
+            with self.model.no_sync() if hasattr(self.model, "no_sync") else contextlib.nullcontext():
+                total.backward()
+            return total.detach()
         total.backward()
         self._reduce_and_update()
         return total.detach()
@@ -232,7 +240,8 @@ class SlimTrainer:
         self._static = self._map_tensors((sample_t0, sample_t1), lambda t: t.to(dev).clone())
         s0, s1 = self._static
         buffers = {k: v.clone() for k, v in self.net.state_dict().items() if v.is_floating_point() or v.dtype == torch.long}
-        if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
+        quiet = hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch")
+        if quiet:
             # the flat gradient views are created on the default stream, warm-up and capture run on side streams
             torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
         side = torch.cuda.Stream(device=dev)
@@ -257,6 +266,8 @@ class SlimTrainer:
             for k, v in self.net.state_dict().items():
                 if k in buffers:
                     v.copy_(buffers[k])
+        if quiet:  # process-wide switch: only silenced while capturing
+            torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(True)
 
     def capture(self, sample_t0, sample_t1):
         """Capture the graph for inputs shaped like these (no collective is issued: callers running several ranks can
@@ -276,7 +287,7 @@ class SlimTrainer:
             self._copy_tensors(self._static, (sample_t0, sample_t1))
         self._graph.replay()
         self._reduce_and_update()
-        return self._static_loss
+        return self._static_loss.clone()  # the captured output is overwritten by the next replay
 
 
 class LisoLoopTrainer:
