@@ -8,6 +8,8 @@ import math
 
 import torch
 
+from liso_amd.datasets.torch_dataset_commons import voxelize_sample
+
 
 def _rays(device, n_rings=64, n_az=1875):
     elev = torch.deg2rad(torch.linspace(-24.8, 2.0, n_rings, device=device))
@@ -150,7 +152,7 @@ def slim_pair(seed, device, n_points=120000, grid=512, bev_range_m=100.0):
     T01 = _se2(float(ego[0]), float(ego[1]), float(ego[2]), device)
 
     def sample(cloud, full, odom):
-        coors = ((cloud[:, :2] + bev_range_m / 2) / bev_range_m * grid).to(torch.int32)
+        coors, _ = voxelize_sample(cloud, (bev_range_m, bev_range_m), (grid, grid))  # the dataset's convention (B4)
         return {"pcl_full_no_ground_ta": [cloud], "pcl_full_w_ground_ta": full[None],
                 "pcl_ta": {"pcl": cloud[None], "pcl_is_valid": torch.ones(1, cloud.shape[0], dtype=torch.bool, device=device),
                            "pillar_coors": coors[None]},
@@ -186,7 +188,7 @@ def cluster_sample(seed, device, batch=1, n_points=120000, grid=512, bev_range_m
         pcls.append(c[idx].contiguous()), flows.append(f[idx].contiguous()), odoms.append(T01), full.append(cloud)
         scenes.append((boxes, speed))
     pcl = torch.stack(pcls)
-    coors = ((pcl[..., :2] + half) / bev_range_m * grid).to(torch.int32)
+    coors = torch.stack([voxelize_sample(p, (bev_range_m, bev_range_m), (grid, grid))[0] for p in pcl])
     sample = {"pcl_ta": {"pcl": pcl, "pcl_is_valid": torch.ones(pcl.shape[:2], dtype=torch.bool, device=device),
                          "pillar_coors": coors},
               "pcl_full_w_ground_ta": torch.stack(full),

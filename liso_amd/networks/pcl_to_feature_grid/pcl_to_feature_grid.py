@@ -154,6 +154,12 @@ class PointsPillarFeatureNetWrapper(nn.Module):
             num_input_channels = [3, 4][cfg.data.use_lidar_intensity]         # reference :31-35
         else:
             num_input_channels = 3
+        # extension (north_star: (x, y, z, intensity, time) points of multi-sweep clouds): `data.num_point_channels: 5`
+        # feeds the 5th channel to the PFN as one more decorated feature, exactly as mmdet3d's PillarFeatureNet treats
+        # any extra input channel (pillar_encoder.py:93-159: features = [points, f_cluster, f_center])
+        if cfg.data.setdefault("num_point_channels", None):
+            num_input_channels = int(cfg.data.num_point_channels)
+            assert num_input_channels in (3, 4, 5), num_input_channels
         self.num_input_channels = num_input_channels
         crf = cfg.network.centerpoint.setdefault("channel_reduction_factor", 1)
         assert 64 // crf == 64, "the fused gfx950 PFN kernel is built for 64 output channels"

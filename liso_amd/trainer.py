@@ -16,11 +16,40 @@ from liso_amd.networks.simple_net.simple_net import BoxLearner
 
 
 def get_optimizer_scheduler(cfg, box_predictor, total_steps=None):
-    """liso_cli.py:792-823 (train_on_box_source == "gt" branch)"""
+    """liso_cli.py:792-823: AdamW(lr, weight_decay 0.01) + OneCycleLR(pct_start 0.4, momentum 0.85-0.95, div 10); training on
+    ground truth runs one cycle over `num_training_steps` (+2, as in the reference), training on mined boxes one cycle per
+    weight-drop period with final_div_factor 10.  `total_steps` overrides the cycle length (benchmarks)."""
     opt = torch.optim.AdamW(box_predictor.parameters(), lr=cfg.optimization.learning_rate, weight_decay=0.01)
-    sched = torch.optim.lr_scheduler.OneCycleLR(
-        optimizer=opt, max_lr=cfg.optimization.learning_rate, pct_start=0.4, base_momentum=0.85, max_momentum=0.95,
-        div_factor=10.0, total_steps=(total_steps or cfg.optimization.num_training_steps) + 2)
+    common = dict(optimizer=opt, max_lr=cfg.optimization.learning_rate, pct_start=0.4, base_momentum=0.85, max_momentum=0.95,
+                  div_factor=10.0)
+    source = cfg.data.setdefault("train_on_box_source", "gt")
+    if source == "gt":
+        sched = torch.optim.lr_scheduler.OneCycleLR(total_steps=(total_steps or cfg.optimization.num_training_steps) + 2, **common)
+    elif source == "mined":
+        assert cfg.optimization.rounds.active, "assuming this"
+        rounds = cfg.optimization.rounds
+        sched = torch.optim.lr_scheduler.OneCycleLR(
+            total_steps=(total_steps or rounds.steps_per_round * rounds.drop_net_weights_every_nth_round) + 2, final_div_factor=10,
+            **common)
+    else:
+        raise NotImplementedError(source)
+    return opt, sched
+
+
+def get_slim_optimizer_scheduler(slim_cfg, params):
+    """slim/experiment.py:200-219: RMSprop(lr = initial) (or Adam) + linear warm-up over `warm_up.step_length` steps, then
+    linear decay to 5 % of the initial rate at `iterations.train`."""
+    from liso_amd.utils.learning_rate import get_polynomial_decay_schedule_with_warmup
+
+    if slim_cfg.optimizer == "rmsprop":
+        opt = torch.optim.RMSprop(params, lr=slim_cfg.learning_rate.initial)
+    elif slim_cfg.optimizer == "adam":
+        opt = torch.optim.Adam(params, lr=slim_cfg.learning_rate.initial)
+    else:
+        raise AssertionError("only rmsprop/adam supported")
+    sched = get_polynomial_decay_schedule_with_warmup(
+        optimizer=opt, num_warmup_steps=slim_cfg.learning_rate.warm_up.step_length,
+        num_training_steps=slim_cfg.iterations.train, lr_end=slim_cfg.learning_rate.initial * 0.05)
     return opt, sched
 
 
@@ -103,8 +132,6 @@ class SlimTrainer:
 
     def __init__(self, cfg, device, num_train_samples=1000, use_graph=False, channels_last=False):
         from liso_amd.slim.model.slim import SLIM
-        from liso_amd.utils.learning_rate import get_polynomial_decay_schedule_with_warmup
-
         self.cfg, self.slim_cfg, self.device = cfg, cfg.SLIM, device
         self.net = SLIM(cfg, num_train_samples=num_train_samples).to(device)
         if channels_last:  # measured slower than NCHW filters on gfx950 (65 vs 59 ms per step): MIOpen's fp32 Winograd is NCHW
@@ -118,11 +145,7 @@ class SlimTrainer:
             self.model = torch.nn.parallel.DistributedDataParallel(
                 self.net, device_ids=[device.index] if device.type == "cuda" else None, bucket_cap_mb=64,
                 broadcast_buffers=False, gradient_as_bucket_view=True)
-        assert self.slim_cfg.optimizer == "rmsprop"
-        self.optimizer = torch.optim.RMSprop(self.net.parameters(), lr=self.slim_cfg.learning_rate.initial)
-        self.lr_scheduler = get_polynomial_decay_schedule_with_warmup(
-            optimizer=self.optimizer, num_warmup_steps=self.slim_cfg.learning_rate.warm_up.step_length,
-            num_training_steps=self.slim_cfg.iterations.train, lr_end=self.slim_cfg.learning_rate.initial * 0.05)
+        self.optimizer, self.lr_scheduler = get_slim_optimizer_scheduler(self.slim_cfg, self.net.parameters())
         import numpy as np
         half = 0.5 * np.array(cfg.data.bev_range_m, dtype=np.float32)
         self.bev_extent = np.concatenate([-half, half], axis=0)

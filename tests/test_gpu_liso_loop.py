@@ -76,3 +76,42 @@ def test_padded_device_nms_keeps_the_same_boxes_as_the_reference_schedule():
         assert r.shape == o.shape, (b, r.shape, o.shape)
         assert torch.equal(r.pos, o.pos) and torch.equal(r.probs, o.probs) and torch.equal(r.rot, o.rot)
     assert int(got.valid[2].sum()) == 0 and int(got.valid[0].sum()) > 5
+
+
+def test_liso_loop_full_size_120k_512_bf16():
+    """BASELINE configs[3] at its real size on one GPU: 120k-point sweeps, 512 x 512 BEV, bf16 detector.  Two trainers
+    from the same seed take identical steps (no float atomics on the path), boxes are mined, the loss is finite, and the
+    mined boxes equal the CPU restatement of FlowClusterDetector fed with the same (GPU-computed) point flow."""
+    from liso_amd.datasets.synthetic import slim_pair
+    from liso_amd.trainer import LisoLoopTrainer
+    from liso_amd.utils.config import apply_slim_simple_knn_training, default_cfg
+    from oracle.flow_cluster import flow_cluster_detector_forward
+
+    dev = torch.device("cuda")
+    s0, s1 = slim_pair(2, dev, n_points=120000, grid=512, bev_range_m=100.0)
+    runs = []
+    for _ in range(2):
+        cfg = apply_slim_simple_knn_training(default_cfg(grid=512, bev_range_m=100.0))
+        torch.manual_seed(0)
+        tr = LisoLoopTrainer(cfg, dev, compute_dtype=torch.bfloat16, total_steps=8)
+        losses = [float(tr.step(s0, s1)) for _ in range(2)]
+        runs.append((losses, int(tr.last_boxes.valid.sum())))
+    assert all(torch.isfinite(torch.tensor(runs[0][0])))
+    assert runs[0][1] == runs[1][1]
+    assert abs(runs[0][0][0] - runs[1][0][0]) <= 1e-3 * abs(runs[0][0][0])
+    # pseudo boxes from the network's flow: device pipeline == CPU restatement on the same flow (before NMS)
+    boxes, flow = tr.mine_boxes(s0, s1)
+    sample = dict(s0)
+    sample["gt"] = {**s0["gt"], "flow_ta_tb": flow}
+    raw = tr.cluster_detector(sample, global_step=1)
+    cpu = lambda t: t.detach().cpu()  # noqa: E731
+    det = tr.cluster_detector
+    ref = flow_cluster_detector_forward(cpu(s0["pcl_ta"]["pcl"]), cpu(s0["pcl_ta"]["pcl_is_valid"]), cpu(s0["pcl_full_w_ground_ta"]),
+                                        cpu(s0["pcl_ta"]["pillar_coors"]), cpu(flow), cpu(s0["gt"]["odom_ta_tb"]),
+                                        cpu(s0["src_trgt_time_delta_s"]), det.pcl_bev_center_coords_homog_np[..., :2],
+                                        det.bev_pixel_per_meter_res_np)
+    assert raw.valid.shape == ref["valid"].shape and torch.equal(cpu(raw.valid), ref["valid"])
+    v = ref["valid"]
+    if int(v.sum()):
+        assert torch.allclose(cpu(raw.pos)[v], ref["pos"][v], atol=1e-4)
+        assert torch.allclose(cpu(raw.dims)[v].double(), ref["dims"][v], atol=1e-4)

@@ -20,6 +20,8 @@ def _module(grid, rng, zc, C, state=None):
     cfg.data.z_pillar_cutoff_value = zc
     if C == 3:
         cfg.data.use_lidar_intensity = False
+    if C == 5:
+        cfg.data.num_point_channels = 5
     m = PointsPillarFeatureNetWrapper(cfg).cuda()
     if state is not None:
         m.pts_voxel_encoder.load_state_dict(state)
@@ -71,11 +73,14 @@ def test_reference_fixtures():
             assert int(lyr.norm.num_batches_tracked) == 1
 
 
-@pytest.mark.parametrize("n,grid,B", [(120000, 512, 1), (40000, 512, 3), (300000, 1024, 1)])
-def test_baseline_size_vs_oracle(n, grid, B):
-    """BASELINE-size clouds against the CPU oracle: voxel set / counts bit exact, features within 1e-3."""
-    pcls = [OP.synthetic_cloud(n, 100 + b, 100.0, 4) for b in range(B)]
-    m = _module(grid, 100.0, 10.0, 4)
+@pytest.mark.parametrize("n,grid,B,C", [(120000, 512, 1, 4), (40000, 512, 3, 4), (300000, 1024, 1, 4), (300000, 1024, 1, 5),
+                                        (50000, 256, 2, 5), (20000, 256, 2, 3)])
+def test_baseline_size_vs_oracle(n, grid, B, C):
+    """BASELINE-size clouds against the CPU oracle: voxel set / counts bit exact, features within 1e-3.  C = 5 is
+    north_star's (x, y, z, intensity, time) point layout (configs[4]: 10-sweep nuScenes clouds), C = 3 the reference's
+    `use_lidar_intensity: False`."""
+    pcls = [OP.synthetic_cloud(n, 100 + b, 100.0, C) for b in range(B)]
+    m = _module(grid, 100.0, 10.0, C)
     torch.manual_seed(0)
     with torch.no_grad():
         m.pts_voxel_encoder.pfn_layers[0].norm.weight.uniform_(0.5, 1.5)

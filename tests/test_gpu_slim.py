@@ -272,7 +272,7 @@ def test_head_decoder_and_loss_match_reference(tag, pointwise):
     assert _rel(net_fw.grad, g[f"{tag}_g_fw"]) < 5e-3 and _rel(net_bw.grad, g[f"{tag}_g_bw"]) < 5e-3
 
 
-@pytest.mark.parametrize("grid,rng,n_points", [(256, 50.0, 30000), (128, 40.0, 10000)])
+@pytest.mark.parametrize("grid,rng,n_points", [(256, 50.0, 30000), (128, 40.0, 10000), (512, 100.0, 120000)])  # last = BASELINE configs[1]
 def test_slim_trainer_hipgraph_step_equals_eager_step(grid, rng, n_points):
     """SlimTrainer(use_graph=True): forward+loss+backward replayed from a hipGraph (inputs copied into the captured
     buffers, flat gradient buffer) must train exactly like the eager step: same losses, same weights, same BatchNorm /

@@ -1,0 +1,130 @@
+"""the trainers against steps captured from the reference (tests/golden/make_train_step_golden.py).
+CPU: optimizer / scheduler factories reproduce the reference's parameter trajectories on a dummy problem.
+GPU: two consecutive detector train steps (HIP pillar path, own convolutions / BatchNorm / fused loss, AdamW + OneCycleLR)
+from the same key-derived initial weights on the same clouds and targets: loss, logits, gradient norms, post-step weights."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+from keyed_init import keyed_state_dict, sample_indices  # noqa: E402
+
+from liso_amd.utils.config import default_cfg, to_attr  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def fx(golden_dir):
+    return np.load(os.path.join(golden_dir, "train_step_reference.npz"))
+
+
+def _dummy_problem():
+    g = torch.Generator().manual_seed(0)
+    params = [torch.randn(7, 5, generator=g), torch.randn(11, generator=g), torch.randn(3, 2, 2, generator=g)]
+    grads = [[torch.randn(p.shape, generator=g) * (0.1 + 0.3 * s) for p in params] for s in range(14)]
+    return params, grads
+
+
+def _trajectory(make, params, grads):
+    ps = [torch.nn.Parameter(p.clone()) for p in params]
+    opt, sched = make(ps)
+    traj, lrs = [], []
+    for gs in grads:
+        for p, g_ in zip(ps, gs):
+            p.grad = g_.clone()
+        opt.step()
+        sched.step()
+        traj.append(torch.cat([p.detach().reshape(-1) for p in ps]).numpy().copy())
+        lrs.append(opt.param_groups[0]["lr"])
+    return np.stack(traj), np.array(lrs)
+
+
+class _Net:
+    def __init__(self, ps):
+        self.ps = ps
+
+    def parameters(self):
+        return self.ps
+
+
+def test_optimizer_scheduler_factories_reproduce_reference_trajectories(fx):
+    from liso_amd.trainer import get_optimizer_scheduler, get_slim_optimizer_scheduler
+
+    params, grads = _dummy_problem()
+    c_gt = to_attr({"optimization": {"learning_rate": 1e-3, "num_training_steps": 12}, "data": {"train_on_box_source": "gt"}})
+    c_mined = to_attr({"optimization": {"learning_rate": 1e-3, "num_training_steps": 12,
+                                        "rounds": {"active": True, "steps_per_round": 6, "drop_net_weights_every_nth_round": 2}},
+                       "data": {"train_on_box_source": "mined"}})
+    for tag, c in (("gt", c_gt), ("mined", c_mined)):
+        traj, lrs = _trajectory(lambda ps: get_optimizer_scheduler(c, _Net(ps)), params, grads[:13])
+        np.testing.assert_allclose(lrs, fx[f"adamw_{tag}_lr"], rtol=1e-12)
+        np.testing.assert_allclose(traj, fx[f"adamw_{tag}_traj"], rtol=1e-6, atol=1e-7)
+    slim = to_attr({"optimizer": "rmsprop", "learning_rate": {"initial": 1e-4, "warm_up": {"step_length": 5}}, "iterations": {"train": 12}})
+    traj, lrs = _trajectory(lambda ps: get_slim_optimizer_scheduler(slim, ps), params, grads)
+    np.testing.assert_allclose(lrs, fx["rmsprop_lr"], rtol=1e-12)
+    np.testing.assert_allclose(traj, fx["rmsprop_traj"], rtol=1e-6, atol=1e-7)
+    assert lrs[0] > 0 and lrs[4] == pytest.approx(1e-4) and lrs[-1] == pytest.approx(5e-6)  # warm-up, then decay to 5 %
+
+
+def test_parameter_order_and_keys_equal_the_reference_assembly(fx):
+    """the optimizer walks parameters in module order: the product's BoxLearner must enumerate the same keys in the same
+    order as the reference's (pfn, rpn, center_head) modules"""
+    from liso_amd.networks.simple_net.simple_net import BoxLearner
+
+    net = BoxLearner(default_cfg(grid=64, bev_range_m=40.0))
+    mine = [k for k, p in net.named_parameters() if p.requires_grad]
+    assert mine == [str(k) for k in fx["param_keys"]]
+
+
+@pytest.mark.gpu
+def test_two_detector_steps_match_the_captured_reference_steps(fx):
+    from liso_amd.trainer import DetectorTrainer
+
+    dev = torch.device("cuda:0")
+    cfg = default_cfg(grid=64, bev_range_m=40.0)
+    cfg.optimization.num_training_steps = 8
+    tr = DetectorTrainer(cfg, dev, compute_dtype=torch.float32)
+    sd = tr.net.state_dict()
+    init = keyed_state_dict({k: (tuple(v.shape), v.dtype) for k, v in sd.items()})
+    assert set(init) == {str(k) for k in fx["key_order"]}
+    tr.net.load_state_dict({**sd, **{k: v.to(dev) for k, v in init.items()}}, strict=True)
+    pcls = [torch.from_numpy(fx["pcl_0"]).to(dev), torch.from_numpy(fx["pcl_1"]).to(dev)]
+    targets = {k: torch.from_numpy(fx["gt_" + k]).to(dev) for k in ("probs", "rot", "dims", "pos")}
+    targets["center_bool_mask"] = torch.from_numpy(fx["center_mask"]).to(dev)
+    keys = [str(k) for k in fx["param_keys"]]
+    named = dict(tr.net.named_parameters())
+    for step in range(2):
+        tr.model.train()
+        tr.optimizer.zero_grad(set_to_none=True)
+        total, _, _ = tr.loss(pcls, targets)
+        with torch.no_grad():
+            pass
+        total.backward()
+        ref_loss = float(fx[f"step{step}_loss"])
+        assert abs(float(total) - ref_loss) <= 1e-3 * abs(ref_loss), (step, float(total), ref_loss)
+        gn = np.array([float(named[k].grad.norm()) for k in keys])
+        ref_gn = fx[f"step{step}_grad_norms"]
+        big = ref_gn > 1e-4 * ref_gn.max()  # conv biases in front of a BatchNorm have a true gradient of 0
+        rel = np.abs(gn - ref_gn)[big] / ref_gn[big]
+        assert rel.max() <= 2e-2 and np.median(rel) <= 1e-3, (step, rel.max(), np.median(rel), keys[int(np.argmax(np.abs(gn - ref_gn) / np.maximum(ref_gn, 1e-12) * big))])
+        tr.optimizer.step()
+        tr.lr_scheduler.step()
+        assert tr.optimizer.param_groups[0]["lr"] == pytest.approx(float(fx[f"step{step}_lr"]), rel=1e-9)
+        lr = float(fx[f"step{step}_lr"])
+        wn = np.array([float(named[k].detach().norm()) for k in keys])
+        np.testing.assert_allclose(wn, fx[f"step{step}_weight_norms"], rtol=1e-3)
+        # AdamW's first steps move every weight by ~lr * sign(g): entries whose gradient is ~0 may differ by 2 lr per step
+        for i, k in enumerate(keys):
+            p = named[k].detach().reshape(-1)
+            idx = sample_indices(k, p.numel())
+            got = p[idx.to(dev)].cpu().numpy()
+            ref = fx[f"step{step}_weight_samples"][i][: len(got)]
+            assert np.abs(got - ref).max() <= 1e-3 * max(np.abs(ref).max(), 1e-3) + 2.0 * (step + 1) * 1e-3, (step, k)
+            assert np.median(np.abs(got - ref)) <= 1e-5 + 1e-4 * np.abs(ref).max(), (step, k)
+    with torch.no_grad():
+        tr.net.train()
+    rpn, head = tr.net.model.rpn, tr.net.model.center_head
+    np.testing.assert_allclose(rpn.blocks[0][2].running_mean.cpu().numpy(), fx["bn_running_mean_rpn_blocks_0_2"], rtol=2e-3, atol=1e-5)
+    np.testing.assert_allclose(head.shared_conv[1].running_var.cpu().numpy(), fx["bn_running_var_head_shared_1"], rtol=2e-3, atol=1e-5)
