@@ -1,0 +1,109 @@
+/*
+ * liso_conv.h -- C ABI of the MI355X-native 2-D convolutions of the BEV networks (gfx950 MFMA implicit GEMM).
+ *
+ * Replaces the cuDNN convolutions (+ the BatchNorm-apply / bias / ReLU kernels around them) the reference reaches
+ * through torch.nn.Conv2d / ConvTranspose2d in
+ *   liso/networks/centerpoint/rpn.py:113-146            (SECOND-style backbone: 3x3 s1/s2, 1x1, 2x2 s2, transposed 2x2 s2)
+ *   liso/networks/centerpoint/center_head.py:60-117     (shared 3x3 conv, SepHead 3x3 convs)
+ *   liso/slim/model/update.py:96-164                    (RAFT update block: 1x1, 3x3, 7x7, ConvGRU)
+ *   liso/slim/model/extractor.py:211-297                (SmallEncoder: 7x7 s2, residual 3x3 s1/s2, 1x1)
+ * forward, data gradient and weight gradient.
+ *
+ * One descriptor covers all of them.  Tensors are NHWC ("channels last": [B, H, W, C], C contiguous; a pixel stride
+ * larger than C addresses a channel slice of a wider tensor).  The kernels work on a *virtual grid* (hv x wv): virtual
+ * pixel v reads input pixels v*is + (tap_dy, tap_dx) and writes output pixel v*os + (class_ooy, class_oox).
+ *   forward conv, stride s, padding p:    is = s, os = 1, taps (kh - p, kw - p), one class
+ *   data gradient of a stride-1 conv:     the same with mirrored taps and transposed weights
+ *   data gradient of a stride-2 conv /    os = 2: up to 4 output-parity classes, each with the subset of taps that
+ *   forward of a transposed conv:         reaches it (no multiplications by inserted zeros)
+ *
+ * Arithmetic: `mode` LISO_CONV_BF16 -- bf16 tensors, fp32 accumulation on v_mfma_f32_32x32x16_bf16;
+ *             `mode` LISO_CONV_F32X3 -- fp32 tensors; every operand is split on the fly into bf16 hi + lo parts and each
+ *             product is evaluated as hi*hi + hi*lo + lo*hi (three MFMAs, fp32 accumulation): relative error per product
+ *             <= 2^-16 (fp32: 2^-24; TF32, cuDNN's default for fp32 convolutions on Ampere: 2^-11) at 3/16 of the cost
+ *             of the native fp32 MFMA.
+ * Fusions (all optional): prologue x' = relu?(x * in_scale[c] + in_shift[c]) applied while the input tile is staged
+ * (the BatchNorm-apply + ReLU of the producing layer: normalised activations never touch HBM; padding stays exactly 0);
+ * epilogue: + bias[c], ReLU, per-channel partial sums of the stored values for the BatchNorm statistics of THIS layer.
+ *
+ * Packed weights (liso_conv_pack_weights): [plane][tap][ci_pad / 8][co_pad][8] bf16, plane 0 = hi (or the bf16 value),
+ * plane 1 = lo (F32X3 only); ci_pad = round_up(ci, 16), co_pad = round_up(co, 64); padding is zero.
+ *
+ * All pointers are device pointers; nothing allocates or synchronises; every call enqueues on `stream` and returns
+ * LISO_OK or a negative LISO_E* code (include/liso_iou3d.h).  Graph-capturable.
+ */
+#ifndef LISO_CONV_H
+#define LISO_CONV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LISO_CONV_MAX_TAPS 49
+#define LISO_CONV_MAX_CLASSES 4
+#define LISO_CONV_BF16 0
+#define LISO_CONV_F32X3 1
+
+typedef struct {
+    int batch, hi, wi, ci;      /* input  [batch, hi, wi, ci] */
+    int x_pix_stride;           /* elements between consecutive input pixels (>= ci) */
+    int ho, wo, co;             /* output [batch, ho, wo, co] */
+    int y_pix_stride, y_ch_off; /* elements between output pixels; first output channel inside the pixel row */
+    int hv, wv;                 /* virtual grid (per class) */
+    int isy, isx, osy, osx;
+    int n_classes;
+    int class_tap_begin[LISO_CONV_MAX_CLASSES + 1]; /* taps of class c: [begin[c], begin[c + 1]) */
+    int class_ooy[LISO_CONV_MAX_CLASSES], class_oox[LISO_CONV_MAX_CLASSES];
+    int n_taps;                 /* over all classes */
+    int tap_dy[LISO_CONV_MAX_TAPS], tap_dx[LISO_CONV_MAX_TAPS]; /* input offset of the tap */
+    int tap_w[LISO_CONV_MAX_TAPS];                              /* tap index inside the packed weights */
+    int w_taps;                 /* taps in the packed weights (kh * kw) */
+    int mode;                   /* LISO_CONV_BF16 | LISO_CONV_F32X3 */
+    int out_f32;                /* BF16 mode: 1 = fp32 output, 0 = bf16 output (F32X3: always fp32) */
+    int in_relu, out_relu;
+} liso_conv_desc;
+
+/* Packs torch-layout fp32 weights for the kernels.
+ *   transposed == 0: src[d0][d1][kh][kw] = weight of nn.Conv2d  (d0 = out channels, d1 = in channels)
+ *   transposed == 1: the same memory read as nn.ConvTranspose2d (d0 = in channels, d1 = out channels)
+ *   for_dgrad  != 0: pack for the data-gradient launch (the roles of in / out channels are exchanged)
+ * dst: bf16 [planes][kh*kw][K_pad/8][N_pad][8], planes = 1 (BF16) or 2 (F32X3); bytes = liso_conv_packed_bytes(). */
+size_t liso_conv_packed_bytes(int k_channels, int n_channels, int taps, int mode);
+int liso_conv_pack_weights(const float* src, int d0, int d1, int kh, int kw, int transposed, int for_dgrad, int mode,
+                           void* dst, void* stream);
+
+/* rows of the statistics buffer one forward launch writes: stats_partial is fp32 [rows][2][co_pad]
+ * (sum and sum of squares of (stored value - stats_shift[c]) over the pixels of one block). */
+int liso_conv_stats_rows(const liso_conv_desc* d);
+
+/* y = conv(x') (+ bias) ; bias / in_scale / in_shift / stats_partial / stats_shift may be NULL */
+int liso_conv_forward(const liso_conv_desc* d, const void* x, const void* w_packed, const float* bias,
+                      const float* in_scale, const float* in_shift, void* y, float* stats_partial,
+                      const float* stats_shift, void* stream);
+
+/* Weight gradient of the convolution described by `d` (a FORWARD descriptor: x = layer input, with the same optional
+ * prologue, dy = gradient of the layer output [batch, ho, wo, co] with pixel stride dy_pix_stride):
+ *   dw[co][ci][kh][kw] (torch layout of nn.Conv2d; transposed != 0: [ci][co][kh][kw]) = sum over pixels, overwritten;
+ *   dbias[co] = sum over pixels of dy (may be NULL).
+ * workspace: liso_conv_wgrad_workspace_bytes(d) bytes of device scratch (split-K slabs). */
+size_t liso_conv_wgrad_workspace_bytes(const liso_conv_desc* d);
+int liso_conv_wgrad(const liso_conv_desc* d, const void* x, const float* in_scale, const float* in_shift, const void* dy,
+                    int dy_pix_stride, int transposed, float* dw, float* dbias, void* workspace, size_t workspace_bytes,
+                    void* stream);
+
+/* BatchNorm statistics from the partial sums of a forward launch (fixed order, fp64 merge):
+ *   mean = shift + S1 / n, var = S2 / n - (S1 / n)^2 (biased), n = batch * ho * wo
+ *   stats[4 * c] = scale | shift | mean | invstd with scale = gamma * invstd, shift = beta - mean * scale
+ *   (the layout liso_bn_relu_bwd of include/liso_bn.h consumes);
+ *   running_mean / running_var (unbiased) are updated in place with `momentum` when they are non-NULL. */
+int liso_conv_bn_finalize(const float* stats_partial, int rows, int co, int co_pad, long n, const float* stats_shift,
+                          const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
+                          float eps, float* stats, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LISO_CONV_H */

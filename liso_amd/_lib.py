@@ -129,11 +129,31 @@ SIGNATURES = {
     "liso_knn_build_f32": (_i, [_vp, _vp, _i, _i, _vp, _sz, _vp]),
     "liso_knn_sorted_ids": (_i, [_vp, _vp, _i, _vp, _vp]),
     "liso_knn_query_f32": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _i, _vp]),
+    # include/liso_conv.h
+    "liso_conv_packed_bytes": (_sz, [_i, _i, _i, _i]),
+    "liso_conv_pack_weights": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "liso_conv_stats_rows": (_i, [_vp]),
+    "liso_conv_forward": (_i, [_vp] * 10),
+    "liso_conv_wgrad_workspace_bytes": (_sz, [_vp]),
+    "liso_conv_wgrad": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "liso_conv_bn_finalize": (_i, [_vp, _i, _i, _i, ctypes.c_long, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp]),
     # include/liso_tracking.h
     "liso_points_in_boxes_workspace_bytes": (_sz, [_vp]),
     "liso_points_in_boxes_f32": (_i, [_vp] * 9 + [_sz, _vp]),
     "liso_match_greedy_f32": (_i, [_vp, ctypes.c_long, ctypes.c_long, _i, _i, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
+
+
+CONV_MAX_TAPS, CONV_MAX_CLASSES, CONV_BF16, CONV_F32X3 = 49, 4, 0, 1
+
+
+class ConvDesc(ctypes.Structure):
+    """mirror of liso_conv_desc (include/liso_conv.h)"""
+    _fields_ = [("batch", _i), ("hi", _i), ("wi", _i), ("ci", _i), ("x_pix_stride", _i), ("ho", _i), ("wo", _i), ("co", _i),
+                ("y_pix_stride", _i), ("y_ch_off", _i), ("hv", _i), ("wv", _i), ("isy", _i), ("isx", _i), ("osy", _i), ("osx", _i),
+                ("n_classes", _i), ("class_tap_begin", _i * (CONV_MAX_CLASSES + 1)), ("class_ooy", _i * CONV_MAX_CLASSES),
+                ("class_oox", _i * CONV_MAX_CLASSES), ("n_taps", _i), ("tap_dy", _i * CONV_MAX_TAPS), ("tap_dx", _i * CONV_MAX_TAPS),
+                ("tap_w", _i * CONV_MAX_TAPS), ("w_taps", _i), ("mode", _i), ("out_f32", _i), ("in_relu", _i), ("out_relu", _i)]
 
 
 class KnnGrid(ctypes.Structure):

@@ -1,0 +1,668 @@
+// NHWC implicit-GEMM convolutions on the gfx950 matrix cores: forward / data gradient (one kernel) -- C ABI and the
+// reference lines it replaces: include/liso_conv.h.  The weight gradient lives in conv_wgrad.hip.
+//
+// Work decomposition.  A 256-thread block (4 wavefronts) owns TH x 32 virtual pixels (TH = 4 or 8) x BNT output channels
+// (32 or 64) of one sample.  The reduction runs over channel slabs (CS = 16/32/64 input channels) x taps:
+//   * per slab the input halo tile ((TH-1)*is + kh_span) x (31*is + kw_span) pixels x CS channels is staged ONCE into LDS
+//     (16-B global loads -> registers -> [BatchNorm-apply + ReLU of the producing layer | fp32 -> bf16 hi/lo split] ->
+//     LDS), so every input element is read from HBM/L2 once per block and used by all taps from LDS;
+//   * the tap's weight panel [CS/8][BNT][8] bf16 (8 KB) is double-buffered in LDS: the panel of tap t+1 is loaded into
+//     registers before and written to LDS after the MFMAs of tap t (one barrier per tap);
+//   * wave w computes pixels [w*M/4, (w+1)*M/4) x all BNT channels: per 16-channel k-step MI A-fragments (pixels,
+//     ds_read_b128: lane = pixel row, 8 consecutive channels) + NJ B-fragments (ds_read_b128: lane = output channel, 8
+//     consecutive input channels of the pre-packed panel) feed MI x NJ v_mfma_f32_32x32x16_bf16.
+// LDS images: a pixel occupies CS*2 + 16 bytes (odd multiple of 16): the 16 lanes of a ds_read_b128 group read 16
+// different pixels at the same channel offset and land on 16 different 16-B bank groups (conflict-free; 2-way for the
+// stride-2 layers).  65-80 KB of LDS and <128 VGPRs per block -> 2 blocks per CU: one block's staging overlaps the other's
+// MFMAs.  The blockIdx -> tile map hands every XCD a contiguous range of tiles (its L2 holds the halo rows it re-reads).
+//
+// F32X3: fp32 tensors.  x = hi + lo with hi = bf16(x), lo = bf16(x - hi); a*b ~ a_hi*b_hi + a_hi*b_lo + a_lo*b_hi
+// (3 MFMAs, fp32 accumulate, small terms first).  Two LDS planes (hi, lo) for tile and panel.
+//
+// Epilogue: C/D layout of the 32x32 MFMA = (column = lane & 31 = output channel, row = pixel).  fp32 outputs: one dword per
+// lane and register, 128-B runs per pixel.  bf16 outputs: neighbouring lanes exchange one value per register pair through
+// DPP (quad_perm 1,0,3,2), so every lane stores 2 adjacent channels of one pixel (4 B; 64-B runs per pixel).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/liso_conv.h"
+#include "../../include/liso_iou3d.h"
+
+namespace {
+
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+constexpr int kThreads = 256;
+constexpr int kMaxWChunks = 4;  // 16-B weight chunks per thread and stage
+
+struct FwdArgs {
+    const void* x;
+    const void* w;
+    const float* bias;
+    const float* in_scale;
+    const float* in_shift;
+    void* y;
+    float* stats;
+    const float* stats_shift;
+    int ci_pad, co_pad;
+    int cs;        // channels per slab
+    int g_taps;    // taps per weight stage
+    int cls_dy0[LISO_CONV_MAX_CLASSES], cls_dx0[LISO_CONV_MAX_CLASSES];
+    int cls_inh[LISO_CONV_MAX_CLASSES], cls_inw[LISO_CONV_MAX_CLASSES];
+    int tiles_x, tiles_y, n_nt, total;
+    int x_plane_bytes;  // LDS bytes of one plane of the input tile (max over classes), multiple of 16
+};
+
+__device__ __forceinline__ int xcd_remap(int bid, int total) {
+    // blocks b and b + 8 share an XCD (round-robin dispatch): give every XCD a contiguous chunk of the logical ids
+    const int q = total >> 3, r = total & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+    const __bf16 x = (__bf16)a, y = (__bf16)b;
+    return (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
+}
+__device__ __forceinline__ float bf16_lo(unsigned w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+__device__ __forceinline__ float round_bf16(float v) { return (float)(__bf16)v; }
+
+__device__ __forceinline__ bf8 as_bf8(const uint4& v) { return __builtin_bit_cast(bf8, v); }
+
+template <int MODE, int MI, int NJ, bool OUT_F32>
+__global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(const liso_conv_desc d, const FwdArgs a) {
+    constexpr int BNT = 32 * NJ;
+    constexpr int TH = 4 * MI;
+    constexpr bool X3 = MODE == LISO_CONV_F32X3;
+    constexpr int PLANES = X3 ? 2 : 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    int t = xcd_remap(blockIdx.x, a.total);
+    const int nt = t % a.n_nt;
+    t /= a.n_nt;
+    const int tx = t % a.tiles_x;
+    t /= a.tiles_x;
+    const int ty = t % a.tiles_y;
+    t /= a.tiles_y;
+    const int b = t % d.batch;
+    const int cls = t / d.batch;
+    const int stats_row = ((cls * d.batch + b) * a.tiles_y + ty) * a.tiles_x + tx;
+    const int n0 = nt * BNT;
+
+    const int tb = d.class_tap_begin[cls], te = d.class_tap_begin[cls + 1];
+    const int dy0 = a.cls_dy0[cls], dx0 = a.cls_dx0[cls], in_h = a.cls_inh[cls], in_w = a.cls_inw[cls];
+    const int cs = a.cs;
+    const int PS = cs * 2 + 16;
+    const int npix = in_h * in_w;
+    const float inv_w = 1.0f / (float)in_w;
+    const int iy0 = ty * TH * d.isy + dy0, ix0 = tx * 32 * d.isx + dx0;
+
+    unsigned char* xs = smem;
+    unsigned char* wsb = smem + a.x_plane_bytes * PLANES;
+    const int k8 = cs >> 3;                  // 8-channel groups per slab
+    const int wtap_bytes = k8 * BNT * 16;    // one tap, one plane
+    const int G = a.g_taps;
+    const int wstage_bytes = G * wtap_bytes * PLANES;
+
+    int a_off[MI];
+#pragma unroll
+    for (int i = 0; i < MI; i++) {
+        const int m = wave * (32 * MI) + i * 32 + r;
+        a_off[i] = (((m >> 5) * d.isy) * in_w + (m & 31) * d.isx) * PS + h * 16;
+    }
+    int b_off[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) b_off[j] = (h * BNT + j * 32 + r) * 16;
+
+    f16v acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; i++)
+#pragma unroll
+        for (int j = 0; j < NJ; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
+
+    const int n_stage = (te - tb + G - 1) / G;
+    const int kgroups_total = a.ci_pad >> 3;
+    const long x_img = (long)b * d.hi * d.wi;
+
+    for (int c0 = 0; c0 < d.ci; c0 += cs) {
+        const int rem = d.ci - c0;
+        const int ksteps = ((rem < cs ? rem : cs) + 15) >> 4;
+        __syncthreads();  // every read of the previous slab's tile / panels is done
+        // ---- stage the input halo tile --------------------------------------------------------------------------------
+        if constexpr (!X3) {
+            const int cpp = k8;  // 16-B chunks (8 bf16) per pixel
+            const int c8 = tid % cpp, p0 = tid / cpp, pstep = kThreads / cpp;
+            const int ch = c0 + c8 * 8;
+            const bool ch_ok = ch < d.ci;
+            float sc[8], sh[8];
+            const bool pro = a.in_scale != nullptr;
+            if (pro) {
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    sc[e] = ch_ok ? a.in_scale[ch + e] : 0.0f;
+                    sh[e] = ch_ok ? a.in_shift[ch + e] : 0.0f;
+                }
+            }
+            const unsigned short* xg = (const unsigned short*)a.x;
+            for (int pix0 = p0; pix0 < npix; pix0 += 4 * pstep) {
+                uint4 v[4];
+                bool ok[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int pix = pix0 + u * pstep;
+                    const int ly = (int)(((float)pix + 0.5f) * inv_w);
+                    const int lx = pix - ly * in_w;
+                    const int iy = iy0 + ly, ix = ix0 + lx;
+                    ok[u] = pix < npix && ch_ok && iy >= 0 && iy < d.hi && ix >= 0 && ix < d.wi;
+                    const long off = ok[u] ? ((x_img + (long)iy * d.wi + ix) * d.x_pix_stride + ch) : 0;
+                    v[u] = *reinterpret_cast<const uint4*>(xg + off);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int pix = pix0 + u * pstep;
+                    if (pix >= npix) continue;
+                    uint4 o = v[u];
+                    if (pro) {
+                        unsigned w[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            float f0 = fmaf(bf16_lo(w[e]), sc[2 * e], sh[2 * e]);
+                            float f1 = fmaf(bf16_hi(w[e]), sc[2 * e + 1], sh[2 * e + 1]);
+                            if (d.in_relu) {
+                                f0 = fmaxf(f0, 0.0f);
+                                f1 = fmaxf(f1, 0.0f);
+                            }
+                            w[e] = pack_bf16(f0, f1);
+                        }
+                        o = make_uint4(w[0], w[1], w[2], w[3]);
+                    }
+                    if (!ok[u]) o = make_uint4(0u, 0u, 0u, 0u);
+                    *reinterpret_cast<uint4*>(xs + pix * PS + c8 * 16) = o;
+                }
+            }
+        } else {
+            const int cpp = cs >> 2;  // 16-B chunks (4 fp32) per pixel
+            const int c4 = tid % cpp, p0 = tid / cpp, pstep = kThreads / cpp;
+            const int ch = c0 + c4 * 4;
+            const bool ch_ok = ch < d.ci;
+            float sc[4], sh[4];
+            const bool pro = a.in_scale != nullptr;
+            if (pro) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    sc[e] = ch_ok ? a.in_scale[ch + e] : 0.0f;
+                    sh[e] = ch_ok ? a.in_shift[ch + e] : 0.0f;
+                }
+            }
+            const float* xg = (const float*)a.x;
+            unsigned char* xs_lo = xs + a.x_plane_bytes;
+            for (int pix0 = p0; pix0 < npix; pix0 += 4 * pstep) {
+                float4 v[4];
+                bool ok[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int pix = pix0 + u * pstep;
+                    const int ly = (int)(((float)pix + 0.5f) * inv_w);
+                    const int lx = pix - ly * in_w;
+                    const int iy = iy0 + ly, ix = ix0 + lx;
+                    ok[u] = pix < npix && ch_ok && iy >= 0 && iy < d.hi && ix >= 0 && ix < d.wi;
+                    const long off = ok[u] ? ((x_img + (long)iy * d.wi + ix) * d.x_pix_stride + ch) : 0;
+                    v[u] = *reinterpret_cast<const float4*>(xg + off);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int pix = pix0 + u * pstep;
+                    if (pix >= npix) continue;
+                    float f[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+                    unsigned hi2[2], lo2[2];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        if (pro) {
+                            f[e] = fmaf(f[e], sc[e], sh[e]);
+                            if (d.in_relu) f[e] = fmaxf(f[e], 0.0f);
+                        }
+                        if (!ok[u]) f[e] = 0.0f;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 2; e++) {
+                        const float h0 = round_bf16(f[2 * e]), h1 = round_bf16(f[2 * e + 1]);
+                        hi2[e] = pack_bf16(h0, h1);
+                        lo2[e] = pack_bf16(f[2 * e] - h0, f[2 * e + 1] - h1);
+                    }
+                    *reinterpret_cast<uint2*>(xs + pix * PS + c4 * 8) = make_uint2(hi2[0], hi2[1]);
+                    *reinterpret_cast<uint2*>(xs_lo + pix * PS + c4 * 8) = make_uint2(lo2[0], lo2[1]);
+                }
+            }
+        }
+        // ---- weight panels: stage 0 now, stage s+1 behind the MFMAs of stage s ----------------------------------------------
+        const unsigned short* wg = (const unsigned short*)a.w;
+        const long plane_elems = (long)d.w_taps * kgroups_total * a.co_pad * 8;
+        auto load_stage = [&](int s, uint4 (&regs)[kMaxWChunks]) {
+            const int g_cur = min(G, te - tb - s * G);
+            const int per_plane = g_cur * k8 * BNT;
+#pragma unroll
+            for (int u = 0; u < kMaxWChunks; u++) {
+                const int q = tid + u * kThreads;
+                const int plane = q / per_plane;  // (per_plane > 0)
+                const int rq = q - plane * per_plane;
+                const int g = rq / (k8 * BNT);
+                const int rr = rq - g * (k8 * BNT);
+                const int c8 = rr / BNT, n = rr - c8 * BNT;
+                const int kg = (c0 >> 3) + c8;
+                const bool okq = plane < PLANES && kg < kgroups_total;
+                const int tw = d.tap_w[tb + s * G + (okq ? g : 0)];
+                const long off = okq ? (plane * plane_elems + (((long)tw * kgroups_total + kg) * a.co_pad + n0 + n) * 8) : 0;
+                uint4 v = *reinterpret_cast<const uint4*>(wg + off);
+                if (!okq) v = make_uint4(0u, 0u, 0u, 0u);
+                regs[u] = v;
+            }
+        };
+        auto store_stage = [&](int s, const uint4 (&regs)[kMaxWChunks]) {
+            const int g_cur = min(G, te - tb - s * G);
+            const int per_plane = g_cur * k8 * BNT;
+            unsigned char* wb = wsb + (s & 1) * wstage_bytes;
+#pragma unroll
+            for (int u = 0; u < kMaxWChunks; u++) {
+                const int q = tid + u * kThreads;
+                const int plane = q / per_plane;
+                if (plane >= PLANES) continue;
+                const int rq = q - plane * per_plane;  // = g * k8 * BNT + c8 * BNT + n: the LDS order
+                *reinterpret_cast<uint4*>(wb + plane * (G * wtap_bytes) + rq * 16) = regs[u];
+            }
+        };
+        uint4 wregs[kMaxWChunks];
+        load_stage(0, wregs);
+        store_stage(0, wregs);
+        __syncthreads();
+        for (int s = 0; s < n_stage; s++) {
+            const bool more = s + 1 < n_stage;
+            if (more) load_stage(s + 1, wregs);
+            const int g_cur = min(G, te - tb - s * G);
+            const unsigned char* wb = wsb + (s & 1) * wstage_bytes;
+            for (int g = 0; g < g_cur; g++) {
+                const int tp = tb + s * G + g;
+                const int toff = ((d.tap_dy[tp] - dy0) * in_w + (d.tap_dx[tp] - dx0)) * PS;
+                const unsigned char* wt = wb + g * wtap_bytes;
+                for (int kk = 0; kk < ksteps; kk++) {
+                    uint4 af[MI], bfr[NJ];
+#pragma unroll
+                    for (int i = 0; i < MI; i++) af[i] = *reinterpret_cast<const uint4*>(xs + a_off[i] + toff + kk * 32);
+#pragma unroll
+                    for (int j = 0; j < NJ; j++) bfr[j] = *reinterpret_cast<const uint4*>(wt + b_off[j] + kk * (2 * BNT * 16));
+                    if constexpr (X3) {
+                        uint4 al[MI], bl[NJ];
+#pragma unroll
+                        for (int i = 0; i < MI; i++)
+                            al[i] = *reinterpret_cast<const uint4*>(xs + a.x_plane_bytes + a_off[i] + toff + kk * 32);
+#pragma unroll
+                        for (int j = 0; j < NJ; j++)
+                            bl[j] = *reinterpret_cast<const uint4*>(wt + G * wtap_bytes + b_off[j] + kk * (2 * BNT * 16));
+#pragma unroll
+                        for (int i = 0; i < MI; i++)
+#pragma unroll
+                            for (int j = 0; j < NJ; j++) {
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(al[i]), as_bf8(bfr[j]), acc[i][j], 0, 0, 0);
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(af[i]), as_bf8(bl[j]), acc[i][j], 0, 0, 0);
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(af[i]), as_bf8(bfr[j]), acc[i][j], 0, 0, 0);
+                            }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < MI; i++)
+#pragma unroll
+                            for (int j = 0; j < NJ; j++)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(af[i]), as_bf8(bfr[j]), acc[i][j], 0, 0, 0);
+                    }
+                }
+            }
+            if (more) store_stage(s + 1, wregs);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue ------------------------------------------------------------------------------------------------------------
+    const bool want_stats = a.stats != nullptr;
+    float s1[NJ], s2[NJ];
+    const int ooy = d.class_ooy[cls], oox = d.class_oox[cls];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+        const int n = n0 + j * 32 + r;
+        const bool n_ok = n < d.co;
+        const float bias_v = (a.bias && n_ok) ? a.bias[n] : 0.0f;
+        const float shift_v = (a.stats_shift && n_ok) ? a.stats_shift[n] : 0.0f;
+        s1[j] = 0.0f;
+        s2[j] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < MI; i++) {
+            float v[16];
+            bool pv[16];
+            long po[16];
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                float val = acc[i][j][e] + bias_v;
+                if (d.out_relu) val = fmaxf(val, 0.0f);
+                const int m = wave * (32 * MI) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                const int vy = ty * TH + (m >> 5), vx = tx * 32 + (m & 31);
+                const int oy = vy * d.osy + ooy, ox = vx * d.osx + oox;
+                pv[e] = vy < d.hv && vx < d.wv && oy < d.ho && ox < d.wo;
+                po[e] = (((long)b * d.ho + oy) * d.wo + ox) * d.y_pix_stride + d.y_ch_off;
+                if constexpr (!OUT_F32) val = round_bf16(val);
+                v[e] = val;
+                if (want_stats && pv[e]) {
+                    const float dd = val - shift_v;
+                    s1[j] += dd;
+                    s2[j] = fmaf(dd, dd, s2[j]);
+                }
+            }
+            if constexpr (OUT_F32) {
+                float* yg = (float*)a.y;
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                    if (pv[e] && n_ok) yg[po[e] + n] = v[e];
+            } else {
+                unsigned short* yg = (unsigned short*)a.y;
+                const bool odd = r & 1;
+                const int n_even = n & ~1;
+                if ((d.y_pix_stride | d.y_ch_off) & 1) {  // odd pixel stride: channel pairs are not 4-B aligned, 2-B stores
+#pragma unroll
+                    for (int e = 0; e < 16; e++)
+                        if (pv[e] && n_ok) yg[po[e] + n] = (unsigned short)(pack_bf16(v[e], 0.0f) & 0xffffu);
+                } else
+#pragma unroll
+                for (int e = 0; e < 16; e += 2) {
+                    const float send = odd ? v[e] : v[e + 1];
+                    const float recv = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(send), 0xB1, 0xF, 0xF, true));
+                    const float c_lo = odd ? recv : v[e];      // channel n_even
+                    const float c_hi = odd ? v[e + 1] : recv;  // channel n_even + 1
+                    const int ee = odd ? e + 1 : e;            // the pixel this lane stores
+                    if (pv[ee]) {
+                        if (n_even + 1 < d.co)
+                            *reinterpret_cast<unsigned*>(yg + po[ee] + n_even) = pack_bf16(c_lo, c_hi);
+                        else if (n_even < d.co)
+                            yg[po[ee] + n_even] = (unsigned short)(pack_bf16(c_lo, 0.0f) & 0xffffu);
+                    }
+                }
+            }
+        }
+    }
+    if (want_stats) {
+        float* red = reinterpret_cast<float*>(smem);  // [4 waves][BNT][2]; the main loop ended with a barrier
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            const float t1 = s1[j] + __shfl_xor(s1[j], 32);
+            const float t2 = s2[j] + __shfl_xor(s2[j], 32);
+            if (h == 0) {
+                red[(wave * BNT + j * 32 + r) * 2 + 0] = t1;
+                red[(wave * BNT + j * 32 + r) * 2 + 1] = t2;
+            }
+        }
+        __syncthreads();
+        if (tid < BNT) {
+            float q1 = 0.0f, q2 = 0.0f;
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                q1 += red[(w * BNT + tid) * 2 + 0];
+                q2 += red[(w * BNT + tid) * 2 + 1];
+            }
+            a.stats[((long)stats_row * 2 + 0) * a.co_pad + n0 + tid] = q1;
+            a.stats[((long)stats_row * 2 + 1) * a.co_pad + n0 + tid] = q2;
+        }
+    }
+}
+
+// ---- weight packing ---------------------------------------------------------------------------------------------------------
+__global__ void pack_weights_kernel(const float* __restrict__ src, int d0, int d1, int taps, int swap_ab, int K, int N, int Kp,
+                                    int Np, int planes, unsigned short* __restrict__ dst) {
+    const long total = (long)planes * taps * (Kp / 8) * Np;  // one thread per 16-B chunk
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= total) return;
+    const int n = (int)(q % Np);
+    long t = q / Np;
+    const int k8 = (int)(t % (Kp / 8));
+    t /= (Kp / 8);
+    const int tap = (int)(t % taps);
+    const int plane = (int)(t / taps);
+    unsigned w[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        float f[2];
+#pragma unroll
+        for (int z = 0; z < 2; z++) {
+            const int k = k8 * 8 + 2 * e + z;
+            float v = 0.0f;
+            if (k < K && n < N) {
+                const int ia = swap_ab ? k : n, ib = swap_ab ? n : k;  // src[ia][ib][tap]
+                v = src[((long)ia * d1 + ib) * taps + tap];
+            }
+            const float hi = round_bf16(v);
+            f[z] = plane == 0 ? hi : (v - hi);
+        }
+        w[e] = pack_bf16(f[0], f[1]);
+    }
+    *reinterpret_cast<uint4*>(dst + q * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// ---- BatchNorm statistics from the per-block partial sums ---------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_bn_finalize_kernel(const float* __restrict__ partial, int rows, int co, int co_pad,
+                                                               long n, const float* __restrict__ stats_shift,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                               float momentum, float eps, float* __restrict__ stats) {
+    __shared__ double red[16][16];
+    const int col = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int c = blockIdx.x * 8 + (col & 7), s = col >> 3;
+    double acc = 0.0;
+    if (c < co)
+        for (int row = rg; row < rows; row += 16) acc += (double)partial[((long)row * 2 + s) * co_pad + c];
+    red[rg][col] = acc;
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        const int cc = blockIdx.x * 8 + threadIdx.x;
+        if (cc < co) {
+            double q1 = 0.0, q2 = 0.0;
+            for (int g = 0; g < 16; g++) {
+                q1 += red[g][threadIdx.x];
+                q2 += red[g][8 + threadIdx.x];
+            }
+            const double k = stats_shift ? (double)stats_shift[cc] : 0.0;
+            const double m1 = q1 / (double)n;
+            double var = q2 / (double)n - m1 * m1;
+            if (var < 0.0) var = 0.0;
+            const double mean = k + m1;
+            const double invstd = 1.0 / sqrt(var + (double)eps);
+            const double sc = (double)gamma[cc] * invstd;
+            stats[cc] = (float)sc;
+            stats[co + cc] = (float)((double)beta[cc] - mean * sc);
+            stats[2 * co + cc] = (float)mean;
+            stats[3 * co + cc] = (float)invstd;
+            if (running_mean) {
+                const double unb = n > 1 ? var * (double)n / (double)(n - 1) : var;
+                running_mean[cc] = (float)((1.0 - momentum) * running_mean[cc] + momentum * mean);
+                running_var[cc] = (float)((1.0 - momentum) * running_var[cc] + momentum * unb);
+            }
+        }
+    }
+}
+
+int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+int check_launch() { return hipGetLastError() == hipSuccess ? LISO_OK : LISO_ELAUNCH; }
+
+struct Plan {
+    int mi, nj, cs, g, lds;
+    FwdArgs a;
+};
+
+bool make_plan(const liso_conv_desc& d, Plan* p) {
+    if (d.batch <= 0 || d.ci <= 0 || d.co <= 0 || d.n_classes < 1 || d.n_classes > LISO_CONV_MAX_CLASSES) return false;
+    if (d.n_taps < 1 || d.n_taps > LISO_CONV_MAX_TAPS || d.class_tap_begin[0] != 0 || d.class_tap_begin[d.n_classes] != d.n_taps)
+        return false;
+    const bool x3 = d.mode == LISO_CONV_F32X3;
+    const int vec = x3 ? 4 : 8;
+    if (d.ci % vec || d.x_pix_stride % vec || d.x_pix_stride < d.ci) return false;
+    const int planes = x3 ? 2 : 1;
+    FwdArgs& a = p->a;
+    a.ci_pad = round_up(d.ci, 16);
+    a.co_pad = round_up(d.co, 64);
+    p->nj = d.co <= 32 ? 1 : 2;
+    const int bnt = 32 * p->nj;
+    a.n_nt = (d.co + bnt - 1) / bnt;
+    // rows per tile: 8 when that still fills the chip, else 4
+    auto blocks = [&](int th) { return (long)d.n_classes * d.batch * ((d.hv + th - 1) / th) * ((d.wv + 31) / 32) * a.n_nt; };
+    p->mi = blocks(8) >= 512 ? 2 : 1;
+    int max_taps = 1;
+    int lds_cap = 79 * 1024;  // 2 blocks per CU; second pass: one block per CU (large halos: 7x7 stride 2 in F32X3)
+    for (;;) {
+        const int th = 4 * p->mi;
+        int max_pix = 0;
+        for (int c = 0; c < d.n_classes; c++) {
+            int y0 = 1 << 30, y1 = -(1 << 30), x0 = 1 << 30, x1 = -(1 << 30);
+            const int nt = d.class_tap_begin[c + 1] - d.class_tap_begin[c];
+            if (nt < 1) return false;
+            max_taps = nt > max_taps ? nt : max_taps;
+            for (int t = d.class_tap_begin[c]; t < d.class_tap_begin[c + 1]; t++) {
+                y0 = d.tap_dy[t] < y0 ? d.tap_dy[t] : y0;
+                y1 = d.tap_dy[t] > y1 ? d.tap_dy[t] : y1;
+                x0 = d.tap_dx[t] < x0 ? d.tap_dx[t] : x0;
+                x1 = d.tap_dx[t] > x1 ? d.tap_dx[t] : x1;
+                if (d.tap_w[t] < 0 || d.tap_w[t] >= d.w_taps) return false;
+            }
+            a.cls_dy0[c] = y0;
+            a.cls_dx0[c] = x0;
+            a.cls_inh[c] = (th - 1) * d.isy + (y1 - y0) + 1;
+            a.cls_inw[c] = 31 * d.isx + (x1 - x0) + 1;
+            const int np = a.cls_inh[c] * a.cls_inw[c];
+            max_pix = np > max_pix ? np : max_pix;
+        }
+        // largest slab whose tile + double-buffered panels fit 80 KB (2 blocks per CU)
+        const int cs_opts[3] = {64, 32, 16};
+        bool found = false;
+        for (int k = x3 ? 1 : 0; k < 3 && !found; k++) {
+            const int cs = cs_opts[k];
+            if (cs > a.ci_pad && k < 2 && cs_opts[k + 1] >= a.ci_pad) continue;  // do not stage channels that do not exist
+            const int xb = round_up(max_pix * (cs * 2 + 16), 16);
+            const int per_tap = planes * (cs / 8) * bnt;  // 16-B chunks per tap
+            int g = kMaxWChunks * kThreads / per_tap;
+            g = g < 1 ? 1 : (g > max_taps ? max_taps : g);
+            for (; g >= 1; g--) {
+                const int lds = xb * planes + 2 * g * per_tap * 16;
+                if (lds <= lds_cap) {
+                    p->cs = cs;
+                    p->g = g;
+                    p->lds = lds < 4 * 64 * 2 * 4 ? 4 * 64 * 2 * 4 : lds;
+                    a.x_plane_bytes = xb;
+                    found = true;
+                    break;
+                }
+            }
+        }
+        if (found) break;
+        if (p->mi == 2) {
+            p->mi = 1;
+            continue;
+        }
+        if (lds_cap < 158 * 1024) {
+            lds_cap = 158 * 1024;
+            p->mi = blocks(8) >= 512 ? 2 : 1;
+            continue;
+        }
+        return false;
+    }
+    const int th = 4 * p->mi;
+    a.cs = p->cs;
+    a.g_taps = p->g;
+    a.tiles_x = (d.wv + 31) / 32;
+    a.tiles_y = (d.hv + th - 1) / th;
+    a.total = (int)blocks(th);
+    return true;
+}
+
+template <int MODE, int MI, int NJ, bool OUT_F32>
+int launch(const liso_conv_desc& d, const Plan& p, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)conv_igemm_kernel<MODE, MI, NJ, OUT_F32>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess)
+            return LISO_ELAUNCH;
+        attr_set = true;
+    }
+    conv_igemm_kernel<MODE, MI, NJ, OUT_F32><<<p.a.total, kThreads, p.lds, st>>>(d, p.a);
+    return check_launch();
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t liso_conv_packed_bytes(int k_channels, int n_channels, int taps, int mode) {
+    if (k_channels <= 0 || n_channels <= 0 || taps <= 0) return 0;
+    const size_t planes = mode == LISO_CONV_F32X3 ? 2 : 1;
+    return planes * (size_t)taps * round_up(k_channels, 16) * round_up(n_channels, 64) * 2;
+}
+
+int liso_conv_pack_weights(const float* src, int d0, int d1, int kh, int kw, int transposed, int for_dgrad, int mode, void* dst,
+                           void* stream) {
+    if (!src || !dst || d0 <= 0 || d1 <= 0 || kh <= 0 || kw <= 0) return LISO_EINVAL;
+    const bool same = (transposed != 0) == (for_dgrad != 0);
+    const int K = same ? d1 : d0, N = same ? d0 : d1;
+    const int Kp = round_up(K, 16), Np = round_up(N, 64), taps = kh * kw, planes = mode == LISO_CONV_F32X3 ? 2 : 1;
+    const long total = (long)planes * taps * (Kp / 8) * Np;
+    pack_weights_kernel<<<(int)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(src, d0, d1, taps, same ? 0 : 1, K, N, Kp, Np,
+                                                                                      planes, (unsigned short*)dst);
+    return check_launch();
+}
+
+int liso_conv_stats_rows(const liso_conv_desc* d) {
+    Plan p;
+    if (!d || !make_plan(*d, &p)) return -1;
+    return d->n_classes * d->batch * p.a.tiles_y * p.a.tiles_x;
+}
+
+int liso_conv_forward(const liso_conv_desc* d, const void* x, const void* w_packed, const float* bias, const float* in_scale,
+                      const float* in_shift, void* y, float* stats_partial, const float* stats_shift, void* stream) {
+    if (!d || !x || !w_packed || !y) return LISO_EINVAL;
+    if ((in_scale == nullptr) != (in_shift == nullptr)) return LISO_EINVAL;
+    if (((uintptr_t)x | (uintptr_t)w_packed) & 15) return LISO_EINVAL;
+    Plan p;
+    if (!make_plan(*d, &p)) return LISO_EINVAL;
+    p.a.x = x;
+    p.a.w = w_packed;
+    p.a.bias = bias;
+    p.a.in_scale = in_scale;
+    p.a.in_shift = in_shift;
+    p.a.y = y;
+    p.a.stats = stats_partial;
+    p.a.stats_shift = stats_shift;
+    hipStream_t st = (hipStream_t)stream;
+    const bool x3 = d->mode == LISO_CONV_F32X3;
+    const bool of32 = x3 || d->out_f32;
+#define LISO_GO(MODE, MI, NJ, OF) return launch<MODE, MI, NJ, OF>(*d, p, st)
+#define LISO_SEL(MODE, OF)                  \
+    do {                                    \
+        if (p.mi == 2 && p.nj == 2) LISO_GO(MODE, 2, 2, OF); \
+        if (p.mi == 2 && p.nj == 1) LISO_GO(MODE, 2, 1, OF); \
+        if (p.mi == 1 && p.nj == 2) LISO_GO(MODE, 1, 2, OF); \
+        LISO_GO(MODE, 1, 1, OF);            \
+    } while (0)
+    if (x3) LISO_SEL(LISO_CONV_F32X3, true);
+    if (of32) LISO_SEL(LISO_CONV_BF16, true);
+    LISO_SEL(LISO_CONV_BF16, false);
+#undef LISO_SEL
+#undef LISO_GO
+}
+
+int liso_conv_bn_finalize(const float* stats_partial, int rows, int co, int co_pad, long n, const float* stats_shift,
+                          const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
+                          float eps, float* stats, void* stream) {
+    if (!stats_partial || !gamma || !beta || !stats || rows <= 0 || co <= 0 || co_pad < co || n <= 0) return LISO_EINVAL;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return LISO_EINVAL;
+    conv_bn_finalize_kernel<<<(co + 7) / 8, 256, 0, (hipStream_t)stream>>>(stats_partial, rows, co, co_pad, n, stats_shift, gamma,
+                                                                          beta, running_mean, running_var, momentum, eps, stats);
+    return check_launch();
+}
+
+}  // extern "C"

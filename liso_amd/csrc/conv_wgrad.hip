@@ -1,0 +1,513 @@
+// Weight gradient of the NHWC convolutions on the gfx950 matrix cores (C ABI: include/liso_conv.h, liso_conv_wgrad).
+//
+//   dW[tap][ci][co] = sum over (sample, virtual pixel v) of  x'[v*is + tap][ci] * dy[v*os + oo][co]
+// is a GEMM whose reduction axis is the PIXEL axis, while both operands are stored channel-contiguous (NHWC).  The MFMA
+// wants 8 consecutive k per lane, i.e. 8 consecutive pixels of one channel: the tiles are staged into LDS exactly as they
+// lie in memory ([pixel][channel], the same halo tile + BatchNorm/ReLU prologue as the forward kernel) and read back with
+// ds_read_b64_tr_b16, gfx950's transposing LDS read (a 16-lane group reads 4 pixels x 16 channels and receives them
+// channel-major): no shuffles, no transposed copy.
+//
+// Block = 256 threads = 4 waves, one (64 input channels x 64 output channels) tile of up to TG taps; wave w owns the
+// 32 x 32 quadrant (ci half w >> 1, co half w & 1) of every tap -> TG accumulators of 16 registers.  The block walks its
+// share of the 4 x 32-pixel tiles of the batch (split-K over pixels), keeps the sums in registers and writes ONE fp32
+// slab at the end; a second kernel adds the slabs in a fixed order (no float atomics: bitwise reproducible) and emits the
+// gradient in torch's weight layout, and the bias gradient (column sums of dy, accumulated while dy is staged).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/liso_conv.h"
+#include "../../include/liso_iou3d.h"
+
+namespace {
+
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef short s4 __attribute__((ext_vector_type(4)));
+typedef s4 __attribute__((address_space(3))) * lds_s4_ptr;
+
+constexpr int kThreads = 256;
+constexpr int TW = 32;  // virtual pixels per tile row; 4, 2 or 1 rows per tile (WgArgs::th), fewer when the halo tile is large
+constexpr int CT = 64;                           // channel tile (both ci and co)
+constexpr int PSY = CT * 2 + 16;                 // LDS bytes per dy pixel
+
+struct WgArgs {
+    const void* x;
+    const float* in_scale;
+    const float* in_shift;
+    const void* dy;
+    float* slab;       // [splits][w_taps][ci_t * 64][co_t * 64]
+    float* bias_slab;  // [classes][splits][co_t * 64] or null
+    int dy_pix_stride;
+    int ci_t, co_t;    // channel tiles
+    int n_groups;      // tap groups over all classes
+    int grp_cls[LISO_CONV_MAX_TAPS], grp_begin[LISO_CONV_MAX_TAPS], grp_cnt[LISO_CONV_MAX_TAPS];
+    int cls_dy0[LISO_CONV_MAX_CLASSES], cls_dx0[LISO_CONV_MAX_CLASSES];
+    int cls_inh[LISO_CONV_MAX_CLASSES], cls_inw[LISO_CONV_MAX_CLASSES];
+    int tiles_x, tiles_y, n_tiles, splits;
+    int x_plane_bytes;  // multiple of 16
+    int psx;            // LDS bytes per x pixel
+    int th;             // tile rows
+};
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+    const __bf16 x = (__bf16)a, y = (__bf16)b;
+    return (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
+}
+__device__ __forceinline__ float bf16_lo(unsigned w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+__device__ __forceinline__ float round_bf16(float v) { return (float)(__bf16)v; }
+
+__device__ __forceinline__ bf8 tr_pair(const unsigned char* p0, const unsigned char* p1) {
+    // two transposing reads: elements 0-3 = 4 consecutive k of this lane's column, elements 4-7 the next 4
+    const s4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)p0);
+    const s4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)p1);
+    typedef short s8 __attribute__((ext_vector_type(8)));
+    const s8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(bf8, v);
+}
+
+template <int MODE, int TG>
+__global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(const liso_conv_desc d, const WgArgs a) {
+    constexpr bool X3 = MODE == LISO_CONV_F32X3;
+    constexpr int PLANES = X3 ? 2 : 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    int t = blockIdx.x;
+    const int split = t % a.splits;
+    t /= a.splits;
+    const int cot = t % a.co_t;
+    t /= a.co_t;
+    const int cit = t % a.ci_t;
+    const int grp = t / a.ci_t;
+    const int cls = a.grp_cls[grp], tb = a.grp_begin[grp], tcnt = a.grp_cnt[grp];
+    const int dy0 = a.cls_dy0[cls], dx0 = a.cls_dx0[cls], in_h = a.cls_inh[cls], in_w = a.cls_inw[cls];
+    const int PSX = a.psx;
+    const int npix = in_h * in_w;
+    const float inv_w = 1.0f / (float)in_w;
+    const int ooy = d.class_ooy[cls], oox = d.class_oox[cls];
+    const int ci0 = cit * CT, co0 = cot * CT;
+
+    unsigned char* xs = smem;
+    unsigned char* ys = smem + a.x_plane_bytes * PLANES;
+    const int TH = a.th, MPIX = TH * TW;
+    const int y_plane = MPIX * PSY;
+
+    // transposing-read lane geometry (16-lane groups): group g -> k half (g >> 1), channel half-tile (g & 1)
+    const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const int ci_half = wave >> 1, co_half = wave & 1;
+    const int a_lane = (8 * (g >> 1) + q) * d.isx * PSX + (ci_half * 32 + 16 * (g & 1) + 4 * p) * 2;
+    const int b_lane = (8 * (g >> 1) + q) * PSY + (co_half * 32 + 16 * (g & 1) + 4 * p) * 2;
+
+    f16v acc[TG];
+#pragma unroll
+    for (int i = 0; i < TG; i++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[i][e] = 0.0f;
+    float bsum[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) bsum[e] = 0.0f;
+    const bool want_bias = a.bias_slab != nullptr && cit == 0 && tb == d.class_tap_begin[cls];  // once per class
+
+    int toff[TG];
+#pragma unroll
+    for (int i = 0; i < TG; i++) {
+        const int tp = tb + (i < tcnt ? i : 0);
+        toff[i] = ((d.tap_dy[tp] - dy0) * in_w + (d.tap_dx[tp] - dx0)) * PSX;
+    }
+
+    for (int tile = split; tile < a.n_tiles; tile += a.splits) {
+        int tt = tile;
+        const int tx = tt % a.tiles_x;
+        tt /= a.tiles_x;
+        const int ty = tt % a.tiles_y;
+        const int b = tt / a.tiles_y;
+        const int iy0 = ty * TH * d.isy + dy0, ix0 = tx * TW * d.isx + dx0;
+        const long x_img = (long)b * d.hi * d.wi;
+        __syncthreads();
+        // ---- stage x' (halo tile, 64 channels) --------------------------------------------------------------------------
+        if constexpr (!X3) {
+            const int c8 = tid & 7, p0 = tid >> 3, pstep = kThreads / 8;
+            const int ch = ci0 + c8 * 8;
+            const bool ch_ok = ch < d.ci;
+            const bool pro = a.in_scale != nullptr;
+            float sc[8], sh[8];
+            if (pro) {
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    sc[e] = ch_ok ? a.in_scale[ch + e] : 0.0f;
+                    sh[e] = ch_ok ? a.in_shift[ch + e] : 0.0f;
+                }
+            }
+            const unsigned short* xg = (const unsigned short*)a.x;
+            for (int pix0 = p0; pix0 < npix; pix0 += 2 * pstep) {
+                uint4 v[2];
+                bool ok[2];
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const int pix = pix0 + u * pstep;
+                    const int ly = (int)(((float)pix + 0.5f) * inv_w);
+                    const int lx = pix - ly * in_w;
+                    const int iy = iy0 + ly, ix = ix0 + lx;
+                    ok[u] = pix < npix && ch_ok && iy >= 0 && iy < d.hi && ix >= 0 && ix < d.wi;
+                    const long off = ok[u] ? ((x_img + (long)iy * d.wi + ix) * d.x_pix_stride + ch) : 0;
+                    v[u] = *reinterpret_cast<const uint4*>(xg + off);
+                }
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const int pix = pix0 + u * pstep;
+                    if (pix >= npix) continue;
+                    uint4 o = v[u];
+                    if (pro) {
+                        unsigned w[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            float f0 = fmaf(bf16_lo(w[e]), sc[2 * e], sh[2 * e]);
+                            float f1 = fmaf(bf16_hi(w[e]), sc[2 * e + 1], sh[2 * e + 1]);
+                            if (d.in_relu) {
+                                f0 = fmaxf(f0, 0.0f);
+                                f1 = fmaxf(f1, 0.0f);
+                            }
+                            w[e] = pack_bf16(f0, f1);
+                        }
+                        o = make_uint4(w[0], w[1], w[2], w[3]);
+                    }
+                    if (!ok[u]) o = make_uint4(0u, 0u, 0u, 0u);
+                    *reinterpret_cast<uint4*>(xs + pix * PSX + c8 * 16) = o;
+                }
+            }
+            // ---- stage dy (128 virtual pixels x 64 channels) -----------------------------------------------------------
+            const unsigned short* yg = (const unsigned short*)a.dy;
+            const int chy = co0 + c8 * 8;
+            const bool chy_ok = chy < d.co;  // (co % 8 == 0 is required in this mode)
+            for (int u = 0; u < MPIX / (kThreads / 8); u++) {
+                const int m = p0 + u * pstep;
+                const int vy = ty * TH + (m >> 5), vx = tx * TW + (m & 31);
+                const int oy = vy * d.osy + ooy, ox = vx * d.osx + oox;
+                const bool ok = chy_ok && vy < d.hv && vx < d.wv && oy < d.ho && ox < d.wo;
+                const long off = ok ? ((((long)b * d.ho + oy) * d.wo + ox) * a.dy_pix_stride + chy) : 0;
+                uint4 v = *reinterpret_cast<const uint4*>(yg + off);
+                if (!ok) v = make_uint4(0u, 0u, 0u, 0u);
+                *reinterpret_cast<uint4*>(ys + m * PSY + c8 * 16) = v;
+                if (want_bias) {
+                    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        bsum[2 * e] += bf16_lo(w[e]);
+                        bsum[2 * e + 1] += bf16_hi(w[e]);
+                    }
+                }
+            }
+        } else {
+            const int c4 = tid & 15, p0 = tid >> 4, pstep = kThreads / 16;
+            const int ch = ci0 + c4 * 4;
+            const bool ch_ok = ch < d.ci;
+            const bool pro = a.in_scale != nullptr;
+            float sc[4], sh[4];
+            if (pro) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    sc[e] = ch_ok ? a.in_scale[ch + e] : 0.0f;
+                    sh[e] = ch_ok ? a.in_shift[ch + e] : 0.0f;
+                }
+            }
+            const float* xg = (const float*)a.x;
+            unsigned char* xs_lo = xs + a.x_plane_bytes;
+            for (int pix0 = p0; pix0 < npix; pix0 += 2 * pstep) {
+                float4 v[2];
+                bool ok[2];
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const int pix = pix0 + u * pstep;
+                    const int ly = (int)(((float)pix + 0.5f) * inv_w);
+                    const int lx = pix - ly * in_w;
+                    const int iy = iy0 + ly, ix = ix0 + lx;
+                    ok[u] = pix < npix && ch_ok && iy >= 0 && iy < d.hi && ix >= 0 && ix < d.wi;
+                    const long off = ok[u] ? ((x_img + (long)iy * d.wi + ix) * d.x_pix_stride + ch) : 0;
+                    v[u] = *reinterpret_cast<const float4*>(xg + off);
+                }
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const int pix = pix0 + u * pstep;
+                    if (pix >= npix) continue;
+                    float f[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+                    unsigned hi2[2], lo2[2];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        if (pro) {
+                            f[e] = fmaf(f[e], sc[e], sh[e]);
+                            if (d.in_relu) f[e] = fmaxf(f[e], 0.0f);
+                        }
+                        if (!ok[u]) f[e] = 0.0f;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 2; e++) {
+                        const float h0 = round_bf16(f[2 * e]), h1 = round_bf16(f[2 * e + 1]);
+                        hi2[e] = pack_bf16(h0, h1);
+                        lo2[e] = pack_bf16(f[2 * e] - h0, f[2 * e + 1] - h1);
+                    }
+                    *reinterpret_cast<uint2*>(xs + pix * PSX + c4 * 8) = make_uint2(hi2[0], hi2[1]);
+                    *reinterpret_cast<uint2*>(xs_lo + pix * PSX + c4 * 8) = make_uint2(lo2[0], lo2[1]);
+                }
+            }
+            const float* yg = (const float*)a.dy;
+            const int chy = co0 + c4 * 4;
+            const bool chy_ok = chy < d.co;  // (co % 4 == 0 is required in this mode)
+            for (int u = 0; u < MPIX / (kThreads / 16); u++) {
+                const int m = p0 + u * pstep;
+                const int vy = ty * TH + (m >> 5), vx = tx * TW + (m & 31);
+                const int oy = vy * d.osy + ooy, ox = vx * d.osx + oox;
+                const bool ok = chy_ok && vy < d.hv && vx < d.wv && oy < d.ho && ox < d.wo;
+                const long off = ok ? ((((long)b * d.ho + oy) * d.wo + ox) * a.dy_pix_stride + chy) : 0;
+                float4 v = *reinterpret_cast<const float4*>(yg + off);
+                float f[4] = {v.x, v.y, v.z, v.w};
+                unsigned hi2[2], lo2[2];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    if (!ok) f[e] = 0.0f;
+                    if (want_bias) bsum[e] += f[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    const float h0 = round_bf16(f[2 * e]), h1 = round_bf16(f[2 * e + 1]);
+                    hi2[e] = pack_bf16(h0, h1);
+                    lo2[e] = pack_bf16(f[2 * e] - h0, f[2 * e + 1] - h1);
+                }
+                *reinterpret_cast<uint2*>(ys + m * PSY + c4 * 8) = make_uint2(hi2[0], hi2[1]);
+                *reinterpret_cast<uint2*>(ys + y_plane + m * PSY + c4 * 8) = make_uint2(lo2[0], lo2[1]);
+            }
+        }
+        __syncthreads();
+        // ---- 8 k-steps of 16 pixels -----------------------------------------------------------------------------------------
+        for (int kk = 0; kk < MPIX / 16; kk++) {
+            const int krow = kk >> 1, kcol = (kk & 1) * 16;
+            const unsigned char* bp = ys + (krow * TW + kcol) * PSY + b_lane;
+            const bf8 bh = tr_pair(bp, bp + 4 * PSY);
+            bf8 bl;
+            if constexpr (X3) bl = tr_pair(bp + y_plane, bp + y_plane + 4 * PSY);
+            const unsigned char* ap = xs + ((krow * d.isy) * in_w + kcol * d.isx) * PSX + a_lane;
+#pragma unroll
+            for (int i = 0; i < TG; i++) {
+                if (i < tcnt) {
+                    const unsigned char* api = ap + toff[i];
+                    const bf8 ah = tr_pair(api, api + 4 * d.isx * PSX);
+                    if constexpr (X3) {
+                        const bf8 al = tr_pair(api + a.x_plane_bytes, api + a.x_plane_bytes + 4 * d.isx * PSX);
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i], 0, 0, 0);
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i], 0, 0, 0);
+                    }
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i], 0, 0, 0);
+                }
+                // keep at most 3 taps' fragments in flight: with 9 accumulator tiles live the scheduler otherwise hoists all
+                // 18 transposing reads of a k-step above the first MFMA and spills
+                if (TG > 3 && (i % 3) == 2) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    // ---- write the slab: D[row = ci][col = co]; col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5) -----------------
+    const int r = lane & 31, h = lane >> 5;
+    const long cip = (long)a.ci_t * CT, cop = (long)a.co_t * CT;
+#pragma unroll
+    for (int i = 0; i < TG; i++) {
+        if (i < tcnt) {
+            const int wt = d.tap_w[tb + i];
+            float* base = a.slab + (((long)split * d.w_taps + wt) * cip + ci0 + ci_half * 32) * cop + co0 + co_half * 32 + r;
+#pragma unroll
+            for (int e = 0; e < 16; e++) base[(long)((e & 3) + 8 * (e >> 2) + 4 * h) * cop] = acc[i][e];
+        }
+    }
+    if (want_bias) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);
+        constexpr int NCH = X3 ? 4 : 8;   // channels per thread
+        constexpr int NGR = X3 ? 16 : 8;  // channel groups
+#pragma unroll
+        for (int e = 0; e < NCH; e++) red[tid * NCH + e] = bsum[e];
+        __syncthreads();
+        if (tid < CT) {
+            const int grp_c = tid / NCH, e = tid % NCH;
+            float s = 0.0f;
+            for (int pp = 0; pp < kThreads / NGR; pp++) s += red[(pp * NGR + grp_c) * NCH + e];
+            a.bias_slab[((long)cls * a.splits + split) * cop + co0 + tid] = s;
+        }
+    }
+}
+
+// dw (torch layout) = sum over splits of the slabs, in split order
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bias_slab, int splits, int bias_rows, int taps,
+                                    int ci, int co, long cip, long cop, int transposed, float* __restrict__ dw,
+                                    float* __restrict__ dbias) {
+    const long total = (long)taps * ci * co;
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < total) {
+        const int n = (int)(q % co);
+        const long t2 = q / co;
+        const int k = (int)(t2 % ci);
+        const int tap = (int)(t2 / ci);
+        float s = 0.0f;
+        for (int sp = 0; sp < splits; sp++) s += slab[(((long)sp * taps + tap) * cip + k) * cop + n];
+        const long o = transposed ? (((long)k * co + n) * taps + tap) : (((long)n * ci + k) * taps + tap);
+        dw[o] = s;
+    }
+    if (dbias && q < co) {
+        float s = 0.0f;
+        for (int sp = 0; sp < bias_rows; sp++) s += bias_slab[(long)sp * cop + q];
+        dbias[q] = s;
+    }
+}
+
+int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+struct WgPlan {
+    int tg, lds, splits, blocks;
+    size_t slab_bytes, bias_bytes;
+    WgArgs a;
+};
+
+bool make_plan(const liso_conv_desc& d, WgPlan* p) {
+    if (d.batch <= 0 || d.ci <= 0 || d.co <= 0 || d.n_classes < 1 || d.n_classes > LISO_CONV_MAX_CLASSES) return false;
+    if (d.n_taps < 1 || d.n_taps > LISO_CONV_MAX_TAPS || d.class_tap_begin[0] != 0 || d.class_tap_begin[d.n_classes] != d.n_taps)
+        return false;
+    const bool x3 = d.mode == LISO_CONV_F32X3;
+    const int vec = x3 ? 4 : 8;
+    if (d.ci % vec || d.co % vec || d.x_pix_stride % vec) return false;
+    const int planes = x3 ? 2 : 1;
+    WgArgs& a = p->a;
+    a.ci_t = (d.ci + CT - 1) / CT;
+    a.co_t = (d.co + CT - 1) / CT;
+    a.tiles_x = (d.wv + TW - 1) / TW;
+    int max_cls_taps = 0, TH = 4;
+    // tile rows: the tallest tile whose LDS image allows 2 blocks per CU (79 KB), else the tallest that fits at all
+    int th_fit = 0;
+    for (int pass = 0; pass < 2 && !th_fit; pass++)
+        for (int th = 4; th >= 1 && !th_fit; th >>= 1) {
+            int mp = 0;
+            for (int c = 0; c < d.n_classes; c++) {
+                int y0 = 1 << 30, y1 = -(1 << 30), x0 = 1 << 30, x1 = -(1 << 30);
+                for (int t = d.class_tap_begin[c]; t < d.class_tap_begin[c + 1]; t++) {
+                    y0 = d.tap_dy[t] < y0 ? d.tap_dy[t] : y0;
+                    y1 = d.tap_dy[t] > y1 ? d.tap_dy[t] : y1;
+                    x0 = d.tap_dx[t] < x0 ? d.tap_dx[t] : x0;
+                    x1 = d.tap_dx[t] > x1 ? d.tap_dx[t] : x1;
+                }
+                const int np = ((th - 1) * d.isy + (y1 - y0) + 1) * ((TW - 1) * d.isx + (x1 - x0) + 1);
+                mp = np > mp ? np : mp;
+            }
+            const int lds = planes * (round_up(mp * (CT * 2 + 16), 16) + th * TW * PSY);
+            if (lds <= (pass == 0 ? 79 : 158) * 1024) th_fit = th;
+        }
+    if (!th_fit) return false;
+    TH = th_fit;
+    a.th = TH;
+    a.tiles_y = (d.hv + TH - 1) / TH;
+    a.n_tiles = d.batch * a.tiles_y * a.tiles_x;
+    int max_pix = 0;
+    for (int c = 0; c < d.n_classes; c++) {
+        int y0 = 1 << 30, y1 = -(1 << 30), x0 = 1 << 30, x1 = -(1 << 30);
+        const int nt = d.class_tap_begin[c + 1] - d.class_tap_begin[c];
+        if (nt < 1) return false;
+        max_cls_taps = nt > max_cls_taps ? nt : max_cls_taps;
+        for (int t = d.class_tap_begin[c]; t < d.class_tap_begin[c + 1]; t++) {
+            y0 = d.tap_dy[t] < y0 ? d.tap_dy[t] : y0;
+            y1 = d.tap_dy[t] > y1 ? d.tap_dy[t] : y1;
+            x0 = d.tap_dx[t] < x0 ? d.tap_dx[t] : x0;
+            x1 = d.tap_dx[t] > x1 ? d.tap_dx[t] : x1;
+            if (d.tap_w[t] < 0 || d.tap_w[t] >= d.w_taps) return false;
+        }
+        a.cls_dy0[c] = y0;
+        a.cls_dx0[c] = x0;
+        a.cls_inh[c] = (TH - 1) * d.isy + (y1 - y0) + 1;
+        a.cls_inw[c] = (TW - 1) * d.isx + (x1 - x0) + 1;
+        const int np = a.cls_inh[c] * a.cls_inw[c];
+        max_pix = np > max_pix ? np : max_pix;
+    }
+    a.psx = CT * 2 + 16;
+    a.x_plane_bytes = round_up(max_pix * a.psx, 16);
+    p->lds = planes * (a.x_plane_bytes + TH * TW * PSY);
+    // taps per block: 9 when the (ci, co, class) tiles alone give enough blocks, else 3, else 1
+    const long cc = (long)a.ci_t * a.co_t;
+    auto groups = [&](int tg) {
+        int n = 0;
+        for (int c = 0; c < d.n_classes; c++) n += (d.class_tap_begin[c + 1] - d.class_tap_begin[c] + tg - 1) / tg;
+        return n;
+    };
+    const int max_splits = a.n_tiles >= 4 ? a.n_tiles / 4 : 1;  // >= 4 tiles per block
+    p->tg = x3 ? 3 : 9;  // (F32X3 issues 3 MFMAs per tap and k-step: 3 taps already balance the staging)
+    if (max_cls_taps == 1) p->tg = 1;
+    else if (cc * groups(9) * max_splits < 384 || max_cls_taps <= 3) p->tg = 3;
+    if (p->tg == 3 && cc * groups(3) * max_splits < 384 && max_cls_taps > 1) p->tg = 1;
+    a.n_groups = 0;
+    for (int c = 0; c < d.n_classes; c++)
+        for (int t = d.class_tap_begin[c]; t < d.class_tap_begin[c + 1]; t += p->tg) {
+            if (a.n_groups >= LISO_CONV_MAX_TAPS) return false;
+            a.grp_cls[a.n_groups] = c;
+            a.grp_begin[a.n_groups] = t;
+            const int left = d.class_tap_begin[c + 1] - t;
+            a.grp_cnt[a.n_groups] = left < p->tg ? left : p->tg;
+            a.n_groups++;
+        }
+    const long per_split = cc * a.n_groups;
+    long s = (768 + per_split - 1) / per_split;
+    s = s < 1 ? 1 : (s > max_splits ? max_splits : s);
+    p->splits = (int)s;
+    a.splits = p->splits;
+    p->blocks = (int)(per_split * s);
+    p->slab_bytes = (size_t)s * d.w_taps * a.ci_t * CT * a.co_t * CT * sizeof(float);
+    p->bias_bytes = (size_t)d.n_classes * s * a.co_t * CT * sizeof(float);
+    return true;
+}
+
+template <int MODE, int TG>
+int launch(const liso_conv_desc& d, const WgPlan& p, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)conv_wgrad_kernel<MODE, TG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
+            hipSuccess)
+            return LISO_ELAUNCH;
+        attr_set = true;
+    }
+    conv_wgrad_kernel<MODE, TG><<<p.blocks, kThreads, p.lds, st>>>(d, p.a);
+    return hipGetLastError() == hipSuccess ? LISO_OK : LISO_ELAUNCH;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t liso_conv_wgrad_workspace_bytes(const liso_conv_desc* d) {
+    WgPlan p;
+    if (!d || !make_plan(*d, &p)) return 0;
+    return p.slab_bytes + p.bias_bytes;
+}
+
+int liso_conv_wgrad(const liso_conv_desc* d, const void* x, const float* in_scale, const float* in_shift, const void* dy,
+                    int dy_pix_stride, int transposed, float* dw, float* dbias, void* workspace, size_t workspace_bytes,
+                    void* stream) {
+    if (!d || !x || !dy || !dw || !workspace) return LISO_EINVAL;
+    if ((in_scale == nullptr) != (in_shift == nullptr)) return LISO_EINVAL;
+    WgPlan p;
+    if (!make_plan(*d, &p)) return LISO_EINVAL;
+    const int vec = d->mode == LISO_CONV_F32X3 ? 4 : 8;
+    if (dy_pix_stride % vec || dy_pix_stride < d->co || (((uintptr_t)x | (uintptr_t)dy) & 15)) return LISO_EINVAL;
+    if (workspace_bytes < p.slab_bytes + p.bias_bytes) return LISO_EWORKSPACE;
+    p.a.x = x;
+    p.a.in_scale = in_scale;
+    p.a.in_shift = in_shift;
+    p.a.dy = dy;
+    p.a.dy_pix_stride = dy_pix_stride;
+    p.a.slab = (float*)workspace;
+    p.a.bias_slab = dbias ? (float*)((char*)workspace + p.slab_bytes) : nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if (d->mode == LISO_CONV_F32X3)
+        rc = p.tg == 3 ? launch<LISO_CONV_F32X3, 3>(*d, p, st) : launch<LISO_CONV_F32X3, 1>(*d, p, st);
+    else
+        rc = p.tg == 9 ? launch<LISO_CONV_BF16, 9>(*d, p, st) : p.tg == 3 ? launch<LISO_CONV_BF16, 3>(*d, p, st)
+                                                                         : launch<LISO_CONV_BF16, 1>(*d, p, st);
+    if (rc != LISO_OK) return rc;
+    const long total = (long)d->w_taps * d->ci * d->co;
+    wgrad_reduce_kernel<<<(int)((total + 255) / 256), 256, 0, st>>>(p.a.slab, p.a.bias_slab, p.splits, p.splits * d->n_classes, d->w_taps, d->ci, d->co,
+                                                                    (long)p.a.ci_t * CT, (long)p.a.co_t * CT, transposed, dw, dbias);
+    return hipGetLastError() == hipSuccess ? LISO_OK : LISO_ELAUNCH;
+}
+
+}  // extern "C"

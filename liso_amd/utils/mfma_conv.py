@@ -1,0 +1,429 @@
+"""Convolutions of the BEV networks on the gfx950 matrix cores (C ABI: include/liso_conv.h).
+
+Host side of the own implicit-GEMM kernels that replace torch.nn.functional.conv2d / conv_transpose2d (cuDNN in the
+reference, MIOpen on ROCm) for
+    liso/networks/centerpoint/rpn.py:113-146, center_head.py:60-117   (bf16 tensors, fp32 accumulation)
+    liso/slim/model/update.py:96-164, extractor.py:211-297            (fp32 tensors as bf16 hi/lo pairs, "F32X3")
+Tensors are logical NCHW with channels-last strides (physical [B, H, W, C]).  `fused_conv` is the autograd entry point:
+    y_raw = conv( relu?(bn(x_raw)) ) + bias          -- the BatchNorm-apply + ReLU of the PRODUCING layer runs in the
+                                                        convolution's prologue; its backward (liso_bn_relu_bwd) follows
+                                                        the data gradient inside this function's backward
+and optionally emits the per-block partial sums from which `finalize_bn` derives the BatchNorm statistics of y_raw
+(no separate statistics pass over the activation).
+"""
+import ctypes
+import os
+
+import torch
+
+from liso_amd import _lib as L
+
+
+def backend():
+    """'mfma' (default) or 'miopen' (LISO_CONV_BACKEND=miopen: comparison runs through torch's convolution)"""
+    return os.environ.get("LISO_CONV_BACKEND", "mfma")
+
+
+class ConvSpec:
+    """geometry of one nn.Conv2d / nn.ConvTranspose2d (square stride / padding, dilation 1, groups 1)"""
+
+    def __init__(self, kh, kw, stride=1, padding=0, transposed=False):
+        self.kh, self.kw, self.stride, self.padding, self.transposed = int(kh), int(kw), int(stride), int(padding), bool(transposed)
+
+    @staticmethod
+    def of(conv):
+        st = conv.stride[0] if isinstance(conv.stride, (tuple, list)) else conv.stride
+        pd = conv.padding[0] if isinstance(conv.padding, (tuple, list)) else conv.padding
+        assert tuple(conv.dilation) == (1, 1) and conv.groups == 1
+        return ConvSpec(conv.kernel_size[0], conv.kernel_size[1], st, pd, isinstance(conv, torch.nn.ConvTranspose2d))
+
+    def out_hw(self, h, w):
+        if self.transposed:
+            return (h - 1) * self.stride - 2 * self.padding + self.kh, (w - 1) * self.stride - 2 * self.padding + self.kw
+        return (h + 2 * self.padding - self.kh) // self.stride + 1, (w + 2 * self.padding - self.kw) // self.stride + 1
+
+
+def _mode(dtype):
+    if dtype == torch.bfloat16:
+        return L.CONV_BF16
+    if dtype == torch.float32:
+        return L.CONV_F32X3
+    raise L.LisoHipError(f"mfma conv: unsupported dtype {dtype}")
+
+
+def _base_desc(B, hi, wi, ci, x_ps, ho, wo, co, y_ps, y_off, mode, out_f32, in_relu, out_relu, w_taps):
+    d = L.ConvDesc()
+    d.batch, d.hi, d.wi, d.ci, d.x_pix_stride = B, hi, wi, ci, x_ps
+    d.ho, d.wo, d.co, d.y_pix_stride, d.y_ch_off = ho, wo, co, y_ps, y_off
+    d.mode, d.out_f32, d.in_relu, d.out_relu, d.w_taps = mode, int(out_f32), int(in_relu), int(out_relu), w_taps
+    return d
+
+
+def gather_desc(spec, B, hi, wi, ci, x_ps, ho, wo, co, y_ps, y_off, mode, out_f32=False, in_relu=False, out_relu=False):
+    """out[v] = sum_taps in[v * s + (k - p)] * w[k]: forward of a convolution, data gradient of a transposed convolution"""
+    d = _base_desc(B, hi, wi, ci, x_ps, ho, wo, co, y_ps, y_off, mode, out_f32, in_relu, out_relu, spec.kh * spec.kw)
+    d.hv, d.wv, d.isy, d.isx, d.osy, d.osx = ho, wo, spec.stride, spec.stride, 1, 1
+    d.n_classes = 1
+    d.class_tap_begin[0], d.class_tap_begin[1] = 0, spec.kh * spec.kw
+    d.n_taps = spec.kh * spec.kw
+    assert d.n_taps <= L.CONV_MAX_TAPS
+    for ky in range(spec.kh):
+        for kx in range(spec.kw):
+            t = ky * spec.kw + kx
+            d.tap_dy[t], d.tap_dx[t], d.tap_w[t] = ky - spec.padding, kx - spec.padding, t
+    return d
+
+
+def scatter_desc(spec, B, hi, wi, ci, x_ps, ho, wo, co, y_ps, y_off, mode, out_f32=False, in_relu=False, out_relu=False):
+    """out[i * s - p + k] += in[i] * w[k], evaluated per output-parity class: forward of a transposed convolution, data
+    gradient of a convolution.  (hi, wi, ci) describe the tensor that is READ, (ho, wo, co) the one that is written."""
+    s, p = spec.stride, spec.padding
+    d = _base_desc(B, hi, wi, ci, x_ps, ho, wo, co, y_ps, y_off, mode, out_f32, in_relu, out_relu, spec.kh * spec.kw)
+    d.hv, d.wv = (ho + s - 1) // s, (wo + s - 1) // s
+    d.isy, d.isx, d.osy, d.osx = 1, 1, s, s
+    n, cls = 0, 0
+    d.class_tap_begin[0] = 0
+    for py in range(s):
+        for px in range(s):
+            taps = [(ky, kx) for ky in range(spec.kh) for kx in range(spec.kw) if (py + p - ky) % s == 0 and (px + p - kx) % s == 0]
+            if not taps:  # kernel smaller than the stride: no input reaches this output parity (the caller zero-fills it)
+                continue
+            for ky, kx in taps:
+                assert n < L.CONV_MAX_TAPS
+                d.tap_dy[n], d.tap_dx[n], d.tap_w[n] = (py + p - ky) // s, (px + p - kx) // s, ky * spec.kw + kx
+                n += 1
+            d.class_ooy[cls], d.class_oox[cls] = py, px
+            cls += 1
+            d.class_tap_begin[cls] = n
+    assert cls <= L.CONV_MAX_CLASSES
+    d.n_classes, d.n_taps = cls, n
+    d.sparse_output = cls < s * s  # (python-side attribute) some output positions are never written
+    return d
+
+
+def _pix_stride(v):
+    B, H, W, C = v.shape
+    if W > 1:
+        return v.stride(2)
+    if H > 1:
+        return v.stride(1)
+    if B > 1:
+        return v.stride(0)
+    return C
+
+
+def as_nhwc(t, vec):
+    """physical NHWC view of a logical-NCHW tensor + its pixel stride (a copy is made unless the layout already is
+    channels-last, possibly as a channel slice of a wider tensor, with a pixel stride that keeps 16-B alignment)"""
+    v = t.permute(0, 2, 3, 1)
+    B, H, W, C = v.shape
+    ps = _pix_stride(v)
+    regular = (v.stride(3) == 1 or C == 1) and ps >= C and (W == 1 or v.stride(2) == ps) and (H == 1 or v.stride(1) == W * ps) and \
+        (B == 1 or v.stride(0) == H * W * ps) and ps % vec == 0 and v.data_ptr() % 16 == 0
+    if not regular:
+        v = t.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
+        if v.stride(3) != 1 and C > 1:  # (channels_last of a C == 1 tensor can report odd strides)
+            v = v.contiguous()
+        ps = C
+    return v, ps
+
+
+def pack_weights(weight, spec, for_dgrad, mode):
+    """torch-layout fp32 master weights -> the kernels' packed bf16 panels (one launch)"""
+    L.require_cuda(weight)
+    w = weight.detach()
+    if w.dtype != torch.float32 or not w.is_contiguous():
+        w = w.float().contiguous()
+    d0, d1 = w.shape[0], w.shape[1]
+    same = spec.transposed == bool(for_dgrad)
+    K, N = (d1, d0) if same else (d0, d1)
+    nbytes = L.lib().liso_conv_packed_bytes(K, N, spec.kh * spec.kw, mode)
+    out = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    with torch.cuda.device(w.device):
+        L.check(L.lib().liso_conv_pack_weights(L.ptr(w), d0, d1, spec.kh, spec.kw, int(spec.transposed), int(bool(for_dgrad)), mode,
+                                               L.ptr(out), L.stream_ptr()), "conv_pack_weights")
+    return out
+
+
+def _vec(mode):
+    return 8 if mode == L.CONV_BF16 else 4
+
+
+def _timer_name(mode, kind):
+    return ("conv_bf16_" if mode == L.CONV_BF16 else "conv_f32x3_") + kind
+
+
+def _flops(d):
+    taps = d.n_taps if d.n_classes == 1 else d.n_taps / d.n_classes  # taps per output pixel (average over parity classes)
+    return 2.0 * d.batch * d.ho * d.wo * d.co * d.ci * taps
+
+
+def conv_forward(x, weight, bias, spec, in_scale=None, in_shift=None, in_relu=False, out_relu=False, out_dtype=None,
+                 want_stats=False, stats_shift=None, packed=None):
+    """x: logical [B,Ci,H,W] (channels-last storage preferred) -> (y logical [B,Co,Ho,Wo] channels-last, stats_partial | None)"""
+    L.require_cuda(x, weight)
+    mode = _mode(x.dtype)
+    xv, xps = as_nhwc(x, _vec(mode))
+    B, hi, wi, ci = xv.shape
+    co = weight.shape[1] if spec.transposed else weight.shape[0]
+    ho, wo = spec.out_hw(hi, wi)
+    out_dtype = out_dtype or x.dtype
+    if mode == L.CONV_F32X3:
+        assert out_dtype == torch.float32
+    out_f32 = out_dtype == torch.float32
+    y = torch.empty((B, ho, wo, co), dtype=out_dtype, device=x.device)
+    build = scatter_desc if spec.transposed else gather_desc
+    d = build(spec, B, hi, wi, ci, xps, ho, wo, co, co, 0, mode, out_f32, in_relu, out_relu)
+    if packed is None:
+        packed = pack_weights(weight, spec, False, mode)
+    lib = L.lib()
+    stats = None
+    if want_stats:
+        rows = lib.liso_conv_stats_rows(ctypes.byref(d))
+        if rows <= 0:
+            raise L.LisoHipError("conv_forward: unsupported geometry")
+        stats = torch.empty((rows, 2, (co + 63) // 64 * 64), dtype=torch.float32, device=x.device)
+    b = bias.detach().float().contiguous() if bias is not None else None
+    with torch.cuda.device(x.device):
+        L.check(L.TIMER.launch(_timer_name(mode, "fwd"), lambda: lib.liso_conv_forward(
+            ctypes.byref(d), L.ptr(xv), L.ptr(packed), L.ptr(b) if b is not None else None,
+            L.ptr(in_scale) if in_scale is not None else None, L.ptr(in_shift) if in_shift is not None else None, L.ptr(y),
+            L.ptr(stats) if stats is not None else None, L.ptr(stats_shift) if stats_shift is not None else None, L.stream_ptr()),
+            units=_flops(d)), "conv_forward")
+    return y.permute(0, 3, 1, 2), stats
+
+
+def _pad_out_channels(dy, weight, spec, vec):
+    """the kernels read channels in 16-B groups: a gradient with 1-3 channels (the head's output convolutions) is padded with
+    zero channels (and the weights with zero filters) -- a few KB"""
+    co = dy.shape[1]
+    pad = (-co) % vec
+    if pad == 0:
+        return dy, weight
+    dy = torch.nn.functional.pad(dy, (0, 0, 0, 0, 0, pad))
+    if weight is not None:
+        weight = torch.nn.functional.pad(weight.detach(), (0, 0, 0, 0, 0, pad) if spec.transposed else (0, 0, 0, 0, 0, 0, 0, pad))
+    return dy, weight
+
+
+def conv_dgrad(dy, weight, spec, x_shape, out_dtype=None):
+    """dy: logical [B,Co,Ho,Wo] -> dx logical [B,Ci,Hi,Wi] (gradient w.r.t. the convolution's INPUT x')"""
+    L.require_cuda(dy, weight)
+    mode = _mode(dy.dtype)
+    dy, weight = _pad_out_channels(dy, weight, spec, _vec(mode))
+    gv, gps = as_nhwc(dy, _vec(mode))
+    B, ho, wo, co = gv.shape
+    _, ci, hi, wi = x_shape
+    out_dtype = out_dtype or dy.dtype
+    out_f32 = out_dtype == torch.float32
+    build = gather_desc if spec.transposed else scatter_desc
+    d = build(spec, B, ho, wo, co, gps, hi, wi, ci, ci, 0, mode, out_f32, False, False)
+    alloc = torch.zeros if getattr(d, "sparse_output", False) else torch.empty
+    if not spec.transposed and ((hi + 2 * spec.padding - spec.kh) % spec.stride or (wi + 2 * spec.padding - spec.kw) % spec.stride):
+        alloc = torch.zeros  # trailing input rows / columns no output window covers: gradient 0
+    dx = alloc((B, hi, wi, ci), dtype=out_dtype, device=dy.device)
+    packed = pack_weights(weight, spec, True, mode)
+    with torch.cuda.device(dy.device):
+        L.check(L.TIMER.launch(_timer_name(mode, "dgrad"), lambda: L.lib().liso_conv_forward(
+            ctypes.byref(d), L.ptr(gv), L.ptr(packed), None, None, None, L.ptr(dx), None, None, L.stream_ptr()), units=_flops(d)),
+            "conv_dgrad")
+    return dx.permute(0, 3, 1, 2)
+
+
+def conv_wgrad(x, dy, weight_shape, spec, in_scale=None, in_shift=None, in_relu=False, want_bias=True):
+    """-> (dw fp32 in torch's layout `weight_shape`, dbias fp32 [Co] | None); None if the geometry is not supported by the
+    kernel (caller falls back to ATen's weight gradient)"""
+    L.require_cuda(x, dy)
+    mode = _mode(x.dtype)
+    if dy.dtype != x.dtype:
+        dy = dy.to(x.dtype)
+    co_true = dy.shape[1]
+    dy, _ = _pad_out_channels(dy, None, spec, _vec(mode))
+    if dy.shape[1] != co_true:
+        weight_shape = ((weight_shape[0], dy.shape[1]) if spec.transposed else (dy.shape[1], weight_shape[1])) + tuple(weight_shape[2:])
+    xv, xps = as_nhwc(x, _vec(mode))
+    gv, gps = as_nhwc(dy, _vec(mode))
+    B, hi, wi, ci = xv.shape
+    _, ho, wo, co = gv.shape
+    build = scatter_desc if spec.transposed else gather_desc
+    d = build(spec, B, hi, wi, ci, xps, ho, wo, co, co, 0, mode, True, in_relu, False)
+    lib = L.lib()
+    nbytes = lib.liso_conv_wgrad_workspace_bytes(ctypes.byref(d))
+    if nbytes == 0:
+        return None
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    dw = torch.empty(weight_shape, dtype=torch.float32, device=x.device)
+    db = torch.empty(co, dtype=torch.float32, device=x.device) if want_bias else None
+    with torch.cuda.device(x.device):
+        L.check(L.TIMER.launch(_timer_name(mode, "wgrad"), lambda: lib.liso_conv_wgrad(
+            ctypes.byref(d), L.ptr(xv), L.ptr(in_scale) if in_scale is not None else None,
+            L.ptr(in_shift) if in_shift is not None else None, L.ptr(gv), gps, int(spec.transposed), L.ptr(dw),
+            L.ptr(db) if db is not None else None, L.ptr(ws), nbytes, L.stream_ptr()), units=_flops(d)), "conv_wgrad")
+    if co != co_true:
+        dw = (dw[:, :co_true] if spec.transposed else dw[:co_true]).contiguous()
+        db = db[:co_true].contiguous() if db is not None else None
+    return dw, db
+
+
+def supported(x, weight, spec):
+    """can the own kernels run this convolution (forward, data and weight gradient)?"""
+    if not x.is_cuda or x.dtype not in (torch.bfloat16, torch.float32):
+        return False
+    vec = 8 if x.dtype == torch.bfloat16 else 4
+    ci = x.shape[1]
+    co = weight.shape[1] if spec.transposed else weight.shape[0]
+    if ci % vec or spec.kh * spec.kw > L.CONV_MAX_TAPS:
+        return False
+    if spec.transposed and (spec.kh != spec.stride or spec.padding != 0):
+        return False
+    return co >= 1
+
+
+# ---- BatchNorm folding ---------------------------------------------------------------------------------------------------
+class BnFold:
+    """A BatchNorm2d(+ReLU) that has NOT been applied yet: the consumer convolution applies it in its prologue.
+    `stats` fp32 [4C] = scale | shift | mean | invstd (the layout of include/liso_bn.h); gamma / beta are the module's
+    parameters (they receive their gradients through the consumer's backward)."""
+
+    def __init__(self, stats, gamma, beta, relu, training):
+        self.stats, self.gamma, self.beta, self.relu, self.training = stats, gamma, beta, bool(relu), bool(training)
+
+    @property
+    def channels(self):
+        return self.gamma.shape[0]
+
+
+def finalize_bn(stats_partial, n_pixels, bn, stats_shift=None):
+    """per-block partial sums of a conv_forward(..., want_stats=True) -> BnFold of `bn` in training mode (batch statistics,
+    running statistics updated with the module's momentum, like torch.nn.BatchNorm2d.forward)"""
+    C = bn.num_features
+    stats = torch.empty(4 * C, dtype=torch.float32, device=stats_partial.device)
+    rows, _, cop = stats_partial.shape
+    mom = bn.momentum if bn.momentum is not None else 0.1
+    track = bn.track_running_stats and bn.training
+    with torch.cuda.device(stats_partial.device):
+        L.check(L.lib().liso_conv_bn_finalize(
+            L.ptr(stats_partial), rows, C, cop, int(n_pixels), L.ptr(stats_shift) if stats_shift is not None else None,
+            L.ptr(bn.weight), L.ptr(bn.bias), L.ptr(bn.running_mean) if track else None, L.ptr(bn.running_var) if track else None,
+            float(mom), float(bn.eps), L.ptr(stats), L.stream_ptr()), "conv_bn_finalize")
+    return BnFold(stats, bn.weight, bn.bias, True, True)
+
+
+def eval_bn_fold(bn, relu=True):
+    """BnFold from the running statistics (eval mode)"""
+    with torch.no_grad():
+        invstd = torch.rsqrt(bn.running_var.float() + bn.eps)
+        scale = bn.weight.detach().float() * invstd
+        shift = bn.bias.detach().float() - bn.running_mean.float() * scale
+        stats = torch.cat([scale, shift, bn.running_mean.float(), invstd]).contiguous()
+    return BnFold(stats, bn.weight, bn.bias, relu, False)
+
+
+def _bn_backward(g, x_raw, fold):
+    """gradient through relu?(bn(x_raw)) given g = dL/d(output): -> (dx_raw, dgamma, dbeta); g, x_raw logical NCHW"""
+    C = fold.channels
+    xv, _ = as_nhwc(x_raw, 1)
+    gv, _ = as_nhwc(g, 1)
+    if not xv.is_contiguous():
+        xv = xv.contiguous()
+    if gv.dtype != xv.dtype:
+        gv = gv.to(xv.dtype)
+    if not gv.is_contiguous():
+        gv = gv.contiguous()
+    M = xv.numel() // C
+    lib = L.lib()
+    dx = torch.empty_like(xv)
+    gg = torch.empty(C, dtype=torch.float32, device=xv.device)
+    gb = torch.empty(C, dtype=torch.float32, device=xv.device)
+    nbytes = lib.liso_bn_workspace_bytes(C)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=xv.device)
+    with torch.cuda.device(xv.device):
+        L.check(L.TIMER.launch("bn_bwd", lambda: lib.liso_bn_relu_bwd(
+            L.ptr(gv), L.ptr(xv), int(xv.dtype == torch.bfloat16), M, C, L.ptr(fold.gamma), L.ptr(fold.stats), int(fold.training),
+            int(fold.relu), L.ptr(dx), L.ptr(gg), L.ptr(gb), L.ptr(ws), nbytes, L.stream_ptr()),
+            units=5 * M * C * xv.element_size()), "bn_relu_bwd")
+    return dx.permute(0, 3, 1, 2), gg, gb
+
+
+class _FusedConv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_raw, weight, bias, gamma, beta, meta):
+        """meta: dict(spec, fold (BnFold | None; its gamma / beta are the `gamma`, `beta` arguments), out_dtype, want_stats,
+        stats_shift, out_relu); the partial statistics are returned through meta['stats_partial']"""
+        spec, fold = meta["spec"], meta["fold"]
+        C = x_raw.shape[1]
+        sc = fold.stats[:C] if fold is not None else None
+        sh = fold.stats[C:2 * C] if fold is not None else None
+        y, part = conv_forward(x_raw, weight, bias, spec, sc, sh, in_relu=fold.relu if fold is not None else False,
+                               out_relu=meta.get("out_relu", False), out_dtype=meta.get("out_dtype"),
+                               want_stats=meta.get("want_stats", False), stats_shift=meta.get("stats_shift"))
+        meta["stats_partial"] = part
+        ctx.save_for_backward(x_raw, weight)
+        ctx.meta = {"spec": spec, "fold": fold, "has_bias": bias is not None}
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x_raw, weight = ctx.saved_tensors
+        spec, fold = ctx.meta["spec"], ctx.meta["fold"]
+        C = x_raw.shape[1]
+        if dy.dtype != x_raw.dtype:
+            dy = dy.to(x_raw.dtype)
+        sc = fold.stats[:C] if fold is not None else None
+        sh = fold.stats[C:2 * C] if fold is not None else None
+        dw = db = dx = dgamma = dbeta = None
+        if ctx.needs_input_grad[1] or (ctx.meta["has_bias"] and ctx.needs_input_grad[2]):
+            res = conv_wgrad(x_raw, dy, tuple(weight.shape), spec, sc, sh, in_relu=fold.relu if fold is not None else False,
+                             want_bias=ctx.meta["has_bias"])
+            if res is None:
+                dw, db = _aten_wgrad(x_raw, dy, weight, spec, fold, ctx.meta["has_bias"])
+            else:
+                dw, db = res
+            dw = dw.to(weight.dtype)
+            if db is not None:
+                db = db.to(weight.dtype)
+        if ctx.needs_input_grad[0] or (fold is not None and fold.gamma.requires_grad):
+            g = conv_dgrad(dy, weight, spec, tuple(x_raw.shape))
+            if fold is not None:
+                dx, dgamma, dbeta = _bn_backward(g, x_raw, fold)
+            else:
+                dx = g
+        return dx, dw, db, dgamma, dbeta, None
+
+
+def _aten_wgrad(x_raw, dy, weight, spec, fold, has_bias):
+    """weight gradient through ATen for the few geometries the own kernel does not cover (large halos)"""
+    x = x_raw
+    if fold is not None:
+        C = x_raw.shape[1]
+        x = x_raw.float() * fold.stats[:C].view(1, C, 1, 1) + fold.stats[C:2 * C].view(1, C, 1, 1)
+        x = torch.relu(x) if fold.relu else x
+        x = x.to(x_raw.dtype)
+    s, p = [spec.stride, spec.stride], [spec.padding, spec.padding]
+    co = weight.shape[1] if spec.transposed else weight.shape[0]
+    _, gw, gb = torch.ops.aten.convolution_backward(dy, x, weight.to(x.dtype), [co] if has_bias else None, s, p, [1, 1], spec.transposed,
+                                                    [0, 0], 1, [False, True, has_bias])
+    return gw.float(), (gb.float() if has_bias else None)
+
+
+def fused_conv(x_raw, fold, conv, out_bn=None, out_dtype=None, out_relu=False, spec=None):
+    """y_raw = conv(relu?(bn(x_raw))) (+ bias).  `fold`: BnFold pending on x_raw or None.  `out_bn`: the BatchNorm2d that
+    follows this convolution -> returns (y_raw, BnFold of out_bn) (training: batch statistics from the convolution's
+    epilogue; eval: running statistics); without it returns (y_raw, None)."""
+    spec = spec or ConvSpec.of(conv)
+    training_bn = out_bn is not None and (out_bn.training or not out_bn.track_running_stats)
+    meta = {"spec": spec, "fold": fold, "out_dtype": out_dtype, "want_stats": training_bn, "out_relu": out_relu}
+    if training_bn and out_bn.track_running_stats:
+        meta["stats_shift"] = out_bn.running_mean  # any per-channel constant close to the mean keeps the sums well conditioned
+    gamma = fold.gamma if fold is not None else None
+    beta = fold.beta if fold is not None else None
+    y = _FusedConv.apply(x_raw, conv.weight, conv.bias, gamma, beta, meta)
+    if out_bn is None:
+        return y, None
+    if training_bn:
+        n = y.shape[0] * y.shape[2] * y.shape[3]
+        if out_bn.training and out_bn.track_running_stats and not getattr(out_bn, "_liso_counter_deferred", False):
+            out_bn.num_batches_tracked += 1
+        # (the finalize kernel reads stats_shift[c] before the same thread writes running_mean[c]: passing the live buffer is safe)
+        return y, finalize_bn(meta["stats_partial"], n, out_bn, meta.get("stats_shift"))
+    return y, eval_bn_fold(out_bn, relu=True)

@@ -1,0 +1,196 @@
+"""GPU parity of the own MFMA convolutions (include/liso_conv.h) against torch's convolution evaluated in fp64 on the
+same (rounded) operands: forward with the fused prologue / epilogue, data gradient, weight gradient, both arithmetic
+modes (bf16; fp32 as bf16 hi/lo pairs), every geometry the BEV networks use (rpn.py:113-146, center_head.py:60-117,
+update.py:96-164, extractor.py:211-297) plus ragged sizes."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+# (B, Ci, Co, H, W, k, stride, pad, transposed)
+GEOMS = [
+    (2, 64, 64, 64, 64, 3, 1, 1, False),      # backbone 3x3
+    (1, 64, 64, 40, 72, 3, 2, 1, False),      # stride-2 stage entry
+    (2, 128, 128, 32, 32, 3, 1, 1, False),
+    (1, 256, 256, 16, 32, 3, 1, 1, False),
+    (2, 64, 128, 32, 64, 2, 2, 0, False),     # deblock 0: conv k2 s2
+    (2, 128, 128, 32, 32, 1, 1, 0, False),    # deblock 1: conv 1x1
+    (2, 256, 128, 16, 16, 2, 2, 0, True),     # deblock 2: transposed k2 s2
+    (1, 384, 64, 32, 32, 3, 1, 1, False),     # head shared conv
+    (2, 64, 3, 32, 32, 3, 1, 1, False),       # head output convs
+    (2, 64, 1, 32, 32, 3, 1, 1, False),
+    (1, 16, 32, 19, 45, 3, 1, 1, False),      # ragged map, partial tiles
+    (3, 32, 96, 9, 7, 3, 2, 1, False),
+    (1, 64, 32, 64, 64, 7, 2, 3, False),      # encoder stem 7x7 s2
+    (2, 8, 64, 32, 32, 7, 1, 3, False),       # motion encoder 7x7 (channels padded to 8)
+    (2, 200, 96, 16, 16, 1, 1, 0, False),     # correlation 1x1 (196 -> padded)
+    (2, 400, 192, 16, 16, 3, 1, 1, False),    # ConvGRU z|r
+    (1, 96, 64, 24, 24, 1, 2, 0, False),      # residual downsample 1x1 s2
+]
+
+
+def _ref_conv(x, w, b, s, p, transposed):
+    x, w = x.double(), w.double()
+    b = b.double() if b is not None else None
+    return F.conv_transpose2d(x, w, b, stride=s, padding=p) if transposed else F.conv2d(x, w, b, stride=s, padding=p)
+
+
+def _mk(geom, dtype, seed=0):
+    B, Ci, Co, H, W, k, s, p, tr = geom
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, Ci, H, W, generator=g)
+    w = torch.randn((Ci, Co, k, k) if tr else (Co, Ci, k, k), generator=g) / (Ci * k * k) ** 0.5
+    b = torch.randn(Co, generator=g) * 0.3
+    if dtype == torch.bfloat16:  # the kernel sees bf16 activations and bf16-rounded weights
+        x = x.bfloat16().float()
+        w = w.bfloat16().float()
+    return x, w, b
+
+
+def _rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp(min=1e-12))
+
+
+@pytest.mark.parametrize("geom", GEOMS)
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_forward_dgrad_wgrad(geom, dtype):
+    from liso_amd.utils import mfma_conv as MC
+
+    B, Ci, Co, H, W, k, s, p, tr = geom
+    x, w, b = _mk(geom, dtype)
+    spec = MC.ConvSpec(k, k, s, p, tr)
+    xd = x.to(dtype).cuda().contiguous(memory_format=torch.channels_last)
+    wd, bd = w.cuda(), b.cuda()
+    y, _ = MC.conv_forward(xd, wd, bd, spec, out_dtype=torch.float32)
+    ref = _ref_conv(x, w, b, s, p, tr)
+    assert y.shape == ref.shape
+    tol = 2e-5 if dtype == torch.bfloat16 else 6e-5  # bf16 mode: exact products, fp32 accumulation; F32X3: 2^-16 per product
+    assert _rel(y, ref) <= tol, _rel(y, ref)
+    if dtype == torch.bfloat16:  # bf16 output = correctly rounded fp32 result (ties aside)
+        y16, _ = MC.conv_forward(xd, wd, bd, spec)
+        assert y16.dtype == torch.bfloat16 and _rel(y16, ref) <= 5e-3
+    # data gradient and weight gradient against autograd in fp64
+    g = torch.Generator().manual_seed(7)
+    dy = torch.randn(ref.shape, generator=g)
+    if dtype == torch.bfloat16:
+        dy = dy.bfloat16().float()
+    x64, w64 = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    b64 = b.double().requires_grad_(True)
+    out = _ref_conv(x64, w64, b64, s, p, tr)
+    gx, gw, gb = torch.autograd.grad(out, [x64, w64, b64], dy.double())
+    dyd = dy.to(dtype).cuda().contiguous(memory_format=torch.channels_last)
+    dx = MC.conv_dgrad(dyd, wd, spec, tuple(x.shape), out_dtype=torch.float32)
+    assert _rel(dx, gx) <= tol, _rel(dx, gx)
+    res = MC.conv_wgrad(xd, dyd, tuple(w.shape), spec)
+    if res is None:
+        assert k == 7 and s == 2  # the only geometry routed to ATen (halo tile larger than LDS)
+    else:
+        dw, db = res
+        assert _rel(dw, gw) <= 2 * tol, _rel(dw, gw)
+        assert _rel(db, gb) <= 2 * tol, _rel(db, gb)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_prologue_epilogue_statistics_and_channel_slices(dtype):
+    """x' = relu(x * scale + shift) fused into the staging (padding stays exactly zero), ReLU + bias epilogue, the partial
+    sums -> BatchNorm statistics (vs torch on the stored tensor), input given as a channel slice of a wider tensor"""
+    from liso_amd.utils import mfma_conv as MC
+
+    geom = (2, 64, 128, 40, 40, 3, 1, 1, False)
+    B, Ci, Co, H, W, k, s, p, tr = geom
+    x, w, b = _mk(geom, dtype, seed=3)
+    g = torch.Generator().manual_seed(5)
+    scale, shift = torch.rand(Ci, generator=g) + 0.5, torch.randn(Ci, generator=g) * 0.5
+    wide = torch.randn(B, 3 * Ci, H, W, generator=g)
+    wide[:, Ci:2 * Ci] = x
+    wide_d = wide.to(dtype).cuda().contiguous(memory_format=torch.channels_last)
+    xs = wide_d[:, Ci:2 * Ci]  # a view: pixel stride 3 * Ci
+    spec = MC.ConvSpec(k, k, s, p, tr)
+    xin = torch.relu(x.double() * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1))
+    if dtype == torch.bfloat16:
+        xin = torch.relu((x * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))).bfloat16().double()  # rounded like the staging does
+    ref = torch.relu(F.conv2d(xin, w.double(), b.double(), stride=s, padding=p))
+    bn = torch.nn.BatchNorm2d(Co).cuda().train()
+    with torch.no_grad():
+        bn.running_mean.uniform_(-0.2, 0.2)
+    shift_stat = bn.running_mean.clone()
+    y, part = MC.conv_forward(xs, w.cuda(), b.cuda(), spec, scale.cuda(), shift.cuda(), in_relu=True, out_relu=True,
+                              want_stats=True, stats_shift=shift_stat)
+    tol = 8e-3 if dtype == torch.bfloat16 else 6e-5
+    assert _rel(y, ref) <= tol, _rel(y, ref)
+    fold = MC.finalize_bn(part, B * y.shape[2] * y.shape[3], bn, shift_stat)
+    yf = y.float()
+    mean, var = yf.mean(dim=(0, 2, 3)), yf.var(dim=(0, 2, 3), unbiased=False)
+    assert _rel(fold.stats[2 * Co:3 * Co], mean) <= 1e-4
+    assert _rel(fold.stats[3 * Co:], torch.rsqrt(var + bn.eps)) <= 1e-4
+    assert _rel(fold.stats[:Co], bn.weight * torch.rsqrt(var + bn.eps)) <= 1e-4
+    n = B * y.shape[2] * y.shape[3]
+    assert _rel(bn.running_mean, 0.9 * shift_stat + 0.1 * mean) <= 1e-4
+    assert _rel(bn.running_var, 0.9 * torch.ones_like(var) + 0.1 * var * n / (n - 1)) <= 1e-4
+    # weight gradient with the same prologue
+    dy = torch.randn(ref.shape, generator=g)
+    if dtype == torch.bfloat16:
+        dy = dy.bfloat16().float()
+    w64 = w.double().requires_grad_(True)
+    gw, = torch.autograd.grad(F.conv2d(xin, w64, None, stride=s, padding=p), [w64], dy.double())
+    dw, _ = MC.conv_wgrad(xs, dy.to(dtype).cuda().contiguous(memory_format=torch.channels_last), tuple(w.shape), spec,
+                          scale.cuda(), shift.cuda(), in_relu=True)
+    assert _rel(dw, gw) <= (2e-4 if dtype == torch.bfloat16 else 1e-4), _rel(dw, gw)
+
+
+def _stat(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    d = (a - b).abs()
+    return float(d.max() / b.abs().max()), float(d.median() / b.abs().median().clamp(min=1e-30)), \
+        float((d > 1e-3 * b.abs().max()).double().mean())
+
+
+@pytest.mark.parametrize("beta_lo,beta_hi", [(3.0, 4.0), (-0.3, 0.3)])
+def test_fused_conv_autograd_chain_matches_torch_modules(beta_lo, beta_hi):
+    """conv -> BN -> ReLU -> conv -> BN -> ReLU -> conv(bias) as the networks chain them (BnFold), training mode, fp32
+    tensors: outputs, input gradient, every parameter gradient and the running statistics against torch.nn modules in fp64.
+    With beta in [3, 4] every ReLU is open, the chain is smooth and everything must agree tightly.  With beta around 0 a
+    ReLU whose input is within the forward rounding error (1e-5 in F32X3 mode) of zero may open on one side only -- the
+    gradient of that single pixel then differs, and through the BatchNorm statistics every gradient upstream moves a
+    little -- so the bulk of every gradient is checked: median error, fraction of outliers."""
+    import copy
+
+    from liso_amd.utils import mfma_conv as MC
+
+    torch.manual_seed(0)
+    convs = [torch.nn.Conv2d(32, 64, 3, stride=2, padding=1, bias=False), torch.nn.Conv2d(64, 64, 3, padding=1, bias=True),
+             torch.nn.Conv2d(64, 8, 3, padding=1, bias=True)]
+    bns = [torch.nn.BatchNorm2d(64), torch.nn.BatchNorm2d(64)]
+    with torch.no_grad():
+        for bn in bns:
+            bn.weight.uniform_(0.5, 1.5), bn.bias.uniform_(beta_lo, beta_hi)
+    x = torch.randn(2, 32, 48, 40)
+    ref = copy.deepcopy(torch.nn.Sequential(convs[0], bns[0], torch.nn.ReLU(), convs[1], bns[1], torch.nn.ReLU(), convs[2])).double().train()
+    x64 = x.double().requires_grad_(True)
+    out64 = ref(x64)
+    wgt = torch.linspace(-1, 1, out64.numel()).view_as(out64).double()
+    (out64 * wgt).sum().backward()
+    for m in convs + bns:
+        m.cuda().train()
+    xd = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y, fold = MC.fused_conv(xd, None, convs[0], out_bn=bns[0])
+    y, fold = MC.fused_conv(y, fold, convs[1], out_bn=bns[1])
+    y, _ = MC.fused_conv(y, fold, convs[2])
+    assert _rel(y, out64) <= 1e-4
+    (y * wgt.float().cuda()).sum().backward()
+    smooth = beta_lo > 1.0
+    pairs = [("x", xd.grad, x64.grad)] + [(f"conv{i}.w", convs[i].weight.grad, ref[j].weight.grad) for i, j in ((0, 0), (1, 3), (2, 6))] + \
+        [("conv2.b", convs[2].bias.grad, ref[6].bias.grad)] + \
+        [(f"bn{i}.{n}", getattr(bns[i], n).grad, getattr(ref[j], n).grad) for i, j in ((0, 1), (1, 4)) for n in ("weight", "bias")]
+    for name, a, b in pairs:
+        mx, med, frac = _stat(a, b)
+        if smooth:
+            assert mx <= 1e-3, (name, mx, med)
+        else:
+            assert med <= 1e-2 and mx <= 0.5, (name, mx, med, frac)
+    for i, j in ((0, 1), (1, 4)):
+        assert _rel(bns[i].running_mean, ref[j].running_mean) <= 1e-4 and _rel(bns[i].running_var, ref[j].running_var) <= 1e-4
+        assert int(bns[i].num_batches_tracked) == 1
