@@ -34,7 +34,6 @@ typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 
 constexpr int kThreads = 256;
-constexpr int kMaxWChunks = 4;  // 16-B weight chunks per thread and stage
 
 struct FwdArgs {
     const void* x;
@@ -71,12 +70,17 @@ __device__ __forceinline__ float round_bf16(float v) { return (float)(__bf16)v; 
 
 __device__ __forceinline__ bf8 as_bf8(const uint4& v) { return __builtin_bit_cast(bf8, v); }
 
-template <int MODE, int MI, int NJ, bool OUT_F32>
+template <int MODE, int MI, int NJ, bool OUT_F32, int CS>
 __global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(const liso_conv_desc d, const FwdArgs a) {
     constexpr int BNT = 32 * NJ;
     constexpr int TH = 4 * MI;
     constexpr bool X3 = MODE == LISO_CONV_F32X3;
     constexpr int PLANES = X3 ? 2 : 1;
+    constexpr int PS = CS * 2 + 16;            // LDS bytes per pixel and plane
+    constexpr int KS = CS / 16;                // k-steps per tap
+    constexpr int K8 = CS / 8;                 // 8-channel groups per slab
+    constexpr int PSZ = K8 * BNT;              // 16-B chunks of one weight panel (one tap, one plane)
+    constexpr int WTAP = PSZ * 16;             // bytes of one panel
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
@@ -94,18 +98,20 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(const liso_conv
 
     const int tb = d.class_tap_begin[cls], te = d.class_tap_begin[cls + 1];
     const int dy0 = a.cls_dy0[cls], dx0 = a.cls_dx0[cls], in_h = a.cls_inh[cls], in_w = a.cls_inw[cls];
-    const int cs = a.cs;
-    const int PS = cs * 2 + 16;
     const int npix = in_h * in_w;
     const float inv_w = 1.0f / (float)in_w;
     const int iy0 = ty * TH * d.isy + dy0, ix0 = tx * 32 * d.isx + dx0;
 
-    unsigned char* xs = smem;
-    unsigned char* wsb = smem + a.x_plane_bytes * PLANES;
-    const int k8 = cs >> 3;                  // 8-channel groups per slab
-    const int wtap_bytes = k8 * BNT * 16;    // one tap, one plane
+    // LDS: [tap tables 512 B][input tile, PLANES planes][weight panels of one stage: [tap][plane][K8][BNT][8]]
+    int* s_toff = reinterpret_cast<int*>(smem);          // byte offset of the tap inside the input tile
+    int* s_tapw = s_toff + 64;                           // tap index inside the packed weights
+    unsigned char* xs = smem + 512;
+    unsigned char* wsb = xs + a.x_plane_bytes * PLANES;
     const int G = a.g_taps;
-    const int wstage_bytes = G * wtap_bytes * PLANES;
+    if (tid < te - tb) {
+        s_toff[tid] = ((d.tap_dy[tb + tid] - dy0) * in_w + (d.tap_dx[tb + tid] - dx0)) * PS;
+        s_tapw[tid] = d.tap_w[tb + tid];
+    }
 
     int a_off[MI];
 #pragma unroll
@@ -125,18 +131,19 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(const liso_conv
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
 
-    const int n_stage = (te - tb + G - 1) / G;
+    const int n_taps = te - tb;
     const int kgroups_total = a.ci_pad >> 3;
     const long x_img = (long)b * d.hi * d.wi;
+    const unsigned short* wg = (const unsigned short*)a.w;
+    const long plane_elems = (long)d.w_taps * kgroups_total * a.co_pad * 8;
 
-    for (int c0 = 0; c0 < d.ci; c0 += cs) {
-        const int rem = d.ci - c0;
-        const int ksteps = ((rem < cs ? rem : cs) + 15) >> 4;
-        __syncthreads();  // every read of the previous slab's tile / panels is done
+    for (int c0 = 0; c0 < d.ci; c0 += CS) {
+        __syncthreads();  // every read of the previous slab's tile / panels is done (and the tap tables are written)
         // ---- stage the input halo tile --------------------------------------------------------------------------------
         if constexpr (!X3) {
-            const int cpp = k8;  // 16-B chunks (8 bf16) per pixel
-            const int c8 = tid % cpp, p0 = tid / cpp, pstep = kThreads / cpp;
+            constexpr int CPP = K8;  // 16-B chunks (8 bf16) per pixel
+            const int c8 = tid % CPP, p0 = tid / CPP;
+            constexpr int pstep = kThreads / CPP;
             const int ch = c0 + c8 * 8;
             const bool ch_ok = ch < d.ci;
             float sc[8], sh[8];
@@ -148,22 +155,30 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(const liso_conv
                     sh[e] = ch_ok ? a.in_shift[ch + e] : 0.0f;
                 }
             }
-            const unsigned short* xg = (const unsigned short*)a.x;
-            for (int pix0 = p0; pix0 < npix; pix0 += 4 * pstep) {
-                uint4 v[4];
-                bool ok[4];
+            const unsigned short* xg = (const unsigned short*)a.x + x_img * d.x_pix_stride;
+            constexpr int XB = 12;  // 16-B loads in flight per thread: the whole tile of the usual geometries in one batch
+            int ly = (int)(((float)p0 + 0.5f) * inv_w);
+            int lx = p0 - ly * in_w;
+            const int step_y = pstep / in_w, step_x = pstep - step_y * in_w;  // (uniform)
+            for (int pix0 = p0; pix0 < npix; pix0 += XB * pstep) {
+                uint4 v[XB];
+                bool ok[XB];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
+                for (int u = 0; u < XB; u++) {
                     const int pix = pix0 + u * pstep;
-                    const int ly = (int)(((float)pix + 0.5f) * inv_w);
-                    const int lx = pix - ly * in_w;
                     const int iy = iy0 + ly, ix = ix0 + lx;
-                    ok[u] = pix < npix && ch_ok && iy >= 0 && iy < d.hi && ix >= 0 && ix < d.wi;
-                    const long off = ok[u] ? ((x_img + (long)iy * d.wi + ix) * d.x_pix_stride + ch) : 0;
+                    ok[u] = pix < npix && ch_ok && (unsigned)iy < (unsigned)d.hi && (unsigned)ix < (unsigned)d.wi;
+                    const int off = ok[u] ? (iy * d.wi + ix) * d.x_pix_stride + ch : 0;  // (a sample has < 2^31 elements)
+                    lx += step_x;
+                    ly += step_y;
+                    if (lx >= in_w) {
+                        lx -= in_w;
+                        ly++;
+                    }
                     v[u] = *reinterpret_cast<const uint4*>(xg + off);
                 }
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
+                for (int u = 0; u < XB; u++) {
                     const int pix = pix0 + u * pstep;
                     if (pix >= npix) continue;
                     uint4 o = v[u];
@@ -186,8 +201,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(const liso_conv
                 }
             }
         } else {
-            const int cpp = cs >> 2;  // 16-B chunks (4 fp32) per pixel
-            const int c4 = tid % cpp, p0 = tid / cpp, pstep = kThreads / cpp;
+            constexpr int CPP = CS / 4;  // 16-B chunks (4 fp32) per pixel
+            const int c4 = tid % CPP, p0 = tid / CPP;
+            constexpr int pstep = kThreads / CPP;
             const int ch = c0 + c4 * 4;
             const bool ch_ok = ch < d.ci;
             float sc[4], sh[4];
@@ -199,23 +215,31 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(const liso_conv
                     sh[e] = ch_ok ? a.in_shift[ch + e] : 0.0f;
                 }
             }
-            const float* xg = (const float*)a.x;
+            const float* xg = (const float*)a.x + x_img * d.x_pix_stride;
             unsigned char* xs_lo = xs + a.x_plane_bytes;
-            for (int pix0 = p0; pix0 < npix; pix0 += 4 * pstep) {
-                float4 v[4];
-                bool ok[4];
+            constexpr int XB = 12;
+            int ly = (int)(((float)p0 + 0.5f) * inv_w);
+            int lx = p0 - ly * in_w;
+            const int step_y = pstep / in_w, step_x = pstep - step_y * in_w;  // (uniform)
+            for (int pix0 = p0; pix0 < npix; pix0 += XB * pstep) {
+                float4 v[XB];
+                bool ok[XB];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
+                for (int u = 0; u < XB; u++) {
                     const int pix = pix0 + u * pstep;
-                    const int ly = (int)(((float)pix + 0.5f) * inv_w);
-                    const int lx = pix - ly * in_w;
                     const int iy = iy0 + ly, ix = ix0 + lx;
-                    ok[u] = pix < npix && ch_ok && iy >= 0 && iy < d.hi && ix >= 0 && ix < d.wi;
-                    const long off = ok[u] ? ((x_img + (long)iy * d.wi + ix) * d.x_pix_stride + ch) : 0;
+                    ok[u] = pix < npix && ch_ok && (unsigned)iy < (unsigned)d.hi && (unsigned)ix < (unsigned)d.wi;
+                    const int off = ok[u] ? (iy * d.wi + ix) * d.x_pix_stride + ch : 0;  // (a sample has < 2^31 elements)
+                    lx += step_x;
+                    ly += step_y;
+                    if (lx >= in_w) {
+                        lx -= in_w;
+                        ly++;
+                    }
                     v[u] = *reinterpret_cast<const float4*>(xg + off);
                 }
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
+                for (int u = 0; u < XB; u++) {
                     const int pix = pix0 + u * pstep;
                     if (pix >= npix) continue;
                     float f[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
@@ -239,151 +263,154 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(const liso_conv
                 }
             }
         }
-        // ---- weight panels: stage 0 now, stage s+1 behind the MFMAs of stage s ----------------------------------------------
-        const unsigned short* wg = (const unsigned short*)a.w;
-        const long plane_elems = (long)d.w_taps * kgroups_total * a.co_pad * 8;
-        auto load_stage = [&](int s, uint4 (&regs)[kMaxWChunks]) {
-            const int g_cur = min(G, te - tb - s * G);
-            const int per_plane = g_cur * k8 * BNT;
+        // ---- taps in stages of G: weight panels [tap][plane][K8][BNT][8] of the stage into LDS, then the MFMAs ------------------
+        for (int s0 = 0; s0 < n_taps; s0 += G) {
+            const int g_cur = min(G, n_taps - s0);
+            if (s0 > 0) __syncthreads();  // the previous stage's panels have been read
+            const int chunks = g_cur * PLANES * PSZ;
+            constexpr int WB = 10;
+            for (int q0 = tid; q0 < chunks; q0 += WB * kThreads) {
+                uint4 v[WB];
 #pragma unroll
-            for (int u = 0; u < kMaxWChunks; u++) {
-                const int q = tid + u * kThreads;
-                const int plane = q / per_plane;  // (per_plane > 0)
-                const int rq = q - plane * per_plane;
-                const int g = rq / (k8 * BNT);
-                const int rr = rq - g * (k8 * BNT);
-                const int c8 = rr / BNT, n = rr - c8 * BNT;
-                const int kg = (c0 >> 3) + c8;
-                const bool okq = plane < PLANES && kg < kgroups_total;
-                const int tw = d.tap_w[tb + s * G + (okq ? g : 0)];
-                const long off = okq ? (plane * plane_elems + (((long)tw * kgroups_total + kg) * a.co_pad + n0 + n) * 8) : 0;
-                uint4 v = *reinterpret_cast<const uint4*>(wg + off);
-                if (!okq) v = make_uint4(0u, 0u, 0u, 0u);
-                regs[u] = v;
-            }
-        };
-        auto store_stage = [&](int s, const uint4 (&regs)[kMaxWChunks]) {
-            const int g_cur = min(G, te - tb - s * G);
-            const int per_plane = g_cur * k8 * BNT;
-            unsigned char* wb = wsb + (s & 1) * wstage_bytes;
+                for (int u = 0; u < WB; u++) {
+                    const int q = q0 + u * kThreads;
+                    const int panel = q / PSZ, inner = q % PSZ;  // (compile-time powers of two)
+                    const int g = panel / PLANES, plane = panel % PLANES;
+                    const int c8 = inner / BNT, n = inner % BNT;
+                    const int kg = (c0 >> 3) + c8;
+                    const bool okq = q < chunks && kg < kgroups_total;
+                    const int tw = s_tapw[s0 + (okq ? g : 0)];
+                    const int off = okq ? (plane * (int)plane_elems + ((tw * kgroups_total + kg) * a.co_pad + n0 + n) * 8) : 0;
+                    v[u] = *reinterpret_cast<const uint4*>(wg + off);
+                    if (!okq) v[u] = make_uint4(0u, 0u, 0u, 0u);
+                }
 #pragma unroll
-            for (int u = 0; u < kMaxWChunks; u++) {
-                const int q = tid + u * kThreads;
-                const int plane = q / per_plane;
-                if (plane >= PLANES) continue;
-                const int rq = q - plane * per_plane;  // = g * k8 * BNT + c8 * BNT + n: the LDS order
-                *reinterpret_cast<uint4*>(wb + plane * (G * wtap_bytes) + rq * 16) = regs[u];
+                for (int u = 0; u < WB; u++) {
+                    const int q = q0 + u * kThreads;
+                    if (q < chunks) *reinterpret_cast<uint4*>(wsb + q * 16) = v[u];
+                }
             }
-        };
-        uint4 wregs[kMaxWChunks];
-        load_stage(0, wregs);
-        store_stage(0, wregs);
-        __syncthreads();
-        for (int s = 0; s < n_stage; s++) {
-            const bool more = s + 1 < n_stage;
-            if (more) load_stage(s + 1, wregs);
-            const int g_cur = min(G, te - tb - s * G);
-            const unsigned char* wb = wsb + (s & 1) * wstage_bytes;
+            __syncthreads();
             for (int g = 0; g < g_cur; g++) {
-                const int tp = tb + s * G + g;
-                const int toff = ((d.tap_dy[tp] - dy0) * in_w + (d.tap_dx[tp] - dx0)) * PS;
-                const unsigned char* wt = wb + g * wtap_bytes;
-                for (int kk = 0; kk < ksteps; kk++) {
-                    uint4 af[MI], bfr[NJ];
+                const int toff = s_toff[s0 + g];
+                const unsigned char* wt = wsb + g * (PLANES * WTAP);
+                uint4 af[KS][MI], bfr[KS][NJ];
 #pragma unroll
-                    for (int i = 0; i < MI; i++) af[i] = *reinterpret_cast<const uint4*>(xs + a_off[i] + toff + kk * 32);
+                for (int kk = 0; kk < KS; kk++) {
 #pragma unroll
-                    for (int j = 0; j < NJ; j++) bfr[j] = *reinterpret_cast<const uint4*>(wt + b_off[j] + kk * (2 * BNT * 16));
-                    if constexpr (X3) {
-                        uint4 al[MI], bl[NJ];
+                    for (int i = 0; i < MI; i++) af[kk][i] = *reinterpret_cast<const uint4*>(xs + a_off[i] + toff + kk * 32);
+#pragma unroll
+                    for (int j = 0; j < NJ; j++) bfr[kk][j] = *reinterpret_cast<const uint4*>(wt + b_off[j] + kk * (2 * BNT * 16));
+                }
+                if constexpr (X3) {
+                    uint4 al[KS][MI], bl[KS][NJ];
+#pragma unroll
+                    for (int kk = 0; kk < KS; kk++) {
 #pragma unroll
                         for (int i = 0; i < MI; i++)
-                            al[i] = *reinterpret_cast<const uint4*>(xs + a.x_plane_bytes + a_off[i] + toff + kk * 32);
+                            al[kk][i] = *reinterpret_cast<const uint4*>(xs + a.x_plane_bytes + a_off[i] + toff + kk * 32);
 #pragma unroll
                         for (int j = 0; j < NJ; j++)
-                            bl[j] = *reinterpret_cast<const uint4*>(wt + G * wtap_bytes + b_off[j] + kk * (2 * BNT * 16));
+                            bl[kk][j] = *reinterpret_cast<const uint4*>(wt + WTAP + b_off[j] + kk * (2 * BNT * 16));
+                    }
+#pragma unroll
+                    for (int kk = 0; kk < KS; kk++)
 #pragma unroll
                         for (int i = 0; i < MI; i++)
 #pragma unroll
                             for (int j = 0; j < NJ; j++) {
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(al[i]), as_bf8(bfr[j]), acc[i][j], 0, 0, 0);
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(af[i]), as_bf8(bl[j]), acc[i][j], 0, 0, 0);
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(af[i]), as_bf8(bfr[j]), acc[i][j], 0, 0, 0);
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(al[kk][i]), as_bf8(bfr[kk][j]), acc[i][j], 0, 0, 0);
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(af[kk][i]), as_bf8(bl[kk][j]), acc[i][j], 0, 0, 0);
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(af[kk][i]), as_bf8(bfr[kk][j]), acc[i][j], 0, 0, 0);
                             }
-                    } else {
+                } else {
+#pragma unroll
+                    for (int kk = 0; kk < KS; kk++)
 #pragma unroll
                         for (int i = 0; i < MI; i++)
 #pragma unroll
                             for (int j = 0; j < NJ; j++)
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(af[i]), as_bf8(bfr[j]), acc[i][j], 0, 0, 0);
-                    }
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(af[kk][i]), as_bf8(bfr[kk][j]), acc[i][j], 0, 0, 0);
                 }
             }
-            if (more) store_stage(s + 1, wregs);
-            __syncthreads();
         }
     }
+    __syncthreads();
 
     // ---- epilogue ------------------------------------------------------------------------------------------------------------
+    // Register e of a 32 x 32 tile is pixel column (e & 3) + 8 (e >> 2) + 4 h of ONE tile row (TW = 32): the row part of the
+    // output offset and the row validity are per (wave, i); the column part is a compile-time multiple of the pixel stride.
     const bool want_stats = a.stats != nullptr;
     float s1[NJ], s2[NJ];
     const int ooy = d.class_ooy[cls], oox = d.class_oox[cls];
+    const int col_stride = d.osx * d.y_pix_stride;  // elements between horizontally adjacent virtual pixels
+    unsigned colmask = 0;                           // bit e: the pixel column of register e exists
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        const int vx = tx * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (vx < d.wv && vx * d.osx + oox < d.wo) colmask |= 1u << e;
+    }
+    const int col0 = (tx * 32 + 4 * h) * d.osx + oox;
 #pragma unroll
     for (int j = 0; j < NJ; j++) {
-        const int n = n0 + j * 32 + r;
-        const bool n_ok = n < d.co;
-        const float bias_v = (a.bias && n_ok) ? a.bias[n] : 0.0f;
-        const float shift_v = (a.stats_shift && n_ok) ? a.stats_shift[n] : 0.0f;
         s1[j] = 0.0f;
         s2[j] = 0.0f;
+    }
 #pragma unroll
-        for (int i = 0; i < MI; i++) {
+    for (int i = 0; i < MI; i++) {
+        const int vy = ty * TH + wave * MI + i;
+        const int oy = vy * d.osy + ooy;
+        const unsigned rowmask = (vy < d.hv && oy < d.ho) ? colmask : 0u;
+        const long row_base = (((long)b * d.ho + oy) * d.wo + col0) * d.y_pix_stride + d.y_ch_off;
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            const int n = n0 + j * 32 + r;
+            const bool n_ok = n < d.co;
+            const float bias_v = (a.bias && n_ok) ? a.bias[n] : 0.0f;
+            const float shift_v = (a.stats_shift && n_ok) ? a.stats_shift[n] : 0.0f;
             float v[16];
-            bool pv[16];
-            long po[16];
 #pragma unroll
             for (int e = 0; e < 16; e++) {
                 float val = acc[i][j][e] + bias_v;
                 if (d.out_relu) val = fmaxf(val, 0.0f);
-                const int m = wave * (32 * MI) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                const int vy = ty * TH + (m >> 5), vx = tx * 32 + (m & 31);
-                const int oy = vy * d.osy + ooy, ox = vx * d.osx + oox;
-                pv[e] = vy < d.hv && vx < d.wv && oy < d.ho && ox < d.wo;
-                po[e] = (((long)b * d.ho + oy) * d.wo + ox) * d.y_pix_stride + d.y_ch_off;
                 if constexpr (!OUT_F32) val = round_bf16(val);
                 v[e] = val;
-                if (want_stats && pv[e]) {
+                if (want_stats && ((rowmask >> e) & 1u)) {
                     const float dd = val - shift_v;
                     s1[j] += dd;
                     s2[j] = fmaf(dd, dd, s2[j]);
                 }
             }
             if constexpr (OUT_F32) {
-                float* yg = (float*)a.y;
+                float* yg = (float*)a.y + row_base + n;
 #pragma unroll
                 for (int e = 0; e < 16; e++)
-                    if (pv[e] && n_ok) yg[po[e] + n] = v[e];
+                    if (((rowmask >> e) & 1u) && n_ok) yg[((e & 3) + 8 * (e >> 2)) * col_stride] = v[e];
             } else {
-                unsigned short* yg = (unsigned short*)a.y;
+                unsigned short* yg = (unsigned short*)a.y + row_base;
                 const bool odd = r & 1;
                 const int n_even = n & ~1;
                 if ((d.y_pix_stride | d.y_ch_off) & 1) {  // odd pixel stride: channel pairs are not 4-B aligned, 2-B stores
 #pragma unroll
                     for (int e = 0; e < 16; e++)
-                        if (pv[e] && n_ok) yg[po[e] + n] = (unsigned short)(pack_bf16(v[e], 0.0f) & 0xffffu);
-                } else
+                        if (((rowmask >> e) & 1u) && n_ok)
+                            yg[((e & 3) + 8 * (e >> 2)) * col_stride + n] = (unsigned short)(pack_bf16(v[e], 0.0f) & 0xffffu);
+                } else {
 #pragma unroll
-                for (int e = 0; e < 16; e += 2) {
-                    const float send = odd ? v[e] : v[e + 1];
-                    const float recv = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(send), 0xB1, 0xF, 0xF, true));
-                    const float c_lo = odd ? recv : v[e];      // channel n_even
-                    const float c_hi = odd ? v[e + 1] : recv;  // channel n_even + 1
-                    const int ee = odd ? e + 1 : e;            // the pixel this lane stores
-                    if (pv[ee]) {
-                        if (n_even + 1 < d.co)
-                            *reinterpret_cast<unsigned*>(yg + po[ee] + n_even) = pack_bf16(c_lo, c_hi);
-                        else if (n_even < d.co)
-                            yg[po[ee] + n_even] = (unsigned short)(pack_bf16(c_lo, 0.0f) & 0xffffu);
+                    for (int e = 0; e < 16; e += 2) {
+                        const float send = odd ? v[e] : v[e + 1];
+                        const float recv = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(send), 0xB1, 0xF, 0xF, true));
+                        const float c_lo = odd ? recv : v[e];      // channel n_even
+                        const float c_hi = odd ? v[e + 1] : recv;  // channel n_even + 1
+                        const int ee = odd ? e + 1 : e;            // the register (pixel) this lane stores: compile-time per parity
+                        const int koff = odd ? ((e + 1) & 3) + 8 * ((e + 1) >> 2) : (e & 3) + 8 * (e >> 2);
+                        if ((rowmask >> ee) & 1u) {
+                            unsigned short* dst = yg + koff * col_stride + n_even;
+                            if (n_even + 1 < d.co)
+                                *reinterpret_cast<unsigned*>(dst) = pack_bf16(c_lo, c_hi);
+                            else if (n_even < d.co)
+                                *dst = (unsigned short)(pack_bf16(c_lo, 0.0f) & 0xffffu);
+                        }
                     }
                 }
             }
@@ -511,67 +538,74 @@ bool make_plan(const liso_conv_desc& d, Plan* p) {
     p->nj = d.co <= 32 ? 1 : 2;
     const int bnt = 32 * p->nj;
     a.n_nt = (d.co + bnt - 1) / bnt;
-    // rows per tile: 8 when that still fills the chip, else 4
     auto blocks = [&](int th) { return (long)d.n_classes * d.batch * ((d.hv + th - 1) / th) * ((d.wv + 31) / 32) * a.n_nt; };
-    p->mi = blocks(8) >= 512 ? 2 : 1;
     int max_taps = 1;
-    int lds_cap = 79 * 1024;  // 2 blocks per CU; second pass: one block per CU (large halos: 7x7 stride 2 in F32X3)
-    for (;;) {
-        const int th = 4 * p->mi;
+    for (int c = 0; c < d.n_classes; c++) {
+        const int nt = d.class_tap_begin[c + 1] - d.class_tap_begin[c];
+        if (nt < 1) return false;
+        max_taps = nt > max_taps ? nt : max_taps;
+        for (int t = d.class_tap_begin[c]; t < d.class_tap_begin[c + 1]; t++)
+            if (d.tap_w[t] < 0 || d.tap_w[t] >= d.w_taps) return false;
+    }
+    auto tile_pixels = [&](int th, int* inh, int* inw, int* y0s, int* x0s) {
         int max_pix = 0;
         for (int c = 0; c < d.n_classes; c++) {
             int y0 = 1 << 30, y1 = -(1 << 30), x0 = 1 << 30, x1 = -(1 << 30);
-            const int nt = d.class_tap_begin[c + 1] - d.class_tap_begin[c];
-            if (nt < 1) return false;
-            max_taps = nt > max_taps ? nt : max_taps;
             for (int t = d.class_tap_begin[c]; t < d.class_tap_begin[c + 1]; t++) {
                 y0 = d.tap_dy[t] < y0 ? d.tap_dy[t] : y0;
                 y1 = d.tap_dy[t] > y1 ? d.tap_dy[t] : y1;
                 x0 = d.tap_dx[t] < x0 ? d.tap_dx[t] : x0;
                 x1 = d.tap_dx[t] > x1 ? d.tap_dx[t] : x1;
-                if (d.tap_w[t] < 0 || d.tap_w[t] >= d.w_taps) return false;
             }
-            a.cls_dy0[c] = y0;
-            a.cls_dx0[c] = x0;
-            a.cls_inh[c] = (th - 1) * d.isy + (y1 - y0) + 1;
-            a.cls_inw[c] = 31 * d.isx + (x1 - x0) + 1;
-            const int np = a.cls_inh[c] * a.cls_inw[c];
+            y0s[c] = y0;
+            x0s[c] = x0;
+            inh[c] = (th - 1) * d.isy + (y1 - y0) + 1;
+            inw[c] = 31 * d.isx + (x1 - x0) + 1;
+            const int np = inh[c] * inw[c];
             max_pix = np > max_pix ? np : max_pix;
         }
-        // largest slab whose tile + double-buffered panels fit 80 KB (2 blocks per CU)
-        const int cs_opts[3] = {64, 32, 16};
-        bool found = false;
-        for (int k = x3 ? 1 : 0; k < 3 && !found; k++) {
-            const int cs = cs_opts[k];
-            if (cs > a.ci_pad && k < 2 && cs_opts[k + 1] >= a.ci_pad) continue;  // do not stage channels that do not exist
-            const int xb = round_up(max_pix * (cs * 2 + 16), 16);
-            const int per_tap = planes * (cs / 8) * bnt;  // 16-B chunks per tap
-            int g = kMaxWChunks * kThreads / per_tap;
-            g = g < 1 ? 1 : (g > max_taps ? max_taps : g);
-            for (; g >= 1; g--) {
-                const int lds = xb * planes + 2 * g * per_tap * 16;
-                if (lds <= lds_cap) {
+        return max_pix;
+    };
+    // Choose (rows per tile, slab width, taps per weight stage): the configuration with the most MFMAs between two barriers
+    // among those that leave room for 2 blocks per CU (79 KB); one block per CU (158 KB) only if nothing else fits.
+    // 8-row tiles only when they still give every CU 2 blocks.
+    const int mi_first = blocks(8) >= 512 ? 2 : 1;
+    const int cs_opts[2] = {x3 ? 32 : 64, x3 ? 16 : 32};
+    long best = -1;
+    for (int pass = 0; pass < 2 && best < 0; pass++) {
+        const int cap = (pass == 0 ? 79 : 158) * 1024;
+        for (int mi = mi_first; mi >= 1; mi--) {
+            int inh[LISO_CONV_MAX_CLASSES], inw[LISO_CONV_MAX_CLASSES], y0s[LISO_CONV_MAX_CLASSES], x0s[LISO_CONV_MAX_CLASSES];
+            const int max_pix = tile_pixels(4 * mi, inh, inw, y0s, x0s);
+            for (int k = 0; k < 2; k++) {
+                const int cs = cs_opts[k];
+                if (k == 0 && cs_opts[1] >= a.ci_pad) continue;  // do not stage channels that do not exist
+                const int xb = round_up(max_pix * (cs * 2 + 16), 16);
+                const int panel = planes * (cs / 8) * bnt * 16;
+                int g = (cap - 512 - xb * planes) / panel;
+                if (g < 1) continue;
+                g = g > max_taps ? max_taps : g;
+                const long score = ((long)g * (cs / 16) * mi * 1000) + cs + (mi == mi_first ? 500000 : 0);
+                if (score > best) {
+                    best = score;
+                    p->mi = mi;
                     p->cs = cs;
                     p->g = g;
-                    p->lds = lds < 4 * 64 * 2 * 4 ? 4 * 64 * 2 * 4 : lds;
                     a.x_plane_bytes = xb;
-                    found = true;
-                    break;
+                    p->lds = 512 + xb * planes + g * panel;
+                    for (int c = 0; c < d.n_classes; c++) {
+                        a.cls_dy0[c] = y0s[c];
+                        a.cls_dx0[c] = x0s[c];
+                        a.cls_inh[c] = inh[c];
+                        a.cls_inw[c] = inw[c];
+                    }
                 }
             }
+            if (best >= 0) break;  // (prefer the taller tile whenever it fits)
         }
-        if (found) break;
-        if (p->mi == 2) {
-            p->mi = 1;
-            continue;
-        }
-        if (lds_cap < 158 * 1024) {
-            lds_cap = 158 * 1024;
-            p->mi = blocks(8) >= 512 ? 2 : 1;
-            continue;
-        }
-        return false;
     }
+    if (best < 0) return false;
+    if (p->lds < 4096) p->lds = 4096;  // the statistics epilogue reuses the front of the buffer
     const int th = 4 * p->mi;
     a.cs = p->cs;
     a.g_taps = p->g;
@@ -581,16 +615,16 @@ bool make_plan(const liso_conv_desc& d, Plan* p) {
     return true;
 }
 
-template <int MODE, int MI, int NJ, bool OUT_F32>
+template <int MODE, int MI, int NJ, bool OUT_F32, int CS>
 int launch(const liso_conv_desc& d, const Plan& p, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)conv_igemm_kernel<MODE, MI, NJ, OUT_F32>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void*)conv_igemm_kernel<MODE, MI, NJ, OUT_F32, CS>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024) != hipSuccess)
             return LISO_ELAUNCH;
         attr_set = true;
     }
-    conv_igemm_kernel<MODE, MI, NJ, OUT_F32><<<p.a.total, kThreads, p.lds, st>>>(d, p.a);
+    conv_igemm_kernel<MODE, MI, NJ, OUT_F32, CS><<<p.a.total, kThreads, p.lds, st>>>(d, p.a);
     return check_launch();
 }
 
@@ -640,17 +674,17 @@ int liso_conv_forward(const liso_conv_desc* d, const void* x, const void* w_pack
     hipStream_t st = (hipStream_t)stream;
     const bool x3 = d->mode == LISO_CONV_F32X3;
     const bool of32 = x3 || d->out_f32;
-#define LISO_GO(MODE, MI, NJ, OF) return launch<MODE, MI, NJ, OF>(*d, p, st)
-#define LISO_SEL(MODE, OF)                  \
+#define LISO_GO(MODE, MI, NJ, OF, CSA, CSB) return p.cs == CSA ? launch<MODE, MI, NJ, OF, CSA>(*d, p, st) : launch<MODE, MI, NJ, OF, CSB>(*d, p, st)
+#define LISO_SEL(MODE, OF, CSA, CSB)                  \
     do {                                    \
-        if (p.mi == 2 && p.nj == 2) LISO_GO(MODE, 2, 2, OF); \
-        if (p.mi == 2 && p.nj == 1) LISO_GO(MODE, 2, 1, OF); \
-        if (p.mi == 1 && p.nj == 2) LISO_GO(MODE, 1, 2, OF); \
-        LISO_GO(MODE, 1, 1, OF);            \
+        if (p.mi == 2 && p.nj == 2) LISO_GO(MODE, 2, 2, OF, CSA, CSB); \
+        if (p.mi == 2 && p.nj == 1) LISO_GO(MODE, 2, 1, OF, CSA, CSB); \
+        if (p.mi == 1 && p.nj == 2) LISO_GO(MODE, 1, 2, OF, CSA, CSB); \
+        LISO_GO(MODE, 1, 1, OF, CSA, CSB);            \
     } while (0)
-    if (x3) LISO_SEL(LISO_CONV_F32X3, true);
-    if (of32) LISO_SEL(LISO_CONV_BF16, true);
-    LISO_SEL(LISO_CONV_BF16, false);
+    if (x3) LISO_SEL(LISO_CONV_F32X3, true, 32, 16);
+    if (of32) LISO_SEL(LISO_CONV_BF16, true, 64, 32);
+    LISO_SEL(LISO_CONV_BF16, false, 64, 32);
 #undef LISO_SEL
 #undef LISO_GO
 }

@@ -14,6 +14,7 @@
 // gradient in torch's weight layout, and the bias gradient (column sums of dy, accumulated while dy is staged).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/liso_conv.h"
 #include "../../include/liso_iou3d.h"
@@ -70,6 +71,7 @@ template <int MODE, int TG>
 __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(const liso_conv_desc d, const WgArgs a) {
     constexpr bool X3 = MODE == LISO_CONV_F32X3;
     constexpr int PLANES = X3 ? 2 : 1;
+    constexpr int XB = TG >= 9 ? 4 : 8;  // 16-B loads in flight per thread while a tile is staged (register budget)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     int t = blockIdx.x;
@@ -139,11 +141,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(const liso_conv
                 }
             }
             const unsigned short* xg = (const unsigned short*)a.x;
-            for (int pix0 = p0; pix0 < npix; pix0 += 2 * pstep) {
-                uint4 v[2];
-                bool ok[2];
+            for (int pix0 = p0; pix0 < npix; pix0 += XB * pstep) {
+                uint4 v[XB];
+                bool ok[XB];
 #pragma unroll
-                for (int u = 0; u < 2; u++) {
+                for (int u = 0; u < XB; u++) {
                     const int pix = pix0 + u * pstep;
                     const int ly = (int)(((float)pix + 0.5f) * inv_w);
                     const int lx = pix - ly * in_w;
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(const liso_conv
                     v[u] = *reinterpret_cast<const uint4*>(xg + off);
                 }
 #pragma unroll
-                for (int u = 0; u < 2; u++) {
+                for (int u = 0; u < XB; u++) {
                     const int pix = pix0 + u * pstep;
                     if (pix >= npix) continue;
                     uint4 o = v[u];
@@ -212,11 +214,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(const liso_conv
             }
             const float* xg = (const float*)a.x;
             unsigned char* xs_lo = xs + a.x_plane_bytes;
-            for (int pix0 = p0; pix0 < npix; pix0 += 2 * pstep) {
-                float4 v[2];
-                bool ok[2];
+            for (int pix0 = p0; pix0 < npix; pix0 += XB * pstep) {
+                float4 v[XB];
+                bool ok[XB];
 #pragma unroll
-                for (int u = 0; u < 2; u++) {
+                for (int u = 0; u < XB; u++) {
                     const int pix = pix0 + u * pstep;
                     const int ly = (int)(((float)pix + 0.5f) * inv_w);
                     const int lx = pix - ly * in_w;
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(const liso_conv
                     v[u] = *reinterpret_cast<const float4*>(xg + off);
                 }
 #pragma unroll
-                for (int u = 0; u < 2; u++) {
+                for (int u = 0; u < XB; u++) {
                     const int pix = pix0 + u * pstep;
                     if (pix >= npix) continue;
                     float f[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
@@ -332,26 +334,39 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(const liso_conv
     }
 }
 
-// dw (torch layout) = sum over splits of the slabs, in split order
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bias_slab, int splits, int bias_rows, int taps,
-                                    int ci, int co, long cip, long cop, int transposed, float* __restrict__ dw,
-                                    float* __restrict__ dbias) {
-    const long total = (long)taps * ci * co;
-    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q < total) {
-        const int n = (int)(q % co);
-        const long t2 = q / co;
-        const int k = (int)(t2 % ci);
-        const int tap = (int)(t2 / ci);
+// dw (torch layout) = sum over splits of the slabs (fixed order: 4 interleaved partial sums per output, then a tree)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bias_slab,
+                                                           int splits, int bias_rows, int taps, int ci, int co, long cip, long cop,
+                                                           int transposed, float* __restrict__ dw, float* __restrict__ dbias) {
+    __shared__ float red[4][64];
+    const int nl = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int n_tiles = (co + 63) / 64;
+    const long rows = (long)taps * ci;
+    const long bid = blockIdx.x;
+    if (bid < rows * n_tiles) {
+        const int ntile = (int)(bid % n_tiles);
+        const long row = bid / n_tiles;  // tap * ci + k
+        const int k = (int)(row % ci), tap = (int)(row / ci);
+        const int n = ntile * 64 + nl;
         float s = 0.0f;
-        for (int sp = 0; sp < splits; sp++) s += slab[(((long)sp * taps + tap) * cip + k) * cop + n];
-        const long o = transposed ? (((long)k * co + n) * taps + tap) : (((long)n * ci + k) * taps + tap);
-        dw[o] = s;
-    }
-    if (dbias && q < co) {
+        if (n < co)
+            for (int sp = part; sp < splits; sp += 4) s += slab[(((long)sp * taps + tap) * cip + k) * cop + n];
+        red[part][nl] = s;
+        __syncthreads();
+        if (part == 0 && n < co) {
+            const float v = (red[0][nl] + red[1][nl]) + (red[2][nl] + red[3][nl]);
+            const long o = transposed ? (((long)k * co + n) * taps + tap) : (((long)n * ci + k) * taps + tap);
+            dw[o] = v;
+        }
+    } else if (dbias) {  // trailing blocks: the bias gradient
+        const int ntile = (int)(bid - rows * n_tiles);
+        const int n = ntile * 64 + nl;
         float s = 0.0f;
-        for (int sp = 0; sp < bias_rows; sp++) s += bias_slab[(long)sp * cop + q];
-        dbias[q] = s;
+        if (n < co)
+            for (int sp = part; sp < bias_rows; sp += 4) s += bias_slab[(long)sp * cop + n];
+        red[part][nl] = s;
+        __syncthreads();
+        if (part == 0 && n < co) dbias[n] = (red[0][nl] + red[1][nl]) + (red[2][nl] + red[3][nl]);
     }
 }
 
@@ -423,18 +438,42 @@ bool make_plan(const liso_conv_desc& d, WgPlan* p) {
     a.psx = CT * 2 + 16;
     a.x_plane_bytes = round_up(max_pix * a.psx, 16);
     p->lds = planes * (a.x_plane_bytes + TH * TW * PSY);
-    // taps per block: 9 when the (ci, co, class) tiles alone give enough blocks, else 3, else 1
+    // taps per block (9 / 3 / 1) and pixel splits: the slabs of all splits together stay below 24 MB (they are written and
+    // read once), every block sees >= 4 tiles, and the grid should reach ~2 blocks per CU; more taps per block = fewer
+    // re-stagings of the same tiles, so the largest tap group that still fills the chip wins.
     const long cc = (long)a.ci_t * a.co_t;
     auto groups = [&](int tg) {
         int n = 0;
         for (int c = 0; c < d.n_classes; c++) n += (d.class_tap_begin[c + 1] - d.class_tap_begin[c] + tg - 1) / tg;
         return n;
     };
-    const int max_splits = a.n_tiles >= 4 ? a.n_tiles / 4 : 1;  // >= 4 tiles per block
-    p->tg = x3 ? 3 : 9;  // (F32X3 issues 3 MFMAs per tap and k-step: 3 taps already balance the staging)
-    if (max_cls_taps == 1) p->tg = 1;
-    else if (cc * groups(9) * max_splits < 384 || max_cls_taps <= 3) p->tg = 3;
-    if (p->tg == 3 && cc * groups(3) * max_splits < 384 && max_cls_taps > 1) p->tg = 1;
+    const long slab_per_split = (long)d.w_taps * a.ci_t * CT * a.co_t * CT * sizeof(float);
+    long split_cap = (24l << 20) / slab_per_split;
+    const long by_tiles = a.n_tiles >= 4 ? a.n_tiles / 4 : 1;
+    split_cap = split_cap < 1 ? 1 : (split_cap > by_tiles ? by_tiles : split_cap);
+    const int tg_opts[3] = {9, 3, 1};
+    long best_blocks = -1;
+    p->tg = 1;
+    for (int k = (x3 ? 1 : 0); k < 3; k++) {
+        const int tg = tg_opts[k];
+        if (tg > 1 && max_cls_taps == 1) continue;
+        const long per_split = cc * groups(tg);
+        long s = (512 + per_split - 1) / per_split;
+        s = s < 1 ? 1 : (s > split_cap ? split_cap : s);
+        const long blocks = per_split * s;
+        if (blocks >= 256) {  // enough: take the largest tap group
+            p->tg = tg;
+            break;
+        }
+        if (blocks > best_blocks) {
+            best_blocks = blocks;
+            p->tg = tg;
+        }
+    }
+    if (const char* e = getenv("LISO_WGRAD_TG")) {  // experiments: force the tap group (9 / 3 / 1)
+        const int v = atoi(e);
+        if ((v == 9 && !x3) || v == 3 || v == 1) p->tg = v;
+    }
     a.n_groups = 0;
     for (int c = 0; c < d.n_classes; c++)
         for (int t = d.class_tap_begin[c]; t < d.class_tap_begin[c + 1]; t += p->tg) {
@@ -446,8 +485,8 @@ bool make_plan(const liso_conv_desc& d, WgPlan* p) {
             a.n_groups++;
         }
     const long per_split = cc * a.n_groups;
-    long s = (768 + per_split - 1) / per_split;
-    s = s < 1 ? 1 : (s > max_splits ? max_splits : s);
+    long s = (512 + per_split - 1) / per_split;
+    s = s < 1 ? 1 : (s > split_cap ? split_cap : s);
     p->splits = (int)s;
     a.splits = p->splits;
     p->blocks = (int)(per_split * s);
@@ -504,8 +543,8 @@ int liso_conv_wgrad(const liso_conv_desc* d, const void* x, const float* in_scal
         rc = p.tg == 9 ? launch<LISO_CONV_BF16, 9>(*d, p, st) : p.tg == 3 ? launch<LISO_CONV_BF16, 3>(*d, p, st)
                                                                          : launch<LISO_CONV_BF16, 1>(*d, p, st);
     if (rc != LISO_OK) return rc;
-    const long total = (long)d->w_taps * d->ci * d->co;
-    wgrad_reduce_kernel<<<(int)((total + 255) / 256), 256, 0, st>>>(p.a.slab, p.a.bias_slab, p.splits, p.splits * d->n_classes, d->w_taps, d->ci, d->co,
+    const long rblocks = ((long)d->w_taps * d->ci + (dbias ? 1 : 0)) * ((d->co + 63) / 64);
+    wgrad_reduce_kernel<<<(int)rblocks, 256, 0, st>>>(p.a.slab, p.a.bias_slab, p.splits, p.splits * d->n_classes, d->w_taps, d->ci, d->co,
                                                                     (long)p.a.ci_t * CT, (long)p.a.co_t * CT, transposed, dw, dbias);
     return hipGetLastError() == hipSuccess ? LISO_OK : LISO_ELAUNCH;
 }

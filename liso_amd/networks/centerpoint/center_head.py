@@ -31,6 +31,20 @@ class SepHead(nn.Module):
                     kaiming_init(m)
             self.__setattr__(head, fc)
 
+    def forward_fused(self, x_raw, fold, MC):
+        """all heads' hidden convolutions (same input, same geometry) as ONE convolution with 4 x head_conv filters and one
+        statistics epilogue; every output convolution then reads its 64-channel slice of that map (fp32 outputs)"""
+        seqs = [list(self.__getattr__(h)) for h in self.heads]
+        if not all(len(q) == 4 and isinstance(q[1], nn.BatchNorm2d) for q in seqs):
+            return None
+        hid, hfold = MC.fused_conv(x_raw, fold, [q[0] for q in seqs], out_bn=[q[1] for q in seqs])
+        out, a = {}, 0
+        for k, (head, q) in enumerate(zip(self.heads, seqs)):
+            c = q[0].out_channels
+            out[head], _ = MC.fused_conv(hid[:, a:a + c], hfold.group(k), q[3], out_dtype=torch.float32)
+            a += c
+        return out
+
     def forward(self, x):
         out = {}
         for head in self.heads:
@@ -65,6 +79,20 @@ class CenterHead(nn.Module):
                                   final_kernel=3))
 
     def forward(self, x, *kwargs):
+        from liso_amd.utils import mfma_conv as MC
+
+        fold = None
+        if isinstance(x, tuple):  # (raw maps, BnFold) from RPN.forward(lazy=True)
+            x, fold = x
+        if x.is_cuda and MC.backend() == "mfma" and x.dtype in (torch.bfloat16, torch.float32):
+            s_raw, s_fold = MC.fused_conv(x, fold, self.shared_conv[0], out_bn=self.shared_conv[1])
+            assert len(self.tasks) == 1, len(self.tasks)
+            ret = self.tasks[0].forward_fused(s_raw, s_fold, MC)
+            if ret is not None:
+                return ret
+            x = MC.materialize(s_raw, s_fold)
+            return self.tasks[0](x)
+        x = MC.materialize(x, fold)
         x = conv_bn_relu(x, self.shared_conv[0], self.shared_conv[1])
         ret = [task(x) for task in self.tasks]
         assert len(ret) == 1, len(ret)

@@ -85,8 +85,15 @@ class RPN(nn.Module):
             if isinstance(m, nn.Conv2d):
                 xavier_init(m, distribution="uniform")
 
-    def forward(self, x):
-        """reference :137-146"""
+    def forward(self, x, lazy=False):
+        """reference :137-146.  On the GPU every convolution runs on the own MFMA kernels with the BatchNorm+ReLU of layer k
+        folded into the prologue of layer k+1 (liso_amd/utils/mfma_conv.py); `lazy=True` (CenterPointStyleNet) returns
+        (raw concatenated maps, BnFold) for CenterHead instead of materialising the normalised feature map."""
+        from liso_amd.utils import mfma_conv as MC
+
+        if x.is_cuda and MC.backend() == "mfma" and x.dtype in (torch.bfloat16, torch.float32):
+            raw, fold = self._forward_fused(x, MC)
+            return (raw, fold) if lazy else MC.materialize(raw, fold)
         ups = []
         for i, block in enumerate(self.blocks):
             mods = list(block)
@@ -99,3 +106,20 @@ class RPN(nn.Module):
         if len(ups) > 0:
             x = torch.cat(ups, dim=1)
         return x
+
+    def _forward_fused(self, x, MC):
+        fold, ups = None, []
+        for i, block in enumerate(self.blocks):
+            mods = list(block)
+            st = mods[1].stride[0]
+            x, fold = MC.fused_conv(x, fold, mods[1], out_bn=mods[2], spec=MC.ConvSpec(3, 3, st, 1))  # ZeroPad2d(1) + conv(pad 0)
+            for j in range(4, len(mods), 3):
+                x, fold = MC.fused_conv(x, fold, mods[j], out_bn=mods[j + 1])
+            if i - self._upsample_start_idx >= 0:
+                d = self.deblocks[i - self._upsample_start_idx]
+                ups.append(MC.fused_conv(x, fold, d[0], out_bn=d[1]))
+        if len(ups) == 0:
+            return x, fold
+        if len(ups) == 1:
+            return ups[0]
+        return torch.cat([u[0] for u in ups], dim=1), MC.BnFold.cat([u[1] for u in ups])

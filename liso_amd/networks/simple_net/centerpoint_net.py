@@ -52,5 +52,5 @@ class CenterPointStyleNet(torch.nn.Module):
     def forward(self, img_t0, pcls):
         bev_enc, bev_occupancy_map = self.pfn(pcl_t0=pcls, img_t0=img_t0)
         aux_outputs = {"bev_net_input_dbg": bev_occupancy_map}
-        pred_dict = self.center_head(self.rpn(bev_enc))
+        pred_dict = self.center_head(self.rpn(bev_enc, lazy=True))
         return {k: v.permute(0, 2, 3, 1) for k, v in pred_dict.items()}, aux_outputs  # reference :111

@@ -59,6 +59,20 @@ def _base_desc(B, hi, wi, ci, x_ps, ho, wo, co, y_ps, y_off, mode, out_f32, in_r
     return d
 
 
+_DESC_CACHE = {}
+
+
+def _cached(fn):
+    def wrapper(spec, *args, **kw):
+        key = (fn.__name__, spec.kh, spec.kw, spec.stride, spec.padding, spec.transposed, args, tuple(sorted(kw.items())))
+        d = _DESC_CACHE.get(key)
+        if d is None:
+            d = _DESC_CACHE[key] = fn(spec, *args, **kw)
+        return d
+    return wrapper
+
+
+@_cached
 def gather_desc(spec, B, hi, wi, ci, x_ps, ho, wo, co, y_ps, y_off, mode, out_f32=False, in_relu=False, out_relu=False):
     """out[v] = sum_taps in[v * s + (k - p)] * w[k]: forward of a convolution, data gradient of a transposed convolution"""
     d = _base_desc(B, hi, wi, ci, x_ps, ho, wo, co, y_ps, y_off, mode, out_f32, in_relu, out_relu, spec.kh * spec.kw)
@@ -74,6 +88,7 @@ def gather_desc(spec, B, hi, wi, ci, x_ps, ho, wo, co, y_ps, y_off, mode, out_f3
     return d
 
 
+@_cached
 def scatter_desc(spec, B, hi, wi, ci, x_ps, ho, wo, co, y_ps, y_off, mode, out_f32=False, in_relu=False, out_relu=False):
     """out[i * s - p + k] += in[i] * w[k], evaluated per output-parity class: forward of a transposed convolution, data
     gradient of a convolution.  (hi, wi, ci) describe the tensor that is READ, (ho, wo, co) the one that is written."""
@@ -183,7 +198,9 @@ def conv_forward(x, weight, bias, spec, in_scale=None, in_shift=None, in_relu=Fa
         if rows <= 0:
             raise L.LisoHipError("conv_forward: unsupported geometry")
         stats = torch.empty((rows, 2, (co + 63) // 64 * 64), dtype=torch.float32, device=x.device)
-    b = bias.detach().float().contiguous() if bias is not None else None
+    b = bias.detach() if bias is not None else None
+    if b is not None and (b.dtype != torch.float32 or not b.is_contiguous()):
+        b = b.float().contiguous()
     with torch.cuda.device(x.device):
         L.check(L.TIMER.launch(_timer_name(mode, "fwd"), lambda: lib.liso_conv_forward(
             ctypes.byref(d), L.ptr(xv), L.ptr(packed), L.ptr(b) if b is not None else None,
@@ -281,32 +298,58 @@ def supported(x, weight, spec):
 
 # ---- BatchNorm folding ---------------------------------------------------------------------------------------------------
 class BnFold:
-    """A BatchNorm2d(+ReLU) that has NOT been applied yet: the consumer convolution applies it in its prologue.
-    `stats` fp32 [4C] = scale | shift | mean | invstd (the layout of include/liso_bn.h); gamma / beta are the module's
-    parameters (they receive their gradients through the consumer's backward)."""
+    """BatchNorm2d(+ReLU) layers that have NOT been applied yet: the consumer convolution applies them in its prologue.
+    One group per BatchNorm module, covering consecutive channel ranges of the raw tensor (several groups = the raw tensor
+    is a channel concatenation of separately normalised maps).  Per group: `stats` fp32 [4C] = scale | shift | mean |
+    invstd (the layout of include/liso_bn.h) and the module's gamma / beta parameters, which receive their gradients
+    through the consumer's backward."""
 
-    def __init__(self, stats, gamma, beta, relu, training):
-        self.stats, self.gamma, self.beta, self.relu, self.training = stats, gamma, beta, bool(relu), bool(training)
+    def __init__(self, groups, relu=True, training=True):
+        self.groups, self.relu, self.training = list(groups), bool(relu), bool(training)
+        self._ss = None
 
     @property
     def channels(self):
-        return self.gamma.shape[0]
+        return sum(g["gamma"].shape[0] for g in self.groups)
+
+    def scale_shift(self):
+        if self._ss is None:
+            if len(self.groups) == 1:
+                st, C = self.groups[0]["stats"], self.groups[0]["gamma"].shape[0]
+                self._ss = (st[:C], st[C:2 * C])
+            else:
+                self._ss = (torch.cat([g["stats"][:g["gamma"].shape[0]] for g in self.groups]).contiguous(),
+                            torch.cat([g["stats"][g["gamma"].shape[0]:2 * g["gamma"].shape[0]] for g in self.groups]).contiguous())
+        return self._ss
+
+    def group(self, k):
+        return BnFold([self.groups[k]], self.relu, self.training)
+
+    @staticmethod
+    def cat(folds):
+        assert all(f.relu == folds[0].relu and f.training == folds[0].training for f in folds)
+        return BnFold([g for f in folds for g in f.groups], folds[0].relu, folds[0].training)
+
+    def params(self):
+        return [t for g in self.groups for t in (g["gamma"], g["beta"])]
 
 
-def finalize_bn(stats_partial, n_pixels, bn, stats_shift=None):
+def finalize_bn(stats_partial, n_pixels, bn, stats_shift=None, channel_offset=0):
     """per-block partial sums of a conv_forward(..., want_stats=True) -> BnFold of `bn` in training mode (batch statistics,
-    running statistics updated with the module's momentum, like torch.nn.BatchNorm2d.forward)"""
+    running statistics updated with the module's momentum, like torch.nn.BatchNorm2d.forward).  `channel_offset`: first
+    channel of this BatchNorm inside the convolution's output (several BatchNorms behind one merged convolution)."""
     C = bn.num_features
     stats = torch.empty(4 * C, dtype=torch.float32, device=stats_partial.device)
     rows, _, cop = stats_partial.shape
     mom = bn.momentum if bn.momentum is not None else 0.1
     track = bn.track_running_stats and bn.training
+    part = ctypes.c_void_p(stats_partial.data_ptr() + 4 * channel_offset)
     with torch.cuda.device(stats_partial.device):
         L.check(L.lib().liso_conv_bn_finalize(
-            L.ptr(stats_partial), rows, C, cop, int(n_pixels), L.ptr(stats_shift) if stats_shift is not None else None,
+            part, rows, C, cop, int(n_pixels), L.ptr(stats_shift) if stats_shift is not None else None,
             L.ptr(bn.weight), L.ptr(bn.bias), L.ptr(bn.running_mean) if track else None, L.ptr(bn.running_var) if track else None,
             float(mom), float(bn.eps), L.ptr(stats), L.stream_ptr()), "conv_bn_finalize")
-    return BnFold(stats, bn.weight, bn.bias, True, True)
+    return BnFold([{"stats": stats, "gamma": bn.weight, "beta": bn.bias}], True, True)
 
 
 def eval_bn_fold(bn, relu=True):
@@ -316,14 +359,15 @@ def eval_bn_fold(bn, relu=True):
         scale = bn.weight.detach().float() * invstd
         shift = bn.bias.detach().float() - bn.running_mean.float() * scale
         stats = torch.cat([scale, shift, bn.running_mean.float(), invstd]).contiguous()
-    return BnFold(stats, bn.weight, bn.bias, relu, False)
+    return BnFold([{"stats": stats, "gamma": bn.weight, "beta": bn.bias}], relu, False)
 
 
-def _bn_backward(g, x_raw, fold):
-    """gradient through relu?(bn(x_raw)) given g = dL/d(output): -> (dx_raw, dgamma, dbeta); g, x_raw logical NCHW"""
-    C = fold.channels
-    xv, _ = as_nhwc(x_raw, 1)
-    gv, _ = as_nhwc(g, 1)
+def _bn_backward_group(g, x_raw, grp, relu, training):
+    """gradient through relu?(bn(x_raw)) of ONE BatchNorm given g = dL/d(output): -> (dx_raw, dgamma, dbeta);
+    g, x_raw logical NCHW (channel slices are copied: the kernels of include/liso_bn.h take dense [M, C] rows)"""
+    C = grp["gamma"].shape[0]
+    xv = x_raw.permute(0, 2, 3, 1)
+    gv = g.permute(0, 2, 3, 1)
     if not xv.is_contiguous():
         xv = xv.contiguous()
     if gv.dtype != xv.dtype:
@@ -339,39 +383,52 @@ def _bn_backward(g, x_raw, fold):
     ws = torch.empty(nbytes, dtype=torch.uint8, device=xv.device)
     with torch.cuda.device(xv.device):
         L.check(L.TIMER.launch("bn_bwd", lambda: lib.liso_bn_relu_bwd(
-            L.ptr(gv), L.ptr(xv), int(xv.dtype == torch.bfloat16), M, C, L.ptr(fold.gamma), L.ptr(fold.stats), int(fold.training),
-            int(fold.relu), L.ptr(dx), L.ptr(gg), L.ptr(gb), L.ptr(ws), nbytes, L.stream_ptr()),
+            L.ptr(gv), L.ptr(xv), int(xv.dtype == torch.bfloat16), M, C, L.ptr(grp["gamma"]), L.ptr(grp["stats"]), int(training),
+            int(relu), L.ptr(dx), L.ptr(gg), L.ptr(gb), L.ptr(ws), nbytes, L.stream_ptr()),
             units=5 * M * C * xv.element_size()), "bn_relu_bwd")
     return dx.permute(0, 3, 1, 2), gg, gb
 
 
+def _bn_backward(g, x_raw, fold):
+    """-> (dx_raw logical NCHW, [dgamma0, dbeta0, dgamma1, dbeta1, ...])"""
+    if len(fold.groups) == 1:
+        dx, gg, gb = _bn_backward_group(g, x_raw, fold.groups[0], fold.relu, fold.training)
+        return dx, [gg, gb]
+    dxs, grads, a = [], [], 0
+    for grp in fold.groups:
+        C = grp["gamma"].shape[0]
+        dx, gg, gb = _bn_backward_group(g[:, a:a + C], x_raw[:, a:a + C], grp, fold.relu, fold.training)
+        dxs.append(dx)
+        grads += [gg, gb]
+        a += C
+    return torch.cat(dxs, dim=1), grads
+
+
 class _FusedConv(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x_raw, weight, bias, gamma, beta, meta):
-        """meta: dict(spec, fold (BnFold | None; its gamma / beta are the `gamma`, `beta` arguments), out_dtype, want_stats,
-        stats_shift, out_relu); the partial statistics are returned through meta['stats_partial']"""
+    def forward(ctx, x_raw, weight, bias, meta, *fold_params):
+        """meta: dict(spec, fold (BnFold | None; `fold_params` = its gamma / beta tensors, passed so that autograd routes
+        their gradients), out_dtype, want_stats, stats_shift, out_relu); the partial statistics are handed back through
+        meta['stats_partial']"""
         spec, fold = meta["spec"], meta["fold"]
-        C = x_raw.shape[1]
-        sc = fold.stats[:C] if fold is not None else None
-        sh = fold.stats[C:2 * C] if fold is not None else None
+        sc, sh = fold.scale_shift() if fold is not None else (None, None)
         y, part = conv_forward(x_raw, weight, bias, spec, sc, sh, in_relu=fold.relu if fold is not None else False,
                                out_relu=meta.get("out_relu", False), out_dtype=meta.get("out_dtype"),
                                want_stats=meta.get("want_stats", False), stats_shift=meta.get("stats_shift"))
         meta["stats_partial"] = part
         ctx.save_for_backward(x_raw, weight)
-        ctx.meta = {"spec": spec, "fold": fold, "has_bias": bias is not None}
+        ctx.meta = {"spec": spec, "fold": fold, "has_bias": bias is not None, "n_fold_params": len(fold_params)}
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x_raw, weight = ctx.saved_tensors
         spec, fold = ctx.meta["spec"], ctx.meta["fold"]
-        C = x_raw.shape[1]
         if dy.dtype != x_raw.dtype:
             dy = dy.to(x_raw.dtype)
-        sc = fold.stats[:C] if fold is not None else None
-        sh = fold.stats[C:2 * C] if fold is not None else None
-        dw = db = dx = dgamma = dbeta = None
+        sc, sh = fold.scale_shift() if fold is not None else (None, None)
+        dw = db = dx = None
+        fold_grads = [None] * ctx.meta["n_fold_params"]
         if ctx.needs_input_grad[1] or (ctx.meta["has_bias"] and ctx.needs_input_grad[2]):
             res = conv_wgrad(x_raw, dy, tuple(weight.shape), spec, sc, sh, in_relu=fold.relu if fold is not None else False,
                              want_bias=ctx.meta["has_bias"])
@@ -382,21 +439,22 @@ class _FusedConv(torch.autograd.Function):
             dw = dw.to(weight.dtype)
             if db is not None:
                 db = db.to(weight.dtype)
-        if ctx.needs_input_grad[0] or (fold is not None and fold.gamma.requires_grad):
+        if ctx.needs_input_grad[0] or any(ctx.needs_input_grad[4:]):
             g = conv_dgrad(dy, weight, spec, tuple(x_raw.shape))
             if fold is not None:
-                dx, dgamma, dbeta = _bn_backward(g, x_raw, fold)
+                dx, fold_grads = _bn_backward(g, x_raw, fold)
             else:
                 dx = g
-        return dx, dw, db, dgamma, dbeta, None
+        return (dx, dw, db, None, *fold_grads)
 
 
 def _aten_wgrad(x_raw, dy, weight, spec, fold, has_bias):
-    """weight gradient through ATen for the few geometries the own kernel does not cover (large halos)"""
+    """weight gradient through ATen for geometries the own kernel does not cover (none of the networks' layers)"""
     x = x_raw
     if fold is not None:
+        sc, sh = fold.scale_shift()
         C = x_raw.shape[1]
-        x = x_raw.float() * fold.stats[:C].view(1, C, 1, 1) + fold.stats[C:2 * C].view(1, C, 1, 1)
+        x = x_raw.float() * sc.view(1, C, 1, 1) + sh.view(1, C, 1, 1)
         x = torch.relu(x) if fold.relu else x
         x = x.to(x_raw.dtype)
     s, p = [spec.stride, spec.stride], [spec.padding, spec.padding]
@@ -407,23 +465,62 @@ def _aten_wgrad(x_raw, dy, weight, spec, fold, has_bias):
 
 
 def fused_conv(x_raw, fold, conv, out_bn=None, out_dtype=None, out_relu=False, spec=None):
-    """y_raw = conv(relu?(bn(x_raw))) (+ bias).  `fold`: BnFold pending on x_raw or None.  `out_bn`: the BatchNorm2d that
-    follows this convolution -> returns (y_raw, BnFold of out_bn) (training: batch statistics from the convolution's
-    epilogue; eval: running statistics); without it returns (y_raw, None)."""
-    spec = spec or ConvSpec.of(conv)
-    training_bn = out_bn is not None and (out_bn.training or not out_bn.track_running_stats)
+    """y_raw = conv(relu?(bn(x_raw))) (+ bias).  `fold`: BnFold pending on x_raw or None.  `conv`: one nn.Conv2d /
+    nn.ConvTranspose2d, or a list of nn.Conv2d with the same geometry and input (run as ONE convolution with the filters
+    concatenated along the output channels).  `out_bn`: the BatchNorm2d (list: one per convolution of the list) that follows
+    -> returns (y_raw, BnFold) (training: batch statistics from the convolution's epilogue; eval: running statistics);
+    without it returns (y_raw, None)."""
+    convs = list(conv) if isinstance(conv, (list, tuple)) else [conv]
+    bns = (list(out_bn) if isinstance(out_bn, (list, tuple)) else [out_bn]) if out_bn is not None else None
+    spec = spec or ConvSpec.of(convs[0])
+    if len(convs) == 1:
+        weight, bias = convs[0].weight, convs[0].bias
+    else:
+        weight = torch.cat([c.weight for c in convs], dim=0)
+        bias = torch.cat([c.bias for c in convs], dim=0) if convs[0].bias is not None else None
+    training_bn = bns is not None and (bns[0].training or not bns[0].track_running_stats)
     meta = {"spec": spec, "fold": fold, "out_dtype": out_dtype, "want_stats": training_bn, "out_relu": out_relu}
-    if training_bn and out_bn.track_running_stats:
-        meta["stats_shift"] = out_bn.running_mean  # any per-channel constant close to the mean keeps the sums well conditioned
-    gamma = fold.gamma if fold is not None else None
-    beta = fold.beta if fold is not None else None
-    y = _FusedConv.apply(x_raw, conv.weight, conv.bias, gamma, beta, meta)
-    if out_bn is None:
+    if training_bn and len(bns) == 1 and bns[0].track_running_stats:
+        # any per-channel constant close to the mean keeps the sums well conditioned: the running mean.  (The finalize kernel
+        # reads stats_shift[c] before the same thread updates running_mean[c]: passing the live buffer is safe.)
+        meta["stats_shift"] = bns[0].running_mean
+    params = fold.params() if fold is not None else []
+    y = _FusedConv.apply(x_raw, weight, bias, meta, *params)
+    if bns is None:
         return y, None
-    if training_bn:
-        n = y.shape[0] * y.shape[2] * y.shape[3]
-        if out_bn.training and out_bn.track_running_stats and not getattr(out_bn, "_liso_counter_deferred", False):
-            out_bn.num_batches_tracked += 1
-        # (the finalize kernel reads stats_shift[c] before the same thread writes running_mean[c]: passing the live buffer is safe)
-        return y, finalize_bn(meta["stats_partial"], n, out_bn, meta.get("stats_shift"))
-    return y, eval_bn_fold(out_bn, relu=True)
+    if not training_bn:
+        return y, BnFold.cat([eval_bn_fold(b, relu=True) for b in bns])
+    n = y.shape[0] * y.shape[2] * y.shape[3]
+    folds, off = [], 0
+    for b in bns:
+        if b.training and b.track_running_stats and not getattr(b, "_liso_counter_deferred", False):
+            b.num_batches_tracked += 1
+        folds.append(finalize_bn(meta["stats_partial"], n, b, meta.get("stats_shift"), channel_offset=off))
+        off += b.num_features
+    return y, BnFold.cat(folds)
+
+
+class _Materialize(torch.autograd.Function):
+    """relu?(bn(x_raw)) as a tensor, for consumers that are not convolutions (API parity: RPN.forward returns a tensor)"""
+
+    @staticmethod
+    def forward(ctx, x_raw, fold, *params):
+        sc, sh = fold.scale_shift()
+        C = x_raw.shape[1]
+        y = x_raw.float() * sc.view(1, C, 1, 1) + sh.view(1, C, 1, 1)
+        y = torch.relu(y) if fold.relu else y
+        ctx.save_for_backward(x_raw)
+        ctx.fold = fold
+        return y.to(x_raw.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x_raw,) = ctx.saved_tensors
+        dx, grads = _bn_backward(g, x_raw, ctx.fold)
+        return (dx, None, *grads)
+
+
+def materialize(x_raw, fold):
+    if fold is None:
+        return x_raw
+    return _Materialize.apply(x_raw, fold, *fold.params())

@@ -124,9 +124,10 @@ def test_prologue_epilogue_statistics_and_channel_slices(dtype):
     fold = MC.finalize_bn(part, B * y.shape[2] * y.shape[3], bn, shift_stat)
     yf = y.float()
     mean, var = yf.mean(dim=(0, 2, 3)), yf.var(dim=(0, 2, 3), unbiased=False)
-    assert _rel(fold.stats[2 * Co:3 * Co], mean) <= 1e-4
-    assert _rel(fold.stats[3 * Co:], torch.rsqrt(var + bn.eps)) <= 1e-4
-    assert _rel(fold.stats[:Co], bn.weight * torch.rsqrt(var + bn.eps)) <= 1e-4
+    st = fold.groups[0]["stats"]
+    assert _rel(st[2 * Co:3 * Co], mean) <= 1e-4
+    assert _rel(st[3 * Co:], torch.rsqrt(var + bn.eps)) <= 1e-4
+    assert _rel(st[:Co], bn.weight * torch.rsqrt(var + bn.eps)) <= 1e-4
     n = B * y.shape[2] * y.shape[3]
     assert _rel(bn.running_mean, 0.9 * shift_stat + 0.1 * mean) <= 1e-4
     assert _rel(bn.running_var, 0.9 * torch.ones_like(var) + 0.1 * var * n / (n - 1)) <= 1e-4
