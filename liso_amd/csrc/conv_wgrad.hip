@@ -125,6 +125,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(const liso_conv
         const int b = tt / a.tiles_y;
         const int iy0 = ty * TH * d.isy + dy0, ix0 = tx * TW * d.isx + dx0;
         const long x_img = (long)b * d.hi * d.wi;
+        const long y_img = (long)b * d.ho * d.wo * a.dy_pix_stride;
         __syncthreads();
         // ---- stage x' (halo tile, 64 channels) --------------------------------------------------------------------------
         if constexpr (!X3) {
@@ -140,18 +141,25 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(const liso_conv
                     sh[e] = ch_ok ? a.in_shift[ch + e] : 0.0f;
                 }
             }
-            const unsigned short* xg = (const unsigned short*)a.x;
+            const unsigned short* xg = (const unsigned short*)a.x + x_img * d.x_pix_stride;
+            int ly = (int)(((float)p0 + 0.5f) * inv_w);
+            int lx = p0 - ly * in_w;
+            const int step_y = pstep / in_w, step_x = pstep - step_y * in_w;  // (uniform)
             for (int pix0 = p0; pix0 < npix; pix0 += XB * pstep) {
                 uint4 v[XB];
                 bool ok[XB];
 #pragma unroll
                 for (int u = 0; u < XB; u++) {
                     const int pix = pix0 + u * pstep;
-                    const int ly = (int)(((float)pix + 0.5f) * inv_w);
-                    const int lx = pix - ly * in_w;
                     const int iy = iy0 + ly, ix = ix0 + lx;
-                    ok[u] = pix < npix && ch_ok && iy >= 0 && iy < d.hi && ix >= 0 && ix < d.wi;
-                    const long off = ok[u] ? ((x_img + (long)iy * d.wi + ix) * d.x_pix_stride + ch) : 0;
+                    ok[u] = pix < npix && ch_ok && (unsigned)iy < (unsigned)d.hi && (unsigned)ix < (unsigned)d.wi;
+                    const int off = ok[u] ? (iy * d.wi + ix) * d.x_pix_stride + ch : 0;  // (a sample has < 2^31 elements)
+                    lx += step_x;
+                    ly += step_y;
+                    if (lx >= in_w) {
+                        lx -= in_w;
+                        ly++;
+                    }
                     v[u] = *reinterpret_cast<const uint4*>(xg + off);
                 }
 #pragma unroll
@@ -186,8 +194,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(const liso_conv
                 const int vy = ty * TH + (m >> 5), vx = tx * TW + (m & 31);
                 const int oy = vy * d.osy + ooy, ox = vx * d.osx + oox;
                 const bool ok = chy_ok && vy < d.hv && vx < d.wv && oy < d.ho && ox < d.wo;
-                const long off = ok ? ((((long)b * d.ho + oy) * d.wo + ox) * a.dy_pix_stride + chy) : 0;
-                uint4 v = *reinterpret_cast<const uint4*>(yg + off);
+                const int off = ok ? (oy * d.wo + ox) * a.dy_pix_stride + chy : 0;
+                uint4 v = *reinterpret_cast<const uint4*>(yg + y_img + off);
                 if (!ok) v = make_uint4(0u, 0u, 0u, 0u);
                 *reinterpret_cast<uint4*>(ys + m * PSY + c8 * 16) = v;
                 if (want_bias) {
@@ -212,19 +220,26 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(const liso_conv
                     sh[e] = ch_ok ? a.in_shift[ch + e] : 0.0f;
                 }
             }
-            const float* xg = (const float*)a.x;
+            const float* xg = (const float*)a.x + x_img * d.x_pix_stride;
             unsigned char* xs_lo = xs + a.x_plane_bytes;
+            int ly = (int)(((float)p0 + 0.5f) * inv_w);
+            int lx = p0 - ly * in_w;
+            const int step_y = pstep / in_w, step_x = pstep - step_y * in_w;  // (uniform)
             for (int pix0 = p0; pix0 < npix; pix0 += XB * pstep) {
                 float4 v[XB];
                 bool ok[XB];
 #pragma unroll
                 for (int u = 0; u < XB; u++) {
                     const int pix = pix0 + u * pstep;
-                    const int ly = (int)(((float)pix + 0.5f) * inv_w);
-                    const int lx = pix - ly * in_w;
                     const int iy = iy0 + ly, ix = ix0 + lx;
-                    ok[u] = pix < npix && ch_ok && iy >= 0 && iy < d.hi && ix >= 0 && ix < d.wi;
-                    const long off = ok[u] ? ((x_img + (long)iy * d.wi + ix) * d.x_pix_stride + ch) : 0;
+                    ok[u] = pix < npix && ch_ok && (unsigned)iy < (unsigned)d.hi && (unsigned)ix < (unsigned)d.wi;
+                    const int off = ok[u] ? (iy * d.wi + ix) * d.x_pix_stride + ch : 0;  // (a sample has < 2^31 elements)
+                    lx += step_x;
+                    ly += step_y;
+                    if (lx >= in_w) {
+                        lx -= in_w;
+                        ly++;
+                    }
                     v[u] = *reinterpret_cast<const float4*>(xg + off);
                 }
 #pragma unroll
@@ -259,8 +274,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(const liso_conv
                 const int vy = ty * TH + (m >> 5), vx = tx * TW + (m & 31);
                 const int oy = vy * d.osy + ooy, ox = vx * d.osx + oox;
                 const bool ok = chy_ok && vy < d.hv && vx < d.wv && oy < d.ho && ox < d.wo;
-                const long off = ok ? ((((long)b * d.ho + oy) * d.wo + ox) * a.dy_pix_stride + chy) : 0;
-                float4 v = *reinterpret_cast<const float4*>(yg + off);
+                const int off = ok ? (oy * d.wo + ox) * a.dy_pix_stride + chy : 0;
+                float4 v = *reinterpret_cast<const float4*>(yg + y_img + off);
                 float f[4] = {v.x, v.y, v.z, v.w};
                 unsigned hi2[2], lo2[2];
 #pragma unroll

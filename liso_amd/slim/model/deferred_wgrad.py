@@ -29,9 +29,19 @@ class _State:
         self.index = {tuple(id(m) for m in op): i for i, op in enumerate(ops)}
         self.stash = [[] for _ in ops]
         self.merged = {}  # op index -> (weight, bias) concatenated once per step
+        self.packs = {}
         self.token = None
         self.direct_accumulate = False
         self.params = []
+
+    def packed(self, li, for_dgrad, dtype):
+        """the kernels' packed panels of op `li` (weights are constant while the state lives: one pack per step and use)"""
+        from liso_amd.utils import mfma_conv as MC
+
+        key = (li, bool(for_dgrad), dtype)
+        if key not in self.packs:
+            self.packs[key] = MC.pack_weights(self.weights(li)[0], MC.ConvSpec.of(self.layers[li]), for_dgrad, MC._mode(dtype))
+        return self.packs[key]
 
     def weights(self, li):
         op = self.ops[li]
@@ -70,8 +80,16 @@ class _ParamGate(torch.autograd.Function):
             w, b = st.weights(li)
             x = items[0][0] if len(items) == 1 else torch.cat([i[0] for i in items], dim=0)
             gy = items[0][1] if len(items) == 1 else torch.cat([i[1] for i in items], dim=0)
-            _, gw, gb = torch.ops.aten.convolution_backward(gy, x, w, [b.numel()], _pair(layer.stride), _pair(layer.padding),
-                                                            _pair(layer.dilation), False, [0, 0], 1, [False, True, True])
+            res = None
+            if _own_kernels(x, w, layer):  # ONE weight-gradient launch over the stacked iterations (split over pixels)
+                from liso_amd.utils import mfma_conv as MC
+
+                res = MC.conv_wgrad(x, gy, tuple(w.shape), MC.ConvSpec.of(layer), want_bias=True)
+            if res is not None:
+                gw, gb = res
+            else:
+                _, gw, gb = torch.ops.aten.convolution_backward(gy, x, w, [b.numel()], _pair(layer.stride), _pair(layer.padding),
+                                                                _pair(layer.dilation), False, [0, 0], 1, [False, True, True])
             if len(op) == 1:
                 grads += [gw, gb]
             else:
@@ -79,6 +97,7 @@ class _ParamGate(torch.autograd.Function):
                 for gwi, gbi in zip(torch.split(gw, sizes, dim=0), torch.split(gb, sizes, dim=0)):
                     grads += [gwi, gbi]
         st.merged.clear()
+        st.packs.clear()
         if st.direct_accumulate:
             # hipGraph capture: add into the (pre-existing) .grad buffers here, on the capturing stream.  Handing the gradients
             # to autograd's AccumulateGrad nodes would run them on the stream those nodes were created on (the warm-up's), a
@@ -93,29 +112,50 @@ class _ParamGate(torch.autograd.Function):
         return (None, *grads)
 
 
+def _own_kernels(x, w, layer):
+    from liso_amd.utils import mfma_conv as MC
+
+    return x.is_cuda and MC.backend() == "mfma" and MC.supported(x, w, MC.ConvSpec.of(layer))
+
+
 class _ConvDeferred(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, token, w, b, state, li):
+    def forward(ctx, x, token, w, b, state, li, relu):
         layer = state.layers[li]
-        ctx.state, ctx.li = state, li
-        ctx.save_for_backward(x, w)
+        ctx.state, ctx.li, ctx.relu = state, li, bool(relu)
+        ctx.own = _own_kernels(x, w, layer)
         ctx.set_materialize_grads(False)
-        return F.conv2d(x, w, b, layer.stride, layer.padding, layer.dilation), token.view_as(token)  # alias: no launch
+        if ctx.own:
+            from liso_amd.utils import mfma_conv as MC
+
+            y, _ = MC.conv_forward(x, w, b, MC.ConvSpec.of(layer), out_relu=ctx.relu, packed=state.packed(li, False, x.dtype))
+        else:
+            y = F.conv2d(x, w, b, layer.stride, layer.padding, layer.dilation)
+            y = torch.relu(y) if ctx.relu else y
+        ctx.save_for_backward(x, w, y if ctx.relu else None)
+        return y, token.view_as(token)  # alias: no launch
 
     @staticmethod
     def backward(ctx, gy, token_grad):
-        x, w = ctx.saved_tensors
+        x, w, y = ctx.saved_tensors
         st, li = ctx.state, ctx.li
         layer = st.layers[li]
         gx = None
         if gy is not None:
+            if ctx.relu:
+                gy = torch.where(y > 0, gy, torch.zeros((), dtype=gy.dtype, device=gy.device))
             if ctx.needs_input_grad[0]:
-                gx = torch.ops.aten.convolution_backward(gy, x, w, None, _pair(layer.stride), _pair(layer.padding),
-                                                         _pair(layer.dilation), False, [0, 0], 1, [True, False, False])[0]
+                if ctx.own:
+                    from liso_amd.utils import mfma_conv as MC
+
+                    gx = MC.conv_dgrad(gy, w, MC.ConvSpec.of(layer), tuple(x.shape), packed=st.packed(li, True, gy.dtype))
+                else:
+                    gx = torch.ops.aten.convolution_backward(gy, x, w, None, _pair(layer.stride), _pair(layer.padding),
+                                                             _pair(layer.dilation), False, [0, 0], 1, [True, False, False])[0]
             st.stash[li].append((x, gy))
         if token_grad is None:  # the last convolution of the chain: nothing consumed its token
             token_grad = st.zero
-        return gx, token_grad, None, None, None, None
+        return gx, token_grad, None, None, None, None, None
 
 
 @contextlib.contextmanager
@@ -146,12 +186,15 @@ def deferred_weight_gradients(module: nn.Module, enabled=True, direct_accumulate
         _ACTIVE = None
 
 
-def conv2d(layer: nn.Conv2d, x):
+def conv2d(layer: nn.Conv2d, x, relu=False):
+    """relu?(layer(x)); inside `deferred_weight_gradients` the weight gradient is deferred to the end of the backward pass"""
     st = _ACTIVE
     if st is None or (id(layer),) not in st.index:
-        return layer(x)
+        from liso_amd.utils import mfma_conv as MC
+
+        return MC.conv2d(layer, x, relu)
     li = st.index[(id(layer),)]
-    y, st.token = _ConvDeferred.apply(x, st.token, *st.weights(li), st, li)
+    y, st.token = _ConvDeferred.apply(x, st.token, *st.weights(li), st, li, relu)
     return y
 
 
@@ -160,9 +203,13 @@ def conv2d_pair(layer_a: nn.Conv2d, layer_b: nn.Conv2d, x):
     st = _ACTIVE
     key = (id(layer_a), id(layer_b))
     if st is None or key not in st.index:
+        from liso_amd.utils import mfma_conv as MC
+
+        if x.is_cuda and MC.backend() == "mfma" and MC.supported(x, layer_a.weight, MC.ConvSpec.of(layer_a)):
+            return MC.fused_conv(x, None, [layer_a, layer_b])[0]
         w = torch.cat([layer_a.weight, layer_b.weight], dim=0)
         b = torch.cat([layer_a.bias, layer_b.bias], dim=0)
         return F.conv2d(x, w, b, layer_a.stride, layer_a.padding, layer_a.dilation)
     li = st.index[key]
-    y, st.token = _ConvDeferred.apply(x, st.token, *st.weights(li), st, li)
+    y, st.token = _ConvDeferred.apply(x, st.token, *st.weights(li), st, li, False)
     return y

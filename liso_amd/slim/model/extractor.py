@@ -4,6 +4,8 @@ are not used by SLIM's RAFT and are out of scope."""
 import torch
 import torch.nn as nn
 
+from liso_amd.utils.mfma_conv import conv2d
+
 
 def _norm(norm_fn, ch, groups=None):
     if norm_fn == "group":
@@ -35,10 +37,16 @@ class ResidualBlock(nn.Module):
             self.downsample = None
 
     def forward(self, x):
-        y = self.relu(self.norm1(self.conv1(x)))
-        y = self.relu(self.norm2(self.conv2(y)))
+        """reference :29-38.  Convolutions on the own MFMA kernels (liso_amd/utils/mfma_conv.py); where no normalisation
+        sits between a convolution and its ReLU (cnet: norm_fn "none") the ReLU runs in the convolution's epilogue."""
+        bare = isinstance(self.norm1, nn.Sequential) and len(self.norm1) == 0
+        if bare:
+            y = conv2d(self.conv2, conv2d(self.conv1, x, relu=True), relu=True)
+        else:
+            y = self.relu(self.norm1(conv2d(self.conv1, x)))
+            y = self.relu(self.norm2(conv2d(self.conv2, y)))
         if self.downsample is not None:
-            x = self.downsample(x)
+            x = self.downsample[1](conv2d(self.downsample[0], x))
         return self.relu(x + y)
 
 
@@ -69,9 +77,12 @@ class SmallEncoder(nn.Module):
         if is_list:
             batch_dim = x[0].shape[0]
             x = torch.cat(x, dim=0)
-        x = self.relu1(self.norm1(self.conv1(x)))
+        if isinstance(self.norm1, nn.Sequential) and len(self.norm1) == 0:
+            x = conv2d(self.conv1, x, relu=True)
+        else:
+            x = self.relu1(self.norm1(conv2d(self.conv1, x)))
         x = self.layer3(self.layer2(self.layer1(x)))
-        x = self.conv2(x)
+        x = conv2d(self.conv2, x)
         if self.training and self.dropout is not None:
             x = self.dropout(x)
         if is_list:

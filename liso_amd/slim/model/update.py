@@ -17,7 +17,7 @@ class FlowOrClassificationHead(nn.Module):
         self.relu = nn.ReLU(inplace=True)
 
     def forward(self, inputs):
-        return conv2d(self.conv2, self.relu(conv2d(self.conv1, inputs)))
+        return conv2d(self.conv2, conv2d(self.conv1, inputs, relu=True))
 
 
 class ConvGRU(nn.Module):
@@ -59,15 +59,15 @@ class SmallMotionEncoder(nn.Module):
 
     def forward(self, flow, corr, logits):
         """reference :74-96"""
-        corr = F.relu(conv2d(self.conv_stat_corr1, corr))
-        flow = F.relu(conv2d(self.conv_flow2, F.relu(conv2d(self.conv_flow1, flow))))
+        corr = conv2d(self.conv_stat_corr1, corr, relu=True)
+        flow = conv2d(self.conv_flow2, conv2d(self.conv_flow1, flow, relu=True), relu=True)
         vals = [corr, flow]
         if self.predict_logits:
-            logits = F.relu(conv2d(self.conv_class2, F.relu(conv2d(self.conv_class1, logits))))
+            logits = conv2d(self.conv_class2, conv2d(self.conv_class1, logits, relu=True), relu=True)
             vals.append(logits)
         else:
             assert logits is None
-        out = F.relu(conv2d(self.conv, torch.cat(vals, dim=1)))
+        out = conv2d(self.conv, torch.cat(vals, dim=1), relu=True)
         if self.predict_logits:
             return torch.cat([out, logits, flow], dim=1)
         return torch.cat([out, flow], dim=1)

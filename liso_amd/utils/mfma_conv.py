@@ -13,6 +13,7 @@ and optionally emits the per-block partial sums from which `finalize_bn` derives
 """
 import ctypes
 import os
+import weakref
 
 import torch
 
@@ -143,9 +144,27 @@ def as_nhwc(t, vec):
     return v, ps
 
 
+_PACK_CACHE = {}
+
+
 def pack_weights(weight, spec, for_dgrad, mode):
-    """torch-layout fp32 master weights -> the kernels' packed bf16 panels (one launch)"""
+    """torch-layout fp32 master weights -> the kernels' packed bf16 panels (one launch).  The result is cached per weight
+    tensor until the tensor is modified in place (`_version`: optimizer steps bump it), so frozen networks pack once and
+    the forward / backward of one training step share the panels of a layer."""
     L.require_cuda(weight)
+    if not isinstance(weight, torch.nn.Parameter):  # (temporaries: their storage is recycled, no stable identity)
+        return _pack_weights(weight, spec, for_dgrad, mode)
+    key = (id(weight), spec.transposed, bool(for_dgrad), mode)
+    hit = _PACK_CACHE.get(key)
+    if hit is not None and hit[0]() is weight and hit[1] == weight._version and hit[2] == weight.data_ptr():
+        return hit[3]
+    out = _pack_weights(weight, spec, for_dgrad, mode)
+    # the entry dies with the Parameter object (a recycled id() can therefore never hit a stale panel)
+    _PACK_CACHE[key] = (weakref.ref(weight, lambda _r, k=key: _PACK_CACHE.pop(k, None)), weight._version, weight.data_ptr(), out)
+    return out
+
+
+def _pack_weights(weight, spec, for_dgrad, mode):
     w = weight.detach()
     if w.dtype != torch.float32 or not w.is_contiguous():
         w = w.float().contiguous()
@@ -223,10 +242,12 @@ def _pad_out_channels(dy, weight, spec, vec):
     return dy, weight
 
 
-def conv_dgrad(dy, weight, spec, x_shape, out_dtype=None):
+def conv_dgrad(dy, weight, spec, x_shape, out_dtype=None, packed=None):
     """dy: logical [B,Co,Ho,Wo] -> dx logical [B,Ci,Hi,Wi] (gradient w.r.t. the convolution's INPUT x')"""
     L.require_cuda(dy, weight)
     mode = _mode(dy.dtype)
+    if dy.shape[1] % _vec(mode):
+        packed = None
     dy, weight = _pad_out_channels(dy, weight, spec, _vec(mode))
     gv, gps = as_nhwc(dy, _vec(mode))
     B, ho, wo, co = gv.shape
@@ -239,7 +260,8 @@ def conv_dgrad(dy, weight, spec, x_shape, out_dtype=None):
     if not spec.transposed and ((hi + 2 * spec.padding - spec.kh) % spec.stride or (wi + 2 * spec.padding - spec.kw) % spec.stride):
         alloc = torch.zeros  # trailing input rows / columns no output window covers: gradient 0
     dx = alloc((B, hi, wi, ci), dtype=out_dtype, device=dy.device)
-    packed = pack_weights(weight, spec, True, mode)
+    if packed is None:
+        packed = pack_weights(weight, spec, True, mode)
     with torch.cuda.device(dy.device):
         L.check(L.TIMER.launch(_timer_name(mode, "dgrad"), lambda: L.lib().liso_conv_forward(
             ctypes.byref(d), L.ptr(gv), L.ptr(packed), None, None, None, L.ptr(dx), None, None, L.stream_ptr()), units=_flops(d)),
@@ -416,16 +438,19 @@ class _FusedConv(torch.autograd.Function):
                                out_relu=meta.get("out_relu", False), out_dtype=meta.get("out_dtype"),
                                want_stats=meta.get("want_stats", False), stats_shift=meta.get("stats_shift"))
         meta["stats_partial"] = part
-        ctx.save_for_backward(x_raw, weight)
-        ctx.meta = {"spec": spec, "fold": fold, "has_bias": bias is not None, "n_fold_params": len(fold_params)}
+        relu = bool(meta.get("out_relu", False))
+        ctx.save_for_backward(x_raw, weight, y if relu else None)
+        ctx.meta = {"spec": spec, "fold": fold, "has_bias": bias is not None, "n_fold_params": len(fold_params), "relu": relu}
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x_raw, weight = ctx.saved_tensors
+        x_raw, weight, y = ctx.saved_tensors
         spec, fold = ctx.meta["spec"], ctx.meta["fold"]
         if dy.dtype != x_raw.dtype:
             dy = dy.to(x_raw.dtype)
+        if ctx.meta["relu"]:  # the ReLU ran in the convolution's epilogue: its mask is the sign of the stored output
+            dy = torch.where(y > 0, dy, torch.zeros((), dtype=dy.dtype, device=dy.device))
         sc, sh = fold.scale_shift() if fold is not None else (None, None)
         dw = db = dx = None
         fold_grads = [None] * ctx.meta["n_fold_params"]
@@ -524,3 +549,13 @@ def materialize(x_raw, fold):
     if fold is None:
         return x_raw
     return _Materialize.apply(x_raw, fold, *fold.params())
+
+
+def conv2d(layer, x, relu=False):
+    """relu?(layer(x)) for an nn.Conv2d / nn.ConvTranspose2d on the own kernels (torch's convolution when the geometry or the
+    device is not covered: CPU tensors in host-logic tests, 2-3 input channels)"""
+    spec = ConvSpec.of(layer)
+    if x.is_cuda and backend() == "mfma" and supported(x, layer.weight, spec):
+        return fused_conv(x, None, layer, out_relu=relu, spec=spec)[0]
+    y = layer(x)
+    return torch.relu(y) if relu else y
