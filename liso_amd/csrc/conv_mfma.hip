@@ -24,6 +24,7 @@
 // DPP (quad_perm 1,0,3,2), so every lane stores 2 adjacent channels of one pixel (4 B; 64-B runs per pixel).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/liso_conv.h"
 #include "../../include/liso_iou3d.h"
@@ -51,6 +52,7 @@ struct FwdArgs {
     int cls_inh[LISO_CONV_MAX_CLASSES], cls_inw[LISO_CONV_MAX_CLASSES];
     int tiles_x, tiles_y, n_nt, total;
     int x_plane_bytes;  // LDS bytes of one plane of the input tile (max over classes), multiple of 16
+    int pipelined;      // one register batch holds a whole slab: loads of slab k+1 overlap the MFMAs of slab k
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int total) {
@@ -137,201 +139,201 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(const liso_conv
     const unsigned short* wg = (const unsigned short*)a.w;
     const long plane_elems = (long)d.w_taps * kgroups_total * a.co_pad * 8;
 
-    for (int c0 = 0; c0 < d.ci; c0 += CS) {
-        __syncthreads();  // every read of the previous slab's tile / panels is done (and the tap tables are written)
-        // ---- stage the input halo tile --------------------------------------------------------------------------------
-        if constexpr (!X3) {
-            constexpr int CPP = K8;  // 16-B chunks (8 bf16) per pixel
-            const int c8 = tid % CPP, p0 = tid / CPP;
-            constexpr int pstep = kThreads / CPP;
-            const int ch = c0 + c8 * 8;
-            const bool ch_ok = ch < d.ci;
-            float sc[8], sh[8];
-            const bool pro = a.in_scale != nullptr;
-            if (pro) {
+    // ---- staging pieces: global -> registers (load_*) and registers -> LDS (store_*), so that the loads of slab k+1 can be
+    // in flight while the MFMAs of slab k run ---------------------------------------------------------------------------------
+    constexpr int CPP = X3 ? CS / 4 : K8;  // 16-B chunks per pixel on the global side (4 fp32 | 8 bf16)
+    constexpr int CHN = X3 ? 4 : 8;        // channels per chunk
+    constexpr int pstep = kThreads / CPP;
+    constexpr int XB = 12, WB = 10;        // 16-B loads per thread and batch
+    const int cx = tid % CPP, p0 = tid / CPP;
+    const int step_y = pstep / in_w, step_x = pstep - step_y * in_w;  // (uniform)
+    const unsigned char* xbase = (const unsigned char*)a.x + x_img * d.x_pix_stride * (X3 ? 4 : 2);
+    const bool pro = a.in_scale != nullptr;
+
+    auto load_x = [&](int c0, int pix_begin, uint4 (&v)[XB], unsigned& okmask) {
+        const int ch = c0 + cx * CHN;
+        const bool ch_ok = ch < d.ci;
+        const int pfirst = pix_begin + p0;
+        int ly = (int)(((float)pfirst + 0.5f) * inv_w);
+        int lx = pfirst - ly * in_w;
+        okmask = 0u;
 #pragma unroll
-                for (int e = 0; e < 8; e++) {
-                    sc[e] = ch_ok ? a.in_scale[ch + e] : 0.0f;
-                    sh[e] = ch_ok ? a.in_shift[ch + e] : 0.0f;
-                }
-            }
-            const unsigned short* xg = (const unsigned short*)a.x + x_img * d.x_pix_stride;
-            constexpr int XB = 12;  // 16-B loads in flight per thread: the whole tile of the usual geometries in one batch
-            int ly = (int)(((float)p0 + 0.5f) * inv_w);
-            int lx = p0 - ly * in_w;
-            const int step_y = pstep / in_w, step_x = pstep - step_y * in_w;  // (uniform)
-            for (int pix0 = p0; pix0 < npix; pix0 += XB * pstep) {
-                uint4 v[XB];
-                bool ok[XB];
-#pragma unroll
-                for (int u = 0; u < XB; u++) {
-                    const int pix = pix0 + u * pstep;
-                    const int iy = iy0 + ly, ix = ix0 + lx;
-                    ok[u] = pix < npix && ch_ok && (unsigned)iy < (unsigned)d.hi && (unsigned)ix < (unsigned)d.wi;
-                    const int off = ok[u] ? (iy * d.wi + ix) * d.x_pix_stride + ch : 0;  // (a sample has < 2^31 elements)
-                    lx += step_x;
-                    ly += step_y;
-                    if (lx >= in_w) {
-                        lx -= in_w;
-                        ly++;
-                    }
-                    v[u] = *reinterpret_cast<const uint4*>(xg + off);
-                }
-#pragma unroll
-                for (int u = 0; u < XB; u++) {
-                    const int pix = pix0 + u * pstep;
-                    if (pix >= npix) continue;
-                    uint4 o = v[u];
-                    if (pro) {
-                        unsigned w[4] = {o.x, o.y, o.z, o.w};
-#pragma unroll
-                        for (int e = 0; e < 4; e++) {
-                            float f0 = fmaf(bf16_lo(w[e]), sc[2 * e], sh[2 * e]);
-                            float f1 = fmaf(bf16_hi(w[e]), sc[2 * e + 1], sh[2 * e + 1]);
-                            if (d.in_relu) {
-                                f0 = fmaxf(f0, 0.0f);
-                                f1 = fmaxf(f1, 0.0f);
-                            }
-                            w[e] = pack_bf16(f0, f1);
-                        }
-                        o = make_uint4(w[0], w[1], w[2], w[3]);
-                    }
-                    if (!ok[u]) o = make_uint4(0u, 0u, 0u, 0u);
-                    *reinterpret_cast<uint4*>(xs + pix * PS + c8 * 16) = o;
-                }
-            }
-        } else {
-            constexpr int CPP = CS / 4;  // 16-B chunks (4 fp32) per pixel
-            const int c4 = tid % CPP, p0 = tid / CPP;
-            constexpr int pstep = kThreads / CPP;
-            const int ch = c0 + c4 * 4;
-            const bool ch_ok = ch < d.ci;
-            float sc[4], sh[4];
-            const bool pro = a.in_scale != nullptr;
-            if (pro) {
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    sc[e] = ch_ok ? a.in_scale[ch + e] : 0.0f;
-                    sh[e] = ch_ok ? a.in_shift[ch + e] : 0.0f;
-                }
-            }
-            const float* xg = (const float*)a.x + x_img * d.x_pix_stride;
-            unsigned char* xs_lo = xs + a.x_plane_bytes;
-            constexpr int XB = 12;
-            int ly = (int)(((float)p0 + 0.5f) * inv_w);
-            int lx = p0 - ly * in_w;
-            const int step_y = pstep / in_w, step_x = pstep - step_y * in_w;  // (uniform)
-            for (int pix0 = p0; pix0 < npix; pix0 += XB * pstep) {
-                float4 v[XB];
-                bool ok[XB];
-#pragma unroll
-                for (int u = 0; u < XB; u++) {
-                    const int pix = pix0 + u * pstep;
-                    const int iy = iy0 + ly, ix = ix0 + lx;
-                    ok[u] = pix < npix && ch_ok && (unsigned)iy < (unsigned)d.hi && (unsigned)ix < (unsigned)d.wi;
-                    const int off = ok[u] ? (iy * d.wi + ix) * d.x_pix_stride + ch : 0;  // (a sample has < 2^31 elements)
-                    lx += step_x;
-                    ly += step_y;
-                    if (lx >= in_w) {
-                        lx -= in_w;
-                        ly++;
-                    }
-                    v[u] = *reinterpret_cast<const float4*>(xg + off);
-                }
-#pragma unroll
-                for (int u = 0; u < XB; u++) {
-                    const int pix = pix0 + u * pstep;
-                    if (pix >= npix) continue;
-                    float f[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-                    unsigned hi2[2], lo2[2];
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        if (pro) {
-                            f[e] = fmaf(f[e], sc[e], sh[e]);
-                            if (d.in_relu) f[e] = fmaxf(f[e], 0.0f);
-                        }
-                        if (!ok[u]) f[e] = 0.0f;
-                    }
-#pragma unroll
-                    for (int e = 0; e < 2; e++) {
-                        const float h0 = round_bf16(f[2 * e]), h1 = round_bf16(f[2 * e + 1]);
-                        hi2[e] = pack_bf16(h0, h1);
-                        lo2[e] = pack_bf16(f[2 * e] - h0, f[2 * e + 1] - h1);
-                    }
-                    *reinterpret_cast<uint2*>(xs + pix * PS + c4 * 8) = make_uint2(hi2[0], hi2[1]);
-                    *reinterpret_cast<uint2*>(xs_lo + pix * PS + c4 * 8) = make_uint2(lo2[0], lo2[1]);
-                }
+        for (int u = 0; u < XB; u++) {
+            const int pix = pfirst + u * pstep;
+            const int iy = iy0 + ly, ix = ix0 + lx;
+            const bool ok = pix < npix && ch_ok && (unsigned)iy < (unsigned)d.hi && (unsigned)ix < (unsigned)d.wi;
+            okmask |= ok ? (1u << u) : 0u;
+            const int off = ok ? (iy * d.wi + ix) * d.x_pix_stride + ch : 0;  // (a sample has < 2^31 elements)
+            v[u] = *reinterpret_cast<const uint4*>(xbase + (long)off * (X3 ? 4 : 2));
+            lx += step_x;
+            ly += step_y;
+            if (lx >= in_w) {
+                lx -= in_w;
+                ly++;
             }
         }
-        // ---- taps in stages of G: weight panels [tap][plane][K8][BNT][8] of the stage into LDS, then the MFMAs ------------------
-        for (int s0 = 0; s0 < n_taps; s0 += G) {
-            const int g_cur = min(G, n_taps - s0);
-            if (s0 > 0) __syncthreads();  // the previous stage's panels have been read
-            const int chunks = g_cur * PLANES * PSZ;
-            constexpr int WB = 10;
-            for (int q0 = tid; q0 < chunks; q0 += WB * kThreads) {
-                uint4 v[WB];
+    };
+    auto store_x = [&](int c0, int pix_begin, const uint4 (&v)[XB], unsigned okmask) {
+        const int ch = c0 + cx * CHN;
+        const bool ch_ok = ch < d.ci;
+        float sc[CHN], sh[CHN];
+        if (pro) {
 #pragma unroll
-                for (int u = 0; u < WB; u++) {
-                    const int q = q0 + u * kThreads;
-                    const int panel = q / PSZ, inner = q % PSZ;  // (compile-time powers of two)
-                    const int g = panel / PLANES, plane = panel % PLANES;
-                    const int c8 = inner / BNT, n = inner % BNT;
-                    const int kg = (c0 >> 3) + c8;
-                    const bool okq = q < chunks && kg < kgroups_total;
-                    const int tw = s_tapw[s0 + (okq ? g : 0)];
-                    const int off = okq ? (plane * (int)plane_elems + ((tw * kgroups_total + kg) * a.co_pad + n0 + n) * 8) : 0;
-                    v[u] = *reinterpret_cast<const uint4*>(wg + off);
-                    if (!okq) v[u] = make_uint4(0u, 0u, 0u, 0u);
-                }
-#pragma unroll
-                for (int u = 0; u < WB; u++) {
-                    const int q = q0 + u * kThreads;
-                    if (q < chunks) *reinterpret_cast<uint4*>(wsb + q * 16) = v[u];
-                }
+            for (int e = 0; e < CHN; e++) {
+                sc[e] = ch_ok ? a.in_scale[ch + e] : 0.0f;
+                sh[e] = ch_ok ? a.in_shift[ch + e] : 0.0f;
             }
-            __syncthreads();
-            for (int g = 0; g < g_cur; g++) {
-                const int toff = s_toff[s0 + g];
-                const unsigned char* wt = wsb + g * (PLANES * WTAP);
-                uint4 af[KS][MI], bfr[KS][NJ];
+        }
+#pragma unroll
+        for (int u = 0; u < XB; u++) {
+            const int pix = pix_begin + p0 + u * pstep;
+            if (pix >= npix) continue;
+            const bool ok = (okmask >> u) & 1u;
+            if constexpr (!X3) {
+                uint4 o = v[u];
+                if (pro) {
+                    unsigned w[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        float f0 = fmaf(bf16_lo(w[e]), sc[2 * e], sh[2 * e]);
+                        float f1 = fmaf(bf16_hi(w[e]), sc[2 * e + 1], sh[2 * e + 1]);
+                        if (d.in_relu) {
+                            f0 = fmaxf(f0, 0.0f);
+                            f1 = fmaxf(f1, 0.0f);
+                        }
+                        w[e] = pack_bf16(f0, f1);
+                    }
+                    o = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+                if (!ok) o = make_uint4(0u, 0u, 0u, 0u);
+                *reinterpret_cast<uint4*>(xs + pix * PS + cx * 16) = o;
+            } else {
+                float f[4] = {__uint_as_float(v[u].x), __uint_as_float(v[u].y), __uint_as_float(v[u].z), __uint_as_float(v[u].w)};
+                unsigned hi2[2], lo2[2];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    if (pro) {
+                        f[e] = fmaf(f[e], sc[e], sh[e]);
+                        if (d.in_relu) f[e] = fmaxf(f[e], 0.0f);
+                    }
+                    if (!ok) f[e] = 0.0f;
+                }
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    const float h0 = round_bf16(f[2 * e]), h1 = round_bf16(f[2 * e + 1]);
+                    hi2[e] = pack_bf16(h0, h1);
+                    lo2[e] = pack_bf16(f[2 * e] - h0, f[2 * e + 1] - h1);
+                }
+                *reinterpret_cast<uint2*>(xs + pix * PS + cx * 8) = make_uint2(hi2[0], hi2[1]);
+                *reinterpret_cast<uint2*>(xs + a.x_plane_bytes + pix * PS + cx * 8) = make_uint2(lo2[0], lo2[1]);
+            }
+        }
+    };
+    auto load_w = [&](int c0, int s0, int chunks, int q_begin, uint4 (&v)[WB]) {
+#pragma unroll
+        for (int u = 0; u < WB; u++) {
+            const int q = q_begin + tid + u * kThreads;
+            const int panel = q / PSZ, inner = q % PSZ;  // (compile-time powers of two)
+            const int g = panel / PLANES, plane = panel % PLANES;
+            const int c8 = inner / BNT, n = inner % BNT;
+            const int kg = (c0 >> 3) + c8;
+            const bool okq = q < chunks && kg < kgroups_total;
+            const int tw = s_tapw[s0 + (okq ? g : 0)];
+            const int off = okq ? (plane * (int)plane_elems + ((tw * kgroups_total + kg) * a.co_pad + n0 + n) * 8) : 0;
+            v[u] = *reinterpret_cast<const uint4*>(wg + off);
+            if (!okq) v[u] = make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    auto store_w = [&](int chunks, int q_begin, const uint4 (&v)[WB]) {
+#pragma unroll
+        for (int u = 0; u < WB; u++) {
+            const int q = q_begin + tid + u * kThreads;
+            if (q < chunks) *reinterpret_cast<uint4*>(wsb + q * 16) = v[u];
+        }
+    };
+    auto mfma_taps = [&](int s0, int g_cur) {
+        for (int g = 0; g < g_cur; g++) {
+            const int toff = s_toff[s0 + g];
+            const unsigned char* wt = wsb + g * (PLANES * WTAP);
+            uint4 af[KS][MI], bfr[KS][NJ];
+#pragma unroll
+            for (int kk = 0; kk < KS; kk++) {
+#pragma unroll
+                for (int i = 0; i < MI; i++) af[kk][i] = *reinterpret_cast<const uint4*>(xs + a_off[i] + toff + kk * 32);
+#pragma unroll
+                for (int j = 0; j < NJ; j++) bfr[kk][j] = *reinterpret_cast<const uint4*>(wt + b_off[j] + kk * (2 * BNT * 16));
+            }
+            if constexpr (X3) {
+                uint4 al[KS][MI], bl[KS][NJ];
 #pragma unroll
                 for (int kk = 0; kk < KS; kk++) {
 #pragma unroll
-                    for (int i = 0; i < MI; i++) af[kk][i] = *reinterpret_cast<const uint4*>(xs + a_off[i] + toff + kk * 32);
+                    for (int i = 0; i < MI; i++)
+                        al[kk][i] = *reinterpret_cast<const uint4*>(xs + a.x_plane_bytes + a_off[i] + toff + kk * 32);
 #pragma unroll
-                    for (int j = 0; j < NJ; j++) bfr[kk][j] = *reinterpret_cast<const uint4*>(wt + b_off[j] + kk * (2 * BNT * 16));
+                    for (int j = 0; j < NJ; j++) bl[kk][j] = *reinterpret_cast<const uint4*>(wt + WTAP + b_off[j] + kk * (2 * BNT * 16));
                 }
-                if constexpr (X3) {
-                    uint4 al[KS][MI], bl[KS][NJ];
 #pragma unroll
-                    for (int kk = 0; kk < KS; kk++) {
+                for (int kk = 0; kk < KS; kk++)
 #pragma unroll
-                        for (int i = 0; i < MI; i++)
-                            al[kk][i] = *reinterpret_cast<const uint4*>(xs + a.x_plane_bytes + a_off[i] + toff + kk * 32);
+                    for (int i = 0; i < MI; i++)
+#pragma unroll
+                        for (int j = 0; j < NJ; j++) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(al[kk][i]), as_bf8(bfr[kk][j]), acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(af[kk][i]), as_bf8(bl[kk][j]), acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(af[kk][i]), as_bf8(bfr[kk][j]), acc[i][j], 0, 0, 0);
+                        }
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < KS; kk++)
+#pragma unroll
+                    for (int i = 0; i < MI; i++)
 #pragma unroll
                         for (int j = 0; j < NJ; j++)
-                            bl[kk][j] = *reinterpret_cast<const uint4*>(wt + WTAP + b_off[j] + kk * (2 * BNT * 16));
-                    }
-#pragma unroll
-                    for (int kk = 0; kk < KS; kk++)
-#pragma unroll
-                        for (int i = 0; i < MI; i++)
-#pragma unroll
-                            for (int j = 0; j < NJ; j++) {
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(al[kk][i]), as_bf8(bfr[kk][j]), acc[i][j], 0, 0, 0);
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(af[kk][i]), as_bf8(bl[kk][j]), acc[i][j], 0, 0, 0);
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(af[kk][i]), as_bf8(bfr[kk][j]), acc[i][j], 0, 0, 0);
-                            }
-                } else {
-#pragma unroll
-                    for (int kk = 0; kk < KS; kk++)
-#pragma unroll
-                        for (int i = 0; i < MI; i++)
-#pragma unroll
-                            for (int j = 0; j < NJ; j++)
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(af[kk][i]), as_bf8(bfr[kk][j]), acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(af[kk][i]), as_bf8(bfr[kk][j]), acc[i][j], 0, 0, 0);
+            }
+        }
+    };
+
+    if (a.pipelined) {
+        // the whole slab (tile + the panels of all taps) fits one batch of registers: software pipeline over the slabs
+        uint4 xv[XB], wv[WB];
+        unsigned xok;
+        const int chunks = n_taps * PLANES * PSZ;
+        __syncthreads();  // tap tables
+        load_x(0, 0, xv, xok);
+        load_w(0, 0, chunks, 0, wv);
+        for (int c0 = 0; c0 < d.ci; c0 += CS) {
+            if (c0 > 0) __syncthreads();  // every read of the previous slab's tile / panels is done
+            store_x(c0, 0, xv, xok);
+            store_w(chunks, 0, wv);
+            __syncthreads();
+            if (c0 + CS < d.ci) {
+                load_x(c0 + CS, 0, xv, xok);
+                load_w(c0 + CS, 0, chunks, 0, wv);
+            }
+            mfma_taps(0, n_taps);
+        }
+    } else {
+        for (int c0 = 0; c0 < d.ci; c0 += CS) {
+            __syncthreads();  // every read of the previous slab's tile / panels is done (and the tap tables are written)
+            for (int pb = 0; pb < npix; pb += XB * pstep) {
+                uint4 xv[XB];
+                unsigned xok;
+                load_x(c0, pb, xv, xok);
+                store_x(c0, pb, xv, xok);
+            }
+            for (int s0 = 0; s0 < n_taps; s0 += G) {
+                const int g_cur = min(G, n_taps - s0);
+                if (s0 > 0) __syncthreads();  // the previous stage's panels have been read
+                const int chunks = g_cur * PLANES * PSZ;
+                for (int qb = 0; qb < chunks; qb += WB * kThreads) {
+                    uint4 wv[WB];
+                    load_w(c0, s0, chunks, qb, wv);
+                    store_w(chunks, qb, wv);
                 }
+                __syncthreads();
+                mfma_taps(s0, g_cur);
             }
         }
     }
@@ -572,8 +574,10 @@ bool make_plan(const liso_conv_desc& d, Plan* p) {
     const int mi_first = blocks(8) >= 512 ? 2 : 1;
     const int cs_opts[2] = {x3 ? 32 : 64, x3 ? 16 : 32};
     long best = -1;
+    bool few_blocks = blocks(4 * mi_first) <= 256;  // at most one block per CU anyway: spend its whole LDS
+    if (const char* e = getenv("LISO_CONV_FEW")) few_blocks = few_blocks && atoi(e) != 0;  // experiments
     for (int pass = 0; pass < 2 && best < 0; pass++) {
-        const int cap = (pass == 0 ? 79 : 158) * 1024;
+        const int cap = (pass == 0 && !few_blocks ? 79 : 158) * 1024;
         for (int mi = mi_first; mi >= 1; mi--) {
             int inh[LISO_CONV_MAX_CLASSES], inw[LISO_CONV_MAX_CLASSES], y0s[LISO_CONV_MAX_CLASSES], x0s[LISO_CONV_MAX_CLASSES];
             const int max_pix = tile_pixels(4 * mi, inh, inw, y0s, x0s);
@@ -609,6 +613,15 @@ bool make_plan(const liso_conv_desc& d, Plan* p) {
     const int th = 4 * p->mi;
     a.cs = p->cs;
     a.g_taps = p->g;
+    {
+        int max_pix = 0;
+        for (int c = 0; c < d.n_classes; c++) max_pix = a.cls_inh[c] * a.cls_inw[c] > max_pix ? a.cls_inh[c] * a.cls_inw[c] : max_pix;
+        const int cpp = x3 ? p->cs / 4 : p->cs / 8;
+        const int x_chunks = (max_pix * cpp + kThreads - 1) / kThreads;          // per thread
+        const int w_chunks = (max_taps * planes * (p->cs / 8) * bnt + kThreads - 1) / kThreads;
+        a.pipelined = (p->g >= max_taps && x_chunks <= 12 && w_chunks <= 10) ? 1 : 0;
+        if (const char* e = getenv("LISO_CONV_PIPE")) a.pipelined = a.pipelined && atoi(e) != 0;  // experiments
+    }
     a.tiles_x = (d.wv + 31) / 32;
     a.tiles_y = (d.hv + th - 1) / th;
     a.total = (int)blocks(th);

@@ -273,6 +273,8 @@ def conv_wgrad(x, dy, weight_shape, spec, in_scale=None, in_shift=None, in_relu=
     """-> (dw fp32 in torch's layout `weight_shape`, dbias fp32 [Co] | None); None if the geometry is not supported by the
     kernel (caller falls back to ATen's weight gradient)"""
     L.require_cuda(x, dy)
+    if spec.kh * spec.kw > 9:
+        return None  # 7x7 kernels: 49 taps re-stage the same large halo tile per tap group; ATen's kernel is faster (3 layers)
     mode = _mode(x.dtype)
     if dy.dtype != x.dtype:
         dy = dy.to(x.dtype)

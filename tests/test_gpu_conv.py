@@ -86,7 +86,7 @@ def test_forward_dgrad_wgrad(geom, dtype):
     assert _rel(dx, gx) <= tol, _rel(dx, gx)
     res = MC.conv_wgrad(xd, dyd, tuple(w.shape), spec)
     if res is None:
-        assert k == 7 and s == 2  # the only geometry routed to ATen (halo tile larger than LDS)
+        assert k == 7  # 7x7 kernels are routed to ATen's weight gradient (49 taps: the tap-group kernel re-stages too much)
     else:
         dw, db = res
         assert _rel(dw, gw) <= 2 * tol, _rel(dw, gw)
