@@ -49,8 +49,10 @@ class CenterPointStyleNet(torch.nn.Module):
         """fp32 = parity configuration; bf16 = BASELINE config 3 (bf16 BEV tensors, fp32 BN stats / head outputs)."""
         self.pfn.out_dtype = dtype
 
-    def forward(self, img_t0, pcls):
-        bev_enc, bev_occupancy_map = self.pfn(pcl_t0=pcls, img_t0=img_t0)
+    def forward(self, img_t0, pcls, canvas=None):
+        """`canvas` (extension): precomputed (bev_enc, occupancy) of `self.pfn` -- callers that replay backbone + head from a
+        hipGraph keep the pillar encoder outside of it"""
+        bev_enc, bev_occupancy_map = canvas if canvas is not None else self.pfn(pcl_t0=pcls, img_t0=img_t0)
         aux_outputs = {"bev_net_input_dbg": bev_occupancy_map}
         pred_dict = self.center_head(self.rpn(bev_enc, lazy=True))
         return {k: v.permute(0, 2, 3, 1) for k, v in pred_dict.items()}, aux_outputs  # reference :111

@@ -39,10 +39,10 @@ class BoxLearner(torch.nn.Module):
                 bev_range_x=cfg.data.bev_range_m[0], bev_range_y=cfg.data.bev_range_m[1],
                 dataset_img_shape=shape).astype(np.float32)[..., 0:2]), requires_grad=False)
 
-    def forward(self, img_t0, pcls_t0, gt_boxes=None, centermaps_gt=None, train=True, decode=True) -> Tuple[Shape, Dict]:
+    def forward(self, img_t0, pcls_t0, gt_boxes=None, centermaps_gt=None, train=True, decode=True, canvas=None) -> Tuple[Shape, Dict]:
         """reference :70-109.  `decode=False` (extension): return the raw network maps only -- (None, None, raw, aux) --
         for callers that run activations + decode + loss fused (liso_amd.losses.fused_centerpoint)."""
-        raw_box_vars, aux_outputs = self.model(img_t0, pcls_t0)
+        raw_box_vars, aux_outputs = self.model(img_t0, pcls_t0, canvas=canvas) if canvas is not None else self.model(img_t0, pcls_t0)
         if not decode:
             return None, None, raw_box_vars, aux_outputs
         decoded, activated = self.apply_all_output_modifications(raw_box_vars=raw_box_vars, gt_boxes=gt_boxes,

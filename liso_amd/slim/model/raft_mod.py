@@ -75,11 +75,16 @@ class RAFT(nn.Module):
         return [p[:B] for p in both], [p[B:] for p in both], aux
 
     @torch.no_grad()
-    def infer_forward_direction(self, pcl_t0, pcl_t1):
+    @torch.no_grad()
+    def encode_pillars(self, pcl_t0, pcl_t1):
+        """the pillar canvases of both sweeps: (img_t0, occ_t0, img_t1, occ_t1)"""
+        return (*self.pp_layer(pcl_t0), *self.pp_layer(pcl_t1))
+
+    def infer_forward_direction(self, pcl_t0, pcl_t1, canvases=None):
         """Inference for consumers of the t0 -> t1 flow only (the box miner): one direction, last iteration.
-        -> ([B,H,W,8(+1)] network output, aux)"""
-        img_t0, occ_t0 = self.pp_layer(pcl_t0)
-        img_t1, occ_t1 = self.pp_layer(pcl_t1)
+        -> ([B,H,W,8(+1)] network output, aux).  `canvases`: precomputed `encode_pillars` result (callers that replay the
+        rest from a hipGraph keep the pillar encoder outside of it)."""
+        img_t0, occ_t0, img_t1, occ_t1 = canvases if canvases is not None else self.encode_pillars(pcl_t0, pcl_t1)
         aux = {"t0": {"bev_net_input_dbg": occ_t0}, "t1": {"bev_net_input_dbg": occ_t1}}
         B = img_t0.shape[0]
         fmap = self.fnet(torch.cat([img_t0, img_t1], dim=0))

@@ -49,13 +49,13 @@ class SLIM(nn.Module):
         self.raft_network = RAFT(cfg=cfg, head_decoder_fw=self.head_decoder_fw, head_decoder_bw=self.head_decoder_bw)
 
     @torch.no_grad()
-    def infer_point_flow_t0_t1(self, sample_data_t0, sample_data_t1):
+    def infer_point_flow_t0_t1(self, sample_data_t0, sample_data_t1, canvases=None):
         """Per-point flow t0 -> t1 of the sweep at t0 (`aggregated_flow` of the last RAFT iteration, [B,N,3]): what
         FlowClusterDetector consumes.  One flow direction, one decode -- the training forward produces 12."""
         dev = next(self.raft_network.parameters()).device
         net_out, aux = self.raft_network.infer_forward_direction(
             get_network_input_pcls(self.cfg, sample_data_t0, "ta", to_device=dev),
-            get_network_input_pcls(self.cfg, sample_data_t1, "ta", to_device=dev))
+            get_network_input_pcls(self.cfg, sample_data_t1, "ta", to_device=dev), canvases=canvases)
         pa = sample_data_t0["pcl_ta"]
         pred = self.head_decoder_fw(
             net_out, self.moving_dynamicness_threshold.value(), pc=pa["pcl"].to(dev),

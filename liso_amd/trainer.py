@@ -54,13 +54,19 @@ def get_slim_optimizer_scheduler(slim_cfg, params):
 
 
 class DetectorTrainer:
-    def __init__(self, cfg, device, compute_dtype=torch.float32, total_steps=None, fused_loss=None):
+    def __init__(self, cfg, device, compute_dtype=torch.float32, total_steps=None, fused_loss=None, use_graph=False):
         """`fused_loss`: activations + decode + CenterPoint loss in one HIP pass (include/liso_detector.h) instead of
         ~140 torch launches; default = whenever the configuration is the overlay the kernel implements and the
-        network runs on the GPU."""
+        network runs on the GPU.
+        `use_graph`: forward + loss + backward of one step (no device->host sync on that path) are captured once per input
+        shape into a hipGraph and replayed; new clouds / targets are copied into the captured input buffers.  Gradients live
+        in one flat buffer: data parallelism is ONE RCCL all-reduce of that buffer after the replay (no DDP wrapper), then
+        the eager AdamW / OneCycleLR step."""
         from liso_amd.losses import fused_centerpoint
 
         self.cfg, self.device = cfg, device
+        self.use_graph = bool(use_graph) and device.type == "cuda"
+        self._graph, self._graph_sig = None, None
         self.fused_loss = (fused_centerpoint.supports(cfg) and device.type == "cuda") if fused_loss is None else fused_loss
         self.net = BoxLearner(cfg).to(device)
         self.net.model.set_compute_dtype(compute_dtype)
@@ -68,17 +74,28 @@ class DetectorTrainer:
             self.net.model.rpn.to(memory_format=torch.channels_last)
             self.net.model.center_head.to(memory_format=torch.channels_last)
         self.model = self.net
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        if self.world > 1 and not self.use_graph:
             # ~19 MB of fp32 gradients: one flat bucket, launched as backward reaches the first layer's grads
             self.model = torch.nn.parallel.DistributedDataParallel(
                 self.net, device_ids=[device.index] if device.type == "cuda" else None, bucket_cap_mb=64,
                 broadcast_buffers=False, gradient_as_bucket_view=True)
+        if self.use_graph:
+            params = [p for p in self.net.parameters() if p.requires_grad]
+            self._flat_grad = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=device)
+            off = 0
+            for p in params:  # gradients are views into one flat buffer: one memset, one all-reduce
+                p.grad = self._flat_grad[off:off + p.numel()].view_as(p)
+                off += p.numel()
+            if self.world > 1:  # replicas start identical (what the DDP constructor would do)
+                for t in list(self.net.parameters()) + list(self.net.buffers()):
+                    dist.broadcast(t.data, src=0)
         self.optimizer, self.lr_scheduler = get_optimizer_scheduler(cfg, self.net, total_steps)
         from liso_amd.networks.centerpoint.fused_bn import defer_batch_counters
         self._bn_counters = defer_batch_counters(self.net.model.rpn) + defer_batch_counters(self.net.model.center_head)
 
-    def loss(self, pcls, targets):
-        """liso_cli.py:452-614"""
+    def loss(self, pcls, targets, canvas=None):
+        """liso_cli.py:452-614.  `canvas`: precomputed pillar canvas (bev, occupancy) -- the hipGraph path"""
         if self.model.training:
             from liso_amd.networks.centerpoint.fused_bn import step_batch_counters
             step_batch_counters(self._bn_counters)
@@ -89,7 +106,7 @@ class DetectorTrainer:
         if self.fused_loss:
             from liso_amd.losses.fused_centerpoint import fused_centerpoint_loss
 
-            _, _, raw, _ = self.model(None, pcls, None, centermaps_gt=None, decode=False)
+            _, _, raw, _ = self.model(None, pcls, None, centermaps_gt=None, decode=False, canvas=canvas)
             total, losses = fused_centerpoint_loss(
                 cfg=cfg, raw_box_maps=raw, gt_maps=gt_maps, gt_center_mask=mask,
                 ignore_region_is_true_mask=targets.get("ignore_region_is_true_mask", None),
@@ -111,12 +128,87 @@ class DetectorTrainer:
 
     def step(self, pcls, targets):
         self.model.train()
+        if self.use_graph:
+            return self._graph_step(pcls, targets)
         self.optimizer.zero_grad(set_to_none=True)
         total, losses, _ = self.loss(pcls, targets)
         total.backward()
         self.optimizer.step()
         self.lr_scheduler.step()
         return total.detach()
+
+    # ---- hipGraph path ----------------------------------------------------------------------------------------------
+    # The graph holds backbone + head + fused loss, forward and backward (~95 % of the step's launches).  The pillar encoder
+    # (voxelise + PFN + scatter; 10 launches) runs eagerly around it: replaying ITS launches from a graph while other pillar-
+    # encoder calls run eagerly in the same process (the LISO loop's SLIM inference) ends in a GPU memory fault -- bisected
+    # to exactly that combination (scripts/try_loop_graph3.py), root cause not found; the other kernels replay cleanly.
+    def _pillars(self, pcls):
+        bev, occ = self.net.model.pfn(pcl_t0=pcls, img_t0=None)
+        return bev, occ
+
+    def _capture(self, pcls, targets):
+        dev = self.device
+        with torch.no_grad():
+            bev, occ = self._pillars(pcls)
+        self._static_bev = bev.detach().clone().requires_grad_(True)
+        self._static_occ = occ.detach().clone()
+        self._static_bev.grad = torch.zeros_like(self._static_bev)
+        self._static_targets = {k: v.to(dev).clone() for k, v in targets.items()}
+        buffers = {k: v.clone() for k, v in self.net.state_dict().items() if v.is_floating_point() or v.dtype == torch.long}
+        quiet = hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch")
+        if quiet:  # the flat gradient views are created on the default stream, warm-up and capture run on a side stream
+            torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+        side = self._capture_stream = torch.cuda.Stream(device=dev)  # (kept alive with the graph)
+        side.wait_stream(torch.cuda.current_stream(dev))
+
+        def body():
+            self._flat_grad.zero_()
+            self._static_bev.grad.zero_()
+            total, _, _ = self.loss(None, self._static_targets, canvas=(self._static_bev, self._static_occ))
+            total.backward()
+            return total.detach()
+
+        with torch.cuda.stream(side):  # warm-up off the capture: lazy initialisations, allocator pools
+            for _ in range(2):
+                body()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        with torch.no_grad():  # the warm-up passes must not count as training steps (BatchNorm statistics / counters)
+            for k, v in self.net.state_dict().items():
+                if k in buffers:
+                    v.copy_(buffers[k])
+        self._graph = torch.cuda.CUDAGraph()
+        # capture on the warm-up's stream: the AccumulateGrad nodes of the parameters were created there; a capture on another
+        # stream forks into it and the replay computes garbage (measured: loss 63 instead of 1082)
+        with torch.cuda.graph(self._graph, stream=side):
+            self._static_loss = body()
+        with torch.no_grad():
+            for k, v in self.net.state_dict().items():
+                if k in buffers:
+                    v.copy_(buffers[k])
+        if quiet:
+            torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(True)
+
+    def _graph_step(self, pcls, targets):
+        sig = (tuple(tuple(p.shape) for p in pcls), tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(targets.items())))
+        if self._graph is None or sig != self._graph_sig:
+            self._graph = None
+            self._capture(pcls, targets)
+            self._graph_sig = sig
+        bev, occ = self._pillars(pcls)
+        with torch.no_grad():
+            self._static_bev.copy_(bev.detach(), non_blocking=True)
+            self._static_occ.copy_(occ, non_blocking=True)
+            for k, v in targets.items():
+                self._static_targets[k].copy_(v, non_blocking=True)
+        self._graph.replay()
+        if bev.requires_grad:  # the pillar encoder's own parameters: its backward runs eagerly on the replayed d loss / d canvas
+            bev.backward(self._static_bev.grad)
+        if self.world > 1:
+            dist.all_reduce(self._flat_grad)
+            self._flat_grad.div_(self.world)
+        self.optimizer.step()
+        self.lr_scheduler.step()
+        return self._static_loss.clone()
 
 
 class SlimTrainer:
@@ -280,7 +372,9 @@ class SlimTrainer:
                 if k in buffers:
                     v.copy_(buffers[k])
         self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
+        # capture on the warm-up's stream: the AccumulateGrad nodes of the parameters live there (a capture on another stream
+        # forks into it: wrong results, measured on the detector step)
+        with torch.cuda.graph(self._graph, stream=side):
             self._flat_grad.zero_()
             total, _, _ = self.loss(s0, s1, all_valid)
             total.backward()
@@ -321,17 +415,23 @@ class LisoLoopTrainer:
     box mining + box DB: tracker/; training: liso_cli.py); here the tensors stay in HBM from the sweep to the gradient.
     Box-DB augmentation and tracking between the stages are outside this loop."""
 
-    def __init__(self, cfg, device, compute_dtype=torch.float32, total_steps=None, slim_state_dict=None):
+    def __init__(self, cfg, device, compute_dtype=torch.float32, total_steps=None, slim_state_dict=None, use_graph=False):
+        """`use_graph`: the frozen SLIM inference (one capture per input shape) and the detector's forward+loss+backward are
+        replayed from hipGraphs; the flow clustering in between stays eager (its box count sizes the padded Shape)."""
         from liso_amd.networks.flow_cluster_detector.flow_cluster_detector import FlowClusterDetector
         from liso_amd.slim.model.slim import SLIM
 
         self.cfg, self.device = cfg, device
+        self.use_graph = bool(use_graph) and device.type == "cuda"
+        self._graph_infer = self.use_graph and use_graph in (True, "infer")
+        self._graph_det = self.use_graph and use_graph in (True, "detector")
+        self._infer_graph, self._infer_sig = None, None
         self.slim = SLIM(cfg, num_train_samples=1000).to(device)
         if slim_state_dict is not None:
             self.slim.load_state_dict(slim_state_dict)
         self.slim.eval()
         self.cluster_detector = FlowClusterDetector(cfg).to(device)
-        self.detector = DetectorTrainer(cfg, device, compute_dtype=compute_dtype, total_steps=total_steps)
+        self.detector = DetectorTrainer(cfg, device, compute_dtype=compute_dtype, total_steps=total_steps, use_graph=self._graph_det)
         tc = cfg.data.tracking_cfg
         self.pre_nms, self.post_nms = tc.max_num_boxes_before_nms, tc.max_num_boxes_after_nms
         self.nms_iou = cfg.setdefault("nms_iou_threshold", 0.1)
@@ -341,7 +441,7 @@ class LisoLoopTrainer:
         """-> (Shape [B,K] after NMS, padded with zeros; point flow [B,N,3])"""
         from liso_amd.utils.nms_iou import perform_nms_on_shapes_padded
 
-        flow = self.slim.infer_point_flow_t0_t1(sample_t0, sample_t1)  # one direction, last RAFT iteration
+        flow = self._infer_flow(sample_t0, sample_t1)  # one direction, last RAFT iteration
         sample = dict(sample_t0)
         sample[self.cfg.data.flow_source] = {**sample_t0.get(self.cfg.data.flow_source, {}), "flow_ta_tb": flow}
         boxes = self.cluster_detector(sample, global_step=1)
@@ -350,6 +450,40 @@ class LisoLoopTrainer:
                                                  pre_nms_max_num_boxes=self.pre_nms)
             boxes.set_padding_val_to(0.0)
         return boxes, flow
+
+    def _infer_flow(self, sample_t0, sample_t1):
+        if not self._graph_infer:
+            return self.slim.infer_point_flow_t0_t1(sample_t0, sample_t1)
+        shapes = []
+        SlimTrainer._map_tensors((sample_t0, sample_t1), lambda t: shapes.append((tuple(t.shape), t.dtype)) or t)
+        sig = tuple(shapes)
+        dev = self.device
+        from liso_amd.slim.model.slim import get_network_input_pcls
+
+        raft = self.slim.raft_network
+        with torch.no_grad():  # pillar encoder eagerly (see DetectorTrainer: its launches must not be replayed from a graph here)
+            canv = raft.encode_pillars(get_network_input_pcls(self.cfg, sample_t0, "ta", to_device=dev),
+                                       get_network_input_pcls(self.cfg, sample_t1, "ta", to_device=dev))
+        if self._infer_graph is None or sig != self._infer_sig:
+            self._static_in = SlimTrainer._map_tensors((sample_t0, sample_t1), lambda t: t.to(dev).clone())
+            self._static_canv = tuple(c.clone() for c in canv)
+            s0, s1 = self._static_in
+            side = self._infer_stream = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side), torch.no_grad():
+                for _ in range(2):
+                    self.slim.infer_point_flow_t0_t1(s0, s1, canvases=self._static_canv)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            self._infer_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._infer_graph, stream=side), torch.no_grad():
+                self._static_flow = self.slim.infer_point_flow_t0_t1(s0, s1, canvases=self._static_canv)
+            self._infer_sig = sig
+        else:
+            SlimTrainer._copy_tensors(self._static_in, (sample_t0, sample_t1))
+            for d, c in zip(self._static_canv, canv):
+                d.copy_(c, non_blocking=True)
+        self._infer_graph.replay()
+        return self._static_flow
 
     def step(self, sample_t0, sample_t1):
         from liso_amd.datasets.targets import render_center_targets

@@ -154,6 +154,10 @@ def pack_weights(weight, spec, for_dgrad, mode):
     L.require_cuda(weight)
     if not isinstance(weight, torch.nn.Parameter):  # (temporaries: their storage is recycled, no stable identity)
         return _pack_weights(weight, spec, for_dgrad, mode)
+    if weight.requires_grad and torch.cuda.is_current_stream_capturing():
+        # a captured training step must re-pack on every replay (the optimizer changes the weights in between): never let a
+        # cache hit elide the pack launch from the graph
+        return _pack_weights(weight, spec, for_dgrad, mode)
     key = (id(weight), spec.transposed, bool(for_dgrad), mode)
     hit = _PACK_CACHE.get(key)
     if hit is not None and hit[0]() is weight and hit[1] == weight._version and hit[2] == weight.data_ptr():
