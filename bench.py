@@ -66,6 +66,9 @@ def parse():
     ap.add_argument("--no-iou3d", action="store_true", help="skip the iou3d_nms section of the line")
     ap.add_argument("--graph", action="store_true",
                     help="slim workload: replay forward+loss+backward from a hipGraph (host-independent step time)")
+    ap.add_argument("--eager", action="store_true",
+                    help="loop / detector workloads: launch every kernel eagerly (default: SLIM inference and the detector's "
+                         "backbone + head + loss fwd/bwd replay from hipGraphs; bit-identical results)")
     ap.add_argument("--conv-benchmark", action="store_true", help="torch.backends.cudnn.benchmark = True (MIOpen layers only)")
     ap.add_argument("--no-miopen-db", action="store_true", help="do not seed MIOpen's user database from liso_amd/miopen_db/")
     ap.add_argument("--miopen-convs", action="store_true",
@@ -337,7 +340,7 @@ def main():
         batch = 1
         dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
         cfg = apply_slim_simple_knn_training(cfg)
-        trainer = LisoLoopTrainer(cfg, dev, compute_dtype=dtype, total_steps=args.steps + args.warmup + 8)
+        trainer = LisoLoopTrainer(cfg, dev, compute_dtype=dtype, total_steps=args.steps + args.warmup + 8, use_graph=not args.eager)
         s0, s1 = slim_pair(2 + rank, dev, n_points=N_POINTS, grid=GRID, bev_range_m=BEV_RANGE)
         step = lambda: trainer.step(s0, s1)  # noqa: E731
         frames_per_step = 2
@@ -347,7 +350,7 @@ def main():
 
         batch = args.batch or BATCH_PER_GPU
         dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-        trainer = DetectorTrainer(cfg, dev, compute_dtype=dtype, total_steps=args.steps + args.warmup + 8)
+        trainer = DetectorTrainer(cfg, dev, compute_dtype=dtype, total_steps=args.steps + args.warmup + 8, use_graph=not args.eager)
         pcls, targets = detector_batch(seed=1 + rank, batch=batch, device=dev, n_points=N_POINTS, grid=GRID,
                                        bev_range_m=BEV_RANGE)
         step = lambda: trainer.step(pcls, targets)  # noqa: E731
@@ -374,7 +377,7 @@ def main():
     for _ in range(args.warmup):
         step()
 
-    graphed = args.workload == "slim" and args.graph
+    graphed = (args.workload == "slim" and args.graph) or (args.workload in ("loop", "detector") and not args.eager)
     if not graphed:  # per-launch HIP events on the launch stream, inside the timed region
         L.TIMER.enable_all()
     L.TIMER.reset()
@@ -397,7 +400,12 @@ def main():
         L.TIMER.reset()
         event_steps = 2
         for _ in range(event_steps):
-            trainer.step(s0, s1, eager=True, update=False)
+            if args.workload == "slim":
+                trainer.step(s0, s1, eager=True, update=False)
+            elif args.workload == "loop":
+                trainer.eager_pass(s0, s1)
+            else:
+                trainer.eager_pass(pcls, targets)
         torch.cuda.synchronize()
         timed_in = f"{event_steps} eager fwd+bwd passes after the timed region (the timed steps replay a hipGraph)"
     L.TIMER.disable_all()
@@ -456,7 +464,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": workload, "points_per_cloud": N_POINTS, "bev_grid": GRID, "batch_per_gpu": batch,
                        "frames_per_step_per_gpu": frames_per_step, "parallelism": f"dp{world}",
-                       "launch": "hipGraph replay of fwd+loss+bwd, eager RMSprop" if graphed else "eager",
+                       "launch": ("eager" if not graphed else "hipGraph replay of fwd+loss+bwd, eager RMSprop" if args.workload == "slim"
+                                  else "hipGraph replays (SLIM inference; detector backbone+head+loss fwd/bwd), eager pillar encoder / "
+                                       "flow clustering / AdamW"),
                        "convolutions": "MIOpen (--miopen-convs)" if args.miopen_convs else "own MFMA implicit-GEMM kernels"},
             "final_loss": float(loss),
             "roofline": {"kernel": kname, "bound": bound, "achieved": achieved, "peak": peak, "unit": runit,

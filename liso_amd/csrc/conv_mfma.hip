@@ -538,6 +538,16 @@ bool make_plan(const liso_conv_desc& d, Plan* p) {
     a.ci_pad = round_up(d.ci, 16);
     a.co_pad = round_up(d.co, 64);
     p->nj = d.co <= 32 ? 1 : 2;
+    {
+        // small maps (the RAFT update block of one sample: 64 x 64 pixels = 32 tiles): 64-channel panels leave most CUs
+        // without a block -> 32-channel panels double the block count (the tile is re-staged from L2 by twice as many blocks)
+        const long tiles4 = (long)d.n_classes * d.batch * ((d.hv + 3) / 4) * ((d.wv + 31) / 32);
+        if (p->nj == 2 && tiles4 * ((d.co + 63) / 64) < 160) p->nj = 1;
+        if (const char* e = getenv("LISO_CONV_NJ")) {  // experiments: 1 | 2 force the panel width
+            if (atoi(e) == 1) p->nj = 1;
+            if (atoi(e) == 2 && d.co > 32) p->nj = 2;
+        }
+    }
     const int bnt = 32 * p->nj;
     a.n_nt = (d.co + bnt - 1) / bnt;
     auto blocks = [&](int th) { return (long)d.n_classes * d.batch * ((d.hv + th - 1) / th) * ((d.wv + 31) / 32) * a.n_nt; };

@@ -137,6 +137,26 @@ class DetectorTrainer:
         self.lr_scheduler.step()
         return total.detach()
 
+    def eager_pass(self, pcls, targets):
+        """forward + loss + backward with eager launches and NO update: no collective, no optimizer / scheduler step (bench.py
+        times individual kernels this way next to graph-replayed steps; every rank may call it independently)"""
+        self.model.train()
+        saved = [p.grad for p in self.net.parameters()]
+        for p in self.net.parameters():
+            p.grad = None
+        bufs = {k: v.clone() for k, v in self.net.state_dict().items() if "running" in k or "num_batches" in k}
+        ctx = self.model.no_sync() if hasattr(self.model, "no_sync") else contextlib.nullcontext()
+        with ctx:
+            total, _, _ = self.loss(pcls, targets)
+            total.backward()
+        with torch.no_grad():
+            for k, v in self.net.state_dict().items():
+                if k in bufs:
+                    v.copy_(bufs[k])
+        for p, g in zip(self.net.parameters(), saved):
+            p.grad = g
+        return total.detach()
+
     # ---- hipGraph path ----------------------------------------------------------------------------------------------
     # The graph holds backbone + head + fused loss, forward and backward (~95 % of the step's launches).  The pillar encoder
     # (voxelise + PFN + scatter; 10 launches) runs eagerly around it: replaying ITS launches from a graph while other pillar-
@@ -430,6 +450,8 @@ class LisoLoopTrainer:
         if slim_state_dict is not None:
             self.slim.load_state_dict(slim_state_dict)
         self.slim.eval()
+        for p_ in self.slim.parameters():  # frozen: its packed convolution panels are built once and never re-packed
+            p_.requires_grad_(False)
         self.cluster_detector = FlowClusterDetector(cfg).to(device)
         self.detector = DetectorTrainer(cfg, device, compute_dtype=compute_dtype, total_steps=total_steps, use_graph=self._graph_det)
         tc = cfg.data.tracking_cfg
@@ -484,6 +506,22 @@ class LisoLoopTrainer:
                 d.copy_(c, non_blocking=True)
         self._infer_graph.replay()
         return self._static_flow
+
+    def eager_pass(self, sample_t0, sample_t1):
+        """the whole iteration with eager launches and no parameter update (per-kernel event timing in bench.py)"""
+        from liso_amd.datasets.targets import render_center_targets
+
+        g, self._graph_infer = self._graph_infer, False
+        try:
+            boxes, _ = self.mine_boxes(sample_t0, sample_t1)
+        finally:
+            self._graph_infer = g
+        if boxes.shape[1] == 0:
+            return None
+        out = tuple(int(v) // 4 for v in self.cfg.data.img_grid_size)
+        targets = render_center_targets(boxes.pos.float(), boxes.dims.float().clamp(min=1e-3), boxes.rot.float(), boxes.valid, out,
+                                        tuple(self.cfg.data.bev_range_m))
+        return self.detector.eager_pass(sample_t0["pcl_full_no_ground_ta"], targets)
 
     def step(self, sample_t0, sample_t1):
         from liso_amd.datasets.targets import render_center_targets

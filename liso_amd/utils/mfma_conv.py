@@ -61,6 +61,7 @@ def _base_desc(B, hi, wi, ci, x_ps, ho, wo, co, y_ps, y_off, mode, out_f32, in_r
 
 
 _DESC_CACHE = {}
+_COPY_LOG = None  # debugging: set to {} to count the layout copies `as_nhwc` has to make, by shape and caller
 
 
 def _cached(fn):
@@ -137,6 +138,10 @@ def as_nhwc(t, vec):
     regular = (v.stride(3) == 1 or C == 1) and ps >= C and (W == 1 or v.stride(2) == ps) and (H == 1 or v.stride(1) == W * ps) and \
         (B == 1 or v.stride(0) == H * W * ps) and ps % vec == 0 and v.data_ptr() % 16 == 0
     if not regular:
+        if _COPY_LOG is not None:
+            import traceback
+            fr = [f"{f.name}:{f.lineno}" for f in traceback.extract_stack(limit=7)[:-1] if "mfma_conv" not in f.filename][-3:]
+            _COPY_LOG[(tuple(t.shape), tuple(t.stride()), tuple(fr))] = _COPY_LOG.get((tuple(t.shape), tuple(t.stride()), tuple(fr)), 0) + 1
         v = t.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
         if v.stride(3) != 1 and C > 1:  # (channels_last of a C == 1 tensor can report odd strides)
             v = v.contiguous()

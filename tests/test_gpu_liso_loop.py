@@ -115,3 +115,24 @@ def test_liso_loop_full_size_120k_512_bf16():
     if int(v.sum()):
         assert torch.allclose(cpu(raw.pos)[v], ref["pos"][v], atol=1e-4)
         assert torch.allclose(cpu(raw.dims)[v].double(), ref["dims"][v], atol=1e-4)
+
+
+@pytest.mark.parametrize("grid,rng,n_points", [(256, 50.0, 40000), (512, 100.0, 120000)])
+def test_graph_replayed_loop_equals_eager_loop(grid, rng, n_points):
+    """LisoLoopTrainer(use_graph=True): the frozen SLIM inference (behind the eagerly launched pillar encoder) and the
+    detector's backbone + head + fused loss forward/backward replay from hipGraphs -- with the inputs refreshed every step
+    (two alternating sweep pairs), eager flow clustering / NMS / target rendering / AdamW in between.  Losses must be
+    IDENTICAL to the eager loop over 6 steps (the round-1 attempt ended in a GPU memory fault at the first refresh)."""
+    from liso_amd.datasets.synthetic import slim_pair
+    from liso_amd.trainer import LisoLoopTrainer
+    from liso_amd.utils.config import apply_slim_simple_knn_training, default_cfg
+
+    dev = torch.device("cuda")
+    pairs = [slim_pair(7 + i, dev, n_points=n_points, grid=grid, bev_range_m=rng) for i in range(2)]
+    out = []
+    for use_graph in (False, True):
+        cfg = apply_slim_simple_knn_training(default_cfg(grid=grid, bev_range_m=rng))
+        torch.manual_seed(0)
+        tr = LisoLoopTrainer(cfg, dev, compute_dtype=torch.bfloat16, total_steps=20, use_graph=use_graph)
+        out.append([float(tr.step(*pairs[i % 2])) for i in range(6)])
+    assert out[0] == out[1], out
