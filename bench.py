@@ -61,6 +61,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--workload", default="loop", choices=["loop", "slim", "detector", "iou3d"])
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="loop workload: all stages of an iteration on one stream, one pair at a time (default: SLIM inference "
+                         "of pair i+2 and box mining of pair i+1 on their own HIP streams, concurrent with the detector step on i)")
     ap.add_argument("--batch", type=int, default=None, help="detector workload: clouds per GPU (default 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-iou3d", action="store_true", help="skip the iou3d_nms section of the line")
@@ -322,6 +325,7 @@ def main():
     cfg = default_cfg(grid=GRID, bev_range_m=BEV_RANGE)
     torch.manual_seed(0)  # identical initial weights on every rank (DDP also broadcasts them)
     s0 = s1 = pcls = targets = None
+    overlap = False
     if args.workload == "slim":
         from liso_amd.datasets.synthetic import slim_pair
         from liso_amd.trainer import SlimTrainer
@@ -340,9 +344,19 @@ def main():
         batch = 1
         dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
         cfg = apply_slim_simple_knn_training(cfg)
-        trainer = LisoLoopTrainer(cfg, dev, compute_dtype=dtype, total_steps=args.steps + args.warmup + 8, use_graph=not args.eager)
-        s0, s1 = slim_pair(2 + rank, dev, n_points=N_POINTS, grid=GRID, bev_range_m=BEV_RANGE)
-        step = lambda: trainer.step(s0, s1)  # noqa: E731
+        overlap = not (args.eager or args.no_overlap)
+        trainer = LisoLoopTrainer(cfg, dev, compute_dtype=dtype, total_steps=args.steps + args.warmup + 8, use_graph=not args.eager,
+                                  overlap=overlap)
+        # a ring of different sweep pairs; step i trains on pair i while (overlap) pairs i+1 / i+2 are in the mining stages
+        pairs = [slim_pair(2 + rank + 100 * i, dev, n_points=N_POINTS, grid=GRID, bev_range_m=BEV_RANGE) for i in range(4)]
+        s0, s1 = pairs[0]
+        counter = [0]
+
+        def step():
+            i = counter[0]
+            counter[0] += 1
+            return trainer.step(*pairs[i % len(pairs)], upcoming=(pairs[(i + 1) % len(pairs)], pairs[(i + 2) % len(pairs)]))
+
         frames_per_step = 2
     else:
         from liso_amd.datasets.synthetic import detector_batch
@@ -466,7 +480,8 @@ def main():
                        "frames_per_step_per_gpu": frames_per_step, "parallelism": f"dp{world}",
                        "launch": ("eager" if not graphed else "hipGraph replay of fwd+loss+bwd, eager RMSprop" if args.workload == "slim"
                                   else "hipGraph replays (SLIM inference; detector backbone+head+loss fwd/bwd), eager pillar encoder / "
-                                       "flow clustering / AdamW"),
+                                       "flow clustering / AdamW" + ("; 3-stage pipeline on 3 HIP streams: SLIM inference of pair i+2 | "
+                                                                    "clustering+NMS+targets of pair i+1 | detector step on pair i" if args.workload == "loop" and overlap else "")),
                        "convolutions": "MIOpen (--miopen-convs)" if args.miopen_convs else "own MFMA implicit-GEMM kernels"},
             "final_loss": float(loss),
             "roofline": {"kernel": kname, "bound": bound, "achieved": achieved, "peak": peak, "unit": runit,

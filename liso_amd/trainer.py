@@ -66,7 +66,7 @@ class DetectorTrainer:
 
         self.cfg, self.device = cfg, device
         self.use_graph = bool(use_graph) and device.type == "cuda"
-        self._graph, self._graph_sig = None, None
+        self._graph, self._graph_sig, self._capture_stream = None, None, None
         self.fused_loss = (fused_centerpoint.supports(cfg) and device.type == "cuda") if fused_loss is None else fused_loss
         self.net = BoxLearner(cfg).to(device)
         self.net.model.set_compute_dtype(compute_dtype)
@@ -178,7 +178,9 @@ class DetectorTrainer:
         quiet = hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch")
         if quiet:  # the flat gradient views are created on the default stream, warm-up and capture run on a side stream
             torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
-        side = self._capture_stream = torch.cuda.Stream(device=dev)  # (kept alive with the graph)
+        if self._capture_stream is None:
+            self._capture_stream = torch.cuda.Stream(device=dev)
+        side = self._capture_stream  # (kept alive with the graph)
         side.wait_stream(torch.cuda.current_stream(dev))
 
         def body():
@@ -435,9 +437,12 @@ class LisoLoopTrainer:
     box mining + box DB: tracker/; training: liso_cli.py); here the tensors stay in HBM from the sweep to the gradient.
     Box-DB augmentation and tracking between the stages are outside this loop."""
 
-    def __init__(self, cfg, device, compute_dtype=torch.float32, total_steps=None, slim_state_dict=None, use_graph=False):
+    def __init__(self, cfg, device, compute_dtype=torch.float32, total_steps=None, slim_state_dict=None, use_graph=False,
+                 overlap=False):
         """`use_graph`: the frozen SLIM inference (one capture per input shape) and the detector's forward+loss+backward are
-        replayed from hipGraphs; the flow clustering in between stays eager (its box count sizes the padded Shape)."""
+        replayed from hipGraphs; the flow clustering in between stays eager (its box count sizes the padded Shape).
+        `overlap`: step(pair_i, upcoming=(pair_i+1, pair_i+2)) runs the iteration as a three-stage software pipeline on
+        three HIP streams (see _stage_a / _stage_b below); results are those of the one-stream loop."""
         from liso_amd.networks.flow_cluster_detector.flow_cluster_detector import FlowClusterDetector
         from liso_amd.slim.model.slim import SLIM
 
@@ -446,6 +451,9 @@ class LisoLoopTrainer:
         self._graph_infer = self.use_graph and use_graph in (True, "infer")
         self._graph_det = self.use_graph and use_graph in (True, "detector")
         self._infer_graph, self._infer_sig = None, None
+        self.overlap = bool(overlap) and device.type == "cuda"
+        self._flow_stream, self._mine_stream, self._main_used_static = None, None, None
+        self._flows, self._mined = [], []
         self.slim = SLIM(cfg, num_train_samples=1000).to(device)
         if slim_state_dict is not None:
             self.slim.load_state_dict(slim_state_dict)
@@ -454,6 +462,12 @@ class LisoLoopTrainer:
             p_.requires_grad_(False)
         self.cluster_detector = FlowClusterDetector(cfg).to(device)
         self.detector = DetectorTrainer(cfg, device, compute_dtype=compute_dtype, total_steps=total_steps, use_graph=self._graph_det)
+        if device.type == "cuda":
+            # three streams in all (the caller's, A, B): HIP multiplexes streams onto 4 hardware queues, and two streams on one
+            # queue take turns.  Graph capture / warm-up of both networks borrows stream A.
+            self._flow_stream = torch.cuda.Stream(device=device)
+            self._mine_stream = torch.cuda.Stream(device=device, priority=-1)  # many tiny kernels + host reads: dispatch first
+            self.detector._capture_stream = self._flow_stream
         tc = cfg.data.tracking_cfg
         self.pre_nms, self.post_nms = tc.max_num_boxes_before_nms, tc.max_num_boxes_after_nms
         self.nms_iou = cfg.setdefault("nms_iou_threshold", 0.1)
@@ -461,16 +475,8 @@ class LisoLoopTrainer:
     @torch.no_grad()
     def mine_boxes(self, sample_t0, sample_t1):
         """-> (Shape [B,K] after NMS, padded with zeros; point flow [B,N,3])"""
-        from liso_amd.utils.nms_iou import perform_nms_on_shapes_padded
-
         flow = self._infer_flow(sample_t0, sample_t1)  # one direction, last RAFT iteration
-        sample = dict(sample_t0)
-        sample[self.cfg.data.flow_source] = {**sample_t0.get(self.cfg.data.flow_source, {}), "flow_ta_tb": flow}
-        boxes = self.cluster_detector(sample, global_step=1)
-        if boxes.shape[1] > 0:
-            boxes = perform_nms_on_shapes_padded(boxes, max_num_boxes=self.post_nms, overlap_threshold=self.nms_iou,
-                                                 pre_nms_max_num_boxes=self.pre_nms)
-            boxes.set_padding_val_to(0.0)
+        _, boxes = self._targets_from_flow(sample_t0, flow)
         return boxes, flow
 
     def _infer_flow(self, sample_t0, sample_t1):
@@ -490,7 +496,7 @@ class LisoLoopTrainer:
             self._static_in = SlimTrainer._map_tensors((sample_t0, sample_t1), lambda t: t.to(dev).clone())
             self._static_canv = tuple(c.clone() for c in canv)
             s0, s1 = self._static_in
-            side = self._infer_stream = torch.cuda.Stream(device=dev)
+            side = self._flow_stream  # (HIP maps streams onto 4 hardware queues: capture on a pipeline stream, no extra one)
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side), torch.no_grad():
                 for _ in range(2):
@@ -523,17 +529,102 @@ class LisoLoopTrainer:
                                         tuple(self.cfg.data.bev_range_m))
         return self.detector.eager_pass(sample_t0["pcl_full_no_ground_ta"], targets)
 
-    def step(self, sample_t0, sample_t1):
+    def _targets_from_flow(self, sample_t0, flow):
+        """flow clustering -> NMS -> CenterPoint target maps (the stage with the two box-count reads)"""
         from liso_amd.datasets.targets import render_center_targets
+        from liso_amd.utils.nms_iou import perform_nms_on_shapes_padded
 
-        boxes, _ = self.mine_boxes(sample_t0, sample_t1)
-        B = boxes.shape[0]
-        if boxes.shape[1] == 0:  # nothing moved: an all-background target (one padded slot)
-            z = torch.zeros((B, 1, 3), device=self.device)
-            pos, dims, rot, valid = z, z + 1.0, z[..., :1], torch.zeros((B, 1), dtype=torch.bool, device=self.device)
+        with torch.no_grad():
+            sample = dict(sample_t0)
+            sample[self.cfg.data.flow_source] = {**sample_t0.get(self.cfg.data.flow_source, {}), "flow_ta_tb": flow}
+            boxes = self.cluster_detector(sample, global_step=1)
+            if boxes.shape[1] > 0:
+                boxes = perform_nms_on_shapes_padded(boxes, max_num_boxes=self.post_nms, overlap_threshold=self.nms_iou,
+                                                     pre_nms_max_num_boxes=self.pre_nms)
+                boxes.set_padding_val_to(0.0)
+            B = boxes.shape[0]
+            if boxes.shape[1] == 0:  # nothing moved: an all-background target (one padded slot)
+                z = torch.zeros((B, 1, 3), device=self.device)
+                pos, dims, rot, valid = z, z + 1.0, z[..., :1], torch.zeros((B, 1), dtype=torch.bool, device=self.device)
+            else:
+                pos, dims, rot, valid = boxes.pos.float(), boxes.dims.float().clamp(min=1e-3), boxes.rot.float(), boxes.valid
+            out = tuple(int(g) // 4 for g in self.cfg.data.img_grid_size)
+            return render_center_targets(pos, dims, rot, valid, out, tuple(self.cfg.data.bev_range_m)), boxes
+
+    # ---- three-stage software pipeline (overlap=True) ------------------------------------------------------------------
+    # stage A: frozen SLIM inference of pair i+2 (no host synchronisation)          -> stream _flow_stream
+    # stage B: flow clustering + NMS + target maps of pair i+1 (two box-count reads) -> stream _mine_stream
+    # stage C: detector train step on pair i                                         -> the caller's stream
+    # A and B depend on the sweeps and the frozen SLIM weights only, never on the detector: every pair gets exactly the
+    # boxes, targets and parameter update of the one-stream loop (tests/test_gpu_liso_loop.py), the three stages -- each far
+    # too small to fill 256 CUs at batch 1 -- share the GPU instead of taking turns, and the host never waits for stage A.
+    def _stage_a(self, pair):
+        dev = self.device
+        side = self._flow_stream
+        if self._main_used_static is not None:  # the static inference buffers were last used on the caller's stream
+            side.wait_event(self._main_used_static)
+            self._main_used_static = None
+        with torch.cuda.stream(side), torch.no_grad():
+            flow = self._infer_flow(*pair).clone()  # (the next replay overwrites the static output)
+            done = torch.cuda.Event()
+            done.record(side)
+        self._flows.append((pair[0], pair[1], flow, done))
+
+    def _take(self, store, sample_t0, sample_t1):
+        for k, e in enumerate(store):
+            if e[0] is sample_t0 and e[1] is sample_t1:
+                return store.pop(k)
+        return None
+
+    def _stage_b(self, pair):
+        f = self._take(self._flows, *pair)
+        if f is None:
+            self._stage_a(pair)
+            f = self._take(self._flows, *pair)
+        side = self._mine_stream
+        side.wait_event(f[3])
+        with torch.cuda.stream(side):
+            f[2].record_stream(side)
+            targets, boxes = self._targets_from_flow(pair[0], f[2])
+            done = torch.cuda.Event()
+            done.record(side)
+        self._mined.append((pair[0], pair[1], targets, boxes, done))
+
+    def step(self, sample_t0, sample_t1, upcoming=()):
+        """one iteration on (sample_t0, sample_t1).  With `overlap`, `upcoming` = the pairs of the following calls (up to two):
+        stage B of upcoming[0] and stage A of upcoming[1] are enqueued behind this call's detector step on their own streams.
+        Prefetched results are matched by object identity; anything announced but not requested next is dropped."""
+        cuda = self.device.type == "cuda"
+        cur = torch.cuda.current_stream(self.device) if cuda else None
+        m = self._take(self._mined, sample_t0, sample_t1)
+        if m is not None:
+            targets, boxes = m[2], m[3]
+            cur.wait_event(m[4])
+            for t in list(targets.values()) + [v for v in boxes.__dict__.values() if torch.is_tensor(v)]:
+                t.record_stream(cur)  # (allocated on the mining stream, consumed here)
         else:
-            pos, dims, rot, valid = boxes.pos.float(), boxes.dims.float().clamp(min=1e-3), boxes.rot.float(), boxes.valid
-        out = tuple(int(g) // 4 for g in self.cfg.data.img_grid_size)
-        targets = render_center_targets(pos, dims, rot, valid, out, tuple(self.cfg.data.bev_range_m))
+            f = self._take(self._flows, sample_t0, sample_t1)
+            if f is not None:
+                cur.wait_event(f[3])
+                f[2].record_stream(cur)
+                flow = f[2]
+            else:
+                with torch.no_grad():
+                    flow = self._infer_flow(sample_t0, sample_t1)
+            targets, boxes = self._targets_from_flow(sample_t0, flow)
+            if self.overlap and f is None:  # the static inference buffers were used on this stream up to here
+                self._main_used_static = torch.cuda.Event()
+                self._main_used_static.record(cur)
         self.last_boxes = boxes
-        return self.detector.step(sample_t0["pcl_full_no_ground_ta"], targets)
+        loss = self.detector.step(sample_t0["pcl_full_no_ground_ta"], targets)
+        if self.overlap and len(upcoming) > 0:
+            up = list(upcoming[:2])
+            has = lambda store, p: any(e[0] is p[0] and e[1] is p[1] for e in store)  # noqa: E731
+            self._mined = [e for e in self._mined if has([e], up[0]) or has([e], up[-1])]
+            self._flows = [e for e in self._flows if has([e], up[0]) or has([e], up[-1])]
+            for p_ in up:  # stage A first: the GPU works on it while the host walks through stage B
+                if not has(self._flows, p_) and not has(self._mined, p_):
+                    self._stage_a(p_)
+            if not has(self._mined, up[0]):
+                self._stage_b(up[0])
+        return loss

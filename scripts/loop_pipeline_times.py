@@ -1,0 +1,48 @@
+"""host-side wall time of the pipeline stages of LisoLoopTrainer.step (overlap=True): where does the host spend a step?"""
+import os, sys, time, collections
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from liso_amd.datasets.synthetic import slim_pair
+from liso_amd.trainer import LisoLoopTrainer, DetectorTrainer
+from liso_amd.utils.config import apply_slim_simple_knn_training, default_cfg
+
+dev = torch.device("cuda")
+overlap = "--no-overlap" not in sys.argv
+cfg = apply_slim_simple_knn_training(default_cfg(grid=512, bev_range_m=100.0))
+torch.manual_seed(0)
+tr = LisoLoopTrainer(cfg, dev, compute_dtype=torch.bfloat16, total_steps=400, use_graph=True, overlap=overlap)
+pairs = [slim_pair(2 + 100 * i, dev) for i in range(4)]
+acc = collections.defaultdict(float)
+
+
+def timed(obj, name, label=None):
+    fn = getattr(obj, name)
+    label = label or name
+
+    def w(*a, **k):
+        t = time.perf_counter()
+        r = fn(*a, **k)
+        acc[label] += time.perf_counter() - t
+        return r
+    setattr(obj, name, w)
+
+
+timed(tr, "_stage_a"); timed(tr, "_stage_b"); timed(tr, "_targets_from_flow"); timed(tr, "_infer_flow")
+timed(tr.detector, "step", "detector.step"); timed(tr.detector, "_pillars", "detector._pillars")
+timed(tr.detector.optimizer, "step", "optimizer.step")
+timed(tr, "cluster_detector", "cluster_detector")
+import liso_amd.utils.nms_iou as NI
+timed(NI, "perform_nms_on_shapes_padded", "nms")
+N = 50
+for i in range(8):
+    tr.step(*pairs[i % 4], upcoming=(pairs[(i + 1) % 4], pairs[(i + 2) % 4]))
+torch.cuda.synchronize(); acc.clear()
+t0 = time.perf_counter()
+for i in range(8, 8 + N):
+    tr.step(*pairs[i % 4], upcoming=(pairs[(i + 1) % 4], pairs[(i + 2) % 4]))
+t_host = time.perf_counter() - t0
+torch.cuda.synchronize()
+t_all = time.perf_counter() - t0
+print(f"overlap={overlap} ms/step {1e3 * t_all / N:.2f} (host loop {1e3 * t_host / N:.2f})")
+for k, v in sorted(acc.items(), key=lambda kv: -kv[1]):
+    print(f"  {k:24s} {1e3 * v / N:7.3f} ms/step")

@@ -136,3 +136,36 @@ def test_graph_replayed_loop_equals_eager_loop(grid, rng, n_points):
         tr = LisoLoopTrainer(cfg, dev, compute_dtype=torch.bfloat16, total_steps=20, use_graph=use_graph)
         out.append([float(tr.step(*pairs[i % 2])) for i in range(6)])
     assert out[0] == out[1], out
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_overlapped_loop_equals_sequential_loop(use_graph):
+    """LisoLoopTrainer(overlap=True): step(pair_i, upcoming=(pair_i+1, pair_i+2)) runs the frozen SLIM inference of pair i+2
+    and the flow clustering / NMS / target rendering of pair i+1 on two more HIP streams while the detector trains on pair
+    i.  The mined boxes depend on the frozen SLIM network and the sweeps only, so losses AND mined boxes must be identical
+    to the one-stream loop, step by step: three different pairs in rotation, calls whose announcements are wrong (the
+    prefetched results are then dropped, not used), short announcements and none at all."""
+    from liso_amd.datasets.synthetic import slim_pair
+    from liso_amd.trainer import LisoLoopTrainer
+    from liso_amd.utils.config import apply_slim_simple_knn_training, default_cfg
+
+    dev = torch.device("cuda")
+    grid, rng = 256, 50.0
+    pairs = [slim_pair(11 + i, dev, n_points=40000, grid=grid, bev_range_m=rng) for i in range(3)]
+    order = [0, 1, 2, 0, 2, 1, 1, 0, 2, 1]
+    announced = [(1, 2), (2, 0), (0, 1), (1, 2), (1,), (1, 0), (0, 2), (), (1, 1), ()]  # step 3 announces 1 but 2 follows
+    out = []
+    for overlap in (False, True):
+        cfg = apply_slim_simple_knn_training(default_cfg(grid=grid, bev_range_m=rng))
+        torch.manual_seed(0)
+        tr = LisoLoopTrainer(cfg, dev, compute_dtype=torch.bfloat16, total_steps=20, use_graph=use_graph, overlap=overlap)
+        losses, boxes = [], []
+        for i, a in zip(order, announced):
+            losses.append(float(tr.step(*pairs[i], upcoming=[pairs[k] for k in a])))
+            b = tr.last_boxes
+            boxes.append(torch.cat([b.pos.float(), b.dims.float(), b.rot.float(), b.valid[..., None].float()], dim=-1).cpu())
+        torch.cuda.synchronize()
+        out.append((losses, boxes))
+    assert out[0][0] == out[1][0], (out[0][0], out[1][0])
+    for a, b in zip(out[0][1], out[1][1]):
+        assert a.shape == b.shape and torch.equal(a, b)
