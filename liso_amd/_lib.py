@@ -121,6 +121,8 @@ SIGNATURES = {
     "liso_centerloss_fwd_f32": (_i, [_vp] * 17 + [_sz, _vp]),
     "liso_centerloss_bwd_f32": (_i, [_vp] * 21),
     "liso_render_center_targets_f32": (_i, [_vp] * 12),
+    # include/liso_optim.h
+    "liso_adamw_step_f32": (_i, [_vp, _vp, _vp, _vp, _sz] + [ctypes.c_double] * 5 + [ctypes.c_long, _vp]),
     # include/liso_bn.h
     "liso_bn_workspace_bytes": (_sz, [_i]),
     "liso_bn_relu_fwd": (_i, [_vp, _i, ctypes.c_long, _i, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _vp, _vp, _vp, _sz, _vp]),

@@ -15,11 +15,16 @@ from liso_amd.losses.centerpoint_loss import centerpoint_loss, rotation_vec_on_u
 from liso_amd.networks.simple_net.simple_net import BoxLearner
 
 
-def get_optimizer_scheduler(cfg, box_predictor, total_steps=None):
+def get_optimizer_scheduler(cfg, box_predictor, total_steps=None, flat=False):
     """liso_cli.py:792-823: AdamW(lr, weight_decay 0.01) + OneCycleLR(pct_start 0.4, momentum 0.85-0.95, div 10); training on
     ground truth runs one cycle over `num_training_steps` (+2, as in the reference), training on mined boxes one cycle per
     weight-drop period with final_div_factor 10.  `total_steps` overrides the cycle length (benchmarks)."""
-    opt = torch.optim.AdamW(box_predictor.parameters(), lr=cfg.optimization.learning_rate, weight_decay=0.01)
+    if flat:  # the same update as one launch over flat buffers (liso_amd/utils/flat_adamw.py, include/liso_optim.h)
+        from liso_amd.utils.flat_adamw import FlatAdamW
+
+        opt = FlatAdamW(box_predictor.parameters(), lr=cfg.optimization.learning_rate, weight_decay=0.01)
+    else:
+        opt = torch.optim.AdamW(box_predictor.parameters(), lr=cfg.optimization.learning_rate, weight_decay=0.01)
     common = dict(optimizer=opt, max_lr=cfg.optimization.learning_rate, pct_start=0.4, base_momentum=0.85, max_momentum=0.95,
                   div_factor=10.0)
     source = cfg.data.setdefault("train_on_box_source", "gt")
@@ -75,22 +80,19 @@ class DetectorTrainer:
             self.net.model.center_head.to(memory_format=torch.channels_last)
         self.model = self.net
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        # on the GPU the parameters, their gradients and the AdamW moments are views into four flat buffers: the update is one
+        # launch, the gradient all-reduce one collective, zero_grad one memset
+        self.optimizer, self.lr_scheduler = get_optimizer_scheduler(cfg, self.net, total_steps, flat=device.type == "cuda")
         if self.world > 1 and not self.use_graph:
             # ~19 MB of fp32 gradients: one flat bucket, launched as backward reaches the first layer's grads
             self.model = torch.nn.parallel.DistributedDataParallel(
                 self.net, device_ids=[device.index] if device.type == "cuda" else None, bucket_cap_mb=64,
-                broadcast_buffers=False, gradient_as_bucket_view=True)
+                broadcast_buffers=False, gradient_as_bucket_view=device.type != "cuda")
         if self.use_graph:
-            params = [p for p in self.net.parameters() if p.requires_grad]
-            self._flat_grad = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=device)
-            off = 0
-            for p in params:  # gradients are views into one flat buffer: one memset, one all-reduce
-                p.grad = self._flat_grad[off:off + p.numel()].view_as(p)
-                off += p.numel()
+            self._flat_grad = self.optimizer.flat_grad  # data parallelism: ONE all-reduce of this buffer after the replay
             if self.world > 1:  # replicas start identical (what the DDP constructor would do)
                 for t in list(self.net.parameters()) + list(self.net.buffers()):
                     dist.broadcast(t.data, src=0)
-        self.optimizer, self.lr_scheduler = get_optimizer_scheduler(cfg, self.net, total_steps)
         from liso_amd.networks.centerpoint.fused_bn import defer_batch_counters
         self._bn_counters = defer_batch_counters(self.net.model.rpn) + defer_batch_counters(self.net.model.center_head)
 

@@ -1,0 +1,81 @@
+"""AdamW over flat buffers: the detector's parameter update as ONE launch of liso_adamw_step_f32 (include/liso_optim.h).
+
+Drop-in for `torch.optim.AdamW(params, lr, weight_decay=0.01)` as the reference builds it (liso/liso_cli.py:792-823): a
+torch.optim.Optimizer with one parameter group carrying `lr` and `betas`, so `OneCycleLR` drives it unchanged (it rewrites
+the group's lr and beta1 before every step), and `state_dict()` keeps torch's layout (per parameter: step, exp_avg,
+exp_avg_sq).  Every parameter's `.data` and `.grad` become strided views (the parameter's own strides, channels-last
+included) into flat fp32 buffers with one element order, and so do both moments: the update is a single HBM-bound pass and
+data-parallel training all-reduces `flat_grad` in one RCCL call."""
+import torch
+
+from liso_amd import _lib as L
+
+
+def _dense(p):
+    """a tensor whose elements tile one contiguous block (contiguous in some dimension order)"""
+    return p.is_contiguous() or p.is_contiguous(memory_format=torch.channels_last) or \
+        (p.dim() == 5 and p.is_contiguous(memory_format=torch.channels_last_3d))
+
+
+class FlatAdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        params = [p for p in params if p.requires_grad]
+        assert len(params) > 0
+        dev = params[0].device
+        L.require_cuda(*params)
+        assert all(p.dtype == torch.float32 and p.device == dev for p in params), "fp32 master parameters on one device"
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        offs, off = [], 0
+        for p in params:
+            offs.append(off)
+            off += (p.numel() + 3) // 4 * 4  # 16-byte aligned views; the gaps stay zero in all four buffers
+        self.numel = off
+        self.flat_param = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.flat_exp_avg = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.flat_exp_avg_sq = torch.zeros(off, dtype=torch.float32, device=dev)
+        self._step = 0
+        for p, o in zip(params, offs):
+            if not _dense(p.data):
+                p.data = p.data.contiguous()
+            size, stride = p.shape, p.stride()
+            view = lambda flat: torch.as_strided(flat, size, stride, o)  # noqa: E731
+            view(self.flat_param).copy_(p.data)
+            p.data = view(self.flat_param)
+            g = view(self.flat_grad)
+            if p.grad is not None:
+                g.copy_(p.grad)
+            p.grad = g
+            self.state[p] = {"step": torch.tensor(0.0), "exp_avg": view(self.flat_exp_avg), "exp_avg_sq": view(self.flat_exp_avg_sq)}
+
+    def zero_grad(self, set_to_none=False):
+        """one memset; the .grad views stay (set_to_none is ignored: autograd accumulates into the flat buffer)"""
+        self.flat_grad.zero_()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        assert closure is None
+        assert len(self.param_groups) == 1, "one parameter group (the reference's optimizer has one)"
+        g = self.param_groups[0]
+        self._step += 1
+        with torch.cuda.device(self.flat_param.device):
+            L.check(L.TIMER.launch("adamw_flat", lambda: L.lib().liso_adamw_step_f32(
+                L.ptr(self.flat_param), L.ptr(self.flat_grad), L.ptr(self.flat_exp_avg), L.ptr(self.flat_exp_avg_sq), self.numel,
+                float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), self._step,
+                L.stream_ptr()), units=28 * self.numel), "adamw_step")
+        # the kernel wrote through a raw pointer: tell autograd / the packed-weight cache that every parameter changed
+        torch.autograd.graph.increment_version(g["params"])
+
+    def state_dict(self):
+        for st in self.state.values():
+            st["step"] = torch.tensor(float(self._step))
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        views = {p: (st["exp_avg"], st["exp_avg_sq"]) for p, st in self.state.items()}
+        super().load_state_dict(state_dict)
+        for p, (m, v) in views.items():  # keep the moments inside the flat buffers
+            st = self.state[p]
+            m.copy_(st["exp_avg"]), v.copy_(st["exp_avg_sq"])
+            self._step = int(float(st["step"]))
+            st["exp_avg"], st["exp_avg_sq"] = m, v

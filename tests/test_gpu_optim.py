@@ -1,0 +1,102 @@
+"""liso_adamw_step_f32 / FlatAdamW (include/liso_optim.h) against the reference's optimizer itself: torch.optim.AdamW driven by
+OneCycleLR exactly as liso/liso_cli.py:792-823 builds them, run on the CPU in fp32."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(64, 64, 3, 3), (64,), (7,), (128, 64, 3, 3), (3, 64, 1, 1), (1,), (9, 5), (2, 64, 2, 2)]
+
+
+def _make(seed, device):
+    g = torch.Generator().manual_seed(seed)
+    ps = []
+    for i, s in enumerate(SHAPES):
+        t = torch.randn(s, generator=g) * (0.05 if len(s) > 1 else 1.0)
+        if len(s) == 4 and i % 2 == 0:
+            t = t.contiguous(memory_format=torch.channels_last)
+        ps.append(torch.nn.Parameter(t.to(device)))
+    return ps
+
+
+def _sched(opt, total):
+    return torch.optim.lr_scheduler.OneCycleLR(optimizer=opt, max_lr=1e-3, pct_start=0.4, base_momentum=0.85, max_momentum=0.95,
+                                               div_factor=10.0, total_steps=total)
+
+
+def test_flat_adamw_follows_torch_adamw_with_onecycle():
+    from liso_amd.utils.flat_adamw import FlatAdamW
+
+    dev = torch.device("cuda")
+    ref_p, my_p = _make(0, "cpu"), _make(0, dev)
+    ref = torch.optim.AdamW(ref_p, lr=1e-3, weight_decay=0.01, foreach=False)
+    mine = FlatAdamW(my_p, lr=1e-3, weight_decay=0.01)
+    assert all(p.data_ptr() >= mine.flat_param.data_ptr() for p in my_p)
+    assert all(a.stride() == b.stride() and a.grad.stride() == a.stride() for a, b in zip(my_p, _make(0, dev)))
+    rs, ms = _sched(ref, 12), _sched(mine, 12)
+    g = torch.Generator().manual_seed(5)
+    for step in range(10):
+        v0 = my_p[0]._version
+        mine.zero_grad()
+        for a, b in zip(ref_p, my_p):
+            grad = torch.randn(a.shape, generator=g) * (10.0 ** ((step % 3) - 2))
+            if step == 4:
+                grad[grad.abs() < 0.5 * grad.abs().max()] = 0.0  # exact zeros: the update is -lr * 0 / (sqrt(v) + eps)
+            a.grad = grad.clone()
+            b.grad.add_(grad.to(dev))  # autograd accumulates into the flat views the same way
+        ref.step(), mine.step()
+        rs.step(), ms.step()
+        assert my_p[0]._version > v0  # the packed-weight cache keys on it
+        assert mine.param_groups[0]["lr"] == ref.param_groups[0]["lr"] and mine.param_groups[0]["betas"] == ref.param_groups[0]["betas"]
+        for a, b in zip(ref_p, my_p):
+            err = (a.detach() - b.detach().cpu()).abs().max() / a.detach().abs().max()
+            assert float(err) <= 2e-6, (step, tuple(a.shape), float(err))
+    sd = mine.state_dict()
+    st = sd["state"][0]
+    assert float(st["step"]) == 10.0
+    assert torch.allclose(st["exp_avg"].cpu(), ref.state[ref_p[0]]["exp_avg"], rtol=1e-5, atol=1e-9)
+    assert torch.allclose(st["exp_avg_sq"].cpu(), ref.state[ref_p[0]]["exp_avg_sq"], rtol=1e-5, atol=1e-12)
+    # the gaps between the 16-byte aligned views never move
+    used = torch.zeros(mine.numel, dtype=torch.bool, device=dev)
+    for p in my_p:
+        off = (p.data_ptr() - mine.flat_param.data_ptr()) // 4
+        used[off:off + p.numel()] = True
+    assert float(mine.flat_param[~used].abs().sum()) == 0.0
+
+
+def test_flat_adamw_state_dict_round_trip_continues_identically():
+    from liso_amd.utils.flat_adamw import FlatAdamW
+
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(9)
+    grads = [[torch.randn(s, generator=g).to(dev) for s in SHAPES] for _ in range(6)]
+
+    def run(split):
+        ps = _make(3, dev)
+        opt = FlatAdamW(ps, lr=1e-3, weight_decay=0.01)
+        for k in range(6):
+            if k == split:  # save, rebuild, load
+                sd = opt.state_dict()
+                ps2 = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+                opt = FlatAdamW(ps2, lr=1e-3, weight_decay=0.01)
+                opt.load_state_dict(sd)
+                ps = ps2
+            opt.zero_grad()
+            for p, gr in zip(ps, grads[k]):
+                p.grad.add_(gr)
+            opt.step()
+        return [p.detach().clone() for p in ps]
+
+    a, b = run(None), run(3)
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+
+
+def test_adamw_rejects_bad_arguments():
+    from liso_amd import _lib as L
+
+    x = torch.zeros(64, device="cuda")
+    lib = L.lib()
+    assert lib.liso_adamw_step_f32(L.ptr(x), L.ptr(x), L.ptr(x), None, 64, 1e-3, 0.9, 0.999, 1e-8, 0.01, 1, L.stream_ptr()) == -1
+    assert lib.liso_adamw_step_f32(L.ptr(x), L.ptr(x), L.ptr(x), L.ptr(x), 64, 1e-3, 0.9, 0.999, 1e-8, 0.01, 0, L.stream_ptr()) == -1
+    assert lib.liso_adamw_step_f32(L.ptr(x[1:]), L.ptr(x), L.ptr(x), L.ptr(x), 60, 1e-3, 0.9, 0.999, 1e-8, 0.01, 1, L.stream_ptr()) == -1
+    assert lib.liso_adamw_step_f32(L.ptr(x), L.ptr(x), L.ptr(x), L.ptr(x), 0, 1e-3, 0.9, 0.999, 1e-8, 0.01, 1, L.stream_ptr()) == 0
