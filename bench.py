@@ -45,6 +45,16 @@ def _seed_miopen_user_db():
     os.environ["MIOPEN_USER_DB_PATH"] = dst
 
 
+def _graph_env():
+    """`--workload slim --graph` captures autograd's reductions / rocPRIM scans, whose hipMemsetAsync nodes the runtime only
+    replays correctly with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 (liso_amd/utils/graph_safety.py); the loop / detector graphs hold
+    no memset node and keep the default (recorded packets: 1 ms per step faster).  Must be set before HIP initialises."""
+    if "--graph" in sys.argv and "slim" in sys.argv:
+        os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
+
+_graph_env()
+
 N_POINTS = 120000
 GRID = 512
 BEV_RANGE = 100.0
@@ -167,12 +177,13 @@ def pmc_traffic(workload, patterns):
         for pat in patterns:
             for kind, factor in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
                 path = os.path.join(ROOT, "profiles", f"{rnd}_{workload}_pmc_{kind}.csv")
-                vals = ([float(r["Counter_Value"]) for r in csv.DictReader(open(path)) if pat in r["Kernel_Name"]]
-                        if os.path.exists(path) else [])
-                if not vals:
+                rows = [r for r in csv.DictReader(open(path)) if pat in r["Kernel_Name"]] if os.path.exists(path) else []
+                if not rows:
                     ok = False
                     break
-                total += factor * 1024.0 * sum(vals) / len(vals)
+                # (round 2 on: one row per kernel instantiation = mean over its launches, weighted by the launch count)
+                wts = [float(r.get("Launches") or 1.0) for r in rows]
+                total += factor * 1024.0 * sum(float(r["Counter_Value"]) * w for r, w in zip(rows, wts)) / sum(wts)
             if not ok:
                 break
         if ok:
@@ -180,8 +191,9 @@ def pmc_traffic(workload, patterns):
     return None, None
 
 
-PMC_PATTERNS = {"conv_bf16_fwd": ["conv_igemm_kernel"], "conv_bf16_dgrad": ["conv_igemm_kernel"], "conv_bf16_wgrad": ["conv_wgrad_kernel"],
-                "conv_f32x3_fwd": ["conv_igemm_kernel"], "conv_f32x3_dgrad": ["conv_igemm_kernel"], "conv_f32x3_wgrad": ["conv_wgrad_kernel"],
+# (template argument 1 of the convolution kernels = arithmetic: 0 bf16, 1 f32x3; forward and data gradient share the kernel)
+PMC_PATTERNS = {"conv_bf16_fwd": ["conv_igemm_kernel<0,"], "conv_bf16_dgrad": ["conv_igemm_kernel<0,"], "conv_bf16_wgrad": ["conv_wgrad_kernel<0,"],
+                "conv_f32x3_fwd": ["conv_igemm_kernel<1,"], "conv_f32x3_dgrad": ["conv_igemm_kernel<1,"], "conv_f32x3_wgrad": ["conv_wgrad_kernel<1,"],
                 "knn_query": ["knn_query_kernel"], "corr_lookup_fwd": ["corr_lookup_fwd_kernel"],
                 "pfn_forward_scatter": ["pfn_forward_kernel"],
                 "dbscan_components": ["dbscan_core_kernel", "dbscan_union_kernel", "dbscan_flatten_kernel"]}

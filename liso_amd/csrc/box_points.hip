@@ -7,6 +7,7 @@
 // boxes), so the per-box accumulators live in LDS and take integer atomics; a block adds its non-zero accumulators to HBM
 // once.  120k points x 100 boxes = 469 blocks, x 1000 boxes = 3752 blocks (>> 256 CUs).
 #include <hip/hip_runtime.h>
+#include "zero_fill.h"
 #include <math.h>
 #include <stdint.h>
 
@@ -251,9 +252,9 @@ extern "C" int liso_points_in_boxes_f32(const liso_boxpts_cfg* c, const float* b
     if (mean_flow != nullptr) {
         if (workspace == nullptr || workspace_bytes < liso_points_in_boxes_workspace_bytes(c)) return LISO_EWORKSPACE;
         fsum = (long long*)workspace;
-        if (hipMemsetAsync(fsum, 0, rows * 3 * sizeof(long long), s) != hipSuccess) return LISO_ELAUNCH;
+        if (liso_zero::zero_async(fsum, rows * 3 * sizeof(long long), s) != hipSuccess) return LISO_ELAUNCH;
     }
-    if (count != nullptr && hipMemsetAsync(count, 0, rows * sizeof(int), s) != hipSuccess) return LISO_ELAUNCH;
+    if (count != nullptr && liso_zero::zero_async(count, rows * sizeof(int), s) != hipSuccess) return LISO_ELAUNCH;
     if (c->n > 0) {
         const dim3 grid((unsigned)((c->n + kThreads - 1) / kThreads), (unsigned)((c->k + kTile - 1) / kTile), (unsigned)c->batch);
         const float* fl = mean_flow != nullptr ? flow : nullptr;

@@ -7,6 +7,7 @@
 //                        min / max of the in-box z in registers: no [N,K,4] fp64 tensor (192 MB at N=120k, K=50)
 //   fit_z_final_kernel   fixed-order combine of the block partials (min/max/sum are order independent)
 #include <hip/hip_runtime.h>
+#include "zero_fill.h"
 #include <math.h>
 #include <stdint.h>
 
@@ -186,7 +187,7 @@ int liso_bev_dynamic_flow_f32(const float* points, int point_stride, const uint8
     const size_t cells = (size_t)batch * h * w;
     long long* sums = (long long*)workspace;
     int* counts = (int*)(sums + cells * 4);
-    if (hipMemsetAsync(workspace, 0, need, st) != hipSuccess) return LISO_ELAUNCH;
+    if (liso_zero::zero_async(workspace, need, st) != hipSuccess) return LISO_ELAUNCH;
     const size_t total = (size_t)batch * n;
     if (total > 0)
         bev_scatter_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(points, point_stride, valid, pillar_coors, flow,

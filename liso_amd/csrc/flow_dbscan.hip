@@ -22,6 +22,7 @@
 //   region_props    one thread per label: centroid, orientation, axis lengths from the second central moments
 //                   (skimage.measure.regionprops formulas, fp64)
 #include <hip/hip_runtime.h>
+#include "zero_fill.h"
 #include <math.h>
 #include <stdint.h>
 
@@ -243,7 +244,7 @@ int liso_region_props(const int32_t* labels, int batch, int gx, int gy, int max_
     hipStream_t st = (hipStream_t)stream;
     const size_t total = (size_t)batch * gx * gy;
     const long regions = (long)batch * max_labels;
-    if (hipMemsetAsync(moments, 0, (size_t)regions * 6 * sizeof(uint64_t), st) != hipSuccess) return LISO_ELAUNCH;
+    if (liso_zero::zero_async(moments, (size_t)regions * 6 * sizeof(uint64_t), st) != hipSuccess) return LISO_ELAUNCH;
     region_moments_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(labels, batch, gx, gy, max_labels,
                                                                           (unsigned long long*)moments);
     region_props_kernel<<<(unsigned)((regions + 255) / 256), 256, 0, st>>>((const unsigned long long*)moments, regions, props);

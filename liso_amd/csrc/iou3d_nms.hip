@@ -20,6 +20,7 @@
 // Built with -ffp-contract=off: the geometry must round like the reference's host code (no FMA).
 // sin/cos are evaluated in double and rounded to float, which matches glibc's sinf/cosf in practice.
 #include <hip/hip_runtime.h>
+#include "zero_fill.h"
 #include <math.h>
 #include <stdint.h>
 
@@ -411,7 +412,7 @@ int launch_nms(bool normal, const float* boxes, int n, float thresh, int64_t* ke
     if (n < 0 || !num_out) return LISO_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     if (n == 0) {
-        if (hipMemsetAsync(num_out, 0, sizeof(int), st) != hipSuccess) return LISO_ELAUNCH;
+        if (liso_zero::zero_async(num_out, sizeof(int), st) != hipSuccess) return LISO_ELAUNCH;
         return LISO_OK;
     }
     if (!boxes || !keep || !ws) return LISO_EINVAL;

@@ -17,6 +17,7 @@
 //     instead of 2x64 per-channel sums over [P*20, 64]; the same moments give the BN backward terms in closed form.
 //   * all cross-workgroup reductions are two-stage with fixed order (no float atomics): results are reproducible.
 #include <hip/hip_runtime.h>
+#include "zero_fill.h"
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/iterator/counting_iterator.hpp>
@@ -755,9 +756,9 @@ int liso_pillars_voxelize_f32(const float* points, const int* offsets_host, int 
     size_t sort_bytes = sort_temp_bytes(cells, n_total);
     const BatchInfo bi = make_batch(offsets_host, batch);
     const int tiles = bi.tile_off[batch];
-    if (hipMemsetAsync(count, 0, 2 * cells * sizeof(int), st) != hipSuccess) return LISO_ELAUNCH;
-    if (hipMemsetAsync(cell_to_voxel, 0, cells * sizeof(int), st) != hipSuccess) return LISO_ELAUNCH;
-    if (hipMemsetAsync(num_voxels, 0, batch * sizeof(int), st) != hipSuccess) return LISO_ELAUNCH;
+    if (liso_zero::zero_async(count, 2 * cells * sizeof(int), st) != hipSuccess) return LISO_ELAUNCH;
+    if (liso_zero::zero_async(cell_to_voxel, cells * sizeof(int), st) != hipSuccess) return LISO_ELAUNCH;
+    if (liso_zero::zero_async(num_voxels, batch * sizeof(int), st) != hipSuccess) return LISO_ELAUNCH;
     if (n_total == 0) return LISO_OK;
     const int nb = (n_total + 255) / 256;
     hipLaunchKernelGGL(assign_kernel, dim3(nb), dim3(256), 0, st, points, n_total, cfg->n_channels, bi, batch, *cfg,

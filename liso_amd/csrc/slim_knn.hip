@@ -13,6 +13,7 @@
 //                unvisited point is at least r*cell + (distance to the own cell's nearest edge) away, so the search
 //                stops as soon as best <= that bound (exact), or when the rings cover the whole grid.
 #include <hip/hip_runtime.h>
+#include "zero_fill.h"
 #include <math.h>
 #include <stdint.h>
 
@@ -272,7 +273,7 @@ int liso_knn_build_f32(const liso_knn_grid* grid, const float* ref, int ref_stri
     int* block_tot = start + cells + 1;
     int* cell_of_pt = block_tot + kTotSlots;
     float4* bucketed = (float4*)((char*)workspace + align16((3 * (size_t)cells + 1 + kTotSlots + (size_t)n_ref) * sizeof(int)));
-    if (hipMemsetAsync(count, 0, 2 * (size_t)cells * sizeof(int), st) != hipSuccess) return LISO_ELAUNCH;
+    if (liso_zero::zero_async(count, 2 * (size_t)cells * sizeof(int), st) != hipSuccess) return LISO_ELAUNCH;
     if (n_ref > 0) knn_count_kernel<<<(n_ref + 255) / 256, 256, 0, st>>>(*grid, ref, ref_stride, n_ref, count, cell_of_pt);
     const int nsb = (cells + 1023) / 1024;
     knn_scan_block_kernel<<<nsb, 1024, 0, st>>>(count, cells, start, block_tot);

@@ -10,6 +10,8 @@ from typing import Dict
 
 import numpy as np
 import torch
+
+from liso_amd.utils.graph_safety import channel_extrema, two_stage_amax, two_stage_amin
 from torch import nn
 
 from liso_amd.slim.slim_loss.numerical_stability import normalized_sigmoid_sum
@@ -243,7 +245,7 @@ class HeadDecoder(nn.Module):
         extremes = None
         if any(v is True or v is False for v in (om.static_logit, om.dynamic_logit, om.ground_logit)):
             lg = network_output[..., :4].detach()
-            extremes = (lg.amax(dim=(0, 1, 2)), lg.amin(dim=(0, 1, 2)))
+            extremes = channel_extrema(lg)  # (staged: no inter-block semaphores, see liso_amd/utils/graph_safety.py)
         # metric centre of every point's pillar: get_voxel_center_coords_m's fp64 arithmetic (bev_utils.py:24-40) on the
         # point's own (row, col) -- bit-identical to reading the [H,W,2] centre map, without a 16-byte-row gather
         lo, span = self._extent_vectors(inv_odom.device)
@@ -380,7 +382,7 @@ def _extreme(a, b, fn):
         tag = getattr(t, "_bev_extreme", None)
         if tag is not None:
             return tag[0] if fn is torch.max else tag[1]
-        return t.detach().amax() if fn is torch.max else t.detach().amin()
+        return two_stage_amax(t) if fn is torch.max else two_stage_amin(t)
     return torch.maximum(one(a), one(b)) if fn is torch.max else torch.minimum(one(a), one(b))
 
 

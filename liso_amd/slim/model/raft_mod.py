@@ -45,15 +45,18 @@ class RAFT(nn.Module):
                                  dropout=self.slim_cfg.model.dropout_rate)
         self.update_block = SmallUpdateBlock(cfg=self.slim_cfg, filters=self.hidden_dim)
 
-    def forward(self, pcl_t0, pcl_t1):
+    def forward(self, pcl_t0, pcl_t1, canvases=None):
         """reference :82-122.  The forward (t0->t1) and backward (t1->t0) flow estimates share every weight and never
         interact inside the network (instance norm in `fnet`, no norm elsewhere), so they run as ONE batch of 2B samples
         through the encoders, the correlation lookup and the 6 update iterations: per-sample results are those of the
         reference's two sequential calls, with half the launches and twice the work per convolution (the 64x64 update
         maps of a single sample cannot fill 256 CUs).  The pillar encoder stays per sweep: its BatchNorm1d statistics are
         per call in the reference."""
-        img_t0, occ_t0 = self.pp_layer(pcl_t0)
-        img_t1, occ_t1 = self.pp_layer(pcl_t1)
+        if canvases is not None:  # (extension) precomputed pillar canvases: callers that replay the rest from a hipGraph
+            img_t0, occ_t0, img_t1, occ_t1 = canvases
+        else:
+            img_t0, occ_t0 = self.pp_layer(pcl_t0)
+            img_t1, occ_t1 = self.pp_layer(pcl_t1)
         aux = {"t0": {"bev_net_input_dbg": occ_t0}, "t1": {"bev_net_input_dbg": occ_t1}}
         if not getattr(self, "batch_directions", True):  # the reference's schedule: two sequential passes (:95-121)
             fmap_t0, fmap_t1 = self.fnet(img_t0), self.fnet(img_t1)
@@ -74,10 +77,9 @@ class RAFT(nn.Module):
         aux["fw_bw_batched"] = both  # per iteration [2B,H,W,8]: samples [:B] = forward flow, [B:] = backward flow
         return [p[:B] for p in both], [p[B:] for p in both], aux
 
-    @torch.no_grad()
-    @torch.no_grad()
     def encode_pillars(self, pcl_t0, pcl_t1):
-        """the pillar canvases of both sweeps: (img_t0, occ_t0, img_t1, occ_t1)"""
+        """the pillar canvases of both sweeps: (img_t0, occ_t0, img_t1, occ_t1); differentiable w.r.t. the pillar encoder's
+        parameters when gradients are enabled"""
         return (*self.pp_layer(pcl_t0), *self.pp_layer(pcl_t1))
 
     def infer_forward_direction(self, pcl_t0, pcl_t1, canvases=None):

@@ -49,26 +49,46 @@ class SLIM(nn.Module):
         self.raft_network = RAFT(cfg=cfg, head_decoder_fw=self.head_decoder_fw, head_decoder_bw=self.head_decoder_bw)
 
     @torch.no_grad()
-    def infer_point_flow_t0_t1(self, sample_data_t0, sample_data_t1, canvases=None):
+    def infer_point_flow_t0_t1(self, sample_data_t0, sample_data_t1, canvases=None, dynamicness_threshold=None):
         """Per-point flow t0 -> t1 of the sweep at t0 (`aggregated_flow` of the last RAFT iteration, [B,N,3]): what
-        FlowClusterDetector consumes.  One flow direction, one decode -- the training forward produces 12."""
+        FlowClusterDetector consumes.  One flow direction, one decode -- the training forward produces 12.
+        `dynamicness_threshold`: `moving_dynamicness_threshold.value()` computed by the caller (a device scan: callers that
+        replay this method from a hipGraph evaluate it eagerly, liso_amd/utils/graph_safety.py)."""
         dev = next(self.raft_network.parameters()).device
         net_out, aux = self.raft_network.infer_forward_direction(
             get_network_input_pcls(self.cfg, sample_data_t0, "ta", to_device=dev),
             get_network_input_pcls(self.cfg, sample_data_t1, "ta", to_device=dev), canvases=canvases)
         pa = sample_data_t0["pcl_ta"]
         pred = self.head_decoder_fw(
-            net_out, self.moving_dynamicness_threshold.value(), pc=pa["pcl"].to(dev),
+            net_out, self.moving_dynamicness_threshold.value() if dynamicness_threshold is None else dynamicness_threshold,
+            pc=pa["pcl"].to(dev),
             pointwise_voxel_coordinates=pa["pillar_coors"].to(dev), pointwise_valid_mask=pa["pcl_is_valid"].to(dev),
             filled_pillar_mask=torch.squeeze(aux["t0"]["bev_net_input_dbg"] > 0.5, dim=1),
             odom=sample_data_t0["gt"]["odom_ta_tb"].to(dev), inv_odom=sample_data_t1["gt"]["odom_ta_tb"].to(dev), summaries=None,
             dynamic_flow_is_non_rigid_flow=self.slim_cfg.model.dynamic_flow_is_non_rigid_flow)
         return pred.aggregated_flow
 
-    def forward(self, sample_data_t0, sample_data_t1, summaries=None):
+    def build_gather_plan(self, sample_data_t0, sample_data_t1, n_it, grid_hw):
+        """point -> BEV cell lists of the batch the decoder sees in forward(): [forward samples x n_it | backward samples x n_it].
+        Depends on the sweeps only (a large device sort): callers that replay forward() from a hipGraph build it eagerly."""
         dev = next(self.raft_network.parameters()).device
-        out_fw, out_bw, aux = self.raft_network(get_network_input_pcls(self.cfg, sample_data_t0, "ta", to_device=dev),
-                                                get_network_input_pcls(self.cfg, sample_data_t1, "ta", to_device=dev))
+        pa, pb = sample_data_t0["pcl_ta"], sample_data_t1["pcl_ta"]
+        B = pa["pcl"].shape[0]
+        fs = self.slim_cfg.model.u_net.final_scale
+        cat = lambda a, b: torch.cat([a.to(dev), b.to(dev)], dim=0)  # noqa: E731
+        tile = lambda t: torch.cat([t[:B]] * n_it + [t[B:]] * n_it, dim=0)  # noqa: E731
+        valid_all, coors_all = tile(cat(pa["pcl_is_valid"], pb["pcl_is_valid"])), tile(cat(pa["pillar_coors"], pb["pillar_coors"]))
+        return BevGatherPlan(torch.div(coors_all, fs, rounding_mode="trunc"), valid_all, grid_hw)
+
+    def forward(self, sample_data_t0, sample_data_t1, summaries=None, canvases=None, gather_plan=None):
+        """`canvases` (extension): the pillar canvases of both sweeps, `raft_network.encode_pillars(...)`, computed by the caller;
+        `gather_plan` (extension): `build_gather_plan(...)` of these samples, computed by the caller"""
+        dev = next(self.raft_network.parameters()).device
+        if canvases is not None:
+            out_fw, out_bw, aux = self.raft_network(None, None, canvases=canvases)
+        else:
+            out_fw, out_bw, aux = self.raft_network(get_network_input_pcls(self.cfg, sample_data_t0, "ta", to_device=dev),
+                                                    get_network_input_pcls(self.cfg, sample_data_t1, "ta", to_device=dev))
         filled0 = torch.squeeze(aux["t0"]["bev_net_input_dbg"] > 0.5, dim=1)
         filled1 = torch.squeeze(aux["t1"]["bev_net_input_dbg"] > 0.5, dim=1)
         thr = self.moving_dynamicness_threshold.value()
@@ -100,7 +120,9 @@ class SLIM(nn.Module):
                 net_all = torch.cat([p[:B] for p in batched] + [p[B:] for p in batched], dim=0)
             tile = lambda t: torch.cat([t[:B]] * n_it + [t[B:]] * n_it, dim=0)  # noqa: E731
             pc_all, valid_all, coors_all = tile(pc), tile(valid), tile(coors)
-            plan = BevGatherPlan(torch.div(coors_all, fs, rounding_mode="trunc"), valid_all, out_fw[0].shape[1:3])
+            self.gather_plan_meta = (n_it, tuple(int(v) for v in out_fw[0].shape[1:3]))
+            plan = gather_plan if gather_plan is not None else BevGatherPlan(torch.div(coors_all, fs, rounding_mode="trunc"), valid_all,
+                                                                             out_fw[0].shape[1:3])
             out_all = self.head_decoder_fw(net_all, pointwise_valid_mask=valid_all, pointwise_voxel_coordinates=coors_all, pc=pc_all,
                                            filled_pillar_mask=tile(filled), odom=tile(odom), inv_odom=tile(inv_odom),
                                            gather_plan=plan, pointwise_only=self.training and getattr(self, "pointwise_decoding", True),

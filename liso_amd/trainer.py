@@ -267,6 +267,9 @@ class SlimTrainer:
         self.bev_extent = np.concatenate([-half, half], axis=0)
         self._graph, self._graph_sig = None, None
         if self.use_graph:
+            from liso_amd.utils.graph_safety import require_node_replay
+
+            require_node_replay("SlimTrainer(use_graph=True)")
             # once-per-step weight gradients of the update block (deferred_wgrad.py): inside a captured graph the gate adds them
             # into the flat gradient buffer itself ("direct"); returned to autograd they would go through AccumulateGrad nodes
             # bound to the warm-up's stream -- a cross-stream hop the capture cannot contain (wrong losses / crashes, measured)
@@ -286,9 +289,10 @@ class SlimTrainer:
         pc2, m2 = sample_t1["pcl_ta"]["pcl"].to(self.device), sample_t1["pcl_ta"]["pcl_is_valid"].to(self.device)
         return pc1, m1, pc2, m2
 
-    def loss(self, sample_t0, sample_t1, all_valid=None):
+    def loss(self, sample_t0, sample_t1, all_valid=None, canvases=None, gather_plan=None):
         """`all_valid` = (bool, bool): whether every row of the two loss clouds is a real point; evaluated here (the step's
-        only device->host sync, before any work is queued) unless the caller already knows."""
+        only device->host sync, before any work is queued) unless the caller already knows.  `canvases`: precomputed pillar
+        canvases of both sweeps (the hipGraph path keeps the pillar encoder outside of the graph)."""
         from liso_amd.slim.slim_loss.knn_graph import KnnIndex
         from liso_amd.slim.slim_loss.slim_loss_adaptor import selfsupervisedSlimSingleScaleLoss
 
@@ -299,7 +303,10 @@ class SlimTrainer:
         # bucket both clouds before the network runs
         idx1 = [KnnIndex(pc1[b][:, :3], extent=ext, all_rows_finite=True) for b in range(pc1.shape[0])] if all_valid[0] else None
         idx2 = [KnnIndex(pc2[b][:, :3], extent=ext, all_rows_finite=True) for b in range(pc2.shape[0])] if all_valid[1] else None
-        preds_fw, preds_bw = self.model(sample_t0, sample_t1, None)
+        if canvases is None:
+            preds_fw, preds_bw = self.model(sample_t0, sample_t1, None)
+        else:
+            preds_fw, preds_bw = self.model(sample_t0, sample_t1, None, canvases=canvases, gather_plan=gather_plan)
         kw = dict(moving_thresh_module=self.net.moving_dynamicness_threshold, loss_cfg=self.slim_cfg.losses.unsupervised,
                   model_cfg=self.slim_cfg.model, bev_extent=self.bev_extent, metrics_collector={})
         stacked = getattr(self.net, "stacked_predictions", None)
@@ -379,17 +386,48 @@ class SlimTrainer:
         self._static = self._map_tensors((sample_t0, sample_t1), lambda t: t.to(dev).clone())
         s0, s1 = self._static
         buffers = {k: v.clone() for k, v in self.net.state_dict().items() if v.is_floating_point() or v.dtype == torch.long}
+        # The pillar encoder stays OUTSIDE the graph (as in DetectorTrainer): a graph that holds its launches faults -- a GPU
+        # memory access fault inside a later replay -- once a few thousand eager launches (the optimizer's, here) have run
+        # between replays (scripts/debug_slim_graph_fault*.py: replays alone, copies, allocations, the scheduler are harmless;
+        # RMSprop.step() with lr = 0 is enough; independent of the convolution backend).  The canvases become graph inputs, their
+        # gradients graph outputs, and the encoder's own backward runs eagerly on them.
+        with torch.no_grad():
+            canv = self._pillars(sample_t0, sample_t1)
+        self._static_canv = tuple(c.detach().clone() for c in canv)
+        for i in (0, 2):
+            self._static_canv[i].requires_grad_(True)
+            self._static_canv[i].grad = torch.zeros_like(self._static_canv[i])
         quiet = hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch")
         if quiet:
             # the flat gradient views are created on the default stream, warm-up and capture run on side streams
             torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
+        # So does the decoder's point -> cell plan: a torch.sort of 12 x B x N (2.9 M) keys.  A captured torch.sort of more than
+        # ~1 M keys is what makes the replay fault after a few thousand unrelated eager launches (scripts/debug_pillar_graph_fault.py:
+        # 1.0 M keys replay cleanly, 1.5 M fault; rocPRIM's large-input radix sort on this ROCm build) -- the root cause of the
+        # "graph + eager launches" faults of rounds 1-2.  The plan depends on the sweeps only: built eagerly, copied in.
+        self._static_plan = None
+        meta = getattr(self.net, "gather_plan_meta", None)
+        if meta is None:
+            with torch.no_grad():
+                self.net(s0, s1, None, canvases=self._static_canv)
+            meta = getattr(self.net, "gather_plan_meta", None)
+        if meta is not None:
+            self._static_plan = self.net.build_gather_plan(s0, s1, *meta)
+            self._static_plan.lin64  # (its lazily built int64 copy is a graph input too)
+
+        def body():
+            self._flat_grad.zero_()
+            for i in (0, 2):
+                self._static_canv[i].grad.zero_()
+            total, _, _ = self.loss(s0, s1, all_valid, canvases=self._static_canv, gather_plan=self._static_plan)
+            total.backward()
+            return total.detach()
+
         with torch.cuda.stream(side):  # warm-up off the capture: MIOpen / rocBLAS pick their kernels, caches fill
             for _ in range(2):
-                self._flat_grad.zero_()
-                total, _, _ = self.loss(s0, s1, all_valid)
-                total.backward()
+                body()
         torch.cuda.current_stream(dev).wait_stream(side)
         with torch.no_grad():  # the warm-up passes must not count as training steps (BN / threshold statistics)
             for k, v in self.net.state_dict().items():
@@ -399,10 +437,7 @@ class SlimTrainer:
         # capture on the warm-up's stream: the AccumulateGrad nodes of the parameters live there (a capture on another stream
         # forks into it: wrong results, measured on the detector step)
         with torch.cuda.graph(self._graph, stream=side):
-            self._flat_grad.zero_()
-            total, _, _ = self.loss(s0, s1, all_valid)
-            total.backward()
-            self._static_loss = total.detach()
+            self._static_loss = body()
         with torch.no_grad():  # capture does not execute, but restore anyway in case the backend ran eagerly
             for k, v in self.net.state_dict().items():
                 if k in buffers:
@@ -423,10 +458,29 @@ class SlimTrainer:
             return True
         return False
 
+    def _pillars(self, sample_t0, sample_t1):
+        from liso_amd.slim.model.slim import get_network_input_pcls
+
+        dev = self.device
+        return self.net.raft_network.encode_pillars(get_network_input_pcls(self.cfg, sample_t0, "ta", to_device=dev),
+                                                    get_network_input_pcls(self.cfg, sample_t1, "ta", to_device=dev))
+
     def _graph_step(self, sample_t0, sample_t1):
         if not self.capture(sample_t0, sample_t1):
             self._copy_tensors(self._static, (sample_t0, sample_t1))
+        canv = self._pillars(sample_t0, sample_t1)  # eager, with autograd: the encoder's parameters get their gradients below
+        with torch.no_grad():
+            for d, c in zip(self._static_canv, canv):
+                d.copy_(c.detach(), non_blocking=True)
+            if self._static_plan is not None:
+                fresh = self.net.build_gather_plan(sample_t0, sample_t1, *self.net.gather_plan_meta)
+                for name in ("lin", "sorted_lin", "order", "seg_rank"):
+                    getattr(self._static_plan, name).copy_(getattr(fresh, name), non_blocking=True)
+                self._static_plan.lin64.copy_(fresh.lin, non_blocking=True)
         self._graph.replay()
+        live = [(canv[i], self._static_canv[i].grad) for i in (0, 2) if canv[i].requires_grad]
+        if live:
+            torch.autograd.backward([c for c, _ in live], [g for _, g in live])
         self._reduce_and_update()
         return self._static_loss.clone()  # the captured output is overwritten by the next replay
 
@@ -494,24 +548,29 @@ class LisoLoopTrainer:
         with torch.no_grad():  # pillar encoder eagerly (see DetectorTrainer: its launches must not be replayed from a graph here)
             canv = raft.encode_pillars(get_network_input_pcls(self.cfg, sample_t0, "ta", to_device=dev),
                                        get_network_input_pcls(self.cfg, sample_t1, "ta", to_device=dev))
+        with torch.no_grad():  # a device scan (torch.cumsum): eagerly, its memset nodes do not survive in a graph (graph_safety.py)
+            thr = self.slim.moving_dynamicness_threshold.value()
         if self._infer_graph is None or sig != self._infer_sig:
             self._static_in = SlimTrainer._map_tensors((sample_t0, sample_t1), lambda t: t.to(dev).clone())
             self._static_canv = tuple(c.clone() for c in canv)
+            self._static_thr = thr.clone()
             s0, s1 = self._static_in
             side = self._flow_stream  # (HIP maps streams onto 4 hardware queues: capture on a pipeline stream, no extra one)
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side), torch.no_grad():
                 for _ in range(2):
-                    self.slim.infer_point_flow_t0_t1(s0, s1, canvases=self._static_canv)
+                    self.slim.infer_point_flow_t0_t1(s0, s1, canvases=self._static_canv, dynamicness_threshold=self._static_thr)
             torch.cuda.current_stream(dev).wait_stream(side)
             self._infer_graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._infer_graph, stream=side), torch.no_grad():
-                self._static_flow = self.slim.infer_point_flow_t0_t1(s0, s1, canvases=self._static_canv)
+                self._static_flow = self.slim.infer_point_flow_t0_t1(s0, s1, canvases=self._static_canv,
+                                                                     dynamicness_threshold=self._static_thr)
             self._infer_sig = sig
         else:
             SlimTrainer._copy_tensors(self._static_in, (sample_t0, sample_t1))
             for d, c in zip(self._static_canv, canv):
                 d.copy_(c, non_blocking=True)
+            self._static_thr.copy_(thr, non_blocking=True)
         self._infer_graph.replay()
         return self._static_flow
 

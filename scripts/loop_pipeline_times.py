@@ -34,6 +34,15 @@ timed(tr, "cluster_detector", "cluster_detector")
 import liso_amd.utils.nms_iou as NI
 timed(NI, "perform_nms_on_shapes_padded", "nms")
 N = 50
+if "--fake-b" in sys.argv:  # upper bound: stage B costs neither host nor GPU time (reuses the first mined result)
+    cache = {}
+    real = tr._targets_from_flow
+
+    def fake(sample_t0, flow):
+        if "r" not in cache:
+            cache["r"] = real(sample_t0, flow)
+        return cache["r"]
+    tr._targets_from_flow = fake
 for i in range(8):
     tr.step(*pairs[i % 4], upcoming=(pairs[(i + 1) % 4], pairs[(i + 2) % 4]))
 torch.cuda.synchronize(); acc.clear()

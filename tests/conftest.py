@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# SlimTrainer(use_graph=True) requires it (liso_amd/utils/graph_safety.py); must be in the environment before HIP initialises.
+# tests/test_gpu_liso_loop.py::test_long_graph_loop_with_recorded_packets runs the loop's graphs WITHOUT it in a child process.
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

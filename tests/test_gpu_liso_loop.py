@@ -169,3 +169,47 @@ def test_overlapped_loop_equals_sequential_loop(use_graph):
     assert out[0][0] == out[1][0], (out[0][0], out[1][0])
     for a, b in zip(out[0][1], out[1][1]):
         assert a.shape == b.shape and torch.equal(a, b)
+
+
+def test_long_graph_loop_with_recorded_packets():
+    """The loop's two hipGraphs replayed from packets recorded at instantiation (the runtime's default, what bench.py times; this
+    test suite otherwise runs with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0): 40 iterations with ~2000 extra eager launches between the
+    steps -- four times the number of launches after which a captured hipMemsetAsync node stops working on this runtime
+    (liso_amd/utils/graph_safety.py) -- must reproduce the eager loop's losses exactly.  Runs in a child process: the switch is
+    read when HIP initialises."""
+    import os
+    import subprocess
+    import sys
+
+    code = r'''
+import torch
+from liso_amd.datasets.synthetic import slim_pair
+from liso_amd.trainer import LisoLoopTrainer
+from liso_amd.utils.config import apply_slim_simple_knn_training, default_cfg
+dev = torch.device("cuda")
+grid, rng = 256, 50.0
+pairs = [slim_pair(21 + i, dev, n_points=40000, grid=grid, bev_range_m=rng) for i in range(3)]
+out = []
+for use_graph in (False, True):
+    cfg = apply_slim_simple_knn_training(default_cfg(grid=grid, bev_range_m=rng))
+    torch.manual_seed(0)
+    tr = LisoLoopTrainer(cfg, dev, compute_dtype=torch.bfloat16, total_steps=60, use_graph=use_graph, overlap=use_graph)
+    # a trained-looking dynamicness histogram: the threshold then really depends on the scan
+    g = torch.Generator().manual_seed(3)
+    tr.slim.moving_dynamicness_threshold.moving_average_importance.copy_((torch.randn(100000, generator=g) * 1e-3).to(dev))
+    tr.slim.moving_dynamicness_threshold.bias_counter.fill_(1.0)
+    t = torch.zeros(64, device=dev)
+    losses = []
+    for i in range(40):
+        losses.append(float(tr.step(*pairs[i % 3], upcoming=(pairs[(i + 1) % 3], pairs[(i + 2) % 3]))))
+        for _ in range(2000):
+            t.add_(1.0)
+    out.append(losses)
+assert out[0] == out[1], [(i, a, b) for i, (a, b) in enumerate(zip(*out)) if a != b][:5]
+print("EQUAL", out[1][-1])
+'''
+    env = {k: v for k, v in os.environ.items() if k != "DEBUG_CLR_GRAPH_PACKET_CAPTURE"}
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0 and "EQUAL" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
