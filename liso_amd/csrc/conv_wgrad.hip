@@ -48,6 +48,7 @@ struct WgArgs {
     int x_plane_bytes;  // multiple of 16
     int psx;            // LDS bytes per x pixel
     int th;             // tile rows
+    int pipelined;      // bf16: the halo tile fits one register batch -> tile k+1 is loaded during the MFMAs of tile k
 };
 
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
@@ -117,6 +118,173 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(const liso_conv
         toff[i] = ((d.tap_dy[tp] - dy0) * in_w + (d.tap_dx[tp] - dx0)) * PSX;
     }
 
+    // ---- bf16 staging as load / store halves: the loads of tile k+1 are issued before the MFMAs of tile k (software pipeline) ----
+    constexpr int YB = 4;  // dy: TH (<= 4) 16-B chunks per thread
+    const int c8 = tid & 7, p0 = tid >> 3, pstep = kThreads / 8;
+    uint4 xv[XB], yv[YB];
+    unsigned xok = 0u, yok = 0u;
+    float sc[8], sh[8];
+    const bool pro = !X3 && a.in_scale != nullptr;
+    if constexpr (!X3) {
+        const int ch = ci0 + c8 * 8;
+        if (pro) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                sc[e] = ch < d.ci ? a.in_scale[ch + e] : 0.0f;
+                sh[e] = ch < d.ci ? a.in_shift[ch + e] : 0.0f;
+            }
+        }
+    }
+    auto tile_origin = [&](int tile, int& b, int& ty, int& tx) {
+        tx = tile % a.tiles_x;
+        tile /= a.tiles_x;
+        ty = tile % a.tiles_y;
+        b = tile / a.tiles_y;
+    };
+    auto load_x = [&](int tile, int pix_begin) {  // XB chunks of the halo tile starting at pixel pix_begin + p0
+        int b, ty, tx;
+        tile_origin(tile, b, ty, tx);
+        const int iy0 = ty * TH * d.isy + dy0, ix0 = tx * TW * d.isx + dx0;
+        const int ch = ci0 + c8 * 8;
+        const bool ch_ok = ch < d.ci;
+        const unsigned short* xg = (const unsigned short*)a.x + (long)b * d.hi * d.wi * d.x_pix_stride;
+        const int pfirst = pix_begin + p0;
+        int ly = (int)(((float)pfirst + 0.5f) * inv_w);
+        int lx = pfirst - ly * in_w;
+        const int step_y = pstep / in_w, step_x = pstep - step_y * in_w;  // (uniform)
+        xok = 0u;
+#pragma unroll
+        for (int u = 0; u < XB; u++) {
+            const int pix = pfirst + u * pstep;
+            const int iy = iy0 + ly, ix = ix0 + lx;
+            const bool ok = pix < npix && ch_ok && (unsigned)iy < (unsigned)d.hi && (unsigned)ix < (unsigned)d.wi;
+            xok |= ok ? (1u << u) : 0u;
+            const int off = ok ? (iy * d.wi + ix) * d.x_pix_stride + ch : 0;  // (a sample has < 2^31 elements)
+            lx += step_x;
+            ly += step_y;
+            if (lx >= in_w) {
+                lx -= in_w;
+                ly++;
+            }
+            xv[u] = *reinterpret_cast<const uint4*>(xg + off);
+        }
+    };
+    auto store_x = [&](int pix_begin) {
+#pragma unroll
+        for (int u = 0; u < XB; u++) {
+            const int pix = pix_begin + p0 + u * pstep;
+            if (pix >= npix) continue;
+            uint4 o = xv[u];
+            if (pro) {
+                unsigned w[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    float f0 = fmaf(bf16_lo(w[e]), sc[2 * e], sh[2 * e]);
+                    float f1 = fmaf(bf16_hi(w[e]), sc[2 * e + 1], sh[2 * e + 1]);
+                    if (d.in_relu) {
+                        f0 = fmaxf(f0, 0.0f);
+                        f1 = fmaxf(f1, 0.0f);
+                    }
+                    w[e] = pack_bf16(f0, f1);
+                }
+                o = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+            if (!((xok >> u) & 1u)) o = make_uint4(0u, 0u, 0u, 0u);
+            *reinterpret_cast<uint4*>(xs + pix * PSX + c8 * 16) = o;
+        }
+    };
+    auto load_y = [&](int tile) {  // TH x 32 virtual pixels x 64 channels of dy
+        int b, ty, tx;
+        tile_origin(tile, b, ty, tx);
+        const unsigned short* yg = (const unsigned short*)a.dy + (long)b * d.ho * d.wo * a.dy_pix_stride;
+        const int chy = co0 + c8 * 8;
+        const bool chy_ok = chy < d.co;  // (co % 8 == 0 is required in this mode)
+        yok = 0u;
+#pragma unroll
+        for (int u = 0; u < YB; u++) {
+            if (u < TH) {
+                const int m = p0 + u * pstep;
+                const int vy = ty * TH + (m >> 5), vx = tx * TW + (m & 31);
+                const int oy = vy * d.osy + ooy, ox = vx * d.osx + oox;
+                const bool ok = chy_ok && vy < d.hv && vx < d.wv && oy < d.ho && ox < d.wo;
+                yok |= ok ? (1u << u) : 0u;
+                const int off = ok ? (oy * d.wo + ox) * a.dy_pix_stride + chy : 0;
+                yv[u] = *reinterpret_cast<const uint4*>(yg + off);
+            }
+        }
+    };
+    auto store_y = [&]() {
+#pragma unroll
+        for (int u = 0; u < YB; u++) {
+            if (u < TH) {
+                const int m = p0 + u * pstep;
+                uint4 v = yv[u];
+                if (!((yok >> u) & 1u)) v = make_uint4(0u, 0u, 0u, 0u);
+                *reinterpret_cast<uint4*>(ys + m * PSY + c8 * 16) = v;
+                if (want_bias) {
+                    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        bsum[2 * e] += bf16_lo(w[e]);
+                        bsum[2 * e + 1] += bf16_hi(w[e]);
+                    }
+                }
+            }
+        }
+    };
+    auto mfma_tile = [&]() {  // 8 k-steps of 16 pixels (TH = 4), all taps of the group
+        for (int kk = 0; kk < MPIX / 16; kk++) {
+            const int krow = kk >> 1, kcol = (kk & 1) * 16;
+            const unsigned char* bp = ys + (krow * TW + kcol) * PSY + b_lane;
+            const bf8 bh = tr_pair(bp, bp + 4 * PSY);
+            bf8 bl;
+            if constexpr (X3) bl = tr_pair(bp + y_plane, bp + y_plane + 4 * PSY);
+            const unsigned char* ap = xs + ((krow * d.isy) * in_w + kcol * d.isx) * PSX + a_lane;
+#pragma unroll
+            for (int i = 0; i < TG; i++) {
+                if (i < tcnt) {
+                    const unsigned char* api = ap + toff[i];
+                    const bf8 ah = tr_pair(api, api + 4 * d.isx * PSX);
+                    if constexpr (X3) {
+                        const bf8 al = tr_pair(api + a.x_plane_bytes, api + a.x_plane_bytes + 4 * d.isx * PSX);
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i], 0, 0, 0);
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i], 0, 0, 0);
+                    }
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i], 0, 0, 0);
+                }
+                // keep at most 3 taps' fragments in flight: with 9 accumulator tiles live the scheduler otherwise hoists all
+                // 18 transposing reads of a k-step above the first MFMA and spills
+                if (TG > 3 && (i % 3) == 2) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+
+    if (!X3 && a.pipelined) {
+        // the halo tile fits one batch of XB chunks per thread: registers hold tile k+1 while the matrix cores work on tile k
+        int tile = split;
+        if (tile < a.n_tiles) {
+            load_x(tile, 0);
+            load_y(tile);
+            store_x(0);
+            store_y();
+        }
+        __syncthreads();
+        for (; tile < a.n_tiles; tile += a.splits) {
+            const int next = tile + a.splits;
+            const bool more = next < a.n_tiles;
+            if (more) {
+                load_x(next, 0);
+                load_y(next);
+            }
+            mfma_tile();
+            __syncthreads();  // every wave is done with this tile's LDS image
+            if (more) {
+                store_x(0);
+                store_y();
+            }
+            __syncthreads();
+        }
+    } else
     for (int tile = split; tile < a.n_tiles; tile += a.splits) {
         int tt = tile;
         const int tx = tt % a.tiles_x;
@@ -129,84 +297,13 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(const liso_conv
         __syncthreads();
         // ---- stage x' (halo tile, 64 channels) --------------------------------------------------------------------------
         if constexpr (!X3) {
-            const int c8 = tid & 7, p0 = tid >> 3, pstep = kThreads / 8;
-            const int ch = ci0 + c8 * 8;
-            const bool ch_ok = ch < d.ci;
-            const bool pro = a.in_scale != nullptr;
-            float sc[8], sh[8];
-            if (pro) {
-#pragma unroll
-                for (int e = 0; e < 8; e++) {
-                    sc[e] = ch_ok ? a.in_scale[ch + e] : 0.0f;
-                    sh[e] = ch_ok ? a.in_shift[ch + e] : 0.0f;
-                }
+            (void)iy0; (void)ix0; (void)x_img; (void)y_img;
+            for (int pix0 = 0; pix0 < npix; pix0 += XB * pstep) {
+                load_x(tile, pix0);
+                store_x(pix0);
             }
-            const unsigned short* xg = (const unsigned short*)a.x + x_img * d.x_pix_stride;
-            int ly = (int)(((float)p0 + 0.5f) * inv_w);
-            int lx = p0 - ly * in_w;
-            const int step_y = pstep / in_w, step_x = pstep - step_y * in_w;  // (uniform)
-            for (int pix0 = p0; pix0 < npix; pix0 += XB * pstep) {
-                uint4 v[XB];
-                bool ok[XB];
-#pragma unroll
-                for (int u = 0; u < XB; u++) {
-                    const int pix = pix0 + u * pstep;
-                    const int iy = iy0 + ly, ix = ix0 + lx;
-                    ok[u] = pix < npix && ch_ok && (unsigned)iy < (unsigned)d.hi && (unsigned)ix < (unsigned)d.wi;
-                    const int off = ok[u] ? (iy * d.wi + ix) * d.x_pix_stride + ch : 0;  // (a sample has < 2^31 elements)
-                    lx += step_x;
-                    ly += step_y;
-                    if (lx >= in_w) {
-                        lx -= in_w;
-                        ly++;
-                    }
-                    v[u] = *reinterpret_cast<const uint4*>(xg + off);
-                }
-#pragma unroll
-                for (int u = 0; u < XB; u++) {
-                    const int pix = pix0 + u * pstep;
-                    if (pix >= npix) continue;
-                    uint4 o = v[u];
-                    if (pro) {
-                        unsigned w[4] = {o.x, o.y, o.z, o.w};
-#pragma unroll
-                        for (int e = 0; e < 4; e++) {
-                            float f0 = fmaf(bf16_lo(w[e]), sc[2 * e], sh[2 * e]);
-                            float f1 = fmaf(bf16_hi(w[e]), sc[2 * e + 1], sh[2 * e + 1]);
-                            if (d.in_relu) {
-                                f0 = fmaxf(f0, 0.0f);
-                                f1 = fmaxf(f1, 0.0f);
-                            }
-                            w[e] = pack_bf16(f0, f1);
-                        }
-                        o = make_uint4(w[0], w[1], w[2], w[3]);
-                    }
-                    if (!ok[u]) o = make_uint4(0u, 0u, 0u, 0u);
-                    *reinterpret_cast<uint4*>(xs + pix * PSX + c8 * 16) = o;
-                }
-            }
-            // ---- stage dy (128 virtual pixels x 64 channels) -----------------------------------------------------------
-            const unsigned short* yg = (const unsigned short*)a.dy;
-            const int chy = co0 + c8 * 8;
-            const bool chy_ok = chy < d.co;  // (co % 8 == 0 is required in this mode)
-            for (int u = 0; u < MPIX / (kThreads / 8); u++) {
-                const int m = p0 + u * pstep;
-                const int vy = ty * TH + (m >> 5), vx = tx * TW + (m & 31);
-                const int oy = vy * d.osy + ooy, ox = vx * d.osx + oox;
-                const bool ok = chy_ok && vy < d.hv && vx < d.wv && oy < d.ho && ox < d.wo;
-                const int off = ok ? (oy * d.wo + ox) * a.dy_pix_stride + chy : 0;
-                uint4 v = *reinterpret_cast<const uint4*>(yg + y_img + off);
-                if (!ok) v = make_uint4(0u, 0u, 0u, 0u);
-                *reinterpret_cast<uint4*>(ys + m * PSY + c8 * 16) = v;
-                if (want_bias) {
-                    const unsigned w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        bsum[2 * e] += bf16_lo(w[e]);
-                        bsum[2 * e + 1] += bf16_hi(w[e]);
-                    }
-                }
-            }
+            load_y(tile);
+            store_y();
         } else {
             const int c4 = tid & 15, p0 = tid >> 4, pstep = kThreads / 16;
             const int ch = ci0 + c4 * 4;
@@ -294,31 +391,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(const liso_conv
             }
         }
         __syncthreads();
-        // ---- 8 k-steps of 16 pixels -----------------------------------------------------------------------------------------
-        for (int kk = 0; kk < MPIX / 16; kk++) {
-            const int krow = kk >> 1, kcol = (kk & 1) * 16;
-            const unsigned char* bp = ys + (krow * TW + kcol) * PSY + b_lane;
-            const bf8 bh = tr_pair(bp, bp + 4 * PSY);
-            bf8 bl;
-            if constexpr (X3) bl = tr_pair(bp + y_plane, bp + y_plane + 4 * PSY);
-            const unsigned char* ap = xs + ((krow * d.isy) * in_w + kcol * d.isx) * PSX + a_lane;
-#pragma unroll
-            for (int i = 0; i < TG; i++) {
-                if (i < tcnt) {
-                    const unsigned char* api = ap + toff[i];
-                    const bf8 ah = tr_pair(api, api + 4 * d.isx * PSX);
-                    if constexpr (X3) {
-                        const bf8 al = tr_pair(api + a.x_plane_bytes, api + a.x_plane_bytes + 4 * d.isx * PSX);
-                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i], 0, 0, 0);
-                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i], 0, 0, 0);
-                    }
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i], 0, 0, 0);
-                }
-                // keep at most 3 taps' fragments in flight: with 9 accumulator tiles live the scheduler otherwise hoists all
-                // 18 transposing reads of a k-step above the first MFMA and spills
-                if (TG > 3 && (i % 3) == 2) __builtin_amdgcn_sched_barrier(0);
-            }
-        }
+        mfma_tile();
     }
     // ---- write the slab: D[row = ci][col = co]; col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5) -----------------
     const int r = lane & 31, h = lane >> 5;
@@ -451,6 +524,8 @@ bool make_plan(const liso_conv_desc& d, WgPlan* p) {
         max_pix = np > max_pix ? np : max_pix;
     }
     a.psx = CT * 2 + 16;
+    // (XB = 8 chunks per thread x 32 pixel rows of threads = 256 halo pixels; XB = 4 in the 9-tap instantiation)
+    a.pipelined = 0;
     a.x_plane_bytes = round_up(max_pix * a.psx, 16);
     p->lds = planes * (a.x_plane_bytes + TH * TW * PSY);
     // taps per block (9 / 3 / 1) and pixel splits: the slabs of all splits together stay below 24 MB (they are written and
@@ -466,6 +541,8 @@ bool make_plan(const liso_conv_desc& d, WgPlan* p) {
     long split_cap = (24l << 20) / slab_per_split;
     const long by_tiles = a.n_tiles >= 4 ? a.n_tiles / 4 : 1;
     split_cap = split_cap < 1 ? 1 : (split_cap > by_tiles ? by_tiles : split_cap);
+    long target = 512;  // ~2 blocks per CU
+    if (const char* e = getenv("LISO_WGRAD_BLOCKS")) target = atol(e) > 0 ? atol(e) : target;  // experiments
     const int tg_opts[3] = {9, 3, 1};
     long best_blocks = -1;
     p->tg = 1;
@@ -473,7 +550,7 @@ bool make_plan(const liso_conv_desc& d, WgPlan* p) {
         const int tg = tg_opts[k];
         if (tg > 1 && max_cls_taps == 1) continue;
         const long per_split = cc * groups(tg);
-        long s = (512 + per_split - 1) / per_split;
+        long s = (target + per_split - 1) / per_split;
         s = s < 1 ? 1 : (s > split_cap ? split_cap : s);
         const long blocks = per_split * s;
         if (blocks >= 256) {  // enough: take the largest tap group
@@ -489,6 +566,11 @@ bool make_plan(const liso_conv_desc& d, WgPlan* p) {
         const int v = atoi(e);
         if ((v == 9 && !x3) || v == 3 || v == 1) p->tg = v;
     }
+    {
+        const int xb = p->tg >= 9 ? 4 : 8;
+        a.pipelined = (!x3 && max_pix <= xb * (kThreads / 8)) ? 1 : 0;
+        if (const char* e = getenv("LISO_WGRAD_PIPE")) a.pipelined = a.pipelined && atoi(e) != 0;  // experiments
+    }
     a.n_groups = 0;
     for (int c = 0; c < d.n_classes; c++)
         for (int t = d.class_tap_begin[c]; t < d.class_tap_begin[c + 1]; t += p->tg) {
@@ -500,7 +582,7 @@ bool make_plan(const liso_conv_desc& d, WgPlan* p) {
             a.n_groups++;
         }
     const long per_split = cc * a.n_groups;
-    long s = (512 + per_split - 1) / per_split;
+    long s = (target + per_split - 1) / per_split;
     s = s < 1 ? 1 : (s > split_cap ? split_cap : s);
     p->splits = (int)s;
     a.splits = p->splits;

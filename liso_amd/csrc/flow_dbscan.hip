@@ -66,19 +66,57 @@ __device__ __forceinline__ void for_each_neighbour(const Cfg& c, const uint8_t* 
         }
 }
 
-__global__ void dbscan_core_kernel(Cfg c, const uint8_t* __restrict__ dyn, const float* __restrict__ xs,
-                                   const float* __restrict__ ys, const float* __restrict__ flow, uint8_t* __restrict__ core,
-                                   int* __restrict__ parent) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+// Wave-cooperative window walk.  Dynamic pillars are sparse (a few thousand of 512 x 512) and come in blobs a handful of
+// columns wide, so a wave of 64 consecutive cells holds 0-10 of them: instead of every such lane walking its 13 x 13 window
+// alone (169 dependent iterations with 1-10 of 64 lanes busy), the wave takes its flagged cells one after the other and all
+// 64 lanes share the window of that cell (3 iterations, consecutive columns = coalesced reads).  f(nb, leader_lane) runs on the
+// lanes whose window cell is a neighbour (dynamic, within eps) of the flagged cell.
+constexpr int kDenseWave = 20;  // flagged cells per wave above which the per-lane walk (169 iterations, all lanes busy) is cheaper
+
+template <typename F>
+__device__ __forceinline__ void wave_for_each_neighbour(const Cfg& c, const uint8_t* __restrict__ dyn, const float* __restrict__ xs,
+                                                        const float* __restrict__ ys, const float* __restrict__ flow, size_t me,
+                                                        int lane, F&& f) {
     const size_t per = (size_t)c.gx * c.gy;
-    if (i >= per * c.batch) return;
-    int is_core = 0;
-    if (dyn[i]) {
-        const int b = (int)(i / per), r = (int)((i % per) / c.gy), col = (int)(i % c.gy);
-        int count = 0;
-        for_each_neighbour(c, dyn, xs, ys, flow, b, r, col, [&](size_t) { count++; });
-        is_core = count >= c.min_samples;
+    const int b = (int)(me / per), r = (int)((me % per) / c.gy), col = (int)(me % c.gy);
+    const size_t base = (size_t)b * per;
+    const int r_lo = max(r - c.win, 0), r_hi = min(r + c.win, c.gx - 1);
+    const int c_lo = max(col - c.win, 0), c_hi = min(col + c.win, c.gy - 1);
+    const int wc = c_hi - c_lo + 1, n = (r_hi - r_lo + 1) * wc;
+    for (int k = lane; k < n; k += 64) {
+        const int rr = r_lo + k / wc, cc = c_lo + k % wc;
+        const size_t nb = base + (size_t)rr * c.gy + cc;
+        if (dyn[nb] && dist_sqr(xs, ys, flow, c.flow_weight, r, col, me, rr, cc, nb) <= c.eps_sqr) f(nb);
     }
+}
+
+__global__ __launch_bounds__(256) void dbscan_core_kernel(Cfg c, const uint8_t* __restrict__ dyn, const float* __restrict__ xs,
+                                                          const float* __restrict__ ys, const float* __restrict__ flow,
+                                                          uint8_t* __restrict__ core, int* __restrict__ parent) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t per = (size_t)c.gx * c.gy, total = per * c.batch;
+    const int lane = threadIdx.x & 63;
+    const bool flagged = i < total && dyn[i];
+    unsigned long long todo = __ballot(flagged);
+    int is_core = 0;
+    if (__popcll(todo) > kDenseWave) {  // a wave inside a large dynamic region: every lane walks its own window (lanes all busy)
+        if (flagged) {
+            int count = 0;
+            for_each_neighbour(c, dyn, xs, ys, flow, (int)(i / per), (int)((i % per) / c.gy), (int)(i % c.gy), [&](size_t) { count++; });
+            is_core = count >= c.min_samples;
+        }
+        todo = 0ull;
+    }
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        int count = 0;
+        wave_for_each_neighbour(c, dyn, xs, ys, flow, i - lane + src, lane, [&](size_t) { count++; });
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) count += __shfl_xor(count, o);
+        if (lane == src) is_core = count >= c.min_samples;
+    }
+    if (i >= total) return;
     core[i] = (uint8_t)is_core;
     parent[i] = is_core ? (int)(i % per) : -1;  // per-sample cell index
 }
@@ -90,30 +128,58 @@ __device__ __forceinline__ int find_root(const int* parent, int x) {
     return x;
 }
 
-__global__ void dbscan_union_kernel(Cfg c, const uint8_t* __restrict__ dyn, const uint8_t* __restrict__ core,
-                                    const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ flow,
-                                    int* __restrict__ parent) {
+__global__ __launch_bounds__(256) void dbscan_union_kernel(Cfg c, const uint8_t* __restrict__ dyn, const uint8_t* __restrict__ core,
+                                                           const float* __restrict__ xs, const float* __restrict__ ys,
+                                                           const float* __restrict__ flow, int* __restrict__ parent) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t per = (size_t)c.gx * c.gy;
-    if (i >= per * c.batch || !core[i]) return;
-    const int b = (int)(i / per), r = (int)((i % per) / c.gy), col = (int)(i % c.gy);
-    int* par = parent + (size_t)b * per;
-    const int me = (int)(i % per);
-    for_each_neighbour(c, dyn, xs, ys, flow, b, r, col, [&](size_t nb) {
-        if (!core[nb]) return;
-        const int other = (int)(nb % per);
-        if (other >= me) return;  // every undirected edge once
-        int x = me, y = other;
-        while (true) {
-            x = find_root(par, x);
-            y = find_root(par, y);
-            if (x == y) break;
-            if (x < y) { const int t = x; x = y; y = t; }  // x: larger root, linked under y
-            const int old = atomicMin(&par[x], y);
-            if (old == x) break;  // x was still a root: linked
-            x = old;              // somebody re-parented x meanwhile: retry from there
+    const size_t per = (size_t)c.gx * c.gy, total = per * c.batch;
+    const int lane = threadIdx.x & 63;
+    unsigned long long todo = __ballot(i < total && core[i]);
+    if (__popcll(todo) > kDenseWave) {
+        if (i < total && core[i]) {
+            const int b = (int)(i / per), r = (int)((i % per) / c.gy), col = (int)(i % c.gy);
+            int* par = parent + (size_t)b * per;
+            const int me = (int)(i % per);
+            for_each_neighbour(c, dyn, xs, ys, flow, b, r, col, [&](size_t nb) {
+                if (!core[nb]) return;
+                const int other = (int)(nb % per);
+                if (other >= me) return;
+                int x = me, y = other;
+                while (true) {
+                    x = find_root(par, x);
+                    y = find_root(par, y);
+                    if (x == y) break;
+                    if (x < y) { const int t = x; x = y; y = t; }
+                    const int old = atomicMin(&par[x], y);
+                    if (old == x) break;
+                    x = old;
+                }
+            });
         }
-    });
+        return;
+    }
+    while (todo) {  // (the final forest -- every tree rooted at its smallest cell -- does not depend on the order of the hooks)
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const size_t cell = i - lane + src;
+        int* par = parent + (cell / per) * per;
+        const int me = (int)(cell % per);
+        wave_for_each_neighbour(c, dyn, xs, ys, flow, cell, lane, [&](size_t nb) {
+            if (!core[nb]) return;
+            const int other = (int)(nb % per);
+            if (other >= me) return;  // every undirected edge once
+            int x = me, y = other;
+            while (true) {
+                x = find_root(par, x);
+                y = find_root(par, y);
+                if (x == y) break;
+                if (x < y) { const int t = x; x = y; y = t; }  // x: larger root, linked under y
+                const int old = atomicMin(&par[x], y);
+                if (old == x) break;  // x was still a root: linked
+                x = old;              // somebody re-parented x meanwhile: retry from there
+            }
+        });
+    }
 }
 
 __global__ void dbscan_flatten_kernel(Cfg c, const uint8_t* __restrict__ core, int* __restrict__ parent,
@@ -154,21 +220,36 @@ __global__ void dbscan_label_kernel(Cfg c, const uint8_t* __restrict__ dyn, cons
     labels[i] = label;
 }
 
-__global__ void region_moments_kernel(const int* __restrict__ labels, int batch, int gx, int gy, int max_labels,
-                                      unsigned long long* __restrict__ mom) {
+// Integer moments of every labelled region.  A wave covers 64 consecutive cells, which carry at most a few distinct labels:
+// the wave reduces the six sums per label (butterfly) and ONE lane issues the atomics -- 6 per (wave, label) instead of 6 per
+// cell, which serialised on the few dozen label rows (243 us at 512 x 512).  Integer sums: any order gives the same bits.
+__global__ __launch_bounds__(256) void region_moments_kernel(const int* __restrict__ labels, int batch, int gx, int gy, int max_labels,
+                                                             unsigned long long* __restrict__ mom) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t per = (size_t)gx * gy;
-    if (i >= per * batch) return;
-    const int l = labels[i];
-    if (l <= 0 || l > max_labels) return;
+    const int lane = threadIdx.x & 63;
+    int l = i < per * batch ? labels[i] : 0;
+    if (l > max_labels) l = 0;
+    const long key = l > 0 ? (long)(i / per) * max_labels + (l - 1) : -1;
     const unsigned long long r = (i % per) / gy, col = i % gy;
-    unsigned long long* m = mom + ((size_t)(i / per) * max_labels + (l - 1)) * 6;
-    atomicAdd(m + 0, 1ull);
-    atomicAdd(m + 1, r);
-    atomicAdd(m + 2, col);
-    atomicAdd(m + 3, r * r);
-    atomicAdd(m + 4, col * col);
-    atomicAdd(m + 5, r * col);
+    unsigned long long todo = __ballot(key >= 0);
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        const long k = __shfl(key, src);
+        const bool mine = key == k;
+        unsigned long long v[6] = {mine ? 1ull : 0ull, mine ? r : 0ull, mine ? col : 0ull, mine ? r * r : 0ull, mine ? col * col : 0ull,
+                                   mine ? r * col : 0ull};
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+            for (int q = 0; q < 6; q++) v[q] += __shfl_xor(v[q], o);
+        if (lane == src) {
+            unsigned long long* m = mom + (size_t)k * 6;
+#pragma unroll
+            for (int q = 0; q < 6; q++) atomicAdd(m + q, v[q]);
+        }
+        todo &= ~__ballot(mine);
+    }
 }
 
 __global__ void region_props_kernel(const unsigned long long* __restrict__ mom, long n_regions, double* __restrict__ props) {

@@ -23,7 +23,7 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kTile = 128;            // points per tile (32 per wave in phase B)
 constexpr int kPtsPerWave = kTile / 4;
-constexpr int kMaxBlocks = 128;       // point blocks per sample
+constexpr int kMaxBlocks = 1024;      // point blocks per sample (one 128-point tile per block up to 131k points: fills 256 CUs at B = 1)
 constexpr int NM = LISO_KABSCH_NMOM;
 constexpr float kPi = 3.14159265358979323846f;
 

@@ -79,12 +79,13 @@ class KabschDecoder(torch.nn.Module):
     @torch.no_grad()
     def get_kabsch_trafos_from_point_flow(self, *, point_cloud_ta, valid_mask_ta, pointwise_flow_ta_tb,
                                           pred_boxes_ta: Shape, sigmoid_slope=None, obj_dim_scale_buffer=None,
-                                          softness_func=None) -> Tuple[torch.Tensor, ...]:
-        """reference :328-399 -> (fg_T[B,S,4,4] f64, fg_w[B,S,N], fg_cum[B,S], bg_T[B,1,4,4] f64, bg_cum[B,1])"""
+                                          softness_func=None, return_weights=True) -> Tuple[torch.Tensor, ...]:
+        """reference :328-399 -> (fg_T[B,S,4,4] f64, fg_w[B,S,N], fg_cum[B,S], bg_T[B,1,4,4] f64, bg_cum[B,1]).
+        `return_weights=False` (extension): fg_w is None -- the [B,S,N] map (14 MB at 30 boxes x 120k points) is not written"""
         slope = sigmoid_slope if sigmoid_slope is not None else self.cfg.mask_rendering.pred_sigmoid_slope
         buf = obj_dim_scale_buffer if obj_dim_scale_buffer is not None else self.cfg.mask_rendering.obj_dim_scale_buffer
         name = self.softness_name if softness_func is None else ("sigmoid" if softness_func is torch.sigmoid else "cauchy")
         T, cum, w = self._run(pred_boxes_ta, point_cloud_ta, valid_mask_ta, pointwise_flow_ta_tb[:, :, 0:2], slope,
-                              1.0 - buf, 1.0 + buf, name, True)
+                              1.0 - buf, 1.0 + buf, name, bool(return_weights))
         S = pred_boxes_ta.pos.shape[1]
         return T[:, :S], w, cum[:, :S], T[:, S:], cum[:, S:]

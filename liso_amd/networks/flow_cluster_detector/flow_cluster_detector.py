@@ -184,7 +184,8 @@ class FlowClusterDetector(torch.nn.Module):
         if s_max > 0:
             # adapt the rotation of the box to the direction of the flow (reference :312-331)
             fg_trafos, _, _, bg_trafo, _ = self.kabsch_decoder.get_kabsch_trafos_from_point_flow(
-                point_cloud_ta=pcl[..., :3], valid_mask_ta=pcl_is_valid, pointwise_flow_ta_tb=point_flow, pred_boxes_ta=boxes)
+                point_cloud_ta=pcl[..., :3], valid_mask_ta=pcl_is_valid, pointwise_flow_ta_tb=point_flow, pred_boxes_ta=boxes,
+                return_weights=False)
             box_translation, _ = extract_motion_in_pred_box_coordinates(boxes, fg_trafos, bg_trafo)
             delta_angle = torch.atan2(box_translation[..., [1]], box_translation[..., [0]])
             box_velo = torch.zeros_like(boxes.probs)
