@@ -64,6 +64,8 @@ typedef struct {
     int mode;                   /* LISO_CONV_BF16 | LISO_CONV_F32X3 */
     int out_f32;                /* BF16 mode: 1 = fp32 output, 0 = bf16 output (F32X3: always fp32) */
     int in_relu, out_relu;
+    int in_affine_batch_stride; /* 0: in_scale / in_shift are [ci], shared by all samples (BatchNorm);
+                                   > 0: per-sample vectors, sample b reads in_scale[b * stride + c] (InstanceNorm) */
 } liso_conv_desc;
 
 /* Packs torch-layout fp32 weights for the kernels.
@@ -102,6 +104,26 @@ int liso_conv_wgrad(const liso_conv_desc* d, const void* x, const float* in_scal
 int liso_conv_bn_finalize(const float* stats_partial, int rows, int co, int co_pad, long n, const float* stats_shift,
                           const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
                           float eps, float* stats, void* stream);
+
+/* InstanceNorm2d statistics from the partial sums of a forward launch of a one-class (gather) descriptor, whose rows are ordered
+ * sample-major: per sample b and channel c over the ho * wo pixels of that sample
+ *   stats[b][4 * co] = scale | shift | mean | invstd, scale = gamma[c] * invstd, shift = beta[c] - mean * scale
+ *   (gamma / beta may be NULL: 1 / 0, nn.InstanceNorm2d's default affine=False); biased variance, like torch.
+ * rows_per_sample = liso_conv_stats_rows(d) / d->batch.
+ * Replaces the InstanceNorm2d layers of liso/slim/model/extractor.py:5-71,211-297 (norm_fn "instance"). */
+int liso_conv_in_finalize(const float* stats_partial, int rows_per_sample, int batch, int co, int co_pad, long n_per_sample,
+                          const float* gamma, const float* beta, float eps, float* stats, void* stream);
+
+/* out = relu( fa(a) + fb(b) ) on NHWC fp32 tensors [batch, pixels, c], c % 4 == 0, where
+ *   fa(a) = a                                   if a_scale == NULL
+ *         = relu?(a * a_scale[n * a_stride + c] + a_shift[n * a_stride + c])  otherwise (per-sample vectors, a_stride elements
+ *           apart, 16-byte aligned; a_relu selects the ReLU)
+ * and fb likewise: the tail of a residual block -- relu(x + y) with the pending normalisation (+ ReLU) of either branch applied
+ * on the fly (liso/slim/model/extractor.py:29-38: `self.relu(x + y)`, y = relu(norm2(conv2(.))), x = norm3(conv1x1(.)) or the
+ * block input).  One read of each input, one write. */
+int liso_residual_affine_relu_f32(const float* a, const float* a_scale, const float* a_shift, int a_stride, int a_relu, const float* b,
+                                  const float* b_scale, const float* b_shift, int b_stride, int b_relu, float* out, int batch,
+                                  long pixels, int c, void* stream);
 
 #ifdef __cplusplus
 }

@@ -121,6 +121,8 @@ SIGNATURES = {
     "liso_centerloss_fwd_f32": (_i, [_vp] * 17 + [_sz, _vp]),
     "liso_centerloss_bwd_f32": (_i, [_vp] * 21),
     "liso_render_center_targets_f32": (_i, [_vp] * 12),
+    "liso_conv_in_finalize": (_i, [_vp, _i, _i, _i, _i, ctypes.c_long, _vp, _vp, _f, _vp, _vp]),
+    "liso_residual_affine_relu_f32": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, ctypes.c_long, _i, _vp]),
     # include/liso_optim.h
     "liso_adamw_step_f32": (_i, [_vp, _vp, _vp, _vp, _sz] + [ctypes.c_double] * 5 + [ctypes.c_long, _vp]),
     # include/liso_bn.h
@@ -155,7 +157,8 @@ class ConvDesc(ctypes.Structure):
                 ("y_pix_stride", _i), ("y_ch_off", _i), ("hv", _i), ("wv", _i), ("isy", _i), ("isx", _i), ("osy", _i), ("osx", _i),
                 ("n_classes", _i), ("class_tap_begin", _i * (CONV_MAX_CLASSES + 1)), ("class_ooy", _i * CONV_MAX_CLASSES),
                 ("class_oox", _i * CONV_MAX_CLASSES), ("n_taps", _i), ("tap_dy", _i * CONV_MAX_TAPS), ("tap_dx", _i * CONV_MAX_TAPS),
-                ("tap_w", _i * CONV_MAX_TAPS), ("w_taps", _i), ("mode", _i), ("out_f32", _i), ("in_relu", _i), ("out_relu", _i)]
+                ("tap_w", _i * CONV_MAX_TAPS), ("w_taps", _i), ("mode", _i), ("out_f32", _i), ("in_relu", _i), ("out_relu", _i),
+                ("in_affine_batch_stride", _i)]
 
 
 class KnnGrid(ctypes.Structure):

@@ -149,6 +149,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(const liso_conv
     const int step_y = pstep / in_w, step_x = pstep - step_y * in_w;  // (uniform)
     const unsigned char* xbase = (const unsigned char*)a.x + x_img * d.x_pix_stride * (X3 ? 4 : 2);
     const bool pro = a.in_scale != nullptr;
+    const int aff_off = b * d.in_affine_batch_stride;  // per-sample prologue vectors (InstanceNorm) or 0
 
     auto load_x = [&](int c0, int pix_begin, uint4 (&v)[XB], unsigned& okmask) {
         const int ch = c0 + cx * CHN;
@@ -180,8 +181,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(const liso_conv
         if (pro) {
 #pragma unroll
             for (int e = 0; e < CHN; e++) {
-                sc[e] = ch_ok ? a.in_scale[ch + e] : 0.0f;
-                sh[e] = ch_ok ? a.in_shift[ch + e] : 0.0f;
+                sc[e] = ch_ok ? a.in_scale[aff_off + ch + e] : 0.0f;
+                sh[e] = ch_ok ? a.in_shift[aff_off + ch + e] : 0.0f;
             }
         }
 #pragma unroll
@@ -482,6 +483,9 @@ __global__ __launch_bounds__(256) void conv_bn_finalize_kernel(const float* __re
                                                                float* __restrict__ running_mean, float* __restrict__ running_var,
                                                                float momentum, float eps, float* __restrict__ stats) {
     __shared__ double red[16][16];
+    // blockIdx.y = sample (InstanceNorm: one statistics row set per sample; BatchNorm launches a single y)
+    partial += (size_t)blockIdx.y * rows * 2 * co_pad;
+    stats += (size_t)blockIdx.y * 4 * co;
     const int col = threadIdx.x & 15, rg = threadIdx.x >> 4;
     const int c = blockIdx.x * 8 + (col & 7), s = col >> 3;
     double acc = 0.0;
@@ -503,9 +507,9 @@ __global__ __launch_bounds__(256) void conv_bn_finalize_kernel(const float* __re
             if (var < 0.0) var = 0.0;
             const double mean = k + m1;
             const double invstd = 1.0 / sqrt(var + (double)eps);
-            const double sc = (double)gamma[cc] * invstd;
+            const double sc = (gamma ? (double)gamma[cc] : 1.0) * invstd;
             stats[cc] = (float)sc;
-            stats[co + cc] = (float)((double)beta[cc] - mean * sc);
+            stats[co + cc] = (float)((beta ? (double)beta[cc] : 0.0) - mean * sc);
             stats[2 * co + cc] = (float)mean;
             stats[3 * co + cc] = (float)invstd;
             if (running_mean) {
@@ -514,6 +518,31 @@ __global__ __launch_bounds__(256) void conv_bn_finalize_kernel(const float* __re
                 running_var[cc] = (float)((1.0 - momentum) * running_var[cc] + momentum * unb);
             }
         }
+    }
+}
+
+// ---- tail of a residual block: out = relu(fa(a) + fb(b)), pending per-sample affine (+ ReLU) of either branch applied on the fly ----
+__global__ __launch_bounds__(256) void residual_affine_relu_kernel(const float4* __restrict__ a, const float* __restrict__ a_scale,
+                                                                   const float* __restrict__ a_shift, int a_relu,
+                                                                   const float4* __restrict__ b, const float* __restrict__ b_scale,
+                                                                   const float* __restrict__ b_shift, int b_relu,
+                                                                   float4* __restrict__ out, long per_sample4, int c4, long total4, int a_stride4,
+                                                                   int b_stride4) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+        const long n = i / per_sample4;
+        const int cq = (int)(i % c4);  // (per_sample4 is a multiple of c4)
+        float4 va = a[i], vb = b[i];
+        if (a_scale) {
+            const float4 s = reinterpret_cast<const float4*>(a_scale)[n * a_stride4 + cq], t = reinterpret_cast<const float4*>(a_shift)[n * a_stride4 + cq];
+            va = make_float4(fmaf(va.x, s.x, t.x), fmaf(va.y, s.y, t.y), fmaf(va.z, s.z, t.z), fmaf(va.w, s.w, t.w));
+            if (a_relu) va = make_float4(fmaxf(va.x, 0.f), fmaxf(va.y, 0.f), fmaxf(va.z, 0.f), fmaxf(va.w, 0.f));
+        }
+        if (b_scale) {
+            const float4 s = reinterpret_cast<const float4*>(b_scale)[n * b_stride4 + cq], t = reinterpret_cast<const float4*>(b_shift)[n * b_stride4 + cq];
+            vb = make_float4(fmaf(vb.x, s.x, t.x), fmaf(vb.y, s.y, t.y), fmaf(vb.z, s.z, t.z), fmaf(vb.w, s.w, t.w));
+            if (b_relu) vb = make_float4(fmaxf(vb.x, 0.f), fmaxf(vb.y, 0.f), fmaxf(vb.z, 0.f), fmaxf(vb.w, 0.f));
+        }
+        out[i] = make_float4(fmaxf(va.x + vb.x, 0.f), fmaxf(va.y + vb.y, 0.f), fmaxf(va.z + vb.z, 0.f), fmaxf(va.w + vb.w, 0.f));
     }
 }
 
@@ -719,6 +748,31 @@ int liso_conv_bn_finalize(const float* stats_partial, int rows, int co, int co_p
     if ((running_mean == nullptr) != (running_var == nullptr)) return LISO_EINVAL;
     conv_bn_finalize_kernel<<<(co + 7) / 8, 256, 0, (hipStream_t)stream>>>(stats_partial, rows, co, co_pad, n, stats_shift, gamma,
                                                                           beta, running_mean, running_var, momentum, eps, stats);
+    return check_launch();
+}
+
+int liso_conv_in_finalize(const float* stats_partial, int rows_per_sample, int batch, int co, int co_pad, long n_per_sample,
+                          const float* gamma, const float* beta, float eps, float* stats, void* stream) {
+    if (!stats_partial || !stats || rows_per_sample <= 0 || batch <= 0 || co <= 0 || co_pad < co || n_per_sample <= 0) return LISO_EINVAL;
+    if ((gamma == nullptr) != (beta == nullptr)) return LISO_EINVAL;
+    conv_bn_finalize_kernel<<<dim3((co + 7) / 8, batch), 256, 0, (hipStream_t)stream>>>(stats_partial, rows_per_sample, co, co_pad,
+                                                                                     n_per_sample, nullptr, gamma, beta, nullptr,
+                                                                                     nullptr, 0.0f, eps, stats);
+    return check_launch();
+}
+
+int liso_residual_affine_relu_f32(const float* a, const float* a_scale, const float* a_shift, int a_stride, int a_relu, const float* b,
+                                  const float* b_scale, const float* b_shift, int b_stride, int b_relu, float* out, int batch,
+                                  long pixels, int c, void* stream) {
+    if (!a || !b || !out || batch <= 0 || pixels <= 0 || c <= 0 || (c & 3) || (a_stride & 3) || (b_stride & 3)) return LISO_EINVAL;
+    if ((a_scale == nullptr) != (a_shift == nullptr) || (b_scale == nullptr) != (b_shift == nullptr)) return LISO_EINVAL;
+    if ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) != 0) return LISO_EINVAL;
+    const long per4 = pixels * (c / 4), total4 = per4 * batch;
+    long blocks = (total4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    residual_affine_relu_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(
+        reinterpret_cast<const float4*>(a), a_scale, a_shift, a_relu, reinterpret_cast<const float4*>(b), b_scale, b_shift, b_relu,
+        reinterpret_cast<float4*>(out), per4, c / 4, total4, a_stride / 4, b_stride / 4);
     return check_launch();
 }
 

@@ -36,6 +36,27 @@ class ResidualBlock(nn.Module):
         else:
             self.downsample = None
 
+    def forward_inference(self, x_raw, fold):
+        """forward() under no_grad on fp32 CUDA tensors with the normalisations folded: (raw block input, its pending InstanceNorm or
+        None) -> materialised block output.  conv1 -> [IN+ReLU pending] -> conv2 (prologue) -> [IN+ReLU pending] -> one residual
+        kernel that applies the pending layers of both branches: no normalised tensor, no separate ReLU / add pass, NHWC throughout."""
+        from liso_amd.utils import mfma_conv as MC
+
+        y, f1 = MC.conv_in(x_raw, fold, self.conv1, self.norm1)
+        y, f2 = MC.conv_in(y, f1, self.conv2, self.norm2)
+        if self.downsample is not None:
+            xs, fx = MC.conv_in(x_raw, fold, self.downsample[0], self.downsample[1], relu=False)
+        else:
+            xs, fx = x_raw, fold
+        return MC.residual_relu(xs, fx, y, f2)
+
+    def foldable(self):
+        from liso_amd.utils import mfma_conv as MC
+
+        norms = [self.norm1, self.norm2] + ([self.downsample[1]] if self.downsample is not None else [])
+        kinds = {MC._norm_kind(n) for n in norms}
+        return len(kinds) == 1 and None not in kinds
+
     def forward(self, x):
         """reference :29-38.  Convolutions on the own MFMA kernels (liso_amd/utils/mfma_conv.py); where no normalisation
         sits between a convolution and its ReLU (cnet: norm_fn "none") the ReLU runs in the convolution's epilogue."""
@@ -72,17 +93,37 @@ class SmallEncoder(nn.Module):
             ResidualBlock(in_filters, out_filters, norm_fn=self.norm_fn, dummy_in_filters=in_filters, stride=stride),
             ResidualBlock(out_filters, out_filters, norm_fn=self.norm_fn, dummy_in_filters=in_filters, stride=1))
 
+    def _fold_inference(self, x):
+        from liso_amd.utils import mfma_conv as MC
+
+        if torch.is_grad_enabled() or not x.is_cuda or x.dtype != torch.float32 or MC.backend() != "mfma":
+            return False
+        if not getattr(self, "fold_inference", True) or MC._norm_kind(self.norm1) is None:
+            return False
+        blocks = list(self.layer1) + list(self.layer2) + list(self.layer3)
+        return all(b.foldable() and MC._norm_kind(b.norm1) == MC._norm_kind(self.norm1) for b in blocks) and \
+            MC.supported(x, self.conv1.weight, MC.ConvSpec.of(self.conv1))
+
     def forward(self, x):
         is_list = isinstance(x, (tuple, list))
         if is_list:
             batch_dim = x[0].shape[0]
             x = torch.cat(x, dim=0)
-        if isinstance(self.norm1, nn.Sequential) and len(self.norm1) == 0:
-            x = conv2d(self.conv1, x, relu=True)
+        if self._fold_inference(x):
+            # inference: every InstanceNorm + ReLU is applied by its consumer, residual tails are one kernel (mfma_conv.InFold)
+            from liso_amd.utils import mfma_conv as MC
+
+            h, fold = MC.conv_in(x, None, self.conv1, self.norm1)
+            for blk in list(self.layer1) + list(self.layer2) + list(self.layer3):
+                h, fold = blk.forward_inference(h, fold), None
+            x = conv2d(self.conv2, h)
         else:
-            x = self.relu1(self.norm1(conv2d(self.conv1, x)))
-        x = self.layer3(self.layer2(self.layer1(x)))
-        x = conv2d(self.conv2, x)
+            if isinstance(self.norm1, nn.Sequential) and len(self.norm1) == 0:
+                x = conv2d(self.conv1, x, relu=True)
+            else:
+                x = self.relu1(self.norm1(conv2d(self.conv1, x)))
+            x = self.layer3(self.layer2(self.layer1(x)))
+            x = conv2d(self.conv2, x)
         if self.training and self.dropout is not None:
             x = self.dropout(x)
         if is_list:

@@ -202,8 +202,9 @@ def _flops(d):
 
 
 def conv_forward(x, weight, bias, spec, in_scale=None, in_shift=None, in_relu=False, out_relu=False, out_dtype=None,
-                 want_stats=False, stats_shift=None, packed=None):
-    """x: logical [B,Ci,H,W] (channels-last storage preferred) -> (y logical [B,Co,Ho,Wo] channels-last, stats_partial | None)"""
+                 want_stats=False, stats_shift=None, packed=None, affine_batch_stride=0):
+    """x: logical [B,Ci,H,W] (channels-last storage preferred) -> (y logical [B,Co,Ho,Wo] channels-last, stats_partial | None).
+    `affine_batch_stride` > 0: in_scale / in_shift hold one vector per sample, that many elements apart (InstanceNorm)."""
     L.require_cuda(x, weight)
     mode = _mode(x.dtype)
     xv, xps = as_nhwc(x, _vec(mode))
@@ -217,6 +218,9 @@ def conv_forward(x, weight, bias, spec, in_scale=None, in_shift=None, in_relu=Fa
     y = torch.empty((B, ho, wo, co), dtype=out_dtype, device=x.device)
     build = scatter_desc if spec.transposed else gather_desc
     d = build(spec, B, hi, wi, ci, xps, ho, wo, co, co, 0, mode, out_f32, in_relu, out_relu)
+    if affine_batch_stride:
+        d = L.ConvDesc.from_buffer_copy(d)  # (descriptors are cached and shared: never edit them in place)
+        d.in_affine_batch_stride = int(affine_batch_stride)
     if packed is None:
         packed = pack_weights(weight, spec, False, mode)
     lib = L.lib()
@@ -534,6 +538,77 @@ def fused_conv(x_raw, fold, conv, out_bn=None, out_dtype=None, out_relu=False, s
         folds.append(finalize_bn(meta["stats_partial"], n, b, meta.get("stats_shift"), channel_offset=off))
         off += b.num_features
     return y, BnFold.cat(folds)
+
+
+# ---- InstanceNorm folding (inference) ----------------------------------------------------------------------------------------
+class InFold:
+    """InstanceNorm2d (+ReLU) that has NOT been applied yet to a raw convolution output: per-sample `stats` fp32 [B, 4C] =
+    scale | shift | mean | invstd (liso_conv_in_finalize).  Consumers apply it on the fly: the next convolution in its prologue
+    (per-sample vectors), a residual tail in `residual_relu`.  No autograd: the SLIM encoders use it under no_grad."""
+
+    def __init__(self, stats, channels, relu=True):
+        self.stats, self.channels, self.relu = stats, int(channels), bool(relu)
+
+    @property
+    def scale(self):
+        return self.stats  # element [b * 4C + c]
+
+    @property
+    def shift(self):
+        return self.stats[:, self.channels:]  # element [b * 4C + C + c]: same stride, offset C
+
+    @property
+    def stride(self):
+        return 4 * self.channels
+
+
+def _norm_kind(norm):
+    """'none' | 'instance' | None (a layer this path does not fold)"""
+    if isinstance(norm, torch.nn.Sequential) and len(norm) == 0:
+        return "none"
+    if isinstance(norm, torch.nn.InstanceNorm2d) and not norm.track_running_stats:
+        return "instance"
+    return None
+
+
+@torch.no_grad()
+def conv_in(x_raw, fold, conv, norm, relu=True, spec=None):
+    """inference: conv(pending(x_raw)) followed by `norm` (InstanceNorm2d or nothing) and an optional ReLU.
+    -> (y_raw, InFold | None): with InstanceNorm the output stays raw and the normalisation (+ReLU) pending; without a
+    normalisation the ReLU runs in the convolution's epilogue."""
+    spec = spec or ConvSpec.of(conv)
+    kind = _norm_kind(norm)
+    kw = {}
+    if fold is not None:
+        kw = dict(in_scale=fold.scale, in_shift=fold.shift, in_relu=fold.relu, affine_batch_stride=fold.stride)
+    if kind == "none":
+        y, _ = conv_forward(x_raw, conv.weight, conv.bias, spec, out_relu=relu, **kw)
+        return y, None
+    y, part = conv_forward(x_raw, conv.weight, conv.bias, spec, want_stats=True, **kw)
+    B, C, H, W = y.shape
+    stats = torch.empty((B, 4 * C), dtype=torch.float32, device=y.device)
+    rows, _, cop = part.shape
+    with torch.cuda.device(y.device):
+        L.check(L.lib().liso_conv_in_finalize(L.ptr(part), rows // B, B, C, cop, H * W,
+                                              L.ptr(norm.weight) if norm.affine else None, L.ptr(norm.bias) if norm.affine else None,
+                                              float(norm.eps), L.ptr(stats), L.stream_ptr()), "conv_in_finalize")
+    return y, InFold(stats, C, relu)
+
+
+@torch.no_grad()
+def residual_relu(a_raw, a_fold, b_raw, b_fold):
+    """relu(fa(a) + fb(b)) with the pending InstanceNorm (+ReLU) of either branch applied on the fly; NHWC fp32 in and out"""
+    av, _ = as_nhwc(a_raw, 4)
+    bv, _ = as_nhwc(b_raw, 4)
+    assert av.shape == bv.shape and av.is_contiguous() and bv.is_contiguous() and av.dtype == torch.float32
+    B, H, W, C = av.shape
+    out = torch.empty_like(av)
+    sa = (L.ptr(a_fold.scale), L.ptr(a_fold.shift), a_fold.stride, int(a_fold.relu)) if a_fold is not None else (None, None, 0, 0)
+    sb = (L.ptr(b_fold.scale), L.ptr(b_fold.shift), b_fold.stride, int(b_fold.relu)) if b_fold is not None else (None, None, 0, 0)
+    with torch.cuda.device(av.device):
+        L.check(L.TIMER.launch("residual_affine_relu", lambda: L.lib().liso_residual_affine_relu_f32(
+            L.ptr(av), *sa, L.ptr(bv), *sb, L.ptr(out), B, H * W, C, L.stream_ptr()), units=12 * av.numel()), "residual_affine_relu")
+    return out.permute(0, 3, 1, 2)
 
 
 class _Materialize(torch.autograd.Function):

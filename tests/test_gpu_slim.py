@@ -540,3 +540,37 @@ def test_fused_conv_gru_equals_reference_op_sequence(defer):
     assert rel(oa, ob) < 1e-5 and rel(ha, hb) < 1e-4
     assert all(rel(a, b) < 1e-4 for a, b in zip(xa, xb))
     assert all(rel(a, b) < 1e-3 for a, b in zip(pa, pb)), [rel(a, b) for a, b in zip(pa, pb)]
+
+
+@pytest.mark.parametrize("norm_fn", ["instance", "none", "instance_affine"])
+def test_small_encoder_folded_inference_equals_module_path(norm_fn):
+    """SmallEncoder under no_grad: InstanceNorm + ReLU applied by the consumer convolution's prologue / the one-kernel residual
+    tail (mfma_conv.InFold, liso_conv_in_finalize, liso_residual_affine_relu_f32) vs the module-by-module path (the same
+    convolution kernels, torch's InstanceNorm2d / ReLU / add), batch of 3 different images"""
+    from liso_amd.slim.model.extractor import SmallEncoder
+
+    dev = torch.device("cuda")
+    torch.manual_seed(3)
+    enc = SmallEncoder(output_dim=128, norm_fn=norm_fn).to(dev).eval()
+    if norm_fn == "instance_affine":
+        with torch.no_grad():
+            for m in enc.modules():
+                if isinstance(m, torch.nn.InstanceNorm2d):
+                    m.weight.uniform_(0.5, 1.5)
+                    m.bias.uniform_(-0.5, 0.5)
+    x = (torch.randn(3, 64, 128, 160, device=dev) * torch.tensor([1.0, 3.0, 0.2], device=dev).view(3, 1, 1, 1) + 0.5)
+    x = x.contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        enc.fold_inference = True
+        assert enc._fold_inference(x)
+        got = enc(x)
+        enc.fold_inference = False
+        ref = enc(x)
+    assert got.shape == ref.shape == (3, 128, 16, 20)
+    err = float((got - ref).abs().max() / ref.abs().max())
+    assert err <= 2e-4, err
+    # per-sample statistics: sample 1 alone gives the same result as inside the batch
+    with torch.no_grad():
+        enc.fold_inference = True
+        alone = enc(x[1:2].contiguous(memory_format=torch.channels_last))
+    assert float((alone - got[1:2]).abs().max()) <= 1e-5 * float(got.abs().max())
