@@ -90,7 +90,7 @@ class _PillarFeatureScatter(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, weight, gamma, beta, running_mean, running_var, points, offsets, pcfg, training, momentum, eps,
-                out_dtype):
+                out_dtype, out=None):
         L.require_cuda(points, weight)
         lib = L.lib()
         dev = points.device
@@ -107,8 +107,13 @@ class _PillarFeatureScatter(torch.autograd.Function):
                                                 L.ptr(weight), L.ptr(gamma), L.ptr(beta), L.ptr(running_mean),
                                                 L.ptr(running_var), float(momentum), float(eps), int(training),
                                                 L.ptr(bn_out), L.ptr(moments), L.ptr(partials), st), "pfn_bn_prepare")
-            canvas = torch.empty((B, pcfg.gx, pcfg.gy, 64), dtype=out_dtype, device=dev)  # written densely by the kernel
-            occupancy = torch.empty((B, 1, pcfg.gx, pcfg.gy), dtype=torch.float32, device=dev)
+            if out is not None:  # caller-owned destination (static graph inputs): [B, gx, gy, 64] rows + occupancy, both dense
+                canvas, occupancy = out
+                assert canvas.shape == (B, pcfg.gx, pcfg.gy, 64) and canvas.dtype == out_dtype and canvas.is_contiguous()
+                assert occupancy.shape == (B, 1, pcfg.gx, pcfg.gy) and occupancy.is_contiguous()
+            else:
+                canvas = torch.empty((B, pcfg.gx, pcfg.gy, 64), dtype=out_dtype, device=dev)  # written densely by the kernel
+                occupancy = torch.empty((B, 1, pcfg.gx, pcfg.gy), dtype=torch.float32, device=dev)
             L.check(L.TIMER.launch("pfn_forward_scatter", lambda: lib.liso_pfn_forward_scatter(
                 L.ptr(feat), L.ptr(pt_off), L.ptr(voxel_cell), ctypes.byref(pcfg), B, L.ptr(cell_to_voxel), L.ptr(weight),
                 L.ptr(bn_out), L.ptr(canvas), int(out_dtype == torch.bfloat16), L.ptr(occupancy), st)),
@@ -137,7 +142,7 @@ class _PillarFeatureScatter(torch.autograd.Function):
                                           L.ptr(num_voxels), L.ptr(weight), L.ptr(gamma), L.ptr(bn_out), L.ptr(moments),
                                           int(ctx.training), L.ptr(g), int(g.dtype == torch.bfloat16), L.ptr(gw), L.ptr(gg),
                                           L.ptr(gb), L.ptr(partials), L.stream_ptr()), "pfn_backward")
-        return gw, gg, gb, None, None, None, None, None, None, None, None, None
+        return gw, gg, gb, None, None, None, None, None, None, None, None, None, None
 
 
 class PointsPillarFeatureNetWrapper(nn.Module):
@@ -208,8 +213,8 @@ class PointsPillarFeatureNetWrapper(nn.Module):
                           torch.zeros((), device=cat.device))
         return vox, num_points[rows], coors[rows]
 
-    def extract_pts_feat(self, pts):
-        """reference :86-102"""
+    def extract_pts_feat(self, pts, out=None):
+        """reference :86-102.  `out` (extension): (canvas rows [B, gx, gy, 64], occupancy [B, 1, gx, gy]) to write into"""
         cat, offsets = self._cat(pts)
         C = cat.shape[1]
         assert C == self.num_input_channels, (C, self.num_input_channels)
@@ -219,9 +224,9 @@ class PointsPillarFeatureNetWrapper(nn.Module):
             lyr.norm.num_batches_tracked += 1
         x, occ = _PillarFeatureScatter.apply(lyr.linear.weight, lyr.norm.weight, lyr.norm.bias, lyr.norm.running_mean,
                                              lyr.norm.running_var, cat, offsets, self._pcfg(C), training,
-                                             lyr.norm.momentum, lyr.norm.eps, self.out_dtype)
+                                             lyr.norm.momentum, lyr.norm.eps, self.out_dtype, out)
         return x, occ
 
-    def forward(self, pcl_t0, img_t0=None):
+    def forward(self, pcl_t0, img_t0=None, out=None):
         """reference :104-107"""
-        return self.extract_pts_feat(pcl_t0)
+        return self.extract_pts_feat(pcl_t0, out=out)

@@ -77,19 +77,28 @@ class RAFT(nn.Module):
         aux["fw_bw_batched"] = both  # per iteration [2B,H,W,8]: samples [:B] = forward flow, [B:] = backward flow
         return [p[:B] for p in both], [p[B:] for p in both], aux
 
-    def encode_pillars(self, pcl_t0, pcl_t1):
+    def encode_pillars(self, pcl_t0, pcl_t1, out=None):
         """the pillar canvases of both sweeps: (img_t0, occ_t0, img_t1, occ_t1); differentiable w.r.t. the pillar encoder's
-        parameters when gradients are enabled"""
-        return (*self.pp_layer(pcl_t0), *self.pp_layer(pcl_t1))
+        parameters when gradients are enabled.  `out` = (rows [2B, gx, gy, 64], occupancy [2B, 1, gx, gy]): both sweeps are
+        written into these buffers (static hipGraph inputs: no copy, and the batch of both sweeps needs no concatenation);
+        the result then carries a fifth element, the stacked canvas [2B, 64, gx, gy]."""
+        if out is None:
+            return (*self.pp_layer(pcl_t0), *self.pp_layer(pcl_t1))
+        rows, occ = out
+        B = rows.shape[0] // 2
+        a = self.pp_layer(pcl_t0, out=(rows[:B], occ[:B]))
+        b = self.pp_layer(pcl_t1, out=(rows[B:], occ[B:]))
+        return (*a, *b, rows.permute(0, 3, 1, 2))
 
     def infer_forward_direction(self, pcl_t0, pcl_t1, canvases=None):
         """Inference for consumers of the t0 -> t1 flow only (the box miner): one direction, last iteration.
         -> ([B,H,W,8(+1)] network output, aux).  `canvases`: precomputed `encode_pillars` result (callers that replay the
         rest from a hipGraph keep the pillar encoder outside of it)."""
-        img_t0, occ_t0, img_t1, occ_t1 = canvases if canvases is not None else self.encode_pillars(pcl_t0, pcl_t1)
+        canvases = canvases if canvases is not None else self.encode_pillars(pcl_t0, pcl_t1)
+        img_t0, occ_t0, img_t1, occ_t1 = canvases[:4]
         aux = {"t0": {"bev_net_input_dbg": occ_t0}, "t1": {"bev_net_input_dbg": occ_t1}}
         B = img_t0.shape[0]
-        fmap = self.fnet(torch.cat([img_t0, img_t1], dim=0))
+        fmap = self.fnet(canvases[4] if len(canvases) > 4 else torch.cat([img_t0, img_t1], dim=0))
         out = self.predict_single_flow_map_and_classes(img_t0, fmap[:B], fmap[B:], self.head_decoder_fw, only_last=True)
         return out[-1], aux
 

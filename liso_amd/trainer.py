@@ -164,8 +164,9 @@ class DetectorTrainer:
     # (voxelise + PFN + scatter; 10 launches) runs eagerly around it: replaying ITS launches from a graph while other pillar-
     # encoder calls run eagerly in the same process (the LISO loop's SLIM inference) ends in a GPU memory fault -- bisected
     # to exactly that combination (scripts/try_loop_graph3.py), root cause not found; the other kernels replay cleanly.
-    def _pillars(self, pcls):
-        bev, occ = self.net.model.pfn(pcl_t0=pcls, img_t0=None)
+    def _pillars(self, pcls, out=None):
+        """`out`: (canvas rows [B, gx, gy, 64], occupancy) to write into -- the graph's static inputs (no copy afterwards)"""
+        bev, occ = self.net.model.pfn(pcl_t0=pcls, img_t0=None, out=out)
         return bev, occ
 
     def _capture(self, pcls, targets):
@@ -218,10 +219,9 @@ class DetectorTrainer:
             self._graph = None
             self._capture(pcls, targets)
             self._graph_sig = sig
-        bev, occ = self._pillars(pcls)
+        # the eager pillar encoder writes straight into the graph's input buffers (its own backward runs on saved feature rows)
+        bev, occ = self._pillars(pcls, out=(self._static_bev.detach().permute(0, 2, 3, 1), self._static_occ))
         with torch.no_grad():
-            self._static_bev.copy_(bev.detach(), non_blocking=True)
-            self._static_occ.copy_(occ, non_blocking=True)
             for k, v in targets.items():
                 self._static_targets[k].copy_(v, non_blocking=True)
         self._graph.replay()
@@ -545,14 +545,22 @@ class LisoLoopTrainer:
         from liso_amd.slim.model.slim import get_network_input_pcls
 
         raft = self.slim.raft_network
-        with torch.no_grad():  # pillar encoder eagerly (see DetectorTrainer: its launches must not be replayed from a graph here)
-            canv = raft.encode_pillars(get_network_input_pcls(self.cfg, sample_t0, "ta", to_device=dev),
-                                       get_network_input_pcls(self.cfg, sample_t1, "ta", to_device=dev))
+        pcls = (get_network_input_pcls(self.cfg, sample_t0, "ta", to_device=dev), get_network_input_pcls(self.cfg, sample_t1, "ta", to_device=dev))
+        first = self._infer_graph is None or sig != self._infer_sig
+        with torch.no_grad():  # pillar encoder eagerly (its rocPRIM sort memsets: liso_amd/utils/graph_safety.py) ...
+            if first:
+                canv = raft.encode_pillars(*pcls)
+            else:  # ... straight into the graph's input buffers: no copy, no concatenation of the two sweeps
+                raft.encode_pillars(*pcls, out=self._static_rows)
         with torch.no_grad():  # a device scan (torch.cumsum): eagerly, its memset nodes do not survive in a graph (graph_safety.py)
             thr = self.slim.moving_dynamicness_threshold.value()
         if self._infer_graph is None or sig != self._infer_sig:
             self._static_in = SlimTrainer._map_tensors((sample_t0, sample_t1), lambda t: t.to(dev).clone())
-            self._static_canv = tuple(c.clone() for c in canv)
+            B_ = canv[0].shape[0]
+            rows = torch.cat([canv[0], canv[2]], dim=0).permute(0, 2, 3, 1).contiguous()  # [2B, gx, gy, 64]
+            occ = torch.cat([canv[1], canv[3]], dim=0).contiguous()
+            self._static_rows = (rows, occ)
+            self._static_canv = (rows[:B_].permute(0, 3, 1, 2), occ[:B_], rows[B_:].permute(0, 3, 1, 2), occ[B_:], rows.permute(0, 3, 1, 2))
             self._static_thr = thr.clone()
             s0, s1 = self._static_in
             side = self._flow_stream  # (HIP maps streams onto 4 hardware queues: capture on a pipeline stream, no extra one)
@@ -568,8 +576,6 @@ class LisoLoopTrainer:
             self._infer_sig = sig
         else:
             SlimTrainer._copy_tensors(self._static_in, (sample_t0, sample_t1))
-            for d, c in zip(self._static_canv, canv):
-                d.copy_(c, non_blocking=True)
             self._static_thr.copy_(thr, non_blocking=True)
         self._infer_graph.replay()
         return self._static_flow
