@@ -53,6 +53,7 @@ struct FwdArgs {
     int tiles_x, tiles_y, n_nt, total;
     int x_plane_bytes;  // LDS bytes of one plane of the input tile (max over classes), multiple of 16
     int pipelined;      // one register batch holds a whole slab: loads of slab k+1 overlap the MFMAs of slab k
+    int group_bytes;    // LDS bytes of one split-K group's tile + panels (SK = 2 instantiations)
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int total) {
@@ -72,8 +73,11 @@ __device__ __forceinline__ float round_bf16(float v) { return (float)(__bf16)v; 
 
 __device__ __forceinline__ bf8 as_bf8(const uint4& v) { return __builtin_bit_cast(bf8, v); }
 
-template <int MODE, int MI, int NJ, bool OUT_F32, int CS>
-__global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(const liso_conv_desc d, const FwdArgs a) {
+// SK = 2 (small maps, one sample: 100-200 blocks of one wave per SIMD, where the slab loop is bound by the latency of its own
+// loads): the block has two groups of 4 waves, each with its own tile + panel buffers, that take alternate channel slabs (twice
+// the loads in flight per CU, half the slab iterations); group 1 hands its accumulators over through LDS before the epilogue.
+template <int MODE, int MI, int NJ, bool OUT_F32, int CS, int SK = 1>
+__global__ __launch_bounds__(kThreads * SK, SK == 1 ? 2 : 1) void conv_igemm_kernel(const liso_conv_desc d, const FwdArgs a) {
     constexpr int BNT = 32 * NJ;
     constexpr int TH = 4 * MI;
     constexpr bool X3 = MODE == LISO_CONV_F32X3;
@@ -85,7 +89,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(const liso_conv
     constexpr int WTAP = PSZ * 16;             // bytes of one panel
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int tid_all = threadIdx.x, grp = SK == 1 ? 0 : tid_all >> 8;
+    const int tid = tid_all & (kThreads - 1), wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
     int t = xcd_remap(blockIdx.x, a.total);
     const int nt = t % a.n_nt;
     t /= a.n_nt;
@@ -107,12 +112,12 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(const liso_conv
     // LDS: [tap tables 512 B][input tile, PLANES planes][weight panels of one stage: [tap][plane][K8][BNT][8]]
     int* s_toff = reinterpret_cast<int*>(smem);          // byte offset of the tap inside the input tile
     int* s_tapw = s_toff + 64;                           // tap index inside the packed weights
-    unsigned char* xs = smem + 512;
+    unsigned char* xs = smem + 512 + (SK == 1 ? 0 : grp * a.group_bytes);
     unsigned char* wsb = xs + a.x_plane_bytes * PLANES;
     const int G = a.g_taps;
-    if (tid < te - tb) {
-        s_toff[tid] = ((d.tap_dy[tb + tid] - dy0) * in_w + (d.tap_dx[tb + tid] - dx0)) * PS;
-        s_tapw[tid] = d.tap_w[tb + tid];
+    if (tid_all < te - tb) {
+        s_toff[tid_all] = ((d.tap_dy[tb + tid_all] - dy0) * in_w + (d.tap_dx[tb + tid_all] - dx0)) * PS;
+        s_tapw[tid_all] = d.tap_w[tb + tid_all];
     }
 
     int a_off[MI];
@@ -296,7 +301,57 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(const liso_conv
         }
     };
 
-    if (a.pipelined) {
+    if constexpr (SK > 1) {
+        // (always pipelined) the groups take alternate slabs; both run the same number of barriers
+        uint4 xv[XB], wv[WB];
+        unsigned xok = 0u;
+        const int chunks = n_taps * PLANES * PSZ;
+        const int nslab = (d.ci + CS - 1) / CS, iters = (nslab + SK - 1) / SK;
+        __syncthreads();  // tap tables
+        int c0 = grp * CS;
+        bool have = c0 < d.ci;
+        if (have) {
+            load_x(c0, 0, xv, xok);
+            load_w(c0, 0, chunks, 0, wv);
+        }
+        for (int it = 0; it < iters; it++) {
+            if (it > 0) __syncthreads();  // every read of the previous slab's tile / panels is done
+            if (have) {
+                store_x(c0, 0, xv, xok);
+                store_w(chunks, 0, wv);
+            }
+            __syncthreads();
+            const int cn = c0 + SK * CS;
+            const bool have_n = cn < d.ci;
+            if (have_n) {
+                load_x(cn, 0, xv, xok);
+                load_w(cn, 0, chunks, 0, wv);
+            }
+            if (have) mfma_taps(0, n_taps);
+            c0 = cn;
+            have = have_n;
+        }
+        __syncthreads();
+        // group 1 -> group 0: accumulators through LDS ([register][thread]: conflict-free), then one epilogue
+        float* xfer = reinterpret_cast<float*>(smem + 512);
+        if (grp == 1) {
+#pragma unroll
+            for (int i = 0; i < MI; i++)
+#pragma unroll
+                for (int j = 0; j < NJ; j++)
+#pragma unroll
+                    for (int e = 0; e < 16; e++) xfer[((i * NJ + j) * 16 + e) * kThreads + tid] = acc[i][j][e];
+        }
+        __syncthreads();
+        if (grp == 0) {
+#pragma unroll
+            for (int i = 0; i < MI; i++)
+#pragma unroll
+                for (int j = 0; j < NJ; j++)
+#pragma unroll
+                    for (int e = 0; e < 16; e++) acc[i][j][e] += xfer[((i * NJ + j) * 16 + e) * kThreads + tid];
+        }
+    } else if (a.pipelined) {
         // the whole slab (tile + the panels of all taps) fits one batch of registers: software pipeline over the slabs
         uint4 xv[XB], wv[WB];
         unsigned xok;
@@ -363,7 +418,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(const liso_conv
     for (int i = 0; i < MI; i++) {
         const int vy = ty * TH + wave * MI + i;
         const int oy = vy * d.osy + ooy;
-        const unsigned rowmask = (vy < d.hv && oy < d.ho) ? colmask : 0u;
+        const unsigned rowmask = (grp == 0 && vy < d.hv && oy < d.ho) ? colmask : 0u;
         const long row_base = (((long)b * d.ho + oy) * d.wo + col0) * d.y_pix_stride + d.y_ch_off;
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
@@ -425,13 +480,13 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(const liso_conv
         for (int j = 0; j < NJ; j++) {
             const float t1 = s1[j] + __shfl_xor(s1[j], 32);
             const float t2 = s2[j] + __shfl_xor(s2[j], 32);
-            if (h == 0) {
+            if (h == 0 && grp == 0) {
                 red[(wave * BNT + j * 32 + r) * 2 + 0] = t1;
                 red[(wave * BNT + j * 32 + r) * 2 + 1] = t2;
             }
         }
         __syncthreads();
-        if (tid < BNT) {
+        if (tid_all < BNT) {
             float q1 = 0.0f, q2 = 0.0f;
 #pragma unroll
             for (int w = 0; w < 4; w++) {
@@ -551,7 +606,7 @@ int round_up(int v, int m) { return (v + m - 1) / m * m; }
 int check_launch() { return hipGetLastError() == hipSuccess ? LISO_OK : LISO_ELAUNCH; }
 
 struct Plan {
-    int mi, nj, cs, g, lds;
+    int mi, nj, cs, g, lds, sk;
     FwdArgs a;
 };
 
@@ -664,19 +719,28 @@ bool make_plan(const liso_conv_desc& d, Plan* p) {
     a.tiles_x = (d.wv + 31) / 32;
     a.tiles_y = (d.hv + th - 1) / th;
     a.total = (int)blocks(th);
+    // split-K inside the block (two groups of 4 waves on alternate slabs): F32X3, one wave tile per wave, at most one block per CU
+    // anyway, at least two slabs, and both groups' buffers + the accumulator hand-over fit the CU's LDS
+    p->sk = 1;
+    a.group_bytes = round_up(a.x_plane_bytes * planes + max_taps * planes * (p->cs / 8) * bnt * 16, 16);
+    if (x3 && a.pipelined && p->mi == 1 && p->nj == 1 && a.total <= 256 && d.ci > p->cs && 512 + 2 * a.group_bytes <= 160 * 1024 &&
+        a.group_bytes >= 16 * kThreads * 4)
+        p->sk = 2;
+    if (const char* e = getenv("LISO_CONV_SK")) p->sk = (atoi(e) >= 2 && p->sk == 2) ? 2 : 1;  // experiments
+    if (p->sk == 2) p->lds = 512 + 2 * a.group_bytes;
     return true;
 }
 
-template <int MODE, int MI, int NJ, bool OUT_F32, int CS>
+template <int MODE, int MI, int NJ, bool OUT_F32, int CS, int SK = 1>
 int launch(const liso_conv_desc& d, const Plan& p, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)conv_igemm_kernel<MODE, MI, NJ, OUT_F32, CS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void*)conv_igemm_kernel<MODE, MI, NJ, OUT_F32, CS, SK>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024) != hipSuccess)
             return LISO_ELAUNCH;
         attr_set = true;
     }
-    conv_igemm_kernel<MODE, MI, NJ, OUT_F32, CS><<<p.a.total, kThreads, p.lds, st>>>(d, p.a);
+    conv_igemm_kernel<MODE, MI, NJ, OUT_F32, CS, SK><<<p.a.total, kThreads * SK, p.lds, st>>>(d, p.a);
     return check_launch();
 }
 
@@ -734,6 +798,8 @@ int liso_conv_forward(const liso_conv_desc* d, const void* x, const void* w_pack
         if (p.mi == 1 && p.nj == 2) LISO_GO(MODE, 1, 2, OF, CSA, CSB); \
         LISO_GO(MODE, 1, 1, OF, CSA, CSB);            \
     } while (0)
+    if (x3 && p.sk == 2)
+        return p.cs == 32 ? launch<LISO_CONV_F32X3, 1, 1, true, 32, 2>(*d, p, st) : launch<LISO_CONV_F32X3, 1, 1, true, 16, 2>(*d, p, st);
     if (x3) LISO_SEL(LISO_CONV_F32X3, true, 32, 16);
     if (of32) LISO_SEL(LISO_CONV_BF16, true, 64, 32);
     LISO_SEL(LISO_CONV_BF16, false, 64, 32);
