@@ -77,6 +77,15 @@ size_t liso_conv_packed_bytes(int k_channels, int n_channels, int taps, int mode
 int liso_conv_pack_weights(const float* src, int d0, int d1, int kh, int kw, int transposed, int for_dgrad, int mode,
                            void* dst, void* stream);
 
+/* The same for several weight tensors in ONE launch (a training step packs every layer twice -- forward and data-gradient
+ * panels: 57 launches of ~5 us for the CenterPoint backbone + head).  `jobs` is a HOST array read during the call. */
+typedef struct {
+    const float* src;
+    void* dst;
+    int d0, d1, kh, kw, transposed, for_dgrad, mode;
+} liso_conv_pack_job;
+int liso_conv_pack_weights_batched(const liso_conv_pack_job* jobs, int n_jobs, void* stream);
+
 /* rows of the statistics buffer one forward launch writes: stats_partial is fp32 [rows][2][co_pad]
  * (sum and sum of squares of (stored value - stats_shift[c]) over the pixels of one block). */
 int liso_conv_stats_rows(const liso_conv_desc* d);

@@ -121,6 +121,7 @@ SIGNATURES = {
     "liso_centerloss_fwd_f32": (_i, [_vp] * 17 + [_sz, _vp]),
     "liso_centerloss_bwd_f32": (_i, [_vp] * 21),
     "liso_render_center_targets_f32": (_i, [_vp] * 12),
+    "liso_conv_pack_weights_batched": (_i, [_vp, _i, _vp]),
     "liso_conv_in_finalize": (_i, [_vp, _i, _i, _i, _i, ctypes.c_long, _vp, _vp, _f, _vp, _vp]),
     "liso_residual_affine_relu_f32": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, ctypes.c_long, _i, _vp]),
     # include/liso_optim.h
@@ -159,6 +160,12 @@ class ConvDesc(ctypes.Structure):
                 ("class_oox", _i * CONV_MAX_CLASSES), ("n_taps", _i), ("tap_dy", _i * CONV_MAX_TAPS), ("tap_dx", _i * CONV_MAX_TAPS),
                 ("tap_w", _i * CONV_MAX_TAPS), ("w_taps", _i), ("mode", _i), ("out_f32", _i), ("in_relu", _i), ("out_relu", _i),
                 ("in_affine_batch_stride", _i)]
+
+
+class ConvPackJob(ctypes.Structure):
+    """mirror of liso_conv_pack_job (include/liso_conv.h)"""
+    _fields_ = [("src", _vp), ("dst", _vp), ("d0", _i), ("d1", _i), ("kh", _i), ("kw", _i), ("transposed", _i), ("for_dgrad", _i),
+                ("mode", _i)]
 
 
 class KnnGrid(ctypes.Structure):

@@ -500,11 +500,41 @@ __global__ __launch_bounds__(kThreads * SK, SK == 1 ? 2 : 1) void conv_igemm_ker
 }
 
 // ---- weight packing ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void pack_chunk(const float* __restrict__ src, int d1, int taps, int swap_ab, int K, int N, int Kp, int Np,
+                                           unsigned short* __restrict__ dst, long q);
+
 __global__ void pack_weights_kernel(const float* __restrict__ src, int d0, int d1, int taps, int swap_ab, int K, int N, int Kp,
                                     int Np, int planes, unsigned short* __restrict__ dst) {
     const long total = (long)planes * taps * (Kp / 8) * Np;  // one thread per 16-B chunk
     const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= total) return;
+    pack_chunk(src, d1, taps, swap_ab, K, N, Kp, Np, dst, q);
+}
+
+// several weight tensors in one launch (a training step packs every layer twice: forward and data-gradient panels)
+constexpr int kPackJobs = 48;
+struct PackJob {
+    const float* src;
+    unsigned short* dst;
+    int d1, taps, swap_ab, K, N, Kp, Np;
+};
+struct PackTable {
+    PackJob job[kPackJobs];
+    long end[kPackJobs];  // exclusive prefix of chunk counts
+    int n;
+};
+
+__global__ void pack_weights_batched_kernel(const PackTable t) {
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= t.end[t.n - 1]) return;
+    int j = 0;
+    while (q >= t.end[j]) j++;
+    const PackJob& b = t.job[j];
+    pack_chunk(b.src, b.d1, b.taps, b.swap_ab, b.K, b.N, b.Kp, b.Np, b.dst, q - (j ? t.end[j - 1] : 0));
+}
+
+__device__ __forceinline__ void pack_chunk(const float* __restrict__ src, int d1, int taps, int swap_ab, int K, int N, int Kp, int Np,
+                                           unsigned short* __restrict__ dst, long q) {
     const int n = (int)(q % Np);
     long t = q / Np;
     const int k8 = (int)(t % (Kp / 8));
@@ -763,6 +793,28 @@ int liso_conv_pack_weights(const float* src, int d0, int d1, int kh, int kw, int
     const long total = (long)planes * taps * (Kp / 8) * Np;
     pack_weights_kernel<<<(int)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(src, d0, d1, taps, same ? 0 : 1, K, N, Kp, Np,
                                                                                       planes, (unsigned short*)dst);
+    return check_launch();
+}
+
+int liso_conv_pack_weights_batched(const liso_conv_pack_job* jobs, int n_jobs, void* stream) {
+    if (n_jobs == 0) return LISO_OK;
+    if (!jobs || n_jobs < 0) return LISO_EINVAL;
+    for (int base = 0; base < n_jobs; base += kPackJobs) {
+        PackTable t;
+        t.n = n_jobs - base < kPackJobs ? n_jobs - base : kPackJobs;
+        long run = 0;
+        for (int i = 0; i < t.n; i++) {
+            const liso_conv_pack_job& j = jobs[base + i];
+            if (!j.src || !j.dst || j.d0 <= 0 || j.d1 <= 0 || j.kh <= 0 || j.kw <= 0) return LISO_EINVAL;
+            const bool same = (j.transposed != 0) == (j.for_dgrad != 0);
+            const int K = same ? j.d1 : j.d0, N = same ? j.d0 : j.d1;
+            const int Kp = round_up(K, 16), Np = round_up(N, 64), taps = j.kh * j.kw, planes = j.mode == LISO_CONV_F32X3 ? 2 : 1;
+            t.job[i] = PackJob{j.src, (unsigned short*)j.dst, j.d1, taps, same ? 0 : 1, K, N, Kp, Np};
+            run += (long)planes * taps * (Kp / 8) * Np;
+            t.end[i] = run;
+        }
+        pack_weights_batched_kernel<<<(unsigned)((run + 255) / 256), 256, 0, (hipStream_t)stream>>>(t);
+    }
     return check_launch();
 }
 

@@ -75,7 +75,11 @@ class DetectorTrainer:
         self.fused_loss = (fused_centerpoint.supports(cfg) and device.type == "cuda") if fused_loss is None else fused_loss
         self.net = BoxLearner(cfg).to(device)
         self.net.model.set_compute_dtype(compute_dtype)
-        if compute_dtype != torch.float32:
+        from liso_amd.utils import mfma_conv as MC
+        if compute_dtype != torch.float32 and MC.backend() != "mfma":
+            # (MIOpen comparison path only: its NHWC kernels want channels-last filters.  The own kernels pack their panels from
+            # the contiguous fp32 master weights: channels-last parameters would cost a layout copy per pack and strided
+            # gradient accumulations -- ~170 extra launches per step, measured)
             self.net.model.rpn.to(memory_format=torch.channels_last)
             self.net.model.center_head.to(memory_format=torch.channels_last)
         self.model = self.net
@@ -186,16 +190,27 @@ class DetectorTrainer:
         side = self._capture_stream  # (kept alive with the graph)
         side.wait_stream(torch.cuda.current_stream(dev))
 
+        from liso_amd.utils import mfma_conv as MC
+
+        self._pack_jobs = None
+
         def body():
             self._flat_grad.zero_()
             self._static_bev.grad.zero_()
-            total, _, _ = self.loss(None, self._static_targets, canvas=(self._static_bev, self._static_occ))
-            total.backward()
+            if self._pack_jobs:  # the forward / data-gradient panels of every layer from ONE launch (recorded in the warm-up)
+                MC.set_step_packs(MC.batched_pack(self._pack_jobs))
+            try:
+                total, _, _ = self.loss(None, self._static_targets, canvas=(self._static_bev, self._static_occ))
+                total.backward()
+            finally:
+                MC.set_step_packs(None)
             return total.detach()
 
         with torch.cuda.stream(side):  # warm-up off the capture: lazy initialisations, allocator pools
-            for _ in range(2):
-                body()
+            MC.record_pack_jobs(True)
+            body()
+            self._pack_jobs = MC.record_pack_jobs(False)
+            body()
         torch.cuda.current_stream(dev).wait_stream(side)
         with torch.no_grad():  # the warm-up passes must not count as training steps (BatchNorm statistics / counters)
             for k, v in self.net.state_dict().items():

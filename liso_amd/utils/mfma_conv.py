@@ -152,6 +152,48 @@ def as_nhwc(t, vec):
 _PACK_CACHE = {}
 
 
+_PACK_RECORD = None  # dict while the pack requests of a step are being recorded
+_STEP_PACKS = None   # dict while a step runs on panels that were packed by ONE batched launch
+
+
+def record_pack_jobs(on=True):
+    """start (-> None) / stop (-> list of jobs) recording which (Parameter, geometry, direction, arithmetic) panels a step asks
+    for.  A trainer records one warm-up step, then opens every captured step with `set_step_packs(batched_pack(jobs))`: one
+    launch instead of one per layer and direction (57 for the CenterPoint backbone + head)."""
+    global _PACK_RECORD
+    if on:
+        _PACK_RECORD = {}
+        return None
+    jobs, _PACK_RECORD = list((_PACK_RECORD or {}).values()), None
+    return jobs
+
+
+def batched_pack(jobs):
+    """-> {key: packed panels} for `set_step_packs`; one liso_conv_pack_weights_batched call"""
+    out, arr = {}, (L.ConvPackJob * len(jobs))()
+    keep = []
+    for i, (key, weight, spec, for_dgrad, mode) in enumerate(jobs):
+        w = weight.detach()
+        if w.dtype != torch.float32 or not w.is_contiguous():
+            w = w.float().contiguous()
+        keep.append(w)
+        d0, d1 = w.shape[0], w.shape[1]
+        same = spec.transposed == bool(for_dgrad)
+        K, N = (d1, d0) if same else (d0, d1)
+        dst = torch.empty(L.lib().liso_conv_packed_bytes(K, N, spec.kh * spec.kw, mode), dtype=torch.uint8, device=w.device)
+        arr[i] = L.ConvPackJob(w.data_ptr(), dst.data_ptr(), d0, d1, spec.kh, spec.kw, int(spec.transposed), int(bool(for_dgrad)), mode)
+        out[key] = dst
+    if jobs:
+        with torch.cuda.device(jobs[0][1].device):
+            L.check(L.lib().liso_conv_pack_weights_batched(arr, len(jobs), L.stream_ptr()), "conv_pack_weights_batched")
+    return out
+
+
+def set_step_packs(packs):
+    global _STEP_PACKS
+    _STEP_PACKS = packs
+
+
 def pack_weights(weight, spec, for_dgrad, mode):
     """torch-layout fp32 master weights -> the kernels' packed bf16 panels (one launch).  The result is cached per weight
     tensor until the tensor is modified in place (`_version`: optimizer steps bump it), so frozen networks pack once and
@@ -159,6 +201,11 @@ def pack_weights(weight, spec, for_dgrad, mode):
     L.require_cuda(weight)
     if not isinstance(weight, torch.nn.Parameter):  # (temporaries: their storage is recycled, no stable identity)
         return _pack_weights(weight, spec, for_dgrad, mode)
+    pkey = (id(weight), spec.kh, spec.kw, spec.transposed, bool(for_dgrad), mode)
+    if _STEP_PACKS is not None and pkey in _STEP_PACKS:
+        return _STEP_PACKS[pkey]
+    if _PACK_RECORD is not None:
+        _PACK_RECORD[pkey] = (pkey, weight, spec, bool(for_dgrad), mode)
     if weight.requires_grad and torch.cuda.is_current_stream_capturing():
         # a captured training step must re-pack on every replay (the optimizer changes the weights in between): never let a
         # cache hit elide the pack launch from the graph
