@@ -199,11 +199,13 @@ class DetectorTrainer:
             self._static_bev.grad.zero_()
             if self._pack_jobs:  # the forward / data-gradient panels of every layer from ONE launch (recorded in the warm-up)
                 MC.set_step_packs(MC.batched_pack(self._pack_jobs))
+            MC.set_direct_grads(True)  # gradients of conv / BatchNorm parameters land in the flat buffer without an add each
             try:
                 total, _, _ = self.loss(None, self._static_targets, canvas=(self._static_bev, self._static_occ))
                 total.backward()
             finally:
                 MC.set_step_packs(None)
+                MC.set_direct_grads(False)
             return total.detach()
 
         with torch.cuda.stream(side):  # warm-up off the capture: lazy initialisations, allocator pools

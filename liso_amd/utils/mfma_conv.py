@@ -329,9 +329,9 @@ def conv_dgrad(dy, weight, spec, x_shape, out_dtype=None, packed=None):
     return dx.permute(0, 3, 1, 2)
 
 
-def conv_wgrad(x, dy, weight_shape, spec, in_scale=None, in_shift=None, in_relu=False, want_bias=True):
+def conv_wgrad(x, dy, weight_shape, spec, in_scale=None, in_shift=None, in_relu=False, want_bias=True, out_dw=None, out_db=None):
     """-> (dw fp32 in torch's layout `weight_shape`, dbias fp32 [Co] | None); None if the geometry is not supported by the
-    kernel (caller falls back to ATen's weight gradient)"""
+    kernel (caller falls back to ATen's weight gradient).  `out_dw` / `out_db`: dense fp32 tensors to write into (overwritten)."""
     L.require_cuda(x, dy)
     if spec.kh * spec.kw > 9:
         return None  # 7x7 kernels: 49 taps re-stage the same large halo tile per tap group; ATen's kernel is faster (3 layers)
@@ -353,8 +353,10 @@ def conv_wgrad(x, dy, weight_shape, spec, in_scale=None, in_shift=None, in_relu=
     if nbytes == 0:
         return None
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-    dw = torch.empty(weight_shape, dtype=torch.float32, device=x.device)
-    db = torch.empty(co, dtype=torch.float32, device=x.device) if want_bias else None
+    if co != co_true:
+        out_dw = out_db = None  # (padded channels: the result is sliced below)
+    dw = out_dw if out_dw is not None else torch.empty(weight_shape, dtype=torch.float32, device=x.device)
+    db = (out_db if out_db is not None else torch.empty(co, dtype=torch.float32, device=x.device)) if want_bias else None
     with torch.cuda.device(x.device):
         L.check(L.TIMER.launch(_timer_name(mode, "wgrad"), lambda: lib.liso_conv_wgrad(
             ctypes.byref(d), L.ptr(xv), L.ptr(in_scale) if in_scale is not None else None,
@@ -446,6 +448,32 @@ def eval_bn_fold(bn, relu=True):
     return BnFold([{"stats": stats, "gamma": bn.weight, "beta": bn.bias}], relu, False)
 
 
+_DIRECT_GRADS = False
+_DIRECT_TOUCHED = set()  # parameters written in place during the current step: a second contribution goes through autograd's add
+
+
+def set_direct_grads(on):
+    """While on, the backward of `_FusedConv` writes the gradients of leaf parameters that already own a dense fp32 `.grad` buffer
+    (a trainer's flat gradient views, zeroed at the start of the step) straight into that buffer -- the weight-gradient reduction,
+    the bias reduction and the BatchNorm backward take it as their output pointer -- and reports None to autograd: no AccumulateGrad
+    `add` per parameter (104 launches per detector step).  The first contribution of a step overwrites the (zeroed) buffer, any
+    further one to the same parameter is returned to autograd and added."""
+    global _DIRECT_GRADS
+    _DIRECT_GRADS = bool(on)
+    _DIRECT_TOUCHED.clear()
+
+
+def _direct_target(p):
+    """the dense fp32 .grad buffer of leaf parameter `p`, or None"""
+    if not _DIRECT_GRADS or not isinstance(p, torch.nn.Parameter):
+        return None
+    g = p.grad
+    if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.shape != p.shape or id(p) in _DIRECT_TOUCHED:
+        return None
+    _DIRECT_TOUCHED.add(id(p))  # (a BatchNorm consumed by two layers -- block output -> next block and deblock -- contributes twice)
+    return g
+
+
 def _bn_backward_group(g, x_raw, grp, relu, training):
     """gradient through relu?(bn(x_raw)) of ONE BatchNorm given g = dL/d(output): -> (dx_raw, dgamma, dbeta);
     g, x_raw logical NCHW (channel slices are copied: the kernels of include/liso_bn.h take dense [M, C] rows)"""
@@ -461,8 +489,10 @@ def _bn_backward_group(g, x_raw, grp, relu, training):
     M = xv.numel() // C
     lib = L.lib()
     dx = torch.empty_like(xv)
-    gg = torch.empty(C, dtype=torch.float32, device=xv.device)
-    gb = torch.empty(C, dtype=torch.float32, device=xv.device)
+    tg, tb = _direct_target(grp["gamma"]), _direct_target(grp["beta"])
+    direct = tg is not None and tb is not None
+    gg = tg if direct else torch.empty(C, dtype=torch.float32, device=xv.device)
+    gb = tb if direct else torch.empty(C, dtype=torch.float32, device=xv.device)
     nbytes = lib.liso_bn_workspace_bytes(C)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=xv.device)
     with torch.cuda.device(xv.device):
@@ -470,7 +500,7 @@ def _bn_backward_group(g, x_raw, grp, relu, training):
             L.ptr(gv), L.ptr(xv), int(xv.dtype == torch.bfloat16), M, C, L.ptr(grp["gamma"]), L.ptr(grp["stats"]), int(training),
             int(relu), L.ptr(dx), L.ptr(gg), L.ptr(gb), L.ptr(ws), nbytes, L.stream_ptr()),
             units=5 * M * C * xv.element_size()), "bn_relu_bwd")
-    return dx.permute(0, 3, 1, 2), gg, gb
+    return dx.permute(0, 3, 1, 2), (None if direct else gg), (None if direct else gb)
 
 
 def _bn_backward(g, x_raw, fold):
@@ -502,7 +532,8 @@ class _FusedConv(torch.autograd.Function):
         meta["stats_partial"] = part
         relu = bool(meta.get("out_relu", False))
         ctx.save_for_backward(x_raw, weight, y if relu else None)
-        ctx.meta = {"spec": spec, "fold": fold, "has_bias": bias is not None, "n_fold_params": len(fold_params), "relu": relu}
+        ctx.meta = {"spec": spec, "fold": fold, "has_bias": bias is not None, "n_fold_params": len(fold_params), "relu": relu,
+                    "bias_param": bias if isinstance(bias, torch.nn.Parameter) else None}
         return y
 
     @staticmethod
@@ -517,13 +548,20 @@ class _FusedConv(torch.autograd.Function):
         dw = db = dx = None
         fold_grads = [None] * ctx.meta["n_fold_params"]
         if ctx.needs_input_grad[1] or (ctx.meta["has_bias"] and ctx.needs_input_grad[2]):
+            tw = _direct_target(weight)
+            tb = _direct_target(ctx.meta["bias_param"]) if tw is not None and ctx.meta["has_bias"] else None
+            if ctx.meta["has_bias"] and tb is None:
+                tw = None  # (both or none: one launch produces both)
             res = conv_wgrad(x_raw, dy, tuple(weight.shape), spec, sc, sh, in_relu=fold.relu if fold is not None else False,
-                             want_bias=ctx.meta["has_bias"])
+                             want_bias=ctx.meta["has_bias"], out_dw=tw, out_db=tb)
             if res is None:
                 dw, db = _aten_wgrad(x_raw, dy, weight, spec, fold, ctx.meta["has_bias"])
             else:
                 dw, db = res
-            dw = dw.to(weight.dtype)
+                if tw is not None and dw is tw:  # written in place: nothing for autograd to accumulate
+                    dw, db = None, None
+            if dw is not None:
+                dw = dw.to(weight.dtype)
             if db is not None:
                 db = db.to(weight.dtype)
         if ctx.needs_input_grad[0] or any(ctx.needs_input_grad[4:]):
