@@ -360,14 +360,14 @@ def main():
         trainer = LisoLoopTrainer(cfg, dev, compute_dtype=dtype, total_steps=args.steps + args.warmup + 8, use_graph=not args.eager,
                                   overlap=overlap)
         # a ring of different sweep pairs; step i trains on pair i while (overlap) pairs i+1 / i+2 are in the mining stages
-        pairs = [slim_pair(2 + rank + 100 * i, dev, n_points=N_POINTS, grid=GRID, bev_range_m=BEV_RANGE) for i in range(4)]
+        pairs = [slim_pair(2 + rank + 100 * i, dev, n_points=N_POINTS, grid=GRID, bev_range_m=BEV_RANGE) for i in range(5)]
         s0, s1 = pairs[0]
         counter = [0]
 
         def step():
             i = counter[0]
             counter[0] += 1
-            return trainer.step(*pairs[i % len(pairs)], upcoming=(pairs[(i + 1) % len(pairs)], pairs[(i + 2) % len(pairs)]))
+            return trainer.step(*pairs[i % len(pairs)], upcoming=tuple(pairs[(i + k) % len(pairs)] for k in (1, 2, 3)))
 
         frames_per_step = 2
     else:

@@ -2,17 +2,21 @@
 // C ABI and the reference lines each stage replaces: include/liso_pillars.h.
 //
 // Design (HBM-bound stage; nothing here is GEMM-shaped enough for MFMA: K = C+6 <= 11):
-//   * voxelise is deterministic and sort-free:
+//   * voxelise is deterministic:
 //       assign      per point: cell id, atomicAdd(count[cell]), atomicMax(first[cell], INT_MAX - i)
 //       tile_count  per 1024-point tile: how many points are the first of their cell
 //       rank        voxel ordinal = exclusive prefix of "is first" in point order (the reference's voxel order),
 //                   voxels >= max_voxels dropped, coors / num_points / cell->row written
-//       fill        each point inserts its index into its voxel's 20 slots with an atomicMin cascade; the final
-//                   state is the 20 smallest indices in ascending order whatever the execution order
-//   * the PFN never materialises voxels[P,20,C], [P,20,10] or [P,20,64]: one wavefront owns one pillar, lanes 0..19
-//     gather the points (16 B each, L2-resident cloud), build the 10 decorated features into LDS, then the 64 lanes
-//     ARE the 64 output channels: 10 FMAs per row against an LDS-broadcast feature row, running max in a register,
-//     one coalesced 64-channel store per pillar into the channels-last canvas.
+//       sort        STABLE radix sort of (cell, point index) pairs (rocPRIM): inside a cell the points stay in arrival order;
+//       run_heads / place_slots: the first max_points entries of every cell's run are the pillar's slots
+//       (an earlier atomicMin insertion cascade cost 290 us at B = 4: adjacent LiDAR rays hit the same pillar together)
+//   * the PFN never materialises voxels[P,20,C], [P,20,10] or [P,20,64]: `pfn_decorate` walks count -> slot indices -> points once
+//     (32 lanes per pillar) and writes 12-float feature rows in pillar order (CSR); statistics / forward / backward stream those
+//     rows: a wave stages the rows of 4 consecutive pillars in LDS, the 64 lanes ARE the 64 output channels (running max in a
+//     register, one coalesced 64-channel store per pillar into the channels-last canvas; empty cells are zero-filled by other
+//     blocks of the same launch: every canvas cell is written exactly once, no memset pass).
+//   * no hipMemsetAsync anywhere (zero_fill.h): memset nodes do not survive hipGraph replays on this runtime; the radix sort does
+//     memset internally, so callers that replay from a graph keep this encoder in front of the graph (liso_amd/utils/graph_safety.py).
 //   * BatchNorm1d batch statistics come from the second moments of the 10-vector (sum f f^T in fp64, 66 numbers)
 //     instead of 2x64 per-channel sums over [P*20, 64]; the same moments give the BN backward terms in closed form.
 //   * all cross-workgroup reductions are two-stage with fixed order (no float atomics): results are reproducible.

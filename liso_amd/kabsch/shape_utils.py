@@ -151,7 +151,7 @@ class Shape:
             for k in keys:
                 v = self.__dict__[k]
                 if _is_t(v):
-                    self.__dict__[k] = torch.where(self.valid[..., None], v, torch.tensor(val).to(v.device, v.dtype))
+                    self.__dict__[k] = torch.where(self.valid[..., None], v, val)  # (scalar overload: no host->device copy)
                 else:
                     self.__dict__[k] = np.where(self.valid[..., None], v, val)
 
@@ -164,8 +164,9 @@ class Shape:
         return pprint.pformat(self.__dict__)
 
     # ---- geometry -----------------------------------------------------------------------------------------
-    def get_poses(self):
-        """reference :271-319 -- sensor_T_box as fp64 [.., 4, 4] (yaw about z only)."""
+    def get_poses(self, check_finite=True):
+        """reference :271-319 -- sensor_T_box as fp64 [.., 4, 4] (yaw about z only).  `check_finite=False` (extension) skips the
+        reference's `assert all(isfinite(rot))`, which is a device->host read."""
         unb = len(self.pos.shape) == 2
         pos = self.pos[None, ...] if unb else self.pos
         rot = None if self.rot is None else (self.rot[None, ...] if unb else self.rot)
@@ -175,7 +176,8 @@ class Shape:
             if rot is None or rot.shape[-1] == 0:
                 th = torch.zeros_like(pos[..., 0], dtype=torch.double)
             else:
-                assert torch.all(torch.isfinite(rot))
+                if check_finite:
+                    assert torch.all(torch.isfinite(rot))
                 th = rot[..., 0].to(torch.double)
             pose = torch_compose_matrix(pos[..., 0].to(torch.double), pos[..., 1].to(torch.double), th, t_z=tz)
         else:
@@ -231,13 +233,15 @@ def is_boxes_clearly_in_bev_range(boxes, bev_range_m):
     return torch.all(ok, dim=-1) if xp is torch else np.all(ok, axis=-1)
 
 
-def extract_box_motion_transform_without_sensor_odometry(pred_boxes_a, fg_kabsch_trafos, bg_kabsch_trafo):
-    """reference :583-605 -- b0_dT_b1 = inv(T_box) inv(T_bg) T_fg T_box (all fp64)."""
-    s0_T_box0 = pred_boxes_a.get_poses()
-    return torch.linalg.inv(s0_T_box0) @ torch.linalg.inv(bg_kabsch_trafo) @ (fg_kabsch_trafos @ s0_T_box0)
+def extract_box_motion_transform_without_sensor_odometry(pred_boxes_a, fg_kabsch_trafos, bg_kabsch_trafo, check=True):
+    """reference :583-605 -- b0_dT_b1 = inv(T_box) inv(T_bg) T_fg T_box (all fp64).  `check=False` (extension): the same LU
+    inverses without torch.linalg.inv's singularity check (a device->host read per call) and without get_poses' finiteness assert."""
+    s0_T_box0 = pred_boxes_a.get_poses(check_finite=check)
+    inv = torch.linalg.inv if check else (lambda m: torch.linalg.inv_ex(m).inverse)
+    return inv(s0_T_box0) @ inv(bg_kabsch_trafo) @ (fg_kabsch_trafos @ s0_T_box0)
 
 
-def extract_motion_in_pred_box_coordinates(pred_boxes_a, fg_kabsch_trafos, bg_kabsch_trafo):
+def extract_motion_in_pred_box_coordinates(pred_boxes_a, fg_kabsch_trafos, bg_kabsch_trafo, check=True):
     """reference :563-580"""
     return torch_decompose_matrix(
-        extract_box_motion_transform_without_sensor_odometry(pred_boxes_a, fg_kabsch_trafos, bg_kabsch_trafo))
+        extract_box_motion_transform_without_sensor_odometry(pred_boxes_a, fg_kabsch_trafos, bg_kabsch_trafo, check=check))

@@ -39,7 +39,7 @@ def fit_bev_box_z_and_height_using_points_in_box(pcl, boxes: Shape, box_height=1
 # ---- clustering block (reference :139-189) ---------------------------------------------------------------------------
 @torch.no_grad()
 def cluster_dynamic_pillars(dynamic_mask, bev_nonrigid_flow, row_coords_m, col_coords_m, eps=1.0, min_samples=5,
-                            flow_similarity_importance=2.0):
+                            flow_similarity_importance=2.0, pitch=None):
     """DBSCAN(eps, min_samples) of the dynamic pillars in (x, y, w fx, w fy, w fz) -- reference :151-172, on the device.
     dynamic_mask [B,gx,gy] bool, bev_nonrigid_flow [B,gx,gy,3] -> (labels int32 [B,gx,gy] with 0 = background/noise and
     k = sklearn label k-1, num_labels int64 [B])."""
@@ -50,7 +50,8 @@ def cluster_dynamic_pillars(dynamic_mask, bev_nonrigid_flow, row_coords_m, col_c
     flow = bev_nonrigid_flow.float().contiguous()
     assert flow.shape == (B, gx, gy, 3), flow.shape
     xs, ys = row_coords_m.float().contiguous(), col_coords_m.float().contiguous()
-    pitch = min(float(xs[1] - xs[0]) if gx > 1 else eps, float(ys[1] - ys[0]) if gy > 1 else eps)
+    if pitch is None:  # (two device->host reads; callers that know the grid pass it)
+        pitch = min(float(xs[1] - xs[0]) if gx > 1 else eps, float(ys[1] - ys[0]) if gy > 1 else eps)
     cfg = L.DbscanCfg(B, gx, gy, int(eps / pitch) + 1, int(min_samples), float(eps), float(flow_similarity_importance))
     core = torch.empty((B, gx, gy), dtype=torch.uint8, device=dev)
     parent = torch.empty((B, gx, gy), dtype=torch.int32, device=dev)
@@ -111,9 +112,19 @@ class FlowClusterDetector(torch.nn.Module):
         self.min_residual_flow_thresh_mps = 1.0  # 0.1 m displacement in 100 ms (reference :70)
         self.bev_img_grid_size = np.array(self.cfg.data.img_grid_size)
         self.kabsch_decoder = KabschDecoder(cfg)
+        c = self.pcl_bev_center_coords_homog_np  # [gx, gy, 4]: pillar pitch for the DBSCAN window, known on the host
+        dx = float(np.float32(c[1, 0, 0]) - np.float32(c[0, 0, 0])) if c.shape[0] > 1 else 1.0
+        dy = float(np.float32(c[0, 1, 1]) - np.float32(c[0, 0, 1])) if c.shape[1] > 1 else 1.0
+        self._pitch = min(dx, dy)
+        self.last_num_labels = None
 
     @torch.no_grad()
-    def forward(self, sample_data_ta, writer=None, writer_prefix: str = "", global_step: int = None, is_batched=True) -> Shape:
+    def forward(self, sample_data_ta, writer=None, writer_prefix: str = "", global_step: int = None, is_batched=True,
+                capacity: int = None) -> Shape:
+        """`capacity` (extension): fixed number of cluster / box slots.  The padded Shape then always has `capacity` columns and
+        the forward issues NO device->host read (the reference-shaped call reads the cluster count and the surviving-box count to
+        size its arrays); valid boxes, their order and values are the same as long as the cluster count (`self.last_num_labels`,
+        a device tensor the caller checks later) does not exceed `capacity`."""
         pcl = sample_data_ta["pcl_ta"]["pcl"]
         pcl_w_ground = sample_data_ta["pcl_full_w_ground_ta"]
         pillar_coors = sample_data_ta["pcl_ta"]["pillar_coors"]
@@ -132,10 +143,14 @@ class FlowClusterDetector(torch.nn.Module):
             target_shape=self.bev_img_grid_size, return_nonrigid_bev_flow=True)
         dynamic_mask = torch.squeeze(bev_dynamicness, dim=-1) > thresh.to(dev)[..., None, None]
         centers = self.pcl_bev_center_coords_homog  # [gx,gy,4] float32; x depends on the row only, y on the column only
-        labels, num_labels = cluster_dynamic_pillars(dynamic_mask, bev_nonrigid_flow, centers[:, 0, 0], centers[0, :, 1])
-        self.last_bev_labels = labels
+        labels, num_labels = cluster_dynamic_pillars(dynamic_mask, bev_nonrigid_flow, centers[:, 0, 0], centers[0, :, 1],
+                                                     pitch=self._pitch if capacity else None)
+        self.last_bev_labels, self.last_num_labels = labels, num_labels
         B = labels.shape[0]
-        k_max = int(num_labels.max()) if B > 0 else 0  # host round trip 1: sizes the padded box arrays
+        if capacity:
+            k_max = int(capacity)
+        else:
+            k_max = int(num_labels.max()) if B > 0 else 0  # host round trip 1: sizes the padded box arrays
         if k_max == 0:
             boxes = Shape.from_list_of_shapes([Shape.createEmpty().to_tensor().to(dev) for _ in range(B)], numeric_padding_value=0.0)
             return boxes if is_batched else boxes[0]
@@ -167,13 +182,13 @@ class FlowClusterDetector(torch.nn.Module):
         # reference :239-248,311: drop the rejected boxes of every sample, pad the batch with zeros
         counts = valid.sum(dim=1)
         order = torch.argsort((~valid).to(torch.uint8), dim=1, stable=True)  # survivors first, label order kept
-        s_max = int(counts.max())  # host round trip 2
+        s_max = k_max if capacity else int(counts.max())  # host round trip 2
         order = order[:, :s_max]
         keep = torch.arange(s_max, device=dev)[None, :] < counts[:, None]
 
         def take(t, pad):
             g = torch.gather(t, 1, order[..., None].expand(-1, -1, t.shape[-1]))
-            return torch.where(keep[..., None], g, torch.as_tensor(pad, dtype=t.dtype, device=dev))
+            return torch.where(keep[..., None], g, pad)  # (scalar overload: no host->device copy)
 
         from liso_amd.kabsch.shape_utils import INVALID_CLASS_ID, UNKNOWN_CLASS_ID
         probs = torch.ones_like(rot)
@@ -183,11 +198,17 @@ class FlowClusterDetector(torch.nn.Module):
                       difficulty=torch.where(keep[..., None], 1, INVALID_CLASS_ID).to(torch.int32))
         if s_max > 0:
             # adapt the rotation of the box to the direction of the flow (reference :312-331)
+            kboxes = boxes
+            if capacity:
+                # the slots beyond the surviving boxes do not exist in the reference-shaped call: park them 1000 km away, where
+                # their soft mask is exactly 0 in fp32 and the background weight prod_s (1 - w_s) does not see them
+                kboxes = Shape(pos=torch.where(keep[..., None], boxes.pos, 1e6), dims=boxes.dims, rot=boxes.rot, probs=boxes.probs,
+                               valid=keep)
             fg_trafos, _, _, bg_trafo, _ = self.kabsch_decoder.get_kabsch_trafos_from_point_flow(
-                point_cloud_ta=pcl[..., :3], valid_mask_ta=pcl_is_valid, pointwise_flow_ta_tb=point_flow, pred_boxes_ta=boxes,
+                point_cloud_ta=pcl[..., :3], valid_mask_ta=pcl_is_valid, pointwise_flow_ta_tb=point_flow, pred_boxes_ta=kboxes,
                 return_weights=False)
-            box_translation, _ = extract_motion_in_pred_box_coordinates(boxes, fg_trafos, bg_trafo)
-            delta_angle = torch.atan2(box_translation[..., [1]], box_translation[..., [0]])
+            box_translation, _ = extract_motion_in_pred_box_coordinates(boxes, fg_trafos, bg_trafo, check=not capacity)
+            delta_angle = torch.atan2(box_translation[..., 1:2], box_translation[..., 0:1])  # (slices: a list index is a host->device copy)
             box_velo = torch.zeros_like(boxes.probs)
             box_velo[..., 0] = torch.linalg.norm(box_translation, dim=-1)
             boxes.rot = boxes.rot + delta_angle

@@ -19,7 +19,8 @@ def get_bev_dynamic_flow_map_from_pcl_flow_and_odom(*, pcl_is_valid, pcl, pillar
     val = pcl_is_valid.to(torch.uint8).contiguous()
     coors = pillar_coors.to(torch.int32).contiguous()
     # bev_flow_utils.py:30-33: inv(odom) - I in fp64 (a [B,4,4] LU inverse; not worth a kernel)
-    ome = (torch.linalg.inv(odom_ta_tb.double()) - torch.eye(4, device=dev, dtype=torch.float64)[None]).contiguous()
+    # (inv_ex = the same LU inverse without torch.linalg.inv's singularity check, which is a device->host read)
+    ome = (torch.linalg.inv_ex(odom_ta_tb.double()).inverse - torch.eye(4, device=dev, dtype=torch.float64)[None]).contiguous()
     dyn = torch.empty((B, h, w, 1), dtype=torch.float32, device=dev)
     nrf = torch.empty((B, h, w, 3), dtype=torch.float32, device=dev)
     lib = L.lib()

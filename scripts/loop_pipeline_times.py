@@ -30,7 +30,7 @@ def timed(obj, name, label=None):
 timed(tr, "_stage_a"); timed(tr, "_stage_b"); timed(tr, "_targets_from_flow"); timed(tr, "_infer_flow")
 timed(tr.detector, "step", "detector.step"); timed(tr.detector, "_pillars", "detector._pillars")
 timed(tr.detector.optimizer, "step", "optimizer.step")
-timed(tr, "cluster_detector", "cluster_detector")
+timed(tr.cluster_detector, "forward", "cluster_detector")
 import liso_amd.utils.nms_iou as NI
 timed(NI, "perform_nms_on_shapes_padded", "nms")
 N = 50

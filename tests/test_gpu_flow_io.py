@@ -1,0 +1,42 @@
+"""SLIM flow ingest on the device: the same tensor ops as tests/test_flow_io.py, inputs resident in HBM,
+against the numpy masked-array restatement; plus the export dictionary built from device predictions."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_point_lookup_and_neighbour_filling_on_the_device():
+    from liso_amd.slim import flow_io
+    from oracle.flow_io import expand_valid_bev_flow_to_zero_flow_neighbor_pillars as ref_expand, point_flow_from_bev as ref_lookup
+
+    dev = torch.device("cuda")
+    for seed, G, n in ((0, 64, 5000), (1, 512, 120000)):
+        g = np.random.default_rng(seed)
+        f = np.zeros((G, G, 2), np.float32)
+        m = g.random((G, G)) < 0.35
+        f[m] = g.normal(0, 1, (int(m.sum()), 2)).astype(np.float32)
+        f[0, :5] = 1.5
+        got_e = flow_io.expand_valid_bev_flow_to_zero_flow_neighbor_pillars(torch.from_numpy(f).to(dev))
+        assert got_e.is_cuda and np.array_equal(got_e.cpu().numpy(), ref_expand(f))
+        pcl = np.concatenate([g.uniform(-60, 60, (n, 2)), g.uniform(-2, 2, (n, 1)), g.random((n, 1))], -1).astype(np.float32)
+        rng = np.array([100.0, 100.0])
+        got = flow_io.point_flow_from_bev(torch.from_numpy(pcl).to(dev), torch.from_numpy(f).to(dev), rng)
+        want = ref_lookup(pcl, f, rng)
+        assert got.is_cuda and got.shape == (n, 3)
+        assert np.allclose(got.cpu().numpy(), want, rtol=1e-5, atol=1e-6)
+
+
+def test_export_dictionary_from_device_predictions():
+    from liso_amd.slim import flow_io
+    from liso_amd.utils.config import AttrDict
+
+    dev = torch.device("cuda")
+    G = 64
+    mk = lambda s: AttrDict(modified_network_output=AttrDict(static_flow=torch.full((1, G, G, 2), float(s), device=dev),  # noqa: E731
+                                                              dynamicness=torch.full((1, G, G), 0.1 * s, device=dev)))
+    content = flow_io.flow_export_dict([mk(1), mk(2)], [mk(3), mk(4)], torch.tensor(0.37, device=dev), np.array([100.0, 100.0]))
+    assert all(isinstance(v, np.ndarray) for v in content.values())  # the wire format is numpy (experiment.py:389-404)
+    assert float(content["bev_raw_flow_t0_t1"][0, 0, 0]) == 2.0 and float(content["bev_raw_flow_t1_t0"][3, 3, 1]) == 4.0
+    assert abs(float(content["static_threshold"]) - 0.37) < 1e-6

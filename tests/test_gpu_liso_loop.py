@@ -162,8 +162,9 @@ def test_overlapped_loop_equals_sequential_loop(use_graph):
         losses, boxes = [], []
         for i, a in zip(order, announced):
             losses.append(float(tr.step(*pairs[i], upcoming=[pairs[k] for k in a])))
-            b = tr.last_boxes
-            boxes.append(torch.cat([b.pos.float(), b.dims.float(), b.rot.float(), b.valid[..., None].float()], dim=-1).cpu())
+            b = tr.last_boxes  # (the pipeline's stage B pads to a fixed number of slots: compare the valid boxes, in order)
+            allb = torch.cat([b.pos.float(), b.dims.float(), b.rot.float(), b.velo.float()], dim=-1)
+            boxes.append(allb[b.valid].cpu())
         torch.cuda.synchronize()
         out.append((losses, boxes))
     assert out[0][0] == out[1][0], (out[0][0], out[1][0])
@@ -213,3 +214,26 @@ print("EQUAL", out[1][-1])
     env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0 and "EQUAL" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+def test_pipeline_falls_back_when_clusters_exceed_the_box_capacity():
+    """stage B of the pipeline runs FlowClusterDetector with a fixed number of box slots and no device->host read; the cluster
+    count is looked at when the result is taken.  With a capacity of 2 every pair overflows: the pair is then redone with the
+    reference-shaped call and the losses / boxes still equal the one-stream loop."""
+    from liso_amd.datasets.synthetic import slim_pair
+    from liso_amd.trainer import LisoLoopTrainer
+    from liso_amd.utils.config import apply_slim_simple_knn_training, default_cfg
+
+    dev = torch.device("cuda")
+    grid, rng = 256, 50.0
+    pairs = [slim_pair(31 + i, dev, n_points=40000, grid=grid, bev_range_m=rng) for i in range(3)]
+    out = []
+    for overlap in (False, True):
+        cfg = apply_slim_simple_knn_training(default_cfg(grid=grid, bev_range_m=rng))
+        cfg.data.tracking_cfg.flow_cluster_capacity = 2
+        torch.manual_seed(0)
+        tr = LisoLoopTrainer(cfg, dev, compute_dtype=torch.bfloat16, total_steps=20, use_graph=True, overlap=overlap)
+        losses = [float(tr.step(*pairs[i % 3], upcoming=(pairs[(i + 1) % 3], pairs[(i + 2) % 3]))) for i in range(6)]
+        out.append((losses, int(tr.last_boxes.valid.sum()), tr.capacity_overflows))
+    assert out[0][0] == out[1][0] and out[0][1] == out[1][1]
+    assert out[0][2] == 0 and out[1][2] >= 4  # the one-stream loop never uses the capacity path; the pipeline overflowed
