@@ -492,8 +492,9 @@ def main():
                        "frames_per_step_per_gpu": frames_per_step, "parallelism": f"dp{world}",
                        "launch": ("eager" if not graphed else "hipGraph replay of fwd+loss+bwd, eager RMSprop" if args.workload == "slim"
                                   else "hipGraph replays (SLIM inference; detector backbone+head+loss fwd/bwd), eager pillar encoder / "
-                                       "flow clustering / AdamW" + ("; 3-stage pipeline on 3 HIP streams: SLIM inference of pair i+2 | "
-                                                                    "clustering+NMS+targets of pair i+1 | detector step on pair i" if args.workload == "loop" and overlap else "")),
+                                       "flow clustering / AdamW" + ("; 3-stage pipeline on 3 HIP streams: SLIM inference two pairs per replay, 2-3 pairs ahead | "
+                                                                    "clustering+NMS+targets 1-2 pairs ahead (fixed box slots, no host reads) | "
+                                                                    "detector step on pair i" if args.workload == "loop" and overlap else "")),
                        "convolutions": "MIOpen (--miopen-convs)" if args.miopen_convs else "own MFMA implicit-GEMM kernels"},
             "final_loss": float(loss),
             "roofline": {"kernel": kname, "bound": bound, "achieved": achieved, "peak": peak, "unit": runit,

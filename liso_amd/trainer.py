@@ -511,7 +511,7 @@ class LisoLoopTrainer:
     Box-DB augmentation and tracking between the stages are outside this loop."""
 
     def __init__(self, cfg, device, compute_dtype=torch.float32, total_steps=None, slim_state_dict=None, use_graph=False,
-                 overlap=False):
+                 overlap=False, infer_batch=2):
         """`use_graph`: the frozen SLIM inference (one capture per input shape) and the detector's forward+loss+backward are
         replayed from hipGraphs; the flow clustering in between stays eager (its box count sizes the padded Shape).
         `overlap`: step(pair_i, upcoming=(pair_i+1, pair_i+2)) runs the iteration as a three-stage software pipeline on
@@ -523,8 +523,9 @@ class LisoLoopTrainer:
         self.use_graph = bool(use_graph) and device.type == "cuda"
         self._graph_infer = self.use_graph and use_graph in (True, "infer")
         self._graph_det = self.use_graph and use_graph in (True, "detector")
-        self._infer_graph, self._infer_sig = None, None
+        self._infer_graph, self._infer_graphs = None, {}
         self.overlap = bool(overlap) and device.type == "cuda"
+        self.infer_batch = int(infer_batch)
         self.box_capacity, self.capacity_overflows = int(cfg.data.tracking_cfg.setdefault("flow_cluster_capacity", 64)), 0
         self._flow_stream, self._mine_stream, self._main_used_static = None, None, None
         self._flows, self._mined = [], []
@@ -553,7 +554,21 @@ class LisoLoopTrainer:
         _, boxes = self._targets_from_flow(sample_t0, flow)
         return boxes, flow
 
+    @staticmethod
+    def _stack_samples(samples):
+        """batch of sample dicts (each with batch size 1) -> one sample dict: tensors are concatenated along the batch axis, lists
+        (per-sample clouds of different lengths) are chained, anything else is taken from the first sample"""
+        first = samples[0]
+        if torch.is_tensor(first):
+            return torch.cat(list(samples), dim=0) if first.dim() > 0 else first
+        if isinstance(first, dict):
+            return {k: LisoLoopTrainer._stack_samples([s_[k] for s_ in samples]) for k in first}
+        if isinstance(first, (list, tuple)):
+            return type(first)(x for s_ in samples for x in s_)
+        return first
+
     def _infer_flow(self, sample_t0, sample_t1):
+        """frozen SLIM inference of one sample pair (any batch size): eager pillar encoder + one hipGraph replay per input signature"""
         if not self._graph_infer:
             return self.slim.infer_point_flow_t0_t1(sample_t0, sample_t1)
         shapes = []
@@ -564,39 +579,39 @@ class LisoLoopTrainer:
 
         raft = self.slim.raft_network
         pcls = (get_network_input_pcls(self.cfg, sample_t0, "ta", to_device=dev), get_network_input_pcls(self.cfg, sample_t1, "ta", to_device=dev))
-        first = self._infer_graph is None or sig != self._infer_sig
+        st = self._infer_graphs.get(sig)
         with torch.no_grad():  # pillar encoder eagerly (its rocPRIM sort memsets: liso_amd/utils/graph_safety.py) ...
-            if first:
+            if st is None:
                 canv = raft.encode_pillars(*pcls)
             else:  # ... straight into the graph's input buffers: no copy, no concatenation of the two sweeps
-                raft.encode_pillars(*pcls, out=self._static_rows)
+                raft.encode_pillars(*pcls, out=st["rows"])
         with torch.no_grad():  # a device scan (torch.cumsum): eagerly, its memset nodes do not survive in a graph (graph_safety.py)
             thr = self.slim.moving_dynamicness_threshold.value()
-        if self._infer_graph is None or sig != self._infer_sig:
-            self._static_in = SlimTrainer._map_tensors((sample_t0, sample_t1), lambda t: t.to(dev).clone())
+        if st is None:
+            st = self._infer_graphs[sig] = {}
+            st["in"] = SlimTrainer._map_tensors((sample_t0, sample_t1), lambda t: t.to(dev).clone())
             B_ = canv[0].shape[0]
             rows = torch.cat([canv[0], canv[2]], dim=0).permute(0, 2, 3, 1).contiguous()  # [2B, gx, gy, 64]
             occ = torch.cat([canv[1], canv[3]], dim=0).contiguous()
-            self._static_rows = (rows, occ)
-            self._static_canv = (rows[:B_].permute(0, 3, 1, 2), occ[:B_], rows[B_:].permute(0, 3, 1, 2), occ[B_:], rows.permute(0, 3, 1, 2))
-            self._static_thr = thr.clone()
-            s0, s1 = self._static_in
+            st["rows"] = (rows, occ)
+            st["canv"] = (rows[:B_].permute(0, 3, 1, 2), occ[:B_], rows[B_:].permute(0, 3, 1, 2), occ[B_:], rows.permute(0, 3, 1, 2))
+            st["thr"] = thr.clone()
+            s0, s1 = st["in"]
             side = self._flow_stream  # (HIP maps streams onto 4 hardware queues: capture on a pipeline stream, no extra one)
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side), torch.no_grad():
                 for _ in range(2):
-                    self.slim.infer_point_flow_t0_t1(s0, s1, canvases=self._static_canv, dynamicness_threshold=self._static_thr)
+                    self.slim.infer_point_flow_t0_t1(s0, s1, canvases=st["canv"], dynamicness_threshold=st["thr"])
             torch.cuda.current_stream(dev).wait_stream(side)
-            self._infer_graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._infer_graph, stream=side), torch.no_grad():
-                self._static_flow = self.slim.infer_point_flow_t0_t1(s0, s1, canvases=self._static_canv,
-                                                                     dynamicness_threshold=self._static_thr)
-            self._infer_sig = sig
+            st["graph"] = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(st["graph"], stream=side), torch.no_grad():
+                st["flow"] = self.slim.infer_point_flow_t0_t1(s0, s1, canvases=st["canv"], dynamicness_threshold=st["thr"])
+            self._infer_graph = st["graph"]  # (the most recently captured one: scripts / bench introspection)
         else:
-            SlimTrainer._copy_tensors(self._static_in, (sample_t0, sample_t1))
-            self._static_thr.copy_(thr, non_blocking=True)
-        self._infer_graph.replay()
-        return self._static_flow
+            SlimTrainer._copy_tensors(st["in"], (sample_t0, sample_t1))
+            st["thr"].copy_(thr, non_blocking=True)
+        st["graph"].replay()
+        return st["flow"]
 
     def eager_pass(self, sample_t0, sample_t1):
         """the whole iteration with eager launches and no parameter update (per-kernel event timing in bench.py)"""
@@ -645,17 +660,33 @@ class LisoLoopTrainer:
     # A and B depend on the sweeps and the frozen SLIM weights only, never on the detector: every pair gets exactly the
     # boxes, targets and parameter update of the one-stream loop (tests/test_gpu_liso_loop.py), the three stages -- each far
     # too small to fill 256 CUs at batch 1 -- share the GPU instead of taking turns, and the host never waits for stage A.
-    def _stage_a(self, pair):
-        dev = self.device
+    def _stage_a(self, *pairs):
+        """SLIM inference of one or several pairs in ONE batch (same shapes): every convolution of the replay then works on twice
+        the pixels -- at batch 1 they launch 100-200 blocks on 256 CUs"""
         side = self._flow_stream
         if self._main_used_static is not None:  # the static inference buffers were last used on the caller's stream
             side.wait_event(self._main_used_static)
             self._main_used_static = None
         with torch.cuda.stream(side), torch.no_grad():
-            flow = self._infer_flow(*pair).clone()  # (the next replay overwrites the static output)
+            if len(pairs) == 1:
+                flows = [self._infer_flow(*pairs[0]).clone()]  # (the next replay overwrites the static output)
+            else:
+                s0 = self._stack_samples([p_[0] for p_ in pairs])
+                s1 = self._stack_samples([p_[1] for p_ in pairs])
+                flow = self._infer_flow(s0, s1)
+                b = flow.shape[0] // len(pairs)
+                flows = [flow[k * b:(k + 1) * b].clone() for k in range(len(pairs))]
             done = torch.cuda.Event()
             done.record(side)
-        self._flows.append((pair[0], pair[1], flow, done))
+        for p_, fl in zip(pairs, flows):
+            self._flows.append((p_[0], p_[1], fl, done))
+
+    @staticmethod
+    def _same_shapes(pa, pb):
+        sa, sb = [], []
+        SlimTrainer._map_tensors(pa, lambda t: sa.append((tuple(t.shape), t.dtype)) or t)
+        SlimTrainer._map_tensors(pb, lambda t: sb.append((tuple(t.shape), t.dtype)) or t)
+        return sa == sb
 
     def _take(self, store, sample_t0, sample_t1):
         for k, e in enumerate(store):
@@ -722,9 +753,20 @@ class LisoLoopTrainer:
             has = lambda store, p: any(e[0] is p[0] and e[1] is p[1] for e in store)  # noqa: E731
             self._mined = [e for e in self._mined if any(has([e], q) for q in up)]
             self._flows = [e for e in self._flows if any(has([e], q) for q in up)]
-            for p_ in up:  # stage A first: the GPU works on it while the host walks through stage B
-                if not has(self._flows, p_) and not has(self._mined, p_):
-                    self._stage_a(p_)
+            # stage A first (the GPU works on it while the host walks through stage B), two pairs per replay when it can wait:
+            # a pair that is only needed the step after next is deferred until its successor is known too
+            missing = [p_ for k, p_ in enumerate(up) if not has(self._flows, p_) and not has(self._mined, p_)
+                       and not any(p_[0] is q[0] and p_[1] is q[1] for q in up[:k])]
+            batch = self.infer_batch if missing and all(self._same_shapes(missing[0], q) for q in missing[1:]) else 1
+            while missing:
+                if len(missing) >= batch and batch > 1:
+                    self._stage_a(*missing[:batch])
+                    missing = missing[batch:]
+                elif batch > 1 and len(up) >= 3 and missing[0] is up[2] and len(missing) == 1:
+                    break  # only the farthest pair is missing: next step it is batched with its successor
+                else:
+                    self._stage_a(missing[0])
+                    missing = missing[1:]
             for p_ in up[:2]:  # stage B runs two pairs ahead: by the time a result is taken, its stream got there long ago
                 if not has(self._mined, p_):
                     self._stage_b(p_)

@@ -237,3 +237,27 @@ def test_pipeline_falls_back_when_clusters_exceed_the_box_capacity():
         out.append((losses, int(tr.last_boxes.valid.sum()), tr.capacity_overflows))
     assert out[0][0] == out[1][0] and out[0][1] == out[1][1]
     assert out[0][2] == 0 and out[1][2] >= 4  # the one-stream loop never uses the capacity path; the pipeline overflowed
+
+
+def test_batched_inference_of_two_pairs_equals_single_pairs():
+    """stage A of the pipeline runs the frozen SLIM inference on two sweep pairs in one batch (every convolution then covers twice the
+    pixels): per-sample results must be those of the single-pair calls, bit for bit (per-sample InstanceNorm, per-sample decoder)."""
+    from liso_amd.datasets.synthetic import slim_pair
+    from liso_amd.trainer import LisoLoopTrainer
+    from liso_amd.utils.config import apply_slim_simple_knn_training, default_cfg
+
+    dev = torch.device("cuda")
+    grid, rng = 256, 50.0
+    cfg = apply_slim_simple_knn_training(default_cfg(grid=grid, bev_range_m=rng))
+    torch.manual_seed(0)
+    tr = LisoLoopTrainer(cfg, dev, compute_dtype=torch.bfloat16, total_steps=20, use_graph=True, overlap=True)
+    pairs = [slim_pair(51 + i, dev, n_points=40000, grid=grid, bev_range_m=rng) for i in range(2)]
+    with torch.no_grad():
+        single = [tr._infer_flow(*p).clone() for p in pairs]
+        s0, s1 = tr._stack_samples([p[0] for p in pairs]), tr._stack_samples([p[1] for p in pairs])
+        assert s0["pcl_ta"]["pcl"].shape[0] == 2 and len(s0["pcl_full_no_ground_ta"]) == 2
+        both = tr._infer_flow(s0, s1).clone()          # captures the batch-2 graph
+        both2 = tr._infer_flow(s0, s1).clone()         # and replays it
+    assert both.shape[0] == 2 and torch.equal(both, both2)
+    for k in range(2):
+        assert torch.equal(both[k:k + 1], single[k]), float((both[k:k + 1] - single[k]).abs().max())
