@@ -71,6 +71,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--workload", default="loop", choices=["loop", "slim", "detector", "iou3d"])
+    ap.add_argument("--lookahead", type=int, default=3,
+                    help="loop workload: sweep pairs announced ahead of the current one (stage A infers lookahead - 1 pairs per replay)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="loop workload: all stages of an iteration on one stream, one pair at a time (default: SLIM inference "
                          "of pair i+2 and box mining of pair i+1 on their own HIP streams, concurrent with the detector step on i)")
@@ -358,16 +360,16 @@ def main():
         cfg = apply_slim_simple_knn_training(cfg)
         overlap = not (args.eager or args.no_overlap)
         trainer = LisoLoopTrainer(cfg, dev, compute_dtype=dtype, total_steps=args.steps + args.warmup + 8, use_graph=not args.eager,
-                                  overlap=overlap)
+                                  overlap=overlap, infer_batch=max(1, args.lookahead - 1))
         # a ring of different sweep pairs; step i trains on pair i while (overlap) pairs i+1 / i+2 are in the mining stages
-        pairs = [slim_pair(2 + rank + 100 * i, dev, n_points=N_POINTS, grid=GRID, bev_range_m=BEV_RANGE) for i in range(5)]
+        pairs = [slim_pair(2 + rank + 100 * i, dev, n_points=N_POINTS, grid=GRID, bev_range_m=BEV_RANGE) for i in range(max(5, args.lookahead + 2))]
         s0, s1 = pairs[0]
         counter = [0]
 
         def step():
             i = counter[0]
             counter[0] += 1
-            return trainer.step(*pairs[i % len(pairs)], upcoming=tuple(pairs[(i + k) % len(pairs)] for k in (1, 2, 3)))
+            return trainer.step(*pairs[i % len(pairs)], upcoming=tuple(pairs[(i + k) % len(pairs)] for k in range(1, args.lookahead + 1)))
 
         frames_per_step = 2
     else:

@@ -714,8 +714,9 @@ class LisoLoopTrainer:
         self._mined.append((pair[0], pair[1], targets, boxes, done, count, f[2]))
 
     def step(self, sample_t0, sample_t1, upcoming=()):
-        """one iteration on (sample_t0, sample_t1).  With `overlap`, `upcoming` = the pairs of the following calls (up to three):
-        stage A (SLIM inference) runs up to three pairs ahead, stage B (box mining) up to two, each on its own stream.
+        """one iteration on (sample_t0, sample_t1).  With `overlap`, `upcoming` = the pairs of the following calls (up to
+        infer_batch + 1): stage A (SLIM inference) runs ahead on batches of them, stage B (box mining) up to two pairs ahead, each on
+        its own stream.
         Prefetched results are matched by object identity; anything announced but not requested next is dropped."""
         cuda = self.device.type == "cuda"
         cur = torch.cuda.current_stream(self.device) if cuda else None
@@ -749,24 +750,22 @@ class LisoLoopTrainer:
         self.last_boxes = boxes
         loss = self.detector.step(sample_t0["pcl_full_no_ground_ta"], targets)
         if self.overlap and len(upcoming) > 0:
-            up = list(upcoming[:3])
+            up = list(upcoming[:self.infer_batch + 1])
             has = lambda store, p: any(e[0] is p[0] and e[1] is p[1] for e in store)  # noqa: E731
             self._mined = [e for e in self._mined if any(has([e], q) for q in up)]
             self._flows = [e for e in self._flows if any(has([e], q) for q in up)]
-            # stage A first (the GPU works on it while the host walks through stage B), two pairs per replay when it can wait:
-            # a pair that is only needed the step after next is deferred until its successor is known too
+            # stage A first (the GPU works on it while the host walks through stage B).  It runs when a pair that stage B needs now
+            # (one of the next two) has no flow yet, and then takes every announced pair without a flow -- up to `infer_batch` of
+            # the same shape -- in one batch: with k pairs announced it runs every k-1 steps on k-1 pairs.
             missing = [p_ for k, p_ in enumerate(up) if not has(self._flows, p_) and not has(self._mined, p_)
                        and not any(p_[0] is q[0] and p_[1] is q[1] for q in up[:k])]
-            batch = self.infer_batch if missing and all(self._same_shapes(missing[0], q) for q in missing[1:]) else 1
-            while missing:
-                if len(missing) >= batch and batch > 1:
-                    self._stage_a(*missing[:batch])
-                    missing = missing[batch:]
-                elif batch > 1 and len(up) >= 3 and missing[0] is up[2] and len(missing) == 1:
-                    break  # only the farthest pair is missing: next step it is batched with its successor
-                else:
-                    self._stage_a(missing[0])
-                    missing = missing[1:]
+            if missing and any(p_ is q for p_ in missing for q in up[:2]):
+                while missing:
+                    n = 1
+                    while n < min(len(missing), self.infer_batch) and self._same_shapes(missing[0], missing[n]):
+                        n += 1
+                    self._stage_a(*missing[:n])
+                    missing = missing[n:]
             for p_ in up[:2]:  # stage B runs two pairs ahead: by the time a result is taken, its stream got there long ago
                 if not has(self._mined, p_):
                     self._stage_b(p_)
