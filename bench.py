@@ -71,7 +71,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--workload", default="loop", choices=["loop", "slim", "detector", "iou3d"])
-    ap.add_argument("--lookahead", type=int, default=3,
+    ap.add_argument("--lookahead", type=int, default=5,
                     help="loop workload: sweep pairs announced ahead of the current one (stage A infers lookahead - 1 pairs per replay)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="loop workload: all stages of an iteration on one stream, one pair at a time (default: SLIM inference "
@@ -431,7 +431,7 @@ def main():
             if args.workload == "slim":
                 trainer.step(s0, s1, eager=True, update=False)
             elif args.workload == "loop":
-                trainer.eager_pass(s0, s1)
+                trainer.eager_pass(s0, s1, also=tuple(pairs[1:trainer.infer_batch]) if overlap else ())
             else:
                 trainer.eager_pass(pcls, targets)
         torch.cuda.synchronize()

@@ -613,13 +613,21 @@ class LisoLoopTrainer:
         st["graph"].replay()
         return st["flow"]
 
-    def eager_pass(self, sample_t0, sample_t1):
-        """the whole iteration with eager launches and no parameter update (per-kernel event timing in bench.py)"""
+    def eager_pass(self, sample_t0, sample_t1, also=()):
+        """the whole iteration with eager launches and no parameter update (per-kernel event timing in bench.py).  `also`: further
+        pairs that join the SLIM inference batch, as in the pipeline's stage A (the kernels are then timed at the batch they run at)"""
         from liso_amd.datasets.targets import render_center_targets
 
         g, self._graph_infer = self._graph_infer, False
         try:
-            boxes, _ = self.mine_boxes(sample_t0, sample_t1)
+            if also:
+                pairs = [(sample_t0, sample_t1), *also]
+                with torch.no_grad():
+                    flow = self._infer_flow(self._stack_samples([p_[0] for p_ in pairs]), self._stack_samples([p_[1] for p_ in pairs]))
+                    b = flow.shape[0] // len(pairs)
+                    _, boxes = self._targets_from_flow(sample_t0, flow[:b].contiguous())
+            else:
+                boxes, _ = self.mine_boxes(sample_t0, sample_t1)
         finally:
             self._graph_infer = g
         if boxes.shape[1] == 0:
