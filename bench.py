@@ -445,8 +445,9 @@ def main():
     if rank == 0:
         durs = {k: L.TIMER.durations_ms(k) for k in list(L.TIMER.events) if L.TIMER.events[k]}
         totals = {k: sum(v) for k, v in durs.items()}
+        per_unit = {k: L.TIMER.weighted_total_ms(k) for k in durs}  # launches that serve a batch of iterations count 1 / batch
         static_bytes = static_algorithmic_bytes(args.workload, batch, 2 if args.dtype == "bf16" else 4)
-        key = max(totals, key=totals.get)  # the hand-written kernel family with the largest share of the step
+        key = max(per_unit, key=per_unit.get)  # the hand-written kernel family with the largest share of the step
         if args.workload == "detector" and key.startswith("pfn"):
             key = "pfn_forward_scatter"
         kname, bound, unit = KERNELS.get(key, (key, "hbm", "bytes"))
@@ -494,19 +495,20 @@ def main():
                        "frames_per_step_per_gpu": frames_per_step, "parallelism": f"dp{world}",
                        "launch": ("eager" if not graphed else "hipGraph replay of fwd+loss+bwd, eager RMSprop" if args.workload == "slim"
                                   else "hipGraph replays (SLIM inference; detector backbone+head+loss fwd/bwd), eager pillar encoder / "
-                                       "flow clustering / AdamW" + ("; 3-stage pipeline on 3 HIP streams: SLIM inference two pairs per replay, 2-3 pairs ahead | "
+                                       "flow clustering / AdamW" + (f"; 3-stage pipeline on 3 HIP streams: SLIM inference {max(1, args.lookahead - 1)} pairs per replay | "
                                                                     "clustering+NMS+targets 1-2 pairs ahead (fixed box slots, no host reads) | "
                                                                     "detector step on pair i" if args.workload == "loop" and overlap else "")),
                        "convolutions": "MIOpen (--miopen-convs)" if args.miopen_convs else "own MFMA implicit-GEMM kernels"},
             "final_loss": float(loss),
             "roofline": {"kernel": kname, "bound": bound, "achieved": achieved, "peak": peak, "unit": runit,
                          "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
-                         "avg_launch_ms": 1e3 * t_total / n_launch, "launches_per_step": n_launch / max(event_steps, 1),
+                         "avg_launch_ms": 1e3 * t_total / n_launch,
+                         "launches_per_step": sum(L.TIMER.weights.get(key, [1.0] * n_launch)) / max(event_steps, 1),
                          ("algorithmic_flop_per_launch" if bound == "mfma" else "algorithmic_bytes_per_launch"): alg_total / n_launch,
-                         "share_of_step": 1e3 * t_total / max(event_steps, 1) / (1e3 * elapsed / args.steps),
+                         "share_of_step": per_unit[key] / max(event_steps, 1) / (1e3 * elapsed / args.steps),
                          "timed_in": timed_in,
                          "timed_kernels_ms_per_step": {k: round(v / max(event_steps, 1), 4) for k, v in
-                                                       sorted(totals.items(), key=lambda kv: -kv[1])}},
+                                                       sorted(per_unit.items(), key=lambda kv: -kv[1])}},
         }
         if bound == "mfma" and "f32x3" in key:
             line["roofline"]["peak_note"] = ("fp32 tensors computed as 3 bf16 MFMAs per product (hi*hi + hi*lo + lo*hi): peak = dense "

@@ -239,6 +239,8 @@ class KernelTimer:
         self.enabled = set()
         self.events = {}
         self.units = {}
+        self.weights = {}
+        self.weight = 1.0
 
     def enable(self, name):
         self.enabled.add(name)
@@ -260,6 +262,7 @@ class KernelTimer:
         r = fn()
         b.record()
         self.events.setdefault(name, []).append((a, b))
+        self.weights.setdefault(name, []).append(float(self.weight))
         if units is not None:
             self.units.setdefault(name, []).append(units)
         return r
@@ -272,10 +275,16 @@ class KernelTimer:
         torch.cuda.synchronize()
         return [a.elapsed_time(b) for a, b in self.events.get(name, [])]
 
+    def weighted_total_ms(self, name):
+        """sum of the launch durations x the weight that was set when each was recorded (`weight` = share of the launch that belongs
+        to one unit of work: 1 / batch for launches that serve a batch of units)"""
+        return sum(d * w for d, w in zip(self.durations_ms(name), self.weights.get(name, [])))
+
     def reset(self):
         for k in self.events:
             self.events[k] = []
         self.units = {}
+        self.weights = {}
 
 
 TIMER = KernelTimer()

@@ -621,9 +621,15 @@ class LisoLoopTrainer:
         g, self._graph_infer = self._graph_infer, False
         try:
             if also:
+                from liso_amd import _lib as L
+
                 pairs = [(sample_t0, sample_t1), *also]
                 with torch.no_grad():
-                    flow = self._infer_flow(self._stack_samples([p_[0] for p_ in pairs]), self._stack_samples([p_[1] for p_ in pairs]))
+                    L.TIMER.weight = 1.0 / len(pairs)  # (these launches serve len(pairs) iterations)
+                    try:
+                        flow = self._infer_flow(self._stack_samples([p_[0] for p_ in pairs]), self._stack_samples([p_[1] for p_ in pairs]))
+                    finally:
+                        L.TIMER.weight = 1.0
                     b = flow.shape[0] // len(pairs)
                     _, boxes = self._targets_from_flow(sample_t0, flow[:b].contiguous())
             else:
