@@ -137,18 +137,34 @@ __global__ __launch_bounds__(kFitThreads) void fit_z_kernel(const float* __restr
     }
 }
 
-__global__ void fit_z_final_kernel(const FitPartial* __restrict__ partials, int nblk, int k,
-                                   const float* __restrict__ points, int ps, int n, float box_height,
-                                   long long* __restrict__ num_pts, float* __restrict__ fz, float* __restrict__ fh) {
-    const int box = blockIdx.x * blockDim.x + threadIdx.x;
+// one wavefront per box: the lanes stride over the block partials (up to 1024 of them: a single thread walking them took 78 us),
+// then a butterfly combines count (sum), zmax (max) and the lowest point (zmin, then smallest index) -- all order independent
+__global__ __launch_bounds__(64) void fit_z_final_kernel(const FitPartial* __restrict__ partials, int nblk, int k,
+                                                         const float* __restrict__ points, int ps, int n, float box_height,
+                                                         long long* __restrict__ num_pts, float* __restrict__ fz,
+                                                         float* __restrict__ fh) {
+    const int box = blockIdx.x, lane = threadIdx.x;
     if (box >= k) return;
     FitPartial r = {0, box_height, -box_height, 0.f, 0x7fffffff};
-    for (int b = 0; b < nblk; b++) {
+    for (int b = lane; b < nblk; b += 64) {
         const FitPartial o = partials[(size_t)b * k + box];
         r.count += o.count;
         r.zmax = fmaxf(r.zmax, o.zmax);
         if (o.zmin < r.zmin || (o.zmin == r.zmin && o.zmin_idx < r.zmin_idx)) { r.zmin = o.zmin; r.zmin_sensor = o.zmin_sensor; r.zmin_idx = o.zmin_idx; }
     }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        FitPartial o;
+        o.count = __shfl_xor(r.count, off);
+        o.zmin = __shfl_xor(r.zmin, off);
+        o.zmax = __shfl_xor(r.zmax, off);
+        o.zmin_sensor = __shfl_xor(r.zmin_sensor, off);
+        o.zmin_idx = __shfl_xor(r.zmin_idx, off);
+        r.count += o.count;
+        r.zmax = fmaxf(r.zmax, o.zmax);
+        if (o.zmin < r.zmin || (o.zmin == r.zmin && o.zmin_idx < r.zmin_idx)) { r.zmin = o.zmin; r.zmin_sensor = o.zmin_sensor; r.zmin_idx = o.zmin_idx; }
+    }
+    if (lane != 0) return;
     // :367-372 height = clip(zmax - zmin, 1, 2); z = sensor z of the lowest in-box point + h/2.  An empty box has
     // zmin == +box_height for every point, argmin == 0: the reference then takes point 0's z.
     const float height = fminf(fmaxf(r.zmax - r.zmin, 1.0f), 2.0f);
@@ -219,7 +235,7 @@ int liso_fit_box_z_f32(const float* points, int point_stride, int n, const float
     fit_z_kernel<<<dim3(nblk, (k + 63) / 64), kFitThreads, 0, st>>>(points, point_stride, n, box_pos, pos_dims, box_dims,
                                                                     dims_dims, box_rot, k, box_height,
                                                                     (FitPartial*)workspace, tpb);
-    fit_z_final_kernel<<<(k + 63) / 64, 64, 0, st>>>((const FitPartial*)workspace, nblk, k, points, point_stride, n,
+    fit_z_final_kernel<<<k, 64, 0, st>>>((const FitPartial*)workspace, nblk, k, points, point_stride, n,
                                                      box_height, (long long*)num_pts, fitted_z, fitted_height);
     return check_launch();
 }

@@ -128,6 +128,14 @@ __device__ __forceinline__ int find_root(const int* parent, int x) {
     return x;
 }
 
+// find + one-step compression: the start node is re-parented to the root that was found (an ancestor with a smaller index:
+// parents still only ever decrease, so concurrent hooks stay valid); the next walk from this node is one hop
+__device__ __forceinline__ int find_root_compress(int* parent, int x0) {
+    const int r = find_root(parent, x0);
+    if (r != x0) atomicMin(&parent[x0], r);
+    return r;
+}
+
 __global__ __launch_bounds__(256) void dbscan_union_kernel(Cfg c, const uint8_t* __restrict__ dyn, const uint8_t* __restrict__ core,
                                                            const float* __restrict__ xs, const float* __restrict__ ys,
                                                            const float* __restrict__ flow, int* __restrict__ parent) {
@@ -146,8 +154,8 @@ __global__ __launch_bounds__(256) void dbscan_union_kernel(Cfg c, const uint8_t*
                 if (other >= me) return;
                 int x = me, y = other;
                 while (true) {
-                    x = find_root(par, x);
-                    y = find_root(par, y);
+                    x = find_root_compress(par, x);
+                    y = find_root_compress(par, y);
                     if (x == y) break;
                     if (x < y) { const int t = x; x = y; y = t; }
                     const int old = atomicMin(&par[x], y);
@@ -170,8 +178,8 @@ __global__ __launch_bounds__(256) void dbscan_union_kernel(Cfg c, const uint8_t*
             if (other >= me) return;  // every undirected edge once
             int x = me, y = other;
             while (true) {
-                x = find_root(par, x);
-                y = find_root(par, y);
+                x = find_root_compress(par, x);
+                y = find_root_compress(par, y);
                 if (x == y) break;
                 if (x < y) { const int t = x; x = y; y = t; }  // x: larger root, linked under y
                 const int old = atomicMin(&par[x], y);
