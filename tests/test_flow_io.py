@@ -52,3 +52,31 @@ def test_export_keys_and_round_trip(tmp_path):
     flow_io.add_flow_to_sample(sample, back, "slim_bev_120m")
     assert sample["slim_bev_120m"]["flow_ta_tb"].shape == (100, 3) and np.allclose(sample["slim_bev_120m"]["flow_ta_tb"][:, :2], 2.0)
     assert np.allclose(sample["slim_bev_120m"]["flow_tb_ta"][:, :2], 4.0)
+
+
+def _fixture():
+    import os
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "flow_io_reference.npz"))
+
+
+def test_oracle_and_host_ops_match_the_reference_fixture():
+    """tests/golden/flow_io_reference.npz was written by the reference's own LidarDataset methods
+    (tests/golden/make_flow_io_golden.py): the numpy restatement (oracle/flow_io.py) and the tensor ops reproduce it."""
+    from oracle.flow_io import expand_valid_bev_flow_to_zero_flow_neighbor_pillars as ref_expand, point_flow_from_bev as ref_lookup
+
+    fx = _fixture()
+    for tag in "abc":
+        f, want = fx[f"expand_{tag}_in"], fx[f"expand_{tag}_out"]
+        assert np.array_equal(ref_expand(f.copy()), want)
+        assert np.array_equal(flow_io.expand_valid_bev_flow_to_zero_flow_neighbor_pillars(f.copy()), want)
+    rng = fx["ingest_bev_range_m"]
+    for a, b in (("t0", "t1"), ("t1", "t0")):
+        pcl, bev, want = fx[f"ingest_pcl_{a}"], fx[f"ingest_bev_{a}_{b}"], fx[f"ingest_flow_{a}_{b}"]
+        assert np.allclose(ref_lookup(pcl, bev, rng), want, rtol=1e-6, atol=1e-7)
+        assert np.allclose(flow_io.point_flow_from_bev(pcl, bev, rng), want, rtol=1e-6, atol=1e-7)
+    # the whole ingest through add_flow_to_sample, keys as the reference's datasets call it (src "t0", target "t1")
+    sample = {"pcl_t0": fx["ingest_pcl_t0"], "pcl_t1": fx["ingest_pcl_t1"]}
+    pred = {"bev_raw_flow_t0_t1": fx["ingest_bev_t0_t1"], "bev_raw_flow_t1_t0": fx["ingest_bev_t1_t0"], "bev_range_m": rng}
+    flow_io.add_flow_to_sample(sample, pred, "slim_bev_120m", src_key="t0", target_key="t1")
+    assert np.allclose(sample["slim_bev_120m"]["flow_t0_t1"], fx["ingest_flow_t0_t1"], rtol=1e-6, atol=1e-7)
+    assert np.allclose(sample["slim_bev_120m"]["flow_t1_t0"], fx["ingest_flow_t1_t0"], rtol=1e-6, atol=1e-7)

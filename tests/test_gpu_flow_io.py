@@ -40,3 +40,20 @@ def test_export_dictionary_from_device_predictions():
     assert all(isinstance(v, np.ndarray) for v in content.values())  # the wire format is numpy (experiment.py:389-404)
     assert float(content["bev_raw_flow_t0_t1"][0, 0, 0]) == 2.0 and float(content["bev_raw_flow_t1_t0"][3, 3, 1]) == 4.0
     assert abs(float(content["static_threshold"]) - 0.37) < 1e-6
+
+
+def test_device_ingest_matches_the_reference_fixture():
+    """the fixture written by the reference's LidarDataset methods (tests/golden/make_flow_io_golden.py), inputs resident in HBM"""
+    import os
+
+    from liso_amd.slim import flow_io
+
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "flow_io_reference.npz"))
+    dev = torch.device("cuda")
+    for tag in "abc":
+        got = flow_io.expand_valid_bev_flow_to_zero_flow_neighbor_pillars(torch.from_numpy(fx[f"expand_{tag}_in"]).to(dev))
+        assert np.array_equal(got.cpu().numpy(), fx[f"expand_{tag}_out"])
+    for a, b in (("t0", "t1"), ("t1", "t0")):
+        got = flow_io.point_flow_from_bev(torch.from_numpy(fx[f"ingest_pcl_{a}"]).to(dev), torch.from_numpy(fx[f"ingest_bev_{a}_{b}"]).to(dev),
+                                          fx["ingest_bev_range_m"])
+        assert np.allclose(got.cpu().numpy(), fx[f"ingest_flow_{a}_{b}"], rtol=1e-5, atol=1e-6)
