@@ -56,8 +56,10 @@ def fit_box_z(pcl, pos, dims, rot, box_height=1000.0):
 # image -- DBSCAN is deterministic given the point order, the labelling rule has not changed) is CALLED here exactly as
 # the reference calls it; scikit-image (pinned 0.19.2) is absent from the image, so regionprops' four properties are
 # restated from its published formulas (skimage/measure/_regionprops.py, _moments.py: inertia_tensor,
-# inertia_tensor_eigvals, orientation, axis_major_length / axis_minor_length).  PARITY UNPINNED for the regionprops
-# restatement: the reference holds no test for this block; the checks are analytic shapes (tests/test_oracle_flow_cluster.py).
+# inertia_tensor_eigvals, orientation, axis_major_length / axis_minor_length).  Pinned (round 2) by
+# tests/golden/regionprops_reference.npz, which scikit-image 0.18.3 itself produced (tests/golden/make_regionprops_golden.py, run
+# with the build container's /opt/conda/bin/python3.9): tests/test_regionprops_reference.py; analytic shapes in
+# tests/test_oracle_flow_cluster.py.
 def dbscan_bev_labels(valid_mask, bev_nonrigid_flow, grid_pts_xy, eps=1.0, min_samples=5, flow_similarity_importance=2.0):
     """one sample: valid_mask [G,G] bool numpy, bev_nonrigid_flow [G,G,3] float32 numpy, grid_pts_xy [G,G,2] float32
     -> label image int64 [G,G] (0 = background / noise), exactly lines :151-172 of the reference"""

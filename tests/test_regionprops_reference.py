@@ -1,0 +1,62 @@
+"""scikit-image's regionprops (flow_cluster_detector.py:175-189 of the reference) pinned by a fixture computed with scikit-image
+itself (tests/golden/make_regionprops_golden.py, run with the build container's /opt/conda/bin/python3.9: scikit-image 0.18.3):
+the restatement in oracle/flow_cluster.py on the CPU, the device kernel (liso_region_props) on the GPU."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+FX = np.load(os.path.join(os.path.dirname(__file__), "golden", "regionprops_reference.npz"))
+NAMES = ["special", "blobs_small", "blobs_512", "blobs_dense"]
+
+
+def _equal_second_moments(labels):
+    """per label: are the row and column variances EXACTLY equal (integer arithmetic)?  scikit-image then either hits its
+    `a - c == 0` special case (orientation = -pi/4 for b < 0) or, when its float sums leave a - c = 1e-17, the general formula, whose
+    limit is +pi/4 for b < 0: its own two branches disagree by pi/2 there, and which one it takes depends on rounding in its dot
+    products.  The restatement and the device kernel (exact integer moments) always take the special case."""
+    out = []
+    for lab in range(1, int(labels.max()) + 1):
+        rr, cc = np.nonzero(labels == lab)
+        rr, cc, n = rr.astype(object), cc.astype(object), len(rr)
+        out.append(n * int((rr * rr).sum()) - int(rr.sum()) ** 2 == n * int((cc * cc).sum()) - int(cc.sum()) ** 2)
+    return np.array(out, dtype=bool)
+
+
+def _close(got, want, labels):
+    assert got.shape == want.shape
+    np.testing.assert_allclose(got[:, [0, 1]], want[:, [0, 1]], rtol=1e-12, atol=1e-9)   # centroid
+    np.testing.assert_allclose(got[:, [3, 4]], want[:, [3, 4]], rtol=1e-9, atol=1e-9)     # axis lengths
+    tie = _equal_second_moments(labels)
+    # an angle of a (nearly) isotropic region is ill-conditioned: compare where the axis lengths differ, modulo pi
+    aniso = ((want[:, 3] - want[:, 4]) > 1e-6 * np.maximum(want[:, 3], 1.0)) & ~tie
+    d = np.abs(got[aniso, 2] - want[aniso, 2])
+    d = np.minimum(d, np.abs(d - np.pi))
+    assert d.size == 0 or d.max() <= 1e-8, d.max()
+    # exact ties: +-pi/4, equal to scikit-image or to its other branch (see _equal_second_moments)
+    assert np.allclose(np.abs(got[tie, 2]), np.pi / 4) and np.allclose(np.abs(want[tie, 2]), np.pi / 4)
+    return int((np.abs(got[tie, 2] - want[tie, 2]) > 1e-9).sum()), int(tie.sum())
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_oracle_restatement_equals_scikit_image(name):
+    from oracle.flow_cluster import regionprops_restated
+
+    flips, ties = _close(regionprops_restated(FX[name + "_labels"]), FX[name + "_props"], FX[name + "_labels"])
+    if name == "special":  # the exact diagonals / square / lines: scikit-image takes its special case too
+        assert flips == 0 and ties >= 3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+def test_device_region_props_equal_scikit_image(name):
+    from liso_amd.networks.flow_cluster_detector.flow_cluster_detector import label_region_props
+
+    lab = torch.from_numpy(FX[name + "_labels"])[None].cuda()
+    K = int(lab.max())
+    got = label_region_props(lab, K)[0].cpu().numpy()
+    _close(got, FX[name + "_props"], FX[name + "_labels"])
+    # more slots than labels (the pipeline's fixed capacity): the extra rows are zeros, the others unchanged
+    got2 = label_region_props(lab, K + 7)[0].cpu().numpy()
+    assert np.array_equal(got2[:K], got) and not got2[K:].any()
