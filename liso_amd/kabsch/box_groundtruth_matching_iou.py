@@ -34,6 +34,35 @@ def greedy_match_iou_matrix(iou_matrix, pred_order, matching_threshold: float):
     return idx_gt, idx_pred, miou, num, pmask[:n_pred].view(torch.bool), gmask[:n_gt].view(torch.bool)
 
 
+def hungarian_match_iou_matrix(iou_matrix, matching_threshold: float):
+    """reference :70-118, the "hungarian" branch: optimal assignment on the host (scipy.optimize.linear_sum_assignment, as the
+    reference does it), the IoU matrix padded with -1 rows / columns to a square, non-finite entries -> -1, matches kept where
+    IoU >= threshold.  iou_matrix: numpy [n_gt, n_pred] -> the reference's five arrays."""
+    from scipy.optimize import linear_sum_assignment
+
+    iou = np.array(iou_matrix, dtype=np.float64 if np.asarray(iou_matrix).dtype == np.float64 else np.asarray(iou_matrix).dtype, copy=True)
+    n_true, n_pred = iou.shape
+    MIN_IOU = -1.0
+    if n_pred > n_true:
+        iou = np.concatenate((iou, np.full((n_pred - n_true, n_pred), MIN_IOU)), axis=0)
+    if n_true > n_pred:
+        iou = np.concatenate((iou, np.full((n_true, n_true - n_pred), MIN_IOU)), axis=1)
+    bad = ~np.isfinite(iou)
+    if np.any(bad):
+        iou[bad] = MIN_IOU
+    idxs_true, matched_pred_idxs = linear_sum_assignment(iou, maximize=True)
+    sel = matched_pred_idxs < n_pred
+    idx_pred_actual, idx_gt_actual = matched_pred_idxs[sel], idxs_true[sel]
+    ious_actual = iou[idx_gt_actual, idx_pred_actual]
+    keep = ious_actual >= matching_threshold
+    idxs_into_gt, idxs_into_preds, matching_dists = idx_gt_actual[keep], idx_pred_actual[keep], ious_actual[keep]
+    det_gts_mask = np.zeros(n_true, dtype=bool)
+    det_gts_mask[idxs_into_gt] = True
+    matched_preds_mask = np.zeros(n_pred, dtype=bool)
+    matched_preds_mask[idxs_into_preds] = True
+    return idxs_into_gt, idxs_into_preds, matching_dists, matched_preds_mask, det_gts_mask
+
+
 @torch.no_grad()
 def match_boxes_by_descending_confidence_iou(non_batched_gt_boxes: Shape, non_batched_pred_boxes: Shape, matching_threshold: float,
                                              iou_mode: str = "iou_bev", matching_mode: str = "greedy"):
@@ -43,10 +72,13 @@ def match_boxes_by_descending_confidence_iou(non_batched_gt_boxes: Shape, non_ba
     assert len(non_batched_gt_boxes.shape) == 1 and len(non_batched_pred_boxes.shape) == 1
     assert torch.all(non_batched_pred_boxes.valid), "need all valid predictions"
     assert torch.all(non_batched_gt_boxes.valid), "need all valid predictions"
-    if matching_mode != "greedy":
-        # the reference's "hungarian" branch is scipy.optimize.linear_sum_assignment on the host (:70-118)
+    if matching_mode not in ("greedy", "hungarian"):
         raise NotImplementedError(matching_mode)
     n_pred, n_true = non_batched_pred_boxes.shape[0], non_batched_gt_boxes.shape[0]
+    if matching_mode == "hungarian":  # IoU matrix from the HIP kernels, the assignment on the host like the reference
+        iou = (np.zeros((n_true, n_pred)) if n_pred == 0 or n_true == 0
+               else box_iou_matrix(non_batched_gt_boxes, non_batched_pred_boxes, iou_mode).cpu().numpy())
+        return hungarian_match_iou_matrix(iou, matching_threshold)
     if n_pred == 0 or n_true == 0:  # reference :24-26: an empty IoU matrix, no pair to visit
         return (np.array([], dtype=np.int64), np.array([], dtype=np.int64), np.array([]), np.zeros(n_pred, dtype=bool),
                 np.zeros(n_true, dtype=bool))

@@ -224,4 +224,4 @@ def test_match_boxes_end_to_end_against_oracle_iou():
         assert np.array_equal(got[3], want[3]) and np.array_equal(got[4], want[4])
         assert all(isinstance(x, np.ndarray) for x in got)
     with pytest.raises(NotImplementedError):
-        match_boxes_by_descending_confidence_iou(gt, pred, 0.3, matching_mode="hungarian")
+        match_boxes_by_descending_confidence_iou(gt, pred, 0.3, matching_mode="auction")  # ("hungarian": tests/test_matching_hungarian.py)
