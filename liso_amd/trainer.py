@@ -502,6 +502,19 @@ class SlimTrainer:
         return self._static_loss.clone()  # the captured output is overwritten by the next replay
 
 
+class _Prefetched:
+    """what the pipeline of LisoLoopTrainer holds for one announced sample pair: the point flow of stage A and, after stage B, the
+    target maps / boxes and the cluster count (pinned host tensor) -- each guarded by the event recorded behind its work"""
+    __slots__ = ("pair", "flow", "done", "targets", "boxes", "cluster_count")
+
+    def __init__(self, pair, flow, done, targets=None, boxes=None, cluster_count=None):
+        self.pair, self.flow, self.done = pair, flow, done
+        self.targets, self.boxes, self.cluster_count = targets, boxes, cluster_count
+
+    def is_for(self, pair):
+        return self.pair[0] is pair[0] and self.pair[1] is pair[1]
+
+
 class LisoLoopTrainer:
     """One fused LISO iteration per sample pair: SLIM forward (no_grad) -> per-point flow ->
     FlowClusterDetector (BEV dynamicness, DBSCAN, region moments, z-fit, filters, Kabsch heading/velocity) -> rotated NMS
@@ -675,8 +688,8 @@ class LisoLoopTrainer:
     # boxes, targets and parameter update of the one-stream loop (tests/test_gpu_liso_loop.py), the three stages -- each far
     # too small to fill 256 CUs at batch 1 -- share the GPU instead of taking turns, and the host never waits for stage A.
     def _stage_a(self, *pairs):
-        """SLIM inference of one or several pairs in ONE batch (same shapes): every convolution of the replay then works on twice
-        the pixels -- at batch 1 they launch 100-200 blocks on 256 CUs"""
+        """SLIM inference of one or several pairs in ONE batch (same shapes): every convolution of the replay then works on that many
+        times the pixels -- at batch 1 they launch 100-200 blocks on 256 CUs"""
         side = self._flow_stream
         if self._main_used_static is not None:  # the static inference buffers were last used on the caller's stream
             side.wait_event(self._main_used_static)
@@ -693,7 +706,7 @@ class LisoLoopTrainer:
             done = torch.cuda.Event()
             done.record(side)
         for p_, fl in zip(pairs, flows):
-            self._flows.append((p_[0], p_[1], fl, done))
+            self._flows.append(_Prefetched(pair=p_, flow=fl, done=done))
 
     @staticmethod
     def _same_shapes(pa, pb):
@@ -702,30 +715,47 @@ class LisoLoopTrainer:
         SlimTrainer._map_tensors(pb, lambda t: sb.append((tuple(t.shape), t.dtype)) or t)
         return sa == sb
 
-    def _take(self, store, sample_t0, sample_t1):
+    @staticmethod
+    def _take(store, pair):
+        """pop the entry prefetched for exactly these sample objects"""
         for k, e in enumerate(store):
-            if e[0] is sample_t0 and e[1] is sample_t1:
+            if e.is_for(pair):
                 return store.pop(k)
         return None
 
     def _stage_b(self, pair):
-        f = self._take(self._flows, *pair)
+        f = self._take(self._flows, pair)
         if f is None:
             self._stage_a(pair)
-            f = self._take(self._flows, *pair)
+            f = self._take(self._flows, pair)
         side = self._mine_stream
-        side.wait_event(f[3])
+        side.wait_event(f.done)
         with torch.cuda.stream(side):
-            f[2].record_stream(side)
+            f.flow.record_stream(side)
             # fixed number of box slots: the host only enqueues (no box-count reads).  The cluster count goes to pinned memory
             # behind the work; step() looks at it when it takes the result (long after this stream got there) and redoes the
             # pair with the reference-shaped call in the -- so far never seen -- case of more clusters than slots.
-            targets, boxes = self._targets_from_flow(pair[0], f[2], capacity=self.box_capacity)
+            targets, boxes = self._targets_from_flow(pair[0], f.flow, capacity=self.box_capacity)
             count = torch.empty(1, dtype=torch.int64, pin_memory=True)
             count.copy_(self.cluster_detector.last_num_labels.max().reshape(1), non_blocking=True)
             done = torch.cuda.Event()
             done.record(side)
-        self._mined.append((pair[0], pair[1], targets, boxes, done, count, f[2]))
+        self._mined.append(_Prefetched(pair=pair, flow=f.flow, done=done, targets=targets, boxes=boxes, cluster_count=count))
+
+    def _take_mined(self, pair, cur):
+        """targets + boxes of `pair` from stage B (made visible to stream `cur`), or None if the pair was not prefetched"""
+        m = self._take(self._mined, pair)
+        if m is None:
+            return None
+        m.done.synchronize()  # (stage B of this pair was enqueued one or two steps ago)
+        cur.wait_event(m.done)
+        if int(m.cluster_count[0]) > self.box_capacity:  # more clusters than slots: the exact, reference-shaped call
+            m.flow.record_stream(cur)
+            self.capacity_overflows += 1
+            return self._targets_from_flow(pair[0], m.flow)
+        for t in list(m.targets.values()) + [v for v in m.boxes.__dict__.values() if torch.is_tensor(v)]:
+            t.record_stream(cur)  # (allocated on the mining stream, consumed here)
+        return m.targets, m.boxes
 
     def step(self, sample_t0, sample_t1, upcoming=()):
         """one iteration on (sample_t0, sample_t1).  With `overlap`, `upcoming` = the pairs of the following calls (up to
@@ -734,26 +764,16 @@ class LisoLoopTrainer:
         Prefetched results are matched by object identity; anything announced but not requested next is dropped."""
         cuda = self.device.type == "cuda"
         cur = torch.cuda.current_stream(self.device) if cuda else None
-        m = self._take(self._mined, sample_t0, sample_t1)
-        if m is not None and len(m) > 5:
-            m[4].synchronize()  # (stage B of this pair was enqueued a whole step ago)
-            if int(m[5][0]) > self.box_capacity:  # more clusters than slots: the exact, reference-shaped call
-                cur.wait_event(m[4])
-                m[6].record_stream(cur)
-                self.capacity_overflows += 1
-                m = (m[0], m[1], *self._targets_from_flow(sample_t0, m[6]), None)
-        if m is not None:
-            targets, boxes = m[2], m[3]
-            if m[4] is not None:
-                cur.wait_event(m[4])
-                for t in list(targets.values()) + [v for v in boxes.__dict__.values() if torch.is_tensor(v)]:
-                    t.record_stream(cur)  # (allocated on the mining stream, consumed here)
+        pair = (sample_t0, sample_t1)
+        got = self._take_mined(pair, cur) if cuda else None
+        if got is not None:
+            targets, boxes = got
         else:
-            f = self._take(self._flows, sample_t0, sample_t1)
+            f = self._take(self._flows, pair)
             if f is not None:
-                cur.wait_event(f[3])
-                f[2].record_stream(cur)
-                flow = f[2]
+                cur.wait_event(f.done)
+                f.flow.record_stream(cur)
+                flow = f.flow
             else:
                 with torch.no_grad():
                     flow = self._infer_flow(sample_t0, sample_t1)
@@ -765,9 +785,9 @@ class LisoLoopTrainer:
         loss = self.detector.step(sample_t0["pcl_full_no_ground_ta"], targets)
         if self.overlap and len(upcoming) > 0:
             up = list(upcoming[:self.infer_batch + 1])
-            has = lambda store, p: any(e[0] is p[0] and e[1] is p[1] for e in store)  # noqa: E731
-            self._mined = [e for e in self._mined if any(has([e], q) for q in up)]
-            self._flows = [e for e in self._flows if any(has([e], q) for q in up)]
+            has = lambda store, p: any(e.is_for(p) for e in store)  # noqa: E731
+            self._mined = [e for e in self._mined if any(e.is_for(q) for q in up)]
+            self._flows = [e for e in self._flows if any(e.is_for(q) for q in up)]
             # stage A first (the GPU works on it while the host walks through stage B).  It runs when a pair that stage B needs now
             # (one of the next two) has no flow yet, and then takes every announced pair without a flow -- up to `infer_batch` of
             # the same shape -- in one batch: with k pairs announced it runs every k-1 steps on k-1 pairs.
