@@ -40,7 +40,11 @@ class _State:
 
         key = (li, bool(for_dgrad), dtype)
         if key not in self.packs:
-            self.packs[key] = MC.pack_weights(self.weights(li)[0], MC.ConvSpec.of(self.layers[li]), for_dgrad, MC._mode(dtype))
+            op = self.ops[li]
+            # (a single layer: hand over the Parameter itself, so that a trainer's batched per-step pack -- mfma_conv.set_step_packs --
+            # can serve it; merged pairs are temporaries and pack on their own)
+            w = op[0].weight if len(op) == 1 else self.weights(li)[0]
+            self.packs[key] = MC.pack_weights(w, MC.ConvSpec.of(self.layers[li]), for_dgrad, MC._mode(dtype))
         return self.packs[key]
 
     def weights(self, li):

@@ -434,17 +434,28 @@ class SlimTrainer:
             self._static_plan = self.net.build_gather_plan(s0, s1, *meta)
             self._static_plan.lin64  # (its lazily built int64 copy is a graph input too)
 
+        from liso_amd.utils import mfma_conv as MC
+
+        self._pack_jobs = None
+
         def body():
             self._flat_grad.zero_()
             for i in (0, 2):
                 self._static_canv[i].grad.zero_()
-            total, _, _ = self.loss(s0, s1, all_valid, canvases=self._static_canv, gather_plan=self._static_plan)
-            total.backward()
+            if self._pack_jobs:  # every layer's forward / data-gradient panels from ONE launch (recorded in the warm-up)
+                MC.set_step_packs(MC.batched_pack(self._pack_jobs))
+            try:
+                total, _, _ = self.loss(s0, s1, all_valid, canvases=self._static_canv, gather_plan=self._static_plan)
+                total.backward()
+            finally:
+                MC.set_step_packs(None)
             return total.detach()
 
         with torch.cuda.stream(side):  # warm-up off the capture: MIOpen / rocBLAS pick their kernels, caches fill
-            for _ in range(2):
-                body()
+            MC.record_pack_jobs(True)
+            body()
+            self._pack_jobs = MC.record_pack_jobs(False)
+            body()
         torch.cuda.current_stream(dev).wait_stream(side)
         with torch.no_grad():  # the warm-up passes must not count as training steps (BN / threshold statistics)
             for k, v in self.net.state_dict().items():
