@@ -61,21 +61,31 @@ __global__ void assign_kernel(const float* __restrict__ pts, int n_total, int C,
                               liso_pillar_cfg cfg, int* __restrict__ cell_of_point, int* __restrict__ count,
                               int* __restrict__ first_enc) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_total) return;
-    const float* p = pts + (size_t)i * C;
-    const float cx = floorf((p[0] - cfg.x_min) / cfg.vx);
-    const float cy = floorf((p[1] - cfg.y_min) / cfg.vy);
-    const float cz = floorf((p[2] - cfg.z_min) / cfg.vz);
-    // NaN fails every comparison below and is dropped
-    const bool ok = cx >= 0.f && cx < (float)cfg.gx && cy >= 0.f && cy < (float)cfg.gy && cz >= 0.f && cz < 1.f;
     int cell = -1;
-    if (ok) {
-        const int b = sample_of(bi, batch, i);
-        cell = (b * cfg.gx + (int)cx) * cfg.gy + (int)cy;
-        atomicAdd(&count[cell], 1);
-        atomicMax(&first_enc[cell], INT_MAX - i);  // == atomicMin over i with a zero-initialised array
+    if (i < n_total) {
+        const float* p = pts + (size_t)i * C;
+        const float cx = floorf((p[0] - cfg.x_min) / cfg.vx);
+        const float cy = floorf((p[1] - cfg.y_min) / cfg.vy);
+        const float cz = floorf((p[2] - cfg.z_min) / cfg.vz);
+        // NaN fails every comparison below and is dropped
+        const bool ok = cx >= 0.f && cx < (float)cfg.gx && cy >= 0.f && cy < (float)cfg.gy && cz >= 0.f && cz < 1.f;
+        if (ok) cell = (sample_of(bi, batch, i) * cfg.gx + (int)cx) * cfg.gy + (int)cy;
+        cell_of_point[i] = cell;
     }
-    cell_of_point[i] = cell;
+    // adjacent LiDAR returns hit the same pillar: one pair of atomics per (wave, pillar) instead of one per point.  The first
+    // lane of a group of equal cells is the group's smallest point index (lanes are in point order).
+    const int lane = threadIdx.x & 63;
+    unsigned long long todo = __ballot(cell >= 0);
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        const int k = __shfl(cell, src);
+        const unsigned long long same = __ballot(cell == k);
+        if (lane == src) {
+            atomicAdd(&count[k], __popcll(same));
+            atomicMax(&first_enc[k], INT_MAX - i);  // == atomicMin over i with a zero-initialised array
+        }
+        todo &= ~same;
+    }
 }
 
 __device__ __forceinline__ bool is_first(const int* cell_of_point, const int* first_enc, int i) {
