@@ -147,7 +147,7 @@ class _ConvDeferred(torch.autograd.Function):
         gx = None
         if gy is not None:
             if ctx.relu:
-                gy = torch.where(y > 0, gy, torch.zeros((), dtype=gy.dtype, device=gy.device))
+                gy = torch.ops.aten.threshold_backward(gy, y, 0.0)  # gy where y > 0 else 0, one launch
             if ctx.needs_input_grad[0]:
                 if ctx.own:
                     from liso_amd.utils import mfma_conv as MC

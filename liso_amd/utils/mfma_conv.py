@@ -543,7 +543,7 @@ class _FusedConv(torch.autograd.Function):
         if dy.dtype != x_raw.dtype:
             dy = dy.to(x_raw.dtype)
         if ctx.meta["relu"]:  # the ReLU ran in the convolution's epilogue: its mask is the sign of the stored output
-            dy = torch.where(y > 0, dy, torch.zeros((), dtype=dy.dtype, device=dy.device))
+            dy = torch.ops.aten.threshold_backward(dy, y, 0.0)  # dy where y > 0 else 0, one launch
         sc, sh = fold.scale_shift() if fold is not None else (None, None)
         dw = db = dx = None
         fold_grads = [None] * ctx.meta["n_fold_params"]
