@@ -7,6 +7,7 @@ gradient all-reduce over RCCL/xGMI in a single flat bucket overlapped with backw
 only addition.
 """
 import contextlib
+import os
 
 import torch
 import torch.distributed as dist
@@ -566,6 +567,13 @@ class LisoLoopTrainer:
             # queue take turns.  Graph capture / warm-up of both networks borrows stream A.
             self._flow_stream = torch.cuda.Stream(device=device)
             self._mine_stream = torch.cuda.Stream(device=device, priority=-1)  # many tiny kernels + host reads: dispatch first
+            # stage B is a chain of ~100 dependent small launches; under contention it is the slowest stage (the host waits ~1.4 ms
+            # per step for it).  LISO_MINE_STREAMS=2 alternates consecutive pairs between two mining streams (two chains in
+            # flight): 4.46-4.65 instead of 4.6-4.8 ms per step on one GPU, but that is the 4th stream -- one more (RCCL's, in a
+            # multi-GPU run) and two streams share a hardware queue (measured with 3 mining streams: 6.4 ms).  Default 1.
+            n_mine = max(1, int(os.environ.get("LISO_MINE_STREAMS", "1")))
+            self._mine_streams = [self._mine_stream] + [torch.cuda.Stream(device=device, priority=-1) for _ in range(n_mine - 1)]
+            self._mine_turn = 0
             self.detector._capture_stream = self._flow_stream
         tc = cfg.data.tracking_cfg
         self.pre_nms, self.post_nms = tc.max_num_boxes_before_nms, tc.max_num_boxes_after_nms
@@ -739,7 +747,8 @@ class LisoLoopTrainer:
         if f is None:
             self._stage_a(pair)
             f = self._take(self._flows, pair)
-        side = self._mine_stream
+        side = self._mine_streams[self._mine_turn % len(self._mine_streams)]
+        self._mine_turn += 1
         side.wait_event(f.done)
         with torch.cuda.stream(side):
             f.flow.record_stream(side)
@@ -804,14 +813,15 @@ class LisoLoopTrainer:
             # the same shape -- in one batch: with k pairs announced it runs every k-1 steps on k-1 pairs.
             missing = [p_ for k, p_ in enumerate(up) if not has(self._flows, p_) and not has(self._mined, p_)
                        and not any(p_[0] is q[0] and p_[1] is q[1] for q in up[:k])]
-            if missing and any(p_ is q for p_ in missing for q in up[:2]):
+            ahead = 1 + len(self._mine_streams)  # stage B runs this many pairs ahead (one more than chains in flight)
+            if missing and any(p_ is q for p_ in missing for q in up[:ahead]):
                 while missing:
                     n = 1
                     while n < min(len(missing), self.infer_batch) and self._same_shapes(missing[0], missing[n]):
                         n += 1
                     self._stage_a(*missing[:n])
                     missing = missing[n:]
-            for p_ in up[:2]:  # stage B runs two pairs ahead: by the time a result is taken, its stream got there long ago
+            for p_ in up[:ahead]:  # by the time a result is taken, its stream got there long ago
                 if not has(self._mined, p_):
                     self._stage_b(p_)
         return loss

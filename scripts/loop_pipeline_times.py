@@ -10,8 +10,9 @@ dev = torch.device("cuda")
 overlap = "--no-overlap" not in sys.argv
 cfg = apply_slim_simple_knn_training(default_cfg(grid=512, bev_range_m=100.0))
 torch.manual_seed(0)
-tr = LisoLoopTrainer(cfg, dev, compute_dtype=torch.bfloat16, total_steps=400, use_graph=True, overlap=overlap)
-pairs = [slim_pair(2 + 100 * i, dev) for i in range(4)]
+IB = 4 if "--ib4" in sys.argv else 2
+tr = LisoLoopTrainer(cfg, dev, compute_dtype=torch.bfloat16, total_steps=400, use_graph=True, overlap=overlap, infer_batch=IB)
+pairs = [slim_pair(2 + 100 * i, dev) for i in range(8)]
 acc = collections.defaultdict(float)
 
 
@@ -28,6 +29,7 @@ def timed(obj, name, label=None):
 
 
 timed(tr, "_stage_a"); timed(tr, "_stage_b"); timed(tr, "_targets_from_flow"); timed(tr, "_infer_flow")
+timed(tr, "_take_mined", "_take_mined (host waits for stage B of this pair)")
 timed(tr.detector, "step", "detector.step"); timed(tr.detector, "_pillars", "detector._pillars")
 timed(tr.detector.optimizer, "step", "optimizer.step")
 timed(tr.cluster_detector, "forward", "cluster_detector")
@@ -43,12 +45,14 @@ if "--fake-b" in sys.argv:  # upper bound: stage B costs neither host nor GPU ti
             cache["r"] = real(sample_t0, flow)
         return cache["r"]
     tr._targets_from_flow = fake
-for i in range(8):
-    tr.step(*pairs[i % 4], upcoming=(pairs[(i + 1) % 4], pairs[(i + 2) % 4]))
+LA = IB + 1
+up = lambda i: tuple(pairs[(i + k) % 8] for k in range(1, LA + 1))
+for i in range(16):
+    tr.step(*pairs[i % 8], upcoming=up(i))
 torch.cuda.synchronize(); acc.clear()
 t0 = time.perf_counter()
-for i in range(8, 8 + N):
-    tr.step(*pairs[i % 4], upcoming=(pairs[(i + 1) % 4], pairs[(i + 2) % 4]))
+for i in range(16, 16 + N):
+    tr.step(*pairs[i % 8], upcoming=up(i))
 t_host = time.perf_counter() - t0
 torch.cuda.synchronize()
 t_all = time.perf_counter() - t0
