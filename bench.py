@@ -71,8 +71,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--workload", default="loop", choices=["loop", "slim", "detector", "iou3d"])
-    ap.add_argument("--lookahead", type=int, default=5,
-                    help="loop workload: sweep pairs announced ahead of the current one (stage A infers lookahead - 1 pairs per replay)")
+    ap.add_argument("--lookahead", type=int, default=7,
+                    help="loop workload: sweep pairs announced ahead of the current one (stage A infers lookahead - 1 - flow_ahead pairs per replay)")
+    ap.add_argument("--flow-ahead", type=int, default=2,
+                    help="loop workload: steps by which a SLIM inference batch is issued before stage B needs its first flow")
     ap.add_argument("--no-overlap", action="store_true",
                     help="loop workload: all stages of an iteration on one stream, one pair at a time (default: SLIM inference "
                          "of pair i+2 and box mining of pair i+1 on their own HIP streams, concurrent with the detector step on i)")
@@ -360,7 +362,7 @@ def main():
         cfg = apply_slim_simple_knn_training(cfg)
         overlap = not (args.eager or args.no_overlap)
         trainer = LisoLoopTrainer(cfg, dev, compute_dtype=dtype, total_steps=args.steps + args.warmup + 8, use_graph=not args.eager,
-                                  overlap=overlap, infer_batch=max(1, args.lookahead - 1))
+                                  overlap=overlap, infer_batch=max(1, args.lookahead - 1 - args.flow_ahead), flow_ahead=args.flow_ahead)
         # a ring of different sweep pairs; step i trains on pair i while (overlap) pairs i+1 / i+2 are in the mining stages
         pairs = [slim_pair(2 + rank + 100 * i, dev, n_points=N_POINTS, grid=GRID, bev_range_m=BEV_RANGE) for i in range(max(5, args.lookahead + 2))]
         s0, s1 = pairs[0]
@@ -495,7 +497,7 @@ def main():
                        "frames_per_step_per_gpu": frames_per_step, "parallelism": f"dp{world}",
                        "launch": ("eager" if not graphed else "hipGraph replay of fwd+loss+bwd, eager RMSprop" if args.workload == "slim"
                                   else "hipGraph replays (SLIM inference; detector backbone+head+loss fwd/bwd), eager pillar encoder / "
-                                       "flow clustering / AdamW" + (f"; 3-stage pipeline on 3 HIP streams: SLIM inference {max(1, args.lookahead - 1)} pairs per replay | "
+                                       "flow clustering / AdamW" + (f"; 3-stage pipeline on 3 HIP streams: SLIM inference {max(1, args.lookahead - 1 - args.flow_ahead)} pairs per replay | "
                                                                     "clustering+NMS+targets 1-2 pairs ahead (fixed box slots, no host reads) | "
                                                                     "detector step on pair i" if args.workload == "loop" and overlap else "")),
                        "convolutions": "MIOpen (--miopen-convs)" if args.miopen_convs else "own MFMA implicit-GEMM kernels"},

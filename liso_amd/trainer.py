@@ -536,11 +536,14 @@ class LisoLoopTrainer:
     Box-DB augmentation and tracking between the stages are outside this loop."""
 
     def __init__(self, cfg, device, compute_dtype=torch.float32, total_steps=None, slim_state_dict=None, use_graph=False,
-                 overlap=False, infer_batch=2):
+                 overlap=False, infer_batch=2, flow_ahead=0):
         """`use_graph`: the frozen SLIM inference (one capture per input shape) and the detector's forward+loss+backward are
         replayed from hipGraphs; the flow clustering in between stays eager (its box count sizes the padded Shape).
         `overlap`: step(pair_i, upcoming=(pair_i+1, pair_i+2)) runs the iteration as a three-stage software pipeline on
-        three HIP streams (see _stage_a / _stage_b below); results are those of the one-stream loop."""
+        three HIP streams (see _stage_a / _stage_b below); results are those of the one-stream loop.
+        `infer_batch`: pairs per SLIM inference replay; `flow_ahead`: steps by which an inference batch is issued BEFORE stage B needs
+        its first flow (0: just in time -- stage B of the next two pairs then queues behind a whole batch replay).  The pipeline uses
+        up to `2 + flow_ahead + infer_batch - 1` announced pairs."""
         from liso_amd.networks.flow_cluster_detector.flow_cluster_detector import FlowClusterDetector
         from liso_amd.slim.model.slim import SLIM
 
@@ -550,7 +553,7 @@ class LisoLoopTrainer:
         self._graph_det = self.use_graph and use_graph in (True, "detector")
         self._infer_graph, self._infer_graphs = None, {}
         self.overlap = bool(overlap) and device.type == "cuda"
-        self.infer_batch = int(infer_batch)
+        self.infer_batch, self.flow_ahead = int(infer_batch), int(flow_ahead)
         self.box_capacity, self.capacity_overflows = int(cfg.data.tracking_cfg.setdefault("flow_cluster_capacity", 64)), 0
         self._flow_stream, self._mine_stream, self._main_used_static = None, None, None
         self._flows, self._mined = [], []
@@ -779,7 +782,7 @@ class LisoLoopTrainer:
 
     def step(self, sample_t0, sample_t1, upcoming=()):
         """one iteration on (sample_t0, sample_t1).  With `overlap`, `upcoming` = the pairs of the following calls (up to
-        infer_batch + 1): stage A (SLIM inference) runs ahead on batches of them, stage B (box mining) up to two pairs ahead, each on
+        infer_batch + flow_ahead + 1): stage A (SLIM inference) runs ahead on batches of them, stage B (box mining) up to two pairs ahead, each on
         its own stream.
         Prefetched results are matched by object identity; anything announced but not requested next is dropped."""
         cuda = self.device.type == "cuda"
@@ -804,7 +807,8 @@ class LisoLoopTrainer:
         self.last_boxes = boxes
         loss = self.detector.step(sample_t0["pcl_full_no_ground_ta"], targets)
         if self.overlap and len(upcoming) > 0:
-            up = list(upcoming[:self.infer_batch + 1])
+            ahead = 1 + len(self._mine_streams)  # stage B runs this many pairs ahead (one more than chains in flight)
+            up = list(upcoming[:ahead + self.flow_ahead + self.infer_batch - 1])
             has = lambda store, p: any(e.is_for(p) for e in store)  # noqa: E731
             self._mined = [e for e in self._mined if any(e.is_for(q) for q in up)]
             self._flows = [e for e in self._flows if any(e.is_for(q) for q in up)]
@@ -813,8 +817,7 @@ class LisoLoopTrainer:
             # the same shape -- in one batch: with k pairs announced it runs every k-1 steps on k-1 pairs.
             missing = [p_ for k, p_ in enumerate(up) if not has(self._flows, p_) and not has(self._mined, p_)
                        and not any(p_[0] is q[0] and p_[1] is q[1] for q in up[:k])]
-            ahead = 1 + len(self._mine_streams)  # stage B runs this many pairs ahead (one more than chains in flight)
-            if missing and any(p_ is q for p_ in missing for q in up[:ahead]):
+            if missing and any(p_ is q for p_ in missing for q in up[:ahead + self.flow_ahead]):
                 while missing:
                     n = 1
                     while n < min(len(missing), self.infer_batch) and self._same_shapes(missing[0], missing[n]):

@@ -261,3 +261,37 @@ def test_batched_inference_of_two_pairs_equals_single_pairs():
     assert both.shape[0] == 2 and torch.equal(both, both2)
     for k in range(2):
         assert torch.equal(both[k:k + 1], single[k]), float((both[k:k + 1] - single[k]).abs().max())
+
+
+def test_inference_issued_ahead_of_need_gives_the_same_steps():
+    """bench.py's schedule in small: 6 pairs announced, SLIM inference in batches of 3 issued two steps before stage B needs the first
+    flow (`flow_ahead=2`), over a rotation of 7 different pairs.  Same mined boxes (count and order) and the same losses as the
+    one-stream loop step by step -- to fp32 summation order, not bit for bit: a batch of 3 pairs changes the tile count of the
+    update-block convolutions and with it their split-K plan (conv_mfma.hip: two wave groups take alternate channel slabs on small
+    launches), so the flows differ in the last bits (measured: losses agree to 1e-7 relative)."""
+    from liso_amd.datasets.synthetic import slim_pair
+    from liso_amd.trainer import LisoLoopTrainer
+    from liso_amd.utils.config import apply_slim_simple_knn_training, default_cfg
+
+    dev = torch.device("cuda")
+    grid, rng = 256, 50.0
+    pairs = [slim_pair(71 + i, dev, n_points=40000, grid=grid, bev_range_m=rng) for i in range(7)]
+    out = []
+    for overlap in (False, True):
+        cfg = apply_slim_simple_knn_training(default_cfg(grid=grid, bev_range_m=rng))
+        torch.manual_seed(0)
+        tr = LisoLoopTrainer(cfg, dev, compute_dtype=torch.bfloat16, total_steps=30, use_graph=True, overlap=overlap, infer_batch=3,
+                             flow_ahead=2)
+        losses, boxes = [], []
+        for i in range(16):
+            losses.append(float(tr.step(*pairs[i % 7], upcoming=[pairs[(i + k) % 7] for k in range(1, 7)])))
+            b = tr.last_boxes
+            boxes.append(torch.cat([b.pos.float(), b.dims.float(), b.rot.float(), b.velo.float()], dim=-1)[b.valid].cpu())
+        torch.cuda.synchronize()
+        if overlap:
+            assert tr.capacity_overflows == 0
+        out.append((losses, boxes))
+    for a, b in zip(out[0][0], out[1][0]):
+        assert abs(a - b) <= 1e-5 * abs(a), (out[0][0], out[1][0])
+    for a, b in zip(out[0][1], out[1][1]):
+        assert a.shape == b.shape and torch.allclose(a, b, rtol=1e-4, atol=1e-4), float((a - b).abs().max())
