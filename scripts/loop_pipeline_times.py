@@ -11,8 +11,9 @@ overlap = "--no-overlap" not in sys.argv
 cfg = apply_slim_simple_knn_training(default_cfg(grid=512, bev_range_m=100.0))
 torch.manual_seed(0)
 IB = 4 if "--ib4" in sys.argv else 2
-tr = LisoLoopTrainer(cfg, dev, compute_dtype=torch.bfloat16, total_steps=400, use_graph=True, overlap=overlap, infer_batch=IB)
-pairs = [slim_pair(2 + 100 * i, dev) for i in range(8)]
+FA = 2 if "--fa2" in sys.argv else 0
+tr = LisoLoopTrainer(cfg, dev, compute_dtype=torch.bfloat16, total_steps=400, use_graph=True, overlap=overlap, infer_batch=IB, flow_ahead=FA)
+pairs = [slim_pair(2 + 100 * i, dev) for i in range(9)]
 acc = collections.defaultdict(float)
 
 
@@ -45,14 +46,14 @@ if "--fake-b" in sys.argv:  # upper bound: stage B costs neither host nor GPU ti
             cache["r"] = real(sample_t0, flow)
         return cache["r"]
     tr._targets_from_flow = fake
-LA = IB + 1
-up = lambda i: tuple(pairs[(i + k) % 8] for k in range(1, LA + 1))
+LA = IB + 1 + FA
+up = lambda i: tuple(pairs[(i + k) % 9] for k in range(1, LA + 1))
 for i in range(16):
-    tr.step(*pairs[i % 8], upcoming=up(i))
+    tr.step(*pairs[i % 9], upcoming=up(i))
 torch.cuda.synchronize(); acc.clear()
 t0 = time.perf_counter()
 for i in range(16, 16 + N):
-    tr.step(*pairs[i % 8], upcoming=up(i))
+    tr.step(*pairs[i % 9], upcoming=up(i))
 t_host = time.perf_counter() - t0
 torch.cuda.synchronize()
 t_all = time.perf_counter() - t0
