@@ -55,13 +55,17 @@ class HeadDecoder(nn.Module):
         broadcast multiply-adds.  (The reference's einsum is a [3x4]x[4xN] fp64 GEMM, which rocBLAS runs with a 128x128
         DGEMM tile: 28 ms per call at N = 120k, measured -- 70 % of the first SLIM step for a quantity forward() then
         discards.)  It depends on the sweep only, so the 6 RAFT iterations of a step share one evaluation."""
-        key = (inv_odom, pc, inv_odom._version, pc._version, homog)
+        # (the stream is part of the key: a hit hands out tensors that were produced on, and belong to the allocator pool of, the
+        # stream that filled the cache -- another stream would read them without an event in between and keep using them after the
+        # entry is replaced and its memory recycled; the loop's pipeline runs this decoder on two streams)
+        stream_id = torch.cuda.current_stream(inv_odom.device).cuda_stream if inv_odom.is_cuda else 0
+        key = (inv_odom, pc, inv_odom._version, pc._version, homog, stream_id)
         c = getattr(self, "_gt_cache", None)
         # (never while a hipGraph is being captured: a hit would leave the computation out of the graph and every replay
         # would keep the values of the capture-time inputs)
         capturing = inv_odom.is_cuda and torch.cuda.is_current_stream_capturing()
         if (not capturing and c is not None and all(a is b for a, b in zip(c[0], key) if torch.is_tensor(a))
-                and c[0][2:4] == key[2:4]):
+                and c[0][2:4] == key[2:4] and c[0][5] == key[5]):
             return c[1]
         M = inv_odom.double() - torch.eye(4, dtype=torch.float64, device=inv_odom.device)[None]
         hb = homog if homog.dim() == 4 else homog[None]  # [B,N,1,4] (per point, pointwise decoding) or the shared [H,W,4]

@@ -798,6 +798,10 @@ class LisoLoopTrainer:
                 f.flow.record_stream(cur)
                 flow = f.flow
             else:
+                if self.overlap and cuda:
+                    # not prefetched (first call, wrong or missing announcement): the inference runs HERE, on the caller's stream,
+                    # with the same static graph buffers, packed weight panels and decoder caches stage A uses on its stream
+                    cur.wait_stream(self._flow_stream)
                 with torch.no_grad():
                     flow = self._infer_flow(sample_t0, sample_t1)
             targets, boxes = self._targets_from_flow(sample_t0, flow)
