@@ -41,9 +41,10 @@ if "--fake-b" in sys.argv:  # upper bound: stage B costs neither host nor GPU ti
     cache = {}
     real = tr._targets_from_flow
 
-    def fake(sample_t0, flow):
+    def fake(sample_t0, flow, capacity=None):
         if "r" not in cache:
-            cache["r"] = real(sample_t0, flow)
+            cache["r"] = real(sample_t0, flow, capacity=capacity)
+            tr.cluster_detector.last_num_labels = tr.cluster_detector.last_num_labels.clone()
         return cache["r"]
     tr._targets_from_flow = fake
 LA = IB + 1 + FA
