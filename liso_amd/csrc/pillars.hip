@@ -21,6 +21,7 @@
 //     instead of 2x64 per-channel sums over [P*20, 64]; the same moments give the BN backward terms in closed form.
 //   * all cross-workgroup reductions are two-stage with fixed order (no float atomics): results are reproducible.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "zero_fill.h"
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
@@ -489,10 +490,11 @@ __device__ __forceinline__ void stage_rows(const float* __restrict__ feat, const
 
 // ---- forward: Linear(F,64, no bias) -> BN -> ReLU -> max over the 20 slots -> canvas[b, x_idx, y_idx, :] ------------
 // One launch, two kinds of blocks, every canvas cell written exactly once (no memset pass, no double write):
-//   blocks [0, zero_blocks): 256 consecutive cells each; empty cells are zero-filled with 16-B stores (consecutive
-//                            threads -> consecutive chunks), the occupancy map is written;
-//   the other blocks:        pillars in voxel order, kGroup per wave step, rows streamed from the CSR feature array,
-//                            one 128-B (bf16) / 256-B (fp32) row store per pillar.
+//   the first blocks:        pillars in voxel order, kGroup per wave step, rows streamed from the CSR feature array,
+//                            one 128-B (bf16) / 256-B (fp32) row store per pillar (dependent loads, little bandwidth: ~25 us
+//                            of work at B = 4 that is scheduled first so it runs underneath the streaming blocks);
+//   the last zero_blocks:    256 consecutive cells each; empty cells are zero-filled with 16-B stores (consecutive
+//                            threads -> consecutive chunks), the occupancy map is written (alone: 21 us = 6.4 TB/s at B = 4).
 constexpr int kCellsPerBlock = 256;
 
 template <int C, typename OutT>
@@ -507,8 +509,9 @@ __global__ __launch_bounds__(kPfnThreads) void pfn_forward_kernel(const float* _
     __shared__ __attribute__((aligned(16))) float frow[kPfnThreads / 64][kStage][kFP];
     __shared__ int vox[kCellsPerBlock];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if ((int)blockIdx.x < zero_blocks) {
-        const long cell0 = (long)blockIdx.x * kCellsPerBlock;
+    const int pillar_blocks = (int)gridDim.x - zero_blocks;
+    if ((int)blockIdx.x >= pillar_blocks) {
+        const long cell0 = (long)((int)blockIdx.x - pillar_blocks) * kCellsPerBlock;
         const long cell = cell0 + tid;
         int v1 = 0;
         if (cell < total_cells) {
@@ -530,8 +533,8 @@ __global__ __launch_bounds__(kPfnThreads) void pfn_forward_kernel(const float* _
     for (int k = 0; k < F; k++) w[k] = weight[lane * F + k];
     const float scale = bn[lane], shift = bn[kOut + lane];
     const float pad_val = fmaxf(shift, 0.f);
-    const int wave_id = ((int)blockIdx.x - zero_blocks) * (kPfnThreads / 64) + wave;
-    const int n_waves = ((int)gridDim.x - zero_blocks) * (kPfnThreads / 64);
+    const int wave_id = (int)blockIdx.x * (kPfnThreads / 64) + wave;
+    const int n_waves = pillar_blocks * (kPfnThreads / 64);
     for (int v0 = wave_id * kGroup; v0 < rows; v0 += n_waves * kGroup) {
         int off[kGroup + 1];
         stage_rows(feat, pt_off, rows, v0, lane, frow[wave], off);
