@@ -73,6 +73,22 @@ int liso_match_greedy_f32(const float* iou, long gt_stride, long pred_stride, in
                           int64_t* idx_gt, int64_t* idx_pred, float* match_iou, int* num_matches,
                           uint8_t* matched_pred_mask, uint8_t* detected_gt_mask, void* stream);
 
+/* ---- local box refinement: rectangle fit to the points inside each box ------------------------------------------------
+ * Replaces, per box, the body of the loop in perform_local_box_refinement (liso/tracker/tracking.py:2037-2066): points of the
+ * sweep whose box-frame x, y (fp64 transform, compared as fp32) lie inside 0.5 * dims_bloat * dims[:2] are handed to
+ * fit_2d_box_modest(..., "closeness_to_edge") (liso/box_fitting/box_fitting.py:93-141,242-258): of the 19 headings 0, 5, ..., 90 deg
+ * the one whose bounding rectangle has the points closest to its edges (sum of 1 / max(distance, 0.01); first maximum), turned by
+ * 90 deg when its y side is the longer one.
+ *   points   float32 [n, point_stride] (x, y first); point_valid uint8 [n] or null
+ *   boxes    float32 [k, 7] (x, y, z, dx, dy, dz, yaw)
+ *   count    int32 [k]    points inside the bloated footprint
+ *   fit      float64 [k, 5] = centre x, centre y, length, width, yaw of the fitted rectangle (NaN when count == 0)
+ *   workspace  liso_fit_boxes_closeness_workspace_bytes(n, k) bytes, 16-byte aligned (the per-box point lists)
+ */
+size_t liso_fit_boxes_closeness_workspace_bytes(long n, int k);
+int liso_fit_boxes_closeness_f32(const float* points, long n, int point_stride, const uint8_t* point_valid, const float* boxes, int k,
+                                 float dims_bloat, int* count, double* fit, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

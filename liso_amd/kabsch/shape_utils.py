@@ -190,6 +190,22 @@ class Shape:
             pose = numpy_compose_matrix(pos[..., 0].astype(np.float64), pos[..., 1].astype(np.float64), th, t_z=tz)
         return pose[0] if unb else pose
 
+    @staticmethod
+    def get_bottom_corner_idxs():
+        return (0, 1, 4, 5)  # reference :373-375
+
+    def get_box_corners(self):
+        """reference :377-436 (tensor branch): the 8 corners in sensor coordinates, fp64 [.., 8, 3], and the edge list; corner order
+        front-right-bottom, front-left-bottom, front-left-top, front-right-top, then the same for the rear"""
+        assert self.dims.shape[-1] == 3 and self.pos.shape[-1] == 3, (self.dims.shape, self.pos.shape)
+        edges = ((0, 1), (1, 2), (2, 3), (3, 0), (4, 5), (5, 6), (6, 7), (7, 4), (0, 4), (1, 5), (2, 6), (3, 7))
+        signs = [(1, -1, -1), (1, 1, -1), (1, 1, 1), (1, -1, 1), (-1, -1, -1), (-1, 1, -1), (-1, 1, 1), (-1, -1, 1)]
+        unit = 0.5 * torch.tensor(signs, dtype=self.dims.dtype, device=self.dims.device)
+        corners = unit * self.dims[..., None, :]
+        homog = torch.cat([corners, torch.ones_like(corners[..., :1])], dim=-1)
+        pose = self.get_poses()
+        return torch.einsum("...ij,...cj->...ci", pose, homog.to(pose.dtype))[..., :3], edges
+
     def transform(self, new_T_old):
         """reference :472-486"""
         out = self.clone()
