@@ -89,6 +89,16 @@ size_t liso_fit_boxes_closeness_workspace_bytes(long n, int k);
 int liso_fit_boxes_closeness_f32(const float* points, long n, int point_stride, const uint8_t* point_valid, const float* boxes, int k,
                                  float dims_bloat, int* count, double* fit, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- minimum-jerk track smoothing -----------------------------------------------------------------------------------------
+ * Replaces the optimisation loop of smooth_track_jerk (liso/tracker/track_smoothing.py:104-230: BatchedSmoothTrack parameters,
+ * get_pos_jerk_magnitude, per_batch_mean_loss, torch.optim.Adam(lr) for max_iters steps): all iterations in one launch, one
+ * block per track.  observed_pos / smooth_pos float32 [batch, timesteps, 3], valid uint8 [batch, timesteps] (padded frames are free
+ * parameters, as in the reference; frame 0 is fixed), timesteps <= 1024.  The loss is the mean over tracks of
+ * sum_t valid * |third difference| / n_valid + pos_regul_loss_weight * sum_t valid * |p - observed|^2 / n_valid.
+ */
+int liso_smooth_tracks_jerk_f32(const float* observed_pos, const uint8_t* valid, int batch, int timesteps, int max_iters,
+                                float learning_rate, float pos_regul_loss_weight, float* smooth_pos, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

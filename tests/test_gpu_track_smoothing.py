@@ -1,0 +1,68 @@
+"""Minimum-jerk track smoothing on the device (include/liso_tracking.h: liso_smooth_tracks_jerk_f32; liso_amd/tracker/track_smoothing.py)
+against the fixture written by the reference's `smooth_track_jerk` and against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(g, tag, iters):
+    from liso_amd.tracker.track_smoothing import smooth_track_jerk
+    pos, valid, yaw = (torch.from_numpy(g[f"{tag}_{k}"]).cuda() for k in ("pos", "valid", "yaw"))
+    p, rot, velo = smooth_track_jerk(pos, valid, yaw, 0.1, max_iters=iters)
+    assert rot.data_ptr() == yaw.data_ptr()  # written into the argument, like the reference
+    return p.cpu().numpy(), rot.cpu().numpy(), velo.cpu().numpy()
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_short_runs_match_reference_fixture(golden_dir, tag):
+    g = np.load(f"{golden_dir}/track_smoothing_reference.npz")
+    valid = g[f"{tag}_valid"]
+    for iters, tol in ((1, 1e-5), (3, 2e-5), (20, 1e-3)):
+        p, rot, velo = _run(g, tag, iters)
+        assert np.abs(p - g[f"{tag}_{iters}_pos"]).max() <= tol, (iters, np.abs(p - g[f"{tag}_{iters}_pos"]).max())
+        assert np.abs(velo - g[f"{tag}_{iters}_velo"])[valid].max() <= 10 * tol
+        assert np.abs(rot - g[f"{tag}_{iters}_rot"])[valid].max() <= 1e-3
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_full_run_within_the_reference_sensitivity_and_loss(golden_dir, tag):
+    from oracle import track_smoothing as ot
+
+    g = np.load(f"{golden_dir}/track_smoothing_reference.npz")
+    obs, valid = g[f"{tag}_pos"], g[f"{tag}_valid"]
+    p, rot, velo = _run(g, tag, 2000)
+    assert np.abs(p - g[f"{tag}_2000_pos"])[valid].max() <= 3 * float(g[f"{tag}_sensitivity"])
+    total, jerk = ot.losses(p, obs, valid)
+    assert np.allclose(total, g[f"{tag}_2000_last_loss"], rtol=0.05), (total, g[f"{tag}_2000_last_loss"])
+    assert np.abs(velo - g[f"{tag}_2000_velo"])[valid].max() <= 6 * float(g[f"{tag}_sensitivity"])
+    assert np.array_equal(p[:, 0], obs[:, 0])  # the first frame is not a parameter
+
+
+def test_short_tracks_and_many_tracks(golden_dir):
+    from liso_amd.tracker.track_smoothing import minimise_jerk, smooth_track_jerk
+    from oracle import track_smoothing as ot
+
+    g = np.load(f"{golden_dir}/track_smoothing_reference.npz")
+    pos, valid, yaw = (torch.from_numpy(g[f"c_{k}"]).cuda() for k in ("pos", "valid", "yaw"))
+    p, rot, velo = smooth_track_jerk(pos, valid, yaw, 0.1, max_iters=20)
+    assert p is pos and np.allclose(velo.cpu().numpy(), g["c_20_velo"], atol=1e-6)
+    # 200 tracks of 150 frames with ragged lengths, 50 steps: the kernel against the numpy restatement
+    rs = np.random.default_rng(3)
+    B, T = 200, 150
+    t = np.arange(T)[None, :, None]
+    obs = (np.concatenate([rs.uniform(-30, 30, (B, 1, 1)) + 0.9 * t, rs.uniform(-30, 30, (B, 1, 1)) + 0.2 * t, np.zeros((B, T, 1))], -1)
+           + rs.normal(0, 0.2, (B, T, 3))).astype(np.float32)
+    lengths = rs.integers(5, T + 1, B)
+    val = np.arange(T)[None] < lengths[:, None]
+    obs[~val] = 0
+    for iters, tol in ((5, 2e-4), (50, None)):
+        got = minimise_jerk(torch.from_numpy(obs).cuda(), torch.from_numpy(val).cuda(), max_iters=iters).cpu().numpy()
+        want = ot.adam_jerk(obs, val, iters)
+        d = np.abs(got - want)[val]
+        if tol is not None:
+            # a coordinate whose gradient cancels to ~1e-9 (the size of Adam's eps) takes a first step that is pure rounding
+            assert np.quantile(d, 0.999) <= tol and d.max() <= 5e-3, (iters, np.quantile(d, 0.999), d.max())
+        else:  # rounding differences grow with the step count (normalised jerk directions, Adam's normalised steps)
+            assert np.quantile(d, 0.5) <= 2e-3 and np.quantile(d, 0.99) <= 0.03 and d.max() <= 0.1, (np.quantile(d, 0.99), d.max())
