@@ -38,11 +38,12 @@ class SepHead(nn.Module):
         if not all(len(q) == 4 and isinstance(q[1], nn.BatchNorm2d) for q in seqs):
             return None
         hid, hfold = MC.fused_conv(x_raw, fold, [q[0] for q in seqs], out_bn=[q[1] for q in seqs])
-        out, a = {}, 0
+        # (split, not four slices: the backward of split is ONE concatenation of the heads' input gradients, the backward of each
+        # slice a zero-filled full-width map + a copy, and autograd then adds the four maps)
+        parts = torch.split(hid, [q[0].out_channels for q in seqs], dim=1)
+        out = {}
         for k, (head, q) in enumerate(zip(self.heads, seqs)):
-            c = q[0].out_channels
-            out[head], _ = MC.fused_conv(hid[:, a:a + c], hfold.group(k), q[3], out_dtype=torch.float32)
-            a += c
+            out[head], _ = MC.fused_conv(parts[k], hfold.group(k), q[3], out_dtype=torch.float32)
         return out
 
     def forward(self, x):
