@@ -306,9 +306,10 @@ def conv_dgrad(dy, weight, spec, x_shape, out_dtype=None, packed=None):
     """dy: logical [B,Co,Ho,Wo] -> dx logical [B,Ci,Hi,Wi] (gradient w.r.t. the convolution's INPUT x')"""
     L.require_cuda(dy, weight)
     mode = _mode(dy.dtype)
-    if dy.shape[1] % _vec(mode):
-        packed = None
-    dy, weight = _pad_out_channels(dy, weight, spec, _vec(mode))
+    # 1-3 output channels (the head's last convolutions): dy gets zero channels up to one 16-B group.  A panel packed from the
+    # UNPADDED weight is already what the kernel needs (its reduction axis is zero-padded to 16 channels either way), so the weight
+    # is only padded when it still has to be packed here.
+    dy, weight = _pad_out_channels(dy, weight if packed is None else None, spec, _vec(mode))
     gv, gps = as_nhwc(dy, _vec(mode))
     B, ho, wo, co = gv.shape
     _, ci, hi, wi = x_shape
@@ -329,7 +330,8 @@ def conv_dgrad(dy, weight, spec, x_shape, out_dtype=None, packed=None):
     return dx.permute(0, 3, 1, 2)
 
 
-def conv_wgrad(x, dy, weight_shape, spec, in_scale=None, in_shift=None, in_relu=False, want_bias=True, out_dw=None, out_db=None):
+def conv_wgrad(x, dy, weight_shape, spec, in_scale=None, in_shift=None, in_relu=False, want_bias=True, out_dw=None, out_db=None,
+               co_true=None):
     """-> (dw fp32 in torch's layout `weight_shape`, dbias fp32 [Co] | None); None if the geometry is not supported by the
     kernel (caller falls back to ATen's weight gradient).  `out_dw` / `out_db`: dense fp32 tensors to write into (overwritten)."""
     L.require_cuda(x, dy)
@@ -338,8 +340,9 @@ def conv_wgrad(x, dy, weight_shape, spec, in_scale=None, in_shift=None, in_relu=
     mode = _mode(x.dtype)
     if dy.dtype != x.dtype:
         dy = dy.to(x.dtype)
-    co_true = dy.shape[1]
-    dy, _ = _pad_out_channels(dy, None, spec, _vec(mode))
+    if co_true is None:  # (`co_true` given: the caller already padded dy with zero channels, see _FusedConv.backward)
+        co_true = dy.shape[1]
+        dy, _ = _pad_out_channels(dy, None, spec, _vec(mode))
     if dy.shape[1] != co_true:
         weight_shape = ((weight_shape[0], dy.shape[1]) if spec.transposed else (dy.shape[1], weight_shape[1])) + tuple(weight_shape[2:])
     xv, xps = as_nhwc(x, _vec(mode))
@@ -547,15 +550,18 @@ class _FusedConv(torch.autograd.Function):
         sc, sh = fold.scale_shift() if fold is not None else (None, None)
         dw = db = dx = None
         fold_grads = [None] * ctx.meta["n_fold_params"]
+        co_true = dy.shape[1]
+        if co_true % _vec(_mode(dy.dtype)):  # 1-3 channels: one zero-padded copy serves the weight AND the data gradient
+            dy, _ = _pad_out_channels(dy, None, spec, _vec(_mode(dy.dtype)))
         if ctx.needs_input_grad[1] or (ctx.meta["has_bias"] and ctx.needs_input_grad[2]):
             tw = _direct_target(weight)
             tb = _direct_target(ctx.meta["bias_param"]) if tw is not None and ctx.meta["has_bias"] else None
             if ctx.meta["has_bias"] and tb is None:
                 tw = None  # (both or none: one launch produces both)
             res = conv_wgrad(x_raw, dy, tuple(weight.shape), spec, sc, sh, in_relu=fold.relu if fold is not None else False,
-                             want_bias=ctx.meta["has_bias"], out_dw=tw, out_db=tb)
+                             want_bias=ctx.meta["has_bias"], out_dw=tw, out_db=tb, co_true=co_true)
             if res is None:
-                dw, db = _aten_wgrad(x_raw, dy, weight, spec, fold, ctx.meta["has_bias"])
+                dw, db = _aten_wgrad(x_raw, dy[:, :co_true], weight, spec, fold, ctx.meta["has_bias"])
             else:
                 dw, db = res
                 if tw is not None and dw is tw:  # written in place: nothing for autograd to accumulate
