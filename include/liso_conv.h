@@ -66,6 +66,9 @@ typedef struct {
     int in_relu, out_relu;
     int in_affine_batch_stride; /* 0: in_scale / in_shift are [ci], shared by all samples (BatchNorm);
                                    > 0: per-sample vectors, sample b reads in_scale[b * stride + c] (InstanceNorm) */
+    int wgrad_co;               /* liso_conv_wgrad only: output channels actually written to dw / dbias (0 = co).  dy may carry
+                                   zero channels beyond it (a 1-3 channel gradient padded to one 16-B group): the extra filters
+                                   are computed and dropped, dw / dbias keep the layer's true shape */
 } liso_conv_desc;
 
 /* Packs torch-layout fp32 weights for the kernels.

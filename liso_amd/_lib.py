@@ -167,7 +167,7 @@ class ConvDesc(ctypes.Structure):
                 ("n_classes", _i), ("class_tap_begin", _i * (CONV_MAX_CLASSES + 1)), ("class_ooy", _i * CONV_MAX_CLASSES),
                 ("class_oox", _i * CONV_MAX_CLASSES), ("n_taps", _i), ("tap_dy", _i * CONV_MAX_TAPS), ("tap_dx", _i * CONV_MAX_TAPS),
                 ("tap_w", _i * CONV_MAX_TAPS), ("w_taps", _i), ("mode", _i), ("out_f32", _i), ("in_relu", _i), ("out_relu", _i),
-                ("in_affine_batch_stride", _i)]
+                ("in_affine_batch_stride", _i), ("wgrad_co", _i)]
 
 
 class ConvPackJob(ctypes.Structure):

@@ -640,8 +640,10 @@ int liso_conv_wgrad(const liso_conv_desc* d, const void* x, const float* in_scal
         rc = p.tg == 9 ? launch<LISO_CONV_BF16, 9>(*d, p, st) : p.tg == 3 ? launch<LISO_CONV_BF16, 3>(*d, p, st)
                                                                          : launch<LISO_CONV_BF16, 1>(*d, p, st);
     if (rc != LISO_OK) return rc;
-    const long rblocks = ((long)d->w_taps * d->ci + (dbias ? 1 : 0)) * ((d->co + 63) / 64);
-    wgrad_reduce_kernel<<<(int)rblocks, 256, 0, st>>>(p.a.slab, p.a.bias_slab, p.splits, p.splits * d->n_classes, d->w_taps, d->ci, d->co,
+    if (d->wgrad_co < 0 || d->wgrad_co > d->co) return LISO_EINVAL;
+    const int co_w = d->wgrad_co > 0 ? d->wgrad_co : d->co;  // channels written (dy may carry zero-padded channels beyond)
+    const long rblocks = ((long)d->w_taps * d->ci + (dbias ? 1 : 0)) * ((co_w + 63) / 64);
+    wgrad_reduce_kernel<<<(int)rblocks, 256, 0, st>>>(p.a.slab, p.a.bias_slab, p.splits, p.splits * d->n_classes, d->w_taps, d->ci, co_w,
                                                                     (long)p.a.ci_t * CT, (long)p.a.co_t * CT, transposed, dw, dbias);
     return hipGetLastError() == hipSuccess ? LISO_OK : LISO_ELAUNCH;
 }

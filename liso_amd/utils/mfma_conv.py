@@ -343,31 +343,27 @@ def conv_wgrad(x, dy, weight_shape, spec, in_scale=None, in_shift=None, in_relu=
     if co_true is None:  # (`co_true` given: the caller already padded dy with zero channels, see _FusedConv.backward)
         co_true = dy.shape[1]
         dy, _ = _pad_out_channels(dy, None, spec, _vec(mode))
-    if dy.shape[1] != co_true:
-        weight_shape = ((weight_shape[0], dy.shape[1]) if spec.transposed else (dy.shape[1], weight_shape[1])) + tuple(weight_shape[2:])
     xv, xps = as_nhwc(x, _vec(mode))
     gv, gps = as_nhwc(dy, _vec(mode))
     B, hi, wi, ci = xv.shape
     _, ho, wo, co = gv.shape
     build = scatter_desc if spec.transposed else gather_desc
     d = build(spec, B, hi, wi, ci, xps, ho, wo, co, co, 0, mode, True, in_relu, False)
+    if co != co_true:  # zero-padded gradient channels: the kernel computes them, the reduction writes the layer's true filters only
+        d = L.ConvDesc.from_buffer_copy(d)
+        d.wgrad_co = co_true
     lib = L.lib()
     nbytes = lib.liso_conv_wgrad_workspace_bytes(ctypes.byref(d))
     if nbytes == 0:
         return None
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-    if co != co_true:
-        out_dw = out_db = None  # (padded channels: the result is sliced below)
     dw = out_dw if out_dw is not None else torch.empty(weight_shape, dtype=torch.float32, device=x.device)
-    db = (out_db if out_db is not None else torch.empty(co, dtype=torch.float32, device=x.device)) if want_bias else None
+    db = (out_db if out_db is not None else torch.empty(co_true, dtype=torch.float32, device=x.device)) if want_bias else None
     with torch.cuda.device(x.device):
         L.check(L.TIMER.launch(_timer_name(mode, "wgrad"), lambda: lib.liso_conv_wgrad(
             ctypes.byref(d), L.ptr(xv), L.ptr(in_scale) if in_scale is not None else None,
             L.ptr(in_shift) if in_shift is not None else None, L.ptr(gv), gps, int(spec.transposed), L.ptr(dw),
             L.ptr(db) if db is not None else None, L.ptr(ws), nbytes, L.stream_ptr()), units=_flops(d)), "conv_wgrad")
-    if co != co_true:
-        dw = (dw[:, :co_true] if spec.transposed else dw[:co_true]).contiguous()
-        db = db[:co_true].contiguous() if db is not None else None
     return dw, db
 
 
