@@ -220,3 +220,36 @@ class ObjectDetectionMetrics:
                 for k, v in e.items():
                     out[pre + f"/{thr:.1f}{self.threshold_unit}/{k}"] = v if k == "tps" else v / max(e["tps"], 1e-6)
         return out
+
+
+def map_scores_from_neg_infs_to_actual_min_score(relevant_scores):
+    """reference :1837-1859: the -inf scores of false negatives become a finite value just below the smallest real score (10 % of the
+    score range below it; -666 when there is no real score), for the sklearn-style curves"""
+    scores = np.asarray(relevant_scores)
+    real = scores[scores != -np.inf]
+    if real.size == 0:
+        print("Warning, no valid scores found: Replacing with magic number -666")
+        fill = -666
+    else:
+        fill = real.min() - 0.1 * (real.max() - real.min())
+    return np.where(scores == -np.inf, fill, scores)
+
+
+def waymo_precisions_recalls_apscore(precisions, recalls, max_recall_gap=0.05):
+    """reference :1862-1906: Waymo-style AP -- wherever two consecutive operating points are more than `max_recall_gap` apart in recall,
+    points are inserted every `max_recall_gap` with the (conservative) precision of the point after the gap; AP = trapezoid area"""
+    precisions, recalls = np.asarray(precisions, np.float64), np.asarray(recalls, np.float64)
+    eps = 1e-6
+    for _ in range(1000):
+        gaps = np.where((np.abs(np.diff(recalls)) - eps) > max_recall_gap)[0]
+        if gaps.size == 0:
+            break
+        i = int(gaps[0])
+        width = recalls[i + 1] - recalls[i]
+        assert width > 0.0, width
+        n_new = int(width / max_recall_gap) - 1
+        new_r = np.linspace(recalls[i] + max_recall_gap, recalls[i + 1] - max_recall_gap, n_new)
+        precisions = np.insert(precisions, np.repeat(i + 1, n_new), np.repeat(precisions[i + 1], n_new))
+        recalls = np.insert(recalls, np.repeat(i + 1, n_new), new_r)
+    trapz = getattr(np, "trapezoid", None) or np.trapz
+    return precisions, recalls, trapz(precisions, recalls)

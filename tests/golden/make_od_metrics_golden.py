@@ -100,6 +100,15 @@ def main():
                 c, p, r = odm.get_conf_prec_rec(lab, sc, fn, use_interpolation=interp)
                 out[f"{tag}_conf_{int(interp)}"], out[f"{tag}_prec_{int(interp)}"], out[f"{tag}_rec_{int(interp)}"] = c, p, r
             out[f"{tag}_ap"] = np.array(odm.calc_ap(odm.get_conf_prec_rec(lab, sc, fn)[1], 0.1, 0.1))
+    # the sklearn-curve score clean-up and the Waymo-style AP
+    for tag, sc in {"m0": np.array([0.9, -np.inf, 0.2, 0.5, -np.inf]), "m1": np.array([-np.inf, -np.inf]), "m2": np.array([0.3])}.items():
+        out[f"{tag}_scores_in"] = sc
+        out[f"{tag}_scores_clean"] = odm.map_scores_from_neg_infs_to_actual_min_score(sc)
+    for tag, (pr, rc) in {"w0": (np.array([1.0, 0.0]), np.array([0.0, 1.0])),
+                          "w1": (np.array([1.0, 0.9, 0.7, 0.65, 0.2]), np.array([0.0, 0.04, 0.31, 0.33, 0.9])),
+                          "w2": (np.linspace(1, 0.5, 30), np.linspace(0, 0.9, 30))}.items():
+        p2, r2, ap = odm.waymo_precisions_recalls_apscore(pr.copy(), rc.copy())
+        out[f"{tag}_prec_in"], out[f"{tag}_rec_in"], out[f"{tag}_prec"], out[f"{tag}_rec"], out[f"{tag}_ap"] = pr, rc, p2, r2, np.array(ap)
     np.savez_compressed(os.path.join(HERE, "od_metrics_reference.npz"), **out)
     print("arrays:", len(out))
 

@@ -37,3 +37,16 @@ def test_tp_error_helpers():
     assert np.allclose(abs_yaw_diff(np.array([3.1, -3.1, 0.2]), np.array([-3.1, 3.1, -0.1])), [2 * np.pi - 6.2, 2 * np.pi - 6.2, 0.3])
     with pytest.raises(AssertionError):
         calc_ap(np.zeros(50), 0.1, 0.1)
+
+
+def test_score_cleanup_and_waymo_ap_match_reference(golden_dir):
+    from liso_amd.eval.od_metrics import map_scores_from_neg_infs_to_actual_min_score, waymo_precisions_recalls_apscore
+
+    g = np.load(f"{golden_dir}/od_metrics_reference.npz")
+    for tag in ("m0", "m1", "m2"):
+        assert np.array_equal(map_scores_from_neg_infs_to_actual_min_score(g[f"{tag}_scores_in"]), g[f"{tag}_scores_clean"]), tag
+    for tag in ("w0", "w1", "w2"):
+        p, r, ap = waymo_precisions_recalls_apscore(g[f"{tag}_prec_in"], g[f"{tag}_rec_in"])
+        assert np.allclose(p, g[f"{tag}_prec"], atol=1e-12) and np.allclose(r, g[f"{tag}_rec"], atol=1e-12), tag
+        assert abs(ap - float(g[f"{tag}_ap"])) <= 1e-12, tag
+    assert abs(float(g["w0_ap"]) - 0.025) < 1e-9  # p(0) = 1, p(1) = 0: the trapezoid over the inserted points gives 0.025 (the comment in the reference says 0.05)
