@@ -253,3 +253,16 @@ class BoxAugmenter:
             centermaps = {}
         augm[self.cfg.data.train_on_box_source] = {"boxes": extra_boxes, "prediscovered_boxes": prediscovered_boxes, **centermaps}
         return augm
+
+    def create_augmented_sample_from_flow_cluster_detector_and_box_snippet_db(self, src_trgt_time_delta_s, sample_data_ta):
+        """reference :1805-1830: the boxes already mined for this sample (`sample[train_on_box_source]["boxes"]`) ride along with the
+        pasted ones when cluster supervision or box augmentation is active; without a snippet database only the time delta is returned"""
+        sup = self.cfg.loss.supervised
+        if ("supervised_on_clusters" in sup and sup.supervised_on_clusters.active) or self.cfg.data.augmentation.boxes.active:
+            prediscovered_boxes = sample_data_ta.get(self.cfg.data.train_on_box_source, {}).get("boxes", None)
+        else:
+            assert "mined" not in sample_data_ta, sample_data_ta["mined"].keys()
+            prediscovered_boxes = None
+        if self.box_augm_db is None:
+            return {"src_trgt_time_delta_s": torch.tensor(src_trgt_time_delta_s)}
+        return self.create_augmented_sample_from_box_snippet_db(src_trgt_time_delta_s, sample_data_ta, prediscovered_boxes=prediscovered_boxes)
