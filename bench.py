@@ -51,6 +51,9 @@ def _graph_env():
     no memset node and keep the default (recorded packets: 1 ms per step faster).  Must be set before HIP initialises."""
     if "--graph" in sys.argv and "slim" in sys.argv:
         os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+    if "--miopen-convs" in sys.argv and "--eager" not in sys.argv:
+        # MIOpen / ATen backward reductions inside the captured detector step bring memset nodes along (same rule)
+        os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 
 
 _graph_env()
@@ -311,12 +314,20 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("LISO_DIST_BACKEND", "nccl") != "nccl":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)  # (test mode: ranks share the GPUs that exist)
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback for the HIP path)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        # "nccl" IS RCCL on ROCm.  LISO_DIST_BACKEND=gloo: the same bench with several ranks sharing ONE GPU (tests/test_gpu_multirank.py;
+        # RCCL refuses two ranks on one device) -- never used for a reported number.
+        backend = os.environ.get("LISO_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     from liso_amd import _lib as L
     from liso_amd.utils.config import apply_slim_simple_knn_training, default_cfg
@@ -473,7 +484,8 @@ def main():
             peak, runit = HBM_PEAK_GBS, "GB/s"
         traffic, traffic_src = pmc_traffic(args.workload, PMC_PATTERNS[key]) if key in PMC_PATTERNS else (None, None)
         workload = {
-            "loop": ("fused LISO iteration (BASELINE configs[3]): SLIM fwd (no_grad) -> FlowClusterDetector (DBSCAN) -> NMS "
+            "loop": ("fused LISO iteration (BASELINE configs[3]): SLIM fwd (no_grad; forward flow direction t0->t1 only, only the last "
+                     "of the 6 RAFT iterations decoded -- what the box miner consumes) -> FlowClusterDetector (DBSCAN) -> NMS "
                      "-> target maps -> CenterPoint-pillar train step, one 120k-pt sweep pair per GPU, 512x512 BEV"),
             "slim": ("SLIM scene-flow train step (BASELINE configs[1]): two 120k-pt KITTI-shaped clouds, 512x512 BEV "
                      "pillars, RAFT 6 iterations fwd+bw flow, kNN loss, fwd+bwd+RMSprop"),
@@ -507,7 +519,11 @@ def main():
                          "avg_launch_ms": 1e3 * t_total / n_launch,
                          "launches_per_step": sum(L.TIMER.weights.get(key, [1.0] * n_launch)) / max(event_steps, 1),
                          ("algorithmic_flop_per_launch" if bound == "mfma" else "algorithmic_bytes_per_launch"): alg_total / n_launch,
-                         "share_of_step": per_unit[key] / max(event_steps, 1) / (1e3 * elapsed / args.steps),
+                         **({"algorithmic_bytes_per_launch": sum(L.TIMER.bytes[key]) / len(L.TIMER.bytes[key])}
+                            if bound == "mfma" and L.TIMER.bytes.get(key) else {}),
+                         # share of the SUMMED event-timed kernel time (the kernels are timed alone on one stream; the pipelined
+                         # step overlaps three streams, so a quotient by the step time would not be a share)
+                         "share_of_timed_kernels": per_unit[key] / max(sum(per_unit.values()), 1e-12),
                          "timed_in": timed_in,
                          "timed_kernels_ms_per_step": {k: round(v / max(event_steps, 1), 4) for k, v in
                                                        sorted(per_unit.items(), key=lambda kv: -kv[1])}},

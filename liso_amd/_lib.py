@@ -247,6 +247,7 @@ class KernelTimer:
         self.enabled = set()
         self.events = {}
         self.units = {}
+        self.bytes = {}
         self.weights = {}
         self.weight = 1.0
 
@@ -261,8 +262,9 @@ class KernelTimer:
     def disable_all(self):
         self.enabled = set()
 
-    def launch(self, name, fn, units=None):
-        """`units`: how many work items (queries, points ...) this launch processes, for per-launch algorithmic bytes"""
+    def launch(self, name, fn, units=None, nbytes=None):
+        """`units`: how many work items (queries, points, flops ...) this launch processes, for per-launch algorithmic bytes;
+        `nbytes`: algorithmic HBM bytes of a launch whose `units` are flops (the partner of the PMC traffic figure)"""
         if name not in self.enabled:
             return fn()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -273,6 +275,8 @@ class KernelTimer:
         self.weights.setdefault(name, []).append(float(self.weight))
         if units is not None:
             self.units.setdefault(name, []).append(units)
+        if nbytes is not None:
+            self.bytes.setdefault(name, []).append(nbytes)
         return r
 
     def mean_units(self, name):
@@ -292,6 +296,7 @@ class KernelTimer:
         for k in self.events:
             self.events[k] = []
         self.units = {}
+        self.bytes = {}
         self.weights = {}
 
 

@@ -77,6 +77,12 @@ class DetectorTrainer:
         self.net = BoxLearner(cfg).to(device)
         self.net.model.set_compute_dtype(compute_dtype)
         from liso_amd.utils import mfma_conv as MC
+        if self.use_graph and (not self.fused_loss or MC.backend() != "mfma"):
+            # only the fused loss + own convolutions keep the captured region free of hipMemsetAsync nodes (graph_safety.py):
+            # torch's multi-block reductions (centerpoint_loss, ATen / MIOpen backward) put them into the graph
+            from liso_amd.utils.graph_safety import require_node_replay
+
+            require_node_replay("DetectorTrainer(use_graph=True) without the fused loss / with LISO_CONV_BACKEND=miopen")
         if compute_dtype != torch.float32 and MC.backend() != "mfma":
             # (MIOpen comparison path only: its NHWC kernels want channels-last filters.  The own kernels pack their panels from
             # the contiguous fp32 master weights: channels-last parameters would cost a layout copy per pack and strided
@@ -176,13 +182,14 @@ class DetectorTrainer:
 
     def _capture(self, pcls, targets):
         dev = self.device
+        # snapshot FIRST: the shape-probing pillar pass below runs the PFN BatchNorm in training mode and must not count as a batch
+        buffers = {k: v.clone() for k, v in self.net.state_dict().items() if v.is_floating_point() or v.dtype == torch.long}
         with torch.no_grad():
             bev, occ = self._pillars(pcls)
         self._static_bev = bev.detach().clone().requires_grad_(True)
         self._static_occ = occ.detach().clone()
         self._static_bev.grad = torch.zeros_like(self._static_bev)
         self._static_targets = {k: v.to(dev).clone() for k, v in targets.items()}
-        buffers = {k: v.clone() for k, v in self.net.state_dict().items() if v.is_floating_point() or v.dtype == torch.long}
         quiet = hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch")
         if quiet:  # the flat gradient views are created on the default stream, warm-up and capture run on a side stream
             torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
@@ -232,7 +239,9 @@ class DetectorTrainer:
             torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(True)
 
     def _graph_step(self, pcls, targets):
-        sig = (tuple(tuple(p.shape) for p in pcls), tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(targets.items())))
+        # what the graph consumes: the [B, 64, gx, gy] canvas (batch size; grid and dtype are fixed per trainer) and the target maps.
+        # The clouds themselves never enter it (the pillar encoder runs eagerly in front): their point counts are not part of the key.
+        sig = (len(pcls), tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(targets.items())))
         if self._graph is None or sig != self._graph_sig:
             self._graph = None
             self._capture(pcls, targets)

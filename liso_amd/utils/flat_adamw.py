@@ -74,8 +74,14 @@ class FlatAdamW(torch.optim.Optimizer):
     def load_state_dict(self, state_dict):
         views = {p: (st["exp_avg"], st["exp_avg_sq"]) for p, st in self.state.items()}
         super().load_state_dict(state_dict)
+        step = 0
         for p, (m, v) in views.items():  # keep the moments inside the flat buffers
             st = self.state[p]
-            m.copy_(st["exp_avg"]), v.copy_(st["exp_avg_sq"])
-            self._step = int(float(st["step"]))
+            if "exp_avg" in st and "exp_avg_sq" in st:
+                m.copy_(st["exp_avg"]), v.copy_(st["exp_avg_sq"])
+                step = max(step, int(float(st.get("step", 0))))
+            else:  # torch.optim.AdamW saved before its first step: empty per-parameter state = zero moments, step 0
+                m.zero_(), v.zero_()
             st["exp_avg"], st["exp_avg_sq"] = m, v
+            st.setdefault("step", torch.tensor(0.0))
+        self._step = step

@@ -248,6 +248,17 @@ def _flops(d):
     return 2.0 * d.batch * d.ho * d.wo * d.co * d.ci * taps
 
 
+def _bytes(d, wgrad=False):
+    """algorithmic HBM bytes of one launch: the tensor that is read + the tensor that is written once each + the weights
+    (forward / data gradient: packed bf16 panels, 2 B x planes; weight gradient: x and dy read once, fp32 dW written)"""
+    es = 2 if d.mode == L.CONV_BF16 else 4
+    w = d.w_taps * d.ci * d.co
+    if wgrad:
+        return d.batch * (d.hi * d.wi * d.ci + d.ho * d.wo * d.co) * es + 4 * w
+    out_es = 4 if (d.out_f32 or d.mode != L.CONV_BF16) else 2
+    return d.batch * (d.hi * d.wi * d.ci * es + d.ho * d.wo * d.co * out_es) + w * (2 if d.mode == L.CONV_BF16 else 4)
+
+
 def conv_forward(x, weight, bias, spec, in_scale=None, in_shift=None, in_relu=False, out_relu=False, out_dtype=None,
                  want_stats=False, stats_shift=None, packed=None, affine_batch_stride=0):
     """x: logical [B,Ci,H,W] (channels-last storage preferred) -> (y logical [B,Co,Ho,Wo] channels-last, stats_partial | None).
@@ -285,7 +296,7 @@ def conv_forward(x, weight, bias, spec, in_scale=None, in_shift=None, in_relu=Fa
             ctypes.byref(d), L.ptr(xv), L.ptr(packed), L.ptr(b) if b is not None else None,
             L.ptr(in_scale) if in_scale is not None else None, L.ptr(in_shift) if in_shift is not None else None, L.ptr(y),
             L.ptr(stats) if stats is not None else None, L.ptr(stats_shift) if stats_shift is not None else None, L.stream_ptr()),
-            units=_flops(d)), "conv_forward")
+            units=_flops(d), nbytes=_bytes(d)), "conv_forward")
     return y.permute(0, 3, 1, 2), stats
 
 
@@ -325,7 +336,7 @@ def conv_dgrad(dy, weight, spec, x_shape, out_dtype=None, packed=None):
         packed = pack_weights(weight, spec, True, mode)
     with torch.cuda.device(dy.device):
         L.check(L.TIMER.launch(_timer_name(mode, "dgrad"), lambda: L.lib().liso_conv_forward(
-            ctypes.byref(d), L.ptr(gv), L.ptr(packed), None, None, None, L.ptr(dx), None, None, L.stream_ptr()), units=_flops(d)),
+            ctypes.byref(d), L.ptr(gv), L.ptr(packed), None, None, None, L.ptr(dx), None, None, L.stream_ptr()), units=_flops(d), nbytes=_bytes(d)),
             "conv_dgrad")
     return dx.permute(0, 3, 1, 2)
 
@@ -363,7 +374,7 @@ def conv_wgrad(x, dy, weight_shape, spec, in_scale=None, in_shift=None, in_relu=
         L.check(L.TIMER.launch(_timer_name(mode, "wgrad"), lambda: lib.liso_conv_wgrad(
             ctypes.byref(d), L.ptr(xv), L.ptr(in_scale) if in_scale is not None else None,
             L.ptr(in_shift) if in_shift is not None else None, L.ptr(gv), gps, int(spec.transposed), L.ptr(dw),
-            L.ptr(db) if db is not None else None, L.ptr(ws), nbytes, L.stream_ptr()), units=_flops(d)), "conv_wgrad")
+            L.ptr(db) if db is not None else None, L.ptr(ws), nbytes, L.stream_ptr()), units=_flops(d), nbytes=_bytes(d, True)), "conv_wgrad")
     return dw, db
 
 

@@ -24,5 +24,11 @@ for k, v in sorted(table.items(), key=lambda kv: -kv[1].get("launches", 0)):
     hbm = (2 * v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0)) * 1024
     # GRBM_GUI_ACTIVE is summed over the 8 XCDs, SQ_VALU_MFMA_BUSY_CYCLES over the 1024 SIMDs (256 CUs x 4)
     busy = v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / max(v.get("GRBM_GUI_ACTIVE", 1) / 8.0 * 1024.0, 1)
-    print(f"{name:72s} x{v.get('launches', 0):5d}  HBM {hbm / 1e6:8.2f} MB/launch  MfmaUtil {busy:6.3f}  "
-          f"MOPS_BF16 {v.get('SQ_INSTS_VALU_MFMA_MOPS_BF16', 0):.3g}  LDS bank conflict cycles/LDS active {v.get('SQ_LDS_BANK_CONFLICT', 0) / max(v.get('SQ_LDS_ACTIVE', 1), 1):.3f}")
+    line = (f"{name:72s} x{v.get('launches', 0):5d}  HBM {hbm / 1e6:8.2f} MB/launch  MfmaUtil {busy:6.3f}  "
+            f"MOPS_BF16 {v.get('SQ_INSTS_VALU_MFMA_MOPS_BF16', 0):.3g}")
+    # LDS column only when BOTH counters were collected (SQ_LDS_IDX_ACTIVE = all LDS-array cycles, MI355X_MICROARCH.md LDS section;
+    # round 2 asked for a counter name this part does not have and divided by 1)
+    act = v.get("SQ_LDS_IDX_ACTIVE")
+    if act and "SQ_LDS_BANK_CONFLICT" in v:
+        line += f"  LDS conflict share {v['SQ_LDS_BANK_CONFLICT'] / act:.3f} (conflict cycles / LDS-array cycles)"
+    print(line)

@@ -16,7 +16,7 @@ P="--steps 3 --warmup 2 --no-cpu-baseline --no-iou3d"
 timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "$KRE" --output-format csv -d $OUT/pmc_FETCH_SIZE -- python3 $R/bench.py $P "$@" > /dev/null 2> $OUT/pmc_fetch.err
 timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "$KRE" --output-format csv -d $OUT/pmc_WRITE_SIZE -- python3 $R/bench.py $P "$@" > /dev/null 2> $OUT/pmc_write.err
 timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE --kernel-include-regex "$KRE" --output-format csv -d $OUT/pmc_MFMA -- python3 $R/bench.py $P "$@" > /dev/null 2> $OUT/pmc_mfma.err
-timeout 400 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS --kernel-include-regex "$KRE" --output-format csv -d $OUT/pmc_LDS -- python3 $R/bench.py $P "$@" > /dev/null 2> $OUT/pmc_lds.err
+timeout 400 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS --kernel-include-regex "$KRE" --output-format csv -d $OUT/pmc_LDS -- python3 $R/bench.py $P "$@" > /dev/null 2> $OUT/pmc_lds.err
 # keep the summaries only: per-dispatch traces are tens of MB and gpurun_out/ is capped at 64 MiB
 find $OUT -name "*_kernel_trace.csv" -delete
 find $OUT -name "*.db" -delete
