@@ -450,10 +450,17 @@ def main():
         torch.cuda.synchronize()
         timed_in = f"{event_steps} eager fwd+bwd passes after the timed region (the timed steps replay a hipGraph)"
     L.TIMER.disable_all()
+    checksums = None
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # data parallelism keeps the replicas identical: every rank's parameter checksum travels to rank 0 and into the line
+        net = trainer.detector.net if args.workload == "loop" else trainer.net
+        cs = torch.stack([p.detach().double().sum() for p in net.parameters()]).sum().reshape(1)
+        got = [torch.zeros_like(cs) for _ in range(world)]
+        dist.all_gather(got, cs)
+        checksums = [float(g.item()) for g in got]
 
     if rank == 0:
         durs = {k: L.TIMER.durations_ms(k) for k in list(L.TIMER.events) if L.TIMER.events[k]}
@@ -542,6 +549,10 @@ def main():
                 line["cpu_baseline"] = cpu_baseline_loop(cfg, trainer, s0, s1, torch)
         if args.workload == "loop":
             line["mined_boxes_last_step"] = int(trainer.last_boxes.valid.sum())
+        if checksums is not None:
+            line["replica_param_checksums"] = checksums
+            line["replicas_identical"] = all(c == checksums[0] for c in checksums)
+            line["dist_backend"] = os.environ.get("LISO_DIST_BACKEND", "nccl")
         if graph_note:
             line["config"]["launch"] = graph_note
         print(json.dumps(line), flush=True)

@@ -55,9 +55,12 @@ class SLIM(nn.Module):
         `dynamicness_threshold`: `moving_dynamicness_threshold.value()` computed by the caller (a device scan: callers that
         replay this method from a hipGraph evaluate it eagerly, liso_amd/utils/graph_safety.py)."""
         dev = next(self.raft_network.parameters()).device
-        net_out, aux = self.raft_network.infer_forward_direction(
-            get_network_input_pcls(self.cfg, sample_data_t0, "ta", to_device=dev),
-            get_network_input_pcls(self.cfg, sample_data_t1, "ta", to_device=dev), canvases=canvases)
+        if canvases is not None:  # (the caller ran the pillar encoder: the network-input clouds are not read here)
+            net_out, aux = self.raft_network.infer_forward_direction(None, None, canvases=canvases)
+        else:
+            net_out, aux = self.raft_network.infer_forward_direction(
+                get_network_input_pcls(self.cfg, sample_data_t0, "ta", to_device=dev),
+                get_network_input_pcls(self.cfg, sample_data_t1, "ta", to_device=dev))
         pa = sample_data_t0["pcl_ta"]
         pred = self.head_decoder_fw(
             net_out, self.moving_dynamicness_threshold.value() if dynamicness_threshold is None else dynamicness_threshold,

@@ -560,7 +560,15 @@ class LisoLoopTrainer:
         self.use_graph = bool(use_graph) and device.type == "cuda"
         self._graph_infer = self.use_graph and use_graph in (True, "infer")
         self._graph_det = self.use_graph and use_graph in (True, "detector")
-        self._infer_graph, self._infer_graphs = None, {}
+        import collections
+        self._infer_graph, self._infer_graphs = None, collections.OrderedDict()
+        # real sweeps differ in their point count from sample to sample: the padded loss clouds are grown to the next multiple of
+        # `infer_point_bucket` rows (NaN rows, pcl_is_valid False, pillar_coors -1: the dataset's own collate padding,
+        # torch_dataset_commons.py:380-431) so that the inference graph's input signature repeats, and at most `max_infer_graphs`
+        # captured graphs (each with its static inputs and a private memory pool) stay resident, least recently used first out
+        tcfg = cfg.data.tracking_cfg
+        self.infer_point_bucket = int(tcfg.setdefault("infer_point_bucket", 2048))
+        self.max_infer_graphs = int(tcfg.setdefault("max_infer_graphs", 6))
         self.overlap = bool(overlap) and device.type == "cuda"
         self.infer_batch, self.flow_ahead = int(infer_batch), int(flow_ahead)
         self.box_capacity, self.capacity_overflows = int(cfg.data.tracking_cfg.setdefault("flow_cluster_capacity", 64)), 0
@@ -611,12 +619,40 @@ class LisoLoopTrainer:
             return type(first)(x for s_ in samples for x in s_)
         return first
 
+    def _pad_loss_cloud(self, sample):
+        """`pcl_ta` with its point axis grown to the next multiple of `infer_point_bucket` (collate-style padding rows)"""
+        pa = sample["pcl_ta"]
+        n, bk = pa["pcl"].shape[1], self.infer_point_bucket
+        pad = (-n) % bk if bk > 1 else 0
+        if pad == 0:
+            return sample
+        F = torch.nn.functional
+        out = dict(sample)
+        out["pcl_ta"] = {**pa, "pcl": F.pad(pa["pcl"], (0, 0, 0, pad), value=float("nan")),
+                         "pcl_is_valid": F.pad(pa["pcl_is_valid"], (0, pad), value=False),
+                         "pillar_coors": F.pad(pa["pillar_coors"], (0, 0, 0, pad), value=-1)}
+        return out
+
     def _infer_flow(self, sample_t0, sample_t1):
-        """frozen SLIM inference of one sample pair (any batch size): eager pillar encoder + one hipGraph replay per input signature"""
+        """frozen SLIM inference of one sample pair (any batch size): eager pillar encoder + one hipGraph replay per input signature.
+        Eager and replayed calls see the same (bucket-padded) clouds: their results are bit-identical."""
+        n_true = sample_t0["pcl_ta"]["pcl"].shape[1]
+        sample_t0, sample_t1 = self._pad_loss_cloud(sample_t0), self._pad_loss_cloud(sample_t1)
+        flow = self._infer_flow_padded(sample_t0, sample_t1)
+        return flow if flow.shape[1] == n_true else flow[:, :n_true].contiguous()
+
+    @staticmethod
+    def _graph_inputs(sample_t0, sample_t1):
+        """what the captured inference reads from the samples (the network-input clouds go through the eager pillar encoder)"""
+        return ({"pcl_ta": sample_t0["pcl_ta"], "gt": {"odom_ta_tb": sample_t0["gt"]["odom_ta_tb"]}},
+                {"pcl_ta": sample_t1["pcl_ta"], "gt": {"odom_ta_tb": sample_t1["gt"]["odom_ta_tb"]}})
+
+    def _infer_flow_padded(self, sample_t0, sample_t1):
         if not self._graph_infer:
             return self.slim.infer_point_flow_t0_t1(sample_t0, sample_t1)
         shapes = []
-        SlimTrainer._map_tensors((sample_t0, sample_t1), lambda t: shapes.append((tuple(t.shape), t.dtype)) or t)
+        # the key holds only what the graph consumes: the padded loss clouds + odometry (the raw clouds' lengths do not enter)
+        SlimTrainer._map_tensors(self._graph_inputs(sample_t0, sample_t1), lambda t: shapes.append((tuple(t.shape), t.dtype)) or t)
         sig = tuple(shapes)
         dev = self.device
         from liso_amd.slim.model.slim import get_network_input_pcls
@@ -631,9 +667,16 @@ class LisoLoopTrainer:
                 raft.encode_pillars(*pcls, out=st["rows"])
         with torch.no_grad():  # a device scan (torch.cumsum): eagerly, its memset nodes do not survive in a graph (graph_safety.py)
             thr = self.slim.moving_dynamicness_threshold.value()
+        if st is not None:
+            self._infer_graphs.move_to_end(sig)
         if st is None:
+            while len(self._infer_graphs) >= max(self.max_infer_graphs, 1):  # least recently used graph + its buffers go
+                _, old = self._infer_graphs.popitem(last=False)
+                if self._infer_graph is old.get("graph"):
+                    self._infer_graph = None
+                old.clear()
             st = self._infer_graphs[sig] = {}
-            st["in"] = SlimTrainer._map_tensors((sample_t0, sample_t1), lambda t: t.to(dev).clone())
+            st["in"] = SlimTrainer._map_tensors(self._graph_inputs(sample_t0, sample_t1), lambda t: t.to(dev).clone())
             B_ = canv[0].shape[0]
             rows = torch.cat([canv[0], canv[2]], dim=0).permute(0, 2, 3, 1).contiguous()  # [2B, gx, gy, 64]
             occ = torch.cat([canv[1], canv[3]], dim=0).contiguous()
@@ -652,7 +695,7 @@ class LisoLoopTrainer:
                 st["flow"] = self.slim.infer_point_flow_t0_t1(s0, s1, canvases=st["canv"], dynamicness_threshold=st["thr"])
             self._infer_graph = st["graph"]  # (the most recently captured one: scripts / bench introspection)
         else:
-            SlimTrainer._copy_tensors(st["in"], (sample_t0, sample_t1))
+            SlimTrainer._copy_tensors(st["in"], self._graph_inputs(sample_t0, sample_t1))
             st["thr"].copy_(thr, non_blocking=True)
         st["graph"].replay()
         return st["flow"]

@@ -95,3 +95,30 @@ def test_two_ranks_liso_loop_keeps_detector_replicas_identical(tmp_path, use_gra
     assert all(bool(torch.isfinite(l).all()) for l in r["losses"])
     assert not torch.equal(r["losses"][0], r["losses"][1])  # the ranks saw different sweeps
     assert torch.equal(r["params"][0], r["params"][1])      # ... and took the same (averaged) steps
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("workload", ["loop", "detector"])
+def test_bench_two_ranks_on_one_gpu_reports_world_and_identical_replicas(workload):
+    """`python bench.py --gpus 2` through its own rank spawner, both ranks on cuda:0, gloo carrying the collectives
+    (LISO_DIST_BACKEND=gloo: RCCL refuses two ranks on one device; the default backend "nccl" = RCCL is what the driver's
+    multi-GPU runs use).  Exercises the world > 1 code of bench.py: barrier-bracketed timing, MAX over ranks, the flat-buffer
+    gradient all-reduce after every replay, rank-0-only line.  The line must report n_gpus 2 and replicas that agree."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LISO_DIST_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--workload", workload,
+                        "--no-cpu-baseline", "--no-iou3d"], env=env, capture_output=True, text=True, timeout=850)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]  # rank 0 only
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and line["scaling"] == "weak"
+    assert line["dist_backend"] == "gloo" and len(line["replica_param_checksums"]) == 2
+    assert line["replicas_identical"] is True
+    assert line["value"] > 0 and line["final_loss"] == line["final_loss"]
