@@ -84,6 +84,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=None, help="detector workload: clouds per GPU (default 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-iou3d", action="store_true", help="skip the iou3d_nms section of the line")
+    ap.add_argument("--no-fp32-leg", action="store_true",
+                    help="loop workload, default dtype: skip the short exact-fp32 leg (`fp32_exact_leg` of the line)")
     ap.add_argument("--graph", action="store_true",
                     help="slim workload: replay forward+loss+backward from a hipGraph (host-independent step time)")
     ap.add_argument("--eager", action="store_true",
@@ -138,6 +140,9 @@ KERNELS = {  # timer name -> (kernel description, bound, unit of `units`)
     "conv_f32x3_fwd": ("conv_igemm_kernel<bf16x3> forward (fp32 tensors, hi/lo bf16 split, 3 MFMAs per product)", "mfma", "flop"),
     "conv_f32x3_dgrad": ("conv_igemm_kernel<bf16x3> data gradient", "mfma", "flop"),
     "conv_f32x3_wgrad": ("conv_wgrad_kernel<bf16x3> weight gradient", "mfma", "flop"),
+    "conv_f32_fwd": ("conv_igemm_kernel<f32> forward (exact fp32 on v_mfma_f32_32x32x2_f32)", "mfma", "flop"),
+    "conv_f32_dgrad": ("conv_igemm_kernel<f32> data gradient (exact fp32)", "mfma", "flop"),
+    "conv_f32_wgrad": ("conv_wgrad_kernel<f32> weight gradient (exact fp32)", "mfma", "flop"),
     "pfn_forward_scatter": ("pfn_forward_kernel (Linear+BN+ReLU+max + dense scatter from CSR feature rows)", "hbm", "bytes"),
     "pfn_decorate": ("pfn_decorate_kernel (+3 scan kernels)", "hbm", "bytes"),
     "corr_lookup_fwd": ("corr_lookup_fwd_kernel (on-the-fly 4-level correlation + bilinear lookup)", "hbm", "bytes"),
@@ -201,6 +206,7 @@ def pmc_traffic(workload, patterns):
 # (template argument 1 of the convolution kernels = arithmetic: 0 bf16, 1 f32x3; forward and data gradient share the kernel)
 PMC_PATTERNS = {"conv_bf16_fwd": ["conv_igemm_kernel<0,"], "conv_bf16_dgrad": ["conv_igemm_kernel<0,"], "conv_bf16_wgrad": ["conv_wgrad_kernel<0,"],
                 "conv_f32x3_fwd": ["conv_igemm_kernel<1,"], "conv_f32x3_dgrad": ["conv_igemm_kernel<1,"], "conv_f32x3_wgrad": ["conv_wgrad_kernel<1,"],
+                "conv_f32_fwd": ["conv_igemm_kernel<2,"], "conv_f32_dgrad": ["conv_igemm_kernel<2,"], "conv_f32_wgrad": ["conv_wgrad_kernel<2,"],
                 "knn_query": ["knn_query_kernel"], "corr_lookup_fwd": ["corr_lookup_fwd_kernel"],
                 "pfn_forward_scatter": ["pfn_forward_kernel"],
                 "dbscan_components": ["dbscan_core_kernel", "dbscan_union_kernel", "dbscan_flatten_kernel"]}
@@ -372,8 +378,10 @@ def main():
         dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
         cfg = apply_slim_simple_knn_training(cfg)
         overlap = not (args.eager or args.no_overlap)
+        # --dtype fp32 = the true-fp32 parity configuration: every convolution (SLIM and detector) on the native fp32 MFMA
         trainer = LisoLoopTrainer(cfg, dev, compute_dtype=dtype, total_steps=args.steps + args.warmup + 8, use_graph=not args.eager,
-                                  overlap=overlap, infer_batch=max(1, args.lookahead - 1 - args.flow_ahead), flow_ahead=args.flow_ahead)
+                                  overlap=overlap, infer_batch=max(1, args.lookahead - 1 - args.flow_ahead), flow_ahead=args.flow_ahead,
+                                  exact=(args.dtype == "fp32"))
         # a ring of different sweep pairs; step i trains on pair i while (overlap) pairs i+1 / i+2 are in the mining stages
         pairs = [slim_pair(2 + rank + 100 * i, dev, n_points=N_POINTS, grid=GRID, bev_range_m=BEV_RANGE) for i in range(max(5, args.lookahead + 2))]
         s0, s1 = pairs[0]
@@ -391,7 +399,8 @@ def main():
 
         batch = args.batch or BATCH_PER_GPU
         dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-        trainer = DetectorTrainer(cfg, dev, compute_dtype=dtype, total_steps=args.steps + args.warmup + 8, use_graph=not args.eager)
+        trainer = DetectorTrainer(cfg, dev, compute_dtype=dtype, total_steps=args.steps + args.warmup + 8, use_graph=not args.eager,
+                                  exact=(args.dtype == "fp32"))
         pcls, targets = detector_batch(seed=1 + rank, batch=batch, device=dev, n_points=N_POINTS, grid=GRID,
                                        bev_range_m=BEV_RANGE)
         step = lambda: trainer.step(pcls, targets)  # noqa: E731
@@ -450,6 +459,37 @@ def main():
         torch.cuda.synchronize()
         timed_in = f"{event_steps} eager fwd+bwd passes after the timed region (the timed steps replay a hipGraph)"
     L.TIMER.disable_all()
+    fp32_leg = None
+    if args.workload == "loop" and args.dtype == "bf16" and world == 1 and not args.no_fp32_leg and not args.miopen_convs:
+        # the same iteration in the true-fp32 parity configuration (native fp32 MFMA for SLIM and detector), a bounded leg
+        from liso_amd.utils import mfma_conv as MC
+
+        prev_mode = MC.fp32_mode()
+        t32 = LisoLoopTrainer(cfg, dev, compute_dtype=torch.float32, total_steps=64, use_graph=not args.eager, overlap=overlap,
+                              infer_batch=max(1, args.lookahead - 1 - args.flow_ahead), flow_ahead=args.flow_ahead, exact=True)
+        t32.detector.net.load_state_dict(trainer.detector.net.state_dict())
+        t32.slim.load_state_dict(trainer.slim.state_dict())
+        c32 = [0]
+
+        def step32():
+            i = c32[0]
+            c32[0] += 1
+            return t32.step(*pairs[i % len(pairs)], upcoming=tuple(pairs[(i + k) % len(pairs)] for k in range(1, args.lookahead + 1)))
+
+        n32 = min(args.steps, 10)
+        for _ in range(4):
+            step32()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n32):
+            l32 = step32()
+        torch.cuda.synchronize()
+        e32 = time.perf_counter() - t0
+        fp32_leg = {"dtype": "f32 (exact: native fp32 MFMA v_mfma_f32_32x32x2_f32, SLIM and detector)", "steps": n32, "warmup": 4,
+                    "ms_per_step": 1e3 * e32 / n32, "value": 2 * n32 / e32, "unit": "frames/s", "final_loss": float(l32),
+                    "note": "same launch structure and inputs as the headline line; `python bench.py --dtype fp32` gives the full line"}
+        del t32
+        MC.set_fp32_mode(prev_mode)
     checksums = None
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -485,7 +525,8 @@ def main():
             t_total += totals["pfn_decorate"] * 1e-3
         if bound == "mfma":
             achieved = alg_total / t_total / 1e12 if t_total > 0 else 0.0
-            peak, runit = (MFMA_PEAK_BF16_TF / 3.0 if "f32x3" in key else MFMA_PEAK_BF16_TF), "TFLOP/s"
+            peak = MFMA_PEAK_BF16_TF / 3.0 if "f32x3" in key else VALU_PEAK_F32_TF if key.startswith("conv_f32_") else MFMA_PEAK_BF16_TF
+            runit = "TFLOP/s"
         else:
             achieved = alg_total / t_total / 1e9 if t_total > 0 else 0.0
             peak, runit = HBM_PEAK_GBS, "GB/s"
@@ -510,7 +551,9 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "bf16 (detector) + f32 via bf16x3 MFMA (SLIM)" if args.workload == "loop" and args.dtype == "bf16" else args.dtype,
+            "dtype": ("bf16 (detector) + f32 via bf16x3 MFMA (SLIM)" if args.workload == "loop" and args.dtype == "bf16" else
+                      "f32 (exact: native fp32 MFMA v_mfma_f32_32x32x2_f32)" if args.dtype == "fp32" and args.workload != "slim" else
+                      "f32 via bf16x3 MFMA" if args.workload == "slim" else args.dtype),
             "data": "synthetic",
             "config": {"workload": workload, "points_per_cloud": N_POINTS, "bev_grid": GRID, "batch_per_gpu": batch,
                        "frames_per_step_per_gpu": frames_per_step, "parallelism": f"dp{world}",
@@ -549,6 +592,8 @@ def main():
                 line["cpu_baseline"] = cpu_baseline_loop(cfg, trainer, s0, s1, torch)
         if args.workload == "loop":
             line["mined_boxes_last_step"] = int(trainer.last_boxes.valid.sum())
+        if fp32_leg is not None:
+            line["fp32_exact_leg"] = fp32_leg
         if checksums is not None:
             line["replica_param_checksums"] = checksums
             line["replicas_identical"] = all(c == checksums[0] for c in checksums)

@@ -22,12 +22,16 @@
  *             product is evaluated as hi*hi + hi*lo + lo*hi (three MFMAs, fp32 accumulation): relative error per product
  *             <= 2^-16 (fp32: 2^-24; TF32, cuDNN's default for fp32 convolutions on Ampere: 2^-11) at 3/16 of the cost
  *             of the native fp32 MFMA.
+ *             `mode` LISO_CONV_F32 -- fp32 tensors, EXACT fp32 arithmetic on v_mfma_f32_32x32x2_f32 (fp32 operands, fp32
+ *             accumulation: bit for bit a k-ordered fmaf chain, 2^-24 per product like the reference's fp32 path; 157 TFLOP/s
+ *             peak): the parity configuration the gradient tests against the reference fixtures run in.
  * Fusions (all optional): prologue x' = relu?(x * in_scale[c] + in_shift[c]) applied while the input tile is staged
  * (the BatchNorm-apply + ReLU of the producing layer: normalised activations never touch HBM; padding stays exactly 0);
  * epilogue: + bias[c], ReLU, per-channel partial sums of the stored values for the BatchNorm statistics of THIS layer.
  *
  * Packed weights (liso_conv_pack_weights): [plane][tap][ci_pad / 8][co_pad][8] bf16, plane 0 = hi (or the bf16 value),
  * plane 1 = lo (F32X3 only); ci_pad = round_up(ci, 16), co_pad = round_up(co, 64); padding is zero.
+ * LISO_CONV_F32: [tap][ci_pad / 4][co_pad][4] fp32 (unrounded), the same number of bytes as the two F32X3 planes.
  *
  * All pointers are device pointers; nothing allocates or synchronises; every call enqueues on `stream` and returns
  * LISO_OK or a negative LISO_E* code (include/liso_iou3d.h).  Graph-capturable.
@@ -46,6 +50,7 @@ extern "C" {
 #define LISO_CONV_MAX_CLASSES 4
 #define LISO_CONV_BF16 0
 #define LISO_CONV_F32X3 1
+#define LISO_CONV_F32 2
 
 typedef struct {
     int batch, hi, wi, ci;      /* input  [batch, hi, wi, ci] */
@@ -61,7 +66,7 @@ typedef struct {
     int tap_dy[LISO_CONV_MAX_TAPS], tap_dx[LISO_CONV_MAX_TAPS]; /* input offset of the tap */
     int tap_w[LISO_CONV_MAX_TAPS];                              /* tap index inside the packed weights */
     int w_taps;                 /* taps in the packed weights (kh * kw) */
-    int mode;                   /* LISO_CONV_BF16 | LISO_CONV_F32X3 */
+    int mode;                   /* LISO_CONV_BF16 | LISO_CONV_F32X3 | LISO_CONV_F32 */
     int out_f32;                /* BF16 mode: 1 = fp32 output, 0 = bf16 output (F32X3: always fp32) */
     int in_relu, out_relu;
     int in_affine_batch_stride; /* 0: in_scale / in_shift are [ci], shared by all samples (BatchNorm);
@@ -75,7 +80,8 @@ typedef struct {
  *   transposed == 0: src[d0][d1][kh][kw] = weight of nn.Conv2d  (d0 = out channels, d1 = in channels)
  *   transposed == 1: the same memory read as nn.ConvTranspose2d (d0 = in channels, d1 = out channels)
  *   for_dgrad  != 0: pack for the data-gradient launch (the roles of in / out channels are exchanged)
- * dst: bf16 [planes][kh*kw][K_pad/8][N_pad][8], planes = 1 (BF16) or 2 (F32X3); bytes = liso_conv_packed_bytes(). */
+ * dst: bf16 [planes][kh*kw][K_pad/8][N_pad][8], planes = 1 (BF16) or 2 (F32X3), or fp32 [kh*kw][K_pad/4][N_pad][4] (F32);
+ * bytes = liso_conv_packed_bytes(). */
 size_t liso_conv_packed_bytes(int k_channels, int n_channels, int taps, int mode);
 int liso_conv_pack_weights(const float* src, int d0, int d1, int kh, int kw, int transposed, int for_dgrad, int mode,
                            void* dst, void* stream);

@@ -157,7 +157,7 @@ SIGNATURES = {
 }
 
 
-CONV_MAX_TAPS, CONV_MAX_CLASSES, CONV_BF16, CONV_F32X3 = 49, 4, 0, 1
+CONV_MAX_TAPS, CONV_MAX_CLASSES, CONV_BF16, CONV_F32X3, CONV_F32 = 49, 4, 0, 1, 2
 
 
 class ConvDesc(ctypes.Structure):

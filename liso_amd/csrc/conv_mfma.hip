@@ -81,10 +81,13 @@ __global__ __launch_bounds__(kThreads * SK, SK == 1 ? 2 : 1) void conv_igemm_ker
     constexpr int BNT = 32 * NJ;
     constexpr int TH = 4 * MI;
     constexpr bool X3 = MODE == LISO_CONV_F32X3;
+    constexpr bool F32 = MODE == LISO_CONV_F32;  // exact fp32: v_mfma_f32_32x32x2_f32 on fp32 tiles / panels (one plane)
+    constexpr bool FIN = X3 || F32;              // fp32 tensors in HBM
     constexpr int PLANES = X3 ? 2 : 1;
-    constexpr int PS = CS * 2 + 16;            // LDS bytes per pixel and plane
-    constexpr int KS = CS / 16;                // k-steps per tap
-    constexpr int K8 = CS / 8;                 // 8-channel groups per slab
+    constexpr int PS = (F32 ? CS * 4 : CS * 2) + 16;  // LDS bytes per pixel and plane
+    constexpr int KS = F32 ? CS / 8 : CS / 16;  // fragment reads per tap: one ds_read_b128 = 8 bf16 | 4 fp32 per lane, both lane halves
+    constexpr int KG = F32 ? 4 : 8;             // channels per 16-B group of a weight panel
+    constexpr int K8 = CS / KG;                 // 16-B channel groups per slab
     constexpr int PSZ = K8 * BNT;              // 16-B chunks of one weight panel (one tap, one plane)
     constexpr int WTAP = PSZ * 16;             // bytes of one panel
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -139,20 +142,20 @@ __global__ __launch_bounds__(kThreads * SK, SK == 1 ? 2 : 1) void conv_igemm_ker
             for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
 
     const int n_taps = te - tb;
-    const int kgroups_total = a.ci_pad >> 3;
+    const int kgroups_total = a.ci_pad / KG;
     const long x_img = (long)b * d.hi * d.wi;
     const unsigned short* wg = (const unsigned short*)a.w;
     const long plane_elems = (long)d.w_taps * kgroups_total * a.co_pad * 8;
 
     // ---- staging pieces: global -> registers (load_*) and registers -> LDS (store_*), so that the loads of slab k+1 can be
     // in flight while the MFMAs of slab k run ---------------------------------------------------------------------------------
-    constexpr int CPP = X3 ? CS / 4 : K8;  // 16-B chunks per pixel on the global side (4 fp32 | 8 bf16)
-    constexpr int CHN = X3 ? 4 : 8;        // channels per chunk
+    constexpr int CPP = FIN ? CS / 4 : CS / 8;  // 16-B chunks per pixel on the global side (4 fp32 | 8 bf16)
+    constexpr int CHN = FIN ? 4 : 8;            // channels per chunk
     constexpr int pstep = kThreads / CPP;
     constexpr int XB = 12, WB = 10;        // 16-B loads per thread and batch
     const int cx = tid % CPP, p0 = tid / CPP;
     const int step_y = pstep / in_w, step_x = pstep - step_y * in_w;  // (uniform)
-    const unsigned char* xbase = (const unsigned char*)a.x + x_img * d.x_pix_stride * (X3 ? 4 : 2);
+    const unsigned char* xbase = (const unsigned char*)a.x + x_img * d.x_pix_stride * (FIN ? 4 : 2);
     const bool pro = a.in_scale != nullptr;
     const int aff_off = b * d.in_affine_batch_stride;  // per-sample prologue vectors (InstanceNorm) or 0
 
@@ -170,7 +173,7 @@ __global__ __launch_bounds__(kThreads * SK, SK == 1 ? 2 : 1) void conv_igemm_ker
             const bool ok = pix < npix && ch_ok && (unsigned)iy < (unsigned)d.hi && (unsigned)ix < (unsigned)d.wi;
             okmask |= ok ? (1u << u) : 0u;
             const int off = ok ? (iy * d.wi + ix) * d.x_pix_stride + ch : 0;  // (a sample has < 2^31 elements)
-            v[u] = *reinterpret_cast<const uint4*>(xbase + (long)off * (X3 ? 4 : 2));
+            v[u] = *reinterpret_cast<const uint4*>(xbase + (long)off * (FIN ? 4 : 2));
             lx += step_x;
             ly += step_y;
             if (lx >= in_w) {
@@ -195,7 +198,7 @@ __global__ __launch_bounds__(kThreads * SK, SK == 1 ? 2 : 1) void conv_igemm_ker
             const int pix = pix_begin + p0 + u * pstep;
             if (pix >= npix) continue;
             const bool ok = (okmask >> u) & 1u;
-            if constexpr (!X3) {
+            if constexpr (!FIN) {
                 uint4 o = v[u];
                 if (pro) {
                     unsigned w[4] = {o.x, o.y, o.z, o.w};
@@ -224,14 +227,18 @@ __global__ __launch_bounds__(kThreads * SK, SK == 1 ? 2 : 1) void conv_igemm_ker
                     }
                     if (!ok) f[e] = 0.0f;
                 }
+                if constexpr (F32) {
+                    *reinterpret_cast<float4*>(xs + pix * PS + cx * 16) = make_float4(f[0], f[1], f[2], f[3]);
+                } else {
 #pragma unroll
-                for (int e = 0; e < 2; e++) {
-                    const float h0 = round_bf16(f[2 * e]), h1 = round_bf16(f[2 * e + 1]);
-                    hi2[e] = pack_bf16(h0, h1);
-                    lo2[e] = pack_bf16(f[2 * e] - h0, f[2 * e + 1] - h1);
+                    for (int e = 0; e < 2; e++) {
+                        const float h0 = round_bf16(f[2 * e]), h1 = round_bf16(f[2 * e + 1]);
+                        hi2[e] = pack_bf16(h0, h1);
+                        lo2[e] = pack_bf16(f[2 * e] - h0, f[2 * e + 1] - h1);
+                    }
+                    *reinterpret_cast<uint2*>(xs + pix * PS + cx * 8) = make_uint2(hi2[0], hi2[1]);
+                    *reinterpret_cast<uint2*>(xs + a.x_plane_bytes + pix * PS + cx * 8) = make_uint2(lo2[0], lo2[1]);
                 }
-                *reinterpret_cast<uint2*>(xs + pix * PS + cx * 8) = make_uint2(hi2[0], hi2[1]);
-                *reinterpret_cast<uint2*>(xs + a.x_plane_bytes + pix * PS + cx * 8) = make_uint2(lo2[0], lo2[1]);
             }
         }
     };
@@ -242,7 +249,7 @@ __global__ __launch_bounds__(kThreads * SK, SK == 1 ? 2 : 1) void conv_igemm_ker
             const int panel = q / PSZ, inner = q % PSZ;  // (compile-time powers of two)
             const int g = panel / PLANES, plane = panel % PLANES;
             const int c8 = inner / BNT, n = inner % BNT;
-            const int kg = (c0 >> 3) + c8;
+            const int kg = c0 / KG + c8;
             const bool okq = q < chunks && kg < kgroups_total;
             const int tw = s_tapw[s0 + (okq ? g : 0)];
             const int off = okq ? (plane * (int)plane_elems + ((tw * kgroups_total + kg) * a.co_pad + n0 + n) * 8) : 0;
@@ -269,7 +276,22 @@ __global__ __launch_bounds__(kThreads * SK, SK == 1 ? 2 : 1) void conv_igemm_ker
 #pragma unroll
                 for (int j = 0; j < NJ; j++) bfr[kk][j] = *reinterpret_cast<const uint4*>(wt + b_off[j] + kk * (2 * BNT * 16));
             }
-            if constexpr (X3) {
+            if constexpr (F32) {
+                // lane (r, h) holds channels kk*8 + 4h + e of its pixel / output channel: MFMA e pairs channel kk*8 + e (k = 0) with
+                // kk*8 + 4 + e (k = 1) on BOTH operands.  Exact fp32 products, one rounding per accumulation step.
+#pragma unroll
+                for (int kk = 0; kk < KS; kk++)
+#pragma unroll
+                    for (int i = 0; i < MI; i++)
+#pragma unroll
+                        for (int j = 0; j < NJ; j++) {
+                            const uint4 av = af[kk][i], bv = bfr[kk][j];
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(av.x), __uint_as_float(bv.x), acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(av.y), __uint_as_float(bv.y), acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(av.z), __uint_as_float(bv.z), acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(av.w), __uint_as_float(bv.w), acc[i][j], 0, 0, 0);
+                        }
+            } else if constexpr (X3) {
                 uint4 al[KS][MI], bl[KS][NJ];
 #pragma unroll
                 for (int kk = 0; kk < KS; kk++) {
@@ -501,14 +523,19 @@ __global__ __launch_bounds__(kThreads * SK, SK == 1 ? 2 : 1) void conv_igemm_ker
 
 // ---- weight packing ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void pack_chunk(const float* __restrict__ src, int d1, int taps, int swap_ab, int K, int N, int Kp, int Np,
-                                           unsigned short* __restrict__ dst, long q);
+                                           int f32, unsigned short* __restrict__ dst, long q);
+
+// 16-B chunks of the packed weights: bf16 planes x taps x Kp/8 x Np; exact fp32 (one plane of 4-float groups): taps x Kp/4 x Np
+__host__ __device__ inline long pack_chunks(int planes, int taps, int Kp, int Np, int f32) {
+    return f32 ? (long)taps * (Kp / 4) * Np : (long)planes * taps * (Kp / 8) * Np;
+}
 
 __global__ void pack_weights_kernel(const float* __restrict__ src, int d0, int d1, int taps, int swap_ab, int K, int N, int Kp,
-                                    int Np, int planes, unsigned short* __restrict__ dst) {
-    const long total = (long)planes * taps * (Kp / 8) * Np;  // one thread per 16-B chunk
+                                    int Np, int planes, int f32, unsigned short* __restrict__ dst) {
+    const long total = pack_chunks(planes, taps, Kp, Np, f32);  // one thread per 16-B chunk
     const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= total) return;
-    pack_chunk(src, d1, taps, swap_ab, K, N, Kp, Np, dst, q);
+    pack_chunk(src, d1, taps, swap_ab, K, N, Kp, Np, f32, dst, q);
 }
 
 // several weight tensors in one launch (a training step packs every layer twice: forward and data-gradient panels)
@@ -516,7 +543,7 @@ constexpr int kPackJobs = 48;
 struct PackJob {
     const float* src;
     unsigned short* dst;
-    int d1, taps, swap_ab, K, N, Kp, Np;
+    int d1, taps, swap_ab, K, N, Kp, Np, f32;
 };
 struct PackTable {
     PackJob job[kPackJobs];
@@ -530,13 +557,29 @@ __global__ void pack_weights_batched_kernel(const PackTable t) {
     int j = 0;
     while (q >= t.end[j]) j++;
     const PackJob& b = t.job[j];
-    pack_chunk(b.src, b.d1, b.taps, b.swap_ab, b.K, b.N, b.Kp, b.Np, b.dst, q - (j ? t.end[j - 1] : 0));
+    pack_chunk(b.src, b.d1, b.taps, b.swap_ab, b.K, b.N, b.Kp, b.Np, b.f32, b.dst, q - (j ? t.end[j - 1] : 0));
 }
 
 __device__ __forceinline__ void pack_chunk(const float* __restrict__ src, int d1, int taps, int swap_ab, int K, int N, int Kp, int Np,
-                                           unsigned short* __restrict__ dst, long q) {
+                                           int f32, unsigned short* __restrict__ dst, long q) {
     const int n = (int)(q % Np);
     long t = q / Np;
+    if (f32) {  // [tap][Kp / 4][Np][4] fp32, unrounded
+        const int k4 = (int)(t % (Kp / 4));
+        const int tap = (int)(t / (Kp / 4));
+        float f[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int k = k4 * 4 + e;
+            f[e] = 0.0f;
+            if (k < K && n < N) {
+                const int ia = swap_ab ? k : n, ib = swap_ab ? n : k;
+                f[e] = src[((long)ia * d1 + ib) * taps + tap];
+            }
+        }
+        *reinterpret_cast<float4*>(dst + q * 8) = make_float4(f[0], f[1], f[2], f[3]);
+        return;
+    }
     const int k8 = (int)(t % (Kp / 8));
     t /= (Kp / 8);
     const int tap = (int)(t % taps);
@@ -644,10 +687,13 @@ bool make_plan(const liso_conv_desc& d, Plan* p) {
     if (d.batch <= 0 || d.ci <= 0 || d.co <= 0 || d.n_classes < 1 || d.n_classes > LISO_CONV_MAX_CLASSES) return false;
     if (d.n_taps < 1 || d.n_taps > LISO_CONV_MAX_TAPS || d.class_tap_begin[0] != 0 || d.class_tap_begin[d.n_classes] != d.n_taps)
         return false;
-    const bool x3 = d.mode == LISO_CONV_F32X3;
-    const int vec = x3 ? 4 : 8;
+    if (d.mode != LISO_CONV_BF16 && d.mode != LISO_CONV_F32X3 && d.mode != LISO_CONV_F32) return false;
+    const bool x3 = d.mode == LISO_CONV_F32X3, f32 = d.mode == LISO_CONV_F32, fin = x3 || f32;
+    const int vec = fin ? 4 : 8;
     if (d.ci % vec || d.x_pix_stride % vec || d.x_pix_stride < d.ci) return false;
     const int planes = x3 ? 2 : 1;
+    auto pix_bytes = [&](int cs) { return (f32 ? cs * 4 : cs * 2) + 16; };                       // LDS bytes per tile pixel and plane
+    auto panel_bytes = [&](int cs, int bnt) { return f32 ? (cs / 4) * bnt * 16 : planes * (cs / 8) * bnt * 16; };  // one tap
     FwdArgs& a = p->a;
     a.ci_pad = round_up(d.ci, 16);
     a.co_pad = round_up(d.co, 64);
@@ -696,7 +742,7 @@ bool make_plan(const liso_conv_desc& d, Plan* p) {
     // among those that leave room for 2 blocks per CU (79 KB); one block per CU (158 KB) only if nothing else fits.
     // 8-row tiles only when they still give every CU 2 blocks.
     const int mi_first = blocks(8) >= 512 ? 2 : 1;
-    const int cs_opts[2] = {x3 ? 32 : 64, x3 ? 16 : 32};
+    const int cs_opts[2] = {fin ? 32 : 64, fin ? 16 : 32};
     long best = -1;
     bool few_blocks = blocks(4 * mi_first) <= 256;  // at most one block per CU anyway: spend its whole LDS
     if (const char* e = getenv("LISO_CONV_FEW")) few_blocks = few_blocks && atoi(e) != 0;  // experiments
@@ -708,8 +754,8 @@ bool make_plan(const liso_conv_desc& d, Plan* p) {
             for (int k = 0; k < 2; k++) {
                 const int cs = cs_opts[k];
                 if (k == 0 && cs_opts[1] >= a.ci_pad) continue;  // do not stage channels that do not exist
-                const int xb = round_up(max_pix * (cs * 2 + 16), 16);
-                const int panel = planes * (cs / 8) * bnt * 16;
+                const int xb = round_up(max_pix * pix_bytes(cs), 16);
+                const int panel = panel_bytes(cs, bnt);
                 int g = (cap - 512 - xb * planes) / panel;
                 if (g < 1) continue;
                 g = g > max_taps ? max_taps : g;
@@ -740,9 +786,9 @@ bool make_plan(const liso_conv_desc& d, Plan* p) {
     {
         int max_pix = 0;
         for (int c = 0; c < d.n_classes; c++) max_pix = a.cls_inh[c] * a.cls_inw[c] > max_pix ? a.cls_inh[c] * a.cls_inw[c] : max_pix;
-        const int cpp = x3 ? p->cs / 4 : p->cs / 8;
+        const int cpp = fin ? p->cs / 4 : p->cs / 8;
         const int x_chunks = (max_pix * cpp + kThreads - 1) / kThreads;          // per thread
-        const int w_chunks = (max_taps * planes * (p->cs / 8) * bnt + kThreads - 1) / kThreads;
+        const int w_chunks = (max_taps * (panel_bytes(p->cs, bnt) / 16) + kThreads - 1) / kThreads;
         a.pipelined = (p->g >= max_taps && x_chunks <= 12 && w_chunks <= 10) ? 1 : 0;
         if (const char* e = getenv("LISO_CONV_PIPE")) a.pipelined = a.pipelined && atoi(e) != 0;  // experiments
     }
@@ -752,7 +798,7 @@ bool make_plan(const liso_conv_desc& d, Plan* p) {
     // split-K inside the block (two groups of 4 waves on alternate slabs): F32X3, one wave tile per wave, at most one block per CU
     // anyway, at least two slabs, and both groups' buffers + the accumulator hand-over fit the CU's LDS
     p->sk = 1;
-    a.group_bytes = round_up(a.x_plane_bytes * planes + max_taps * planes * (p->cs / 8) * bnt * 16, 16);
+    a.group_bytes = round_up(a.x_plane_bytes * planes + max_taps * panel_bytes(p->cs, bnt), 16);
     if (x3 && a.pipelined && p->mi == 1 && p->nj == 1 && a.total <= 256 && d.ci > p->cs && 512 + 2 * a.group_bytes <= 160 * 1024 &&
         a.group_bytes >= 16 * kThreads * 4)
         p->sk = 2;
@@ -780,7 +826,7 @@ extern "C" {
 
 size_t liso_conv_packed_bytes(int k_channels, int n_channels, int taps, int mode) {
     if (k_channels <= 0 || n_channels <= 0 || taps <= 0) return 0;
-    const size_t planes = mode == LISO_CONV_F32X3 ? 2 : 1;
+    const size_t planes = mode == LISO_CONV_BF16 ? 1 : 2;  // (exact fp32: 4 B per element = the bytes of two bf16 planes)
     return planes * (size_t)taps * round_up(k_channels, 16) * round_up(n_channels, 64) * 2;
 }
 
@@ -790,9 +836,10 @@ int liso_conv_pack_weights(const float* src, int d0, int d1, int kh, int kw, int
     const bool same = (transposed != 0) == (for_dgrad != 0);
     const int K = same ? d1 : d0, N = same ? d0 : d1;
     const int Kp = round_up(K, 16), Np = round_up(N, 64), taps = kh * kw, planes = mode == LISO_CONV_F32X3 ? 2 : 1;
-    const long total = (long)planes * taps * (Kp / 8) * Np;
+    const int f32 = mode == LISO_CONV_F32;
+    const long total = pack_chunks(planes, taps, Kp, Np, f32);
     pack_weights_kernel<<<(int)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(src, d0, d1, taps, same ? 0 : 1, K, N, Kp, Np,
-                                                                                      planes, (unsigned short*)dst);
+                                                                                      planes, f32, (unsigned short*)dst);
     return check_launch();
 }
 
@@ -809,8 +856,9 @@ int liso_conv_pack_weights_batched(const liso_conv_pack_job* jobs, int n_jobs, v
             const bool same = (j.transposed != 0) == (j.for_dgrad != 0);
             const int K = same ? j.d1 : j.d0, N = same ? j.d0 : j.d1;
             const int Kp = round_up(K, 16), Np = round_up(N, 64), taps = j.kh * j.kw, planes = j.mode == LISO_CONV_F32X3 ? 2 : 1;
-            t.job[i] = PackJob{j.src, (unsigned short*)j.dst, j.d1, taps, same ? 0 : 1, K, N, Kp, Np};
-            run += (long)planes * taps * (Kp / 8) * Np;
+            const int f32 = j.mode == LISO_CONV_F32;
+            t.job[i] = PackJob{j.src, (unsigned short*)j.dst, j.d1, taps, same ? 0 : 1, K, N, Kp, Np, f32};
+            run += pack_chunks(planes, taps, Kp, Np, f32);
             t.end[i] = run;
         }
         pack_weights_batched_kernel<<<(unsigned)((run + 255) / 256), 256, 0, (hipStream_t)stream>>>(t);
@@ -842,6 +890,7 @@ int liso_conv_forward(const liso_conv_desc* d, const void* x, const void* w_pack
     hipStream_t st = (hipStream_t)stream;
     const bool x3 = d->mode == LISO_CONV_F32X3;
     const bool of32 = x3 || d->out_f32;
+    const bool f32 = d->mode == LISO_CONV_F32;
 #define LISO_GO(MODE, MI, NJ, OF, CSA, CSB) return p.cs == CSA ? launch<MODE, MI, NJ, OF, CSA>(*d, p, st) : launch<MODE, MI, NJ, OF, CSB>(*d, p, st)
 #define LISO_SEL(MODE, OF, CSA, CSB)                  \
     do {                                    \
@@ -852,6 +901,7 @@ int liso_conv_forward(const liso_conv_desc* d, const void* x, const void* w_pack
     } while (0)
     if (x3 && p.sk == 2)
         return p.cs == 32 ? launch<LISO_CONV_F32X3, 1, 1, true, 32, 2>(*d, p, st) : launch<LISO_CONV_F32X3, 1, 1, true, 16, 2>(*d, p, st);
+    if (f32) LISO_SEL(LISO_CONV_F32, true, 32, 16);
     if (x3) LISO_SEL(LISO_CONV_F32X3, true, 32, 16);
     if (of32) LISO_SEL(LISO_CONV_BF16, true, 64, 32);
     LISO_SEL(LISO_CONV_BF16, false, 64, 32);

@@ -29,7 +29,8 @@ typedef s4 __attribute__((address_space(3))) * lds_s4_ptr;
 constexpr int kThreads = 256;
 constexpr int TW = 32;  // virtual pixels per tile row; 4, 2 or 1 rows per tile (WgArgs::th), fewer when the halo tile is large
 constexpr int CT = 64;                           // channel tile (both ci and co)
-constexpr int PSY = CT * 2 + 16;                 // LDS bytes per dy pixel
+constexpr int PSY = CT * 2 + 16;                 // LDS bytes per dy pixel (bf16 planes)
+constexpr int PS32 = CT * 4 + 16;                // LDS bytes per pixel of an fp32 tile (exact mode: x and dy)
 
 struct WgArgs {
     const void* x;
@@ -71,7 +72,10 @@ __device__ __forceinline__ bf8 tr_pair(const unsigned char* p0, const unsigned c
 template <int MODE, int TG>
 __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(const liso_conv_desc d, const WgArgs a) {
     constexpr bool X3 = MODE == LISO_CONV_F32X3;
+    constexpr bool F32 = MODE == LISO_CONV_F32;  // exact fp32 on v_mfma_f32_32x32x2_f32: fp32 tiles, plain 4-B LDS reads
+    constexpr bool FIN = X3 || F32;
     constexpr int PLANES = X3 ? 2 : 1;
+    constexpr int PSYM = F32 ? PS32 : PSY;
     constexpr int XB = TG >= 9 ? 4 : 8;  // 16-B loads in flight per thread while a tile is staged (register budget)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -93,7 +97,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(const liso_conv
     unsigned char* xs = smem;
     unsigned char* ys = smem + a.x_plane_bytes * PLANES;
     const int TH = a.th, MPIX = TH * TW;
-    const int y_plane = MPIX * PSY;
+    const int y_plane = MPIX * PSYM;
 
     // transposing-read lane geometry (16-lane groups): group g -> k half (g >> 1), channel half-tile (g & 1)
     const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
@@ -124,8 +128,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(const liso_conv
     uint4 xv[XB], yv[YB];
     unsigned xok = 0u, yok = 0u;
     float sc[8], sh[8];
-    const bool pro = !X3 && a.in_scale != nullptr;
-    if constexpr (!X3) {
+    const bool pro = !FIN && a.in_scale != nullptr;
+    if constexpr (!FIN) {
         const int ch = ci0 + c8 * 8;
         if (pro) {
 #pragma unroll
@@ -233,6 +237,34 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(const liso_conv
         }
     };
     auto mfma_tile = [&]() {  // 8 k-steps of 16 pixels (TH = 4), all taps of the group
+        if constexpr (F32) {
+            // D[ci][co] += A[ci][k] B[k][co], k = 2 pixels per MFMA: lane (r = lane & 31, h = lane >> 5) holds x'[pixel 2s + h][ci r]
+            // and dy[pixel 2s + h][co r] -- one 4-B LDS read each (32 consecutive channels of one pixel per lane half: conflict-free)
+            const int r = lane & 31, h = lane >> 5;
+            const unsigned char* bb = ys + (co_half * 32 + r) * 4;
+            const unsigned char* ab = xs + (ci_half * 32 + r) * 4;
+            for (int s2 = 0; s2 < MPIX / 2; s2 += 4) {
+                float bv[4];
+                int xo[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int m = 2 * (s2 + u) + h;
+                    bv[u] = *reinterpret_cast<const float*>(bb + m * PS32);
+                    xo[u] = (((m >> 5) * d.isy) * in_w + (m & 31) * d.isx) * PSX;
+                }
+#pragma unroll
+                for (int i = 0; i < TG; i++) {
+                    if (i < tcnt) {
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            const float av = *reinterpret_cast<const float*>(ab + xo[u] + toff[i]);
+                            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[u], acc[i], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            return;
+        }
         for (int kk = 0; kk < MPIX / 16; kk++) {
             const int krow = kk >> 1, kcol = (kk & 1) * 16;
             const unsigned char* bp = ys + (krow * TW + kcol) * PSY + b_lane;
@@ -259,7 +291,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(const liso_conv
         }
     };
 
-    if (!X3 && a.pipelined) {
+    if (!FIN && a.pipelined) {
         // the halo tile fits one batch of XB chunks per thread: registers hold tile k+1 while the matrix cores work on tile k
         int tile = split;
         if (tile < a.n_tiles) {
@@ -296,7 +328,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(const liso_conv
         const long y_img = (long)b * d.ho * d.wo * a.dy_pix_stride;
         __syncthreads();
         // ---- stage x' (halo tile, 64 channels) --------------------------------------------------------------------------
-        if constexpr (!X3) {
+        if constexpr (!FIN) {
             (void)iy0; (void)ix0; (void)x_img; (void)y_img;
             for (int pix0 = 0; pix0 < npix; pix0 += XB * pstep) {
                 load_x(tile, pix0);
@@ -353,6 +385,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(const liso_conv
                         }
                         if (!ok[u]) f[e] = 0.0f;
                     }
+                    if constexpr (F32) {
+                        *reinterpret_cast<float4*>(xs + pix * PSX + c4 * 16) = make_float4(f[0], f[1], f[2], f[3]);
+                        continue;
+                    }
 #pragma unroll
                     for (int e = 0; e < 2; e++) {
                         const float h0 = round_bf16(f[2 * e]), h1 = round_bf16(f[2 * e + 1]);
@@ -379,6 +415,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(const liso_conv
                 for (int e = 0; e < 4; e++) {
                     if (!ok) f[e] = 0.0f;
                     if (want_bias) bsum[e] += f[e];
+                }
+                if constexpr (F32) {
+                    *reinterpret_cast<float4*>(ys + m * PS32 + c4 * 16) = make_float4(f[0], f[1], f[2], f[3]);
+                    continue;
                 }
 #pragma unroll
                 for (int e = 0; e < 2; e++) {
@@ -408,8 +448,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(const liso_conv
     if (want_bias) {
         __syncthreads();
         float* red = reinterpret_cast<float*>(smem);
-        constexpr int NCH = X3 ? 4 : 8;   // channels per thread
-        constexpr int NGR = X3 ? 16 : 8;  // channel groups
+        constexpr int NCH = FIN ? 4 : 8;   // channels per thread
+        constexpr int NGR = FIN ? 16 : 8;  // channel groups
 #pragma unroll
         for (int e = 0; e < NCH; e++) red[tid * NCH + e] = bsum[e];
         __syncthreads();
@@ -470,10 +510,13 @@ bool make_plan(const liso_conv_desc& d, WgPlan* p) {
     if (d.batch <= 0 || d.ci <= 0 || d.co <= 0 || d.n_classes < 1 || d.n_classes > LISO_CONV_MAX_CLASSES) return false;
     if (d.n_taps < 1 || d.n_taps > LISO_CONV_MAX_TAPS || d.class_tap_begin[0] != 0 || d.class_tap_begin[d.n_classes] != d.n_taps)
         return false;
-    const bool x3 = d.mode == LISO_CONV_F32X3;
+    if (d.mode != LISO_CONV_BF16 && d.mode != LISO_CONV_F32X3 && d.mode != LISO_CONV_F32) return false;
+    const bool f32 = d.mode == LISO_CONV_F32;
+    const bool x3 = d.mode == LISO_CONV_F32X3 || f32;  // (plan: the exact mode shares the fp32-tensor choices of F32X3)
     const int vec = x3 ? 4 : 8;
     if (d.ci % vec || d.co % vec || d.x_pix_stride % vec) return false;
-    const int planes = x3 ? 2 : 1;
+    const int planes = (x3 && !f32) ? 2 : 1;
+    const int psx = f32 ? PS32 : CT * 2 + 16, psy = f32 ? PS32 : PSY;
     WgArgs& a = p->a;
     a.ci_t = (d.ci + CT - 1) / CT;
     a.co_t = (d.co + CT - 1) / CT;
@@ -495,7 +538,7 @@ bool make_plan(const liso_conv_desc& d, WgPlan* p) {
                 const int np = ((th - 1) * d.isy + (y1 - y0) + 1) * ((TW - 1) * d.isx + (x1 - x0) + 1);
                 mp = np > mp ? np : mp;
             }
-            const int lds = planes * (round_up(mp * (CT * 2 + 16), 16) + th * TW * PSY);
+            const int lds = planes * (round_up(mp * psx, 16) + th * TW * psy);
             if (lds <= (pass == 0 ? 79 : 158) * 1024) th_fit = th;
         }
     if (!th_fit) return false;
@@ -523,11 +566,11 @@ bool make_plan(const liso_conv_desc& d, WgPlan* p) {
         const int np = a.cls_inh[c] * a.cls_inw[c];
         max_pix = np > max_pix ? np : max_pix;
     }
-    a.psx = CT * 2 + 16;
+    a.psx = psx;
     // (XB = 8 chunks per thread x 32 pixel rows of threads = 256 halo pixels; XB = 4 in the 9-tap instantiation)
     a.pipelined = 0;
     a.x_plane_bytes = round_up(max_pix * a.psx, 16);
-    p->lds = planes * (a.x_plane_bytes + TH * TW * PSY);
+    p->lds = planes * (a.x_plane_bytes + TH * TW * psy);
     // taps per block (9 / 3 / 1) and pixel splits: the slabs of all splits together stay below 24 MB (they are written and
     // read once), every block sees >= 4 tiles, and the grid should reach ~2 blocks per CU; more taps per block = fewer
     // re-stagings of the same tiles, so the largest tap group that still fills the chip wins.
@@ -622,7 +665,7 @@ int liso_conv_wgrad(const liso_conv_desc* d, const void* x, const float* in_scal
     if ((in_scale == nullptr) != (in_shift == nullptr)) return LISO_EINVAL;
     WgPlan p;
     if (!make_plan(*d, &p)) return LISO_EINVAL;
-    const int vec = d->mode == LISO_CONV_F32X3 ? 4 : 8;
+    const int vec = d->mode == LISO_CONV_BF16 ? 8 : 4;
     if (dy_pix_stride % vec || dy_pix_stride < d->co || (((uintptr_t)x | (uintptr_t)dy) & 15)) return LISO_EINVAL;
     if (workspace_bytes < p.slab_bytes + p.bias_bytes) return LISO_EWORKSPACE;
     p.a.x = x;
@@ -634,7 +677,9 @@ int liso_conv_wgrad(const liso_conv_desc* d, const void* x, const float* in_scal
     p.a.bias_slab = dbias ? (float*)((char*)workspace + p.slab_bytes) : nullptr;
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    if (d->mode == LISO_CONV_F32X3)
+    if (d->mode == LISO_CONV_F32)
+        rc = p.tg == 3 ? launch<LISO_CONV_F32, 3>(*d, p, st) : launch<LISO_CONV_F32, 1>(*d, p, st);
+    else if (d->mode == LISO_CONV_F32X3)
         rc = p.tg == 3 ? launch<LISO_CONV_F32X3, 3>(*d, p, st) : launch<LISO_CONV_F32X3, 1>(*d, p, st);
     else
         rc = p.tg == 9 ? launch<LISO_CONV_BF16, 9>(*d, p, st) : p.tg == 3 ? launch<LISO_CONV_BF16, 3>(*d, p, st)

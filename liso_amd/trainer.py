@@ -60,8 +60,11 @@ def get_slim_optimizer_scheduler(slim_cfg, params):
 
 
 class DetectorTrainer:
-    def __init__(self, cfg, device, compute_dtype=torch.float32, total_steps=None, fused_loss=None, use_graph=False):
-        """`fused_loss`: activations + decode + CenterPoint loss in one HIP pass (include/liso_detector.h) instead of
+    def __init__(self, cfg, device, compute_dtype=torch.float32, total_steps=None, fused_loss=None, use_graph=False, exact=None):
+        """`exact` (with compute_dtype float32): True = fp32 convolutions on the native fp32 MFMA (2^-24 per product, the reference's
+        fp32 semantics; the parity configuration), False = as bf16 hi/lo pairs (F32X3, 2^-16 per product), None = leave the
+        process-wide setting (liso_amd.utils.mfma_conv.set_fp32_mode) as it is.
+        `fused_loss`: activations + decode + CenterPoint loss in one HIP pass (include/liso_detector.h) instead of
         ~140 torch launches; default = whenever the configuration is the overlay the kernel implements and the
         network runs on the GPU.
         `use_graph`: forward + loss + backward of one step (no device->host sync on that path) are captured once per input
@@ -77,6 +80,8 @@ class DetectorTrainer:
         self.net = BoxLearner(cfg).to(device)
         self.net.model.set_compute_dtype(compute_dtype)
         from liso_amd.utils import mfma_conv as MC
+        if exact is not None:
+            MC.set_fp32_mode("exact" if exact else "x3")
         if self.use_graph and (not self.fused_loss or MC.backend() != "mfma"):
             # only the fused loss + own convolutions keep the captured region free of hipMemsetAsync nodes (graph_safety.py):
             # torch's multi-block reductions (centerpoint_loss, ATen / MIOpen backward) put them into the graph
@@ -273,8 +278,13 @@ class SlimTrainer:
     live in one flat buffer: data parallelism is one RCCL all-reduce of that buffer after the replay (no DDP wrapper),
     then the eager RMSprop step."""
 
-    def __init__(self, cfg, device, num_train_samples=1000, use_graph=False, channels_last=False):
+    def __init__(self, cfg, device, num_train_samples=1000, use_graph=False, channels_last=False, exact=None):
+        """`exact`: True = every fp32 convolution on the native fp32 MFMA (parity configuration), False = bf16 hi/lo pairs (F32X3,
+        the production default), None = leave the process-wide setting (mfma_conv.set_fp32_mode)"""
         from liso_amd.slim.model.slim import SLIM
+        if exact is not None:
+            from liso_amd.utils import mfma_conv as MC
+            MC.set_fp32_mode("exact" if exact else "x3")
         self.cfg, self.slim_cfg, self.device = cfg, cfg.SLIM, device
         self.net = SLIM(cfg, num_train_samples=num_train_samples).to(device)
         if channels_last:  # measured slower than NCHW filters on gfx950 (65 vs 59 ms per step): MIOpen's fp32 Winograd is NCHW
@@ -545,7 +555,7 @@ class LisoLoopTrainer:
     Box-DB augmentation and tracking between the stages are outside this loop."""
 
     def __init__(self, cfg, device, compute_dtype=torch.float32, total_steps=None, slim_state_dict=None, use_graph=False,
-                 overlap=False, infer_batch=2, flow_ahead=0):
+                 overlap=False, infer_batch=2, flow_ahead=0, exact=None):
         """`use_graph`: the frozen SLIM inference (one capture per input shape) and the detector's forward+loss+backward are
         replayed from hipGraphs; the flow clustering in between stays eager (its box count sizes the padded Shape).
         `overlap`: step(pair_i, upcoming=(pair_i+1, pair_i+2)) runs the iteration as a three-stage software pipeline on
@@ -557,6 +567,9 @@ class LisoLoopTrainer:
         from liso_amd.slim.model.slim import SLIM
 
         self.cfg, self.device = cfg, device
+        if exact is not None:  # arithmetic of the fp32 convolutions (SLIM; the detector too when compute_dtype is float32)
+            from liso_amd.utils import mfma_conv as MC
+            MC.set_fp32_mode("exact" if exact else "x3")
         self.use_graph = bool(use_graph) and device.type == "cuda"
         self._graph_infer = self.use_graph and use_graph in (True, "infer")
         self._graph_det = self.use_graph and use_graph in (True, "detector")

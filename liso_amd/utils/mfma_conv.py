@@ -44,11 +44,44 @@ class ConvSpec:
         return (h + 2 * self.padding - self.kh) // self.stride + 1, (w + 2 * self.padding - self.kw) // self.stride + 1
 
 
+# Arithmetic of fp32 tensors: "x3" = three bf16 MFMAs per product (2^-16 per product, the production default of the SLIM networks)
+# or "exact" = native fp32 MFMA (v_mfma_f32_32x32x2_f32: 2^-24 per product, the reference's fp32 semantics; the parity mode).
+# Process-wide; LISO_CONV_FP32=exact sets the initial value.  bf16 tensors are not affected.
+_FP32_MODE = "exact" if os.environ.get("LISO_CONV_FP32", "x3") == "exact" else "x3"
+
+
+def set_fp32_mode(mode):
+    """"x3" | "exact" -> the previous mode"""
+    global _FP32_MODE
+    assert mode in ("x3", "exact"), mode
+    prev, _FP32_MODE = _FP32_MODE, mode
+    return prev
+
+
+def fp32_mode():
+    return _FP32_MODE
+
+
+class fp32_arithmetic:
+    """with fp32_arithmetic("exact"): ... -- forward AND backward of the graph built inside should run inside the block"""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = set_fp32_mode(self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        set_fp32_mode(self.prev)
+        return False
+
+
 def _mode(dtype):
     if dtype == torch.bfloat16:
         return L.CONV_BF16
     if dtype == torch.float32:
-        return L.CONV_F32X3
+        return L.CONV_F32 if _FP32_MODE == "exact" else L.CONV_F32X3
     raise L.LisoHipError(f"mfma conv: unsupported dtype {dtype}")
 
 
@@ -240,7 +273,7 @@ def _vec(mode):
 
 
 def _timer_name(mode, kind):
-    return ("conv_bf16_" if mode == L.CONV_BF16 else "conv_f32x3_") + kind
+    return ("conv_bf16_" if mode == L.CONV_BF16 else "conv_f32x3_" if mode == L.CONV_F32X3 else "conv_f32_") + kind
 
 
 def _flops(d):
@@ -270,7 +303,7 @@ def conv_forward(x, weight, bias, spec, in_scale=None, in_shift=None, in_relu=Fa
     co = weight.shape[1] if spec.transposed else weight.shape[0]
     ho, wo = spec.out_hw(hi, wi)
     out_dtype = out_dtype or x.dtype
-    if mode == L.CONV_F32X3:
+    if mode != L.CONV_BF16:
         assert out_dtype == torch.float32
     out_f32 = out_dtype == torch.float32
     y = torch.empty((B, ho, wo, co), dtype=out_dtype, device=x.device)

@@ -5,6 +5,9 @@ from liso_amd.utils import mfma_conv as MC
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 dt = torch.bfloat16 if (len(sys.argv) < 3 or sys.argv[2] == "bf16") else torch.float32
+if len(sys.argv) >= 3 and sys.argv[2] == "exact":  # fp32 tensors on the native fp32 MFMA instead of bf16 hi/lo pairs
+    MC.set_fp32_mode("exact")
+DET32 = len(sys.argv) >= 4 and sys.argv[3] == "det"  # fp32 / exact on the DETECTOR's layer shapes
 LAYERS = [  # name, Ci, Co, H (input), k, s, p, transposed
     ("b0.s2 64->64 512", 64, 64, 512, 3, 2, 1, False), ("b0 64->64 256", 64, 64, 256, 3, 1, 1, False),
     ("b1.s2 64->128 256", 64, 128, 256, 3, 2, 1, False), ("b1 128->128 128", 128, 128, 128, 3, 1, 1, False),
@@ -13,7 +16,7 @@ LAYERS = [  # name, Ci, Co, H (input), k, s, p, transposed
     ("de2 T 256->128 64", 256, 128, 64, 2, 2, 0, True), ("head 384->64 128", 384, 64, 128, 3, 1, 1, False),
     ("heads 64->256 128", 64, 256, 128, 3, 1, 1, False), ("out 64->3 128", 64, 3, 128, 3, 1, 1, False),
 ]
-if dt == torch.float32:
+if dt == torch.float32 and not DET32:
     LAYERS = [("enc 7x7s2 64->32 512", 64, 32, 512, 7, 2, 3, False), ("enc 32->32 256", 32, 32, 256, 3, 1, 1, False),
               ("enc 64->64 128", 64, 64, 128, 3, 1, 1, False), ("enc 96->96 64", 96, 96, 64, 3, 1, 1, False),
               ("corr 1x1 196->96 64", 196, 96, 64, 1, 1, 0, False), ("gru zr 400->192 64", 400, 192, 64, 3, 1, 1, False),

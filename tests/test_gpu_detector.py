@@ -108,6 +108,40 @@ def test_bf16_step_runs_and_tracks_fp32():
     assert all(np.isfinite(a)) and a[-1] < a[0]  # it trains
 
 
+def test_bf16_detector_logit_error_vs_exact_fp32_at_full_size():
+    """The headline configuration runs the detector with bf16 BEV tensors.  Its error is quantified here against the EXACT fp32
+    path (native fp32 MFMA) on the bench's input -- 120k-point clouds, 512^2 BEV, train-mode BatchNorm, same weights: maximum and
+    root-mean-square error of every head's raw logits relative to the head's largest / rms logit, and the loss.
+    Budget (documented in DESIGN.md section 5): worst element <= 6e-2 of the head's range, rms <= 1.5e-2, loss <= 5e-2 --
+    bf16 carries 8 significant bits (2^-9 = 2e-3 per rounding) through 17 convolution + BatchNorm layers; north_star's 1e-3 on
+    logits is the requirement on the fp32 parity configuration (asserted in test_logits_match_oracle_* / the fixture tests)."""
+    from liso_amd.utils import mfma_conv as MC
+
+    prev = MC.fp32_mode()
+    try:
+        tr32, pcls, targets = _setup(512, 100.0, 1, 120000, torch.float32, seed=11)
+        MC.set_fp32_mode("exact")
+        tr16, _, _ = _setup(512, 100.0, 1, 120000, torch.bfloat16, seed=11)
+        tr16.net.load_state_dict(tr32.net.state_dict())
+        tr32.model.train(), tr16.model.train()
+        with torch.no_grad():
+            _, _, raw32, _ = tr32.net(None, pcls, None, decode=False)
+            _, _, raw16, _ = tr16.net(None, pcls, None, decode=False)
+        l32, _, _ = tr32.loss(pcls, targets)
+        l16, _, _ = tr16.loss(pcls, targets)
+    finally:
+        MC.set_fp32_mode(prev)
+    report = {}
+    for h in HEADS:
+        a, b = raw16[h].detach().double(), raw32[h].detach().double()
+        report[h] = (float((a - b).abs().max() / b.abs().max()), float((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt()))
+    print("bf16 vs exact fp32, per head (max / range, rms / rms):", {k: (f"{v[0]:.2e}", f"{v[1]:.2e}") for k, v in report.items()},
+          f"loss {abs(float(l16) - float(l32)) / abs(float(l32)):.2e}")
+    for h, (mx, rms) in report.items():
+        assert mx <= 6e-2 and rms <= 1.5e-2, (h, mx, rms)
+    assert abs(float(l16) - float(l32)) <= 5e-2 * abs(float(l32))
+
+
 def test_full_size_step_properties():
     """BASELINE config 3 shape: 120k points, 512^2, B=2 -> finite loss, every parameter gets a finite gradient,
     two identical steps from the same state are bitwise identical (no float atomics in our kernels; MIOpen permitting
@@ -196,8 +230,12 @@ def test_logit_maps_and_rpn_features_match_oracle_fp32():
             assert _rel(raw[h], raw64[h]) <= 1e-3, (training, h, _rel(raw[h], raw64[h]))
 
 
-def test_rpn_head_on_gpu_match_reference_fixture(golden_dir):
-    """the reference's own RPN / CenterHead outputs (tests/golden/detector_rpn_head.npz, generated by importing
+@pytest.mark.parametrize("fmode", ["exact", "x3"])
+def test_rpn_head_on_gpu_match_reference_fixture(golden_dir, fmode):
+    """`fmode` = arithmetic of the fp32 convolutions: "exact" (native fp32 MFMA, the reference's fp32 semantics: gradients at the
+    limits the true-fp32 library path met before the F32X3 kernels existed) and "x3" (bf16 hi/lo pairs, the production default of
+    the SLIM networks: bulk / worst-element limits).
+    The reference's own RPN / CenterHead outputs (tests/golden/detector_rpn_head.npz, generated by importing
     liso/networks/centerpoint/{rpn,center_head}.py) reproduced ON THE GPU through the own convolution / BatchNorm kernels:
     feature map and every head's logits <= 1e-3, train and eval mode; gradients as in the CPU test of the same fixture."""
     import os
@@ -205,7 +243,10 @@ def test_rpn_head_on_gpu_match_reference_fixture(golden_dir):
     from liso_amd.networks.centerpoint.center_head import CenterHead
     from liso_amd.networks.centerpoint.rpn import RPN
 
+    from liso_amd.utils import mfma_conv as MC
+
     g = np.load(os.path.join(golden_dir, "detector_rpn_head.npz"))
+    prev_mode = MC.set_fp32_mode(fmode)
 
     def sd(prefix):
         tag = "sd_" + prefix + "__"
@@ -237,10 +278,13 @@ def test_rpn_head_on_gpu_match_reference_fixture(golden_dir):
 
             for got, key in ((x.grad, "train_grad_x"), (rpn.blocks[0][1].weight.grad, "train_grad_rpn_blocks_0_1_weight"),
                              (rpn.deblocks[2][0].weight.grad, "train_grad_rpn_deblocks_2_0_weight")):
-                assert bulk(got, g[key]) <= 5e-2 and _rel(got, torch.from_numpy(g[key])) <= 0.3, (key, bulk(got, g[key]))  # (8x8 maps: 128 values per BN statistic)
+                lim_bulk, lim_worst = (1e-3, 4e-3) if fmode == "exact" else (5e-2, 0.3)  # (8x8 maps: 128 values per BN statistic)
+                assert bulk(got, g[key]) <= lim_bulk and _rel(got, torch.from_numpy(g[key])) <= lim_worst, \
+                    (fmode, key, bulk(got, g[key]), _rel(got, torch.from_numpy(g[key])))
             # (the fixture's upstream gradient sums to ~0 over the map: this bias gradient is pure rounding, |g| = 3e-4)
             assert abs(float(head.tasks[0].probs[3].bias.grad) - float(g["train_grad_head_probs_3_bias"])) <= 2e-3
             assert _rel(rpn.blocks[0][2].running_mean, torch.from_numpy(g["train_rm_after_rpn_blocks_0_2"])) <= 1e-3
+    MC.set_fp32_mode(prev_mode)
 
 
 def test_config5_train_step_300k_points_1024_grid_bf16():

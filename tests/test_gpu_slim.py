@@ -122,7 +122,20 @@ def _build(seed=1234):
     return fnet, cnet, ub, raft, HeadDecoder(cfg.SLIM, name="fw", bev_extent=None)
 
 
-def test_raft_loop_matches_reference():
+@pytest.mark.parametrize("fmode", ["exact", "x3"])
+def test_raft_loop_matches_reference(fmode):
+    """`fmode`: arithmetic of the fp32 convolutions -- "exact" (native fp32 MFMA) must meet the limits of the true-fp32 library
+    path, "x3" (bf16 hi/lo pairs, production default) the documented wider ones on the deepest gradient"""
+    from liso_amd.utils import mfma_conv as MC
+
+    prev_mode = MC.set_fp32_mode(fmode)
+    try:
+        _raft_loop_matches_reference(fmode)
+    finally:
+        MC.set_fp32_mode(prev_mode)
+
+
+def _raft_loop_matches_reference(fmode):
     g = _g()
     fnet, cnet, ub, raft, dec = _build()
     sd = {"fnet." + k: v for k, v in fnet.state_dict().items()}
@@ -149,11 +162,16 @@ def test_raft_loop_matches_reference():
     # true-fp32 MIOpen path measures 3.9e-3 here with a forward error of 3e-6; the F32X3 convolutions, forward error 3e-5 =
     # 2^-15, measure 3e-2 -- scripts/debug_raft_grads.py).  The bulk of the tensor is checked tightly, the tail loosely.
     gf, rf = fnet.conv1.weight.grad.detach().cpu().double().numpy(), g["raft_g_fnet_conv1"].astype(np.float64)
-    assert np.median(np.abs(gf - rf)) <= 2e-2 * np.median(np.abs(rf)) and _rel(fnet.conv1.weight.grad, g["raft_g_fnet_conv1"]) < 6e-2
-    assert _rel(cnet.conv2.weight.grad, g["raft_g_cnet_conv2"]) < 5e-3
-    assert _rel(ub.gru.convz.weight.grad[:, ::8], g["raft_g_gru_convz"]) < 5e-3
-    assert _rel(ub.static_flow_head.conv2.weight.grad, g["raft_g_flow_head"]) < 5e-3
-    assert _rel(ub.motion_encoder.conv_stat_corr1.weight.grad[..., 0, 0], g["raft_g_corr_conv"]) < 5e-3
+    if fmode == "exact":
+        assert np.median(np.abs(gf - rf)) <= 1e-3 * np.median(np.abs(rf)) and _rel(fnet.conv1.weight.grad, g["raft_g_fnet_conv1"]) < 5e-3, \
+            (np.median(np.abs(gf - rf)) / np.median(np.abs(rf)), _rel(fnet.conv1.weight.grad, g["raft_g_fnet_conv1"]))
+    else:
+        assert np.median(np.abs(gf - rf)) <= 2e-2 * np.median(np.abs(rf)) and _rel(fnet.conv1.weight.grad, g["raft_g_fnet_conv1"]) < 6e-2
+    lim = 1e-3 if fmode == "exact" else 5e-3
+    assert _rel(cnet.conv2.weight.grad, g["raft_g_cnet_conv2"]) < lim, _rel(cnet.conv2.weight.grad, g["raft_g_cnet_conv2"])
+    assert _rel(ub.gru.convz.weight.grad[:, ::8], g["raft_g_gru_convz"]) < lim, _rel(ub.gru.convz.weight.grad[:, ::8], g["raft_g_gru_convz"])
+    assert _rel(ub.static_flow_head.conv2.weight.grad, g["raft_g_flow_head"]) < lim, _rel(ub.static_flow_head.conv2.weight.grad, g["raft_g_flow_head"])
+    assert _rel(ub.motion_encoder.conv_stat_corr1.weight.grad[..., 0, 0], g["raft_g_corr_conv"]) < lim
 
 
 # ---- SLIM decoder + self-supervised loss (E6/E7) -------------------------------------------------------------------------
