@@ -81,7 +81,9 @@ def parse():
     ap.add_argument("--no-overlap", action="store_true",
                     help="loop workload: all stages of an iteration on one stream, one pair at a time (default: SLIM inference "
                          "of pair i+2 and box mining of pair i+1 on their own HIP streams, concurrent with the detector step on i)")
-    ap.add_argument("--batch", type=int, default=None, help="detector workload: clouds per GPU (default 4)")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="clouds (detector workload, default 4) / sweep pairs (loop workload, default 2 = the reference's batch_size, "
+                         "liso_config.yml:121) per GPU and step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-iou3d", action="store_true", help="skip the iou3d_nms section of the line")
     ap.add_argument("--no-fp32-leg", action="store_true",
@@ -374,7 +376,7 @@ def main():
         from liso_amd.datasets.synthetic import slim_pair
         from liso_amd.trainer import LisoLoopTrainer
 
-        batch = 1
+        batch = args.batch or 2  # sweep pairs per detector step: the reference's default batch_size (liso_config.yml:121)
         dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
         cfg = apply_slim_simple_knn_training(cfg)
         overlap = not (args.eager or args.no_overlap)
@@ -383,16 +385,18 @@ def main():
                                   overlap=overlap, infer_batch=max(1, args.lookahead - 1 - args.flow_ahead), flow_ahead=args.flow_ahead,
                                   exact=(args.dtype == "fp32"))
         # a ring of different sweep pairs; step i trains on pair i while (overlap) pairs i+1 / i+2 are in the mining stages
-        pairs = [slim_pair(2 + rank + 100 * i, dev, n_points=N_POINTS, grid=GRID, bev_range_m=BEV_RANGE) for i in range(max(5, args.lookahead + 2))]
+        n_up = batch * (2 + args.flow_ahead) + max(1, args.lookahead - 1 - args.flow_ahead) - 1  # pairs the pipeline looks at (step_batch)
+        pairs = [slim_pair(2 + rank + 100 * i, dev, n_points=N_POINTS, grid=GRID, bev_range_m=BEV_RANGE) for i in range(max(5, n_up + batch + 2))]
         s0, s1 = pairs[0]
         counter = [0]
 
         def step():
-            i = counter[0]
+            i = counter[0] * batch
             counter[0] += 1
-            return trainer.step(*pairs[i % len(pairs)], upcoming=tuple(pairs[(i + k) % len(pairs)] for k in range(1, args.lookahead + 1)))
+            return trainer.step_batch([pairs[(i + k) % len(pairs)] for k in range(batch)],
+                                      upcoming=tuple(pairs[(i + k) % len(pairs)] for k in range(batch, batch + n_up)))
 
-        frames_per_step = 2
+        frames_per_step = 2 * batch
     else:
         from liso_amd.datasets.synthetic import detector_batch
         from liso_amd.trainer import DetectorTrainer
@@ -453,7 +457,7 @@ def main():
             if args.workload == "slim":
                 trainer.step(s0, s1, eager=True, update=False)
             elif args.workload == "loop":
-                trainer.eager_pass(s0, s1, also=tuple(pairs[1:trainer.infer_batch]) if overlap else ())
+                trainer.eager_pass_batch(pairs[:batch], also=tuple(pairs[batch:max(batch, trainer.infer_batch)]) if overlap else ())
             else:
                 trainer.eager_pass(pcls, targets)
         torch.cuda.synchronize()
@@ -472,9 +476,10 @@ def main():
         c32 = [0]
 
         def step32():
-            i = c32[0]
+            i = c32[0] * batch
             c32[0] += 1
-            return t32.step(*pairs[i % len(pairs)], upcoming=tuple(pairs[(i + k) % len(pairs)] for k in range(1, args.lookahead + 1)))
+            return t32.step_batch([pairs[(i + k) % len(pairs)] for k in range(batch)],
+                                  upcoming=tuple(pairs[(i + k) % len(pairs)] for k in range(batch, batch + n_up)))
 
         n32 = min(args.steps, 10)
         for _ in range(4):
@@ -486,7 +491,7 @@ def main():
         torch.cuda.synchronize()
         e32 = time.perf_counter() - t0
         fp32_leg = {"dtype": "f32 (exact: native fp32 MFMA v_mfma_f32_32x32x2_f32, SLIM and detector)", "steps": n32, "warmup": 4,
-                    "ms_per_step": 1e3 * e32 / n32, "value": 2 * n32 / e32, "unit": "frames/s", "final_loss": float(l32),
+                    "ms_per_step": 1e3 * e32 / n32, "value": 2 * batch * n32 / e32, "unit": "frames/s", "final_loss": float(l32),
                     "note": "same launch structure and inputs as the headline line; `python bench.py --dtype fp32` gives the full line"}
         del t32
         MC.set_fp32_mode(prev_mode)
@@ -506,7 +511,7 @@ def main():
         durs = {k: L.TIMER.durations_ms(k) for k in list(L.TIMER.events) if L.TIMER.events[k]}
         totals = {k: sum(v) for k, v in durs.items()}
         per_unit = {k: L.TIMER.weighted_total_ms(k) for k in durs}  # launches that serve a batch of iterations count 1 / batch
-        static_bytes = static_algorithmic_bytes(args.workload, batch, 2 if args.dtype == "bf16" else 4)
+        static_bytes = static_algorithmic_bytes(args.workload, 1 if args.workload == "loop" else batch, 2 if args.dtype == "bf16" else 4)
         key = max(per_unit, key=per_unit.get)  # the hand-written kernel family with the largest share of the step
         if args.workload == "detector" and key.startswith("pfn"):
             key = "pfn_forward_scatter"
@@ -534,7 +539,8 @@ def main():
         workload = {
             "loop": ("fused LISO iteration (BASELINE configs[3]): SLIM fwd (no_grad; forward flow direction t0->t1 only, only the last "
                      "of the 6 RAFT iterations decoded -- what the box miner consumes) -> FlowClusterDetector (DBSCAN) -> NMS "
-                     "-> target maps -> CenterPoint-pillar train step, one 120k-pt sweep pair per GPU, 512x512 BEV"),
+                     f"-> target maps (per sweep pair) -> ONE CenterPoint-pillar train step on the batch of {batch} sweep pairs per GPU "
+                     "(the reference's batch_size), 120k-pt sweeps, 512x512 BEV"),
             "slim": ("SLIM scene-flow train step (BASELINE configs[1]): two 120k-pt KITTI-shaped clouds, 512x512 BEV "
                      "pillars, RAFT 6 iterations fwd+bw flow, kNN loss, fwd+bwd+RMSprop"),
             "detector": ("CenterPoint-pillar detector train step (BASELINE configs[2]): 120k-pt KITTI-shaped clouds, "

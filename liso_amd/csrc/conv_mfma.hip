@@ -741,8 +741,13 @@ bool make_plan(const liso_conv_desc& d, Plan* p) {
     // Choose (rows per tile, slab width, taps per weight stage): the configuration with the most MFMAs between two barriers
     // among those that leave room for 2 blocks per CU (79 KB); one block per CU (158 KB) only if nothing else fits.
     // 8-row tiles only when they still give every CU 2 blocks.
-    const int mi_first = blocks(8) >= 512 ? 2 : 1;
-    const int cs_opts[2] = {fin ? 32 : 64, fin ? 16 : 32};
+    int mi_first = blocks(8) >= 512 ? 2 : 1;
+    if (const char* e = getenv("LISO_CONV_MI")) mi_first = atoi(e) == 2 ? 2 : atoi(e) == 1 ? 1 : mi_first;  // experiments
+    int cs_opts[2] = {fin ? 32 : 64, fin ? 16 : 32};
+    if (const char* e = getenv("LISO_CONV_CS")) {  // experiments: force the slab width (bf16: 64 | 32; fp32 tensors: 32 | 16)
+        const int v = atoi(e);
+        if (v == cs_opts[0] || v == cs_opts[1]) cs_opts[0] = cs_opts[1] = v;
+    }
     long best = -1;
     bool few_blocks = blocks(4 * mi_first) <= 256;  // at most one block per CU anyway: spend its whole LDS
     if (const char* e = getenv("LISO_CONV_FEW")) few_blocks = few_blocks && atoi(e) != 0;  // experiments

@@ -246,7 +246,8 @@ class DetectorTrainer:
     def _graph_step(self, pcls, targets):
         # what the graph consumes: the [B, 64, gx, gy] canvas (batch size; grid and dtype are fixed per trainer) and the target maps.
         # The clouds themselves never enter it (the pillar encoder runs eagerly in front): their point counts are not part of the key.
-        sig = (len(pcls), tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(targets.items())))
+        tsig = targets.shapes() if isinstance(targets, _BatchedTargets) else tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(targets.items()))
+        sig = (len(pcls), tsig)
         if self._graph is None or sig != self._graph_sig:
             self._graph = None
             self._capture(pcls, targets)
@@ -254,8 +255,13 @@ class DetectorTrainer:
         # the eager pillar encoder writes straight into the graph's input buffers (its own backward runs on saved feature rows)
         bev, occ = self._pillars(pcls, out=(self._static_bev.detach().permute(0, 2, 3, 1), self._static_occ))
         with torch.no_grad():
-            for k, v in targets.items():
-                self._static_targets[k].copy_(v, non_blocking=True)
+            if isinstance(targets, _BatchedTargets):
+                for b, t in enumerate(targets.per_sample):
+                    for k, v in t.items():
+                        self._static_targets[k][b:b + v.shape[0]].copy_(v, non_blocking=True)
+            else:
+                for k, v in targets.items():
+                    self._static_targets[k].copy_(v, non_blocking=True)
         self._graph.replay()
         if bev.requires_grad:  # the pillar encoder's own parameters: its backward runs eagerly on the replayed d loss / d canvas
             bev.backward(self._static_bev.grad)
@@ -546,6 +552,37 @@ class _Prefetched:
         return self.pair[0] is pair[0] and self.pair[1] is pair[1]
 
 
+class _BatchedTargets(dict):
+    """target maps of a batch given as one dict per sample ([1, ...] tensors): behaves like the concatenated dict (built lazily,
+    one torch.cat per key) and lets the graph path copy sample by sample into its captured inputs without concatenating"""
+
+    def __init__(self, per_sample):
+        super().__init__()
+        self.per_sample = list(per_sample)
+        for k in self.per_sample[0]:
+            dict.__setitem__(self, k, None)
+
+    def __getitem__(self, k):
+        v = dict.__getitem__(self, k)
+        if v is None:
+            v = torch.cat([t[k] for t in self.per_sample], dim=0)
+            dict.__setitem__(self, k, v)
+        return v
+
+    def get(self, k, default=None):
+        return self[k] if k in self else default
+
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
+
+    def values(self):
+        return [self[k] for k in self.keys()]
+
+    def shapes(self):
+        n = len(self.per_sample)
+        return tuple((k, (n * v.shape[0],) + tuple(v.shape[1:]), v.dtype) for k, v in sorted(self.per_sample[0].items()))
+
+
 class LisoLoopTrainer:
     """One fused LISO iteration per sample pair: SLIM forward (no_grad) -> per-point flow ->
     FlowClusterDetector (BEV dynamicness, DBSCAN, region moments, z-fit, filters, Kabsch heading/velocity) -> rotated NMS
@@ -714,34 +751,40 @@ class LisoLoopTrainer:
         return st["flow"]
 
     def eager_pass(self, sample_t0, sample_t1, also=()):
-        """the whole iteration with eager launches and no parameter update (per-kernel event timing in bench.py).  `also`: further
-        pairs that join the SLIM inference batch, as in the pipeline's stage A (the kernels are then timed at the batch they run at)"""
+        return self.eager_pass_batch([(sample_t0, sample_t1)], also)
+
+    def eager_pass_batch(self, pairs, also=()):
+        """the whole iteration on a batch of pairs with eager launches and no parameter update (per-kernel event timing in bench.py).
+        `also`: further pairs that join the SLIM inference batch, as in the pipeline's stage A (the kernels are then timed at the
+        batch they run at; their launches count len(pairs) / (len(pairs) + len(also)) towards this step)"""
+        from liso_amd import _lib as L
         from liso_amd.datasets.targets import render_center_targets
 
         g, self._graph_infer = self._graph_infer, False
         try:
-            if also:
-                from liso_amd import _lib as L
-
-                pairs = [(sample_t0, sample_t1), *also]
-                with torch.no_grad():
-                    L.TIMER.weight = 1.0 / len(pairs)  # (these launches serve len(pairs) iterations)
-                    try:
-                        flow = self._infer_flow(self._stack_samples([p_[0] for p_ in pairs]), self._stack_samples([p_[1] for p_ in pairs]))
-                    finally:
-                        L.TIMER.weight = 1.0
-                    b = flow.shape[0] // len(pairs)
-                    _, boxes = self._targets_from_flow(sample_t0, flow[:b].contiguous())
-            else:
-                boxes, _ = self.mine_boxes(sample_t0, sample_t1)
+            allp = [*pairs, *also]
+            with torch.no_grad():
+                L.TIMER.weight = len(pairs) / len(allp)  # (these launches serve len(allp) pairs, the step consumes len(pairs))
+                try:
+                    if len(allp) == 1:
+                        flow = self._infer_flow(*allp[0])
+                    else:
+                        flow = self._infer_flow(self._stack_samples([p_[0] for p_ in allp]), self._stack_samples([p_[1] for p_ in allp]))
+                finally:
+                    L.TIMER.weight = 1.0
+                b = flow.shape[0] // len(allp)
+                boxes = [self._targets_from_flow(p_[0], flow[k * b:(k + 1) * b].contiguous())[1] for k, p_ in enumerate(pairs)]
         finally:
             self._graph_infer = g
-        if boxes.shape[1] == 0:
-            return None
         out = tuple(int(v) // 4 for v in self.cfg.data.img_grid_size)
-        targets = render_center_targets(boxes.pos.float(), boxes.dims.float().clamp(min=1e-3), boxes.rot.float(), boxes.valid, out,
-                                        tuple(self.cfg.data.bev_range_m))
-        return self.detector.eager_pass(sample_t0["pcl_full_no_ground_ta"], targets)
+        per = []
+        for bx in boxes:
+            if bx.shape[1] == 0:
+                return None
+            per.append(render_center_targets(bx.pos.float(), bx.dims.float().clamp(min=1e-3), bx.rot.float(), bx.valid, out,
+                                             tuple(self.cfg.data.bev_range_m)))
+        targets = per[0] if len(per) == 1 else {k: torch.cat([t[k] for t in per], dim=0) for k in per[0]}
+        return self.detector.eager_pass([c for p_ in pairs for c in p_[0]["pcl_full_no_ground_ta"]], targets)
 
     def _targets_from_flow(self, sample_t0, flow, capacity=None):
         """flow clustering -> NMS -> CenterPoint target maps.  Reference-shaped call: two box-count reads size the padded Shape.
@@ -850,43 +893,59 @@ class LisoLoopTrainer:
         infer_batch + flow_ahead + 1): stage A (SLIM inference) runs ahead on batches of them, stage B (box mining) up to two pairs ahead, each on
         its own stream.
         Prefetched results are matched by object identity; anything announced but not requested next is dropped."""
+        return self.step_batch([(sample_t0, sample_t1)], upcoming)
+
+    def step_batch(self, pairs, upcoming=()):
+        """one iteration on a BATCH of sweep pairs (each a (sample_t0, sample_t1) with batch size 1): boxes are mined per pair, the
+        detector takes ONE train step on the batch of len(pairs) clouds and target maps -- the reference's `batch_size` (2 in
+        liso_config.yml:121, 4 in the README commands :637-639), BatchNorm statistics over that batch like the reference's.
+        `upcoming`: the pairs of the following calls in order (flat list); the pipeline keeps stage B two batches ahead."""
         cuda = self.device.type == "cuda"
         cur = torch.cuda.current_stream(self.device) if cuda else None
-        pair = (sample_t0, sample_t1)
-        got = self._take_mined(pair, cur) if cuda else None
-        if got is not None:
-            targets, boxes = got
-        else:
-            f = self._take(self._flows, pair)
-            if f is not None:
-                cur.wait_event(f.done)
-                f.flow.record_stream(cur)
-                flow = f.flow
-            else:
-                if self.overlap and cuda:
-                    # not prefetched (first call, wrong or missing announcement): the inference runs HERE, on the caller's stream,
-                    # with the same static graph buffers, packed weight panels and decoder caches stage A uses on its stream
-                    cur.wait_stream(self._flow_stream)
-                with torch.no_grad():
-                    flow = self._infer_flow(sample_t0, sample_t1)
-            targets, boxes = self._targets_from_flow(sample_t0, flow)
-            if self.overlap and f is None:  # the static inference buffers were used on this stream up to here
-                self._main_used_static = torch.cuda.Event()
-                self._main_used_static.record(cur)
-        self.last_boxes = boxes
-        loss = self.detector.step(sample_t0["pcl_full_no_ground_ta"], targets)
+        mined = []
+        for pair in pairs:
+            sample_t0, sample_t1 = pair
+            got = self._take_mined(pair, cur) if cuda else None
+            if got is None:
+                f = self._take(self._flows, pair)
+                if f is not None:
+                    cur.wait_event(f.done)
+                    f.flow.record_stream(cur)
+                    flow = f.flow
+                else:
+                    if self.overlap and cuda:
+                        # not prefetched (first call, wrong or missing announcement): the inference runs HERE, on the caller's stream,
+                        # with the same static graph buffers, packed weight panels and decoder caches stage A uses on its stream
+                        cur.wait_stream(self._flow_stream)
+                    with torch.no_grad():
+                        flow = self._infer_flow(sample_t0, sample_t1)
+                got = self._targets_from_flow(sample_t0, flow)
+                if self.overlap and f is None:  # the static inference buffers were used on this stream up to here
+                    self._main_used_static = torch.cuda.Event()
+                    self._main_used_static.record(cur)
+            mined.append(got)
+        self.last_boxes = mined[-1][1]
+        self.last_boxes_batch = [m[1] for m in mined]
+        nb = len(pairs)
+        if nb == 1:
+            targets = mined[0][0]
+        else:  # (the graph path copies each sample's maps into its slice of the captured inputs: no concatenation launch)
+            targets = _BatchedTargets([m[0] for m in mined])
+        pcls = [c for p_ in pairs for c in p_[0]["pcl_full_no_ground_ta"]]
+        loss = self.detector.step(pcls, targets)
         if self.overlap and len(upcoming) > 0:
-            ahead = 1 + len(self._mine_streams)  # stage B runs this many pairs ahead (one more than chains in flight)
-            up = list(upcoming[:ahead + self.flow_ahead + self.infer_batch - 1])
+            ahead = nb * (1 + len(self._mine_streams))  # stage B runs this many pairs ahead (one batch more than chains in flight)
+            fa = nb * self.flow_ahead
+            up = list(upcoming[:ahead + fa + self.infer_batch - 1])
             has = lambda store, p: any(e.is_for(p) for e in store)  # noqa: E731
             self._mined = [e for e in self._mined if any(e.is_for(q) for q in up)]
             self._flows = [e for e in self._flows if any(e.is_for(q) for q in up)]
             # stage A first (the GPU works on it while the host walks through stage B).  It runs when a pair that stage B needs now
-            # (one of the next two) has no flow yet, and then takes every announced pair without a flow -- up to `infer_batch` of
-            # the same shape -- in one batch: with k pairs announced it runs every k-1 steps on k-1 pairs.
+            # (one of the next two batches) has no flow yet, and then takes every announced pair without a flow -- up to `infer_batch`
+            # of the same shape -- in one batch: with k pairs announced it runs every k-1 pairs on k-1 pairs.
             missing = [p_ for k, p_ in enumerate(up) if not has(self._flows, p_) and not has(self._mined, p_)
                        and not any(p_[0] is q[0] and p_[1] is q[1] for q in up[:k])]
-            if missing and any(p_ is q for p_ in missing for q in up[:ahead + self.flow_ahead]):
+            if missing and any(p_ is q for p_ in missing for q in up[:ahead + fa]):
                 while missing:
                     n = 1
                     while n < min(len(missing), self.infer_batch) and self._same_shapes(missing[0], missing[n]):

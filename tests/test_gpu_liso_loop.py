@@ -295,3 +295,47 @@ def test_inference_issued_ahead_of_need_gives_the_same_steps():
         assert abs(a - b) <= 1e-5 * abs(a), (out[0][0], out[1][0])
     for a, b in zip(out[0][1], out[1][1]):
         assert a.shape == b.shape and torch.allclose(a, b, rtol=1e-4, atol=1e-4), float((a - b).abs().max())
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_batched_loop_step_trains_on_the_batch_and_pipeline_equals_sequential(use_graph):
+    """step_batch([pair_a, pair_b]): boxes are mined per pair, the detector takes ONE step on both clouds (the reference's
+    batch_size 2, liso_config.yml:121).  (1) The step equals a DetectorTrainer step on the concatenated per-pair target maps;
+    (2) the three-stream pipeline with batches gives the losses and boxes of the one-stream loop, step by step."""
+    from liso_amd.datasets.synthetic import slim_pair
+    from liso_amd.trainer import LisoLoopTrainer
+    from liso_amd.utils.config import apply_slim_simple_knn_training, default_cfg
+
+    dev = torch.device("cuda")
+    grid, rng = 256, 50.0
+    pairs = [slim_pair(31 + i, dev, n_points=40000, grid=grid, bev_range_m=rng) for i in range(6)]
+    out = []
+    for overlap in (False, True):
+        cfg = apply_slim_simple_knn_training(default_cfg(grid=grid, bev_range_m=rng))
+        torch.manual_seed(0)
+        tr = LisoLoopTrainer(cfg, dev, compute_dtype=torch.bfloat16, total_steps=20, use_graph=use_graph, overlap=overlap,
+                             infer_batch=2, flow_ahead=1)
+        if not overlap:  # (1) reference for the first step: per-pair mining + one detector step on the concatenation
+            torch.manual_seed(0)
+            ref = LisoLoopTrainer(cfg, dev, compute_dtype=torch.bfloat16, total_steps=20, use_graph=False, overlap=False)
+            ref.slim.load_state_dict(tr.slim.state_dict()), ref.detector.net.load_state_dict(tr.detector.net.state_dict())
+            ts = [ref._targets_from_flow(p[0], ref._infer_flow(*p))[0] for p in pairs[:2]]
+            cat = {k: torch.cat([t[k] for t in ts], dim=0) for k in ts[0]}
+            ref_loss = float(ref.detector.step([pairs[0][0]["pcl_full_no_ground_ta"][0], pairs[1][0]["pcl_full_no_ground_ta"][0]], cat))
+        losses, boxes = [], []
+        for i in range(5):
+            cur = [pairs[(2 * i + k) % 6] for k in range(2)]
+            up = [pairs[(2 * i + k) % 6] for k in range(2, 6)]
+            losses.append(float(tr.step_batch(cur, upcoming=up)))
+            for b in tr.last_boxes_batch:
+                allb = torch.cat([b.pos.float(), b.dims.float(), b.rot.float(), b.velo.float()], dim=-1)
+                boxes.append(allb[b.valid].cpu())
+        torch.cuda.synchronize()
+        if not overlap:
+            assert abs(losses[0] - ref_loss) <= 1e-6 * abs(ref_loss), (losses[0], ref_loss)
+        out.append((losses, boxes))
+    assert out[0][0] == out[1][0], (out[0][0], out[1][0])
+    assert len(out[0][1]) == 10
+    for a, b in zip(out[0][1], out[1][1]):
+        assert a.shape == b.shape and torch.equal(a, b)
+    assert out[0][0][-1] != out[0][0][0]
