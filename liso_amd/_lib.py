@@ -124,6 +124,15 @@ SIGNATURES = {
     "liso_conv_pack_weights_batched": (_i, [_vp, _i, _vp]),
     "liso_conv_in_finalize": (_i, [_vp, _i, _i, _i, _i, ctypes.c_long, _vp, _vp, _f, _vp, _vp]),
     "liso_residual_affine_relu_f32": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, ctypes.c_long, _i, _vp]),
+    # include/liso_box_mining.h
+    "liso_scan_workspace_bytes": (_sz, [_i, ctypes.c_long]),
+    "liso_scan_inclusive_i32": (_i, [_vp, _i, ctypes.c_long, _vp, _vp, _sz, _vp]),
+    "liso_mine_boxes_from_regions": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "liso_mine_filter_compact": (_i, [_vp] * 21),
+    "liso_mine_box_motion": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "liso_mine_nms_workspace_bytes": (_sz, [_i, _i]),
+    "liso_mine_nms_prepare": (_i, [_i, _i, _i] + [_vp] * 11 + [_sz, _vp]),
+    "liso_mine_nms_finish": (_i, [_i, _i, _i] + [_vp] * 16),
     # include/liso_optim.h
     "liso_adamw_step_f32": (_i, [_vp, _vp, _vp, _vp, _sz] + [ctypes.c_double] * 5 + [ctypes.c_long, _vp]),
     # include/liso_bn.h
@@ -205,6 +214,12 @@ class GruCfg(ctypes.Structure):
 class UpsampleCfg(ctypes.Structure):
     """mirror of liso_upsample_cfg (include/liso_slim.h)"""
     _fields_ = [("n_it", _i), ("batch2", _i), ("dirs", _i), ("h", _i), ("w", _i), ("factor", _i), ("flow_scale", _f)]
+
+
+class MineFilterCfg(ctypes.Structure):
+    """mirror of liso_mine_filter_cfg (include/liso_box_mining.h)"""
+    _fields_ = [("batch", _i), ("k", _i), ("min_points", _i), ("aspect_ratio_max", ctypes.c_double), ("max_box_len_m", ctypes.c_double),
+                ("min_box_area_m2", ctypes.c_double), ("min_box_volume_m3", ctypes.c_double), ("park_invalid", _i)]
 
 
 class TargetsCfg(ctypes.Structure):

@@ -89,3 +89,15 @@ class KabschDecoder(torch.nn.Module):
                               1.0 - buf, 1.0 + buf, name, bool(return_weights))
         S = pred_boxes_ta.pos.shape[1]
         return T[:, :S], w, cum[:, :S], T[:, S:], cum[:, S:]
+
+    @torch.no_grad()
+    def trafos_from_point_flow_packed(self, *, point_cloud_ta, valid_mask_ta, pointwise_flow_ta_tb, pred_boxes_ta: Shape,
+                                      sigmoid_slope=None, obj_dim_scale_buffer=None, softness_func=None):
+        """get_kabsch_trafos_from_point_flow without the weight map, as ONE tensor fp64 [B, S+1, 4, 4]: slots 0..S-1 the per-box
+        transforms, slot S the background transform (what liso_mine_box_motion of include/liso_box_mining.h takes)"""
+        slope = sigmoid_slope if sigmoid_slope is not None else self.cfg.mask_rendering.pred_sigmoid_slope
+        buf = obj_dim_scale_buffer if obj_dim_scale_buffer is not None else self.cfg.mask_rendering.obj_dim_scale_buffer
+        name = self.softness_name if softness_func is None else ("sigmoid" if softness_func is torch.sigmoid else "cauchy")
+        T, _, _ = self._run(pred_boxes_ta, point_cloud_ta, valid_mask_ta, pointwise_flow_ta_tb[:, :, 0:2], slope, 1.0 - buf, 1.0 + buf,
+                            name, False)
+        return T

@@ -63,7 +63,8 @@ def cluster_dynamic_pillars(dynamic_mask, bev_nonrigid_flow, row_coords_m, col_c
         L.check(L.TIMER.launch("dbscan_components", lambda: lib.liso_dbscan_components(
             ctypes.byref(cfg), L.ptr(dyn), L.ptr(xs), L.ptr(ys), L.ptr(flow), L.ptr(core), L.ptr(parent), L.ptr(is_root),
             L.stream_ptr())), "dbscan_components")
-        rank = torch.cumsum(is_root.view(B, -1), dim=1, dtype=torch.int32).view(B, gx, gy).contiguous()
+        from liso_amd.networks.flow_cluster_detector.mining_ops import inclusive_scan_i32
+        rank = inclusive_scan_i32(is_root.view(B, -1)).view(B, gx, gy)  # (own scan: no memset node when captured into a hipGraph)
         L.check(L.TIMER.launch("dbscan_labels", lambda: lib.liso_dbscan_labels(
             ctypes.byref(cfg), L.ptr(dyn), L.ptr(xs), L.ptr(ys), L.ptr(flow), L.ptr(core), L.ptr(parent), L.ptr(rank),
             L.ptr(labels), L.stream_ptr())), "dbscan_labels")
@@ -155,64 +156,49 @@ class FlowClusterDetector(torch.nn.Module):
             boxes = Shape.from_list_of_shapes([Shape.createEmpty().to_tensor().to(dev) for _ in range(B)], numeric_padding_value=0.0)
             return boxes if is_batched else boxes[0]
         props = label_region_props(labels, k_max)  # [B,K,5] float64
-        exists = torch.arange(k_max, device=dev)[None, :] < num_labels[:, None]
-        gx, gy = centers.shape[:2]
-        # reference :176-180: centroid -> int (truncation), clipped, then the centre of THAT pillar
-        pix = props[..., 0:2].to(torch.int64).clamp(min=0, max=min(gx, gy) - 1)
-        box_center_m = centers[pix[..., 0], pix[..., 1], 0:2]                                   # float32 [B,K,2]
-        rot = props[..., 2:3]                                                                    # float64 [B,K,1]
-        box_dims = props[..., 3:5] * 1.0 / self.bev_pixel_per_meter_resolution.to(dev)          # float64 [B,K,2]
-        assert box_dims.shape[-1] == 2, "otherwise box fitting will use bad box size from clustering!"
-        num_pts, fit_z, fit_h = [], [], []
+        from liso_amd.kabsch.shape_utils import Shape as _Shape
+        from liso_amd.networks.flow_cluster_detector import mining_ops as MO
+
+        # reference :176-206: one box per region (centroid -> pillar centre, axis lengths -> metres), one launch
+        ppm = self.bev_pixel_per_meter_res_np
+        center, dims2, rot1, dims2_f32, rot1_f32 = MO.boxes_from_regions(props, centers[:, 0, 0].contiguous(), centers[0, :, 1].contiguous(), ppm)
+        assert dims2.shape[-1] == 2, "otherwise box fitting will use bad box size from clustering!"
+        # z / height from the points inside every box (reference :339-384), all samples into one set of outputs
+        zbuf = torch.zeros(B * k_max * 16, dtype=torch.uint8, device=dev)
+        num_pts = zbuf[:B * k_max * 8].view(torch.int64).view(B, k_max)
+        fit_z = zbuf[B * k_max * 8:B * k_max * 12].view(torch.float32).view(B, k_max)
+        fit_h = zbuf[B * k_max * 12:].view(torch.float32).view(B, k_max)
+        lib = L.lib()
         for b in range(B):
-            pb = Shape(pos=box_center_m[b], dims=box_dims[b], rot=rot[b], probs=torch.ones_like(rot[b]))
-            n, z, h = fit_bev_box_z_and_height_using_points_in_box(pcl_w_ground[b][:, :3], pb, box_height=1000.0)
-            num_pts.append(n), fit_z.append(z), fit_h.append(h)
-        num_pts, fit_z, fit_h = torch.stack(num_pts), torch.stack(fit_z), torch.stack(fit_h)
-        # plausibility filters, reference :208-237
-        enough_points = num_pts >= self.min_num_pts_per_box
-        aspect_ratio = box_dims[..., 0] / torch.max(box_dims[..., 1], 0.001 * torch.ones_like(box_dims[..., 1]))
-        aspect_ok = aspect_ratio <= self.aspect_ratio_max
-        not_too_large = box_dims[..., 0] <= self.max_box_len_m
-        footprint_ok = torch.prod(box_dims[..., :2], dim=-1) > self.min_box_area_m2
-        dims3 = torch.cat([box_dims, fit_h[..., None].to(box_dims.dtype)], dim=-1)
-        pos3 = torch.cat([box_center_m, fit_z[..., None].to(box_center_m.dtype)], dim=-1)
-        volume_ok = torch.prod(dims3, dim=-1) > self.min_box_volume_m3
-        valid = exists & enough_points & aspect_ok & not_too_large & footprint_ok & volume_ok
-        # reference :239-248,311: drop the rejected boxes of every sample, pad the batch with zeros
-        counts = valid.sum(dim=1)
-        order = torch.argsort((~valid).to(torch.uint8), dim=1, stable=True)  # survivors first, label order kept
-        s_max = k_max if capacity else int(counts.max())  # host round trip 2
-        order = order[:, :s_max]
-        keep = torch.arange(s_max, device=dev)[None, :] < counts[:, None]
+            pts = pcl_w_ground[b][:, :3].float().contiguous()
+            nbytes = lib.liso_fit_box_z_workspace_bytes(pts.shape[0], k_max)
+            ws = torch.empty(max(nbytes, 8), dtype=torch.uint8, device=dev)
+            with torch.cuda.device(dev):
+                L.check(L.TIMER.launch("fit_box_z", lambda: lib.liso_fit_box_z_f32(
+                    L.ptr(pts), pts.shape[-1], pts.shape[0], L.ptr(center[b]), 2, L.ptr(dims2_f32[b]), 2, L.ptr(rot1_f32[b]), k_max,
+                    1000.0, L.ptr(num_pts[b]), L.ptr(fit_z[b]), L.ptr(fit_h[b]), L.ptr(ws), nbytes, L.stream_ptr())), "fit_box_z")
+        # plausibility filters + dropping the rejected boxes of every sample + zero padding (reference :208-248, :311), one launch
+        arr = MO.filter_compact(num_labels, center, dims2, rot1, num_pts, fit_z, fit_h, min_points=self.min_num_pts_per_box,
+                                aspect_ratio_max=self.aspect_ratio_max, max_box_len_m=self.max_box_len_m,
+                                min_box_area_m2=self.min_box_area_m2, min_box_volume_m3=self.min_box_volume_m3,
+                                park_invalid=bool(capacity))
+        s_max = k_max if capacity else int(arr["counts"].max())  # host round trip 2
 
-        def take(t, pad):
-            g = torch.gather(t, 1, order[..., None].expand(-1, -1, t.shape[-1]))
-            return torch.where(keep[..., None], g, pad)  # (scalar overload: no host->device copy)
+        def cut(t):
+            return t if s_max == t.shape[1] else t[:, :s_max].contiguous()
 
-        from liso_amd.kabsch.shape_utils import INVALID_CLASS_ID, UNKNOWN_CLASS_ID
-        probs = torch.ones_like(rot)
-        boxes = Shape(pos=take(pos3, 0.0), dims=take(dims3, 0.0), rot=take(rot, 0.0), probs=take(probs, 0.0),
-                      velo=torch.zeros((B, s_max, 1), dtype=probs.dtype, device=dev), valid=keep,
-                      class_id=torch.where(keep[..., None], UNKNOWN_CLASS_ID, INVALID_CLASS_ID).to(torch.int32),
-                      difficulty=torch.where(keep[..., None], 1, INVALID_CLASS_ID).to(torch.int32))
+        keep = cut(arr["valid"]).view(torch.bool)
+        boxes = _Shape(pos=cut(arr["pos"]), dims=cut(arr["dims"]), rot=cut(arr["rot"]), probs=cut(arr["probs"]), velo=cut(arr["velo"]),
+                       valid=keep, class_id=cut(arr["class_id"]), difficulty=cut(arr["difficulty"]))
         if s_max > 0:
-            # adapt the rotation of the box to the direction of the flow (reference :312-331)
-            kboxes = boxes
-            if capacity:
-                # the slots beyond the surviving boxes do not exist in the reference-shaped call: park them 1000 km away, where
-                # their soft mask is exactly 0 in fp32 and the background weight prod_s (1 - w_s) does not see them
-                kboxes = Shape(pos=torch.where(keep[..., None], boxes.pos, 1e6), dims=boxes.dims, rot=boxes.rot, probs=boxes.probs,
-                               valid=keep)
-            fg_trafos, _, _, bg_trafo, _ = self.kabsch_decoder.get_kabsch_trafos_from_point_flow(
-                point_cloud_ta=pcl[..., :3], valid_mask_ta=pcl_is_valid, pointwise_flow_ta_tb=point_flow, pred_boxes_ta=kboxes,
-                return_weights=False)
-            box_translation, _ = extract_motion_in_pred_box_coordinates(boxes, fg_trafos, bg_trafo, check=not capacity)
-            delta_angle = torch.atan2(box_translation[..., 1:2], box_translation[..., 0:1])  # (slices: a list index is a host->device copy)
-            box_velo = torch.zeros_like(boxes.probs)
-            box_velo[..., 0] = torch.linalg.norm(box_translation, dim=-1)
-            boxes.rot = boxes.rot + delta_angle
-            boxes.velo = box_velo
+            # adapt the rotation of the box to the direction of the flow (reference :312-331).  The slots beyond the surviving boxes do
+            # not exist in the reference-shaped call: with fixed slots their Kabsch copies are parked 1000 km away, where their soft
+            # mask is exactly 0 in fp32 and the background weight prod_s (1 - w_s) does not see them
+            kboxes = _Shape(pos=cut(arr["kabsch_pos"]), dims=cut(arr["kabsch_dims"]), rot=cut(arr["kabsch_rot"])[..., None],
+                            probs=boxes.probs, valid=keep)
+            trafos = self.kabsch_decoder.trafos_from_point_flow_packed(
+                point_cloud_ta=pcl[..., :3], valid_mask_ta=pcl_is_valid, pointwise_flow_ta_tb=point_flow, pred_boxes_ta=kboxes)
+            MO.box_motion(trafos, boxes.pos, boxes.rot, boxes.velo)  # heading += atan2(t_y, t_x), speed = |t|, one launch
         if not is_batched:
             boxes = boxes[0]
             assert len(boxes.shape) == 1, boxes.shape

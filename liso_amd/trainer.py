@@ -758,7 +758,6 @@ class LisoLoopTrainer:
         `also`: further pairs that join the SLIM inference batch, as in the pipeline's stage A (the kernels are then timed at the
         batch they run at; their launches count len(pairs) / (len(pairs) + len(also)) towards this step)"""
         from liso_amd import _lib as L
-        from liso_amd.datasets.targets import render_center_targets
 
         g, self._graph_infer = self._graph_infer, False
         try:
@@ -773,16 +772,9 @@ class LisoLoopTrainer:
                 finally:
                     L.TIMER.weight = 1.0
                 b = flow.shape[0] // len(allp)
-                boxes = [self._targets_from_flow(p_[0], flow[k * b:(k + 1) * b].contiguous())[1] for k, p_ in enumerate(pairs)]
+                per = [self._targets_from_flow(p_[0], flow[k * b:(k + 1) * b].contiguous())[0] for k, p_ in enumerate(pairs)]
         finally:
             self._graph_infer = g
-        out = tuple(int(v) // 4 for v in self.cfg.data.img_grid_size)
-        per = []
-        for bx in boxes:
-            if bx.shape[1] == 0:
-                return None
-            per.append(render_center_targets(bx.pos.float(), bx.dims.float().clamp(min=1e-3), bx.rot.float(), bx.valid, out,
-                                             tuple(self.cfg.data.bev_range_m)))
         targets = per[0] if len(per) == 1 else {k: torch.cat([t[k] for t in per], dim=0) for k in per[0]}
         return self.detector.eager_pass([c for p_ in pairs for c in p_[0]["pcl_full_no_ground_ta"]], targets)
 
@@ -797,16 +789,17 @@ class LisoLoopTrainer:
             sample = dict(sample_t0)
             sample[self.cfg.data.flow_source] = {**sample_t0.get(self.cfg.data.flow_source, {}), "flow_ta_tb": flow}
             boxes = self.cluster_detector(sample, global_step=1, capacity=capacity)
-            if boxes.shape[1] > 0:
-                boxes = perform_nms_on_shapes_padded(boxes, max_num_boxes=self.post_nms, overlap_threshold=self.nms_iou,
-                                                     pre_nms_max_num_boxes=self.pre_nms)
-                boxes.set_padding_val_to(0.0)
             B = boxes.shape[0]
-            if boxes.shape[1] == 0:  # nothing moved: an all-background target (one padded slot)
+            if boxes.shape[1] > 0:
+                # confidence order, pre-NMS cut, rotated NMS, post-NMS selection, padding values: 3 small launches around the NMS
+                # kernels; the fp32 box arrays for the target renderer come out of the last one
+                boxes, (pos, dims, rot, valid) = perform_nms_on_shapes_padded(
+                    boxes, max_num_boxes=self.post_nms, overlap_threshold=self.nms_iou, pre_nms_max_num_boxes=self.pre_nms,
+                    return_target_arrays=True)
+                rot = rot[..., None]
+            else:  # nothing moved: an all-background target (one padded slot)
                 z = torch.zeros((B, 1, 3), device=self.device)
                 pos, dims, rot, valid = z, z + 1.0, z[..., :1], torch.zeros((B, 1), dtype=torch.bool, device=self.device)
-            else:
-                pos, dims, rot, valid = boxes.pos.float(), boxes.dims.float().clamp(min=1e-3), boxes.rot.float(), boxes.valid
             out = tuple(int(g) // 4 for g in self.cfg.data.img_grid_size)
             return render_center_targets(pos, dims, rot, valid, out, tuple(self.cfg.data.bev_range_m)), boxes
 
