@@ -98,6 +98,6 @@ class KabschDecoder(torch.nn.Module):
         slope = sigmoid_slope if sigmoid_slope is not None else self.cfg.mask_rendering.pred_sigmoid_slope
         buf = obj_dim_scale_buffer if obj_dim_scale_buffer is not None else self.cfg.mask_rendering.obj_dim_scale_buffer
         name = self.softness_name if softness_func is None else ("sigmoid" if softness_func is torch.sigmoid else "cauchy")
-        T, _, _ = self._run(pred_boxes_ta, point_cloud_ta, valid_mask_ta, pointwise_flow_ta_tb[:, :, 0:2], slope, 1.0 - buf, 1.0 + buf,
-                            name, False)
+        # (the kernel reads x, y, z / flow x, y with the row strides: no [..., :3] / [..., 0:2] copies)
+        T, _, _ = self._run(pred_boxes_ta, point_cloud_ta, valid_mask_ta, pointwise_flow_ta_tb, slope, 1.0 - buf, 1.0 + buf, name, False)
         return T

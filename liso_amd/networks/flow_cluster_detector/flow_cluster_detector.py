@@ -118,14 +118,19 @@ class FlowClusterDetector(torch.nn.Module):
         dy = float(np.float32(c[0, 1, 1]) - np.float32(c[0, 0, 1])) if c.shape[1] > 1 else 1.0
         self._pitch = min(dx, dy)
         self.last_num_labels = None
+        # metric pillar centres per row / column as dense vectors (the kernels' inputs; slices of the [gx,gy,4] Parameter are strided)
+        self.register_buffer("_row_coords", torch.from_numpy(np.ascontiguousarray(c[:, 0, 0])).float(), persistent=False)
+        self.register_buffer("_col_coords", torch.from_numpy(np.ascontiguousarray(c[0, :, 1])).float(), persistent=False)
 
     @torch.no_grad()
     def forward(self, sample_data_ta, writer=None, writer_prefix: str = "", global_step: int = None, is_batched=True,
-                capacity: int = None) -> Shape:
+                capacity: int = None, odom_minus_eye=None) -> Shape:
         """`capacity` (extension): fixed number of cluster / box slots.  The padded Shape then always has `capacity` columns and
         the forward issues NO device->host read (the reference-shaped call reads the cluster count and the surviving-box count to
         size its arrays); valid boxes, their order and values are the same as long as the cluster count (`self.last_num_labels`,
-        a device tensor the caller checks later) does not exceed `capacity`."""
+        a device tensor the caller checks later) does not exceed `capacity`.
+        `odom_minus_eye` (extension): inv(odom_ta_tb) - I as fp64 [B,4,4], computed by the caller (a library LU inverse: callers that
+        replay this method from a hipGraph evaluate it eagerly in front of the replay)."""
         pcl = sample_data_ta["pcl_ta"]["pcl"]
         pcl_w_ground = sample_data_ta["pcl_full_w_ground_ta"]
         pillar_coors = sample_data_ta["pcl_ta"]["pillar_coors"]
@@ -141,10 +146,10 @@ class FlowClusterDetector(torch.nn.Module):
         dev = pcl.device
         bev_dynamicness, bev_nonrigid_flow = get_bev_dynamic_flow_map_from_pcl_flow_and_odom(
             pcl_is_valid=pcl_is_valid, pcl=pcl, pillar_coors=pillar_coors, point_flow=point_flow, odom_ta_tb=odom_ta_tb,
-            target_shape=self.bev_img_grid_size, return_nonrigid_bev_flow=True)
+            target_shape=self.bev_img_grid_size, return_nonrigid_bev_flow=True, odom_minus_eye=odom_minus_eye)
         dynamic_mask = torch.squeeze(bev_dynamicness, dim=-1) > thresh.to(dev)[..., None, None]
         centers = self.pcl_bev_center_coords_homog  # [gx,gy,4] float32; x depends on the row only, y on the column only
-        labels, num_labels = cluster_dynamic_pillars(dynamic_mask, bev_nonrigid_flow, centers[:, 0, 0], centers[0, :, 1],
+        labels, num_labels = cluster_dynamic_pillars(dynamic_mask, bev_nonrigid_flow, self._row_coords, self._col_coords,
                                                      pitch=self._pitch if capacity else None)
         self.last_bev_labels, self.last_num_labels = labels, num_labels
         B = labels.shape[0]
@@ -161,7 +166,7 @@ class FlowClusterDetector(torch.nn.Module):
 
         # reference :176-206: one box per region (centroid -> pillar centre, axis lengths -> metres), one launch
         ppm = self.bev_pixel_per_meter_res_np
-        center, dims2, rot1, dims2_f32, rot1_f32 = MO.boxes_from_regions(props, centers[:, 0, 0].contiguous(), centers[0, :, 1].contiguous(), ppm)
+        center, dims2, rot1, dims2_f32, rot1_f32 = MO.boxes_from_regions(props, self._row_coords, self._col_coords, ppm)
         assert dims2.shape[-1] == 2, "otherwise box fitting will use bad box size from clustering!"
         # z / height from the points inside every box (reference :339-384), all samples into one set of outputs
         zbuf = torch.zeros(B * k_max * 16, dtype=torch.uint8, device=dev)
@@ -170,7 +175,7 @@ class FlowClusterDetector(torch.nn.Module):
         fit_h = zbuf[B * k_max * 12:].view(torch.float32).view(B, k_max)
         lib = L.lib()
         for b in range(B):
-            pts = pcl_w_ground[b][:, :3].float().contiguous()
+            pts = pcl_w_ground[b].float().contiguous()  # [M, >= 3]: the kernel reads x, y, z with the row stride
             nbytes = lib.liso_fit_box_z_workspace_bytes(pts.shape[0], k_max)
             ws = torch.empty(max(nbytes, 8), dtype=torch.uint8, device=dev)
             with torch.cuda.device(dev):
@@ -197,7 +202,7 @@ class FlowClusterDetector(torch.nn.Module):
             kboxes = _Shape(pos=cut(arr["kabsch_pos"]), dims=cut(arr["kabsch_dims"]), rot=cut(arr["kabsch_rot"])[..., None],
                             probs=boxes.probs, valid=keep)
             trafos = self.kabsch_decoder.trafos_from_point_flow_packed(
-                point_cloud_ta=pcl[..., :3], valid_mask_ta=pcl_is_valid, pointwise_flow_ta_tb=point_flow, pred_boxes_ta=kboxes)
+                point_cloud_ta=pcl, valid_mask_ta=pcl_is_valid, pointwise_flow_ta_tb=point_flow, pred_boxes_ta=kboxes)
             MO.box_motion(trafos, boxes.pos, boxes.rot, boxes.velo)  # heading += atan2(t_y, t_x), speed = |t|, one launch
         if not is_batched:
             boxes = boxes[0]

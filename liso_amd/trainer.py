@@ -552,6 +552,29 @@ class _Prefetched:
         return self.pair[0] is pair[0] and self.pair[1] is pair[1]
 
 
+def _pack_tensors(named):
+    """[(name, tensor)] -> (flat uint8 tensor = ONE torch.cat launch, layout) with every segment aligned for its dtype: 8-byte types
+    first, then 4-byte, then the rest"""
+    order = sorted(range(len(named)), key=lambda i: -named[i][1].element_size())
+    layout, parts, off = [], [], 0
+    for i in order:
+        name, t = named[i]
+        t = t.contiguous()
+        u = t.view(torch.uint8) if t.dtype != torch.bool else t.view(torch.uint8)
+        layout.append((name, off, u.numel(), t.dtype, tuple(t.shape)))
+        parts.append(u.reshape(-1))
+        off += u.numel()
+    return torch.cat(parts), layout
+
+
+def _unpack_tensors(flat, layout):
+    out = {}
+    for name, off, nbytes, dtype, shape in layout:
+        seg = flat[off:off + nbytes]
+        out[name] = (seg.view(torch.uint8).view(dtype) if dtype != torch.bool else seg.view(torch.bool)).view(shape)
+    return out
+
+
 class _BatchedTargets(dict):
     """target maps of a batch given as one dict per sample ([1, ...] tensors): behaves like the concatenated dict (built lazily,
     one torch.cat per key) and lets the graph path copy sample by sample into its captured inputs without concatenating"""
@@ -612,6 +635,8 @@ class LisoLoopTrainer:
         self._graph_det = self.use_graph and use_graph in (True, "detector")
         import collections
         self._infer_graph, self._infer_graphs = None, collections.OrderedDict()
+        self._mine_graphs = collections.OrderedDict()
+        self._graph_mine = self.use_graph and use_graph is True
         # real sweeps differ in their point count from sample to sample: the padded loss clouds are grown to the next multiple of
         # `infer_point_bucket` rows (NaN rows, pcl_is_valid False, pillar_coors -1: the dataset's own collate padding,
         # torch_dataset_commons.py:380-431) so that the inference graph's input signature repeats, and at most `max_infer_graphs`
@@ -778,7 +803,59 @@ class LisoLoopTrainer:
         targets = per[0] if len(per) == 1 else {k: torch.cat([t[k] for t in per], dim=0) for k in per[0]}
         return self.detector.eager_pass([c for p_ in pairs for c in p_[0]["pcl_full_no_ground_ta"]], targets)
 
-    def _targets_from_flow(self, sample_t0, flow, capacity=None):
+    def _mine_from_graph(self, sample_t0, flow, side):
+        """stage B of one sweep pair -- flow clustering, z-fit, filters, Kabsch heading, NMS, target maps with `box_capacity` fixed
+        slots -- replayed from a hipGraph on stream `side` (the caller's current stream): ~45 nodes, no scan / sort library call and
+        therefore no memset node (liso_amd/utils/graph_safety.py), no host read.  The pair's tensors are copied into the captured
+        inputs, inv(odom) - I (a library LU inverse that depends on the sample only) is computed eagerly in front of the replay, and
+        all results come out of ONE packed buffer that is cloned behind the replay (the next replay overwrites the captured one).
+        -> (targets dict, boxes Shape, max cluster count int64 [1])"""
+        from liso_amd.kabsch.shape_utils import Shape
+        from liso_amd.utils.bev_flow_utils import odometry_minus_identity
+
+        dev = self.device
+        pa = sample_t0["pcl_ta"]
+        gt = sample_t0[self.cfg.data.odom_source]
+        ome = gt.get("_odom_minus_eye")
+        if ome is None:  # once per sample object
+            ome = gt["_odom_minus_eye"] = odometry_minus_identity(gt["odom_ta_tb"].to(dev))
+        ins = {"pcl": pa["pcl"], "valid": pa["pcl_is_valid"], "coors": pa["pillar_coors"], "full": sample_t0["pcl_full_w_ground_ta"],
+               "flow": flow, "ome": ome, "dt": sample_t0["src_trgt_time_delta_s"], "odom": gt["odom_ta_tb"]}
+        sig = tuple((k, tuple(v.shape), v.dtype) for k, v in ins.items())
+        st = self._mine_graphs.get(sig)
+        if st is not None:
+            self._mine_graphs.move_to_end(sig)
+            for k, v in ins.items():
+                st["in"][k].copy_(v, non_blocking=True)
+        else:
+            while len(self._mine_graphs) >= max(self.max_infer_graphs, 1):
+                self._mine_graphs.popitem(last=False)[1].clear()
+            st = self._mine_graphs[sig] = {"in": {k: v.to(dev).clone() for k, v in ins.items()}}
+            si = st["in"]
+            sample = {"pcl_ta": {"pcl": si["pcl"], "pcl_is_valid": si["valid"], "pillar_coors": si["coors"]},
+                      "pcl_full_w_ground_ta": si["full"], "src_trgt_time_delta_s": si["dt"],
+                      self.cfg.data.odom_source: {"odom_ta_tb": si["odom"]}}
+
+            def body():
+                targets, boxes = self._targets_from_flow(sample, si["flow"], capacity=self.box_capacity, odom_minus_eye=si["ome"])
+                named = [("t_" + k, v) for k, v in targets.items()] + \
+                    [("b_" + k, v) for k, v in boxes.__dict__.items() if torch.is_tensor(v)] + \
+                    [("n_clusters", self.cluster_detector.last_num_labels.max().reshape(1))]
+                return _pack_tensors(named)
+
+            with torch.no_grad():
+                for _ in range(2):  # warm-up on the capture stream: lazy initialisations, allocator pools
+                    body()
+                st["graph"] = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(st["graph"], stream=side):
+                    st["flat"], st["layout"] = body()
+        st["graph"].replay()
+        out = _unpack_tensors(st["flat"].clone(), st["layout"])
+        targets = {k[2:]: v for k, v in out.items() if k.startswith("t_")}
+        boxes = Shape(**{k[2:]: v for k, v in out.items() if k.startswith("b_")})
+        return targets, boxes, out["n_clusters"]
+
+    def _targets_from_flow(self, sample_t0, flow, capacity=None, odom_minus_eye=None):
         """flow clustering -> NMS -> CenterPoint target maps.  Reference-shaped call: two box-count reads size the padded Shape.
         `capacity`: fixed number of box slots and no device->host read at all (FlowClusterDetector.forward); the caller compares
         `self.cluster_detector.last_num_labels` with the capacity later."""
@@ -788,7 +865,7 @@ class LisoLoopTrainer:
         with torch.no_grad():
             sample = dict(sample_t0)
             sample[self.cfg.data.flow_source] = {**sample_t0.get(self.cfg.data.flow_source, {}), "flow_ta_tb": flow}
-            boxes = self.cluster_detector(sample, global_step=1, capacity=capacity)
+            boxes = self.cluster_detector(sample, global_step=1, capacity=capacity, odom_minus_eye=odom_minus_eye)
             B = boxes.shape[0]
             if boxes.shape[1] > 0:
                 # confidence order, pre-NMS cut, rotated NMS, post-NMS selection, padding values: 3 small launches around the NMS
@@ -859,9 +936,13 @@ class LisoLoopTrainer:
             # fixed number of box slots: the host only enqueues (no box-count reads).  The cluster count goes to pinned memory
             # behind the work; step() looks at it when it takes the result (long after this stream got there) and redoes the
             # pair with the reference-shaped call in the -- so far never seen -- case of more clusters than slots.
-            targets, boxes = self._targets_from_flow(pair[0], f.flow, capacity=self.box_capacity)
             count = torch.empty(1, dtype=torch.int64, pin_memory=True)
-            count.copy_(self.cluster_detector.last_num_labels.max().reshape(1), non_blocking=True)
+            if self._graph_mine:
+                targets, boxes, n_clusters = self._mine_from_graph(pair[0], f.flow, side)
+                count.copy_(n_clusters, non_blocking=True)
+            else:
+                targets, boxes = self._targets_from_flow(pair[0], f.flow, capacity=self.box_capacity)
+                count.copy_(self.cluster_detector.last_num_labels.max().reshape(1), non_blocking=True)
             done = torch.cuda.Event()
             done.record(side)
         self._mined.append(_Prefetched(pair=pair, flow=f.flow, done=done, targets=targets, boxes=boxes, cluster_count=count))

@@ -8,7 +8,7 @@ from liso_amd import _lib as L
 
 @torch.no_grad()
 def get_bev_dynamic_flow_map_from_pcl_flow_and_odom(*, pcl_is_valid, pcl, pillar_coors, point_flow, odom_ta_tb,
-                                                    target_shape, return_nonrigid_bev_flow=False):
+                                                    target_shape, return_nonrigid_bev_flow=False, odom_minus_eye=None):
     L.require_cuda(pcl, point_flow)
     B, N = pcl_is_valid.shape
     h, w = int(target_shape[0]), int(target_shape[1])
@@ -20,7 +20,7 @@ def get_bev_dynamic_flow_map_from_pcl_flow_and_odom(*, pcl_is_valid, pcl, pillar
     coors = pillar_coors.to(torch.int32).contiguous()
     # bev_flow_utils.py:30-33: inv(odom) - I in fp64 (a [B,4,4] LU inverse; not worth a kernel)
     # (inv_ex = the same LU inverse without torch.linalg.inv's singularity check, which is a device->host read)
-    ome = (torch.linalg.inv_ex(odom_ta_tb.double()).inverse - torch.eye(4, device=dev, dtype=torch.float64)[None]).contiguous()
+    ome = odom_minus_eye if odom_minus_eye is not None else odometry_minus_identity(odom_ta_tb)
     dyn = torch.empty((B, h, w, 1), dtype=torch.float32, device=dev)
     nrf = torch.empty((B, h, w, 3), dtype=torch.float32, device=dev)
     lib = L.lib()
@@ -33,3 +33,10 @@ def get_bev_dynamic_flow_map_from_pcl_flow_and_odom(*, pcl_is_valid, pcl, pillar
     if return_nonrigid_bev_flow:
         return dyn, nrf
     return dyn
+
+
+@torch.no_grad()
+def odometry_minus_identity(odom_ta_tb):
+    """inv(odom_ta_tb) - I in fp64 [B,4,4] (bev_flow_utils.py:30-33): depends on the sample only"""
+    dev = odom_ta_tb.device
+    return (torch.linalg.inv_ex(odom_ta_tb.double()).inverse - torch.eye(4, device=dev, dtype=torch.float64)[None]).contiguous()
