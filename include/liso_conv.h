@@ -104,6 +104,15 @@ int liso_conv_forward(const liso_conv_desc* d, const void* x, const void* w_pack
                       const float* in_scale, const float* in_shift, void* y, float* stats_partial,
                       const float* stats_shift, void* stream);
 
+/* The same for a SPARSE input: `occupancy` fp32 [batch, hi, wi] with 0 where the input pixel is exactly zero in every channel
+ * (the pillar canvas of liso/networks/pcl_to_feature_grid, whose occupancy map PointPillarsScatter produces beside it,
+ * pillar_scatter.py:62-102): blocks whose whole input window is unoccupied skip their loads and multiplications -- they
+ * would only add exact zeros -- and write bias / ReLU / statistics like every other block.  Results are bit-identical to
+ * liso_conv_forward.  Requires in_scale == NULL (a prologue would turn the zeros into relu(shift)).  occupancy == NULL: dense. */
+int liso_conv_forward_sparse(const liso_conv_desc* d, const void* x, const void* w_packed, const float* bias,
+                             const float* in_scale, const float* in_shift, void* y, float* stats_partial,
+                             const float* stats_shift, const float* occupancy, void* stream);
+
 /* Weight gradient of the convolution described by `d` (a FORWARD descriptor: x = layer input, with the same optional
  * prologue, dy = gradient of the layer output [batch, ho, wo, co] with pixel stride dy_pix_stride):
  *   dw[co][ci][kh][kw] (torch layout of nn.Conv2d; transposed != 0: [ci][co][kh][kw]) = sum over pixels, overwritten;

@@ -148,6 +148,7 @@ SIGNATURES = {
     "liso_conv_pack_weights": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "liso_conv_stats_rows": (_i, [_vp]),
     "liso_conv_forward": (_i, [_vp] * 10),
+    "liso_conv_forward_sparse": (_i, [_vp] * 11),
     "liso_conv_wgrad_workspace_bytes": (_sz, [_vp]),
     "liso_conv_wgrad": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "liso_conv_bn_finalize": (_i, [_vp, _i, _i, _i, ctypes.c_long, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp]),

@@ -54,6 +54,7 @@ struct FwdArgs {
     int x_plane_bytes;  // LDS bytes of one plane of the input tile (max over classes), multiple of 16
     int pipelined;      // one register batch holds a whole slab: loads of slab k+1 overlap the MFMAs of slab k
     int group_bytes;    // LDS bytes of one split-K group's tile + panels (SK = 2 instantiations)
+    const float* occ;   // optional [batch, hi, wi]: 0 = the input pixel is exactly zero in every channel (sparse BEV canvases)
     int a8;             // 8-wave kernel with the weight panels streamed by LDS-DMA (conv_igemm8_kernel)
     int stage_taps;     // a8: taps per weight stage
     int ring;           // a8: weight stages resident in LDS (2..4): stage s + ring - 1 is in flight while stage s is multiplied
@@ -125,6 +126,28 @@ __global__ __launch_bounds__(kThreads * SK, SK == 1 ? 2 : 1) void conv_igemm_ker
     if (tid_all < te - tb) {
         s_toff[tid_all] = ((d.tap_dy[tb + tid_all] - dy0) * in_w + (d.tap_dx[tb + tid_all] - dx0)) * PS;
         s_tapw[tid_all] = d.tap_w[tb + tid_all];
+    }
+    // Sparse input (the pillar canvas in front of the encoders' first convolution: a few percent of the BEV cells hold points): a
+    // block whose whole halo tile is unoccupied multiplies exact zeros -- its accumulators stay +0 and it goes straight to the
+    // epilogue (bias / ReLU / statistics), bit for bit what the full computation gives, without reading the tile or the weights.
+    bool tile_empty = false;
+    if (a.occ) {
+        int any = 0;
+        const float* oc = a.occ + (long)b * d.hi * d.wi;
+        for (int pix = tid_all; pix < npix; pix += kThreads * SK) {
+            const int ly = pix / in_w, lx = pix - ly * in_w;
+            const int iy = iy0 + ly, ix = ix0 + lx;
+            if ((unsigned)iy < (unsigned)d.hi && (unsigned)ix < (unsigned)d.wi) any |= oc[iy * d.wi + ix] != 0.0f;
+        }
+        // block-wide OR through the (not yet used) front of the tile buffer: __syncthreads_or would add static LDS on top of the
+        // 160 KB dynamic allocation
+        int* flag = reinterpret_cast<int*>(smem + 512);  // (group 0's buffer: one flag for the whole block)
+        if (tid_all == 0) *flag = 0;
+        __syncthreads();
+        if (any) *flag = 1;
+        __syncthreads();
+        tile_empty = *flag == 0;
+        __syncthreads();
     }
 
     int a_off[MI];
@@ -327,7 +350,9 @@ __global__ __launch_bounds__(kThreads * SK, SK == 1 ? 2 : 1) void conv_igemm_ker
         }
     };
 
-    if constexpr (SK > 1) {
+    if (tile_empty) {
+        // nothing to accumulate
+    } else if constexpr (SK > 1) {
         // (always pipelined) the groups take alternate slabs; both run the same number of barriers
         uint4 xv[XB], wv[WB];
         unsigned xok = 0u;
@@ -1390,7 +1415,14 @@ int liso_conv_stats_rows(const liso_conv_desc* d) {
 
 int liso_conv_forward(const liso_conv_desc* d, const void* x, const void* w_packed, const float* bias, const float* in_scale,
                       const float* in_shift, void* y, float* stats_partial, const float* stats_shift, void* stream) {
+    return liso_conv_forward_sparse(d, x, w_packed, bias, in_scale, in_shift, y, stats_partial, stats_shift, nullptr, stream);
+}
+
+int liso_conv_forward_sparse(const liso_conv_desc* d, const void* x, const void* w_packed, const float* bias, const float* in_scale,
+                             const float* in_shift, void* y, float* stats_partial, const float* stats_shift,
+                             const float* occupancy, void* stream) {
     if (!d || !x || !w_packed || !y) return LISO_EINVAL;
+    if (occupancy && in_scale) return LISO_EINVAL;  // (a prologue maps zeros to relu(shift): the tile is no longer zero)
     if ((in_scale == nullptr) != (in_shift == nullptr)) return LISO_EINVAL;
     if (((uintptr_t)x | (uintptr_t)w_packed) & 15) return LISO_EINVAL;
     Plan p;
@@ -1403,6 +1435,8 @@ int liso_conv_forward(const liso_conv_desc* d, const void* x, const void* w_pack
     p.a.y = y;
     p.a.stats = stats_partial;
     p.a.stats_shift = stats_shift;
+    p.a.occ = occupancy;
+    if (occupancy) p.a.a8 = 0;  // (the tile-skipping test lives in the 4-wave kernel)
     hipStream_t st = (hipStream_t)stream;
     const bool x3 = d->mode == LISO_CONV_F32X3;
     const bool of32 = x3 || d->out_f32;

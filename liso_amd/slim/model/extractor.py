@@ -104,7 +104,9 @@ class SmallEncoder(nn.Module):
         return all(b.foldable() and MC._norm_kind(b.norm1) == MC._norm_kind(self.norm1) for b in blocks) and \
             MC.supported(x, self.conv1.weight, MC.ConvSpec.of(self.conv1))
 
-    def forward(self, x):
+    def forward(self, x, occupancy=None):
+        """`occupancy` (extension, inference): the occupancy map of the pillar canvas `x` (fp32 [B,1,H,W], 0 = no pillar): the first
+        convolution then skips the tiles of the (sparse) BEV canvas that hold no pillar at all -- same result, bit for bit"""
         is_list = isinstance(x, (tuple, list))
         if is_list:
             batch_dim = x[0].shape[0]
@@ -113,7 +115,7 @@ class SmallEncoder(nn.Module):
             # inference: every InstanceNorm + ReLU is applied by its consumer, residual tails are one kernel (mfma_conv.InFold)
             from liso_amd.utils import mfma_conv as MC
 
-            h, fold = MC.conv_in(x, None, self.conv1, self.norm1)
+            h, fold = MC.conv_in(x, None, self.conv1, self.norm1, occupancy=occupancy if not is_list else None)
             for blk in list(self.layer1) + list(self.layer2) + list(self.layer3):
                 h, fold = blk.forward_inference(h, fold), None
             x = conv2d(self.conv2, h)

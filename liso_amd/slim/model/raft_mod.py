@@ -98,11 +98,15 @@ class RAFT(nn.Module):
         img_t0, occ_t0, img_t1, occ_t1 = canvases[:4]
         aux = {"t0": {"bev_net_input_dbg": occ_t0}, "t1": {"bev_net_input_dbg": occ_t1}}
         B = img_t0.shape[0]
-        fmap = self.fnet(canvases[4] if len(canvases) > 4 else torch.cat([img_t0, img_t1], dim=0))
-        out = self.predict_single_flow_map_and_classes(img_t0, fmap[:B], fmap[B:], self.head_decoder_fw, only_last=True)
+        # (canvases[4] / [5]: both sweeps stacked along the batch axis and their occupancy maps, when the caller holds them that way)
+        occ_all = canvases[5] if len(canvases) > 5 else None
+        fmap = self.fnet(canvases[4] if len(canvases) > 4 else torch.cat([img_t0, img_t1], dim=0), occupancy=occ_all)
+        out = self.predict_single_flow_map_and_classes(img_t0, fmap[:B], fmap[B:], self.head_decoder_fw, only_last=True,
+                                                       occupancy_t0=occ_t0)
         return out[-1], aux
 
-    def predict_single_flow_map_and_classes(self, img_t0, fmap_t0, fmap_t1, decoder, only_last=False, fused_dirs=None):
+    def predict_single_flow_map_and_classes(self, img_t0, fmap_t0, fmap_t1, decoder, only_last=False, fused_dirs=None,
+                                            occupancy_t0=None):
         """reference :124-259.  `only_last` (extension, inference): upsample / assemble the network output of the last
         iteration only -- the intermediate ones exist for the training loss.  `fused_dirs` (extension): the batch holds
         `fused_dirs` flow directions x B samples; the outputs of all iterations are then assembled by one launch
@@ -118,7 +122,7 @@ class RAFT(nn.Module):
         use_w = m.predict_weight_for_static_aggregation is not False
         wl = torch.zeros((b, 1, h, w), dtype=torch.float32, device=img_t0.device) if use_w else None
         correlation = CorrBlock(fmap_t0, fmap_t1, num_levels=m.corr_cfg.num_levels, radius=m.corr_cfg.search_radius)
-        cnet = self.cnet(img_t0)
+        cnet = self.cnet(img_t0, occupancy=occupancy_t0) if occupancy_t0 is not None else self.cnet(img_t0)
         net, inp = torch.split(cnet, [self.hidden_dim, self.context_dim], dim=1)
         net, inp = torch.tanh(net), torch.relu(inp)
         # (rows, cols) metres per pixel; equal (asserted in __init__), so a python scalar does the job of the reference's

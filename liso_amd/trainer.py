@@ -756,7 +756,7 @@ class LisoLoopTrainer:
             rows = torch.cat([canv[0], canv[2]], dim=0).permute(0, 2, 3, 1).contiguous()  # [2B, gx, gy, 64]
             occ = torch.cat([canv[1], canv[3]], dim=0).contiguous()
             st["rows"] = (rows, occ)
-            st["canv"] = (rows[:B_].permute(0, 3, 1, 2), occ[:B_], rows[B_:].permute(0, 3, 1, 2), occ[B_:], rows.permute(0, 3, 1, 2))
+            st["canv"] = (rows[:B_].permute(0, 3, 1, 2), occ[:B_], rows[B_:].permute(0, 3, 1, 2), occ[B_:], rows.permute(0, 3, 1, 2), occ)
             st["thr"] = thr.clone()
             s0, s1 = st["in"]
             side = self._flow_stream  # (HIP maps streams onto 4 hardware queues: capture on a pipeline stream, no extra one)

@@ -293,9 +293,11 @@ def _bytes(d, wgrad=False):
 
 
 def conv_forward(x, weight, bias, spec, in_scale=None, in_shift=None, in_relu=False, out_relu=False, out_dtype=None,
-                 want_stats=False, stats_shift=None, packed=None, affine_batch_stride=0):
+                 want_stats=False, stats_shift=None, packed=None, affine_batch_stride=0, occupancy=None):
     """x: logical [B,Ci,H,W] (channels-last storage preferred) -> (y logical [B,Co,Ho,Wo] channels-last, stats_partial | None).
-    `affine_batch_stride` > 0: in_scale / in_shift hold one vector per sample, that many elements apart (InstanceNorm)."""
+    `affine_batch_stride` > 0: in_scale / in_shift hold one vector per sample, that many elements apart (InstanceNorm).
+    `occupancy`: fp32 [B,1,H,W] / [B,H,W], 0 where x is exactly zero in every channel (the pillar canvas's occupancy map): blocks
+    whose whole input window is unoccupied skip their loads and MFMAs (bit-identical result; no prologue allowed)."""
     L.require_cuda(x, weight)
     mode = _mode(x.dtype)
     xv, xps = as_nhwc(x, _vec(mode))
@@ -324,11 +326,16 @@ def conv_forward(x, weight, bias, spec, in_scale=None, in_shift=None, in_relu=Fa
     b = bias.detach() if bias is not None else None
     if b is not None and (b.dtype != torch.float32 or not b.is_contiguous()):
         b = b.float().contiguous()
+    occ = None
+    if occupancy is not None and in_scale is None and spec.transposed is False:
+        occ = occupancy
+        assert occ.dtype == torch.float32 and occ.is_contiguous() and occ.numel() == B * hi * wi, (occ.shape, occ.dtype)
     with torch.cuda.device(x.device):
-        L.check(L.TIMER.launch(_timer_name(mode, "fwd"), lambda: lib.liso_conv_forward(
+        L.check(L.TIMER.launch(_timer_name(mode, "fwd"), lambda: lib.liso_conv_forward_sparse(
             ctypes.byref(d), L.ptr(xv), L.ptr(packed), L.ptr(b) if b is not None else None,
             L.ptr(in_scale) if in_scale is not None else None, L.ptr(in_shift) if in_shift is not None else None, L.ptr(y),
-            L.ptr(stats) if stats is not None else None, L.ptr(stats_shift) if stats_shift is not None else None, L.stream_ptr()),
+            L.ptr(stats) if stats is not None else None, L.ptr(stats_shift) if stats_shift is not None else None,
+            L.ptr(occ) if occ is not None else None, L.stream_ptr()),
             units=_flops(d), nbytes=_bytes(d)), "conv_forward")
     return y.permute(0, 3, 1, 2), stats
 
@@ -703,7 +710,7 @@ def _norm_kind(norm):
 
 
 @torch.no_grad()
-def conv_in(x_raw, fold, conv, norm, relu=True, spec=None):
+def conv_in(x_raw, fold, conv, norm, relu=True, spec=None, occupancy=None):
     """inference: conv(pending(x_raw)) followed by `norm` (InstanceNorm2d or nothing) and an optional ReLU.
     -> (y_raw, InFold | None): with InstanceNorm the output stays raw and the normalisation (+ReLU) pending; without a
     normalisation the ReLU runs in the convolution's epilogue."""
@@ -712,6 +719,8 @@ def conv_in(x_raw, fold, conv, norm, relu=True, spec=None):
     kw = {}
     if fold is not None:
         kw = dict(in_scale=fold.scale, in_shift=fold.shift, in_relu=fold.relu, affine_batch_stride=fold.stride)
+    if fold is None and occupancy is not None:
+        kw["occupancy"] = occupancy
     if kind == "none":
         y, _ = conv_forward(x_raw, conv.weight, conv.bias, spec, out_relu=relu, **kw)
         return y, None

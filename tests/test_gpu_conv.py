@@ -247,3 +247,30 @@ def test_eight_wave_dma_kernel_matches_fp64(geom, arith, monkeypatch):
     gx, = torch.autograd.grad(_ref_conv(x64, w, b, s, p, tr), [x64], dy.double())
     dx = MC.conv_dgrad(dy.to(dtype).cuda().contiguous(memory_format=torch.channels_last), w.cuda(), spec, tuple(x.shape), out_dtype=torch.float32)
     assert _rel(dx, gx) <= tol, _rel(dx, gx)
+
+
+@pytest.mark.parametrize("arith", ARITH[:2])
+def test_sparse_input_tile_skipping_is_bit_identical(arith):
+    """liso_conv_forward_sparse: with the occupancy map of a sparse canvas (3 % of the cells occupied, clustered) the blocks whose
+    input window holds no occupied cell skip their work; output and BatchNorm partial sums must equal the dense call bit for bit"""
+    from liso_amd.utils import mfma_conv as MC
+
+    dtype, fmode = arith
+    MC.set_fp32_mode(fmode)
+    g = torch.Generator().manual_seed(3)
+    B, C, H, W = 2, 64, 256, 256
+    occ = torch.zeros(B, 1, H, W)
+    for b in range(B):
+        for _ in range(12):
+            y0, x0 = int(torch.randint(0, H - 24, (1,), generator=g)), int(torch.randint(0, W - 24, (1,), generator=g))
+            occ[b, 0, y0:y0 + 20, x0:x0 + 24] = (torch.rand(20, 24, generator=g) > 0.5).float()
+    x = torch.randn(B, C, H, W, generator=g) * occ
+    w = torch.randn(32, C, 7, 7, generator=g) * 0.05
+    bias = torch.randn(32, generator=g)
+    spec = MC.ConvSpec(7, 7, 2, 3, False)
+    xd = x.to(dtype).cuda().contiguous(memory_format=torch.channels_last)
+    dense, pd = MC.conv_forward(xd, w.cuda(), bias.cuda(), spec, out_relu=True, want_stats=True, out_dtype=torch.float32)
+    sparse, ps = MC.conv_forward(xd, w.cuda(), bias.cuda(), spec, out_relu=True, want_stats=True, out_dtype=torch.float32,
+                                 occupancy=occ.cuda().contiguous())
+    assert torch.equal(dense, sparse) and torch.equal(pd[..., :32], ps[..., :32])  # (columns beyond the 32 channels are never written)
+    assert float((dense - torch.relu(bias.cuda()).view(1, -1, 1, 1)).abs().amax()) > 0.1  # (not all-bias)
