@@ -99,15 +99,19 @@ __global__ __launch_bounds__(kThreads * SK, SK == 1 ? 2 : 1) void conv_igemm_ker
 
     const int tid_all = threadIdx.x, grp = SK == 1 ? 0 : tid_all >> 8;
     const int tid = tid_all & (kThreads - 1), wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
-    int t = xcd_remap(blockIdx.x, a.total);
+    // sparse inputs: occupied tiles cluster (the sensor sits in the middle of the BEV map).  Blocks b and b + 8 share an XCD: dealt in
+    // plain order every XCD would own one tile COLUMN, with contiguous ranges one group of rows -- either way a few XCDs get all the
+    // occupied tiles.  So the tiles are dealt round-robin with the column rotated by the row (every XCD sees every column).
+    int t = a.occ ? (int)blockIdx.x : xcd_remap(blockIdx.x, a.total);
     const int nt = t % a.n_nt;
     t /= a.n_nt;
-    const int tx = t % a.tiles_x;
+    int tx = t % a.tiles_x;
     t /= a.tiles_x;
     const int ty = t % a.tiles_y;
     t /= a.tiles_y;
     const int b = t % d.batch;
     const int cls = t / d.batch;
+    if (a.occ) tx = (tx + ty + b) % a.tiles_x;
     const int stats_row = ((cls * d.batch + b) * a.tiles_y + ty) * a.tiles_x + tx;
     const int n0 = nt * BNT;
 
