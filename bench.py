@@ -14,7 +14,10 @@ BASELINE.json's metric), `roofline` (the hand-written kernel family with the lar
 HIP events on the launch stream) and `cpu_baseline` (the oracle port of the same iteration on the host cores).
 `--workload slim` (configs[1]): one SLIM self-supervised TRAIN step on one pair, B=1 per GPU as in the reference's
 `slim_RAFT batch_size_one`.  `--workload detector` (configs[2]): one detector train step, B=4 clouds per GPU, bf16.
-`--workload iou3d`: only the iou3d_nms section.
+`--workload iou3d`: only the iou3d_nms section.  `--workload stress` (configs[4] on one GPU): the detector train step on
+nuScenes-shaped 300k-point clouds (5 channels: x, y, z, intensity, time), 1024 x 1024 BEV, bf16 -- the HBM-bound stress of
+the pillar path; the line carries `roofline_pillars` (decorate + forward launches timed together, HBM roofline) beside the
+dominant kernel's `roofline`.
 Weak scaling: per-GPU work fixed, samples sharded across ranks by seed, the only collective is the gradient
 all-reduce.  Rank 0 prints ONE JSON line.  `python bench.py --gpus N` without a launcher starts the N ranks itself.
 """
@@ -73,7 +76,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--workload", default="loop", choices=["loop", "slim", "detector", "iou3d"])
+    ap.add_argument("--workload", default="loop", choices=["loop", "slim", "detector", "iou3d", "stress"])
     ap.add_argument("--lookahead", type=int, default=7,
                     help="loop workload: sweep pairs announced ahead of the current one (stage A infers lookahead - 1 - flow_ahead pairs per replay)")
     ap.add_argument("--flow-ahead", type=int, default=2,
@@ -357,6 +360,9 @@ def main():
             dist.destroy_process_group()
         return
 
+    if args.workload == "stress":  # BASELINE configs[4]: 300k points, 1024^2 BEV (module constants: the byte formulas read them)
+        global N_POINTS, GRID
+        N_POINTS, GRID = 300000, 1024
     cfg = default_cfg(grid=GRID, bev_range_m=BEV_RANGE)
     torch.manual_seed(0)  # identical initial weights on every rank (DDP also broadcasts them)
     s0 = s1 = pcls = targets = None
@@ -401,12 +407,18 @@ def main():
         from liso_amd.datasets.synthetic import detector_batch
         from liso_amd.trainer import DetectorTrainer
 
-        batch = args.batch or BATCH_PER_GPU
+        stress = args.workload == "stress"
+        if stress:
+            cfg.data.num_point_channels = 5
+        batch = args.batch or (2 if stress else BATCH_PER_GPU)
         dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
         trainer = DetectorTrainer(cfg, dev, compute_dtype=dtype, total_steps=args.steps + args.warmup + 8, use_graph=not args.eager,
                                   exact=(args.dtype == "fp32"))
         pcls, targets = detector_batch(seed=1 + rank, batch=batch, device=dev, n_points=N_POINTS, grid=GRID,
                                        bev_range_m=BEV_RANGE)
+        if stress:  # 5th channel: sweep time offset of a 10-sweep accumulation in [0, 0.5) s
+            gen = torch.Generator().manual_seed(3 + rank)
+            pcls = [torch.cat([p_, (torch.randint(0, 10, (p_.shape[0], 1), generator=gen).float() * 0.05).to(dev)], dim=1) for p_ in pcls]
         step = lambda: trainer.step(pcls, targets)  # noqa: E731
         frames_per_step = batch
 
@@ -431,7 +443,7 @@ def main():
     for _ in range(args.warmup):
         step()
 
-    graphed = (args.workload == "slim" and args.graph) or (args.workload in ("loop", "detector") and not args.eager)
+    graphed = (args.workload == "slim" and args.graph) or (args.workload in ("loop", "detector", "stress") and not args.eager)
     if not graphed:  # per-launch HIP events on the launch stream, inside the timed region
         L.TIMER.enable_all()
     L.TIMER.reset()
@@ -513,7 +525,7 @@ def main():
         per_unit = {k: L.TIMER.weighted_total_ms(k) for k in durs}  # launches that serve a batch of iterations count 1 / batch
         static_bytes = static_algorithmic_bytes(args.workload, 1 if args.workload == "loop" else batch, 2 if args.dtype == "bf16" else 4)
         key = max(per_unit, key=per_unit.get)  # the hand-written kernel family with the largest share of the step
-        if args.workload == "detector" and key.startswith("pfn"):
+        if args.workload in ("detector", "stress") and key.startswith("pfn"):
             key = "pfn_forward_scatter"
         kname, bound, unit = KERNELS.get(key, (key, "hbm", "bytes"))
         n_launch = max(len(durs[key]), 1)
@@ -545,6 +557,9 @@ def main():
                      "pillars, RAFT 6 iterations fwd+bw flow, kNN loss, fwd+bwd+RMSprop"),
             "detector": ("CenterPoint-pillar detector train step (BASELINE configs[2]): 120k-pt KITTI-shaped clouds, "
                          "512x512 BEV pillars, fwd+bwd+AdamW"),
+            "stress": ("CenterPoint-pillar detector train step (BASELINE configs[4] on one GPU): nuScenes-shaped 300k-pt clouds "
+                       "(x, y, z, intensity, time), 1024x1024 BEV pillars, max 40000 pillars per cloud (deterministic first-come "
+                       "cap), fwd+bwd+AdamW"),
         }[args.workload]
         line = {
             "metric": "LISO train-step frames/sec (120k-pt clouds)",
@@ -584,6 +599,20 @@ def main():
                          "timed_kernels_ms_per_step": {k: round(v / max(event_steps, 1), 4) for k, v in
                                                        sorted(per_unit.items(), key=lambda kv: -kv[1])}},
         }
+        if "pfn_forward_scatter" in totals:
+            # the pillar path as its own HBM roofline: decorate (+ scans) and forward launches timed together over the event passes;
+            # algorithmic bytes = points read once + dense canvas + occupancy written once
+            n_p = max(len(durs["pfn_forward_scatter"]), 1)
+            t_p = (totals["pfn_forward_scatter"] + totals.get("pfn_decorate", 0.0)) * 1e-3
+            c_in = 5 if args.workload == "stress" else 4
+            pb = batch_for_pillars = (batch if args.workload != "loop" else 1)
+            bytes_p = pb * (N_POINTS * c_in * 4 + 64 * GRID * GRID * (2 if args.dtype == "bf16" else 4) + GRID * GRID * 4)
+            tr_p, src_p = pmc_traffic(args.workload, ["pfn_forward_kernel", "pfn_decorate_kernel"])
+            line["roofline_pillars"] = {"kernel": "pfn_decorate_kernel (+3 scan kernels) + pfn_forward_kernel", "bound": "hbm",
+                                        "achieved": bytes_p * n_p / t_p / 1e9 if t_p > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "frac": (bytes_p * n_p / t_p / 1e9 / HBM_PEAK_GBS) if t_p > 0 else 0.0,
+                                        "algorithmic_bytes_per_launch_pair": bytes_p, "avg_pair_ms": 1e3 * t_p / n_p,
+                                        "traffic": tr_p, "traffic_source": src_p, "batch": pb}
         if bound == "mfma" and "f32x3" in key:
             line["roofline"]["peak_note"] = ("fp32 tensors computed as 3 bf16 MFMAs per product (hi*hi + hi*lo + lo*hi): peak = dense "
                                              "bf16 MFMA / 3 in algorithmic fp32 flops (native f32 MFMA peak: 157.3 TFLOP/s)")
@@ -594,6 +623,8 @@ def main():
                 line["cpu_baseline"] = cpu_baseline_slim(cfg, trainer, s0, s1, torch)
             elif args.workload == "detector":
                 line["cpu_baseline"] = cpu_baseline_detector(trainer, pcls, targets, torch)
+            elif args.workload == "stress":
+                line["cpu_baseline"] = None  # (the 1024^2 oracle step takes minutes: the 512^2 `--workload detector` line carries the CPU port)
             else:
                 line["cpu_baseline"] = cpu_baseline_loop(cfg, trainer, s0, s1, torch)
         if args.workload == "loop":

@@ -193,7 +193,9 @@ def deferred_weight_gradients(module: nn.Module, enabled=True, direct_accumulate
 def conv2d(layer: nn.Conv2d, x, relu=False):
     """relu?(layer(x)); inside `deferred_weight_gradients` the weight gradient is deferred to the end of the backward pass"""
     st = _ACTIVE
-    if st is None or (id(layer),) not in st.index:
+    if st is None or (id(layer),) not in st.index or not _own_kernels(x, layer.weight, layer):
+        # (not deferred: layers outside the context, and the 2-channel conv_flow1, which mfma_conv.conv2d runs on the own kernels
+        # with zero-padded channels -- its tiny weight gradient is computed per iteration)
         from liso_amd.utils import mfma_conv as MC
 
         return MC.conv2d(layer, x, relu)

@@ -783,5 +783,22 @@ def conv2d(layer, x, relu=False):
     spec = ConvSpec.of(layer)
     if x.is_cuda and backend() == "mfma" and supported(x, layer.weight, spec):
         return fused_conv(x, None, layer, out_relu=relu, spec=spec)[0]
+    if x.is_cuda and backend() == "mfma" and x.dtype in (torch.bfloat16, torch.float32) and not spec.transposed:
+        # 1-3 (7) input channels -- the motion encoder's conv_flow1: 7x7 on the 2-channel flow, liso/slim/model/update.py:53-60 --
+        # the kernels read channels in 16-B groups: zero channels (and zero filter slices) up to one group, then the own kernel
+        vec = 8 if x.dtype == torch.bfloat16 else 4
+        pad = (-x.shape[1]) % vec
+        xp = torch.cat([x, x.new_zeros((x.shape[0], pad) + tuple(x.shape[2:]))], dim=1).contiguous(memory_format=torch.channels_last)
+        if torch.is_grad_enabled() and layer.weight.requires_grad:
+            wp = torch.nn.functional.pad(layer.weight, (0, 0, 0, 0, 0, pad))
+        else:  # frozen / inference: the padded filter is built once per weight version (its packed panels are cached with it)
+            hit = getattr(layer, "_liso_padded_weight", None)
+            if hit is None or hit[0] != layer.weight._version or hit[1].device != layer.weight.device:
+                wp = torch.nn.Parameter(torch.nn.functional.pad(layer.weight.detach(), (0, 0, 0, 0, 0, pad)), requires_grad=False)
+                layer._liso_padded_weight = (layer.weight._version, wp)
+            wp = layer._liso_padded_weight[1]
+        if supported(xp, wp, spec):
+            import types
+            return fused_conv(xp, None, types.SimpleNamespace(weight=wp, bias=layer.bias), out_relu=relu, spec=spec)[0]
     y = layer(x)
     return torch.relu(y) if relu else y
