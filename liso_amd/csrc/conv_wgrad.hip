@@ -29,7 +29,10 @@ typedef s4 __attribute__((address_space(3))) * lds_s4_ptr;
 constexpr int kThreads = 256;
 constexpr int TW = 32;  // virtual pixels per tile row; 4, 2 or 1 rows per tile (WgArgs::th), fewer when the halo tile is large
 constexpr int CT = 64;                           // channel tile (both ci and co)
-constexpr int PSY = CT * 2 + 16;                 // LDS bytes per dy pixel (bf16 planes)
+// LDS bytes per pixel of a bf16 tile (x and dy): 64 channels + 64 B.  The transposing reads of one 32-lane group touch 4 consecutive
+// pixels x 64 B: with this stride (48 banks) the four 16-bank ranges tile the 64 banks exactly -- the former 144-B stride (36 banks)
+// made pixels 0 / 2 and 1 / 3 overlap by 8 banks: 36 % of all LDS cycles were bank conflicts (profiles/r03_detector_pmc_LDS.csv)
+constexpr int PSB = CT * 2 + 64;
 constexpr int PS32 = CT * 4 + 16;                // LDS bytes per pixel of an fp32 tile (exact mode: x and dy)
 
 struct WgArgs {
@@ -75,7 +78,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(const liso_conv
     constexpr bool F32 = MODE == LISO_CONV_F32;  // exact fp32 on v_mfma_f32_32x32x2_f32: fp32 tiles, plain 4-B LDS reads
     constexpr bool FIN = X3 || F32;
     constexpr int PLANES = X3 ? 2 : 1;
-    constexpr int PSYM = F32 ? PS32 : PSY;
+    constexpr int PSYM = F32 ? PS32 : PSB;
+    constexpr int PSY = PSB;
     constexpr int XB = TG >= 9 ? 4 : 8;  // 16-B loads in flight per thread while a tile is staged (register budget)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -516,7 +520,7 @@ bool make_plan(const liso_conv_desc& d, WgPlan* p) {
     const int vec = x3 ? 4 : 8;
     if (d.ci % vec || d.co % vec || d.x_pix_stride % vec) return false;
     const int planes = (x3 && !f32) ? 2 : 1;
-    const int psx = f32 ? PS32 : CT * 2 + 16, psy = f32 ? PS32 : PSY;
+    const int psx = f32 ? PS32 : PSB, psy = f32 ? PS32 : PSB;
     WgArgs& a = p->a;
     a.ci_t = (d.ci + CT - 1) / CT;
     a.co_t = (d.co + CT - 1) / CT;

@@ -102,19 +102,22 @@ class ObjectDetectionMetrics:
                  class_idxs: Tuple[int] = (0,), min_precision=0.1, min_recall=0.1, use_slow_nuscenes_matching=True,
                  box_matching_criterion="iou_bev", iou_matching_thresholds=(0.25, 0.3, 0.4, 0.5),
                  filter_detections_by_bev_area_min_max_m=None, min_eval_range_m=None, max_eval_range_m=None):
-        if box_matching_criterion not in ("iou_3d", "iou_bev"):
-            raise NotImplementedError(f"{box_matching_criterion}: the centre-distance matching of the reference is not part of this build")
-        if not use_slow_nuscenes_matching:
+        if box_matching_criterion not in ("iou_3d", "iou_bev", "dist"):
+            raise NotImplementedError(box_matching_criterion)
+        if not use_slow_nuscenes_matching and box_matching_criterion != "dist":
             raise NotImplementedError("IoU criteria are matched greedily by descending confidence (reference :320-341)")
+        self.use_slow_nuscenes_matching = use_slow_nuscenes_matching
         self.min_eval_range_m, self.max_eval_range_m = min_eval_range_m, max_eval_range_m
         self.eval_movable_classes_as_one = eval_movable_classes_as_one
         if class_names == ("overall",):
             class_idxs = (0,)
         assert len(class_names) == len(class_idxs), (class_names, class_idxs)
         self.class_idxs, self.class_names = class_idxs, class_names
-        self.tp_metric_thresh = 0.5
-        self.threshold_unit = box_matching_criterion
-        self.matching_thresholds = tuple(iou_matching_thresholds)
+        if box_matching_criterion == "dist":  # reference :186-190: centre distance in metres
+            self.tp_metric_thresh, self.threshold_unit, self.matching_thresholds = 2.0, "m", (0.5, 1.0, 2.0, 4.0)
+        else:
+            self.tp_metric_thresh, self.threshold_unit = 0.5, box_matching_criterion
+            self.matching_thresholds = tuple(iou_matching_thresholds)
         assert self.tp_metric_thresh in self.matching_thresholds
         self.box_matching_criterion = box_matching_criterion
         self.bev_range_min_xy_m = self.bev_range_max_xy_m = None
@@ -163,8 +166,16 @@ class ObjectDetectionMetrics:
 
     def _update_class_threshold(self, gt, pred, thr, class_name):
         assert bool(gt.valid.all()) and bool(pred.valid.all()), "invalid objects not supported!"
-        idx_gt, idx_pred, _, pred_mask, gt_mask = match_boxes_by_descending_confidence_iou(
-            gt, pred, matching_threshold=thr, iou_mode=self.box_matching_criterion, matching_mode="greedy")
+        if self.box_matching_criterion == "dist":  # reference :310-325 (greedy, 2-D) / :343-355 (optimal assignment, 2-D)
+            from liso_amd.kabsch.box_groundtruth_matching import match_bboxes, slow_greedy_match_boxes_by_desending_confidence_by_dist
+            if self.use_slow_nuscenes_matching:
+                idx_gt, idx_pred, _, pred_mask, gt_mask = slow_greedy_match_boxes_by_desending_confidence_by_dist(
+                    gt.pos, pred.pos, non_batched_pred_confidence=torch.squeeze(pred.probs, dim=-1), matching_threshold=thr, match_in_nd=2)
+            else:
+                idx_gt, idx_pred, _, pred_mask, gt_mask = match_bboxes(gt.pos, pred.pos, DIST_MATCHING_THRESHOLD=thr, match_in_nd=2)
+        else:
+            idx_gt, idx_pred, _, pred_mask, gt_mask = match_boxes_by_descending_confidence_iou(
+                gt, pred, matching_threshold=thr, iou_mode=self.box_matching_criterion, matching_mode="greedy")
         g, p = gt.numpy(), pred.numpy()
         logits = np.squeeze(p.probs, axis=-1)
         moving = np.linalg.norm(g.velo, axis=-1) > self.moving_velocity_thresh
@@ -219,6 +230,57 @@ class ObjectDetectionMetrics:
                 e = self.tp_errors[class_name][thr]
                 for k, v in e.items():
                     out[pre + f"/{thr:.1f}{self.threshold_unit}/{k}"] = v if k == "tps" else v / max(e["tps"], 1e-6)
+        return out
+
+
+    # ---- ROC / detection-error-tradeoff curves (reference :547-653, :924-1105): the numbers behind the reference's figures ------------
+    def roc_curves(self, class_name: str = "overall", category: str = "overall", writer_prefix: str = ""):
+        """per matching threshold: (fpr, tpr, confidence thresholds decreasing) of sklearn's roc_curve with the false negatives'
+        -inf scores mapped below the smallest real score, without the final point, and the area under the curve (0 when only one
+        label is present) -- what log_roc_curves plots and writes as `<prefix>/area_under_roc_curve@<thr><unit>`.
+        -> (curves {thr: dict(fpr, tpr, thresholds, area)}, metrics {label: area})"""
+        from sklearn.metrics import roc_auc_score, roc_curve
+
+        curves, metrics = {}, {}
+        for thr in self.matching_thresholds:
+            all_gt, all_scores, _ = self.collected(class_name, thr, category)
+            scores = map_scores_from_neg_infs_to_actual_min_score(all_scores)
+            if scores.size == 0:
+                continue
+            fpr, tpr, conf = roc_curve(all_gt, scores)
+            area = 0.0 if len(np.unique(all_gt)) <= 1 else float(roc_auc_score(all_gt, scores))
+            metrics[writer_prefix.rstrip("/") + f"/area_under_roc_curve@{thr:.1f}{self.threshold_unit}"] = area
+            curves[thr] = {"fpr": fpr[:-1], "tpr": tpr[:-1], "thresholds": conf[:-1], "area": area}
+        return curves, metrics
+
+    def det_tp_fp_curves(self, class_name: str = "overall", category: str = "overall"):
+        """per matching threshold: false-positive / false-negative rates over decreasing confidence thresholds (sklearn det_curve) and
+        the absolute numbers of false / true positives (sklearn's binary classification curve), with the reference's special cases for
+        samples that are all true or all false positives (:947-975); every array without its final point (:989-1003)"""
+        from sklearn.metrics import det_curve
+        from sklearn.metrics._ranking import _binary_clf_curve
+
+        out = {}
+        for thr in self.matching_thresholds:
+            all_gt, all_scores, _ = self.collected(class_name, thr, category)
+            cats = np.unique(all_gt)
+            if cats.size == 0:
+                continue
+            scores = map_scores_from_neg_infs_to_actual_min_score(all_scores)
+            if len(cats) == 1:
+                desc = np.sort(scores)[::-1]
+                only_tp = bool(cats[0])
+                fp_rate = np.zeros_like(scores) if only_tp else np.ones_like(scores)
+                fn_rate = np.zeros_like(scores) if only_tp else np.ones_like(scores)
+                thr_ratio, thr_abs = desc, np.copy(desc)
+                fps = all_gt.size * (np.zeros_like(desc) if only_tp else np.ones_like(desc))
+                tps = all_gt.size * (np.ones_like(desc) if only_tp else np.zeros_like(desc))
+            else:
+                fp_rate, fn_rate, thr_ratio = det_curve(all_gt, scores)
+                res = _binary_clf_curve(all_gt, scores)
+                fps, tps, thr_abs = res[0], res[1], res[2]
+            out[thr] = {"fp_rate": fp_rate[:-1], "fn_rate": fn_rate[:-1], "thresholds_for_ratios": thr_ratio[:-1], "num_fps": fps[:-1],
+                        "num_tps": tps[:-1], "thresholds_abs": thr_abs[:-1]}
         return out
 
 
