@@ -821,7 +821,9 @@ class LisoLoopTrainer:
             ome = gt["_odom_minus_eye"] = odometry_minus_identity(gt["odom_ta_tb"].to(dev))
         ins = {"pcl": pa["pcl"], "valid": pa["pcl_is_valid"], "coors": pa["pillar_coors"], "full": sample_t0["pcl_full_w_ground_ta"],
                "flow": flow, "ome": ome, "dt": sample_t0["src_trgt_time_delta_s"], "odom": gt["odom_ta_tb"]}
-        sig = tuple((k, tuple(v.shape), v.dtype) for k, v in ins.items())
+        # (one captured graph -- static inputs, intermediates, packed output -- per mining stream: replays on different streams run
+        # concurrently and must not share buffers)
+        sig = (side.cuda_stream,) + tuple((k, tuple(v.shape), v.dtype) for k, v in ins.items())
         st = self._mine_graphs.get(sig)
         if st is not None:
             self._mine_graphs.move_to_end(sig)
