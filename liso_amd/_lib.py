@@ -107,6 +107,17 @@ SIGNATURES = {
     "liso_corr_lookup_bwd_dvol_f32": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "liso_nearest_point_loss_fwd_f32": (_i, [_vp] * 8),
     "liso_nearest_point_loss_bwd_f32": (_i, [_vp] * 9),
+    # include/liso_slim_decode.h
+    "liso_slim_decode_weights_fwd": (_i, [_vp] * 6 + [_i] + [_vp] * 4),
+    "liso_slim_decode_weights_bwd": (_i, [_vp] * 9),
+    "liso_slim_decode_points_fwd": (_i, [_vp] * 9),
+    "liso_slim_decode_points_bwd": (_i, [_vp] * 11),
+    "liso_slim_loss_workspace_bytes": (_sz, []),
+    "liso_slim_static_points_loss_fwd": (_i, [_i, ctypes.c_long, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "liso_slim_static_points_loss_bwd": (_i, [_i, ctypes.c_long, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "liso_slim_knn_queries": (_i, [_i, _i, ctypes.c_long, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "liso_slim_nearest_point_loss_fwd": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "liso_slim_nearest_point_loss_bwd": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "liso_bev_gather_fwd_f32": (_i, [_vp, _vp, ctypes.c_long, _i, ctypes.c_float, _vp, _vp]),
     "liso_bev_gather_bwd_f32": (_i, [_vp, _vp, _vp, _vp, ctypes.c_long, _i, _vp, _vp, _vp]),
     "liso_gru_in_fwd_f32": (_i, [_vp, _vp, _vp, ctypes.c_long, _vp, _vp, _vp, _vp, _vp]),
@@ -200,6 +211,24 @@ class CenterLossCfg(ctypes.Structure):
 class NpLossCfg(ctypes.Structure):
     """mirror of liso_nploss_cfg (include/liso_slim.h)"""
     _fields_ = [("batch", _i), ("n", ctypes.c_long), ("n_b", ctypes.c_long), ("ext", _f * 4), ("fov_mode", _i), ("delta", _f)]
+
+
+class SlimDecodeCfg(ctypes.Structure):
+    """mirror of liso_slim_decode_cfg (include/liso_slim_decode.h)"""
+    _fields_ = [("samples", _i), ("n", ctypes.c_long), ("h", _i), ("w", _i), ("logit_mode", _i * 4), ("static_flow_zero", _i),
+                ("dynamic_flow_zero", _i), ("overwrite_flow", _i), ("overwrite_logits", _i), ("non_rigid", _i), ("use_static_aggr", _i),
+                ("dyn_grad_scale", _f), ("ext_lo", ctypes.c_double * 2), ("ext_span", ctypes.c_double * 2)]
+
+
+class SlimDecodeOut(ctypes.Structure):
+    """mirror of liso_slim_decode_out: 11 float pointers + the flags pointer (None = not wanted)"""
+    FIELDS = ("dis_logit", "dis", "logits", "probs", "staticness", "dynamicness", "groundness", "dyn_flow", "stat_flow", "agg_flow", "saf_flow")
+    _fields_ = [(k, _vp) for k in FIELDS] + [("flags", _vp)]
+
+
+class SlimNpLossCfg(ctypes.Structure):
+    """mirror of liso_slim_nploss_cfg"""
+    _fields_ = [("samples", _i), ("clouds", _i), ("n", ctypes.c_long), ("n_b", ctypes.c_long), ("ext", _f * 4), ("fov_mode", _i), ("delta", _f)]
 
 
 class BoxPtsCfg(ctypes.Structure):

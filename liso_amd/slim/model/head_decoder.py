@@ -244,6 +244,28 @@ class HeadDecoder(nn.Module):
         H, W = int(network_output.shape[1]), int(network_output.shape[2])
         om = self.cfg.model.output_modification
         raw = batched_grid_data_to_pointwise_data(network_output, coors_fs, pointwise_valid_mask, 0.0, plan=gather_plan)
+        from liso_amd.slim.model import fused_decode as FD
+
+        if getattr(self, "fused_decoding", True) and FD.decode_supported(self.cfg, network_output) and pc.dtype == torch.float32:
+            # the whole per-point decode as two launches around the Kabsch fit (include/liso_slim_decode.h)
+            extremes = None
+            if any(v is True or v is False for v in (om.static_logit, om.dynamic_logit, om.ground_logit)):
+                extremes = channel_extrema(network_output[..., :4].detach())
+            meta = FD.DecodeMeta(self.cfg, self.bev_extent, gather_plan, filled_pillar_mask, extremes, dynamicness_threshold,
+                                 pc.contiguous(), non_rigid=dynamic_flow_is_non_rigid_flow)
+            x, y, w = FD.decode_weights(raw, meta)
+            from liso_amd.slim.slim_loss.weighted_pc_alignment import batched_weighted_pc_alignment
+
+            static_aggr_trafo, not_enough_points = batched_weighted_pc_alignment(
+                x, y, w, pointwise_valid_mask,
+                use_epsilon_on_weights=self.cfg.losses.unsupervised.use_epsilon_for_weighted_pc_alignment)
+            o = FD.decode_points(raw, static_aggr_trafo, meta)
+            fl = o["flags"]
+            return Munch(disappearing_logit=o["dis_logit"], disappearing=o["dis"], class_logits=o["logits"], class_probs=o["probs"],
+                         staticness=o["staticness"], dynamicness=o["dynamicness"], groundness=o["groundness"], is_static=fl[..., 0],
+                         is_dynamic=fl[..., 1], is_ground=fl[..., 2], dynamic_flow=o["dyn_flow"], static_flow=o["stat_flow"],
+                         aggregated_flow=o["agg_flow"], static_aggr_flow=o["saf_flow"], static_aggr_trafo=static_aggr_trafo,
+                         dynamicness_threshold=dynamicness_threshold, not_enough_points=not_enough_points)
         safe = gather_plan.lin64.clamp(min=0)
         filled_pt = (filled_pillar_mask.reshape(-1)[safe].view(S, N) & pointwise_valid_mask).view(S, N, 1)
         extremes = None

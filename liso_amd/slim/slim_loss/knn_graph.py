@@ -44,9 +44,13 @@ class KnnIndex:
         n = self.ref.shape[0]
         if extent is not None:  # (x_min, y_min, x_max, y_max) known up front (the BEV range): no host sync at all;
             lo, hi = [float(extent[0]), float(extent[1])], [float(extent[2]), float(extent[3])]  # outliers are clamped
-        elif n > 0:
-            lo = self.ref[:, :2].amin(dim=0).tolist()  # one small sync per index build
-            hi = self.ref[:, :2].amax(dim=0).tolist()
+        elif n > 0:  # one small sync per index build; rows marked NaN (padding, knn_loss.py:44-45) do not count
+            xy = self.ref[:, :2]
+            fin = torch.isfinite(xy)
+            lo = torch.where(fin, xy, float("inf")).amin(dim=0).tolist()
+            hi = torch.where(fin, xy, float("-inf")).amax(dim=0).tolist()
+            if not all(v == v and abs(v) != float("inf") for v in lo + hi):
+                lo, hi = [0.0, 0.0], [1.0, 1.0]
         else:
             lo, hi = [0.0, 0.0], [1.0, 1.0]
         with torch.cuda.device(ref.device):

@@ -9,6 +9,18 @@ from liso_amd.slim.slim_loss.knn_loss import compute_knn_loss_components
 from liso_amd.utils.torch_transformation import homogenize_pcl
 
 
+_FUSED = [True]
+
+
+def fused_losses_enabled():
+    return _FUSED[0]
+
+
+def set_fused_losses(on: bool):
+    """False: the torch formulation of every loss term (the kernels' reference in tests/test_gpu_slim.py)"""
+    _FUSED[0] = bool(on)
+
+
 def trafo_distance(delta_trafos, points, mask):
     """reference :9-33 -- mean squared displacement of the points under (T - I)"""
     points = points.detach()
@@ -45,6 +57,36 @@ def symmetric_static_points_loss(pc0, valid_mask_pc0, static_flow_fw, static_agg
     return loss0, fb_loss
 
 
+def _fused_module():
+    from liso_amd.slim.model import fused_decode
+
+    return fused_decode
+
+
+def knn_flow_types(loss_cfg, model_cfg):
+    """the flow types whose nearest-point loss the configuration needs (knn_loss.py:27-43)"""
+    types = {"aggregated"}
+    if loss_cfg.artificial_labels.cross_entropy_penalty > 0.0:
+        types.add("dynamic")
+        types.add("static_aggr" if loss_cfg.artificial_labels.use_static_aggr_flow else "static")
+    if loss_cfg.knn_on_dynamic_penalty != 0.0:
+        types.add("dynamic")
+    if loss_cfg.knn_on_static_penalty != 0.0:
+        types.add("static_aggr" if model_cfg.use_static_aggr_flow_for_aggr_flow else "static")
+    return sorted(types)
+
+
+def _knn_mean(entry, weights, mask):
+    """masked mean of one flow type's nearest-point loss: already reduced by the fused kernel, or from the per-point losses"""
+    if "mean" in entry:
+        return entry["mean"]
+    return _masked_mean(weights * entry["loss"], mask)
+
+
+def _nearest_dist(knn):
+    return knn["nearest_dist"] if "nearest_dist" in knn else knn["nearest_dist_sqr"].sqrt()
+
+
 def _masked_mean(x, mask):
     """x[mask].mean() without the boolean-index compaction (a device->host sync per call)"""
     return torch.where(mask, x, 0.0).sum() / mask.sum()
@@ -55,17 +97,27 @@ def selfsupervisedSlimSingleScaleLoss(pc1, valid_mask_pc1, pc2, valid_mask_pc2, 
                                       knn_index_pc1=None, knn_index_pc2=None):
     """reference :123-348.  knn_index_pc{1,2}: optional per-batch lists of device KnnIndex built once per cloud."""
     total = torch.zeros(1, device=pc1.device)
+    fused = (pc1.is_cuda and pc1.dtype == torch.float32 and pc2.dtype == torch.float32 and fused_losses_enabled()
+             and loss_cfg.knn_loss.range_based_weights.weight_slope == 0.0)
     sfp, fbp = loss_cfg.static_flow_penalty_factor != 0.0, loss_cfg.fw_bw_static_trafo_penalty_factor != 0.0
     if sfp or fbp:
         det = loss_cfg.artificial_labels.cross_entropy_penalty > 0.0
         st_fw = pred_fw.staticness.detach() if det else pred_fw.staticness
         st_bw = pred_bw.staticness.detach() if det else pred_bw.staticness
-        l_fw, fb = symmetric_static_points_loss(pc0=pc1, valid_mask_pc0=valid_mask_pc1, static_flow_fw=pred_fw.static_flow,
-                                                static_aggr_trafo_fw=pred_fw.static_aggr_trafo, staticness_fw=st_fw, pc1=pc2,
-                                                valid_mask_pc1=valid_mask_pc2, static_aggr_trafo_bw=pred_bw.static_aggr_trafo)
-        l_bw = symmetric_static_points_loss(pc0=pc2, valid_mask_pc0=valid_mask_pc2, static_flow_fw=pred_bw.static_flow,
-                                            static_aggr_trafo_fw=pred_bw.static_aggr_trafo, staticness_fw=st_bw)
-        static_flow_loss = 0.5 * (_masked_mean(l_fw, valid_mask_pc1) + _masked_mean(l_bw, valid_mask_pc2))
+        if fused:  # one reduction launch per direction (include/liso_slim_decode.h) + the fw/bw distance from the clouds' second moments
+            FD = _fused_module()
+            fbT = torch.einsum("boc,bcx->box", pred_bw.static_aggr_trafo, pred_fw.static_aggr_trafo)
+            fb = FD.trafo_distance_from_moments(fbT - torch.eye(4, device=fbT.device), torch.cat([pc1[..., :3], pc2[..., :3]], dim=1),
+                                                torch.cat([valid_mask_pc1, valid_mask_pc2], dim=1)).mean()
+            static_flow_loss = 0.5 * (FD.static_points_loss_mean(pc1, valid_mask_pc1, pred_fw.static_flow, st_fw, pred_fw.static_aggr_trafo)
+                                      + FD.static_points_loss_mean(pc2, valid_mask_pc2, pred_bw.static_flow, st_bw, pred_bw.static_aggr_trafo))
+        else:
+            l_fw, fb = symmetric_static_points_loss(pc0=pc1, valid_mask_pc0=valid_mask_pc1, static_flow_fw=pred_fw.static_flow,
+                                                    static_aggr_trafo_fw=pred_fw.static_aggr_trafo, staticness_fw=st_fw, pc1=pc2,
+                                                    valid_mask_pc1=valid_mask_pc2, static_aggr_trafo_bw=pred_bw.static_aggr_trafo)
+            l_bw = symmetric_static_points_loss(pc0=pc2, valid_mask_pc0=valid_mask_pc2, static_flow_fw=pred_bw.static_flow,
+                                                static_aggr_trafo_fw=pred_bw.static_aggr_trafo, staticness_fw=st_bw)
+            static_flow_loss = 0.5 * (_masked_mean(l_fw, valid_mask_pc1) + _masked_mean(l_bw, valid_mask_pc2))
         metrics_collector["static_flow_loss"] = static_flow_loss.detach()
         metrics_collector["for_back_static_trafo_loss"] = fb.detach()
         if sfp:
@@ -73,10 +125,19 @@ def selfsupervisedSlimSingleScaleLoss(pc1, valid_mask_pc1, pc2, valid_mask_pc2, 
         if fbp:
             total = total + fb * loss_cfg.fw_bw_static_trafo_penalty_factor
     kw = dict(loss_cfg=loss_cfg, model_cfg=model_cfg, bev_extent=bev_extent)
-    knn_fw = compute_knn_loss_components(pc1[..., :3], valid_mask_pc1, pc2[..., :3], valid_mask_pc2, prediction=pred_fw,
-                                         knn_indices=knn_index_pc2, query_order_indices=knn_index_pc1, **kw)
-    knn_bw = compute_knn_loss_components(pc2[..., :3], valid_mask_pc2, pc1[..., :3], valid_mask_pc1, prediction=pred_bw,
-                                         knn_indices=knn_index_pc1, query_order_indices=knn_index_pc2, **kw)
+    knn_fw = knn_bw = None
+    if fused and loss_cfg.knn_dist_measure == "point":
+        FD = _fused_module()
+        types = knn_flow_types(loss_cfg, model_cfg)
+        fkw = dict(bev_extent=bev_extent, knn_loss_cfg=loss_cfg.knn_loss)
+        knn_fw = FD.knn_losses(pc1, valid_mask_pc1, pc2, {t: pred_fw["%s_flow" % t] for t in types}, knn_index_pc2, knn_index_pc1, **fkw)
+        if knn_fw is not None:
+            knn_bw = FD.knn_losses(pc2, valid_mask_pc2, pc1, {t: pred_bw["%s_flow" % t] for t in types}, knn_index_pc1, knn_index_pc2, **fkw)
+    if knn_fw is None or knn_bw is None:
+        knn_fw = compute_knn_loss_components(pc1[..., :3], valid_mask_pc1, pc2[..., :3], valid_mask_pc2, prediction=pred_fw,
+                                             knn_indices=knn_index_pc2, query_order_indices=knn_index_pc1, **kw)
+        knn_bw = compute_knn_loss_components(pc2[..., :3], valid_mask_pc2, pc1[..., :3], valid_mask_pc1, prediction=pred_bw,
+                                             knn_indices=knn_index_pc1, query_order_indices=knn_index_pc2, **kw)
     ce = loss_cfg.artificial_labels.cross_entropy_penalty > 0.0
     if ce:
         ce_fw = _masked_mean(compute_artificial_label_loss(prediction={"staticness": pred_fw.staticness}, knn_results=knn_fw,
@@ -85,27 +146,24 @@ def selfsupervisedSlimSingleScaleLoss(pc1, valid_mask_pc1, pc2, valid_mask_pc2, 
                                                            loss_cfg=loss_cfg), valid_mask_pc2)
     assert loss_cfg.knn_loss.range_based_weights.weight_slope == 0.0, "range-based kNN weights are not on the hot path"
     w1, w2 = torch.ones_like(pc1[..., 0]), torch.ones_like(pc2[..., 0])
-    flow_loss = 0.5 * (_masked_mean(w2 * knn_bw["aggregated"]["loss"], valid_mask_pc2)
-                       + _masked_mean(w1 * knn_fw["aggregated"]["loss"], valid_mask_pc1))
+    flow_loss = 0.5 * (_knn_mean(knn_bw["aggregated"], w2, valid_mask_pc2) + _knn_mean(knn_fw["aggregated"], w1, valid_mask_pc1))
     if loss_cfg.knn_loss_penalty_factor != 0.0:
         total = total + flow_loss * loss_cfg.knn_loss_penalty_factor
     if loss_cfg.knn_on_dynamic_penalty != 0.0:
-        dyn = 0.5 * (_masked_mean(w2 * knn_bw["dynamic"]["loss"], valid_mask_pc2)
-                     + _masked_mean(w1 * knn_fw["dynamic"]["loss"], valid_mask_pc1))
+        dyn = 0.5 * (_knn_mean(knn_bw["dynamic"], w2, valid_mask_pc2) + _knn_mean(knn_fw["dynamic"], w1, valid_mask_pc1))
         metrics_collector["dynamic_flow_loss"] = dyn.detach()
         total = total + dyn * loss_cfg.knn_on_dynamic_penalty
     if loss_cfg.knn_on_static_penalty != 0.0:
         assert loss_cfg.knn_on_static_penalty == 1.0 and model_cfg.use_static_aggr_flow_for_aggr_flow
-        st = 0.5 * (_masked_mean(w2 * knn_bw["static_aggr"]["loss"], valid_mask_pc2)
-                    + _masked_mean(w1 * knn_fw["static_aggr"]["loss"], valid_mask_pc1))
+        st = 0.5 * (_knn_mean(knn_bw["static_aggr"], w2, valid_mask_pc2) + _knn_mean(knn_fw["static_aggr"], w1, valid_mask_pc1))
         metrics_collector["static_flow_loss"] = st.detach()
         total = total + st * loss_cfg.knn_on_static_penalty
     assert loss_cfg.opposite_flow_penalty_factor == 0.0
     if model_cfg.use_static_aggr_flow_for_aggr_flow:  # reference :294-335: update the dynamicness threshold
         es, ed, sc, vm = [], [], [], []
         for res, pred, m in ((knn_fw, pred_fw, valid_mask_pc1), (knn_bw, pred_bw, valid_mask_pc2)):
-            es.append(res["static_aggr"]["knn"]["nearest_dist"].flatten())
-            ed.append(res["dynamic"]["knn"]["nearest_dist"].flatten())
+            es.append(_nearest_dist(res["static_aggr"]["knn"]).flatten())
+            ed.append(_nearest_dist(res["dynamic"]["knn"]).flatten())
             sc.append(pred.dynamicness.flatten())
             vm.append(m.flatten())
         # the reference compacts the three arrays with `[mask]` (:300-320); the histogram update ignores rows through

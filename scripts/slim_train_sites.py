@@ -37,7 +37,9 @@ class Sites(TorchDispatchMode):
 
 if __name__ == "__main__":
     dev = torch.device("cuda:0")
-    cfg = apply_slim_simple_knn_training(default_cfg(grid=512, bev_range_m=100.0))
+    cfg = default_cfg(grid=512, bev_range_m=100.0)
+    if "full" not in sys.argv[1:]:  # `full`: the reference's default SLIM losses (static-flow + fw/bw transform penalties) instead of the kNN-only overlay
+        cfg = apply_slim_simple_knn_training(cfg)
     torch.manual_seed(0)
     tr = SlimTrainer(cfg, dev, use_graph=False)
     s0, s1 = slim_pair(2, dev, n_points=120000, grid=512, bev_range_m=100.0)
@@ -51,5 +53,9 @@ if __name__ == "__main__":
     for (name, site, shape), (n, mb) in st.c.items():
         by_op[name] += n
     print(by_op.most_common(25))
-    for (name, site, shape), (n, mb) in sorted(st.c.items(), key=lambda kv: -kv[1][0])[:90]:
+    by_file = collections.Counter()
+    for (name, site, shape), (n, mb) in st.c.items():
+        by_file[site.split(":")[0]] += n
+    print(by_file.most_common())
+    for (name, site, shape), (n, mb) in sorted(st.c.items(), key=lambda kv: -kv[1][0])[:400]:
         print(f"{n:4d} x {name:20s} {mb:9.2f} MB {str(shape):28s} {site}")

@@ -592,3 +592,98 @@ def test_small_encoder_folded_inference_equals_module_path(norm_fn):
         enc.fold_inference = True
         alone = enc(x[1:2].contiguous(memory_format=torch.channels_last))
     assert float((alone - got[1:2]).abs().max()) <= 1e-5 * float(got.abs().max())
+
+
+@pytest.mark.parametrize("variant", ["default", "simple_knn", "non_rigid_static_aggr_ce", "knn_on_dynamic_padded", "all_off_flows_zero"])
+def test_fused_decoder_and_losses_equal_torch_formulation(variant):
+    """include/liso_slim_decode.h (decode passes, static-points loss, nearest-point loss with query order and masked mean, fw/bw
+    transform distance from second moments) against the torch formulation of the same reference arithmetic
+    (head_decoder.py:67-408, slim_loss_adaptor.py:123-348): predictions, loss and the gradient of the network output, on
+    S = iterations x clouds stacked samples with padding rows, for the output modes / loss terms the configurations can select"""
+    from liso_amd.slim.model.head_decoder import HeadDecoder
+    from liso_amd.slim.slim_loss import slim_loss_adaptor as A
+    from liso_amd.slim.slim_loss.knn_graph import KnnIndex
+    from liso_amd.slim.slim_loss.movavg_cls_threshold import MovingAverageThreshold
+    from liso_amd.utils.config import apply_slim_simple_knn_training, default_cfg
+
+    cfg = default_cfg(grid=64, bev_range_m=40.0)
+    u, m = cfg.SLIM.losses.unsupervised, cfg.SLIM.model
+    padded, non_rigid = False, False
+    if variant == "simple_knn":
+        cfg = apply_slim_simple_knn_training(cfg)
+    elif variant == "non_rigid_static_aggr_ce":
+        m.use_static_aggr_flow_for_aggr_flow, non_rigid = True, True
+        u.artificial_labels.cross_entropy_penalty, u.knn_on_static_penalty = 0.1, 1.0
+        m.output_modification.dynamic_flow_grad_scale = 0.5
+    elif variant == "knn_on_dynamic_padded":
+        u.knn_on_dynamic_penalty, padded = 0.5, True
+        u.knn_loss.fov_mode, u.knn_loss.L1_delta = "ignore_out_fov", 0.3
+    elif variant == "all_off_flows_zero":
+        om = m.output_modification
+        om.static_logit, om.dynamic_logit, om.ground_logit, om.static_flow, om.disappearing_logit = False, True, False, "zero", True
+    R, G, clouds, n_it, N = 40.0, 64, 2, 3, 3000
+    ext = np.array([-R / 2, -R / 2, R / 2, R / 2])
+    gen = torch.Generator().manual_seed(11)
+    S = clouds * n_it
+
+    def cloud():
+        p = (torch.rand(clouds, N, 4, generator=gen) - 0.5) * torch.tensor([R * 0.98, R * 0.98, 3.0, 1.0])
+        return p.cuda()
+
+    pcs = [cloud(), cloud()]
+    valids = [torch.ones(clouds, N, dtype=torch.bool, device="cuda") for _ in range(2)]
+    if padded:
+        for v in valids:
+            v[:, -137:] = False
+    rep = lambda t: t.repeat(n_it, *([1] * (t.dim() - 1)))  # noqa: E731
+    coors = lambda pc: ((pc[..., :2] + R / 2) / R * G).to(torch.int32).clamp(0, G - 1)  # noqa: E731
+
+    def filled(c, v):
+        mk = torch.zeros(S, G, G, dtype=torch.bool, device="cuda")
+        for s in range(S):
+            cs = c[s][v[s]].long()
+            mk[s, cs[:, 0], cs[:, 1]] = True
+        mk[:, :3] = False  # some points sit in pillars the mask calls unfilled: defaults
+        return mk
+
+    odom = torch.eye(4, device="cuda")[None].repeat(S, 1, 1)
+    odom[:, 0, 3] = 0.4
+    nets = [(torch.randn(S, G, G, 8, generator=gen) * torch.tensor([1.0, 1.5, 1.5, 1.0, 0.3, 0.3, 0.5, 0.5])).cuda() for _ in range(2)]
+    idx = None if padded else [[KnnIndex(pcs[k][b][:, :3].contiguous(), extent=[float(v) for v in ext], all_rows_finite=True)
+                                for b in range(clouds)] * n_it for k in range(2)]
+    res = []
+    for fused in (True, False):
+        A.set_fused_losses(fused)
+        try:
+            thr = MovingAverageThreshold(num_train_samples=100, num_moving=621013971, num_still=None).cuda()
+            leaves = [n.clone().requires_grad_(True) for n in nets]
+            preds = []
+            for k in range(2):
+                dec = HeadDecoder(cfg.SLIM, "d%d" % k, ext)
+                dec.fused_decoding = fused
+                pc, v = rep(pcs[k]), rep(valids[k])
+                c = coors(pc)
+                preds.append(dec(leaves[k], thr.value(), pc=pc, pointwise_voxel_coordinates=c, pointwise_valid_mask=v,
+                                 filled_pillar_mask=filled(c, v), odom=odom, inv_odom=torch.linalg.inv(odom), summaries=None,
+                                 dynamic_flow_is_non_rigid_flow=non_rigid, pointwise_only=True))
+            loss = A.selfsupervisedSlimSingleScaleLoss(
+                pc1=rep(pcs[0]), valid_mask_pc1=rep(valids[0]), pc2=rep(pcs[1]), valid_mask_pc2=rep(valids[1]), pred_fw=preds[0],
+                pred_bw=preds[1], moving_thresh_module=thr, loss_cfg=u, model_cfg=m, bev_extent=ext, metrics_collector={},
+                knn_index_pc1=None if idx is None else idx[0], knn_index_pc2=None if idx is None else idx[1])
+            loss.backward()
+            res.append((preds, float(loss), [l.grad.clone() for l in leaves], {k: v.clone() for k, v in thr.state_dict().items()}))
+        finally:
+            A.set_fused_losses(True)
+    (pa, la, ga, ta), (pb, lb, gb, tb) = res
+    for k in range(2):
+        for key in ("disappearing_logit", "disappearing", "class_logits", "class_probs", "staticness", "dynamicness", "groundness",
+                    "dynamic_flow", "static_flow", "aggregated_flow", "static_aggr_flow", "static_aggr_trafo"):
+            a, b = pa[k][key].detach().double(), pb[k][key].detach().double()
+            assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(b.abs().max())), (key, float((a - b).abs().max()))
+        for key in ("is_static", "is_dynamic", "is_ground"):
+            assert float((pa[k][key] != pb[k][key]).float().mean()) <= 1e-4, key  # (a probability within an ulp of the threshold)
+    assert abs(la - lb) <= 1e-5 * abs(lb), (la, lb)
+    for a, b in zip(ga, gb):
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-12, float((a - b).abs().max())
+    for k in ta:
+        assert torch.allclose(ta[k].double(), tb[k].double(), rtol=1e-5, atol=1e-7), k
