@@ -11,7 +11,7 @@
  * no E[x^2]-E[x]^2 cancellation (MIOpen's spatial BN loses ~2e-4 relative at mean/std = 50, measured), reproducible.
  *
  * x, y, dy, dx: [M, C] row-major (M = N*H*W pixels, channels-last), dtype fp32 (is_bf16 = 0) or bf16 (is_bf16 = 1);
- * C % 8 == 0, C <= 256, 256 % (C / V) == 0 with V = 4 (fp32) or 8 (bf16).  gamma/beta/running_*: fp32 [C].  stats: fp32 [4*C] = scale | shift | mean | invstd.
+ * C % 8 == 0, C <= 256 (V = 4 channels per lane in fp32, 8 in bf16; 256 / (C / V) rows per block pass).  gamma/beta/running_*: fp32 [C].  stats: fp32 [4*C] = scale | shift | mean | invstd.
  * All pointers are device pointers; nothing allocates or synchronises.
  */
 #ifndef LISO_BN_H
@@ -37,6 +37,18 @@ int liso_bn_relu_fwd(const void* x, int is_bf16, long m, int c, const float* gam
 int liso_bn_relu_bwd(const void* dy, const void* x, int is_bf16, long m, int c, const float* gamma, const float* stats,
                      int training, int relu, void* dx, float* grad_gamma, float* grad_beta, void* workspace,
                      size_t workspace_bytes, void* stream);
+
+/* ---- InstanceNorm2d(+ReLU), training: the same passes with one set of statistics per sample ---------------------------------
+ * Replaces `nn.InstanceNorm2d(affine=True)` + `ReLU` of the SLIM encoders in training (liso/slim/model/extractor.py:24-38,
+ * 219-230; norm_fn "instance" / "instance_affine"), which PyTorch runs through the BatchNorm kernels on a [1, B*C, H, W] view
+ * (weight / bias repeated B times) in NCHW.  x, y, dy, dx: [groups, m, C] channels-last (groups = samples, m = H*W pixels each);
+ * stats fp32 [groups, 4*C]; grad_gamma / grad_beta fp32 [groups, C] (per sample: the caller adds the samples).
+ * No running statistics (track_running_stats = False). */
+size_t liso_in_workspace_bytes(int groups, int c);
+int liso_in_relu_fwd(const void* x, int is_bf16, int groups, long m, int c, const float* gamma, const float* beta, float eps, int relu,
+                     void* y, float* stats, void* workspace, size_t workspace_bytes, void* stream);
+int liso_in_relu_bwd(const void* dy, const void* x, int is_bf16, int groups, long m, int c, const float* gamma, const float* stats,
+                     int relu, void* dx, float* grad_gamma, float* grad_beta, void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

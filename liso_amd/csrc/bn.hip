@@ -70,6 +70,8 @@ __global__ __launch_bounds__(kThreads) void bn_stats_kernel(const T* __restrict_
     constexpr int V = Vec<T>::V;
     __shared__ float s_1[kThreads][V + 1];
     __shared__ float s_2[kThreads][V + 1];
+    x += (size_t)blockIdx.y * m * c;                        // blockIdx.y = group (InstanceNorm: sample), 0 for BatchNorm
+    partial += (size_t)blockIdx.y * gridDim.x * 2 * c;
     const int tid = threadIdx.x;
     const int col = tid % g.cg, rlane = tid / g.cg;
     const long r0 = (long)blockIdx.x * g.rows_per_block;
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(kThreads) void bn_stats_kernel(const T* __restrict_
 #pragma unroll
     for (int j = 0; j < V; j++) { s1[j] = 0.f; s2[j] = 0.f; }
 #pragma unroll 8
-    for (long r = r0 + rlane; r < r1; r += g.rl) {
+    for (long r = rlane < g.rl ? r0 + rlane : r1; r < r1; r += g.rl) {  // (rlane >= rl: C / V does not divide the block, idle lanes)
         float v[V];
         Vec<T>::load(x + r * c + col * V, v);
 #pragma unroll
@@ -115,6 +117,8 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
                                                            float* __restrict__ stats) {
     __shared__ double sh[1024];
     __shared__ double sh_mean[512];
+    partial += (size_t)blockIdx.x * nblk * 2 * c;           // blockIdx.x = group
+    stats += (size_t)blockIdx.x * 4 * c;
     const int tid = threadIdx.x;
     const int chunks = 1024 / c > 0 ? 1024 / c : 1;
     const int ch = tid % c, chunk = tid / c;
@@ -174,7 +178,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
         stats[c + tid] = (float)((double)beta[tid] - mean * (double)gamma[tid] * invstd);
         stats[2 * c + tid] = (float)mean;
         stats[3 * c + tid] = (float)invstd;
-        if (cnt > 1.0) {
+        if (running_mean && cnt > 1.0) {
             running_mean[tid] = (1.f - momentum) * running_mean[tid] + momentum * (float)mean;
             running_var[tid] = (1.f - momentum) * running_var[tid] + momentum * (float)(m2 / (cnt - 1.0));
         }
@@ -198,11 +202,12 @@ __global__ __launch_bounds__(kThreads) void bn_apply_kernel(const T* __restrict_
                                                             const float* __restrict__ stats, T* __restrict__ y) {
     constexpr int V = Vec<T>::V;
     const int col = threadIdx.x % g.cg, rlane = threadIdx.x / g.cg;
+    x += (size_t)blockIdx.y * m * c; y += (size_t)blockIdx.y * m * c; stats += (size_t)blockIdx.y * 4 * c;
     float sc[V], sh[V];
 #pragma unroll
     for (int j = 0; j < V; j++) { sc[j] = stats[col * V + j]; sh[j] = stats[c + col * V + j]; }
     const long stride = (long)gridDim.x * g.rl;
-    for (long r = (long)blockIdx.x * g.rl + rlane; r < m; r += stride) {
+    for (long r = rlane < g.rl ? (long)blockIdx.x * g.rl + rlane : m; r < m; r += stride) {
         float v[V];
         Vec<T>::load(x + r * c + col * V, v);
 #pragma unroll
@@ -222,6 +227,8 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(const T* __rest
     constexpr int V = Vec<T>::V;
     __shared__ float s_a[kThreads][V + 1];
     __shared__ float s_b[kThreads][V + 1];
+    x += (size_t)blockIdx.y * m * c; dy += (size_t)blockIdx.y * m * c; stats += (size_t)blockIdx.y * 4 * c;
+    partial += (size_t)blockIdx.y * gridDim.x * 2 * c;
     const int tid = threadIdx.x;
     const int col = tid % g.cg, rlane = tid / g.cg;
     float sc[V], sh[V], mu[V], is[V], a[V], b[V];
@@ -234,7 +241,7 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(const T* __rest
     const long r0 = (long)blockIdx.x * g.rows_per_block;
     const long r1 = r0 + g.rows_per_block < m ? r0 + g.rows_per_block : m;
 #pragma unroll 4
-    for (long r = r0 + rlane; r < r1; r += g.rl) {
+    for (long r = rlane < g.rl ? r0 + rlane : r1; r < r1; r += g.rl) {
         float vx[V], vg[V];
         Vec<T>::load(x + r * c + col * V, vx);
         Vec<T>::load(dy + r * c + col * V, vg);
@@ -266,6 +273,9 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
                                                                float* __restrict__ grad_gamma, float* __restrict__ grad_beta,
                                                                float* __restrict__ coef) {
     __shared__ double sh_a[1024], sh_b[1024];
+    partial += (size_t)blockIdx.x * nblk * 2 * c;           // blockIdx.x = group
+    stats += (size_t)blockIdx.x * 4 * c; coef += (size_t)blockIdx.x * 3 * c;
+    grad_gamma += (size_t)blockIdx.x * c; grad_beta += (size_t)blockIdx.x * c;
     const int tid = threadIdx.x;
     const int chunks = 1024 / c > 0 ? 1024 / c : 1;
     const int ch = tid % c, chunk = tid / c;
@@ -302,6 +312,8 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_dx_kernel(const T* __restrict
                                                              const float* __restrict__ coef, T* __restrict__ dx) {
     constexpr int V = Vec<T>::V;
     const int col = threadIdx.x % g.cg, rlane = threadIdx.x / g.cg;
+    x += (size_t)blockIdx.y * m * c; dy += (size_t)blockIdx.y * m * c; dx += (size_t)blockIdx.y * m * c;
+    stats += (size_t)blockIdx.y * 4 * c; coef += (size_t)blockIdx.y * 3 * c;
     float sc[V], sh[V], mu[V], is[V], A[V], Bc[V], Cc[V];
 #pragma unroll
     for (int j = 0; j < V; j++) {
@@ -310,7 +322,7 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_dx_kernel(const T* __restrict
         A[j] = coef[ch]; Bc[j] = coef[c + ch]; Cc[j] = coef[2 * c + ch];
     }
     const long stride = (long)gridDim.x * g.rl;
-    for (long r = (long)blockIdx.x * g.rl + rlane; r < m; r += stride) {
+    for (long r = rlane < g.rl ? (long)blockIdx.x * g.rl + rlane : m; r < m; r += stride) {
         float vx[V], vg[V];
         Vec<T>::load(x + r * c + col * V, vx);
         Vec<T>::load(dy + r * c + col * V, vg);
@@ -329,7 +341,7 @@ inline int check_launch() { return hipGetLastError() == hipSuccess ? LISO_OK : L
 inline bool geom(int c, int v, long m, Geom* g, int* nblk) {
     if (c <= 0 || c % v != 0 || c > kThreads) return false;
     const int cg = c / v;
-    if (cg > kThreads || (kThreads % cg) != 0) return false;
+    if (cg > kThreads) return false;
     g->cg = cg;
     g->rl = kThreads / cg;
     // ~256 blocks (1 per CU) keeps the single-block finalize short; never fewer than kRowsPerBlock rows per block
@@ -404,6 +416,56 @@ int liso_bn_relu_bwd(const void* dy, const void* x, int is_bf16, long m, int c, 
         bn_bwd_reduce_kernel<T, R><<<nblk, kThreads, 0, st>>>((const T*)dy, (const T*)x, m, c, g, stats, partial);          \
         bn_bwd_finalize_kernel<<<1, 1024, 0, st>>>(partial, nblk, m, c, gamma, stats, training, grad_gamma, grad_beta, coef); \
         bn_bwd_dx_kernel<T, R><<<grid, kThreads, 0, st>>>((const T*)dy, (const T*)x, m, c, g, stats, coef, (T*)dx);          \
+    } while (0)
+    if (is_bf16) { if (relu) LISO_BWD(__hip_bfloat16, true); else LISO_BWD(__hip_bfloat16, false); }
+    else { if (relu) LISO_BWD(float, true); else LISO_BWD(float, false); }
+#undef LISO_BWD
+    return check_launch();
+}
+
+size_t liso_in_workspace_bytes(int groups, int c) {
+    if (groups <= 0 || c <= 0) return 0;
+    return (size_t)groups * liso_bn_workspace_bytes(c);
+}
+
+int liso_in_relu_fwd(const void* x, int is_bf16, int groups, long m, int c, const float* gamma, const float* beta, float eps, int relu,
+                     void* y, float* stats, void* workspace, size_t workspace_bytes, void* stream) {
+    Geom g;
+    int nblk;
+    if (groups < 1 || m <= 0 || !geom(c, is_bf16 ? 8 : 4, m, &g, &nblk)) return LISO_EINVAL;
+    if (!gamma || !beta || !stats || !workspace || !x || !y) return LISO_EINVAL;
+    if (workspace_bytes < liso_in_workspace_bytes(groups, c)) return LISO_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float* partial = (float*)workspace;
+    const dim3 gs((unsigned)nblk, (unsigned)groups), ga((unsigned)stream_grid(m, g), (unsigned)groups);
+    if (is_bf16)
+        bn_stats_kernel<__hip_bfloat16><<<gs, kThreads, 0, st>>>((const __hip_bfloat16*)x, m, c, g, partial);
+    else
+        bn_stats_kernel<float><<<gs, kThreads, 0, st>>>((const float*)x, m, c, g, partial);
+    bn_finalize_kernel<<<groups, 1024, 0, st>>>(partial, nblk, m, c, g.rows_per_block, gamma, beta, nullptr, nullptr, 0.f, eps, stats);
+#define LISO_APPLY(T, R) bn_apply_kernel<T, R><<<ga, kThreads, 0, st>>>((const T*)x, m, c, g, stats, (T*)y)
+    if (is_bf16) { if (relu) LISO_APPLY(__hip_bfloat16, true); else LISO_APPLY(__hip_bfloat16, false); }
+    else { if (relu) LISO_APPLY(float, true); else LISO_APPLY(float, false); }
+#undef LISO_APPLY
+    return check_launch();
+}
+
+int liso_in_relu_bwd(const void* dy, const void* x, int is_bf16, int groups, long m, int c, const float* gamma, const float* stats,
+                     int relu, void* dx, float* grad_gamma, float* grad_beta, void* workspace, size_t workspace_bytes, void* stream) {
+    Geom g;
+    int nblk;
+    if (groups < 1 || m <= 0 || !geom(c, is_bf16 ? 8 : 4, m, &g, &nblk)) return LISO_EINVAL;
+    if (!dy || !x || !gamma || !stats || !dx || !grad_gamma || !grad_beta || !workspace) return LISO_EINVAL;
+    if (workspace_bytes < liso_in_workspace_bytes(groups, c)) return LISO_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float* partial = (float*)workspace;
+    float* coef = partial + (size_t)groups * kMaxBlocks * 2 * c;
+    const dim3 gs((unsigned)nblk, (unsigned)groups), ga((unsigned)stream_grid(m, g), (unsigned)groups);
+#define LISO_BWD(T, R)                                                                                                     \
+    do {                                                                                                                   \
+        bn_bwd_reduce_kernel<T, R><<<gs, kThreads, 0, st>>>((const T*)dy, (const T*)x, m, c, g, stats, partial);            \
+        bn_bwd_finalize_kernel<<<groups, 1024, 0, st>>>(partial, nblk, m, c, gamma, stats, 1, grad_gamma, grad_beta, coef); \
+        bn_bwd_dx_kernel<T, R><<<ga, kThreads, 0, st>>>((const T*)dy, (const T*)x, m, c, g, stats, coef, (T*)dx);            \
     } while (0)
     if (is_bf16) { if (relu) LISO_BWD(__hip_bfloat16, true); else LISO_BWD(__hip_bfloat16, false); }
     else { if (relu) LISO_BWD(float, true); else LISO_BWD(float, false); }

@@ -15,7 +15,7 @@ from liso_amd import _lib as L
 
 def _supported(c, dtype):
     v = 8 if dtype == torch.bfloat16 else 4
-    return dtype in (torch.float32, torch.bfloat16) and c % v == 0 and c <= 256 and (256 % (c // v)) == 0
+    return dtype in (torch.float32, torch.bfloat16) and c % v == 0 and c <= 256
 
 
 class _BnAct(torch.autograd.Function):

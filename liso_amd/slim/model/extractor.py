@@ -4,6 +4,7 @@ are not used by SLIM's RAFT and are out of scope."""
 import torch
 import torch.nn as nn
 
+from liso_amd.slim.model.fused_norm import in_act
 from liso_amd.utils.mfma_conv import conv2d
 
 
@@ -63,11 +64,11 @@ class ResidualBlock(nn.Module):
         bare = isinstance(self.norm1, nn.Sequential) and len(self.norm1) == 0
         if bare:
             y = conv2d(self.conv2, conv2d(self.conv1, x, relu=True), relu=True)
-        else:
-            y = self.relu(self.norm1(conv2d(self.conv1, x)))
-            y = self.relu(self.norm2(conv2d(self.conv2, y)))
+        else:  # (InstanceNorm + ReLU: one set of channels-last passes, fused_norm.py; other norms: the modules)
+            y = in_act(conv2d(self.conv1, x), self.norm1)
+            y = in_act(conv2d(self.conv2, y), self.norm2)
         if self.downsample is not None:
-            x = self.downsample[1](conv2d(self.downsample[0], x))
+            x = in_act(conv2d(self.downsample[0], x), self.downsample[1], relu=False)
         return self.relu(x + y)
 
 
@@ -123,7 +124,7 @@ class SmallEncoder(nn.Module):
             if isinstance(self.norm1, nn.Sequential) and len(self.norm1) == 0:
                 x = conv2d(self.conv1, x, relu=True)
             else:
-                x = self.relu1(self.norm1(conv2d(self.conv1, x)))
+                x = in_act(conv2d(self.conv1, x), self.norm1)
             x = self.layer3(self.layer2(self.layer1(x)))
             x = conv2d(self.conv2, x)
         if self.training and self.dropout is not None:

@@ -71,3 +71,38 @@ def test_bn_relu_bf16_and_better_than_library_bn():
     xb2 = xb.clone().requires_grad_(True)
     (bn_act(xb2, bn, relu=True) * g).sum().backward()
     assert torch.isfinite(xb2.grad.float()).all() and xb2.grad.dtype == torch.bfloat16
+
+
+@pytest.mark.parametrize("C,H,W,B,affine,relu,dtype", [(32, 64, 64, 2, True, True, torch.float32), (96, 16, 24, 3, True, True, torch.float32),
+                                                       (64, 32, 32, 1, False, False, torch.float32), (96, 32, 32, 2, True, True, torch.bfloat16),
+                                                       (24, 8, 8, 2, True, True, torch.float32)])
+def test_instance_norm_relu_matches_fp64_module(C, H, W, B, affine, relu, dtype):
+    """in_act (the grouped passes of include/liso_bn.h) vs nn.InstanceNorm2d (+ReLU) in fp64: the SLIM encoders' training norm
+    (liso/slim/model/extractor.py:24-38), incl. 96 channels (24 lanes per row: does not divide the 256-thread block) and a bf16 tensor"""
+    from liso_amd.slim.model.fused_norm import in_act, supported
+
+    torch.manual_seed(C + H)
+    x = (torch.randn(B, C, H, W) * torch.linspace(0.2, 2.0, C)[None, :, None, None] + 0.7).cuda().to(dtype)
+    x = x.contiguous(memory_format=torch.channels_last)
+    norm = torch.nn.InstanceNorm2d(C, eps=1e-3, affine=affine).cuda()
+    if affine:
+        with torch.no_grad():
+            norm.weight.uniform_(0.5, 1.5); norm.bias.uniform_(-0.5, 0.5)
+    assert supported(x, norm)
+    ref = torch.nn.InstanceNorm2d(C, eps=1e-3, affine=affine).cuda().double()
+    if affine:
+        ref.load_state_dict({k: v.double() for k, v in norm.state_dict().items()})
+    xd = x.detach().double().requires_grad_(True)
+    yd = ref(xd)
+    yd = F.relu(yd) if relu else yd
+    g = torch.randn_like(yd)
+    (yd * g).sum().backward()
+    xg = x.clone().requires_grad_(True)
+    y = in_act(xg, norm, relu=relu)
+    assert y.shape == x.shape and y.dtype == dtype and y.is_contiguous(memory_format=torch.channels_last)
+    (y.float() * g.float()).sum().backward()
+    tf, tb = (1e-5, 2e-4) if dtype == torch.float32 else (1e-2, 3e-2)
+    assert _rel(y, yd) < tf
+    assert _rel(xg.grad, xd.grad) < tb
+    if affine:
+        assert _rel(norm.weight.grad, ref.weight.grad) < tb and _rel(norm.bias.grad, ref.bias.grad) < tb
