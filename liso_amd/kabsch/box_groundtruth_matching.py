@@ -50,6 +50,16 @@ def slow_greedy_match_boxes_by_desending_confidence_by_dist(non_batched_gt_boxes
 
         dist = distance_matrix(non_batched_gt_boxes_pos.astype(np.float32), non_batched_pred_boxes_pos.astype(np.float32))
         return _greedy_host(dist, np.argsort(non_batched_pred_confidence)[::-1], matching_threshold)
+    if not non_batched_gt_boxes_pos.is_cuda:
+        # host tensors (the sequence tracker keeps its few boxes per frame on the host, as the reference does,
+        # liso/tracker/global_box_tracker.py:56-57): the same calls on the host -- torch.argsort's order of equal confidences is the
+        # host's, which decides the association order when several tracks have confidence 1
+        if n_pred == 0 or n_true == 0:
+            return (np.array([], dtype=np.int64), np.array([], dtype=np.int64), np.array([]), np.zeros(n_pred, dtype=bool),
+                    np.zeros(n_true, dtype=bool))
+        dist = torch.cdist(non_batched_gt_boxes_pos[..., :match_in_nd].to(torch.float32),
+                           non_batched_pred_boxes_pos[..., :match_in_nd].to(torch.float32)).numpy()
+        return _greedy_host(dist, torch.argsort(non_batched_pred_confidence, descending=True).numpy(), matching_threshold)
     L.require_cuda(non_batched_gt_boxes_pos, non_batched_pred_boxes_pos, non_batched_pred_confidence)
     if n_pred == 0 or n_true == 0:
         return (np.array([], dtype=np.int64), np.array([], dtype=np.int64), np.array([]), np.zeros(n_pred, dtype=bool),
