@@ -99,6 +99,21 @@ int liso_fit_boxes_closeness_f32(const float* points, long n, int point_stride, 
 int liso_smooth_tracks_jerk_f32(const float* observed_pos, const uint8_t* valid, int batch, int timesteps, int max_iters,
                                 float learning_rate, float pos_regul_loss_weight, float* smooth_pos, void* stream);
 
+/* ---- bicycle-model track smoothing: the rollout and its adjoint ----------------------------------------------------------------
+ * Replaces forward_compiled / car_dynamics (liso/tracker/track_smoothing.py:300-337,490-528), the scripted loop inside every loss
+ * evaluation of smooth_track_bike_model's L-BFGS (:577-741), and its autograd backward.  One lane per track:
+ *   state = (x, y, heading, velocity, heading rate); per frame t < T-1
+ *   rate' = clamp(rate + steering[t] dt; -max_yaw_rate, max_yaw_rate), heading' = heading + dt |velocity| / length * rate',
+ *   velocity' = clamp(velocity + accel[t] dt; 0, max_velocity), x' = x + velocity' cos(heading') dt, y' likewise with sin;
+ *   clamp(u; a, b) = a + (b - a) (0.5 + atan(u / 100) / pi)   (soft_sigmoid_clamp, :28-35).
+ * initial_state [batch,5]; accel, steering [batch,T] (column T-1 is not read); vehicle_length [batch]; states [batch,T,5].
+ * Backward: grad_states [batch,T,5] -> grad_initial_state [batch,5], grad_accel / grad_steering [batch,T] (column T-1 = 0). */
+int liso_bike_rollout_fwd_f32(int batch, int timesteps, const float* initial_state, const float* accel, const float* steering,
+                              const float* vehicle_length, float dt, float max_yaw_rate, float max_velocity, float* states, void* stream);
+int liso_bike_rollout_bwd_f32(int batch, int timesteps, const float* accel, const float* steering, const float* vehicle_length, float dt,
+                              float max_yaw_rate, float max_velocity, const float* states, const float* grad_states,
+                              float* grad_initial_state, float* grad_accel, float* grad_steering, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

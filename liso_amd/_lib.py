@@ -172,6 +172,8 @@ SIGNATURES = {
     "liso_match_greedy_f32": (_i, [_vp, ctypes.c_long, ctypes.c_long, _i, _i, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "liso_fit_boxes_closeness_workspace_bytes": (_sz, [ctypes.c_long, _i]),
     "liso_fit_boxes_closeness_f32": (_i, [_vp, ctypes.c_long, _i, _vp, _vp, _i, _f, _vp, _vp, _vp, _sz, _vp]),
+    "liso_bike_rollout_fwd_f32": (_i, [_i, _i, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp]),
+    "liso_bike_rollout_bwd_f32": (_i, [_i, _i, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "liso_smooth_tracks_jerk_f32": (_i, [_vp, _vp, _i, _i, _i, _f, _f, _vp, _vp]),
     # include/liso_augment.h
     "liso_bev_free_mask_workspace_bytes": (_sz, [_i, _i]),

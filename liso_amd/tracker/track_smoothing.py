@@ -12,7 +12,10 @@ Parity: the reference's own result moves by 4e-2 m when one input coordinate cha
 jittering around the optimum; measured, stored in tests/golden/track_smoothing_reference.npz).  Short runs (1 / 3 / 20 steps) match the
 reference to float32 rounding; the 2000-step result matches within that sensitivity and in the final loss.
 
-The bicycle-model variant (`smooth_track_bike_model`) is not built."""
+The bicycle-model variant (`smooth_track_bike_model`, :300-741; `track_smoothing_method: "bike_model"`) keeps the reference's optimiser
+(torch.optim.LBFGS with strong-Wolfe line search, 20 inner iterations x `max_iters` steps) and replaces what every one of its loss
+evaluations spends its time in: the scripted per-frame rollout (~30 launches per frame and direction) is one launch forward and one
+backward (liso_bike_rollout_{fwd,bwd}_f32, one lane per track, hand-written adjoint)."""
 import numpy as np
 import torch
 
@@ -88,3 +91,148 @@ def smooth_track_jerk(batched_observed_pos_m, batched_valid_mask, batched_observ
     last = batched_valid_mask.sum(dim=1) - 1
     rot_along_track[batch_idx, last, 0] = rot_along_track[batch_idx, last - 1, 0]
     return track_positions_m, rot_along_track, batched_displacement_from_pos(track_positions_m)[..., None]
+
+
+# ---- bicycle-model smoothing (reference :15-35, :300-741) ---------------------------------------------------------------------------
+def torch_yaw_signed_diff(gt_yaw, pred_yaw, period: float = 2 * np.pi):
+    diff = (gt_yaw - pred_yaw + period / 2) % period - period / 2
+    return torch.where(diff > np.pi, diff - (2 * np.pi), diff)
+
+
+def per_batch_mean_loss(per_element_loss, valid_mask, num_elements_in_batch):
+    return torch.sum(per_element_loss * valid_mask.float(), dim=-1) / num_elements_in_batch
+
+
+class _BikeRollout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, initial_state, accel, steering, vehicle_length, dt, max_yaw_rate, max_velocity):
+        L.require_cuda(initial_state, accel, steering, vehicle_length)
+        init, a, st = initial_state.float().contiguous(), accel.float().contiguous(), steering.float().contiguous()
+        ln = vehicle_length.float().contiguous()
+        B, T = a.shape
+        states = torch.empty((B, T, 5), dtype=torch.float32, device=a.device)
+        with torch.cuda.device(a.device):
+            L.check(L.TIMER.launch("bike_rollout_fwd", lambda: L.lib().liso_bike_rollout_fwd_f32(
+                B, T, L.ptr(init), L.ptr(a), L.ptr(st), L.ptr(ln), float(dt), float(max_yaw_rate), float(max_velocity), L.ptr(states),
+                L.stream_ptr())), "bike_rollout_fwd")
+        ctx.save_for_backward(a, st, ln, states)
+        ctx.cfg = (float(dt), float(max_yaw_rate), float(max_velocity))
+        return states
+
+    @staticmethod
+    def backward(ctx, grad_states):
+        a, st, ln, states = ctx.saved_tensors
+        B, T = a.shape
+        g = grad_states.float().contiguous()
+        gi = torch.empty((B, 5), dtype=torch.float32, device=a.device)
+        ga, gs = torch.empty_like(a), torch.empty_like(st)
+        dt, myr, mv = ctx.cfg
+        with torch.cuda.device(a.device):
+            L.check(L.TIMER.launch("bike_rollout_bwd", lambda: L.lib().liso_bike_rollout_bwd_f32(
+                B, T, L.ptr(a), L.ptr(st), L.ptr(ln), dt, myr, mv, L.ptr(states), L.ptr(g), L.ptr(gi), L.ptr(ga), L.ptr(gs),
+                L.stream_ptr())), "bike_rollout_bwd")
+        return gi, ga, gs, None, None, None, None
+
+
+class BatchedBikeModel(torch.nn.Module):
+    """reference :340-457: a batch of tracks as kinematic bicycle models -- per-frame acceleration / steering inputs and the initial
+    state are the parameters, the positions follow from the rollout.  state = [x, y, heading, velocity, heading rate]"""
+
+    def __init__(self, *, batched_observed_track_pos, batched_vehicle_length, time_between_frames_s: float, max_yaw_rate: float,
+                 max_velocity: float, optimize_initial_pos=True):
+        super().__init__()
+        assert len(batched_observed_track_pos.shape) == 3, batched_observed_track_pos.shape
+        B, T, _ = batched_observed_track_pos.shape
+        assert T >= MIN_TRACK_LEN_FOR_SMOOTHING, f"need at least {MIN_TRACK_LEN_FOR_SMOOTHING} positions for smoothing"
+        self.batch_size, self.num_time_steps = int(B), int(T)
+        obs = batched_observed_track_pos
+        self.propagated_states = []
+        velo0 = torch.linalg.norm(obs[:, 2:, :2] - obs[:, :-2, :2], dim=-1) / (2 * time_between_frames_s)
+        yaw0 = get_orientations_along_track(pos=obs[:, :, :2])
+        yaw_rate0 = torch_yaw_signed_diff(yaw0[:, 1:], yaw0[:, :1]) / time_between_frames_s
+        P = torch.nn.Parameter
+        self.accel_over_time = P(torch.zeros_like(obs[..., 0]), requires_grad=True)
+        self.steering_input_over_time = P(torch.zeros_like(obs[..., 0]), requires_grad=True)
+        self.initial_pos = P(obs[:, 0, 0:2], requires_grad=optimize_initial_pos)
+        self.initial_yaw = P(yaw0[:, [0]], requires_grad=True)
+        self.initial_velo_mps = P(velo0[:, [0]], requires_grad=True)
+        self.initial_yaw_rate_radps = P(yaw_rate0[:, [0]], requires_grad=True)
+        self.x_idx, self.y_idx, self.heading_idx, self.velo_idx, self.hdot_idx = 0, 1, 2, 3, 4
+        self.time_between_frames_s = float(time_between_frames_s)
+        assert batched_vehicle_length.shape == (B,)
+        self.vehicle_length, self.max_yaw_rate, self.max_velocity = batched_vehicle_length, max_yaw_rate, max_velocity
+
+    def forward(self):
+        initial_state = torch.cat([self.initial_pos, self.initial_yaw, self.initial_velo_mps, self.initial_yaw_rate_radps], dim=-1)
+        self.propagated_states = _BikeRollout.apply(initial_state, self.accel_over_time, self.steering_input_over_time, self.vehicle_length,
+                                                    self.time_between_frames_s, self.max_yaw_rate, self.max_velocity)
+        return self.propagated_states
+
+    @property
+    def pos(self):
+        return self.propagated_states[..., [self.x_idx, self.y_idx]]
+
+    @property
+    def rot(self):
+        return self.propagated_states[..., [self.heading_idx]]
+
+    @property
+    def yaw_rate(self):
+        return self.propagated_states[..., [self.hdot_idx]]
+
+    @property
+    def velo(self):
+        return self.propagated_states[..., [self.velo_idx]]
+
+    def get_pos_jerk_magnitude(self):
+        return torch.linalg.norm(torch.diff(self.pos, n=3, dim=0), dim=-1)
+
+
+def smooth_track_bike_model(*, batched_observed_pos_m, batched_valid_mask, batched_observed_yaw_angle_rad, batched_vehicle_length_m,
+                            time_between_frames_s: float, max_iters=30, learning_rate=0.1, accel_penalty_weight=0.1,
+                            velo_penalty_weight=0.1, pos_regul_loss_weight=1.0, max_velocity_mps=50.0, max_yaw_rate_radps=np.pi / 2,
+                            verbose=False, return_losses=False):
+    """reference :577-741 -- same arguments and return tuple (positions [B,T,3], headings [B,T,1], per-frame displacement [B,T,1]
+    (+ the loss terms of every evaluation with `return_losses`))"""
+    batched_observed_pos_m = batched_observed_pos_m.clone()
+    batched_observed_yaw_angle_rad = batched_observed_yaw_angle_rad.clone()
+    if batched_observed_pos_m.shape[1] < MIN_TRACK_LEN_FOR_SMOOTHING:
+        return batched_observed_pos_m, batched_observed_yaw_angle_rad, batched_displacement_from_pos(batched_observed_pos_m)
+    track = BatchedBikeModel(batched_observed_track_pos=batched_observed_pos_m, time_between_frames_s=time_between_frames_s,
+                             batched_vehicle_length=batched_vehicle_length_m, max_velocity=max_velocity_mps,
+                             max_yaw_rate=max_yaw_rate_radps)
+    optimizer = torch.optim.LBFGS(track.parameters(), lr=learning_rate, max_iter=20, line_search_fn="strong_wolfe")
+    track.train()
+    losses = []
+    valid = batched_valid_mask
+    n_valid = torch.sum(valid, dim=1)
+    zeros = torch.zeros((valid.shape[0],), device=batched_observed_pos_m.device)
+
+    def closure():
+        optimizer.zero_grad()
+        track.forward()
+        lin = yaw = rate = zeros
+        if accel_penalty_weight > 0.0:
+            lin = accel_penalty_weight * per_batch_mean_loss(track.accel_over_time ** 2, valid, n_valid)
+            yaw = accel_penalty_weight * per_batch_mean_loss(track.steering_input_over_time ** 2, valid, n_valid)
+        if velo_penalty_weight > 0.0:
+            r = torch.squeeze(track.yaw_rate, dim=-1)
+            rate = per_batch_mean_loss(torch.where(torch.abs(r) > max_yaw_rate_radps, r ** 2, torch.zeros_like(r)), valid, n_valid)
+        shift = ((track.pos - batched_observed_pos_m[:, :, :2]) ** 2).sum(dim=-1)
+        pos = pos_regul_loss_weight * per_batch_mean_loss(shift, valid, n_valid)
+        per_track = lin + yaw + rate + pos
+        loss = per_track.mean()
+        loss.backward()
+        if return_losses:
+            losses.append({"per_batch_loss": per_track.detach().cpu().numpy(), "linear_accel_penalty": lin.detach().cpu().numpy(),
+                           "yaw_accel_penalty": yaw.detach().cpu().numpy(), "yaw_rate_penalty": rate.detach().cpu().numpy(),
+                           "pos_regul": pos.detach().cpu().numpy()})
+        return loss
+
+    for _ in range(max_iters):
+        optimizer.step(closure)
+    optimized_pos = torch.cat([track.pos, batched_observed_pos_m[:, :, 2:]], dim=-1)
+    optimized_velo = batched_displacement_from_pos(optimized_pos)[..., None]
+    if return_losses:
+        return optimized_pos, track.rot, optimized_velo, losses
+    return optimized_pos, track.rot, optimized_velo
