@@ -108,14 +108,14 @@ _OUT_SHAPES = {"dis_logit": (), "dis": (), "logits": (3,), "probs": (3,), "stati
 
 class _DecodePoints(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, raw, trafo, meta):
+    def forward(ctx, raw, trafo, meta, want=None):
         S, N, _, _ = meta.shape
         raw = raw.contiguous()
         T = trafo.detach().double().contiguous()
         dev = raw.device
-        outs = {k: torch.empty((S, N) + _OUT_SHAPES[k], dtype=torch.float32, device=dev) for k in _OUT}
-        flags = torch.empty((S, N, 3), dtype=torch.bool, device=dev)
-        o = L.SlimDecodeOut(*[L.ptr(outs[k]) for k in _OUT], L.ptr(flags))
+        outs = {k: (torch.empty((S, N) + _OUT_SHAPES[k], dtype=torch.float32, device=dev) if want is None or k in want else None) for k in _OUT}
+        flags = torch.empty((S, N, 3), dtype=torch.bool, device=dev) if want is None else None
+        o = L.SlimDecodeOut(*[L.ptr(outs[k]) if outs[k] is not None else None for k in _OUT], L.ptr(flags) if flags is not None else None)
         with torch.cuda.device(dev):
             L.check(L.lib().liso_slim_decode_points_fwd(
                 ctypes.byref(meta.cfg), L.ptr(raw), L.ptr(meta.lin), L.ptr(meta.filled),
@@ -124,7 +124,8 @@ class _DecodePoints(torch.autograd.Function):
         ctx.save_for_backward(raw, T)
         ctx.meta = meta
         ctx.set_materialize_grads(False)
-        ctx.mark_non_differentiable(flags)
+        if flags is not None:
+            ctx.mark_non_differentiable(flags)
         return tuple(outs[k] for k in _OUT) + (flags,)
 
     @staticmethod
@@ -154,12 +155,12 @@ class _DecodePoints(torch.autograd.Function):
             gT[:, :2, 0] = (g64 * cx[..., None]).sum(dim=1)
             gT[:, :2, 1] = (g64 * cy[..., None]).sum(dim=1)
             gT[:, :2, 3] = g64.sum(dim=1)
-        return graw, gT, None
+        return graw, gT, None, None
 
 
-def decode_points(raw, trafo, meta):
-    """-> dict of the per-point predictions (float tensors + `flags` bool [S,N,3])"""
-    res = _DecodePoints.apply(raw, trafo, meta)
+def decode_points(raw, trafo, meta, want=None):
+    """-> dict of the per-point predictions (float tensors + `flags` bool [S,N,3]); `want`: the subset of outputs to write (inference)"""
+    res = _DecodePoints.apply(raw, trafo, meta, want)
     out = dict(zip(_OUT, res[:-1]))
     out["flags"] = res[-1]
     return out

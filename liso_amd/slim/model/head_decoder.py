@@ -202,11 +202,13 @@ class HeadDecoder(nn.Module):
     def forward(self, network_output, dynamicness_threshold, *, pc, pointwise_voxel_coordinates, pointwise_valid_mask,
                 filled_pillar_mask, odom, inv_odom, summaries, gt_flow_bev=None, per_point_cluster_idxs_gt=None,
                 ohe_gt_stat_dyn_ground_label_bev_map=None, dynamic_flow_is_non_rigid_flow=False, gather_plan=None,
-                pointwise_only=False):
+                pointwise_only=False, aggregated_flow_only=False):
         """reference :410-496.  `gather_plan` (extension): a BevGatherPlan of (pointwise_voxel_coordinates // final_scale,
         pointwise_valid_mask) to reuse across the RAFT iterations of one cloud; built here when absent.
         `pointwise_only` (extension, training): return the per-point predictions, `static_aggr_trafo`, `not_enough_points`
-        and `dynamicness_threshold` only -- everything the losses read -- without `dense_maps` / `modified_network_output`."""
+        and `dynamicness_threshold` only -- everything the losses read -- without `dense_maps` / `modified_network_output`.
+        `aggregated_flow_only` (extension, inference; with `pointwise_only`): the caller reads nothing but `aggregated_flow`; when that
+        does not depend on the static aggregation (model.use_static_aggr_flow_for_aggr_flow False) the Kabsch fit is skipped."""
         coors_fs = torch.div(pointwise_voxel_coordinates, self.cfg.model.u_net.final_scale, rounding_mode="trunc")
         if gather_plan is None:
             gather_plan = BevGatherPlan(coors_fs, pointwise_valid_mask, network_output.shape[1:3])
@@ -215,7 +217,7 @@ class HeadDecoder(nn.Module):
             return self._forward_pointwise(network_output, dynamicness_threshold, pc=pc, coors_fs=coors_fs,
                                            pointwise_valid_mask=pointwise_valid_mask, filled_pillar_mask=filled_pillar_mask,
                                            inv_odom=inv_odom, dynamic_flow_is_non_rigid_flow=dynamic_flow_is_non_rigid_flow,
-                                           gather_plan=gather_plan)
+                                           gather_plan=gather_plan, aggregated_flow_only=aggregated_flow_only)
         (modified, nod, gt_flow_bev, _, _, _, _, _, static_aggr_trafo, not_enough_points) = self.apply_output_modification(
             network_output, dynamicness_threshold, pc=pc, pointwise_voxel_coordinates_fs=coors_fs,
             pointwise_valid_mask=pointwise_valid_mask, filled_pillar_mask=filled_pillar_mask, inv_odom=inv_odom,
@@ -233,7 +235,7 @@ class HeadDecoder(nn.Module):
 
 
     def _forward_pointwise(self, network_output, dynamicness_threshold, *, pc, coors_fs, pointwise_valid_mask, filled_pillar_mask,
-                           inv_odom, dynamic_flow_is_non_rigid_flow, gather_plan):
+                           inv_odom, dynamic_flow_is_non_rigid_flow, gather_plan, aggregated_flow_only=False):
         """Gather first, decode second.  Every step of apply_output_modification (:67-298) is pointwise in the BEV cell --
         defaults at unfilled pillars, softmax, thresholds, flow selection -- except (a) the BEV-wide extrema of the
         True / False logit modes and (b) the static aggregation, which itself only reads the maps at the points' pillars and
@@ -253,6 +255,10 @@ class HeadDecoder(nn.Module):
                 extremes = channel_extrema(network_output[..., :4].detach())
             meta = FD.DecodeMeta(self.cfg, self.bev_extent, gather_plan, filled_pillar_mask, extremes, dynamicness_threshold,
                                  pc.contiguous(), non_rigid=dynamic_flow_is_non_rigid_flow)
+            if aggregated_flow_only and not self.cfg.model.use_static_aggr_flow_for_aggr_flow and not torch.is_grad_enabled():
+                eye = _cached_eye(S, raw.device)
+                return Munch(aggregated_flow=FD.decode_points(raw, eye, meta, want=("agg_flow",))["agg_flow"],
+                             dynamicness_threshold=dynamicness_threshold)
             x, y, w = FD.decode_weights(raw, meta)
             from liso_amd.slim.slim_loss.weighted_pc_alignment import batched_weighted_pc_alignment
 
@@ -369,6 +375,13 @@ def artificial_network_output(*, network_output_dict: Dict[str, torch.Tensor], d
 
 
 _VECTOR_CACHE = {}
+
+
+def _cached_eye(n, device):
+    key = ("eye", n, str(device))
+    if key not in _VECTOR_CACHE:
+        _VECTOR_CACHE[key] = torch.eye(4, dtype=torch.float64, device=device)[None].repeat(n, 1, 1).contiguous()
+    return _VECTOR_CACHE[key]
 
 
 def _cached_vector(values, device, dtype):

@@ -68,7 +68,8 @@ class SLIM(nn.Module):
             pointwise_voxel_coordinates=pa["pillar_coors"].to(dev), pointwise_valid_mask=pa["pcl_is_valid"].to(dev),
             filled_pillar_mask=torch.squeeze(aux["t0"]["bev_net_input_dbg"] > 0.5, dim=1),
             odom=sample_data_t0["gt"]["odom_ta_tb"].to(dev), inv_odom=sample_data_t1["gt"]["odom_ta_tb"].to(dev), summaries=None,
-            dynamic_flow_is_non_rigid_flow=self.slim_cfg.model.dynamic_flow_is_non_rigid_flow)
+            dynamic_flow_is_non_rigid_flow=self.slim_cfg.model.dynamic_flow_is_non_rigid_flow, pointwise_only=True,
+            aggregated_flow_only=True)
         return pred.aggregated_flow
 
     def build_gather_plan(self, sample_data_t0, sample_data_t1, n_it, grid_hw):
@@ -81,7 +82,7 @@ class SLIM(nn.Module):
         cat = lambda a, b: torch.cat([a.to(dev), b.to(dev)], dim=0)  # noqa: E731
         tile = lambda t: torch.cat([t[:B]] * n_it + [t[B:]] * n_it, dim=0)  # noqa: E731
         valid_all, coors_all = tile(cat(pa["pcl_is_valid"], pb["pcl_is_valid"])), tile(cat(pa["pillar_coors"], pb["pillar_coors"]))
-        return BevGatherPlan(torch.div(coors_all, fs, rounding_mode="trunc"), valid_all, grid_hw)
+        return BevGatherPlan(torch.div(coors_all, fs, rounding_mode="trunc"), valid_all, grid_hw).prepare_backward()
 
     def forward(self, sample_data_t0, sample_data_t1, summaries=None, canvases=None, gather_plan=None):
         """`canvases` (extension): the pillar canvases of both sweeps, `raft_network.encode_pillars(...)`, computed by the caller;

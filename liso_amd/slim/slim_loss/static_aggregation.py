@@ -17,12 +17,35 @@ class BevGatherPlan:
         b = torch.arange(B, device=c.device)[:, None]
         lin = (b * H + c[..., 0]) * W + c[..., 1]
         self.lin = torch.where(pointwise_valid_mask, lin, -1).to(torch.int32).reshape(-1).contiguous()
-        sorted_lin, order = torch.sort(self.lin, stable=True)
-        self.sorted_lin, self.order = sorted_lin.contiguous(), order.to(torch.int32).contiguous()
-        pos = torch.arange(sorted_lin.numel(), device=c.device, dtype=torch.int32)
-        # first row of every run of equal cells = lower bound of the value in the sorted list itself
-        self.seg_rank = (pos - torch.searchsorted(sorted_lin, sorted_lin, right=False).to(torch.int32)).contiguous()
         self.shape = (B, N, H, W)
+        self._sorted = None
+
+    def _sort(self):
+        """the cell-sorted view of the list: only the adjoint needs it (inference never builds it)"""
+        if self._sorted is None:
+            sorted_lin, order = torch.sort(self.lin, stable=True)
+            pos = torch.arange(sorted_lin.numel(), device=self.lin.device, dtype=torch.int32)
+            # first row of every run of equal cells = lower bound of the value in the sorted list itself
+            seg_rank = (pos - torch.searchsorted(sorted_lin, sorted_lin, right=False).to(torch.int32)).contiguous()
+            self._sorted = (sorted_lin.contiguous(), order.to(torch.int32).contiguous(), seg_rank)
+        return self._sorted
+
+    def prepare_backward(self):
+        """build the sorted view now (callers that capture the backward pass into a hipGraph: the sort must stay outside)"""
+        self._sort()
+        return self
+
+    @property
+    def sorted_lin(self):
+        return self._sort()[0]
+
+    @property
+    def order(self):
+        return self._sort()[1]
+
+    @property
+    def seg_rank(self):
+        return self._sort()[2]
 
     @property
     def lin64(self):
