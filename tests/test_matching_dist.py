@@ -55,8 +55,11 @@ def test_device_greedy_distance_matching_matches_reference(g):
         res = slow_greedy_match_boxes_by_desending_confidence_by_dist(
             torch.from_numpy(gt).cuda(), torch.from_numpy(pred).cuda(), torch.from_numpy(conf).cuda(), thr, match_in_nd=2)
         _same(res, g, f"m{i}_greedy")
-    with pytest.raises(Exception):  # device operator: CPU tensors are refused (no CPU fallback)
-        slow_greedy_match_boxes_by_desending_confidence_by_dist(torch.zeros(2, 3), torch.zeros(2, 3), torch.zeros(2), 1.0)
+    # host tensors (the sequence tracker's per-frame boxes live on the host, as in the reference): the reference's own host calls
+    for i in range(int(g["n_cases"])):
+        gt, pred, conf, thr = g[f"m{i}_gt_pos"], g[f"m{i}_pred_pos"], g[f"m{i}_conf"], float(g[f"m{i}_thr"])
+        _same(slow_greedy_match_boxes_by_desending_confidence_by_dist(torch.from_numpy(gt), torch.from_numpy(pred), torch.from_numpy(conf), thr,
+                                                                      match_in_nd=2), g, f"m{i}_greedy")
 
 
 @pytest.mark.gpu
