@@ -152,6 +152,12 @@ int liso_residual_affine_relu_f32(const float* a, const float* a_scale, const fl
                                   const float* b_scale, const float* b_shift, int b_stride, int b_relu, float* out, int batch,
                                   long pixels, int c, void* stream);
 
+/* Process-wide launch-plan options.  LISO_CONV_OPT_SHARED_GPU (value != 0): kernels of other streams run next to the convolutions
+ * (the three pipeline stages of the LISO loop) -- plans then never spend a CU's whole LDS on one block, so that other kernels' blocks
+ * can share the CU.  Results are unaffected.  Returns LISO_EINVAL for an unknown option. */
+#define LISO_CONV_OPT_SHARED_GPU 1
+int liso_conv_set_option(int option, int value);
+
 #ifdef __cplusplus
 }
 #endif

@@ -162,6 +162,7 @@ SIGNATURES = {
     "liso_conv_pack_weights": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "liso_conv_stats_rows": (_i, [_vp]),
     "liso_conv_forward": (_i, [_vp] * 10),
+    "liso_conv_set_option": (_i, [_i, _i]),
     "liso_conv_forward_sparse": (_i, [_vp] * 11),
     "liso_conv_wgrad_workspace_bytes": (_sz, [_vp]),
     "liso_conv_wgrad": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
@@ -184,6 +185,7 @@ SIGNATURES = {
 
 
 CONV_MAX_TAPS, CONV_MAX_CLASSES, CONV_BF16, CONV_F32X3, CONV_F32 = 49, 4, 0, 1, 2
+CONV_OPT_SHARED_GPU = 1
 
 
 class ConvDesc(ctypes.Structure):

@@ -1161,6 +1161,8 @@ struct Plan {
     FwdArgs a;
 };
 
+int g_shared_gpu = 0;  // liso_conv_set_option(LISO_CONV_OPT_SHARED_GPU)
+
 bool make_plan(const liso_conv_desc& d, Plan* p) {
     if (d.batch <= 0 || d.ci <= 0 || d.co <= 0 || d.n_classes < 1 || d.n_classes > LISO_CONV_MAX_CLASSES) return false;
     if (d.n_taps < 1 || d.n_taps > LISO_CONV_MAX_TAPS || d.class_tap_begin[0] != 0 || d.class_tap_begin[d.n_classes] != d.n_taps)
@@ -1227,10 +1229,14 @@ bool make_plan(const liso_conv_desc& d, Plan* p) {
         if (v == cs_opts[0] || v == cs_opts[1]) cs_opts[0] = cs_opts[1] = v;
     }
     long best = -1;
-    bool few_blocks = blocks(4 * mi_first) <= 256;  // at most one block per CU anyway: spend its whole LDS
+    // at most one block per CU anyway: spend its whole LDS -- unless other streams' kernels share the GPU (the LISO loop's three
+    // pipeline stages): a block that owns all 160 KB keeps every other kernel's blocks off its CU while its own 4 waves mostly wait
+    // (loop, 60 steps: 6.16 -> 6.04 ms per step with the 79-KB plans)
+    bool few_blocks = !g_shared_gpu && blocks(4 * mi_first) <= 256;
     if (const char* e = getenv("LISO_CONV_FEW")) few_blocks = few_blocks && atoi(e) != 0;  // experiments
     for (int pass = 0; pass < 2 && best < 0; pass++) {
-        const int cap = (pass == 0 && !few_blocks ? 79 : 158) * 1024;
+        int cap = (pass == 0 && !few_blocks ? 79 : 158) * 1024;
+        if (const char* e = getenv("LISO_CONV_LDS_KB")) { if (pass == 0 && atoi(e) >= 16) cap = atoi(e) * 1024; }  // experiments
         for (int mi = mi_first; mi >= 1; mi--) {
             int inh[LISO_CONV_MAX_CLASSES], inw[LISO_CONV_MAX_CLASSES], y0s[LISO_CONV_MAX_CLASSES], x0s[LISO_CONV_MAX_CLASSES];
             const int max_pix = tile_pixels(4 * mi, inh, inw, y0s, x0s);
@@ -1366,6 +1372,12 @@ int launch(const liso_conv_desc& d, const Plan& p, hipStream_t st) {
 }
 
 }  // namespace
+
+extern "C" int liso_conv_set_option(int option, int value) {
+    if (option != LISO_CONV_OPT_SHARED_GPU) return LISO_EINVAL;
+    g_shared_gpu = value != 0;
+    return LISO_OK;
+}
 
 extern "C" {
 

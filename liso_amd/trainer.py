@@ -972,6 +972,15 @@ class LisoLoopTrainer:
         return self.step_batch([(sample_t0, sample_t1)], upcoming)
 
     def step_batch(self, pairs, upcoming=()):
+        """`_step_batch` with the convolution plans of a shared GPU (the three pipeline stages run next to each other)"""
+        if self.device.type != "cuda":
+            return self._step_batch(pairs, upcoming)
+        from liso_amd.utils import mfma_conv as MC
+
+        with MC.shared_gpu():
+            return self._step_batch(pairs, upcoming)
+
+    def _step_batch(self, pairs, upcoming=()):
         """one iteration on a BATCH of sweep pairs (each a (sample_t0, sample_t1) with batch size 1): boxes are mined per pair, the
         detector takes ONE train step on the batch of len(pairs) clouds and target maps -- the reference's `batch_size` (2 in
         liso_config.yml:121, 4 in the README commands :637-639), BatchNorm statistics over that batch like the reference's.

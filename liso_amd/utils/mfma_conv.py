@@ -185,6 +185,28 @@ def as_nhwc(t, vec):
 _PACK_CACHE = {}
 
 
+_SHARED_DEPTH = [0]
+
+
+class shared_gpu:
+    """`with shared_gpu():` -- the launches planned inside (incl. those captured into hipGraphs) share the GPU with other streams'
+    kernels: convolution plans never take a CU's whole LDS for one block (include/liso_conv.h: LISO_CONV_OPT_SHARED_GPU).  The LISO
+    loop's pipeline runs its steps inside; stand-alone trainers keep the single-stream plans.  Results do not depend on it beyond
+    the summation order inside a convolution."""
+
+    def __enter__(self):
+        _SHARED_DEPTH[0] += 1
+        if _SHARED_DEPTH[0] == 1:
+            L.check(L.lib().liso_conv_set_option(L.CONV_OPT_SHARED_GPU, 1), "conv_set_option")
+        return self
+
+    def __exit__(self, *exc):
+        _SHARED_DEPTH[0] -= 1
+        if _SHARED_DEPTH[0] == 0:
+            L.check(L.lib().liso_conv_set_option(L.CONV_OPT_SHARED_GPU, 0), "conv_set_option")
+        return False
+
+
 _PACK_RECORD = None  # dict while the pack requests of a step are being recorded
 _STEP_PACKS = None   # dict while a step runs on panels that were packed by ONE batched launch
 

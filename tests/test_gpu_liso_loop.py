@@ -319,9 +319,12 @@ def test_batched_loop_step_trains_on_the_batch_and_pipeline_equals_sequential(us
             torch.manual_seed(0)
             ref = LisoLoopTrainer(cfg, dev, compute_dtype=torch.bfloat16, total_steps=20, use_graph=False, overlap=False)
             ref.slim.load_state_dict(tr.slim.state_dict()), ref.detector.net.load_state_dict(tr.detector.net.state_dict())
-            ts = [ref._targets_from_flow(p[0], ref._infer_flow(*p))[0] for p in pairs[:2]]
-            cat = {k: torch.cat([t[k] for t in ts], dim=0) for k in ts[0]}
-            ref_loss = float(ref.detector.step([pairs[0][0]["pcl_full_no_ground_ta"][0], pairs[1][0]["pcl_full_no_ground_ta"][0]], cat))
+            from liso_amd.utils import mfma_conv as MC
+
+            with MC.shared_gpu():  # (the launch plans of the loop's steps: same summation order inside every convolution)
+                ts = [ref._targets_from_flow(p[0], ref._infer_flow(*p))[0] for p in pairs[:2]]
+                cat = {k: torch.cat([t[k] for t in ts], dim=0) for k in ts[0]}
+                ref_loss = float(ref.detector.step([pairs[0][0]["pcl_full_no_ground_ta"][0], pairs[1][0]["pcl_full_no_ground_ta"][0]], cat))
         losses, boxes = [], []
         for i in range(5):
             cur = [pairs[(2 * i + k) % 6] for k in range(2)]
