@@ -40,6 +40,21 @@ s0, s1 = slim_pair(2, dev, n_points=120000, grid=512, bev_range_m=100.0)
 for _ in range(3):
     tr.step(s0, s1)
 which = sys.argv[1] if len(sys.argv) > 1 else "slim"
+if which == "glue":  # the eager launches AROUND the replayed graphs of steady-state loop steps (2 pairs per step, 4 steps)
+    pairs = [slim_pair(10 + i % 2, dev, n_points=120000, grid=512, bev_range_m=100.0) for i in range(8)]  # (two distinct pairs: one graph signature)
+    ring = lambda i: [pairs[(2 * i + k) % 8] for k in range(2)]  # noqa: E731
+    up = lambda i: [p for j in range(1, 5) for p in ring(i + j)]  # noqa: E731
+    for i in range(16):
+        tr.step_batch(ring(i), upcoming=up(i))
+    torch.cuda.synchronize()
+    with Sites() as st:
+        for i in range(16, 20):
+            tr.step_batch(ring(i), upcoming=up(i))
+    tot = sum(v[0] for v in st.c.values())
+    print(f"glue: {tot / 4:.1f} non-view aten ops per step outside the graphs")
+    for (name, site), (n, mb) in sorted(st.c.items(), key=lambda kv: -kv[1][0])[:80]:
+        print(f"{n / 4:6.1f} x {name:22s} {mb / 4:9.2f} MB  {site}")
+    sys.exit(0)
 with Sites() as st:
     if which == "slim":
         with torch.no_grad():
