@@ -83,3 +83,60 @@ def test_flow_cluster_detector_without_motion_returns_no_boxes():
               "gt": {k: v[0] for k, v in sample["gt"].items()}, "src_trgt_time_delta_s": sample["src_trgt_time_delta_s"][0]}
     b1 = det(single, global_step=1, is_batched=False)  # reference :105-112 un-batched call
     assert b1.valid.shape == (0,)
+
+
+def test_slim_decoder_kernels_with_a_sample_of_padding_rows_only():
+    """include/liso_slim_decode.h: a sample whose rows are all padding next to a small cloud (4 points, 3 padding rows) through the fused
+    decoder and the static-points loss: zeros out and zero gradients for every padding row, gradients only at the points' pillars"""
+    from liso_amd.slim.model.head_decoder import HeadDecoder
+    from liso_amd.slim.model import fused_decode as FD
+    from liso_amd.utils.config import default_cfg
+
+    cfg = default_cfg(grid=32, bev_range_m=20.0)
+    ext = np.array([-10.0, -10.0, 10.0, 10.0])
+    dec = HeadDecoder(cfg.SLIM, "d", ext)
+    S, N, G, K = 2, 7, 32, 4
+    pc = torch.zeros(S, N, 4, device=DEV)
+    pc[1, :K, :3] = torch.tensor([[1.0, -2.0, 0.3], [4.0, 3.0, -0.2], [-6.0, 1.5, 0.1], [2.5, 7.0, 0.4]])
+    valid = torch.zeros(S, N, dtype=torch.bool, device=DEV)
+    valid[1, :K] = True                                           # sample 0: nothing valid
+    coors = ((pc[..., :2] + 10.0) / 20.0 * G).to(torch.int32).clamp(0, G - 1)
+    filled = torch.zeros(S, G, G, dtype=torch.bool, device=DEV)
+    filled[1, coors[1, :K, 0].long(), coors[1, :K, 1].long()] = True
+    net = torch.randn(S, G, G, 8, device=DEV, requires_grad=True)
+    odom = torch.eye(4, device=DEV)[None].repeat(S, 1, 1)
+    out = dec(net, 0.5, pc=pc, pointwise_voxel_coordinates=coors, pointwise_valid_mask=valid, filled_pillar_mask=filled, odom=odom,
+              inv_odom=odom, summaries=None, pointwise_only=True)
+    for k in ("aggregated_flow", "static_flow", "dynamic_flow", "class_probs", "staticness"):
+        assert torch.isfinite(out[k]).all() and float(out[k][0].abs().sum()) == 0.0 and float(out[k][1, K:].abs().sum()) == 0.0, k
+    assert torch.allclose(out.class_probs[1, :K].sum(dim=-1), torch.ones(K, device=DEV), atol=1e-6)
+    # (sample 0 has no point at all: its transform is undefined, as in the reference; nothing reads it through a valid row)
+    loss = FD.static_points_loss_mean(pc[1:], valid[1:], out.static_flow[1:], out.staticness[1:], out.static_aggr_trafo[1:])
+    assert torch.isfinite(loss)
+    (loss + out.aggregated_flow.sum()).backward()
+    assert torch.isfinite(net.grad).all()
+    touched = net.grad.abs().sum(dim=-1) > 0
+    assert 1 <= int(touched.sum()) <= K and not bool(touched[0].any())   # only the points' pillars receive a gradient
+
+
+def test_bike_rollout_and_instance_norm_degenerate_shapes():
+    """liso_bike_rollout_*: an empty batch and the minimum track length; liso_in_relu_*: one sample, one pixel row"""
+    from liso_amd.slim.model.fused_norm import in_act
+    from liso_amd.tracker.track_smoothing import BatchedBikeModel, smooth_track_bike_model
+
+    pos = torch.zeros(0, 6, 3, device=DEV)
+    m = BatchedBikeModel(batched_observed_track_pos=pos, batched_vehicle_length=torch.zeros(0, device=DEV), time_between_frames_s=0.1,
+                         max_yaw_rate=1.5, max_velocity=50.0)
+    assert m.forward().shape == (0, 6, 5)
+    short = torch.randn(2, 3, 3, device=DEV)  # fewer frames than the smoother needs: inputs come back unchanged (reference :596-605)
+    p, y, d = smooth_track_bike_model(batched_observed_pos_m=short, batched_valid_mask=torch.ones(2, 3, dtype=torch.bool, device=DEV),
+                                      batched_observed_yaw_angle_rad=torch.zeros(2, 3, 1, device=DEV),
+                                      batched_vehicle_length_m=torch.full((2,), 4.0, device=DEV), time_between_frames_s=0.1)
+    assert torch.equal(p, short) and d.shape == (2, 3)
+    norm = torch.nn.InstanceNorm2d(8, eps=1e-3, affine=True).to(DEV)
+    x = torch.randn(1, 8, 1, 5, device=DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = in_act(x, norm)
+    ref = torch.relu(norm(x.detach()))
+    assert torch.allclose(y, ref, atol=1e-5)
+    y.sum().backward()
+    assert torch.isfinite(x.grad).all()
