@@ -675,9 +675,17 @@ def fused_conv(x_raw, fold, conv, out_bn=None, out_dtype=None, out_relu=False, s
     spec = spec or ConvSpec.of(convs[0])
     if len(convs) == 1:
         weight, bias = convs[0].weight, convs[0].bias
-    else:
+    elif torch.is_grad_enabled() and any(c.weight.requires_grad for c in convs):
         weight = torch.cat([c.weight for c in convs], dim=0)
         bias = torch.cat([c.bias for c in convs], dim=0) if convs[0].bias is not None else None
+    else:  # frozen / inference: the concatenated filters are built once per weight version (their packed panels are cached with them)
+        key = tuple((id(c), c.weight._version, c.weight.data_ptr(), None if c.bias is None else c.bias._version) for c in convs)
+        hit = getattr(convs[0], "_liso_merged_weights", None)
+        if hit is None or hit[0] != key:
+            w = torch.nn.Parameter(torch.cat([c.weight.detach() for c in convs], dim=0), requires_grad=False)
+            b = torch.cat([c.bias.detach() for c in convs], dim=0) if convs[0].bias is not None else None
+            hit = convs[0]._liso_merged_weights = (key, w, b)
+        weight, bias = hit[1], hit[2]
     training_bn = bns is not None and (bns[0].training or not bns[0].track_running_stats)
     meta = {"spec": spec, "fold": fold, "out_dtype": out_dtype, "want_stats": training_bn, "out_relu": out_relu}
     if training_bn and len(bns) == 1 and bns[0].track_running_stats:
@@ -810,7 +818,7 @@ def conv2d(layer, x, relu=False):
         # the kernels read channels in 16-B groups: zero channels (and zero filter slices) up to one group, then the own kernel
         vec = 8 if x.dtype == torch.bfloat16 else 4
         pad = (-x.shape[1]) % vec
-        xp = torch.cat([x, x.new_zeros((x.shape[0], pad) + tuple(x.shape[2:]))], dim=1).contiguous(memory_format=torch.channels_last)
+        xp = torch.nn.functional.pad(x.permute(0, 2, 3, 1), (0, pad)).permute(0, 3, 1, 2)  # one launch: dense NHWC rows of one 16-B group
         if torch.is_grad_enabled() and layer.weight.requires_grad:
             wp = torch.nn.functional.pad(layer.weight, (0, 0, 0, 0, 0, pad))
         else:  # frozen / inference: the padded filter is built once per weight version (its packed panels are cached with it)
