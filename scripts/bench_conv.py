@@ -70,5 +70,13 @@ for name, ci, co, H, k, s, p, tr in LAYERS:
     conv = (lambda: torch.nn.functional.conv_transpose2d(x, wt, stride=s, padding=p)) if tr else \
         (lambda: torch.nn.functional.conv2d(x, wt, stride=s, padding=p))
     t_m = timeit(conv)
+    # the library's (MIOpen's) weight gradient and data gradient on the same tensors
+    def lib_bwd(mask):
+        return torch.ops.aten.convolution_backward(dy, x, wt, None, [s, s], [p, p], [1, 1], tr, [0, 0], 1, mask)
+    try:
+        t_mw, t_md = timeit(lambda: lib_bwd([False, True, False])), timeit(lambda: lib_bwd([True, False, False]))
+    except Exception as e:  # (a geometry the library refuses)
+        t_mw = t_md = float("nan")
     print(f"{name:24s} fwd {t_f*1e6:7.1f} us {fl/t_f/1e12:6.1f} TF | +bn-prologue+stats {t_fp*1e6:7.1f} us | dgrad {t_d*1e6:7.1f} us "
-          f"{fl/t_d/1e12:6.1f} TF | wgrad {t_w*1e6:7.1f} us {fl/t_w/1e12:6.1f} TF | torch fwd {t_m*1e6:7.1f} us {fl/t_m/1e12:6.1f} TF")
+          f"{fl/t_d/1e12:6.1f} TF | wgrad {t_w*1e6:7.1f} us {fl/t_w/1e12:6.1f} TF | torch fwd {t_m*1e6:7.1f} us {fl/t_m/1e12:6.1f} TF"
+          f" dgrad {t_md*1e6:7.1f} us wgrad {t_mw*1e6:7.1f} us")
