@@ -53,6 +53,8 @@ struct WgArgs {
     int psx;            // LDS bytes per x pixel
     int th;             // tile rows
     int pipelined;      // bf16: the halo tile fits one register batch -> tile k+1 is loaded during the MFMAs of tile k
+    int compact;        // strided convolution whose tap groups each sit in ONE kernel row: the LDS tile holds only the input rows that
+                        // group reads (row r of the tile = input row iy0 + (group's dy) + r * isy) instead of the class's dense halo
 };
 
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
@@ -119,11 +121,14 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(const liso_conv
     for (int e = 0; e < 8; e++) bsum[e] = 0.0f;
     const bool want_bias = a.bias_slab != nullptr && cit == 0 && tb == d.class_tap_begin[cls];  // once per class
 
+    const int gdy = a.compact ? d.tap_dy[tb] - dy0 : 0;   // the group's kernel row (compact tiles start there)
+    const int row_mul = a.compact ? d.isy : 1;            // input rows per tile row
+    const int row_step = a.compact ? 1 : d.isy;           // tile rows per output row
     int toff[TG];
 #pragma unroll
     for (int i = 0; i < TG; i++) {
         const int tp = tb + (i < tcnt ? i : 0);
-        toff[i] = ((d.tap_dy[tp] - dy0) * in_w + (d.tap_dx[tp] - dx0)) * PSX;
+        toff[i] = ((d.tap_dy[tp] - dy0 - gdy) * in_w + (d.tap_dx[tp] - dx0)) * PSX;
     }
 
     // ---- bf16 staging as load / store halves: the loads of tile k+1 are issued before the MFMAs of tile k (software pipeline) ----
@@ -164,7 +169,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(const liso_conv
 #pragma unroll
         for (int u = 0; u < XB; u++) {
             const int pix = pfirst + u * pstep;
-            const int iy = iy0 + ly, ix = ix0 + lx;
+            const int iy = iy0 + gdy + ly * row_mul, ix = ix0 + lx;
             const bool ok = pix < npix && ch_ok && (unsigned)iy < (unsigned)d.hi && (unsigned)ix < (unsigned)d.wi;
             xok |= ok ? (1u << u) : 0u;
             const int off = ok ? (iy * d.wi + ix) * d.x_pix_stride + ch : 0;  // (a sample has < 2^31 elements)
@@ -254,7 +259,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(const liso_conv
                 for (int u = 0; u < 4; u++) {
                     const int m = 2 * (s2 + u) + h;
                     bv[u] = *reinterpret_cast<const float*>(bb + m * PS32);
-                    xo[u] = (((m >> 5) * d.isy) * in_w + (m & 31) * d.isx) * PSX;
+                    xo[u] = (((m >> 5) * row_step) * in_w + (m & 31) * d.isx) * PSX;
                 }
 #pragma unroll
                 for (int i = 0; i < TG; i++) {
@@ -275,7 +280,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(const liso_conv
             const bf8 bh = tr_pair(bp, bp + 4 * PSY);
             bf8 bl;
             if constexpr (X3) bl = tr_pair(bp + y_plane, bp + y_plane + 4 * PSY);
-            const unsigned char* ap = xs + ((krow * d.isy) * in_w + kcol * d.isx) * PSX + a_lane;
+            const unsigned char* ap = xs + ((krow * row_step) * in_w + kcol * d.isx) * PSX + a_lane;
 #pragma unroll
             for (int i = 0; i < TG; i++) {
                 if (i < tcnt) {
@@ -364,7 +369,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(const liso_conv
 #pragma unroll
                 for (int u = 0; u < XB; u++) {
                     const int pix = pix0 + u * pstep;
-                    const int iy = iy0 + ly, ix = ix0 + lx;
+                    const int iy = iy0 + gdy + ly * row_mul, ix = ix0 + lx;
                     ok[u] = pix < npix && ch_ok && (unsigned)iy < (unsigned)d.hi && (unsigned)ix < (unsigned)d.wi;
                     const int off = ok[u] ? (iy * d.wi + ix) * d.x_pix_stride + ch : 0;  // (a sample has < 2^31 elements)
                     lx += step_x;
@@ -510,7 +515,7 @@ struct WgPlan {
     WgArgs a;
 };
 
-bool make_plan(const liso_conv_desc& d, WgPlan* p) {
+bool make_plan_impl(const liso_conv_desc& d, WgPlan* p, bool compact) {
     if (d.batch <= 0 || d.ci <= 0 || d.co <= 0 || d.n_classes < 1 || d.n_classes > LISO_CONV_MAX_CLASSES) return false;
     if (d.n_taps < 1 || d.n_taps > LISO_CONV_MAX_TAPS || d.class_tap_begin[0] != 0 || d.class_tap_begin[d.n_classes] != d.n_taps)
         return false;
@@ -539,7 +544,7 @@ bool make_plan(const liso_conv_desc& d, WgPlan* p) {
                     x0 = d.tap_dx[t] < x0 ? d.tap_dx[t] : x0;
                     x1 = d.tap_dx[t] > x1 ? d.tap_dx[t] : x1;
                 }
-                const int np = ((th - 1) * d.isy + (y1 - y0) + 1) * ((TW - 1) * d.isx + (x1 - x0) + 1);
+                const int np = (compact ? th : (th - 1) * d.isy + (y1 - y0) + 1) * ((TW - 1) * d.isx + (x1 - x0) + 1);
                 mp = np > mp ? np : mp;
             }
             const int lds = planes * (round_up(mp * psx, 16) + th * TW * psy);
@@ -565,12 +570,13 @@ bool make_plan(const liso_conv_desc& d, WgPlan* p) {
         }
         a.cls_dy0[c] = y0;
         a.cls_dx0[c] = x0;
-        a.cls_inh[c] = (TH - 1) * d.isy + (y1 - y0) + 1;
+        a.cls_inh[c] = compact ? TH : (TH - 1) * d.isy + (y1 - y0) + 1;
         a.cls_inw[c] = (TW - 1) * d.isx + (x1 - x0) + 1;
         const int np = a.cls_inh[c] * a.cls_inw[c];
         max_pix = np > max_pix ? np : max_pix;
     }
     a.psx = psx;
+    a.compact = compact ? 1 : 0;
     // (XB = 8 chunks per thread x 32 pixel rows of threads = 256 halo pixels; XB = 4 in the 9-tap instantiation)
     a.pipelined = 0;
     a.x_plane_bytes = round_up(max_pix * a.psx, 16);
@@ -593,7 +599,7 @@ bool make_plan(const liso_conv_desc& d, WgPlan* p) {
     const int tg_opts[3] = {9, 3, 1};
     long best_blocks = -1;
     p->tg = 1;
-    for (int k = (x3 ? 1 : 0); k < 3; k++) {
+    for (int k = ((x3 || compact) ? 1 : 0); k < 3; k++) {  // (compact tiles hold one kernel row: no 9-tap groups)
         const int tg = tg_opts[k];
         if (tg > 1 && max_cls_taps == 1) continue;
         const long per_split = cc * groups(tg);
@@ -611,7 +617,7 @@ bool make_plan(const liso_conv_desc& d, WgPlan* p) {
     }
     if (const char* e = getenv("LISO_WGRAD_TG")) {  // experiments: force the tap group (9 / 3 / 1)
         const int v = atoi(e);
-        if ((v == 9 && !x3) || v == 3 || v == 1) p->tg = v;
+        if ((v == 9 && !x3 && !compact) || v == 3 || v == 1) p->tg = v;
     }
     {
         const int xb = p->tg >= 9 ? 4 : 8;
@@ -626,6 +632,9 @@ bool make_plan(const liso_conv_desc& d, WgPlan* p) {
             a.grp_begin[a.n_groups] = t;
             const int left = d.class_tap_begin[c + 1] - t;
             a.grp_cnt[a.n_groups] = left < p->tg ? left : p->tg;
+            if (compact)  // every tap of the group must sit in the same kernel row
+                for (int q = 1; q < a.grp_cnt[a.n_groups]; q++)
+                    if (d.tap_dy[t + q] != d.tap_dy[t]) return false;
             a.n_groups++;
         }
     const long per_split = cc * a.n_groups;
@@ -637,6 +646,15 @@ bool make_plan(const liso_conv_desc& d, WgPlan* p) {
     p->slab_bytes = (size_t)s * d.w_taps * a.ci_t * CT * a.co_t * CT * sizeof(float);
     p->bias_bytes = (size_t)d.n_classes * s * a.co_t * CT * sizeof(float);
     return true;
+}
+
+// Strided convolutions (the backbone's three stride-2 layers): a tap group of one kernel row reads every isy-th input row only --
+// its tile then holds those rows alone (2.5x fewer staged pixels for 3x3 / 2, and twice the output rows per tile in the same LDS).
+bool make_plan(const liso_conv_desc& d, WgPlan* p) {
+    bool want = d.isy > 1;
+    if (const char* e = getenv("LISO_WGRAD_COMPACT")) want = want && atoi(e) != 0;  // experiments
+    if (want && make_plan_impl(d, p, true)) return true;
+    return make_plan_impl(d, p, false);
 }
 
 template <int MODE, int TG>
