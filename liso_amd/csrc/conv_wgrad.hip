@@ -450,8 +450,12 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(const liso_conv
         if (i < tcnt) {
             const int wt = d.tap_w[tb + i];
             float* base = a.slab + (((long)split * d.w_taps + wt) * cip + ci0 + ci_half * 32) * cop + co0 + co_half * 32 + r;
+            // (columns beyond the real output channels are never read by the reduction: the 3-channel heads write 3 of 64 columns,
+            // 24 MB of slab traffic per launch otherwise)
+            if (co0 + co_half * 32 + r < (d.wgrad_co > 0 ? d.wgrad_co : d.co)) {
 #pragma unroll
-            for (int e = 0; e < 16; e++) base[(long)((e & 3) + 8 * (e >> 2) + 4 * h) * cop] = acc[i][e];
+                for (int e = 0; e < 16; e++) base[(long)((e & 3) + 8 * (e >> 2) + 4 * h) * cop] = acc[i][e];
+            }
         }
     }
     if (want_bias) {
