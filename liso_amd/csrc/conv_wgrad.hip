@@ -453,8 +453,12 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(const liso_conv
             // (columns beyond the real output channels are never read by the reduction: the 3-channel heads write 3 of 64 columns,
             // 24 MB of slab traffic per launch otherwise)
             if (co0 + co_half * 32 + r < (d.wgrad_co > 0 ? d.wgrad_co : d.co)) {
+                const int rows_left = d.ci - (ci0 + ci_half * 32);  // (rows beyond the real input channels are never read either)
 #pragma unroll
-                for (int e = 0; e < 16; e++) base[(long)((e & 3) + 8 * (e >> 2) + 4 * h) * cop] = acc[i][e];
+                for (int e = 0; e < 16; e++) {
+                    const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+                    if (row < rows_left) base[(long)row * cop] = acc[i][e];
+                }
             }
         }
     }
