@@ -122,3 +122,20 @@ def test_bench_two_ranks_on_one_gpu_reports_world_and_identical_replicas(workloa
     assert line["dist_backend"] == "gloo" and len(line["replica_param_checksums"]) == 2
     assert line["replicas_identical"] is True
     assert line["value"] > 0 and line["final_loss"] == line["final_loss"]
+
+
+def test_rccl_process_group_next_to_graph_captures_and_replays():
+    """RCCL itself (backend "nccl"), one rank on the one GPU there is: a live process group (communicator + watchdog thread) while the
+    loop captures and replays its three hipGraphs, and an all-reduce of the detector's flat gradient buffer between replays -- the calls
+    a second rank adds (two ranks cannot share a device under RCCL; the multi-rank logic itself runs over gloo above)"""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "rccl_single_rank_check.py")], cwd=root, env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "ok: 10 loop steps" in r.stdout
