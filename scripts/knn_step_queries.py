@@ -9,8 +9,9 @@ from liso_amd.slim.slim_loss.knn_graph import KnnIndex
 dev = torch.device("cuda:0")
 s0, s1 = slim_pair(2, dev, n_points=120000, grid=512, bev_range_m=100.0)
 ext = [-50.0, -50.0, 50.0, 50.0]
-ref = KnnIndex(s1["pcl_ta"]["pcl"][0, :, :3].contiguous(), extent=ext, all_rows_finite=True)
-own = KnnIndex(s0["pcl_ta"]["pcl"][0, :, :3].contiguous(), extent=ext, all_rows_finite=True)
+CELL = float(os.environ.get("KNN_CELL", "0.2"))  # fine cell size (the default of KnnIndex: 0.2 m)
+ref = KnnIndex(s1["pcl_ta"]["pcl"][0, :, :3].contiguous(), cell=CELL, extent=ext, all_rows_finite=True)
+own = KnnIndex(s0["pcl_ta"]["pcl"][0, :, :3].contiguous(), cell=CELL, extent=ext, all_rows_finite=True)
 g = torch.Generator(device="cpu").manual_seed(0)
 p0 = s0["pcl_ta"]["pcl"][0, :, :3]
 for sigma in (0.05, 0.3, 1.0):
