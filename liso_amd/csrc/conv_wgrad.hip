@@ -599,7 +599,9 @@ bool make_plan_impl(const liso_conv_desc& d, WgPlan* p, bool compact) {
         return n;
     };
     const long slab_per_split = (long)d.w_taps * a.ci_t * CT * a.co_t * CT * sizeof(float);
-    long split_cap = (24l << 20) / slab_per_split;
+    long slab_mb = 24;
+    if (const char* e = getenv("LISO_WGRAD_SLAB_MB")) slab_mb = atol(e) > 0 ? atol(e) : slab_mb;  // experiments
+    long split_cap = (slab_mb << 20) / slab_per_split;
     const long by_tiles = a.n_tiles >= 4 ? a.n_tiles / 4 : 1;
     split_cap = split_cap < 1 ? 1 : (split_cap > by_tiles ? by_tiles : split_cap);
     long target = 512;  // ~2 blocks per CU
