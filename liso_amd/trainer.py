@@ -799,6 +799,15 @@ class LisoLoopTrainer:
         return self.eager_pass_batch([(sample_t0, sample_t1)], also)
 
     def eager_pass_batch(self, pairs, also=()):
+        """`_eager_pass_batch` with the convolution plans the pipelined steps use (the kernels bench.py times are the replayed ones)"""
+        if self.device.type != "cuda":
+            return self._eager_pass_batch(pairs, also)
+        from liso_amd.utils import mfma_conv as MC
+
+        with MC.shared_gpu():
+            return self._eager_pass_batch(pairs, also)
+
+    def _eager_pass_batch(self, pairs, also=()):
         """the whole iteration on a batch of pairs with eager launches and no parameter update (per-kernel event timing in bench.py).
         `also`: further pairs that join the SLIM inference batch, as in the pipeline's stage A (the kernels are then timed at the
         batch they run at; their launches count len(pairs) / (len(pairs) + len(also)) towards this step)"""
