@@ -32,6 +32,11 @@ int liso_bev_dynamic_flow_f32(const float* points, int point_stride, const uint8
                               int w, float* dynamicness, float* nonrigid_flow, void* workspace, size_t workspace_bytes,
                               void* stream);
 
+/* inv(odom_ta_tb) - I of `batch` row-major 4x4 fp64 matrices (bev_flow_utils.py:30-33, `torch.linalg.inv(odom) - eye`), by cofactor
+ * expansion in fp64: the `odom_minus_eye` input of liso_bev_dynamic_flow_f32 without a library LU call (graph-capturable, no host
+ * check).  odom, out: [batch,4,4] fp64. */
+int liso_odom_inverse_minus_eye_f64(const double* odom, int batch, double* out, void* stream);
+
 /* scratch for liso_fit_box_z_f32 */
 size_t liso_fit_box_z_workspace_bytes(int n_points, int n_boxes);
 

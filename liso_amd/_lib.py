@@ -97,6 +97,7 @@ SIGNATURES = {
     # include/liso_flow_cluster.h
     "liso_bev_dynamic_flow_workspace_bytes": (_sz, [_i, _i, _i]),
     "liso_bev_dynamic_flow_f32": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "liso_odom_inverse_minus_eye_f64": (_i, [_vp, _i, _vp, _vp]),
     "liso_fit_box_z_workspace_bytes": (_sz, [_i, _i]),
     "liso_fit_box_z_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _vp, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
     "liso_dbscan_components": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -174,6 +174,38 @@ __global__ __launch_bounds__(64) void fit_z_final_kernel(const FitPartial* __res
     fz[box] = zlow + 0.5f * height;
 }
 
+// inv(M) - I of B row-major 4x4 fp64 matrices by cofactor expansion (bev_flow_utils.py:30-33: torch.linalg.inv(odom) - eye): one
+// thread per matrix.  A singular matrix gives inf / nan entries like the reference's LU inverse.
+__global__ void odom_inverse_minus_eye_kernel(const double* __restrict__ m_all, int batch, double* __restrict__ out_all) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    const double* m = m_all + (size_t)b * 16;
+    double* o = out_all + (size_t)b * 16;
+    const double a00 = m[0], a01 = m[1], a02 = m[2], a03 = m[3], a10 = m[4], a11 = m[5], a12 = m[6], a13 = m[7];
+    const double a20 = m[8], a21 = m[9], a22 = m[10], a23 = m[11], a30 = m[12], a31 = m[13], a32 = m[14], a33 = m[15];
+    const double s0 = a00 * a11 - a10 * a01, s1 = a00 * a12 - a10 * a02, s2 = a00 * a13 - a10 * a03;
+    const double s3 = a01 * a12 - a11 * a02, s4 = a01 * a13 - a11 * a03, s5 = a02 * a13 - a12 * a03;
+    const double c5 = a22 * a33 - a32 * a23, c4 = a21 * a33 - a31 * a23, c3 = a21 * a32 - a31 * a22;
+    const double c2 = a20 * a33 - a30 * a23, c1 = a20 * a32 - a30 * a22, c0 = a20 * a31 - a30 * a21;
+    const double inv = 1.0 / (s0 * c5 - s1 * c4 + s2 * c3 + s3 * c2 - s4 * c1 + s5 * c0);
+    o[0] = (a11 * c5 - a12 * c4 + a13 * c3) * inv - 1.0;
+    o[1] = (-a01 * c5 + a02 * c4 - a03 * c3) * inv;
+    o[2] = (a31 * s5 - a32 * s4 + a33 * s3) * inv;
+    o[3] = (-a21 * s5 + a22 * s4 - a23 * s3) * inv;
+    o[4] = (-a10 * c5 + a12 * c2 - a13 * c1) * inv;
+    o[5] = (a00 * c5 - a02 * c2 + a03 * c1) * inv - 1.0;
+    o[6] = (-a30 * s5 + a32 * s2 - a33 * s1) * inv;
+    o[7] = (a20 * s5 - a22 * s2 + a23 * s1) * inv;
+    o[8] = (a10 * c4 - a11 * c2 + a13 * c0) * inv;
+    o[9] = (-a00 * c4 + a01 * c2 - a03 * c0) * inv;
+    o[10] = (a30 * s4 - a31 * s2 + a33 * s0) * inv - 1.0;
+    o[11] = (-a20 * s4 + a21 * s2 - a23 * s0) * inv;
+    o[12] = (-a10 * c3 + a11 * c1 - a12 * c0) * inv;
+    o[13] = (a00 * c3 - a01 * c1 + a02 * c0) * inv;
+    o[14] = (-a30 * s3 + a31 * s1 - a32 * s0) * inv;
+    o[15] = (a20 * s3 - a21 * s1 + a22 * s0) * inv - 1.0;
+}
+
 inline int check_launch() { return hipGetLastError() == hipSuccess ? LISO_OK : LISO_ELAUNCH; }
 
 inline int fit_blocks(int n) {
@@ -210,6 +242,13 @@ int liso_bev_dynamic_flow_f32(const float* points, int point_stride, const uint8
                                                                           flow_stride, odom_minus_eye, batch, n, h, w, sums,
                                                                           counts);
     bev_mean_kernel<<<(unsigned)((cells + 255) / 256), 256, 0, st>>>(sums, counts, cells, dynamicness, nonrigid_flow);
+    return check_launch();
+}
+
+int liso_odom_inverse_minus_eye_f64(const double* odom, int batch, double* out, void* stream) {
+    if (batch < 0 || (batch > 0 && (!odom || !out))) return LISO_EINVAL;
+    if (batch == 0) return LISO_OK;
+    odom_inverse_minus_eye_kernel<<<(batch + 63) / 64, 64, 0, (hipStream_t)stream>>>(odom, batch, out);
     return check_launch();
 }
 

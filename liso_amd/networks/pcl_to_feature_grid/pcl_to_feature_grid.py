@@ -81,7 +81,7 @@ def decorate_rows(points, pcfg, B, coors, num_points, slots, num_voxels):
     with torch.cuda.device(dev):
         L.check(L.TIMER.launch("pfn_decorate", lambda: lib.liso_pfn_decorate_f32(
             L.ptr(points), ctypes.byref(pcfg), B, L.ptr(coors), L.ptr(num_points), L.ptr(slots), L.ptr(num_voxels), L.ptr(pt_off),
-            L.ptr(feat), L.ptr(voxel_cell), L.ptr(ws), nbytes, L.stream_ptr())), "pfn_decorate")
+            L.ptr(feat), L.ptr(voxel_cell), L.ptr(ws), nbytes, L.stream_ptr()), units=points.shape[0] * (points.shape[1] * 4 + 48)), "pfn_decorate")
     return pt_off, feat, voxel_cell
 
 
@@ -116,7 +116,9 @@ class _PillarFeatureScatter(torch.autograd.Function):
                 occupancy = torch.empty((B, 1, pcfg.gx, pcfg.gy), dtype=torch.float32, device=dev)
             L.check(L.TIMER.launch("pfn_forward_scatter", lambda: lib.liso_pfn_forward_scatter(
                 L.ptr(feat), L.ptr(pt_off), L.ptr(voxel_cell), ctypes.byref(pcfg), B, L.ptr(cell_to_voxel), L.ptr(weight),
-                L.ptr(bn_out), L.ptr(canvas), int(out_dtype == torch.bfloat16), L.ptr(occupancy), st)),
+                L.ptr(bn_out), L.ptr(canvas), int(out_dtype == torch.bfloat16), L.ptr(occupancy), st),
+                # algorithmic bytes: points read once + dense canvas (its own element size) + occupancy written once
+                units=points.numel() * 4 + canvas.numel() * canvas.element_size() + occupancy.numel() * 4),
                 "pfn_forward_scatter")
         ctx.save_for_backward(feat, pt_off, voxel_cell, num_voxels, weight, gamma, bn_out, moments)
         ctx.pcfg, ctx.B, ctx.training = pcfg, B, bool(training)

@@ -256,9 +256,12 @@ class DetectorTrainer:
         bev, occ = self._pillars(pcls, out=(self._static_bev.detach().permute(0, 2, 3, 1), self._static_occ))
         with torch.no_grad():
             if isinstance(targets, _BatchedTargets):
-                for b, t in enumerate(targets.per_sample):
+                off = {}
+                for t in targets.per_sample:  # (running offset per key: samples may carry more than one row)
                     for k, v in t.items():
-                        self._static_targets[k][b:b + v.shape[0]].copy_(v, non_blocking=True)
+                        o = off.get(k, 0)
+                        self._static_targets[k][o:o + v.shape[0]].copy_(v, non_blocking=True)
+                        off[k] = o + v.shape[0]
             else:
                 for k, v in targets.items():
                     self._static_targets[k].copy_(v, non_blocking=True)
@@ -622,8 +625,8 @@ class _BatchedTargets(dict):
         return [self[k] for k in self.keys()]
 
     def shapes(self):
-        n = len(self.per_sample)
-        return tuple((k, (n * v.shape[0],) + tuple(v.shape[1:]), v.dtype) for k, v in sorted(self.per_sample[0].items()))
+        rows = {k: sum(t[k].shape[0] for t in self.per_sample) for k in self.per_sample[0]}
+        return tuple((k, (rows[k],) + tuple(v.shape[1:]), v.dtype) for k, v in sorted(self.per_sample[0].items()))
 
 
 class LisoLoopTrainer:
@@ -662,8 +665,15 @@ class LisoLoopTrainer:
         # torch_dataset_commons.py:380-431) so that the inference graph's input signature repeats, and at most `max_infer_graphs`
         # captured graphs (each with its static inputs and a private memory pool) stay resident, least recently used first out
         tcfg = cfg.data.tracking_cfg
-        self.infer_point_bucket = int(tcfg.setdefault("infer_point_bucket", 2048))
-        self.max_infer_graphs = int(tcfg.setdefault("max_infer_graphs", 6))
+        self.infer_point_bucket = int(tcfg.setdefault("infer_point_bucket", 8192))
+        self.max_infer_graphs = int(tcfg.setdefault("max_infer_graphs", 8))
+        # stage B's captured graphs are keyed on the same bucket-padded shapes (plus the full cloud's padded length): resident graphs
+        # per mining stream, and the number of captures after which a new signature runs the eager fixed-slot path instead of evicting
+        # a graph whose replays may still be in flight
+        self.max_mine_graphs = int(tcfg.setdefault("max_mine_graphs", 6))
+        self.mine_capture_budget = int(tcfg.setdefault("mine_capture_budget", 24))
+        self.mine_captures, self.mine_eager_fallbacks = 0, 0
+        self._views = collections.OrderedDict()  # id(sample) -> (sample, bucket-padded view); the samples themselves are never edited
         self.overlap = bool(overlap) and device.type == "cuda"
         self.infer_batch, self.flow_ahead = int(infer_batch), int(flow_ahead)
         self.box_capacity, self.capacity_overflows = int(cfg.data.tracking_cfg.setdefault("flow_cluster_capacity", 64)), 0
@@ -715,25 +725,52 @@ class LisoLoopTrainer:
         return first
 
     def _pad_loss_cloud(self, sample):
-        """`pcl_ta` with its point axis grown to the next multiple of `infer_point_bucket` (collate-style padding rows)"""
+        """the sample with the point axis of `pcl_ta` (NaN rows, pcl_is_valid False, pillar_coors -1: the dataset's own collate padding,
+        torch_dataset_commons.py:380-431) and of `pcl_full_w_ground_ta` (NaN rows at the end: no box contains them) grown to the next
+        multiple of `infer_point_bucket`.  A new dict: the caller's sample is not modified."""
         pa = sample["pcl_ta"]
-        n, bk = pa["pcl"].shape[1], self.infer_point_bucket
+        bk = self.infer_point_bucket
+        n = pa["pcl"].shape[1]
         pad = (-n) % bk if bk > 1 else 0
-        if pad == 0:
+        full = sample.get("pcl_full_w_ground_ta")
+        fpad = (-full.shape[1]) % bk if (bk > 1 and torch.is_tensor(full) and full.dim() == 3) else 0
+        if pad == 0 and fpad == 0:
             return sample
         F = torch.nn.functional
         out = dict(sample)
-        out["pcl_ta"] = {**pa, "pcl": F.pad(pa["pcl"], (0, 0, 0, pad), value=float("nan")),
-                         "pcl_is_valid": F.pad(pa["pcl_is_valid"], (0, pad), value=False),
-                         "pillar_coors": F.pad(pa["pillar_coors"], (0, 0, 0, pad), value=-1)}
+        if pad:
+            out["pcl_ta"] = {**pa, "pcl": F.pad(pa["pcl"], (0, 0, 0, pad), value=float("nan")),
+                             "pcl_is_valid": F.pad(pa["pcl_is_valid"], (0, pad), value=False),
+                             "pillar_coors": F.pad(pa["pillar_coors"], (0, 0, 0, pad), value=-1)}
+        if fpad:
+            out["pcl_full_w_ground_ta"] = F.pad(full, (0, 0, 0, fpad), value=float("nan"))
         return out
+
+    def _view(self, sample):
+        """bucket-padded view of a sample, built once per sample object and kept on the trainer (bounded, oldest first out)"""
+        hit = self._views.get(id(sample))
+        if hit is not None and hit[0] is sample:
+            self._views.move_to_end(id(sample))
+            return hit[1]
+        v = self._pad_loss_cloud(sample)
+        self._views[id(sample)] = (sample, v)  # (the strong reference keeps id(sample) from being recycled while the entry lives)
+        while len(self._views) > 64:
+            self._views.popitem(last=False)
+        return v
+
+    def _infer_view(self, sample):
+        """what the frozen SLIM inference reads from a (padded) sample: the loss cloud, the odometry and the network-input clouds --
+        samples whose OTHER tensors differ in shape (the full cloud with ground) still stack into one inference batch"""
+        v = self._view(sample)
+        key = "pcl_full_w_ground_ta" if self.cfg.data.use_ground_for_network else "pcl_full_no_ground_ta"
+        return {"pcl_ta": v["pcl_ta"], "gt": {"odom_ta_tb": v["gt"]["odom_ta_tb"]}, key: list(sample[key])}
 
     def _infer_flow(self, sample_t0, sample_t1):
         """frozen SLIM inference of one sample pair (any batch size): eager pillar encoder + one hipGraph replay per input signature.
-        Eager and replayed calls see the same (bucket-padded) clouds: their results are bit-identical."""
+        Eager and replayed calls see the same (bucket-padded) clouds: their results are bit-identical.  -> flow [B, N, 3] of the
+        sample's own rows."""
         n_true = sample_t0["pcl_ta"]["pcl"].shape[1]
-        sample_t0, sample_t1 = self._pad_loss_cloud(sample_t0), self._pad_loss_cloud(sample_t1)
-        flow = self._infer_flow_padded(sample_t0, sample_t1)
+        flow = self._infer_flow_padded(self._infer_view(sample_t0), self._infer_view(sample_t1))
         return flow if flow.shape[1] == n_true else flow[:, :n_true].contiguous()
 
     @staticmethod
@@ -765,6 +802,8 @@ class LisoLoopTrainer:
         if st is not None:
             self._infer_graphs.move_to_end(sig)
         if st is None:
+            if len(self._infer_graphs) >= max(self.max_infer_graphs, 1):
+                torch.cuda.synchronize(dev)  # (replays of the graph that goes may still be in flight on the inference stream)
             while len(self._infer_graphs) >= max(self.max_infer_graphs, 1):  # least recently used graph + its buffers go
                 _, old = self._infer_graphs.popitem(last=False)
                 if self._infer_graph is old.get("graph"):
@@ -819,10 +858,7 @@ class LisoLoopTrainer:
             with torch.no_grad():
                 L.TIMER.weight = len(pairs) / len(allp)  # (these launches serve len(allp) pairs, the step consumes len(pairs))
                 try:
-                    if len(allp) == 1:
-                        flow = self._infer_flow(*allp[0])
-                    else:
-                        flow = self._infer_flow(self._stack_samples([p_[0] for p_ in allp]), self._stack_samples([p_[1] for p_ in allp]))
+                    flow = self._infer_flow_padded(self._stack_infer_views([p_[0] for p_ in allp]), self._stack_infer_views([p_[1] for p_ in allp]))
                 finally:
                     L.TIMER.weight = 1.0
                 b = flow.shape[0] // len(allp)
@@ -835,45 +871,57 @@ class LisoLoopTrainer:
     def _mine_from_graph(self, sample_t0, flow, side):
         """stage B of one sweep pair -- flow clustering, z-fit, filters, Kabsch heading, NMS, target maps with `box_capacity` fixed
         slots -- replayed from a hipGraph on stream `side` (the caller's current stream): ~45 nodes, no scan / sort library call and
-        therefore no memset node (liso_amd/utils/graph_safety.py), no host read.  The pair's tensors are copied into the captured
-        inputs, inv(odom) - I (a library LU inverse that depends on the sample only) is computed eagerly in front of the replay, and
-        all results come out of ONE packed buffer that is cloned behind the replay (the next replay overwrites the captured one).
+        therefore no memset node (liso_amd/utils/graph_safety.py), no host read.  The inputs are the sample's BUCKET-PADDED view
+        (`_view`: loss cloud, validity, pillar coordinates, full cloud, all grown to multiples of `infer_point_bucket` like the
+        inference graph's) and the padded flow, so sweeps of different point counts share a signature; they are copied into the
+        captured inputs by one launch, inv(odom) - I is computed INSIDE the graph (liso_odom_inverse_minus_eye_f64), and all results
+        come out of ONE packed buffer that is cloned behind the replay (the next replay overwrites the captured one).  Beyond
+        `mine_capture_budget` captures a new signature runs the eager fixed-slot path instead of evicting a graph.
         -> (targets dict, boxes Shape, max cluster count int64 [1])"""
         from liso_amd.kabsch.shape_utils import Shape
-        from liso_amd.utils.bev_flow_utils import odometry_minus_identity
 
         dev = self.device
-        pa = sample_t0["pcl_ta"]
-        gt = sample_t0[self.cfg.data.odom_source]
-        ome = gt.get("_odom_minus_eye")
-        if ome is None:  # once per sample object
-            ome = gt["_odom_minus_eye"] = odometry_minus_identity(gt["odom_ta_tb"].to(dev))
-        ins = {"pcl": pa["pcl"], "valid": pa["pcl_is_valid"], "coors": pa["pillar_coors"], "full": sample_t0["pcl_full_w_ground_ta"],
-               "flow": flow, "ome": ome, "dt": sample_t0["src_trgt_time_delta_s"], "odom": gt["odom_ta_tb"]}
+        v = self._view(sample_t0)
+        pa = v["pcl_ta"]
+        gt = v[self.cfg.data.odom_source]
+        flow = self._pad_flow(flow, pa["pcl"].shape[1])
+        ins = {"pcl": pa["pcl"], "valid": pa["pcl_is_valid"], "coors": pa["pillar_coors"], "full": v["pcl_full_w_ground_ta"],
+               "flow": flow, "dt": v["src_trgt_time_delta_s"], "odom": gt["odom_ta_tb"]}
+        ins = {k: (t if t.device == dev else t.to(dev, non_blocking=True)) for k, t in ins.items()}  # (host-resident loader outputs)
         # (one captured graph -- static inputs, intermediates, packed output -- per mining stream: replays on different streams run
         # concurrently and must not share buffers)
-        sig = (side.cuda_stream,) + tuple((k, tuple(v.shape), v.dtype) for k, v in ins.items())
+        sig = (side.cuda_stream,) + tuple((k, tuple(t.shape), t.dtype) for k, t in ins.items())
         st = self._mine_graphs.get(sig)
+        if st is None and self.mine_captures >= self.mine_capture_budget:
+            # too many different signatures (bucket too fine for this data): same kernels, launched eagerly, nothing evicted
+            self.mine_eager_fallbacks += 1
+            targets, boxes = self._targets_from_flow(sample_t0, flow, capacity=self.box_capacity)
+            return targets, boxes, self.cluster_detector.last_num_labels.max().reshape(1)
         if st is not None:
             self._mine_graphs.move_to_end(sig)
             if st["in_flat"] is not None:  # every input into the captured buffers with ONE launch (a byte-wise concatenation)
-                torch.cat([ins[k].reshape(-1).view(torch.uint8) for k in st["order"]], out=st["in_flat"])
+                parts = [ins[k].reshape(-1).view(torch.uint8) for k in st["order"]]
+                assert sum(p_.numel() for p_ in parts) == st["in_flat"].numel()  # (cat(out=) would silently resize the static buffer)
+                torch.cat(parts, out=st["in_flat"])
             else:
-                for k, v in ins.items():
-                    st["in"][k].copy_(v, non_blocking=True)
+                for k, t in ins.items():
+                    st["in"][k].copy_(t, non_blocking=True)
         else:
-            while len(self._mine_graphs) >= max(self.max_infer_graphs, 1):
+            if len(self._mine_graphs) >= max(self.max_mine_graphs, 1):
+                torch.cuda.synchronize(dev)  # (replays of the graph that goes may still be in flight on a mining stream)
+            while len(self._mine_graphs) >= max(self.max_mine_graphs, 1):
                 self._mine_graphs.popitem(last=False)[1].clear()
-            st = self._mine_graphs[sig] = _packed_inputs({k: v.to(dev) for k, v in ins.items()})
+            self.mine_captures += 1
+            st = self._mine_graphs[sig] = _packed_inputs(ins)
             si = st["in"]
             sample = {"pcl_ta": {"pcl": si["pcl"], "pcl_is_valid": si["valid"], "pillar_coors": si["coors"]},
                       "pcl_full_w_ground_ta": si["full"], "src_trgt_time_delta_s": si["dt"],
                       self.cfg.data.odom_source: {"odom_ta_tb": si["odom"]}}
 
             def body():
-                targets, boxes = self._targets_from_flow(sample, si["flow"], capacity=self.box_capacity, odom_minus_eye=si["ome"])
-                named = [("t_" + k, v) for k, v in targets.items()] + \
-                    [("b_" + k, v) for k, v in boxes.__dict__.items() if torch.is_tensor(v)] + \
+                targets, boxes = self._targets_from_flow(sample, si["flow"], capacity=self.box_capacity, padded=True)
+                named = [("t_" + k, t) for k, t in targets.items()] + \
+                    [("b_" + k, t) for k, t in boxes.__dict__.items() if torch.is_tensor(t)] + \
                     [("n_clusters", self.cluster_detector.last_num_labels.max().reshape(1))]
                 return _pack_tensors(named)
 
@@ -885,18 +933,32 @@ class LisoLoopTrainer:
                     st["flat"], st["layout"] = body()
         st["graph"].replay()
         out = _unpack_tensors(st["flat"].clone(), st["layout"])
-        targets = {k[2:]: v for k, v in out.items() if k.startswith("t_")}
-        boxes = Shape(**{k[2:]: v for k, v in out.items() if k.startswith("b_")})
+        targets = {k[2:]: t for k, t in out.items() if k.startswith("t_")}
+        boxes = Shape(**{k[2:]: t for k, t in out.items() if k.startswith("b_")})
         return targets, boxes, out["n_clusters"]
 
-    def _targets_from_flow(self, sample_t0, flow, capacity=None, odom_minus_eye=None):
+    @staticmethod
+    def _pad_flow(flow, n):
+        """point flow [B, n', 3] -> [B, n, 3] (zero rows for the padding points, which are invalid everywhere downstream)"""
+        if flow.shape[1] == n:
+            return flow
+        if flow.shape[1] > n:  # inferred in a batch with a larger point-count bucket: drop the extra padding rows
+            return flow[:, :n].contiguous()
+        return torch.nn.functional.pad(flow, (0, 0, 0, n - flow.shape[1]))
+
+    def _targets_from_flow(self, sample_t0, flow, capacity=None, odom_minus_eye=None, padded=False):
         """flow clustering -> NMS -> CenterPoint target maps.  Reference-shaped call: two box-count reads size the padded Shape.
         `capacity`: fixed number of box slots and no device->host read at all (FlowClusterDetector.forward); the caller compares
-        `self.cluster_detector.last_num_labels` with the capacity later."""
+        `self.cluster_detector.last_num_labels` with the capacity later.  Every path (one-stream loop, pipeline stage B eager or
+        replayed) works on the sample's bucket-padded view (`_view`) and the flow padded to it: identical inputs, identical boxes;
+        `padded`: `sample_t0` already is such a view (the mining graph's static inputs)."""
         from liso_amd.datasets.targets import render_center_targets
         from liso_amd.utils.nms_iou import perform_nms_on_shapes_padded
 
         with torch.no_grad():
+            if not padded:
+                sample_t0 = self._view(sample_t0)
+            flow = self._pad_flow(flow, sample_t0["pcl_ta"]["pcl"].shape[1])
             sample = dict(sample_t0)
             sample[self.cfg.data.flow_source] = {**sample_t0.get(self.cfg.data.flow_source, {}), "flow_ta_tb": flow}
             boxes = self.cluster_detector(sample, global_step=1, capacity=capacity, odom_minus_eye=odom_minus_eye)
@@ -929,12 +991,13 @@ class LisoLoopTrainer:
             side.wait_event(self._main_used_static)
             self._main_used_static = None
         with torch.cuda.stream(side), torch.no_grad():
+            # (the flows stay bucket-padded: stage B reads them next to the padded view of the sample)
             if len(pairs) == 1:
-                flows = [self._infer_flow(*pairs[0]).clone()]  # (the next replay overwrites the static output)
+                flows = [self._infer_flow_padded(self._infer_view(pairs[0][0]), self._infer_view(pairs[0][1])).clone()]  # (the next replay overwrites the static output)
             else:
-                s0 = self._stack_samples([p_[0] for p_ in pairs])
-                s1 = self._stack_samples([p_[1] for p_ in pairs])
-                flow = self._infer_flow(s0, s1)
+                # pairs from different point-count buckets share the batch at the largest bucket among them (more padding rows,
+                # ignored everywhere): the inference graph's signature is (batch size, largest bucket), not one per combination
+                flow = self._infer_flow_padded(self._stack_infer_views([p_[0] for p_ in pairs]), self._stack_infer_views([p_[1] for p_ in pairs]))
                 b = flow.shape[0] // len(pairs)
                 flows = [flow[k * b:(k + 1) * b].clone() for k in range(len(pairs))]
             done = torch.cuda.Event()
@@ -942,12 +1005,33 @@ class LisoLoopTrainer:
         for p_, fl in zip(pairs, flows):
             self._flows.append(_Prefetched(pair=p_, flow=fl, done=done))
 
+    def _same_shapes(self, pa, pb):
+        """can the two pairs share one inference batch?  What the captured inference consumes -- the loss clouds and the odometry --
+        must agree in everything but the (bucket-padded) point count, which `_stage_a` levels to the largest bucket of the batch."""
+        def sig(pair):
+            out = []
+            SlimTrainer._map_tensors(self._graph_inputs(self._infer_view(pair[0]), self._infer_view(pair[1])),
+                                     lambda t: out.append((tuple(t.shape[:1]) + tuple(t.shape[2:]), t.dtype)) or t)
+            return out
+        return sig(pa) == sig(pb)
+
+    def _stack_infer_views(self, samples):
+        """the inference views of several samples as one batch, levelled to the largest point-count bucket among them"""
+        views = [self._infer_view(s_) for s_ in samples]
+        n = max(v["pcl_ta"]["pcl"].shape[1] for v in views)
+        return self._stack_samples([self._grow_view(v, n) for v in views])
+
     @staticmethod
-    def _same_shapes(pa, pb):
-        sa, sb = [], []
-        SlimTrainer._map_tensors(pa, lambda t: sa.append((tuple(t.shape), t.dtype)) or t)
-        SlimTrainer._map_tensors(pb, lambda t: sb.append((tuple(t.shape), t.dtype)) or t)
-        return sa == sb
+    def _grow_view(view, n):
+        """an inference view with its loss cloud padded further, to `n` rows"""
+        pa = view["pcl_ta"]
+        pad = n - pa["pcl"].shape[1]
+        if pad == 0:
+            return view
+        F = torch.nn.functional
+        return {**view, "pcl_ta": {**pa, "pcl": F.pad(pa["pcl"], (0, 0, 0, pad), value=float("nan")),
+                                   "pcl_is_valid": F.pad(pa["pcl_is_valid"], (0, pad), value=False),
+                                   "pillar_coors": F.pad(pa["pillar_coors"], (0, 0, 0, pad), value=-1)}}
 
     @staticmethod
     def _take(store, pair):
@@ -1035,7 +1119,7 @@ class LisoLoopTrainer:
                         # with the same static graph buffers, packed weight panels and decoder caches stage A uses on its stream
                         cur.wait_stream(self._flow_stream)
                     with torch.no_grad():
-                        flow = self._infer_flow(sample_t0, sample_t1)
+                        flow = self._infer_flow_padded(self._infer_view(sample_t0), self._infer_view(sample_t1))
                 got = self._targets_from_flow(sample_t0, flow)
                 if self.overlap and f is None:  # the static inference buffers were used on this stream up to here
                     self._main_used_static = torch.cuda.Event()

@@ -18,8 +18,7 @@ def get_bev_dynamic_flow_map_from_pcl_flow_and_odom(*, pcl_is_valid, pcl, pillar
     assert fl.shape[-1] >= 3, fl.shape
     val = pcl_is_valid.to(torch.uint8).contiguous()
     coors = pillar_coors.to(torch.int32).contiguous()
-    # bev_flow_utils.py:30-33: inv(odom) - I in fp64 (a [B,4,4] LU inverse; not worth a kernel)
-    # (inv_ex = the same LU inverse without torch.linalg.inv's singularity check, which is a device->host read)
+    # bev_flow_utils.py:30-33: inv(odom) - I in fp64 [B,4,4]
     ome = odom_minus_eye if odom_minus_eye is not None else odometry_minus_identity(odom_ta_tb)
     dyn = torch.empty((B, h, w, 1), dtype=torch.float32, device=dev)
     nrf = torch.empty((B, h, w, 3), dtype=torch.float32, device=dev)
@@ -37,6 +36,14 @@ def get_bev_dynamic_flow_map_from_pcl_flow_and_odom(*, pcl_is_valid, pcl, pillar
 
 @torch.no_grad()
 def odometry_minus_identity(odom_ta_tb):
-    """inv(odom_ta_tb) - I in fp64 [B,4,4] (bev_flow_utils.py:30-33): depends on the sample only"""
+    """inv(odom_ta_tb) - I in fp64 [B,4,4] (bev_flow_utils.py:30-33).  On the device: one launch of the cofactor-expansion kernel
+    (liso_odom_inverse_minus_eye_f64) -- no library LU call, no singularity check that reads back to the host, capturable into a
+    hipGraph; host tensors (CPU-side tests) take torch's LU inverse like the reference."""
     dev = odom_ta_tb.device
-    return (torch.linalg.inv_ex(odom_ta_tb.double()).inverse - torch.eye(4, device=dev, dtype=torch.float64)[None]).contiguous()
+    if not odom_ta_tb.is_cuda:
+        return (torch.linalg.inv_ex(odom_ta_tb.double()).inverse - torch.eye(4, device=dev, dtype=torch.float64)[None]).contiguous()
+    m = odom_ta_tb.double().contiguous()
+    out = torch.empty_like(m)
+    with torch.cuda.device(dev):
+        L.check(L.lib().liso_odom_inverse_minus_eye_f64(L.ptr(m), m.numel() // 16, L.ptr(out), L.stream_ptr()), "odom_inverse_minus_eye")
+    return out

@@ -164,3 +164,30 @@ def test_flow_cluster_detector_matches_oracle_and_finds_movers():
             d = (sb[:, :2] - boxes.pos[b, k, :2].float()).norm(dim=-1)
             j = int(d.argmin())
             assert float(d[j]) < 3.5 and float(speed[j]) > 0.1, (b, int(k), float(d[j]), float(speed[j]))
+
+
+def test_odom_inverse_minus_eye_kernel_matches_lu_inverse():
+    """liso_odom_inverse_minus_eye_f64 (cofactor expansion, one launch, capturable) vs torch.linalg.inv(odom) - I in fp64
+    (bev_flow_utils.py:30-33): rigid transforms as the datasets provide them and general well-conditioned 4x4 matrices"""
+    import math
+
+    from liso_amd.utils.bev_flow_utils import odometry_minus_identity
+
+    g = torch.Generator().manual_seed(3)
+    mats = []
+    for _ in range(33):
+        th, tx, ty, tz = [float(v) for v in (torch.rand(4, generator=g, dtype=torch.float64) - 0.5) * torch.tensor([6.28, 40.0, 40.0, 2.0], dtype=torch.float64)]
+        T = torch.eye(4, dtype=torch.float64)
+        T[0, 0], T[0, 1], T[1, 0], T[1, 1] = math.cos(th), -math.sin(th), math.sin(th), math.cos(th)
+        T[0, 3], T[1, 3], T[2, 3] = tx, ty, tz
+        mats.append(T)
+    for _ in range(31):
+        mats.append(torch.eye(4, dtype=torch.float64) * 2.0 + torch.randn(4, 4, generator=g, dtype=torch.float64) * 0.4)
+    m = torch.stack(mats)
+    got = odometry_minus_identity(m.cuda()).cpu()
+    want = torch.linalg.inv(m) - torch.eye(4, dtype=torch.float64)
+    assert got.dtype == torch.float64 and got.shape == (64, 4, 4)
+    assert float((got - want).abs().max()) <= 1e-12 * float(want.abs().max())
+    # fp32 odometry (some loaders) is promoted like the reference's .double()
+    got32 = odometry_minus_identity(m[:4].float().cuda()).cpu()
+    assert float((got32 - (torch.linalg.inv(m[:4].float().double()) - torch.eye(4, dtype=torch.float64))).abs().max()) <= 1e-12 * 50

@@ -342,3 +342,67 @@ def test_batched_loop_step_trains_on_the_batch_and_pipeline_equals_sequential(us
     for a, b in zip(out[0][1], out[1][1]):
         assert a.shape == b.shape and torch.equal(a, b)
     assert out[0][0][-1] != out[0][0][0]
+
+
+def test_sweeps_of_different_point_counts_share_graphs_and_give_the_one_stream_results():
+    """Real sweeps differ in their point counts.  The inference graph AND the box-mining graph are keyed on bucket-padded shapes
+    (`infer_point_bucket` rows; collate-style NaN / invalid / -1 padding, which every kernel ignores), so 9 pairs with 9 different
+    point counts inside two buckets need at most two captures each -- not one per pair -- stack into inference batches, and the
+    pipelined loop gives the losses and boxes of the one-stream loop bit for bit.  The samples are not modified (no cached tensors
+    written into the caller's dicts)."""
+    from liso_amd.datasets.synthetic import slim_pair
+    from liso_amd.trainer import LisoLoopTrainer
+    from liso_amd.utils.config import apply_slim_simple_knn_training, default_cfg
+
+    dev = torch.device("cuda")
+    grid, rng = 256, 50.0
+    counts = [40000, 39711, 41313, 40959, 39001, 41001, 38913, 40500, 41999]  # buckets of 8192 rows: <= 40960 | 40961..49152
+    pairs = [slim_pair(91 + i, dev, n_points=n, grid=grid, bev_range_m=rng) for i, n in enumerate(counts)]
+    keys0 = [sorted(p[0].keys()) + sorted(p[0]["gt"].keys()) + sorted(p[0]["pcl_ta"].keys()) for p in pairs]
+    out = []
+    for overlap in (False, True):
+        cfg = apply_slim_simple_knn_training(default_cfg(grid=grid, bev_range_m=rng))
+        torch.manual_seed(0)
+        tr = LisoLoopTrainer(cfg, dev, compute_dtype=torch.bfloat16, total_steps=40, use_graph=True, overlap=overlap, infer_batch=2,
+                             flow_ahead=1)
+        losses, boxes = [], []
+        for i in range(14):
+            up = [pairs[(i + k) % 9] for k in range(1, 5)]
+            losses.append(float(tr.step(*pairs[i % 9], upcoming=up)))
+            b = tr.last_boxes
+            boxes.append(torch.cat([b.pos.float(), b.dims.float(), b.rot.float(), b.velo.float()], dim=-1)[b.valid].cpu())
+        torch.cuda.synchronize()
+        if overlap:
+            assert tr.mine_captures <= 2 and tr.mine_eager_fallbacks == 0, (tr.mine_captures, tr.mine_eager_fallbacks)
+            assert len(tr._mine_graphs) <= 2
+        # inference graphs: (batch 1 | batch 2) x two buckets at most
+        assert len(tr._infer_graphs) <= 4, len(tr._infer_graphs)
+        out.append((losses, boxes))
+    assert [sorted(p[0].keys()) + sorted(p[0]["gt"].keys()) + sorted(p[0]["pcl_ta"].keys()) for p in pairs] == keys0
+    for a, b in zip(out[0][0], out[1][0]):
+        assert abs(a - b) <= 1e-5 * abs(a), (out[0][0], out[1][0])
+    for a, b in zip(out[0][1], out[1][1]):
+        assert a.shape == b.shape and torch.allclose(a, b, rtol=1e-4, atol=1e-4)
+
+
+def test_mining_graph_budget_falls_back_to_eager_launches():
+    """more signatures than `mine_capture_budget`: the extra ones run the same kernels eagerly (no eviction churn), same results"""
+    from liso_amd.datasets.synthetic import slim_pair
+    from liso_amd.trainer import LisoLoopTrainer
+    from liso_amd.utils.config import apply_slim_simple_knn_training, default_cfg
+
+    dev = torch.device("cuda")
+    grid, rng = 256, 50.0
+    pairs = [slim_pair(61 + i, dev, n_points=n, grid=grid, bev_range_m=rng) for i, n in enumerate((30000, 34000, 38000))]
+    out = []
+    for budget in (24, 1):
+        cfg = apply_slim_simple_knn_training(default_cfg(grid=grid, bev_range_m=rng))
+        cfg.data.tracking_cfg["mine_capture_budget"] = budget
+        torch.manual_seed(0)
+        tr = LisoLoopTrainer(cfg, dev, compute_dtype=torch.bfloat16, total_steps=20, use_graph=True, overlap=True)
+        losses = [float(tr.step(*pairs[i % 3], upcoming=[pairs[(i + 1) % 3], pairs[(i + 2) % 3]])) for i in range(6)]
+        torch.cuda.synchronize()
+        out.append(losses)
+        if budget == 1:
+            assert tr.mine_captures == 1 and tr.mine_eager_fallbacks >= 2
+    assert out[0] == out[1], out
