@@ -432,9 +432,9 @@ def main():
         # (8192 rows) before they reach the captured graphs, so the ring exercises two input signatures per graph cache
         n_up = batch * (2 + args.flow_ahead) + max(1, args.lookahead - 1 - args.flow_ahead) - 1  # pairs the pipeline looks at (step_batch)
         n_pairs = max(16, n_up + batch + 2)
-        counts = [N_POINTS if args.uniform_clouds else N_POINTS - 4000 + (i * 3203) % 8001 for i in range(n_pairs)]
-        if not args.uniform_clouds:
-            counts[-1] += N_POINTS * n_pairs - sum(counts)  # mean exactly N_POINTS
+        offs = [((i * 3203) % 4001) for i in range(n_pairs // 2)]  # 0 .. 4000, mirrored around the mean: mean exactly N_POINTS
+        counts = [N_POINTS] * n_pairs if args.uniform_clouds else \
+            [N_POINTS + (offs[i // 2] if i % 2 == 0 else -offs[i // 2]) for i in range(n_pairs // 2 * 2)] + [N_POINTS] * (n_pairs % 2)
         pairs = [slim_pair(2 + rank + 100 * i, dev, n_points=counts[i], grid=GRID, bev_range_m=BEV_RANGE) for i in range(n_pairs)]
         s0, s1 = pairs[0]
         counter = [0]

@@ -479,6 +479,217 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(const liso_conv
     }
 }
 
+// ---- 3x3 / stride 1 / one class, bf16: ALL NINE taps per block, row-stationary fragments ------------------------------------------
+// The generic kernel above gives a block 1-3 taps: every tap group stages the same halo tile and dy tile again (3.3x the algorithmic
+// HBM bytes measured, profiles/r03_detector_pmc_*), reads one A fragment pair per MFMA, and its 0.35-us MFMA phase per tile cannot
+// hide a ~2-us tile load (one tile of prefetch): the launch sat at a quarter of the rate the forward kernel reaches on the same
+// layer.  Here a block owns a 64 x 64 channel tile of all 9 taps (9 x 16 accumulator registers per wave, one block per CU) and walks
+// TH x 32-pixel tiles:
+//   * x and dy are staged ONCE per pixel tile for all taps (halo rows shared by the three kernel rows);
+//   * fragments are reused from registers: the A fragments of input row r (three horizontal shifts) serve the kernel rows
+//     ky = 0, 1, 2 with the dy fragments of output rows r, r - 1, r - 2 (kept for three input rows) -- 1.2 transposing LDS reads per
+//     MFMA instead of 2.7;
+//   * the MFMA phase of a tile (2 x TH x 9 MFMAs per wave: 2.1 us at TH = 8) covers the latency of the next tile's loads, which are
+//     issued into registers in front of it (19 x 16 B per thread at TH = 8).
+// Slabs, bias sums and the fixed-order reduction are those of the generic kernel.
+template <int TH>
+__global__ __launch_bounds__(kThreads, 1) void conv_wgrad_rs3_kernel(const liso_conv_desc d, const WgArgs a) {
+    constexpr int IW = TW + 2, IH = TH + 2;         // halo tile (padding 1)
+    constexpr int NPX = IH * IW;                     // halo pixels
+    constexpr int XB = (NPX + 31) / 32;              // 16-B chunks per thread (32 pixel rows of threads x 8 chunks per pixel)
+    constexpr int YB = TH;                           // dy: TH x 32 pixels
+    constexpr int MPIX = TH * TW;
+    constexpr int X_BYTES = (NPX * PSB + 15) / 16 * 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* xs = smem;
+    unsigned char* ys = smem + X_BYTES;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    int t = blockIdx.x;
+    const int split = t % a.splits;
+    t /= a.splits;
+    const int cot = t % a.co_t;
+    const int cit = t / a.co_t;
+    const int ci0 = cit * CT, co0 = cot * CT;
+    const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const int ci_half = wave >> 1, co_half = wave & 1;
+    const int a_lane = (8 * (g >> 1) + q) * PSB + (ci_half * 32 + 16 * (g & 1) + 4 * p) * 2;
+    const int b_lane = (8 * (g >> 1) + q) * PSB + (co_half * 32 + 16 * (g & 1) + 4 * p) * 2;
+
+    f16v acc[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[i][e] = 0.0f;
+    float bsum[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) bsum[e] = 0.0f;
+    const bool want_bias = a.bias_slab != nullptr && cit == 0;
+
+    const int c8 = tid & 7, p0 = tid >> 3;
+    uint4 xv[XB], yv[YB];
+    unsigned xok = 0u, yok = 0u;
+    float sc[8], sh[8];
+    const bool pro = a.in_scale != nullptr;
+    {
+        const int ch = ci0 + c8 * 8;
+        if (pro) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                sc[e] = ch < d.ci ? a.in_scale[ch + e] : 0.0f;
+                sh[e] = ch < d.ci ? a.in_shift[ch + e] : 0.0f;
+            }
+        }
+    }
+    auto tile_origin = [&](int tile, int& b, int& ty, int& tx) {
+        tx = tile % a.tiles_x;
+        tile /= a.tiles_x;
+        ty = tile % a.tiles_y;
+        b = tile / a.tiles_y;
+    };
+    auto load_tile = [&](int tile) {
+        int b, ty, tx;
+        tile_origin(tile, b, ty, tx);
+        const int iy0 = ty * TH - 1, ix0 = tx * TW - 1;
+        const int ch = ci0 + c8 * 8;
+        const bool ch_ok = ch < d.ci;
+        const unsigned short* xg = (const unsigned short*)a.x + (long)b * d.hi * d.wi * d.x_pix_stride;
+        xok = 0u;
+#pragma unroll
+        for (int u = 0; u < XB; u++) {
+            const int pix = p0 + u * 32;
+            const int ly = pix / IW, lx = pix - ly * IW;  // (compile-time divisor)
+            const int iy = iy0 + ly, ix = ix0 + lx;
+            const bool ok = pix < NPX && ch_ok && (unsigned)iy < (unsigned)d.hi && (unsigned)ix < (unsigned)d.wi;
+            xok |= ok ? (1u << u) : 0u;
+            const int off = ok ? (iy * d.wi + ix) * d.x_pix_stride + ch : 0;
+            xv[u] = *reinterpret_cast<const uint4*>(xg + off);
+        }
+        const unsigned short* yg = (const unsigned short*)a.dy + (long)b * d.ho * d.wo * a.dy_pix_stride;
+        const int chy = co0 + c8 * 8;
+        const bool chy_ok = chy < d.co;
+        yok = 0u;
+#pragma unroll
+        for (int u = 0; u < YB; u++) {
+            const int oy = ty * TH + u, ox = tx * TW + p0;
+            const bool ok = chy_ok && oy < d.ho && ox < d.wo;
+            yok |= ok ? (1u << u) : 0u;
+            const int off = ok ? (oy * d.wo + ox) * a.dy_pix_stride + chy : 0;
+            yv[u] = *reinterpret_cast<const uint4*>(yg + off);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int u = 0; u < XB; u++) {
+            const int pix = p0 + u * 32;
+            if (pix >= NPX) continue;
+            uint4 o = xv[u];
+            if (pro) {
+                unsigned w[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    float f0 = fmaf(bf16_lo(w[e]), sc[2 * e], sh[2 * e]);
+                    float f1 = fmaf(bf16_hi(w[e]), sc[2 * e + 1], sh[2 * e + 1]);
+                    if (d.in_relu) {
+                        f0 = fmaxf(f0, 0.0f);
+                        f1 = fmaxf(f1, 0.0f);
+                    }
+                    w[e] = pack_bf16(f0, f1);
+                }
+                o = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+            if (!((xok >> u) & 1u)) o = make_uint4(0u, 0u, 0u, 0u);
+            *reinterpret_cast<uint4*>(xs + pix * PSB + c8 * 16) = o;
+        }
+#pragma unroll
+        for (int u = 0; u < YB; u++) {
+            uint4 v = yv[u];
+            if (!((yok >> u) & 1u)) v = make_uint4(0u, 0u, 0u, 0u);
+            *reinterpret_cast<uint4*>(ys + (u * TW + p0) * PSB + c8 * 16) = v;
+            if (want_bias) {
+                const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    bsum[2 * e] += bf16_lo(w[e]);
+                    bsum[2 * e + 1] += bf16_hi(w[e]);
+                }
+            }
+        }
+    };
+    auto mfma_tile = [&]() {
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            bf8 bf[3];
+#pragma unroll
+            for (int r = 0; r < IH; r++) {
+                bf8 af[3];
+#pragma unroll
+                for (int kx = 0; kx < 3; kx++) {
+                    const unsigned char* ap = xs + (r * IW + 16 * c + kx) * PSB + a_lane;
+                    af[kx] = tr_pair(ap, ap + 4 * PSB);
+                }
+                if (r < TH) {
+                    const unsigned char* bp = ys + (r * TW + 16 * c) * PSB + b_lane;
+                    bf[r % 3] = tr_pair(bp, bp + 4 * PSB);
+                }
+#pragma unroll
+                for (int ky = 0; ky < 3; ky++) {
+                    const int o = r - ky;
+                    if (o >= 0 && o < TH) {
+#pragma unroll
+                        for (int kx = 0; kx < 3; kx++)
+                            acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kx], bf[o % 3], acc[ky * 3 + kx], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    };
+
+    int tile = split;
+    if (tile < a.n_tiles) {
+        load_tile(tile);
+        store_tile();
+    }
+    __syncthreads();
+    for (; tile < a.n_tiles; tile += a.splits) {
+        const int next = tile + a.splits;
+        const bool more = next < a.n_tiles;
+        if (more) load_tile(next);
+        mfma_tile();
+        __syncthreads();  // every wave is done with this tile's LDS image
+        if (more) store_tile();
+        __syncthreads();
+    }
+    // ---- slab: D[row = ci][col = co]; col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5) ---------------------------------
+    const int r = lane & 31, h = lane >> 5;
+    const long cip = (long)a.ci_t * CT, cop = (long)a.co_t * CT;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const int wt = d.tap_w[i];  // (taps are listed ky-major, kx-minor: checked by the plan)
+        float* base = a.slab + (((long)split * d.w_taps + wt) * cip + ci0 + ci_half * 32) * cop + co0 + co_half * 32 + r;
+        if (co0 + co_half * 32 + r < (d.wgrad_co > 0 ? d.wgrad_co : d.co)) {
+            const int rows_left = d.ci - (ci0 + ci_half * 32);
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (row < rows_left) base[(long)row * cop] = acc[i][e];
+            }
+        }
+    }
+    if (want_bias) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int e = 0; e < 8; e++) red[tid * 8 + e] = bsum[e];
+        __syncthreads();
+        if (tid < CT) {
+            const int grp_c = tid / 8, e = tid % 8;
+            float s = 0.0f;
+            for (int pp = 0; pp < kThreads / 8; pp++) s += red[(pp * 8 + grp_c) * 8 + e];
+            a.bias_slab[(long)split * cop + co0 + tid] = s;
+        }
+    }
+}
+
 // dw (torch layout) = sum over splits of the slabs (fixed order: 4 interleaved partial sums per output, then a tree)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bias_slab,
                                                            int splits, int bias_rows, int taps, int ci, int co, long cip, long cop,
@@ -680,13 +891,71 @@ int launch(const liso_conv_desc& d, const WgPlan& p, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? LISO_OK : LISO_ELAUNCH;
 }
 
+// ---- plan of the row-stationary 3x3 kernel ----------------------------------------------------------------------------------------
+struct Rs3Plan {
+    int th, lds, blocks;
+    size_t slab_bytes, bias_bytes;
+    WgArgs a;
+};
+
+bool make_rs3_plan(const liso_conv_desc& d, Rs3Plan* p) {
+    if (const char* e = getenv("LISO_WGRAD_RS3"))  // experiments / A-B runs: 0 = the generic kernel everywhere
+        if (atoi(e) == 0) return false;
+    if (d.mode != LISO_CONV_BF16 || d.n_classes != 1 || d.n_taps != 9 || d.w_taps != 9) return false;
+    if (d.isy != 1 || d.isx != 1 || d.osy != 1 || d.osx != 1 || d.in_affine_batch_stride != 0) return false;
+    if (d.hv != d.ho || d.wv != d.wo || d.hi != d.ho || d.wi != d.wo || d.batch <= 0) return false;
+    if (d.ci % 8 || d.co % 8 || d.x_pix_stride % 8 || d.class_tap_begin[0] != 0 || d.class_tap_begin[1] != 9) return false;
+    for (int t = 0; t < 9; t++)
+        if (d.tap_dy[t] != t / 3 - 1 || d.tap_dx[t] != t % 3 - 1 || d.tap_w[t] < 0 || d.tap_w[t] >= 9) return false;
+    WgArgs& a = p->a;
+    a.ci_t = (d.ci + CT - 1) / CT;
+    a.co_t = (d.co + CT - 1) / CT;
+    const long cc = (long)a.ci_t * a.co_t;
+    long want = 256 / cc;  // one block per CU
+    if (const char* e = getenv("LISO_WGRAD_BLOCKS")) want = (atol(e) > 0 ? atol(e) : 256) / cc;  // experiments
+    want = want < 1 ? 1 : want;
+    a.tiles_x = (d.wo + TW - 1) / TW;
+    const long tiles8 = (long)d.batch * ((d.ho + 7) / 8) * a.tiles_x;
+    int th = tiles8 >= 4 * want ? 8 : 4;
+    if (const char* e = getenv("LISO_WGRAD_TH")) th = atoi(e) == 8 ? 8 : atoi(e) == 4 ? 4 : th;  // experiments
+    a.th = th;
+    a.tiles_y = (d.ho + th - 1) / th;
+    a.n_tiles = d.batch * a.tiles_y * a.tiles_x;
+    long s = a.n_tiles / 4;  // >= 4 tiles per block: the first tile's load is exposed, the others hide behind MFMAs
+    s = s > want ? want : s;
+    s = s < 1 ? 1 : s;
+    a.splits = (int)s;
+    a.n_groups = 1;
+    p->th = th;
+    p->blocks = (int)(cc * s);
+    p->lds = ((th + 2) * (TW + 2) * PSB + 15) / 16 * 16 + th * TW * PSB;
+    p->slab_bytes = (size_t)s * 9 * a.ci_t * CT * a.co_t * CT * sizeof(float);
+    p->bias_bytes = (size_t)s * a.co_t * CT * sizeof(float);
+    return true;
+}
+
+template <int TH>
+int launch_rs3(const liso_conv_desc& d, const Rs3Plan& p, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)conv_wgrad_rs3_kernel<TH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return LISO_ELAUNCH;
+        attr_set = true;
+    }
+    conv_wgrad_rs3_kernel<TH><<<p.blocks, kThreads, p.lds, st>>>(d, p.a);
+    return hipGetLastError() == hipSuccess ? LISO_OK : LISO_ELAUNCH;
+}
+
 }  // namespace
 
 extern "C" {
 
 size_t liso_conv_wgrad_workspace_bytes(const liso_conv_desc* d) {
+    if (!d) return 0;
+    Rs3Plan r;
+    if (make_rs3_plan(*d, &r)) return r.slab_bytes + r.bias_bytes;
     WgPlan p;
-    if (!d || !make_plan(*d, &p)) return 0;
+    if (!make_plan(*d, &p)) return 0;
     return p.slab_bytes + p.bias_bytes;
 }
 
@@ -695,10 +964,30 @@ int liso_conv_wgrad(const liso_conv_desc* d, const void* x, const float* in_scal
                     void* stream) {
     if (!d || !x || !dy || !dw || !workspace) return LISO_EINVAL;
     if ((in_scale == nullptr) != (in_shift == nullptr)) return LISO_EINVAL;
-    WgPlan p;
-    if (!make_plan(*d, &p)) return LISO_EINVAL;
     const int vec = d->mode == LISO_CONV_BF16 ? 8 : 4;
     if (dy_pix_stride % vec || dy_pix_stride < d->co || (((uintptr_t)x | (uintptr_t)dy) & 15)) return LISO_EINVAL;
+    if (d->wgrad_co < 0 || d->wgrad_co > d->co) return LISO_EINVAL;
+    Rs3Plan r3;
+    if (make_rs3_plan(*d, &r3)) {  // 3x3 / stride 1, bf16: all taps per block, row-stationary fragments
+        if (workspace_bytes < r3.slab_bytes + r3.bias_bytes) return LISO_EWORKSPACE;
+        r3.a.x = x;
+        r3.a.in_scale = in_scale;
+        r3.a.in_shift = in_shift;
+        r3.a.dy = dy;
+        r3.a.dy_pix_stride = dy_pix_stride;
+        r3.a.slab = (float*)workspace;
+        r3.a.bias_slab = dbias ? (float*)((char*)workspace + r3.slab_bytes) : nullptr;
+        hipStream_t st3 = (hipStream_t)stream;
+        const int rc3 = r3.th == 8 ? launch_rs3<8>(*d, r3, st3) : launch_rs3<4>(*d, r3, st3);
+        if (rc3 != LISO_OK) return rc3;
+        const int co_w3 = d->wgrad_co > 0 ? d->wgrad_co : d->co;
+        const long rblocks3 = ((long)d->w_taps * d->ci + (dbias ? 1 : 0)) * ((co_w3 + 63) / 64);
+        wgrad_reduce_kernel<<<(int)rblocks3, 256, 0, st3>>>(r3.a.slab, r3.a.bias_slab, r3.a.splits, r3.a.splits, d->w_taps, d->ci, co_w3,
+                                                           (long)r3.a.ci_t * CT, (long)r3.a.co_t * CT, transposed, dw, dbias);
+        return hipGetLastError() == hipSuccess ? LISO_OK : LISO_ELAUNCH;
+    }
+    WgPlan p;
+    if (!make_plan(*d, &p)) return LISO_EINVAL;
     if (workspace_bytes < p.slab_bytes + p.bias_bytes) return LISO_EWORKSPACE;
     p.a.x = x;
     p.a.in_scale = in_scale;

@@ -747,16 +747,41 @@ class LisoLoopTrainer:
         return out
 
     def _view(self, sample):
-        """bucket-padded view of a sample, built once per sample object and kept on the trainer (bounded, oldest first out)"""
+        """bucket-padded view of a sample, built once per sample object and kept on the trainer (bounded, oldest first out).  The
+        three pipeline stages run on different streams: the padding launches are followed by an event, a stage that meets the view on
+        another stream waits for it and marks the padded tensors as in use there (they must not be recycled under that stream when
+        the entry leaves the cache)."""
+        cuda = self.device.type == "cuda"
+        cur = torch.cuda.current_stream(self.device) if cuda else None
         hit = self._views.get(id(sample))
         if hit is not None and hit[0] is sample:
             self._views.move_to_end(id(sample))
-            return hit[1]
+            _, v, ev, made_on, seen = hit
+            if cuda and ev is not None and cur.cuda_stream != made_on and cur.cuda_stream not in seen:
+                cur.wait_event(ev)
+                for t in self._padded_tensors(sample, v):
+                    t.record_stream(cur)
+                seen.add(cur.cuda_stream)
+            return v
         v = self._pad_loss_cloud(sample)
-        self._views[id(sample)] = (sample, v)  # (the strong reference keeps id(sample) from being recycled while the entry lives)
+        ev = None
+        if cuda and v is not sample:
+            ev = torch.cuda.Event()
+            ev.record(cur)
+        self._views[id(sample)] = (sample, v, ev, cur.cuda_stream if cuda else None, set())  # (the strong reference pins id(sample))
         while len(self._views) > 64:
             self._views.popitem(last=False)
         return v
+
+    @staticmethod
+    def _padded_tensors(sample, view):
+        """the tensors `_pad_loss_cloud` created for `view` (those that are not the sample's own)"""
+        out = []
+        if view["pcl_ta"] is not sample["pcl_ta"]:
+            out += [view["pcl_ta"][k] for k in ("pcl", "pcl_is_valid", "pillar_coors")]
+        if view.get("pcl_full_w_ground_ta") is not sample.get("pcl_full_w_ground_ta"):
+            out.append(view["pcl_full_w_ground_ta"])
+        return out
 
     def _infer_view(self, sample):
         """what the frozen SLIM inference reads from a (padded) sample: the loss cloud, the odometry and the network-input clouds --
