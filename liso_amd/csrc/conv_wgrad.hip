@@ -479,30 +479,43 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(const liso_conv
     }
 }
 
-// ---- 3x3 / stride 1 / one class, bf16: ALL NINE taps per block, row-stationary fragments ------------------------------------------
+// ---- 3x3 / stride 1 / one class, bf16: ALL NINE taps per block, row-stationary fragments, loader / MFMA wave roles -----------------
 // The generic kernel above gives a block 1-3 taps: every tap group stages the same halo tile and dy tile again (3.3x the algorithmic
 // HBM bytes measured, profiles/r03_detector_pmc_*), reads one A fragment pair per MFMA, and its 0.35-us MFMA phase per tile cannot
 // hide a ~2-us tile load (one tile of prefetch): the launch sat at a quarter of the rate the forward kernel reaches on the same
-// layer.  Here a block owns a 64 x 64 channel tile of all 9 taps (9 x 16 accumulator registers per wave, one block per CU) and walks
-// TH x 32-pixel tiles:
+// layer.  Here a block of 8 waves (one per CU) owns a 64 x 64 channel tile of ALL 9 taps and walks TH x 32-pixel tiles:
+//   * waves 4-7 LOAD: global -> registers (the tile after next is in flight while the next one is written) -> BatchNorm / ReLU
+//     prologue -> LDS buffer (k + 1) & 1; waves 0-3 MULTIPLY on buffer k & 1 (9 x 16 accumulator registers each, 32 x 32 quadrant of
+//     every tap): address arithmetic, the prologue's vector ALU work and the LDS stores run beside the matrix cores instead of
+//     between their phases; one barrier per tile;
 //   * x and dy are staged ONCE per pixel tile for all taps (halo rows shared by the three kernel rows);
 //   * fragments are reused from registers: the A fragments of input row r (three horizontal shifts) serve the kernel rows
-//     ky = 0, 1, 2 with the dy fragments of output rows r, r - 1, r - 2 (kept for three input rows) -- 1.2 transposing LDS reads per
-//     MFMA instead of 2.7;
-//   * the MFMA phase of a tile (2 x TH x 9 MFMAs per wave: 2.1 us at TH = 8) covers the latency of the next tile's loads, which are
-//     issued into registers in front of it (19 x 16 B per thread at TH = 8).
+//     ky = 0, 1, 2 with the dy fragments of output rows r, r - 1, r - 2 (kept for three input rows) -- 1.06 transposing LDS read
+//     pairs per MFMA instead of 2.7;
+//   * LDS pixels are 128 B apart (no padding: two buffers of a TH = 8 tile fit 160 KB); the two 64-B halves of a pixel are swapped
+//     where bit 1 of the pixel index is set, so the four pixels a 32-lane group of ds_read_b64_tr_b16 touches fall into four
+//     different 16-bank ranges for any starting pixel (the horizontal taps start at every alignment).
 // Slabs, bias sums and the fixed-order reduction are those of the generic kernel.
-template <int TH>
-__global__ __launch_bounds__(kThreads, 1) void conv_wgrad_rs3_kernel(const liso_conv_desc d, const WgArgs a) {
+constexpr int kRsThreads = 512;
+constexpr int RPS = 128;  // LDS bytes per pixel and plane (64 bf16 channels)
+
+// MODE = LISO_CONV_BF16 (TH = 8 | 4) or LISO_CONV_F32X3 (fp32 tensors split into bf16 hi + lo planes while they are staged, three
+// MFMAs per product; TH = 3: two buffers of two planes fit 160 KB)
+template <int MODE, int TH>
+__global__ __launch_bounds__(kRsThreads, 1) void conv_wgrad_rs3_kernel(const liso_conv_desc d, const WgArgs a) {
+    constexpr bool X3 = MODE == LISO_CONV_F32X3;
+    constexpr int PLANES = X3 ? 2 : 1;
     constexpr int IW = TW + 2, IH = TH + 2;         // halo tile (padding 1)
     constexpr int NPX = IH * IW;                     // halo pixels
-    constexpr int XB = (NPX + 31) / 32;              // 16-B chunks per thread (32 pixel rows of threads x 8 chunks per pixel)
-    constexpr int YB = TH;                           // dy: TH x 32 pixels
-    constexpr int MPIX = TH * TW;
-    constexpr int X_BYTES = (NPX * PSB + 15) / 16 * 16;
+    constexpr int CPP = X3 ? 16 : 8;                 // 16-B global chunks per pixel (64 channels)
+    constexpr int PSL = 256 / CPP;                   // pixel slots of the 256 loader threads
+    constexpr int XB = (NPX + PSL - 1) / PSL;        // chunks per loader thread
+    constexpr int YB = TH * TW / PSL;                // dy: TH x 32 pixels
+    constexpr int X_PLANE = NPX * RPS, Y_PLANE = TH * TW * RPS;
+    constexpr int X_BYTES = PLANES * X_PLANE;
+    constexpr int BUF = X_BYTES + PLANES * Y_PLANE;
+    constexpr int NE = X3 ? 4 : 8;                   // channels per chunk
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* xs = smem;
-    unsigned char* ys = smem + X_BYTES;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     int t = blockIdx.x;
     const int split = t % a.splits;
@@ -510,158 +523,247 @@ __global__ __launch_bounds__(kThreads, 1) void conv_wgrad_rs3_kernel(const liso_
     const int cot = t % a.co_t;
     const int cit = t / a.co_t;
     const int ci0 = cit * CT, co0 = cot * CT;
+    const long cip = (long)a.ci_t * CT, cop = (long)a.co_t * CT;
+    const int n_mine = split < a.n_tiles ? (a.n_tiles - split + a.splits - 1) / a.splits : 0;  // tiles of this block
+
+    if (wave >= 4) {
+        // ================================ loader waves ================================
+        const int ltid = tid - 256;
+        const int cc = ltid % CPP, p0 = ltid / CPP;
+        uint4 xv[XB], yv[YB];
+        unsigned xok = 0u, yok = 0u;
+        float sc[NE], sh[NE];
+        float bsum[NE];
+#pragma unroll
+        for (int e = 0; e < NE; e++) bsum[e] = 0.0f;
+        const bool want_bias = a.bias_slab != nullptr && cit == 0;
+        const bool pro = a.in_scale != nullptr;
+        const int ch = ci0 + cc * NE, chy = co0 + cc * NE;
+        const bool ch_ok = ch < d.ci, chy_ok = chy < d.co;
+        if (pro) {
+#pragma unroll
+            for (int e = 0; e < NE; e++) {
+                sc[e] = ch_ok ? a.in_scale[ch + e] : 0.0f;
+                sh[e] = ch_ok ? a.in_shift[ch + e] : 0.0f;
+            }
+        }
+        // this thread's halo pixels: position inside the tile, element offset relative to the tile's first pixel
+        int rel[XB];
+        unsigned lyx[XB];
+#pragma unroll
+        for (int u = 0; u < XB; u++) {
+            const int pix = p0 + u * PSL;
+            const int ly = pix / IW, lx = pix - ly * IW;
+            rel[u] = (ly * d.wi + lx) * d.x_pix_stride;
+            lyx[u] = (unsigned)ly | ((unsigned)lx << 8) | (pix < NPX && ch_ok ? 0x10000u : 0u);
+        }
+        auto load_tile = [&](int tile) {
+            const int tx = tile % a.tiles_x;
+            const int tq = tile / a.tiles_x;
+            const int ty = tq % a.tiles_y, b = tq / a.tiles_y;
+            const int iy0 = ty * TH - 1, ix0 = tx * TW - 1;
+            const long xbase = (long)b * d.hi * d.wi * d.x_pix_stride + ch;
+            const int org = (iy0 * d.wi + ix0) * d.x_pix_stride;
+            const bool inner = iy0 >= 0 && iy0 + IH <= d.hi && ix0 >= 0 && ix0 + IW <= d.wi;  // (uniform) no pixel outside the image
+            xok = 0u;
+#pragma unroll
+            for (int u = 0; u < XB; u++) {
+                bool ok = (lyx[u] >> 16) != 0u;
+                if (!inner) {
+                    const int iy = iy0 + (int)(lyx[u] & 0xffu), ix = ix0 + (int)((lyx[u] >> 8) & 0xffu);
+                    ok = ok && (unsigned)iy < (unsigned)d.hi && (unsigned)ix < (unsigned)d.wi;
+                }
+                xok |= ok ? (1u << u) : 0u;
+                const long off = xbase + (ok ? org + rel[u] : 0);
+                if constexpr (X3)
+                    xv[u] = *reinterpret_cast<const uint4*>((const float*)a.x + off);
+                else
+                    xv[u] = *reinterpret_cast<const uint4*>((const unsigned short*)a.x + off);
+            }
+            const long ybase = (long)b * d.ho * d.wo * a.dy_pix_stride + chy;
+            yok = 0u;
+#pragma unroll
+            for (int u = 0; u < YB; u++) {
+                const int m = p0 + u * PSL;
+                const int oy = ty * TH + (m >> 5), ox = tx * TW + (m & 31);
+                const bool ok = chy_ok && oy < d.ho && ox < d.wo;
+                yok |= ok ? (1u << u) : 0u;
+                const long off = ybase + (ok ? (long)(oy * d.wo + ox) * a.dy_pix_stride : 0);
+                if constexpr (X3)
+                    yv[u] = *reinterpret_cast<const uint4*>((const float*)a.dy + off);
+                else
+                    yv[u] = *reinterpret_cast<const uint4*>((const unsigned short*)a.dy + off);
+            }
+        };
+        auto store_tile = [&](unsigned char* buf) {
+            unsigned char* xs = buf;
+            unsigned char* ys = buf + X_BYTES;
+#pragma unroll
+            for (int u = 0; u < XB; u++) {
+                const int pix = p0 + u * PSL;
+                if (pix >= NPX) continue;
+                const int swz = ((pix >> 1) & 1) << 6;
+                if constexpr (X3) {
+                    float f[4] = {__uint_as_float(xv[u].x), __uint_as_float(xv[u].y), __uint_as_float(xv[u].z), __uint_as_float(xv[u].w)};
+                    unsigned hi2[2], lo2[2];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        if (pro) {
+                            f[e] = fmaf(f[e], sc[e], sh[e]);
+                            if (d.in_relu) f[e] = fmaxf(f[e], 0.0f);
+                        }
+                        if (!((xok >> u) & 1u)) f[e] = 0.0f;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 2; e++) {
+                        const float h0 = round_bf16(f[2 * e]), h1 = round_bf16(f[2 * e + 1]);
+                        hi2[e] = pack_bf16(h0, h1);
+                        lo2[e] = pack_bf16(f[2 * e] - h0, f[2 * e + 1] - h1);
+                    }
+                    *reinterpret_cast<uint2*>(xs + pix * RPS + ((cc * 8) ^ swz)) = make_uint2(hi2[0], hi2[1]);
+                    *reinterpret_cast<uint2*>(xs + X_PLANE + pix * RPS + ((cc * 8) ^ swz)) = make_uint2(lo2[0], lo2[1]);
+                } else {
+                    uint4 o = xv[u];
+                    if (pro) {
+                        unsigned w[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            float f0 = fmaf(bf16_lo(w[e]), sc[2 * e], sh[2 * e]);
+                            float f1 = fmaf(bf16_hi(w[e]), sc[2 * e + 1], sh[2 * e + 1]);
+                            if (d.in_relu) {
+                                f0 = fmaxf(f0, 0.0f);
+                                f1 = fmaxf(f1, 0.0f);
+                            }
+                            w[e] = pack_bf16(f0, f1);
+                        }
+                        o = make_uint4(w[0], w[1], w[2], w[3]);
+                    }
+                    if (!((xok >> u) & 1u)) o = make_uint4(0u, 0u, 0u, 0u);
+                    *reinterpret_cast<uint4*>(xs + pix * RPS + ((cc * 16) ^ swz)) = o;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < YB; u++) {
+                const int m = p0 + u * PSL;
+                const int swz = ((m >> 1) & 1) << 6;
+                uint4 v = yv[u];
+                if (!((yok >> u) & 1u)) v = make_uint4(0u, 0u, 0u, 0u);
+                if constexpr (X3) {
+                    const float f[4] = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+                    unsigned hi2[2], lo2[2];
+#pragma unroll
+                    for (int e = 0; e < 2; e++) {
+                        const float h0 = round_bf16(f[2 * e]), h1 = round_bf16(f[2 * e + 1]);
+                        hi2[e] = pack_bf16(h0, h1);
+                        lo2[e] = pack_bf16(f[2 * e] - h0, f[2 * e + 1] - h1);
+                    }
+                    *reinterpret_cast<uint2*>(ys + m * RPS + ((cc * 8) ^ swz)) = make_uint2(hi2[0], hi2[1]);
+                    *reinterpret_cast<uint2*>(ys + Y_PLANE + m * RPS + ((cc * 8) ^ swz)) = make_uint2(lo2[0], lo2[1]);
+                    if (want_bias) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) bsum[e] += f[e];
+                    }
+                } else {
+                    *reinterpret_cast<uint4*>(ys + m * RPS + ((cc * 16) ^ swz)) = v;
+                    if (want_bias) {
+                        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            bsum[2 * e] += bf16_lo(w[e]);
+                            bsum[2 * e + 1] += bf16_hi(w[e]);
+                        }
+                    }
+                }
+            }
+        };
+        if (n_mine > 0) {
+            load_tile(split);
+            store_tile(smem);
+            if (n_mine > 1) load_tile(split + a.splits);
+        }
+        __syncthreads();  // (A) buffer 0 is ready
+        for (int k = 0; k < n_mine; k++) {
+            if (k + 1 < n_mine) {
+                store_tile(smem + ((k + 1) & 1) * BUF);  // the tile the MFMA waves take next (they left this buffer at barrier k - 1)
+                if (k + 2 < n_mine) load_tile(split + (k + 2) * a.splits);
+            }
+            __syncthreads();  // (B k)
+        }
+        if (want_bias) {  // (the MFMA waves are past their last LDS read: barrier B of the last tile)
+            float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+            for (int e = 0; e < NE; e++) red[ltid * NE + e] = bsum[e];
+        }
+        __syncthreads();  // (C)
+        if (want_bias && ltid < CT) {
+            const float* red = reinterpret_cast<const float*>(smem);
+            const int grp_c = ltid / NE, e = ltid % NE;
+            float s_ = 0.0f;
+            for (int pp = 0; pp < PSL; pp++) s_ += red[(pp * CPP + grp_c) * NE + e];
+            a.bias_slab[(long)split * cop + co0 + ltid] = s_;
+        }
+        return;
+    }
+    // ================================ MFMA waves ================================
     const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
     const int ci_half = wave >> 1, co_half = wave & 1;
-    const int a_lane = (8 * (g >> 1) + q) * PSB + (ci_half * 32 + 16 * (g & 1) + 4 * p) * 2;
-    const int b_lane = (8 * (g >> 1) + q) * PSB + (co_half * 32 + 16 * (g & 1) + 4 * p) * 2;
+    // lane offsets of the transposing reads for the four alignments of a fragment's first pixel (the 64-B swap follows bit 1 of the
+    // pixel index; + 4 or + 8 pixels never change it)
+    int a_lane[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+        a_lane[m] = (8 * (g >> 1) + q) * RPS + ((ci_half * 64 + 32 * (g & 1) + 8 * p) ^ ((((m + q) >> 1) & 1) << 6));
+    const int b_lane = (8 * (g >> 1) + q) * RPS + ((co_half * 64 + 32 * (g & 1) + 8 * p) ^ (((q >> 1) & 1) << 6));
 
     f16v acc[9];
 #pragma unroll
     for (int i = 0; i < 9; i++)
 #pragma unroll
         for (int e = 0; e < 16; e++) acc[i][e] = 0.0f;
-    float bsum[8];
-#pragma unroll
-    for (int e = 0; e < 8; e++) bsum[e] = 0.0f;
-    const bool want_bias = a.bias_slab != nullptr && cit == 0;
 
-    const int c8 = tid & 7, p0 = tid >> 3;
-    uint4 xv[XB], yv[YB];
-    unsigned xok = 0u, yok = 0u;
-    float sc[8], sh[8];
-    const bool pro = a.in_scale != nullptr;
-    {
-        const int ch = ci0 + c8 * 8;
-        if (pro) {
-#pragma unroll
-            for (int e = 0; e < 8; e++) {
-                sc[e] = ch < d.ci ? a.in_scale[ch + e] : 0.0f;
-                sh[e] = ch < d.ci ? a.in_shift[ch + e] : 0.0f;
-            }
-        }
-    }
-    auto tile_origin = [&](int tile, int& b, int& ty, int& tx) {
-        tx = tile % a.tiles_x;
-        tile /= a.tiles_x;
-        ty = tile % a.tiles_y;
-        b = tile / a.tiles_y;
-    };
-    auto load_tile = [&](int tile) {
-        int b, ty, tx;
-        tile_origin(tile, b, ty, tx);
-        const int iy0 = ty * TH - 1, ix0 = tx * TW - 1;
-        const int ch = ci0 + c8 * 8;
-        const bool ch_ok = ch < d.ci;
-        const unsigned short* xg = (const unsigned short*)a.x + (long)b * d.hi * d.wi * d.x_pix_stride;
-        xok = 0u;
-#pragma unroll
-        for (int u = 0; u < XB; u++) {
-            const int pix = p0 + u * 32;
-            const int ly = pix / IW, lx = pix - ly * IW;  // (compile-time divisor)
-            const int iy = iy0 + ly, ix = ix0 + lx;
-            const bool ok = pix < NPX && ch_ok && (unsigned)iy < (unsigned)d.hi && (unsigned)ix < (unsigned)d.wi;
-            xok |= ok ? (1u << u) : 0u;
-            const int off = ok ? (iy * d.wi + ix) * d.x_pix_stride + ch : 0;
-            xv[u] = *reinterpret_cast<const uint4*>(xg + off);
-        }
-        const unsigned short* yg = (const unsigned short*)a.dy + (long)b * d.ho * d.wo * a.dy_pix_stride;
-        const int chy = co0 + c8 * 8;
-        const bool chy_ok = chy < d.co;
-        yok = 0u;
-#pragma unroll
-        for (int u = 0; u < YB; u++) {
-            const int oy = ty * TH + u, ox = tx * TW + p0;
-            const bool ok = chy_ok && oy < d.ho && ox < d.wo;
-            yok |= ok ? (1u << u) : 0u;
-            const int off = ok ? (oy * d.wo + ox) * a.dy_pix_stride + chy : 0;
-            yv[u] = *reinterpret_cast<const uint4*>(yg + off);
-        }
-    };
-    auto store_tile = [&]() {
-#pragma unroll
-        for (int u = 0; u < XB; u++) {
-            const int pix = p0 + u * 32;
-            if (pix >= NPX) continue;
-            uint4 o = xv[u];
-            if (pro) {
-                unsigned w[4] = {o.x, o.y, o.z, o.w};
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    float f0 = fmaf(bf16_lo(w[e]), sc[2 * e], sh[2 * e]);
-                    float f1 = fmaf(bf16_hi(w[e]), sc[2 * e + 1], sh[2 * e + 1]);
-                    if (d.in_relu) {
-                        f0 = fmaxf(f0, 0.0f);
-                        f1 = fmaxf(f1, 0.0f);
-                    }
-                    w[e] = pack_bf16(f0, f1);
-                }
-                o = make_uint4(w[0], w[1], w[2], w[3]);
-            }
-            if (!((xok >> u) & 1u)) o = make_uint4(0u, 0u, 0u, 0u);
-            *reinterpret_cast<uint4*>(xs + pix * PSB + c8 * 16) = o;
-        }
-#pragma unroll
-        for (int u = 0; u < YB; u++) {
-            uint4 v = yv[u];
-            if (!((yok >> u) & 1u)) v = make_uint4(0u, 0u, 0u, 0u);
-            *reinterpret_cast<uint4*>(ys + (u * TW + p0) * PSB + c8 * 16) = v;
-            if (want_bias) {
-                const unsigned w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    bsum[2 * e] += bf16_lo(w[e]);
-                    bsum[2 * e + 1] += bf16_hi(w[e]);
-                }
-            }
-        }
-    };
-    auto mfma_tile = [&]() {
+    __syncthreads();  // (A)
+    for (int k = 0; k < n_mine; k++) {
+        const unsigned char* xs = smem + (k & 1) * BUF;
+        const unsigned char* ys = xs + X_BYTES;
 #pragma unroll
         for (int c = 0; c < 2; c++) {
-            bf8 bf[3];
+            bf8 bf[3], bl[3];
 #pragma unroll
             for (int r = 0; r < IH; r++) {
-                bf8 af[3];
+                bf8 af[3], al[3];
 #pragma unroll
                 for (int kx = 0; kx < 3; kx++) {
-                    const unsigned char* ap = xs + (r * IW + 16 * c + kx) * PSB + a_lane;
-                    af[kx] = tr_pair(ap, ap + 4 * PSB);
+                    const int base = r * IW + 16 * c + kx;
+                    const unsigned char* ap = xs + base * RPS + a_lane[base & 3];
+                    af[kx] = tr_pair(ap, ap + 4 * RPS);
+                    if constexpr (X3) al[kx] = tr_pair(ap + X_PLANE, ap + X_PLANE + 4 * RPS);
                 }
                 if (r < TH) {
-                    const unsigned char* bp = ys + (r * TW + 16 * c) * PSB + b_lane;
-                    bf[r % 3] = tr_pair(bp, bp + 4 * PSB);
+                    const unsigned char* bp = ys + (r * TW + 16 * c) * RPS + b_lane;
+                    bf[r % 3] = tr_pair(bp, bp + 4 * RPS);
+                    if constexpr (X3) bl[r % 3] = tr_pair(bp + Y_PLANE, bp + Y_PLANE + 4 * RPS);
                 }
 #pragma unroll
                 for (int ky = 0; ky < 3; ky++) {
                     const int o = r - ky;
                     if (o >= 0 && o < TH) {
 #pragma unroll
-                        for (int kx = 0; kx < 3; kx++)
+                        for (int kx = 0; kx < 3; kx++) {
+                            if constexpr (X3) {
+                                acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[kx], bf[o % 3], acc[ky * 3 + kx], 0, 0, 0);
+                                acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kx], bl[o % 3], acc[ky * 3 + kx], 0, 0, 0);
+                            }
                             acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kx], bf[o % 3], acc[ky * 3 + kx], 0, 0, 0);
+                        }
                     }
                 }
             }
         }
-    };
-
-    int tile = split;
-    if (tile < a.n_tiles) {
-        load_tile(tile);
-        store_tile();
+        __syncthreads();  // (B k)
     }
-    __syncthreads();
-    for (; tile < a.n_tiles; tile += a.splits) {
-        const int next = tile + a.splits;
-        const bool more = next < a.n_tiles;
-        if (more) load_tile(next);
-        mfma_tile();
-        __syncthreads();  // every wave is done with this tile's LDS image
-        if (more) store_tile();
-        __syncthreads();
-    }
+    __syncthreads();  // (C)
     // ---- slab: D[row = ci][col = co]; col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5) ---------------------------------
     const int r = lane & 31, h = lane >> 5;
-    const long cip = (long)a.ci_t * CT, cop = (long)a.co_t * CT;
 #pragma unroll
     for (int i = 0; i < 9; i++) {
         const int wt = d.tap_w[i];  // (taps are listed ky-major, kx-minor: checked by the plan)
@@ -675,55 +777,91 @@ __global__ __launch_bounds__(kThreads, 1) void conv_wgrad_rs3_kernel(const liso_
             }
         }
     }
-    if (want_bias) {
+}
+
+// dw (torch layout) = sum over splits of the slabs, in a fixed order.  PARTS = 16: block = one (tap, k) row x 64 output channels;
+// thread = 4 consecutive channels (one 16-B load per split) x one of 16 split groups (group g adds splits g, g + 16, ... in that
+// order, four loads in flight), then the 16 group sums are added pairwise in a fixed tree.  PARTS = 1 (<= 16 splits): block = 16
+// rows x 64 channels, every thread walks all splits of its 4 channels (all loads in flight), no tree.  The slabs were written a
+// moment ago and sit in L2 / the Infinity Cache; what the reduction needs is bytes in flight (the former version: one 4-B load at a
+// time per thread, 2 TB/s on 37 MB of slabs).
+template <int PARTS>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bias_slab,
+                                                           int splits, int bias_rows, int taps, int ci, int co, long cip, long cop,
+                                                           int transposed, float* __restrict__ dw, float* __restrict__ dbias) {
+    constexpr int RPB = 16 / PARTS;  // rows per block
+    __shared__ float4 red[16][16];
+    const int c4 = threadIdx.x & 15, part = PARTS == 16 ? threadIdx.x >> 4 : 0, rib = PARTS == 16 ? 0 : threadIdx.x >> 4;
+    const int n_tiles = (co + 63) / 64;
+    const long rows = (long)taps * ci;
+    const long row_blocks = (rows + RPB - 1) / RPB;
+    const long bid = blockIdx.x;
+    const bool is_bias = bid >= row_blocks * n_tiles;
+    if (is_bias && !dbias) return;
+    const int ntile = (int)(is_bias ? bid - row_blocks * n_tiles : bid % n_tiles);
+    const long row = is_bias ? 0 : (bid / n_tiles) * RPB + rib;  // tap * ci + k
+    const bool row_ok = is_bias ? rib == 0 : row < rows;
+    const int k = (int)(row % ci), tap = (int)(row / ci);
+    const int n = ntile * 64 + c4 * 4;
+    const int count = is_bias ? bias_rows : splits;
+    const float* src = is_bias ? bias_slab + n : slab + ((long)tap * cip + k) * cop + n;
+    const long stride = is_bias ? cop : (long)taps * cip * cop;
+    float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (n < co && row_ok) {
+        int sp = part;
+        for (; sp + 3 * PARTS < count; sp += 4 * PARTS) {  // four loads in flight per thread
+            const float4 v0 = *reinterpret_cast<const float4*>(src + (long)sp * stride);
+            const float4 v1 = *reinterpret_cast<const float4*>(src + (long)(sp + PARTS) * stride);
+            const float4 v2 = *reinterpret_cast<const float4*>(src + (long)(sp + 2 * PARTS) * stride);
+            const float4 v3 = *reinterpret_cast<const float4*>(src + (long)(sp + 3 * PARTS) * stride);
+            s.x = (((s.x + v0.x) + v1.x) + v2.x) + v3.x;
+            s.y = (((s.y + v0.y) + v1.y) + v2.y) + v3.y;
+            s.z = (((s.z + v0.z) + v1.z) + v2.z) + v3.z;
+            s.w = (((s.w + v0.w) + v1.w) + v2.w) + v3.w;
+        }
+        for (; sp < count; sp += PARTS) {
+            const float4 v = *reinterpret_cast<const float4*>(src + (long)sp * stride);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    }
+    if constexpr (PARTS == 16) {
+        red[part][c4] = s;
         __syncthreads();
-        float* red = reinterpret_cast<float*>(smem);
 #pragma unroll
-        for (int e = 0; e < 8; e++) red[tid * 8 + e] = bsum[e];
-        __syncthreads();
-        if (tid < CT) {
-            const int grp_c = tid / 8, e = tid % 8;
-            float s = 0.0f;
-            for (int pp = 0; pp < kThreads / 8; pp++) s += red[(pp * 8 + grp_c) * 8 + e];
-            a.bias_slab[(long)split * cop + co0 + tid] = s;
+        for (int w = 8; w >= 1; w >>= 1) {  // fixed pairing: (p, p + w)
+            if (part < w) {
+                const float4 o = red[part + w][c4];
+                s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+                red[part][c4] = s;
+            }
+            __syncthreads();
+        }
+    }
+    if (part == 0 && n < co && row_ok) {
+        const float v[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            if (n + e >= co) break;
+            if (is_bias)
+                dbias[n + e] = v[e];
+            else
+                dw[transposed ? (((long)k * co + n + e) * taps + tap) : (((long)(n + e) * ci + k) * taps + tap)] = v[e];
         }
     }
 }
 
-// dw (torch layout) = sum over splits of the slabs (fixed order: 4 interleaved partial sums per output, then a tree)
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bias_slab,
-                                                           int splits, int bias_rows, int taps, int ci, int co, long cip, long cop,
-                                                           int transposed, float* __restrict__ dw, float* __restrict__ dbias) {
-    __shared__ float red[4][64];
-    const int nl = threadIdx.x & 63, part = threadIdx.x >> 6;
-    const int n_tiles = (co + 63) / 64;
+int launch_reduce(const float* slab, const float* bias_slab, int splits, int bias_rows, int taps, int ci, int co_w, long cip, long cop,
+                  int transposed, float* dw, float* dbias, hipStream_t st) {
     const long rows = (long)taps * ci;
-    const long bid = blockIdx.x;
-    if (bid < rows * n_tiles) {
-        const int ntile = (int)(bid % n_tiles);
-        const long row = bid / n_tiles;  // tap * ci + k
-        const int k = (int)(row % ci), tap = (int)(row / ci);
-        const int n = ntile * 64 + nl;
-        float s = 0.0f;
-        if (n < co)
-            for (int sp = part; sp < splits; sp += 4) s += slab[(((long)sp * taps + tap) * cip + k) * cop + n];
-        red[part][nl] = s;
-        __syncthreads();
-        if (part == 0 && n < co) {
-            const float v = (red[0][nl] + red[1][nl]) + (red[2][nl] + red[3][nl]);
-            const long o = transposed ? (((long)k * co + n) * taps + tap) : (((long)n * ci + k) * taps + tap);
-            dw[o] = v;
-        }
-    } else if (dbias) {  // trailing blocks: the bias gradient
-        const int ntile = (int)(bid - rows * n_tiles);
-        const int n = ntile * 64 + nl;
-        float s = 0.0f;
-        if (n < co)
-            for (int sp = part; sp < bias_rows; sp += 4) s += bias_slab[(long)sp * cop + n];
-        red[part][nl] = s;
-        __syncthreads();
-        if (part == 0 && n < co) dbias[n] = (red[0][nl] + red[1][nl]) + (red[2][nl] + red[3][nl]);
+    const int n_tiles = (co_w + 63) / 64;
+    if (splits > 16) {
+        const long blocks = (rows + (dbias ? 1 : 0)) * n_tiles;
+        wgrad_reduce_kernel<16><<<(int)blocks, 256, 0, st>>>(slab, bias_slab, splits, bias_rows, taps, ci, co_w, cip, cop, transposed, dw, dbias);
+    } else {
+        const long blocks = ((rows + 15) / 16 + (dbias ? 1 : 0)) * n_tiles;
+        wgrad_reduce_kernel<1><<<(int)blocks, 256, 0, st>>>(slab, bias_slab, splits, bias_rows, taps, ci, co_w, cip, cop, transposed, dw, dbias);
     }
+    return hipGetLastError() == hipSuccess ? LISO_OK : LISO_ELAUNCH;
 }
 
 int round_up(int v, int m) { return (v + m - 1) / m * m; }
@@ -901,10 +1039,12 @@ struct Rs3Plan {
 bool make_rs3_plan(const liso_conv_desc& d, Rs3Plan* p) {
     if (const char* e = getenv("LISO_WGRAD_RS3"))  // experiments / A-B runs: 0 = the generic kernel everywhere
         if (atoi(e) == 0) return false;
-    if (d.mode != LISO_CONV_BF16 || d.n_classes != 1 || d.n_taps != 9 || d.w_taps != 9) return false;
+    if ((d.mode != LISO_CONV_BF16 && d.mode != LISO_CONV_F32X3) || d.n_classes != 1 || d.n_taps != 9 || d.w_taps != 9) return false;
+    const bool x3 = d.mode == LISO_CONV_F32X3;
+    const int vec = x3 ? 4 : 8;
     if (d.isy != 1 || d.isx != 1 || d.osy != 1 || d.osx != 1 || d.in_affine_batch_stride != 0) return false;
     if (d.hv != d.ho || d.wv != d.wo || d.hi != d.ho || d.wi != d.wo || d.batch <= 0) return false;
-    if (d.ci % 8 || d.co % 8 || d.x_pix_stride % 8 || d.class_tap_begin[0] != 0 || d.class_tap_begin[1] != 9) return false;
+    if (d.ci % vec || d.co % vec || d.x_pix_stride % vec || d.class_tap_begin[0] != 0 || d.class_tap_begin[1] != 9) return false;
     for (int t = 0; t < 9; t++)
         if (d.tap_dy[t] != t / 3 - 1 || d.tap_dx[t] != t % 3 - 1 || d.tap_w[t] < 0 || d.tap_w[t] >= 9) return false;
     WgArgs& a = p->a;
@@ -918,6 +1058,7 @@ bool make_rs3_plan(const liso_conv_desc& d, Rs3Plan* p) {
     const long tiles8 = (long)d.batch * ((d.ho + 7) / 8) * a.tiles_x;
     int th = tiles8 >= 4 * want ? 8 : 4;
     if (const char* e = getenv("LISO_WGRAD_TH")) th = atoi(e) == 8 ? 8 : atoi(e) == 4 ? 4 : th;  // experiments
+    if (x3) th = 3;  // (two planes per operand: two buffers of a 3-row tile fit the LDS)
     a.th = th;
     a.tiles_y = (d.ho + th - 1) / th;
     a.n_tiles = d.batch * a.tiles_y * a.tiles_x;
@@ -928,21 +1069,21 @@ bool make_rs3_plan(const liso_conv_desc& d, Rs3Plan* p) {
     a.n_groups = 1;
     p->th = th;
     p->blocks = (int)(cc * s);
-    p->lds = ((th + 2) * (TW + 2) * PSB + 15) / 16 * 16 + th * TW * PSB;
+    p->lds = 2 * (x3 ? 2 : 1) * ((th + 2) * (TW + 2) + th * TW) * RPS;  // two tile buffers (of two planes each for F32X3)
     p->slab_bytes = (size_t)s * 9 * a.ci_t * CT * a.co_t * CT * sizeof(float);
     p->bias_bytes = (size_t)s * a.co_t * CT * sizeof(float);
     return true;
 }
 
-template <int TH>
+template <int MODE, int TH>
 int launch_rs3(const liso_conv_desc& d, const Rs3Plan& p, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)conv_wgrad_rs3_kernel<TH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)conv_wgrad_rs3_kernel<MODE, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return LISO_ELAUNCH;
         attr_set = true;
     }
-    conv_wgrad_rs3_kernel<TH><<<p.blocks, kThreads, p.lds, st>>>(d, p.a);
+    conv_wgrad_rs3_kernel<MODE, TH><<<p.blocks, kRsThreads, p.lds, st>>>(d, p.a);
     return hipGetLastError() == hipSuccess ? LISO_OK : LISO_ELAUNCH;
 }
 
@@ -978,13 +1119,13 @@ int liso_conv_wgrad(const liso_conv_desc* d, const void* x, const float* in_scal
         r3.a.slab = (float*)workspace;
         r3.a.bias_slab = dbias ? (float*)((char*)workspace + r3.slab_bytes) : nullptr;
         hipStream_t st3 = (hipStream_t)stream;
-        const int rc3 = r3.th == 8 ? launch_rs3<8>(*d, r3, st3) : launch_rs3<4>(*d, r3, st3);
+        const int rc3 = d->mode == LISO_CONV_F32X3 ? launch_rs3<LISO_CONV_F32X3, 3>(*d, r3, st3)
+                        : r3.th == 8           ? launch_rs3<LISO_CONV_BF16, 8>(*d, r3, st3)
+                                               : launch_rs3<LISO_CONV_BF16, 4>(*d, r3, st3);
         if (rc3 != LISO_OK) return rc3;
         const int co_w3 = d->wgrad_co > 0 ? d->wgrad_co : d->co;
-        const long rblocks3 = ((long)d->w_taps * d->ci + (dbias ? 1 : 0)) * ((co_w3 + 63) / 64);
-        wgrad_reduce_kernel<<<(int)rblocks3, 256, 0, st3>>>(r3.a.slab, r3.a.bias_slab, r3.a.splits, r3.a.splits, d->w_taps, d->ci, co_w3,
-                                                           (long)r3.a.ci_t * CT, (long)r3.a.co_t * CT, transposed, dw, dbias);
-        return hipGetLastError() == hipSuccess ? LISO_OK : LISO_ELAUNCH;
+        return launch_reduce(r3.a.slab, r3.a.bias_slab, r3.a.splits, r3.a.splits, d->w_taps, d->ci, co_w3, (long)r3.a.ci_t * CT,
+                             (long)r3.a.co_t * CT, transposed, dw, dbias, st3);
     }
     WgPlan p;
     if (!make_plan(*d, &p)) return LISO_EINVAL;
@@ -1008,10 +1149,8 @@ int liso_conv_wgrad(const liso_conv_desc* d, const void* x, const float* in_scal
     if (rc != LISO_OK) return rc;
     if (d->wgrad_co < 0 || d->wgrad_co > d->co) return LISO_EINVAL;
     const int co_w = d->wgrad_co > 0 ? d->wgrad_co : d->co;  // channels written (dy may carry zero-padded channels beyond)
-    const long rblocks = ((long)d->w_taps * d->ci + (dbias ? 1 : 0)) * ((co_w + 63) / 64);
-    wgrad_reduce_kernel<<<(int)rblocks, 256, 0, st>>>(p.a.slab, p.a.bias_slab, p.splits, p.splits * d->n_classes, d->w_taps, d->ci, co_w,
-                                                                    (long)p.a.ci_t * CT, (long)p.a.co_t * CT, transposed, dw, dbias);
-    return hipGetLastError() == hipSuccess ? LISO_OK : LISO_ELAUNCH;
+    return launch_reduce(p.a.slab, p.a.bias_slab, p.splits, p.splits * d->n_classes, d->w_taps, d->ci, co_w, (long)p.a.ci_t * CT,
+                         (long)p.a.co_t * CT, transposed, dw, dbias, st);
 }
 
 }  // extern "C"
