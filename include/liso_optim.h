@@ -32,6 +32,12 @@ extern "C" {
 int liso_adamw_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr, double beta1,
                         double beta2, double eps, double weight_decay, long step, void* stream);
 
+/* The same update on grad * grad_scale: data-parallel training all-reduces the flat gradient buffer with SUM and passes
+ * grad_scale = 1 / world_size here instead of launching a division over the buffer (the reference is single-GPU; the gradient mean
+ * over ranks is this build's addition).  grad_scale = 1 is bit-identical to liso_adamw_step_f32. */
+int liso_adamw_step_scaled_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr, double beta1,
+                               double beta2, double eps, double weight_decay, double grad_scale, long step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -955,10 +955,12 @@ bool make_plan_impl(const liso_conv_desc& d, WgPlan* p, bool compact) {
     split_cap = split_cap < 1 ? 1 : (split_cap > by_tiles ? by_tiles : split_cap);
     long target = 512;  // ~2 blocks per CU
     if (const char* e = getenv("LISO_WGRAD_BLOCKS")) target = atol(e) > 0 ? atol(e) : target;  // experiments
-    const int tg_opts[3] = {9, 3, 1};
+    // 7 x 7 kernels (the SLIM encoders' stem, the motion encoder's flow / class convolutions): one kernel ROW of 7 taps per block
+    const bool rows7 = max_cls_taps == 49 && d.n_classes == 1;
+    const int tg_opts[3] = {rows7 ? 7 : 9, rows7 ? 1 : 3, 1};
     long best_blocks = -1;
     p->tg = 1;
-    for (int k = ((x3 || compact) ? 1 : 0); k < 3; k++) {  // (compact tiles hold one kernel row: no 9-tap groups)
+    for (int k = ((!rows7 && (x3 || compact)) ? 1 : 0); k < 3; k++) {  // (compact tiles hold one kernel row: no 9-tap groups)
         const int tg = tg_opts[k];
         if (tg > 1 && max_cls_taps == 1) continue;
         const long per_split = cc * groups(tg);
@@ -976,7 +978,7 @@ bool make_plan_impl(const liso_conv_desc& d, WgPlan* p, bool compact) {
     }
     if (const char* e = getenv("LISO_WGRAD_TG")) {  // experiments: force the tap group (9 / 3 / 1)
         const int v = atoi(e);
-        if ((v == 9 && !x3 && !compact) || v == 3 || v == 1) p->tg = v;
+        if ((v == 9 && !x3 && !compact && !rows7) || (v == 3 && !rows7) || v == 1 || (v == 7 && rows7)) p->tg = v;
     }
     {
         const int xb = p->tg >= 9 ? 4 : 8;
@@ -1140,12 +1142,16 @@ int liso_conv_wgrad(const liso_conv_desc* d, const void* x, const float* in_scal
     hipStream_t st = (hipStream_t)stream;
     int rc;
     if (d->mode == LISO_CONV_F32)
-        rc = p.tg == 3 ? launch<LISO_CONV_F32, 3>(*d, p, st) : launch<LISO_CONV_F32, 1>(*d, p, st);
+        rc = p.tg == 7 ? launch<LISO_CONV_F32, 7>(*d, p, st) : p.tg == 3 ? launch<LISO_CONV_F32, 3>(*d, p, st) : launch<LISO_CONV_F32, 1>(*d, p, st);
     else if (d->mode == LISO_CONV_F32X3)
-        rc = p.tg == 3 ? launch<LISO_CONV_F32X3, 3>(*d, p, st) : launch<LISO_CONV_F32X3, 1>(*d, p, st);
+        rc = p.tg == 7   ? launch<LISO_CONV_F32X3, 7>(*d, p, st)
+             : p.tg == 3 ? launch<LISO_CONV_F32X3, 3>(*d, p, st)
+                         : launch<LISO_CONV_F32X3, 1>(*d, p, st);
     else
-        rc = p.tg == 9 ? launch<LISO_CONV_BF16, 9>(*d, p, st) : p.tg == 3 ? launch<LISO_CONV_BF16, 3>(*d, p, st)
-                                                                         : launch<LISO_CONV_BF16, 1>(*d, p, st);
+        rc = p.tg == 9   ? launch<LISO_CONV_BF16, 9>(*d, p, st)
+             : p.tg == 7 ? launch<LISO_CONV_BF16, 7>(*d, p, st)
+             : p.tg == 3 ? launch<LISO_CONV_BF16, 3>(*d, p, st)
+                         : launch<LISO_CONV_BF16, 1>(*d, p, st);
     if (rc != LISO_OK) return rc;
     if (d->wgrad_co < 0 || d->wgrad_co > d->co) return LISO_EINVAL;
     const int co_w = d->wgrad_co > 0 ? d->wgrad_co : d->co;  // channels written (dy may carry zero-padded channels beyond)

@@ -20,9 +20,11 @@ struct AdamwScalars {
     float bc2_sqrt;   // sqrt(1 - beta2^step)
     float eps;
     float step_size;  // lr / (1 - beta1^step)
+    float gscale;     // factor on the gradient (1 / world size behind a SUM all-reduce; 1 = none, bit-identical to no factor)
 };
 
 __device__ __forceinline__ void adamw_one(float& p, float g, float& m, float& v, const AdamwScalars& s) {
+    g = g * s.gscale;
     p = p * s.decay;
     m = fmaf(s.w1, g - m, m);
     v = fmaf(s.w2, g * g, v * s.beta2);
@@ -54,8 +56,18 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, 
 
 }  // namespace
 
+extern "C" int liso_adamw_step_scaled_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr,
+                                          double beta1, double beta2, double eps, double weight_decay, double grad_scale, long step,
+                                          void* stream);
+
 extern "C" int liso_adamw_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr,
                                    double beta1, double beta2, double eps, double weight_decay, long step, void* stream) {
+    return liso_adamw_step_scaled_f32(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, 1.0, step, stream);
+}
+
+extern "C" int liso_adamw_step_scaled_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr,
+                                          double beta1, double beta2, double eps, double weight_decay, double grad_scale, long step,
+                                          void* stream) {
     if (n == 0) return LISO_OK;
     if (!param || !grad || !exp_avg || !exp_avg_sq || step < 1) return LISO_EINVAL;
     if ((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) != 0) return LISO_EINVAL;
@@ -67,6 +79,7 @@ extern "C" int liso_adamw_step_f32(float* param, const float* grad, float* exp_a
     s.bc2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)step));
     s.eps = (float)eps;
     s.step_size = (float)(lr / (1.0 - pow(beta1, (double)step)));
+    s.gscale = (float)grad_scale;
     const size_t n4 = n / 4;
     size_t blocks = (n4 + 255) / 256;
     if (blocks > 2048) blocks = 2048;  // 256 CUs x 8 blocks: the rest is the grid-stride loop

@@ -59,9 +59,57 @@ def get_slim_optimizer_scheduler(slim_cfg, params):
     return opt, sched
 
 
+_EXTERNAL_EVENTS = {}
+
+
+def external_graph_events_work(device):
+    """Can a hipGraph replay signal an EXTERNAL event from the middle of the graph (torch.cuda.Event(external=True) recorded during
+    capture) that another stream waits for?  Probed once per process with a two-kernel graph; any failure -> False (the trainers
+    then reduce their gradients in one piece behind the replay)."""
+    key = str(device)
+    if key in _EXTERNAL_EVENTS:
+        return _EXTERNAL_EVENTS[key]
+    ok = False
+    try:
+        a = torch.zeros(1 << 20, device=device)
+        out = torch.zeros_like(a)
+        ev = torch.cuda.Event(external=True)
+        cap, side = torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)
+        cap.wait_stream(torch.cuda.current_stream(device))
+
+        def body():
+            a.fill_(3.0)
+            ev.record(torch.cuda.current_stream(device))
+            a.add_(0.0)
+
+        with torch.cuda.stream(cap):
+            body()
+        torch.cuda.synchronize(device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=cap):
+            body()
+        a.zero_()
+        torch.cuda.synchronize(device)
+        g.replay()
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            out.copy_(a)
+        torch.cuda.synchronize(device)
+        ok = bool((out == 3.0).all())
+    except Exception:  # noqa: BLE001 -- a runtime that refuses the capture
+        ok = False
+    _EXTERNAL_EVENTS[key] = ok
+    return ok
+
+
 class DetectorTrainer:
-    def __init__(self, cfg, device, compute_dtype=torch.float32, total_steps=None, fused_loss=None, use_graph=False, exact=None):
-        """`exact` (with compute_dtype float32): True = fp32 convolutions on the native fp32 MFMA (2^-24 per product, the reference's
+    def __init__(self, cfg, device, compute_dtype=torch.float32, total_steps=None, fused_loss=None, use_graph=False, exact=None,
+                 grad_buckets=None):
+        """`grad_buckets` (graph path, several ranks): 2 = the flat gradient buffer is reduced in two parts -- everything behind the
+        backbone's first block as soon as the replayed backward pass has produced it (an external event recorded inside the graph),
+        overlapping the rest of backward; 1 = one all-reduce behind the replay; None = 2 when the runtime signals external events from
+        graph replays (probed once), else 1.
+        `exact` (with compute_dtype float32): True = fp32 convolutions on the native fp32 MFMA (2^-24 per product, the reference's
         fp32 semantics; the parity configuration), False = as bf16 hi/lo pairs (F32X3, 2^-16 per product), None = leave the
         process-wide setting (liso_amd.utils.mfma_conv.set_fp32_mode) as it is.
         `fused_loss`: activations + decode + CenterPoint loss in one HIP pass (include/liso_detector.h) instead of
@@ -104,13 +152,56 @@ class DetectorTrainer:
             self.model = torch.nn.parallel.DistributedDataParallel(
                 self.net, device_ids=[device.index] if device.type == "cuda" else None, bucket_cap_mb=64,
                 broadcast_buffers=False, gradient_as_bucket_view=device.type != "cuda")
+        self.n_grad_buckets = 1
         if self.use_graph:
-            self._flat_grad = self.optimizer.flat_grad  # data parallelism: ONE all-reduce of this buffer after the replay
+            self._flat_grad = self.optimizer.flat_grad  # data parallelism: SUM all-reduce of this buffer, 1 / world inside the AdamW launch
             if self.world > 1:  # replicas start identical (what the DDP constructor would do)
                 for t in list(self.net.parameters()) + list(self.net.buffers()):
                     dist.broadcast(t.data, src=0)
+                self.optimizer.grad_scale = 1.0 / self.world
+                self._setup_gradient_buckets(grad_buckets)
         from liso_amd.networks.centerpoint.fused_bn import defer_batch_counters
         self._bn_counters = defer_batch_counters(self.net.model.rpn) + defer_batch_counters(self.net.model.center_head)
+
+    def _setup_gradient_buckets(self, grad_buckets):
+        """two gradient buckets: [pillar encoder | backbone block 0] and [everything else] -- the second one is complete when the
+        backward pass arrives at the output of block 0 (rpn.py: grad_marker), with block 0's backward (the layers at the largest
+        resolution) and the pillar encoder's still to come"""
+        rpn = self.net.model.rpn
+        if grad_buckets is None:
+            grad_buckets = 2 if external_graph_events_work(self.device) else 1
+        if grad_buckets < 2 or len(rpn.blocks) < 2 or not hasattr(self.optimizer, "offsets"):
+            return
+        first = next(rpn.blocks[1].parameters())
+        split = self.optimizer.offsets[id(first)]
+        # (the flat buffer follows net.parameters(): pillar encoder, blocks 0.., deblocks, head)
+        order = [id(p_) for p_ in self.net.parameters() if p_.requires_grad]
+        assert all(self.optimizer.offsets[i] < split for i in order[:order.index(id(first))])
+        self._bucket_split = int(split)
+        self._bucket_event = torch.cuda.Event(external=True)
+        self._comm_stream = torch.cuda.Stream(device=self.device)
+        rpn.grad_marker = lambda: self._bucket_event.record(torch.cuda.current_stream(self.device))
+        self.n_grad_buckets = 2
+
+    def _reduce_gradients(self, after_replay):
+        """SUM all-reduce of the flat gradient buffer over the ranks (the mean's 1 / world is applied inside the AdamW launch).
+        `after_replay()` = the rest of the step's backward work that is not in the graph (the pillar encoder's)."""
+        if self.n_grad_buckets < 2:
+            after_replay()
+            dist.all_reduce(self._flat_grad)
+            return
+        cur = torch.cuda.current_stream(self.device)
+        comm = self._comm_stream
+        comm.wait_event(self._bucket_event)  # signalled from INSIDE the replay, behind the backward pass of everything but block 0
+        with torch.cuda.stream(comm):
+            late = self._flat_grad[self._bucket_split:]
+            late.record_stream(comm)
+            w1 = dist.all_reduce(late, async_op=True)
+        after_replay()
+        w2 = dist.all_reduce(self._flat_grad[:self._bucket_split], async_op=True)
+        w1.wait()  # (the caller's stream waits for both collectives)
+        w2.wait()
+        cur.wait_stream(comm)
 
     def loss(self, pcls, targets, canvas=None):
         """liso_cli.py:452-614.  `canvas`: precomputed pillar canvas (bev, occupancy) -- the hipGraph path"""
@@ -266,11 +357,15 @@ class DetectorTrainer:
                 for k, v in targets.items():
                     self._static_targets[k].copy_(v, non_blocking=True)
         self._graph.replay()
-        if bev.requires_grad:  # the pillar encoder's own parameters: its backward runs eagerly on the replayed d loss / d canvas
-            bev.backward(self._static_bev.grad)
+
+        def pillar_backward():
+            if bev.requires_grad:  # the pillar encoder's own parameters: its backward runs eagerly on the replayed d loss / d canvas
+                bev.backward(self._static_bev.grad)
+
         if self.world > 1:
-            dist.all_reduce(self._flat_grad)
-            self._flat_grad.div_(self.world)
+            self._reduce_gradients(pillar_backward)
+        else:
+            pillar_backward()
         self.optimizer.step()
         self.lr_scheduler.step()
         return self._static_loss.clone()

@@ -35,6 +35,8 @@ class FlatAdamW(torch.optim.Optimizer):
         self.flat_exp_avg = torch.zeros(off, dtype=torch.float32, device=dev)
         self.flat_exp_avg_sq = torch.zeros(off, dtype=torch.float32, device=dev)
         self._step = 0
+        self.grad_scale = 1.0  # factor on the gradients inside the update (data parallelism: 1 / world size behind a SUM all-reduce)
+        self.offsets = {id(p): o for p, o in zip(params, offs)}  # first element of every parameter inside the flat buffers
         for p, o in zip(params, offs):
             if not _dense(p.data):
                 p.data = p.data.contiguous()
@@ -59,10 +61,10 @@ class FlatAdamW(torch.optim.Optimizer):
         g = self.param_groups[0]
         self._step += 1
         with torch.cuda.device(self.flat_param.device):
-            L.check(L.TIMER.launch("adamw_flat", lambda: L.lib().liso_adamw_step_f32(
+            L.check(L.TIMER.launch("adamw_flat", lambda: L.lib().liso_adamw_step_scaled_f32(
                 L.ptr(self.flat_param), L.ptr(self.flat_grad), L.ptr(self.flat_exp_avg), L.ptr(self.flat_exp_avg_sq), self.numel,
-                float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), self._step,
-                L.stream_ptr()), units=28 * self.numel), "adamw_step")
+                float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
+                float(self.grad_scale), self._step, L.stream_ptr()), units=28 * self.numel), "adamw_step")
         # the kernel wrote through a raw pointer: tell autograd / the packed-weight cache that every parameter changed
         torch.autograd.graph.increment_version(g["params"])
 

@@ -408,8 +408,6 @@ def conv_wgrad(x, dy, weight_shape, spec, in_scale=None, in_shift=None, in_relu=
     """-> (dw fp32 in torch's layout `weight_shape`, dbias fp32 [Co] | None); None if the geometry is not supported by the
     kernel (caller falls back to ATen's weight gradient).  `out_dw` / `out_db`: dense fp32 tensors to write into (overwritten)."""
     L.require_cuda(x, dy)
-    if spec.kh * spec.kw > 9:
-        return None  # 7x7 kernels: 49 taps re-stage the same large halo tile per tap group; ATen's kernel is faster (3 layers)
     mode = _mode(x.dtype)
     if dy.dtype != x.dtype:
         dy = dy.to(x.dtype)
@@ -805,6 +803,27 @@ def materialize(x_raw, fold):
     if fold is None:
         return x_raw
     return _Materialize.apply(x_raw, fold, *fold.params())
+
+
+class _GradMarker(torch.autograd.Function):
+    """identity whose backward calls `hook()` first: by then every backward node created AFTER this point of the forward pass has run
+    (autograd executes ready nodes latest-created first), i.e. the gradients of all parameters used downstream are complete.  A
+    data-parallel trainer records an event there and starts the all-reduce of that part of the flat gradient buffer while the rest of
+    the backward pass still runs (liso_amd/trainer.py)."""
+
+    @staticmethod
+    def forward(ctx, x, hook):
+        ctx.hook = hook
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.hook()
+        return g, None
+
+
+def mark_gradient(x, hook):
+    return x if hook is None or not x.requires_grad else _GradMarker.apply(x, hook)
 
 
 def conv2d(layer, x, relu=False):

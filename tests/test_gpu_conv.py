@@ -102,12 +102,10 @@ def test_forward_dgrad_wgrad(geom, arith):
     dx = MC.conv_dgrad(dyd, wd, spec, tuple(x.shape), out_dtype=torch.float32)
     assert _rel(dx, gx) <= tol, _rel(dx, gx)
     res = MC.conv_wgrad(xd, dyd, tuple(w.shape), spec)
-    if res is None:
-        assert k == 7  # 7x7 kernels are routed to ATen's weight gradient (49 taps: the tap-group kernel re-stages too much)
-    else:
-        dw, db = res
-        assert _rel(dw, gw) <= 2 * tol, _rel(dw, gw)
-        assert _rel(db, gb) <= 2 * tol, _rel(db, gb)
+    assert res is not None  # every geometry of the networks runs on the own kernel (7 x 7: one kernel row of taps per block)
+    dw, db = res
+    assert _rel(dw, gw) <= 2 * tol, _rel(dw, gw)
+    assert _rel(db, gb) <= 2 * tol, _rel(db, gb)
 
 
 @pytest.mark.parametrize("arith", ARITH)
