@@ -408,6 +408,11 @@ def conv_wgrad(x, dy, weight_shape, spec, in_scale=None, in_shift=None, in_relu=
     """-> (dw fp32 in torch's layout `weight_shape`, dbias fp32 [Co] | None); None if the geometry is not supported by the
     kernel (caller falls back to ATen's weight gradient).  `out_dw` / `out_db`: dense fp32 tensors to write into (overwritten)."""
     L.require_cuda(x, dy)
+    if spec.kh * spec.kw > 9 and x.shape[1] > 8 and not os.environ.get("LISO_WGRAD_7X7"):
+        # the encoders' 7x7 / 2 stem on the dense pillar canvas (64 input channels): the row-of-taps kernel re-stages the canvas once
+        # per kernel row (measured 1.9 ms vs 0.31 ms for the library's kernel at two sweeps); the motion encoder's 7x7 convolutions
+        # (2-4 input channels) run on the own kernel.  LISO_WGRAD_7X7=1 forces the own kernel (tests, measurements).
+        return None
     mode = _mode(x.dtype)
     if dy.dtype != x.dtype:
         dy = dy.to(x.dtype)

@@ -69,7 +69,7 @@ def _restore_fp32_mode():
 
 @pytest.mark.parametrize("geom", GEOMS)
 @pytest.mark.parametrize("arith", ARITH)
-def test_forward_dgrad_wgrad(geom, arith):
+def test_forward_dgrad_wgrad(geom, arith, monkeypatch):
     from liso_amd.utils import mfma_conv as MC
 
     dtype, fmode = arith
@@ -101,8 +101,9 @@ def test_forward_dgrad_wgrad(geom, arith):
     dyd = dy.to(dtype).cuda().contiguous(memory_format=torch.channels_last)
     dx = MC.conv_dgrad(dyd, wd, spec, tuple(x.shape), out_dtype=torch.float32)
     assert _rel(dx, gx) <= tol, _rel(dx, gx)
+    monkeypatch.setenv("LISO_WGRAD_7X7", "1")  # (the 64-channel 7x7 stem defaults to the library's kernel: measured faster)
     res = MC.conv_wgrad(xd, dyd, tuple(w.shape), spec)
-    assert res is not None  # every geometry of the networks runs on the own kernel (7 x 7: one kernel row of taps per block)
+    assert res is not None  # every geometry of the networks can run on the own kernel (7 x 7: one kernel row of taps per block)
     dw, db = res
     assert _rel(dw, gw) <= 2 * tol, _rel(dw, gw)
     assert _rel(db, gb) <= 2 * tol, _rel(db, gb)
