@@ -115,9 +115,9 @@ class RPN(nn.Module):
             x, fold = MC.fused_conv(x, fold, mods[1], out_bn=mods[2], spec=MC.ConvSpec(3, 3, st, 1))  # ZeroPad2d(1) + conv(pad 0)
             for j in range(4, len(mods), 3):
                 x, fold = MC.fused_conv(x, fold, mods[j], out_bn=mods[j + 1])
-            hook = getattr(self, "grad_marker", None)
-            if hook is not None and i == 0:  # (extension) behind block 0, in front of its two consumers: see mfma_conv.mark_gradient
-                x = MC.mark_gradient(x, hook)
+            cut = getattr(self, "grad_cut", None)
+            if cut is not None and i == 0:  # (extension) behind block 0, in front of its two consumers: see mfma_conv.GradCut
+                x = cut.split(x)
             if i - self._upsample_start_idx >= 0:
                 d = self.deblocks[i - self._upsample_start_idx]
                 ups.append(MC.fused_conv(x, fold, d[0], out_bn=d[1]))

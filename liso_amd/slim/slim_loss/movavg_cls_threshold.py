@@ -23,6 +23,11 @@ class MovingAverageThreshold(nn.Module):
             self.register_buffer("still_counter", torch.tensor(self.num_still, dtype=torch.long))
         self.register_buffer("bias_counter", torch.zeros((), dtype=torch.double))
         self.register_buffer("moving_average_importance", torch.zeros((self.resolution,), dtype=torch.float))
+        # (extension) while this is a list, update() appends its per-rank histogram increment and count instead of reducing and
+        # applying them: a trainer that replays the step from a hipGraph -- which cannot hold a collective -- reduces all increments
+        # of the step in ONE all-reduce behind the replay and applies them in order (apply_deferred).  Within a step the threshold
+        # is read once, before the first update (slim.py), so deferring the updates to the end of the step changes nothing.
+        self._defer = None
 
     def value(self):
         """reference :56-60; the `if bias_counter > 0` branch is a torch.where (no device->host sync)"""
@@ -53,6 +58,19 @@ class MovingAverageThreshold(nn.Module):
         self.bias_counter *= w
         self.bias_counter += 1.0 - w
 
+    def apply_deferred(self, items):
+        """the updates recorded while `_defer` was a list: one SUM all-reduce of all histogram increments / counts over the ranks,
+        then the moving-average updates in the recorded order (= what the immediate path does update by update)"""
+        if not items:
+            return
+        cur = torch.stack([c for c, _ in items])
+        cnt = torch.stack([n for _, n in items])
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(cur)
+            dist.all_reduce(cnt)
+        for k in range(cur.shape[0]):
+            self._update_values(cur[k], cnt[k])
+
     def update(self, epes_stat_flow, epes_dyn_flow, moving_mask, dynamicness_scores, training, valid_mask=None,
                compute_value=True):
         """reference :118-157.  Extensions: `valid_mask` -- rows to ignore (instead of the caller compacting the arrays
@@ -68,6 +86,10 @@ class MovingAverageThreshold(nn.Module):
                 bins = torch.where(valid_mask, bins, 0).clamp(min=0)
                 count = valid_mask.sum()
             cur = torch.zeros((self.resolution,), dtype=imp.dtype, device=imp.device).scatter_add_(0, bins, imp)
+            if self._defer is not None:
+                assert self.num_still is None, "deferred updates: unsupervised mode only (no moving / still counters)"
+                self._defer.append((cur, torch.as_tensor(count, dtype=torch.long, device=imp.device).reshape(())))
+                return self.value() if compute_value else None
             if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
                 # data parallel: every rank applies the histogram increment of the GLOBAL batch (400 KB all-reduce), so
                 # the threshold buffers stay identical on all replicas

@@ -59,56 +59,15 @@ def get_slim_optimizer_scheduler(slim_cfg, params):
     return opt, sched
 
 
-_EXTERNAL_EVENTS = {}
-
-
-def external_graph_events_work(device):
-    """Can a hipGraph replay signal an EXTERNAL event from the middle of the graph (torch.cuda.Event(external=True) recorded during
-    capture) that another stream waits for?  Probed once per process with a two-kernel graph; any failure -> False (the trainers
-    then reduce their gradients in one piece behind the replay)."""
-    key = str(device)
-    if key in _EXTERNAL_EVENTS:
-        return _EXTERNAL_EVENTS[key]
-    ok = False
-    try:
-        a = torch.zeros(1 << 20, device=device)
-        out = torch.zeros_like(a)
-        ev = torch.cuda.Event(external=True)
-        cap, side = torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)
-        cap.wait_stream(torch.cuda.current_stream(device))
-
-        def body():
-            a.fill_(3.0)
-            ev.record(torch.cuda.current_stream(device))
-            a.add_(0.0)
-
-        with torch.cuda.stream(cap):
-            body()
-        torch.cuda.synchronize(device)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=cap):
-            body()
-        a.zero_()
-        torch.cuda.synchronize(device)
-        g.replay()
-        side.wait_event(ev)
-        with torch.cuda.stream(side):
-            out.copy_(a)
-        torch.cuda.synchronize(device)
-        ok = bool((out == 3.0).all())
-    except Exception:  # noqa: BLE001 -- a runtime that refuses the capture
-        ok = False
-    _EXTERNAL_EVENTS[key] = ok
-    return ok
-
-
 class DetectorTrainer:
     def __init__(self, cfg, device, compute_dtype=torch.float32, total_steps=None, fused_loss=None, use_graph=False, exact=None,
                  grad_buckets=None):
-        """`grad_buckets` (graph path, several ranks): 2 = the flat gradient buffer is reduced in two parts -- everything behind the
-        backbone's first block as soon as the replayed backward pass has produced it (an external event recorded inside the graph),
-        overlapping the rest of backward; 1 = one all-reduce behind the replay; None = 2 when the runtime signals external events from
-        graph replays (probed once), else 1.
+        """`grad_buckets` (graph path, several ranks): 2 (default) = the step is captured as TWO graphs, cut behind the backbone's first
+        block (mfma_conv.GradCut): the gradients of everything downstream of the cut -- 97 % of the parameters -- are all-reduced
+        between the two replays and the collective overlaps block 0's backward pass (the layers at the largest resolution), the
+        pillar encoder's backward and the second, small all-reduce; 1 = one graph, one all-reduce behind it.  (ROCm refuses external
+        events inside a captured graph -- "External events are disallowed in rocm" -- so the signal cannot come from inside ONE
+        graph.)  A single rank always runs one graph.
         `exact` (with compute_dtype float32): True = fp32 convolutions on the native fp32 MFMA (2^-24 per product, the reference's
         fp32 semantics; the parity configuration), False = as bf16 hi/lo pairs (F32X3, 2^-16 per product), None = leave the
         process-wide setting (liso_amd.utils.mfma_conv.set_fp32_mode) as it is.
@@ -123,7 +82,7 @@ class DetectorTrainer:
 
         self.cfg, self.device = cfg, device
         self.use_graph = bool(use_graph) and device.type == "cuda"
-        self._graph, self._graph_sig, self._capture_stream = None, None, None
+        self._graph, self._graph2, self._graph_sig, self._capture_stream = None, None, None, None
         self.fused_loss = (fused_centerpoint.supports(cfg) and device.type == "cuda") if fused_loss is None else fused_loss
         self.net = BoxLearner(cfg).to(device)
         self.net.model.set_compute_dtype(compute_dtype)
@@ -160,48 +119,47 @@ class DetectorTrainer:
                     dist.broadcast(t.data, src=0)
                 self.optimizer.grad_scale = 1.0 / self.world
                 self._setup_gradient_buckets(grad_buckets)
+            elif grad_buckets == 2:  # (one rank, asked for explicitly: the two-graph step without a collective -- tests)
+                self._setup_gradient_buckets(2)
         from liso_amd.networks.centerpoint.fused_bn import defer_batch_counters
         self._bn_counters = defer_batch_counters(self.net.model.rpn) + defer_batch_counters(self.net.model.center_head)
 
     def _setup_gradient_buckets(self, grad_buckets):
         """two gradient buckets: [pillar encoder | backbone block 0] and [everything else] -- the second one is complete when the
-        backward pass arrives at the output of block 0 (rpn.py: grad_marker), with block 0's backward (the layers at the largest
+        backward pass arrives at the output of block 0 (rpn.py: grad_cut), with block 0's backward (the layers at the largest
         resolution) and the pillar encoder's still to come"""
+        from liso_amd.utils import mfma_conv as MC
+
         rpn = self.net.model.rpn
         if grad_buckets is None:
-            grad_buckets = 2 if external_graph_events_work(self.device) else 1
-        if grad_buckets < 2 or len(rpn.blocks) < 2 or not hasattr(self.optimizer, "offsets"):
+            grad_buckets = int(os.environ.get("LISO_GRAD_BUCKETS", "2"))
+        if grad_buckets < 2 or len(rpn.blocks) < 2 or not hasattr(self.optimizer, "offsets") or MC.backend() != "mfma":
             return
         first = next(rpn.blocks[1].parameters())
         split = self.optimizer.offsets[id(first)]
         # (the flat buffer follows net.parameters(): pillar encoder, blocks 0.., deblocks, head)
         order = [id(p_) for p_ in self.net.parameters() if p_.requires_grad]
         assert all(self.optimizer.offsets[i] < split for i in order[:order.index(id(first))])
+        assert all(self.optimizer.offsets[i] >= split for i in order[order.index(id(first)):])
         self._bucket_split = int(split)
-        self._bucket_event = torch.cuda.Event(external=True)
-        self._comm_stream = torch.cuda.Stream(device=self.device)
-        rpn.grad_marker = lambda: self._bucket_event.record(torch.cuda.current_stream(self.device))
+        self._grad_cut = MC.GradCut()
         self.n_grad_buckets = 2
 
-    def _reduce_gradients(self, after_replay):
+    def _reduce_gradients(self, rest_of_backward):
         """SUM all-reduce of the flat gradient buffer over the ranks (the mean's 1 / world is applied inside the AdamW launch).
-        `after_replay()` = the rest of the step's backward work that is not in the graph (the pillar encoder's)."""
+        Called behind the replay of the (first) graph; `rest_of_backward()` = what is still to run: the second graph (two buckets)
+        and the pillar encoder's eager backward."""
         if self.n_grad_buckets < 2:
-            after_replay()
+            rest_of_backward()
             dist.all_reduce(self._flat_grad)
             return
-        cur = torch.cuda.current_stream(self.device)
-        comm = self._comm_stream
-        comm.wait_event(self._bucket_event)  # signalled from INSIDE the replay, behind the backward pass of everything but block 0
-        with torch.cuda.stream(comm):
-            late = self._flat_grad[self._bucket_split:]
-            late.record_stream(comm)
-            w1 = dist.all_reduce(late, async_op=True)
-        after_replay()
+        # (the collective runs on the process group's own stream, which waits for the caller's stream as it stands NOW: behind the
+        # first graph; the caller's stream goes on with the rest of the backward pass and waits for both collectives at the end)
+        w1 = dist.all_reduce(self._flat_grad[self._bucket_split:], async_op=True)
+        rest_of_backward()
         w2 = dist.all_reduce(self._flat_grad[:self._bucket_split], async_op=True)
-        w1.wait()  # (the caller's stream waits for both collectives)
+        w1.wait()
         w2.wait()
-        cur.wait_stream(comm)
 
     def loss(self, pcls, targets, canvas=None):
         """liso_cli.py:452-614.  `canvas`: precomputed pillar canvas (bev, occupancy) -- the hipGraph path"""
@@ -298,19 +256,33 @@ class DetectorTrainer:
 
         self._pack_jobs = None
 
-        def body():
-            self._flat_grad.zero_()
-            self._static_bev.grad.zero_()
-            if self._pack_jobs:  # the forward / data-gradient panels of every layer from ONE launch (recorded in the warm-up)
-                MC.set_step_packs(MC.batched_pack(self._pack_jobs))
-            MC.set_direct_grads(True)  # gradients of conv / BatchNorm parameters land in the flat buffer without an add each
+        cut = self._grad_cut if self.n_grad_buckets == 2 else None
+        rpn = self.net.model.rpn
+
+        def body(part=None):
+            """part None: the whole step; 1: forward + loss + backward down to the cut; 2: the backward pass above the cut"""
+            if part in (None, 1):
+                self._flat_grad.zero_()
+                self._static_bev.grad.zero_()
+                if self._pack_jobs:  # the forward / data-gradient panels of every layer from ONE launch (recorded in the warm-up)
+                    self._step_packs = MC.batched_pack(self._pack_jobs)
+            MC.set_step_packs(getattr(self, "_step_packs", None))
+            MC.set_direct_grads(True, keep_touched=part == 2)  # gradients of conv / BatchNorm parameters land in the flat buffer without an add each
             try:
-                total, _, _ = self.loss(None, self._static_targets, canvas=(self._static_bev, self._static_occ))
-                total.backward()
+                if part in (None, 1):
+                    rpn.grad_cut = cut
+                    try:
+                        total, _, _ = self.loss(None, self._static_targets, canvas=(self._static_bev, self._static_occ))
+                    finally:
+                        rpn.grad_cut = None
+                    total.backward()
+                    self._body_loss = total.detach()
+                if cut is not None and part in (None, 2):
+                    cut.finish()
             finally:
                 MC.set_step_packs(None)
-                MC.set_direct_grads(False)
-            return total.detach()
+                MC.set_direct_grads(False, keep_touched=True)
+            return self._body_loss
 
         with torch.cuda.stream(side):  # warm-up off the capture: lazy initialisations, allocator pools
             MC.record_pack_jobs(True)
@@ -322,11 +294,18 @@ class DetectorTrainer:
             for k, v in self.net.state_dict().items():
                 if k in buffers:
                     v.copy_(buffers[k])
-        self._graph = torch.cuda.CUDAGraph()
+        self._graph, self._graph2 = torch.cuda.CUDAGraph(), None
         # capture on the warm-up's stream: the AccumulateGrad nodes of the parameters were created there; a capture on another
         # stream forks into it and the replay computes garbage (measured: loss 63 instead of 1082)
-        with torch.cuda.graph(self._graph, stream=side):
-            self._static_loss = body()
+        if cut is None:
+            with torch.cuda.graph(self._graph, stream=side):
+                self._static_loss = body()
+        else:  # two graphs sharing one memory pool: the second one reads the leaf gradient and the saved tensors of the first
+            with torch.cuda.graph(self._graph, stream=side):
+                self._static_loss = body(1)
+            self._graph2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph2, stream=side, pool=self._graph.pool()):
+                body(2)
         with torch.no_grad():
             for k, v in self.net.state_dict().items():
                 if k in buffers:
@@ -358,14 +337,16 @@ class DetectorTrainer:
                     self._static_targets[k].copy_(v, non_blocking=True)
         self._graph.replay()
 
-        def pillar_backward():
+        def rest_of_backward():
+            if self._graph2 is not None:  # (two gradient buckets: the backward pass above the cut)
+                self._graph2.replay()
             if bev.requires_grad:  # the pillar encoder's own parameters: its backward runs eagerly on the replayed d loss / d canvas
                 bev.backward(self._static_bev.grad)
 
         if self.world > 1:
-            self._reduce_gradients(pillar_backward)
+            self._reduce_gradients(rest_of_backward)
         else:
-            pillar_backward()
+            rest_of_backward()
         self.optimizer.step()
         self.lr_scheduler.step()
         return self._static_loss.clone()
@@ -472,8 +453,7 @@ class SlimTrainer:
         """`update=False` (with `eager=True`): forward + loss + backward only -- no collective, no optimizer / scheduler step
         (bench.py times individual kernels this way after a graph-replayed region; every rank may call it independently)."""
         self.model.train()
-        if self.use_graph and not eager and not (self.world > 1 and self.slim_cfg.model.use_static_aggr_flow_for_aggr_flow):
-            # (with several ranks the dynamicness-threshold update all-reduces inside the loss: keep that step eager)
+        if self.use_graph and not eager:
             return self._graph_step(sample_t0, sample_t1)
         total, _, _ = self.loss(sample_t0, sample_t1)
         if self.use_graph:
@@ -562,17 +542,26 @@ class SlimTrainer:
 
         self._pack_jobs = None
 
+        # several ranks + the dynamicness threshold learned from the loss (static aggregation): its updates all-reduce a histogram
+        # increment each -- a collective cannot sit inside the graph -- so the captured step only RECORDS the per-rank increments and
+        # `_graph_step` reduces and applies them behind the replay (movavg_cls_threshold.py: apply_deferred)
+        thr = self.net.moving_dynamicness_threshold
+        defer = self.world > 1 and bool(self.slim_cfg.model.use_static_aggr_flow_for_aggr_flow)
+        self._thr_items = None
+
         def body():
             self._flat_grad.zero_()
             for i in (0, 2):
                 self._static_canv[i].grad.zero_()
             if self._pack_jobs:  # every layer's forward / data-gradient panels from ONE launch (recorded in the warm-up)
                 MC.set_step_packs(MC.batched_pack(self._pack_jobs))
+            thr._defer = [] if defer else None
             try:
                 total, _, _ = self.loss(s0, s1, all_valid, canvases=self._static_canv, gather_plan=self._static_plan)
                 total.backward()
             finally:
                 MC.set_step_packs(None)
+                self._thr_items, thr._defer = thr._defer, None
             return total.detach()
 
         with torch.cuda.stream(side):  # warm-up off the capture: MIOpen / rocBLAS pick their kernels, caches fill
@@ -630,6 +619,9 @@ class SlimTrainer:
                     getattr(self._static_plan, name).copy_(getattr(fresh, name), non_blocking=True)
                 self._static_plan.lin64.copy_(fresh.lin, non_blocking=True)
         self._graph.replay()
+        if self._thr_items:  # (several ranks: the threshold updates the captured step recorded, reduced over the ranks and applied)
+            with torch.no_grad():
+                self.net.moving_dynamicness_threshold.apply_deferred(self._thr_items)
         live = [(canv[i], self._static_canv[i].grad) for i in (0, 2) if canv[i].requires_grad]
         if live:
             torch.autograd.backward([c for c, _ in live], [g for _, g in live])

@@ -527,7 +527,7 @@ _DIRECT_GRADS = False
 _DIRECT_TOUCHED = set()  # parameters written in place during the current step: a second contribution goes through autograd's add
 
 
-def set_direct_grads(on):
+def set_direct_grads(on, keep_touched=False):
     """While on, the backward of `_FusedConv` writes the gradients of leaf parameters that already own a dense fp32 `.grad` buffer
     (a trainer's flat gradient views, zeroed at the start of the step) straight into that buffer -- the weight-gradient reduction,
     the bias reduction and the BatchNorm backward take it as their output pointer -- and reports None to autograd: no AccumulateGrad
@@ -535,7 +535,8 @@ def set_direct_grads(on):
     further one to the same parameter is returned to autograd and added."""
     global _DIRECT_GRADS
     _DIRECT_GRADS = bool(on)
-    _DIRECT_TOUCHED.clear()
+    if not keep_touched:  # (`keep_touched`: the second half of a backward pass that was split in two, see GradCut)
+        _DIRECT_TOUCHED.clear()
 
 
 def _direct_target(p):
@@ -810,25 +811,26 @@ def materialize(x_raw, fold):
     return _Materialize.apply(x_raw, fold, *fold.params())
 
 
-class _GradMarker(torch.autograd.Function):
-    """identity whose backward calls `hook()` first: by then every backward node created AFTER this point of the forward pass has run
-    (autograd executes ready nodes latest-created first), i.e. the gradients of all parameters used downstream are complete.  A
-    data-parallel trainer records an event there and starts the all-reduce of that part of the flat gradient buffer while the rest of
-    the backward pass still runs (liso_amd/trainer.py)."""
+class GradCut:
+    """Splits a backward pass in two at one activation: `split(x)` hands the consumers a detached leaf, `finish()` -- called after
+    the loss's backward() has filled that leaf's gradient -- continues the backward pass into the layers that produced x.  A
+    data-parallel trainer captures the two halves as two hipGraphs and starts the all-reduce of the gradients the first half
+    produced between the two replays (liso_amd/trainer.py); the arithmetic is that of the single backward pass."""
 
-    @staticmethod
-    def forward(ctx, x, hook):
-        ctx.hook = hook
-        return x.view_as(x)
+    def __init__(self):
+        self.upstream, self.leaf = None, None
 
-    @staticmethod
-    def backward(ctx, g):
-        ctx.hook()
-        return g, None
+    def split(self, x):
+        if not x.requires_grad:
+            return x
+        self.upstream = x
+        self.leaf = x.detach().requires_grad_(True)
+        return self.leaf
 
-
-def mark_gradient(x, hook):
-    return x if hook is None or not x.requires_grad else _GradMarker.apply(x, hook)
+    def finish(self):
+        up, leaf, self.upstream, self.leaf = self.upstream, self.leaf, None, None
+        if up is not None and leaf.grad is not None:
+            up.backward(leaf.grad)
 
 
 def conv2d(layer, x, relu=False):

@@ -145,6 +145,19 @@ def _slim_worker(rank, world, port, out):
         thr.update(es, ed, None, sc, True, valid_mask=torch.rand(500, generator=g) > 0.2)
         hist = thr.moving_average_importance.clone()
         bias = thr.bias_counter.clone().reshape(1)
+        # deferred form (hipGraph steps cannot hold a collective): record two updates, reduce + apply them behind the step -- must
+        # equal two immediate updates on the same inputs
+        now, later = MovingAverageThreshold(num_train_samples=100, num_moving=1000), MovingAverageThreshold(num_train_samples=100, num_moving=1000)
+        later._defer = []
+        for k in range(2):
+            a, b_, c = torch.rand(300, generator=g), torch.rand(300, generator=g), torch.rand(300, generator=g)
+            vm = torch.rand(300, generator=g) > 0.3
+            now.update(a, b_, None, c, True, valid_mask=vm)
+            later.update(a, b_, None, c, True, valid_mask=vm)
+        assert float(later.bias_counter) == 0.0
+        items, later._defer = later._defer, None
+        later.apply_deferred(items)
+        assert torch.equal(now.moving_average_importance, later.moving_average_importance) and torch.equal(now.bias_counter, later.bias_counter)
         g_flat = [torch.zeros_like(flat) for _ in range(world)]
         g_hist = [torch.zeros_like(hist) for _ in range(world)]
         g_bias = [torch.zeros_like(bias) for _ in range(world)]

@@ -323,3 +323,25 @@ def test_config5_train_step_300k_points_1024_grid_bf16():
         del tr
         torch.cuda.empty_cache()
     assert abs(losses[torch.bfloat16] - losses[torch.float32]) <= 5e-2 * abs(losses[torch.float32]), losses
+
+
+def test_two_graph_step_with_the_backward_pass_cut_behind_block0_equals_the_one_graph_step():
+    """DetectorTrainer(use_graph=True, grad_buckets=2): the step is captured as two hipGraphs cut behind the backbone's first block
+    (mfma_conv.GradCut; several ranks all-reduce the first graph's gradients while the second one runs).  Same arithmetic as the
+    one-graph step: losses and parameters after 4 steps bit for bit."""
+    from liso_amd.datasets.synthetic import detector_batch
+    from liso_amd.trainer import DetectorTrainer
+    from liso_amd.utils.config import default_cfg
+
+    dev = torch.device("cuda:0")
+    pcls, targets = detector_batch(44, 2, dev, n_points=30000, grid=256, bev_range_m=50.0)
+    out = []
+    for buckets in (1, 2):
+        torch.manual_seed(3)
+        tr = DetectorTrainer(default_cfg(grid=256, bev_range_m=50.0), dev, compute_dtype=torch.bfloat16, total_steps=12, use_graph=True,
+                             grad_buckets=buckets)
+        losses = [float(tr.step(pcls, targets)) for _ in range(4)]
+        assert tr.n_grad_buckets == buckets and (tr._graph2 is not None) == (buckets == 2)
+        out.append((losses, torch.cat([p.detach().float().flatten() for p in tr.net.parameters()]).cpu()))
+    assert out[0][0] == out[1][0], (out[0][0], out[1][0])
+    assert torch.equal(out[0][1], out[1][1])

@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out, use_graph):
+def _worker(rank, world, port, out, use_graph, static_aggr=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -30,7 +30,11 @@ def _worker(rank, world, port, out, use_graph):
         from liso_amd.utils.config import apply_slim_simple_knn_training, default_cfg
 
         dev = torch.device("cuda:0")
-        cfg = apply_slim_simple_knn_training(default_cfg(grid=128, bev_range_m=40.0))
+        if static_aggr:  # the loss also updates the dynamicness threshold: one histogram all-reduce per update
+            cfg = default_cfg(grid=128, bev_range_m=40.0)
+            cfg.SLIM.model.use_static_aggr_flow_for_aggr_flow = True
+        else:
+            cfg = apply_slim_simple_knn_training(default_cfg(grid=128, bev_range_m=40.0))
         torch.manual_seed(rank)  # different initial weights on purpose: the constructor must broadcast rank 0's
         tr = SlimTrainer(cfg, dev, use_graph=use_graph)
         assert (tr.model is tr.net) == use_graph  # no DDP wrapper in graph mode
@@ -39,11 +43,15 @@ def _worker(rank, world, port, out, use_graph):
             g["lr"] = 1e-3
         tr.lr_scheduler = torch.optim.lr_scheduler.LambdaLR(tr.optimizer, lambda s: 1.0)
         losses = [float(tr.step(s0, s1)) for _ in range(3)]
-        flat = torch.cat([p.detach().flatten() for p in tr.net.parameters()]).cpu()
+        if use_graph:
+            assert tr._graph is not None  # (the step really replayed a graph, also with the threshold updates of static aggregation)
+        thr = tr.net.moving_dynamicness_threshold
+        flat = torch.cat([p.detach().flatten() for p in tr.net.parameters()] +
+                         [thr.moving_average_importance.detach().flatten(), thr.bias_counter.detach().float().reshape(1)]).cpu()
         gathered = [torch.zeros_like(flat) for _ in range(world)]
         dist.all_gather(gathered, flat)
         if rank == 0:
-            torch.save({"params": gathered, "losses": losses}, out)
+            torch.save({"params": gathered, "losses": losses, "bias": float(thr.bias_counter)}, out)
     finally:
         dist.destroy_process_group()
 
@@ -59,6 +67,19 @@ def test_two_ranks_slim_step_keeps_replicas_identical(tmp_path, use_graph):
     assert r["losses"][2] != r["losses"][0]  # the weights moved
 
 
+@pytest.mark.timeout(900)
+def test_two_ranks_slim_graph_step_with_static_aggregation_reduces_the_threshold_updates(tmp_path):
+    """hipGraph step + several ranks + the dynamicness threshold learned from the loss: the captured step records the per-rank
+    histogram increments, ONE all-reduce behind the replay makes them global and the updates are applied in order
+    (movavg_cls_threshold.py: apply_deferred) -- parameters AND threshold buffers identical on both ranks, threshold updated"""
+    out = str(tmp_path / "mr_sa.pt")
+    mp.spawn(_worker, args=(2, _free_port(), out, True, True), nprocs=2, join=True)
+    r = torch.load(out)
+    assert all(l == l for l in r["losses"])
+    assert torch.equal(r["params"][0], r["params"][1])
+    assert r["bias"] > 0.0  # the moving average really took updates
+
+
 def _loop_worker(rank, world, port, out, use_graph):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -71,6 +92,9 @@ def _loop_worker(rank, world, port, out, use_graph):
         cfg = apply_slim_simple_knn_training(default_cfg(grid=256, bev_range_m=50.0))
         torch.manual_seed(0)  # (the frozen SLIM network is part of the checkpoint every rank loads: same seed)
         tr = LisoLoopTrainer(cfg, dev, compute_dtype=torch.bfloat16, total_steps=20, use_graph=use_graph, overlap=bool(use_graph))
+        if use_graph:  # two gradient buckets around a two-graph step unless LISO_GRAD_BUCKETS=1 asks for the single all-reduce
+            assert tr.detector.n_grad_buckets == int(os.environ.get("LISO_GRAD_BUCKETS", "2"))
+            assert tr.detector.optimizer.grad_scale == 0.5  # (the mean over ranks is folded into the AdamW launch)
         pairs = [slim_pair(60 + 10 * rank + i, dev, n_points=30000, grid=256, bev_range_m=50.0) for i in range(3)]
         losses = [float(tr.step(*pairs[i % 3], upcoming=(pairs[(i + 1) % 3], pairs[(i + 2) % 3]))) for i in range(5)]
         flat = torch.cat([p.detach().float().flatten() for p in tr.detector.net.parameters()]).cpu()
@@ -95,6 +119,17 @@ def test_two_ranks_liso_loop_keeps_detector_replicas_identical(tmp_path, use_gra
     assert all(bool(torch.isfinite(l).all()) for l in r["losses"])
     assert not torch.equal(r["losses"][0], r["losses"][1])  # the ranks saw different sweeps
     assert torch.equal(r["params"][0], r["params"][1])      # ... and took the same (averaged) steps
+    if use_graph:
+        # the bucketed schedule (two graphs, the large bucket reduced between them) changes WHEN the sums travel, not what they are:
+        # same losses and parameters, bit for bit, as the single all-reduce behind one graph
+        out1 = str(tmp_path / "mr_loop_1bucket.pt")
+        os.environ["LISO_GRAD_BUCKETS"] = "1"
+        try:
+            mp.spawn(_loop_worker, args=(2, _free_port(), out1, use_graph), nprocs=2, join=True)
+        finally:
+            os.environ.pop("LISO_GRAD_BUCKETS", None)
+        r1 = torch.load(out1)
+        assert torch.equal(r["params"][0], r1["params"][0]) and all(torch.equal(a, b) for a, b in zip(r["losses"], r1["losses"]))
 
 
 @pytest.mark.timeout(900)
