@@ -113,6 +113,16 @@ int liso_conv_forward_sparse(const liso_conv_desc* d, const void* x, const void*
                              const float* in_scale, const float* in_shift, void* y, float* stats_partial,
                              const float* stats_shift, const float* occupancy, void* stream);
 
+/* Weight gradient for a SPARSE fp32 input (the SLIM encoders' 7x7 / 2 stem on the pillar canvas, liso/slim/model/extractor.py:230-232
+ * with the canvas of pillar_scatter.py:62-102): `occupancy` fp32 [batch, hi, wi], 0 where the input pixel is exactly zero in every
+ * channel.  Only occupied cells are visited (listed on the device in (sample, row, column) order), products and sums are exact fp32
+ * FMAs in a fixed order (bitwise reproducible; at least the accuracy of either fp32 mode of liso_conv_wgrad).  `d` = the forward
+ * descriptor of a one-class (gather-form) convolution with ci, co <= 64 and no prologue; dw / dbias as liso_conv_wgrad
+ * (transposed = 0).  0 bytes from the workspace query = geometry not covered. */
+size_t liso_conv_wgrad_sparse_workspace_bytes(const liso_conv_desc* d);
+int liso_conv_wgrad_sparse_f32(const liso_conv_desc* d, const float* x, const float* occupancy, const float* dy, int dy_pix_stride,
+                               float* dw, float* dbias, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Weight gradient of the convolution described by `d` (a FORWARD descriptor: x = layer input, with the same optional
  * prologue, dy = gradient of the layer output [batch, ho, wo, co] with pixel stride dy_pix_stride):
  *   dw[co][ci][kh][kw] (torch layout of nn.Conv2d; transposed != 0: [ci][co][kh][kw]) = sum over pixels, overwritten;

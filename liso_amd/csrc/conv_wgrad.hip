@@ -967,7 +967,8 @@ bool make_plan_impl(const liso_conv_desc& d, WgPlan* p, bool compact) {
         long s = (target + per_split - 1) / per_split;
         s = s < 1 ? 1 : (s > split_cap ? split_cap : s);
         const long blocks = per_split * s;
-        if (blocks >= 256) {  // enough: take the largest tap group
+        if (blocks >= 256 || (rows7 && tg == 7)) {  // enough: take the largest tap group (7 x 7: always whole kernel rows -- single
+                                                     // taps would stage the halo tile 49 times)
             p->tg = tg;
             break;
         }
@@ -1029,6 +1030,191 @@ int launch(const liso_conv_desc& d, const WgPlan& p, hipStream_t st) {
     }
     conv_wgrad_kernel<MODE, TG><<<p.blocks, kThreads, p.lds, st>>>(d, p.a);
     return hipGetLastError() == hipSuccess ? LISO_OK : LISO_ELAUNCH;
+}
+
+// ---- sparse-input weight gradient (the encoders' 7x7 / 2 stem on the pillar canvas) ----------------------------------------------
+// The canvas holds a feature row at 1-2 % of its cells (pillar_scatter.py:62-102); every other cell is exactly zero and contributes
+// nothing to dW[tap][ci][co] = sum_cells x[cell][ci] * dy[out pixel(cell, tap)][co].  The dense kernels stage the whole 134-MB fp32
+// canvas (once per kernel row), the library's kernel takes 0.31 ms per two sweeps; here
+//   cells_count / cells_scan / cells_fill   list the occupied cells in (sample, row, column) order from the occupancy map
+//                                           (per-row ballot counts, one-block scan of the row counts: deterministic order);
+//   wgrad_sparse_kernel                     block = (tap, split): walks its share of the list, keeps the cells whose parity puts an
+//                                           output pixel under this tap (1 of 4 at stride 2), stages their feature rows and dy rows
+//                                           in LDS and accumulates the 64 x 64 tile with fp32 FMAs (exact fp32 products: the
+//                                           arithmetic of LISO_CONV_F32, better than F32X3), 8 outputs per thread;
+//   dy_colsum_kernel                        the bias gradient (a dense column sum of dy) as rows of the bias slab;
+// and the fixed-order slab reduction of the dense kernels.  Everything is order-fixed: bitwise reproducible.
+constexpr int kSpSplits = 16;
+constexpr int kSpBatch = 64;  // candidate cells per staging round
+
+__global__ __launch_bounds__(256) void cells_count_kernel(const float* __restrict__ occ, int wi, int* __restrict__ row_count) {
+    __shared__ int wsum[4];
+    const long row = blockIdx.x;
+    int n = 0;
+    for (int c = threadIdx.x; c < wi; c += 256) n += occ[row * wi + c] != 0.0f ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) row_count[row] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// one block: row_off[r] = exclusive prefix of row_count, row_off[n_rows] = total
+__global__ __launch_bounds__(1024) void cells_scan_kernel(const int* __restrict__ row_count, int n_rows, int* __restrict__ row_off) {
+    __shared__ int part[1024];
+    const int per = (n_rows + 1023) / 1024;
+    const int b0 = threadIdx.x * per;
+    int s = 0;
+    for (int i = 0; i < per; i++)
+        if (b0 + i < n_rows) s += row_count[b0 + i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {  // Hillis-Steele inclusive scan of the 1024 partial sums
+        const int v = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = threadIdx.x > 0 ? part[threadIdx.x - 1] : 0;
+    for (int i = 0; i < per; i++)
+        if (b0 + i < n_rows) {
+            row_off[b0 + i] = run;
+            run += row_count[b0 + i];
+        }
+    if (threadIdx.x == 1023) row_off[n_rows] = part[1023];
+}
+
+__global__ __launch_bounds__(64) void cells_fill_kernel(const float* __restrict__ occ, int wi, const int* __restrict__ row_off,
+                                                        int* __restrict__ cells) {
+    const long row = blockIdx.x;
+    int base = row_off[row];
+    for (int c0 = 0; c0 < wi; c0 += 64) {
+        const int c = c0 + threadIdx.x;
+        const bool on = c < wi && occ[row * wi + c] != 0.0f;
+        const unsigned long long m = __ballot(on);
+        if (on) cells[base + __popcll(m & ((1ull << threadIdx.x) - 1ull))] = (int)(row * wi + c);
+        base += __popcll(m);
+    }
+}
+
+struct SpArgs {
+    const float* x;
+    const float* dy;
+    const int* cells;
+    const int* n_cells;  // row_off[n_rows]
+    float* slab;         // [splits][w_taps][64][64]
+    int dy_pix_stride;
+    int pad;             // -tap_dy of kernel row 0 (= the convolution's padding)
+};
+
+__global__ __launch_bounds__(256) void wgrad_sparse_kernel(const liso_conv_desc d, const SpArgs a) {
+    __shared__ __attribute__((aligned(16))) float xs[kSpBatch][64];
+    __shared__ __attribute__((aligned(16))) float ys[kSpBatch][64];
+    __shared__ int src_x[kSpBatch], src_y[kSpBatch], n_sel;
+    const int tap = blockIdx.x, split = blockIdx.y, tid = threadIdx.x;
+    const int tdy = d.tap_dy[tap], tdx = d.tap_dx[tap];
+    const int n = *a.n_cells;
+    const int chunk = (n + kSpSplits - 1) / kSpSplits;
+    const int begin = split * chunk, end = begin + chunk < n ? begin + chunk : n;
+    const int ci = tid >> 2, co8 = (tid & 3) * 16;  // thread: one input channel x 16 output channels (two 8-groups: co8, co8 + 8)
+    float acc[16];
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[e] = 0.0f;
+    const int plane = d.hi * d.wi;
+    for (int c0 = begin; c0 < end; c0 += kSpBatch) {
+        __syncthreads();  // (the previous round's LDS rows are done)
+        if (tid < 64) {   // wave 0 selects: input cell (r, c) lies under tap (tdy, tdx) of output pixel (oy, ox) iff r = oy * isy + tdy
+            bool ok = false;
+            int sx = 0, sy = 0;
+            if (c0 + tid < end) {
+                const int cell = a.cells[c0 + tid];
+                const int b = cell / plane, rc = cell - b * plane;
+                const int r = rc / d.wi, c = rc - r * d.wi;
+                const int ny = r - tdy, nx = c - tdx;
+                if (ny >= 0 && nx >= 0 && ny % d.isy == 0 && nx % d.isx == 0) {
+                    const int oy = ny / d.isy, ox = nx / d.isx;
+                    if (oy < d.ho && ox < d.wo) {
+                        ok = true;
+                        sx = cell;
+                        sy = (b * d.ho + oy) * d.wo + ox;
+                    }
+                }
+            }
+            const unsigned long long m = __ballot(ok);
+            if (ok) {
+                const int k = __popcll(m & ((1ull << tid) - 1ull));
+                src_x[k] = sx;
+                src_y[k] = sy;
+            }
+            if (tid == 0) n_sel = __popcll(m);
+        }
+        __syncthreads();
+        const int ns = n_sel;
+        // stage the selected rows: 16 float4 per x row (64 channels, zero beyond ci) and per dy row (zero beyond co)
+        for (int i = tid; i < ns * 16; i += 256) {
+            const int j = i >> 4, q4 = (i & 15) * 4;
+            float4 vx = make_float4(0.f, 0.f, 0.f, 0.f), vy = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q4 < d.ci) vx = *reinterpret_cast<const float4*>(a.x + (long)src_x[j] * d.x_pix_stride + q4);
+            if (q4 < d.co) vy = *reinterpret_cast<const float4*>(a.dy + (long)src_y[j] * a.dy_pix_stride + q4);
+            *reinterpret_cast<float4*>(&xs[j][q4]) = vx;
+            *reinterpret_cast<float4*>(&ys[j][q4]) = vy;
+        }
+        __syncthreads();
+        for (int j = 0; j < ns; j++) {
+            const float xv = xs[j][ci];
+            const float4 y0 = *reinterpret_cast<const float4*>(&ys[j][co8]), y1 = *reinterpret_cast<const float4*>(&ys[j][co8 + 4]);
+            const float4 y2 = *reinterpret_cast<const float4*>(&ys[j][co8 + 8]), y3 = *reinterpret_cast<const float4*>(&ys[j][co8 + 12]);
+            acc[0] = fmaf(xv, y0.x, acc[0]); acc[1] = fmaf(xv, y0.y, acc[1]); acc[2] = fmaf(xv, y0.z, acc[2]); acc[3] = fmaf(xv, y0.w, acc[3]);
+            acc[4] = fmaf(xv, y1.x, acc[4]); acc[5] = fmaf(xv, y1.y, acc[5]); acc[6] = fmaf(xv, y1.z, acc[6]); acc[7] = fmaf(xv, y1.w, acc[7]);
+            acc[8] = fmaf(xv, y2.x, acc[8]); acc[9] = fmaf(xv, y2.y, acc[9]); acc[10] = fmaf(xv, y2.z, acc[10]); acc[11] = fmaf(xv, y2.w, acc[11]);
+            acc[12] = fmaf(xv, y3.x, acc[12]); acc[13] = fmaf(xv, y3.y, acc[13]); acc[14] = fmaf(xv, y3.z, acc[14]); acc[15] = fmaf(xv, y3.w, acc[15]);
+        }
+    }
+    if (ci < d.ci) {
+        float* o = a.slab + (((long)split * d.w_taps + d.tap_w[tap]) * 64 + ci) * 64 + co8;
+#pragma unroll
+        for (int e = 0; e < 16; e += 4)
+            if (co8 + e < d.co) *reinterpret_cast<float4*>(o + e) = make_float4(acc[e], acc[e + 1], acc[e + 2], acc[e + 3]);
+    }
+}
+
+// bias_slab[row][64] = column sums of dy over the pixels of chunk `row` (fixed order inside a chunk, rows added by the reduction)
+__global__ __launch_bounds__(256) void dy_colsum_kernel(const float* __restrict__ dy, long n_pix, int pix_stride, int co, long per_block,
+                                                        float* __restrict__ bias_slab) {
+    __shared__ float red[4][64];
+    const int c = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const long p0 = (long)blockIdx.x * per_block, p1 = p0 + per_block < n_pix ? p0 + per_block : n_pix;
+    float s = 0.0f;
+    if (c < co)
+        for (long p = p0 + part; p < p1; p += 4) s += dy[p * pix_stride + c];
+    red[part][c] = s;
+    __syncthreads();
+    if (part == 0) bias_slab[(long)blockIdx.x * 64 + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+}
+
+constexpr int kSpBiasRows = 256;
+
+size_t sparse_layout(const liso_conv_desc& d, size_t* off_rowcnt, size_t* off_rowoff, size_t* off_cells, size_t* off_slab, size_t* off_bias) {
+    const size_t rows = (size_t)d.batch * d.hi;
+    size_t o = 0;
+    auto take = [&](size_t bytes) {
+        const size_t at = o;
+        o += (bytes + 255) / 256 * 256;
+        return at;
+    };
+    *off_rowcnt = take(rows * 4);
+    *off_rowoff = take((rows + 1) * 4);
+    *off_cells = take(rows * d.wi * 4);  // (worst case: every cell occupied)
+    *off_slab = take((size_t)kSpSplits * d.w_taps * 64 * 64 * 4);
+    *off_bias = take((size_t)kSpBiasRows * 64 * 4);
+    return o;
+}
+
+bool sparse_ok(const liso_conv_desc& d) {
+    return d.batch > 0 && d.n_classes == 1 && d.osy == 1 && d.osx == 1 && d.ci <= 64 && d.co <= 64 && d.ci % 4 == 0 && d.co % 4 == 0 &&
+           d.x_pix_stride % 4 == 0 && d.n_taps >= 1 && d.n_taps <= LISO_CONV_MAX_TAPS && d.n_taps == d.w_taps &&
+           (d.mode == LISO_CONV_F32X3 || d.mode == LISO_CONV_F32) && (long)d.batch * d.hi * d.wi < (1l << 31) &&
+           (long)d.batch * d.hi <= 1024l * 64 && d.in_affine_batch_stride == 0;
 }
 
 // ---- plan of the row-stationary 3x3 kernel ----------------------------------------------------------------------------------------
@@ -1100,6 +1286,43 @@ size_t liso_conv_wgrad_workspace_bytes(const liso_conv_desc* d) {
     WgPlan p;
     if (!make_plan(*d, &p)) return 0;
     return p.slab_bytes + p.bias_bytes;
+}
+
+size_t liso_conv_wgrad_sparse_workspace_bytes(const liso_conv_desc* d) {
+    if (!d || !sparse_ok(*d)) return 0;
+    size_t a, b, c, e, f;
+    return sparse_layout(*d, &a, &b, &c, &e, &f);
+}
+
+int liso_conv_wgrad_sparse_f32(const liso_conv_desc* d, const float* x, const float* occupancy, const float* dy, int dy_pix_stride,
+                               float* dw, float* dbias, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!d || !x || !occupancy || !dy || !dw || !workspace) return LISO_EINVAL;
+    if (!sparse_ok(*d) || dy_pix_stride % 4 || dy_pix_stride < d->co || (((uintptr_t)x | (uintptr_t)dy) & 15)) return LISO_EINVAL;
+    size_t o_cnt, o_off, o_cells, o_slab, o_bias;
+    if (workspace_bytes < sparse_layout(*d, &o_cnt, &o_off, &o_cells, &o_slab, &o_bias)) return LISO_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    const int rows = d->batch * d->hi;
+    cells_count_kernel<<<rows, 256, 0, st>>>(occupancy, d->wi, (int*)(ws + o_cnt));
+    cells_scan_kernel<<<1, 1024, 0, st>>>((const int*)(ws + o_cnt), rows, (int*)(ws + o_off));
+    cells_fill_kernel<<<rows, 64, 0, st>>>(occupancy, d->wi, (const int*)(ws + o_off), (int*)(ws + o_cells));
+    SpArgs a;
+    a.x = x;
+    a.dy = dy;
+    a.cells = (const int*)(ws + o_cells);
+    a.n_cells = (const int*)(ws + o_off) + rows;
+    a.slab = (float*)(ws + o_slab);
+    a.dy_pix_stride = dy_pix_stride;
+    a.pad = 0;
+    wgrad_sparse_kernel<<<dim3(d->n_taps, kSpSplits), 256, 0, st>>>(*d, a);
+    if (dbias) {
+        const long n_pix = (long)d->batch * d->ho * d->wo;
+        const long per = (n_pix + kSpBiasRows - 1) / kSpBiasRows;
+        dy_colsum_kernel<<<kSpBiasRows, 256, 0, st>>>(dy, n_pix, dy_pix_stride, d->co, per, (float*)(ws + o_bias));
+    }
+    if (hipGetLastError() != hipSuccess) return LISO_ELAUNCH;
+    return launch_reduce((const float*)(ws + o_slab), (const float*)(ws + o_bias), kSpSplits, kSpBiasRows, d->w_taps, d->ci, d->co, 64, 64, 0,
+                         dw, dbias, st);
 }
 
 int liso_conv_wgrad(const liso_conv_desc* d, const void* x, const float* in_scale, const float* in_shift, const void* dy,

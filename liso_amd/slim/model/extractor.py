@@ -106,8 +106,9 @@ class SmallEncoder(nn.Module):
             MC.supported(x, self.conv1.weight, MC.ConvSpec.of(self.conv1))
 
     def forward(self, x, occupancy=None):
-        """`occupancy` (extension, inference): the occupancy map of the pillar canvas `x` (fp32 [B,1,H,W], 0 = no pillar): the first
-        convolution then skips the tiles of the (sparse) BEV canvas that hold no pillar at all -- same result, bit for bit"""
+        """`occupancy` (extension): the occupancy map of the pillar canvas `x` (fp32 [B,1,H,W], 0 = no pillar): the first
+        convolution then skips the tiles of the (sparse) BEV canvas that hold no pillar at all -- same result, bit for bit -- and,
+        in training, its weight gradient walks the occupied cells only (mfma_conv.conv_wgrad_sparse)"""
         is_list = isinstance(x, (tuple, list))
         if is_list:
             batch_dim = x[0].shape[0]
@@ -121,10 +122,11 @@ class SmallEncoder(nn.Module):
                 h, fold = blk.forward_inference(h, fold), None
             x = conv2d(self.conv2, h)
         else:
+            occ = occupancy if (occupancy is not None and not is_list and x.is_cuda) else None
             if isinstance(self.norm1, nn.Sequential) and len(self.norm1) == 0:
-                x = conv2d(self.conv1, x, relu=True)
+                x = conv2d(self.conv1, x, relu=True, occupancy=occ)
             else:
-                x = in_act(conv2d(self.conv1, x), self.norm1)
+                x = in_act(conv2d(self.conv1, x, occupancy=occ), self.norm1)
             x = self.layer3(self.layer2(self.layer1(x)))
             x = conv2d(self.conv2, x)
         if self.training and self.dropout is not None:

@@ -65,10 +65,12 @@ class RAFT(nn.Module):
             return fw, bw, aux
         B = img_t0.shape[0]
         imgs = torch.cat([img_t0, img_t1], dim=0)
-        fmap = self.fnet(imgs)
+        occ = torch.cat([occ_t0, occ_t1], dim=0) if imgs.is_cuda else None  # (the sparse-canvas paths of the encoders' first convolution)
+        fmap = self.fnet(imgs, occupancy=occ)
         fmap_swapped = torch.cat([fmap[B:], fmap[:B]], dim=0)
         both = self.predict_single_flow_map_and_classes(imgs, fmap, fmap_swapped, self.head_decoder_fw,
-                                                        fused_dirs=2 if getattr(self, "fused_outputs", True) else None)
+                                                        fused_dirs=2 if getattr(self, "fused_outputs", True) else None,
+                                                        occupancy_t0=occ)
         if torch.is_tensor(both):  # all iterations assembled by one launch: [fw it0..itN | bw it0..itN] x B samples
             n_it = both.shape[0] // (2 * B)
             aux["net_all"] = both

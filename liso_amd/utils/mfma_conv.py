@@ -443,6 +443,37 @@ def conv_wgrad(x, dy, weight_shape, spec, in_scale=None, in_shift=None, in_relu=
     return dw, db
 
 
+def conv_wgrad_sparse(x, occupancy, dy, weight_shape, spec, want_bias=True):
+    """weight (and bias) gradient of a convolution whose fp32 input is a sparse canvas with an occupancy map (the encoders' 7x7 / 2
+    stem): only occupied cells are visited (liso_conv_wgrad_sparse_f32) -> (dw fp32 `weight_shape`, dbias | None), or None when the
+    geometry is not covered (the caller takes the dense path)"""
+    L.require_cuda(x, dy, occupancy)
+    if x.dtype != torch.float32 or spec.transposed or occupancy.dtype != torch.float32:
+        return None
+    if dy.dtype != torch.float32:
+        dy = dy.float()
+    xv, xps = as_nhwc(x, 4)
+    gv, gps = as_nhwc(dy, 4)
+    B, hi, wi, ci = xv.shape
+    _, ho, wo, co = gv.shape
+    occ = occupancy.contiguous()
+    if occ.numel() != B * hi * wi:
+        return None
+    d = gather_desc(spec, B, hi, wi, ci, xps, ho, wo, co, co, 0, _mode(x.dtype), True, False, False)
+    lib = L.lib()
+    nbytes = lib.liso_conv_wgrad_sparse_workspace_bytes(ctypes.byref(d))
+    if nbytes == 0:
+        return None
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    dw = torch.empty(weight_shape, dtype=torch.float32, device=x.device)
+    db = torch.empty(co, dtype=torch.float32, device=x.device) if want_bias else None
+    with torch.cuda.device(x.device):
+        L.check(L.TIMER.launch("conv_wgrad_sparse", lambda: lib.liso_conv_wgrad_sparse_f32(
+            ctypes.byref(d), L.ptr(xv), L.ptr(occ), L.ptr(gv), gps, L.ptr(dw), L.ptr(db) if db is not None else None, L.ptr(ws), nbytes,
+            L.stream_ptr()), units=_flops(d), nbytes=_bytes(d, True)), "conv_wgrad_sparse")
+    return dw, db
+
+
 def supported(x, weight, spec):
     """can the own kernels run this convolution (forward, data and weight gradient)?"""
     if not x.is_cuda or x.dtype not in (torch.bfloat16, torch.float32):
@@ -602,14 +633,15 @@ class _FusedConv(torch.autograd.Function):
         meta['stats_partial']"""
         spec, fold = meta["spec"], meta["fold"]
         sc, sh = fold.scale_shift() if fold is not None else (None, None)
+        occ = meta.get("occupancy") if fold is None else None  # (sparse pillar canvas: tile skipping forward, cell list backward)
         y, part = conv_forward(x_raw, weight, bias, spec, sc, sh, in_relu=fold.relu if fold is not None else False,
                                out_relu=meta.get("out_relu", False), out_dtype=meta.get("out_dtype"),
-                               want_stats=meta.get("want_stats", False), stats_shift=meta.get("stats_shift"))
+                               want_stats=meta.get("want_stats", False), stats_shift=meta.get("stats_shift"), occupancy=occ)
         meta["stats_partial"] = part
         relu = bool(meta.get("out_relu", False))
         ctx.save_for_backward(x_raw, weight, y if relu else None)
         ctx.meta = {"spec": spec, "fold": fold, "has_bias": bias is not None, "n_fold_params": len(fold_params), "relu": relu,
-                    "bias_param": bias if isinstance(bias, torch.nn.Parameter) else None}
+                    "bias_param": bias if isinstance(bias, torch.nn.Parameter) else None, "occupancy": occ}
         return y
 
     @staticmethod
@@ -631,8 +663,13 @@ class _FusedConv(torch.autograd.Function):
             tb = _direct_target(ctx.meta["bias_param"]) if tw is not None and ctx.meta["has_bias"] else None
             if ctx.meta["has_bias"] and tb is None:
                 tw = None  # (both or none: one launch produces both)
-            res = conv_wgrad(x_raw, dy, tuple(weight.shape), spec, sc, sh, in_relu=fold.relu if fold is not None else False,
-                             want_bias=ctx.meta["has_bias"], out_dw=tw, out_db=tb, co_true=co_true)
+            res = None
+            if ctx.meta.get("occupancy") is not None and co_true == dy.shape[1]:
+                res = conv_wgrad_sparse(x_raw, ctx.meta["occupancy"], dy, tuple(weight.shape), spec, want_bias=ctx.meta["has_bias"])
+                tw = None if res is not None else tw
+            if res is None:
+                res = conv_wgrad(x_raw, dy, tuple(weight.shape), spec, sc, sh, in_relu=fold.relu if fold is not None else False,
+                                 want_bias=ctx.meta["has_bias"], out_dw=tw, out_db=tb, co_true=co_true)
             if res is None:
                 dw, db = _aten_wgrad(x_raw, dy[:, :co_true], weight, spec, fold, ctx.meta["has_bias"])
             else:
@@ -668,7 +705,7 @@ def _aten_wgrad(x_raw, dy, weight, spec, fold, has_bias):
     return gw.float(), (gb.float() if has_bias else None)
 
 
-def fused_conv(x_raw, fold, conv, out_bn=None, out_dtype=None, out_relu=False, spec=None):
+def fused_conv(x_raw, fold, conv, out_bn=None, out_dtype=None, out_relu=False, spec=None, occupancy=None):
     """y_raw = conv(relu?(bn(x_raw))) (+ bias).  `fold`: BnFold pending on x_raw or None.  `conv`: one nn.Conv2d /
     nn.ConvTranspose2d, or a list of nn.Conv2d with the same geometry and input (run as ONE convolution with the filters
     concatenated along the output channels).  `out_bn`: the BatchNorm2d (list: one per convolution of the list) that follows
@@ -691,7 +728,7 @@ def fused_conv(x_raw, fold, conv, out_bn=None, out_dtype=None, out_relu=False, s
             hit = convs[0]._liso_merged_weights = (key, w, b)
         weight, bias = hit[1], hit[2]
     training_bn = bns is not None and (bns[0].training or not bns[0].track_running_stats)
-    meta = {"spec": spec, "fold": fold, "out_dtype": out_dtype, "want_stats": training_bn, "out_relu": out_relu}
+    meta = {"spec": spec, "fold": fold, "out_dtype": out_dtype, "want_stats": training_bn, "out_relu": out_relu, "occupancy": occupancy}
     if training_bn and len(bns) == 1 and bns[0].track_running_stats:
         # any per-channel constant close to the mean keeps the sums well conditioned: the running mean.  (The finalize kernel
         # reads stats_shift[c] before the same thread updates running_mean[c]: passing the live buffer is safe.)
@@ -833,12 +870,13 @@ class GradCut:
             up.backward(leaf.grad)
 
 
-def conv2d(layer, x, relu=False):
+def conv2d(layer, x, relu=False, occupancy=None):
     """relu?(layer(x)) for an nn.Conv2d / nn.ConvTranspose2d on the own kernels (torch's convolution when the geometry or the
-    device is not covered: CPU tensors in host-logic tests, 2-3 input channels)"""
+    device is not covered: CPU tensors in host-logic tests, 2-3 input channels).  `occupancy`: fp32 [B,1,H,W] / [B,H,W] map with 0
+    where x is zero in every channel (the pillar canvas): empty tiles are skipped forward, the weight gradient walks occupied cells"""
     spec = ConvSpec.of(layer)
     if x.is_cuda and backend() == "mfma" and supported(x, layer.weight, spec):
-        return fused_conv(x, None, layer, out_relu=relu, spec=spec)[0]
+        return fused_conv(x, None, layer, out_relu=relu, spec=spec, occupancy=occupancy if x.dtype == torch.float32 else None)[0]
     if x.is_cuda and backend() == "mfma" and x.dtype in (torch.bfloat16, torch.float32) and not spec.transposed:
         # 1-3 (7) input channels -- the motion encoder's conv_flow1: 7x7 on the 2-channel flow, liso/slim/model/update.py:53-60 --
         # the kernels read channels in 16-B groups: zero channels (and zero filter slices) up to one group, then the own kernel

@@ -273,3 +273,55 @@ def test_sparse_input_tile_skipping_is_bit_identical(arith):
                                  occupancy=occ.cuda().contiguous())
     assert torch.equal(dense, sparse) and torch.equal(pd[..., :32], ps[..., :32])  # (columns beyond the 32 channels are never written)
     assert float((dense - torch.relu(bias.cuda()).view(1, -1, 1, 1)).abs().amax()) > 0.1  # (not all-bias)
+
+
+@pytest.mark.parametrize("geom", [(2, 64, 32, 128, 128, 7, 2, 3), (1, 16, 24, 45, 70, 3, 2, 1), (3, 64, 64, 33, 31, 7, 2, 3), (1, 8, 4, 64, 64, 5, 1, 2),
+                                  (2, 64, 32, 512, 512, 7, 2, 3)])
+@pytest.mark.parametrize("density", [0.02, 0.5, 0.0])
+def test_sparse_canvas_weight_gradient_matches_fp64(geom, density):
+    """liso_conv_wgrad_sparse_f32: the weight / bias gradient of a convolution on a sparse canvas (the encoders' 7x7 / 2 stem on the
+    pillar canvas, extractor.py:230-232) from the occupied cells alone, against autograd in fp64 on the same canvas: the SLIM stem at
+    the bench's size, ragged maps, other kernels / strides, a dense-ish and an empty canvas; bitwise reproducible."""
+    from liso_amd.utils import mfma_conv as MC
+
+    B, Ci, Co, H, W, k, s, p = geom
+    g = torch.Generator().manual_seed(3)
+    occ = (torch.rand(B, 1, H, W, generator=g) < density).float()
+    x = torch.randn(B, Ci, H, W, generator=g) * occ
+    w = torch.randn(Co, Ci, k, k, generator=g) / (Ci * k * k) ** 0.5
+    b = torch.randn(Co, generator=g)
+    spec = MC.ConvSpec(k, k, s, p, False)
+    x64, w64, b64 = x.double(), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    out = F.conv2d(x64, w64, b64, stride=s, padding=p)
+    dy = torch.randn(out.shape, generator=g)
+    gw, gb = torch.autograd.grad(out, [w64, b64], dy.double())
+    xd = x.cuda().contiguous(memory_format=torch.channels_last)
+    dyd = dy.cuda().contiguous(memory_format=torch.channels_last)
+    res = MC.conv_wgrad_sparse(xd, occ.cuda(), dyd, tuple(w.shape), spec)
+    assert res is not None
+    dw, db = res
+    scale = max(float(gw.abs().max()), 1e-30)
+    assert float((dw.double().cpu() - gw).abs().max()) <= 3e-6 * scale + 1e-12, float((dw.double().cpu() - gw).abs().max()) / scale
+    assert _rel(db, gb) <= 1e-5
+    dw2, db2 = MC.conv_wgrad_sparse(xd, occ.cuda(), dyd, tuple(w.shape), spec)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
+
+
+def test_stem_convolution_with_occupancy_trains_like_the_dense_path():
+    """mfma_conv.conv2d(layer, canvas, occupancy=...) in training: forward bit-identical to the dense call (tile skipping), weight /
+    bias gradients from the sparse kernel within fp32 rounding of the dense F32X3 kernel's, input gradient unchanged"""
+    from liso_amd.utils import mfma_conv as MC
+
+    g = torch.Generator().manual_seed(5)
+    occ = (torch.rand(2, 1, 128, 128, generator=g) < 0.03).float().cuda()
+    x = (torch.randn(2, 64, 128, 128, generator=g).cuda() * occ).contiguous(memory_format=torch.channels_last)
+    outs = []
+    for use_occ in (False, True):
+        torch.manual_seed(1)
+        layer = torch.nn.Conv2d(64, 32, 7, stride=2, padding=3).cuda()
+        xi = x.clone().requires_grad_(True)
+        y = MC.conv2d(layer, xi, relu=True, occupancy=occ if use_occ else None)
+        (y * torch.linspace(-1, 1, y.numel(), device="cuda").view_as(y)).sum().backward()
+        outs.append((y.detach(), layer.weight.grad.clone(), layer.bias.grad.clone(), xi.grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][3], outs[1][3])
+    assert _rel(outs[1][1], outs[0][1]) <= 1e-4 and _rel(outs[1][2], outs[0][2]) <= 1e-4

@@ -33,6 +33,8 @@ def _worker(rank, world, port, out, use_graph, static_aggr=False):
         if static_aggr:  # the loss also updates the dynamicness threshold: one histogram all-reduce per update
             cfg = default_cfg(grid=128, bev_range_m=40.0)
             cfg.SLIM.model.use_static_aggr_flow_for_aggr_flow = True
+            cfg.SLIM.losses.unsupervised.knn_on_static_penalty = 1.0  # (the threshold update compares static-aggregated and dynamic flow errors)
+            cfg.SLIM.losses.unsupervised.artificial_labels.cross_entropy_penalty = 0.1
         else:
             cfg = apply_slim_simple_knn_training(default_cfg(grid=128, bev_range_m=40.0))
         torch.manual_seed(rank)  # different initial weights on purpose: the constructor must broadcast rank 0's
