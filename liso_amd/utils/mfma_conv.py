@@ -408,10 +408,11 @@ def conv_wgrad(x, dy, weight_shape, spec, in_scale=None, in_shift=None, in_relu=
     """-> (dw fp32 in torch's layout `weight_shape`, dbias fp32 [Co] | None); None if the geometry is not supported by the
     kernel (caller falls back to ATen's weight gradient).  `out_dw` / `out_db`: dense fp32 tensors to write into (overwritten)."""
     L.require_cuda(x, dy)
-    if spec.kh * spec.kw > 9 and x.shape[1] > 8 and not os.environ.get("LISO_WGRAD_7X7"):
-        # the encoders' 7x7 / 2 stem on the dense pillar canvas (64 input channels): the row-of-taps kernel re-stages the canvas once
-        # per kernel row (measured 1.9 ms vs 0.31 ms for the library's kernel at two sweeps); the motion encoder's 7x7 convolutions
-        # (2-4 input channels) run on the own kernel.  LISO_WGRAD_7X7=1 forces the own kernel (tests, measurements).
+    if spec.kh * spec.kw > 9 and not os.environ.get("LISO_WGRAD_7X7"):
+        # 7x7 kernels on DENSE inputs: the row-of-taps kernel re-stages the halo tile once per kernel row and pads 2-4 input channels
+        # to a 64-channel tile -- measured 0.33 ms vs 0.05 ms for the library's kernel on the motion encoder's 7x7 convolutions
+        # (update.py:57,66), 1.9 ms vs 0.31 ms on the encoders' stem.  The stem's canvas is sparse and takes conv_wgrad_sparse
+        # (0.11 ms); the motion encoder's two layers stay on the library.  LISO_WGRAD_7X7=1 forces the own kernel (tests).
         return None
     mode = _mode(x.dtype)
     if dy.dtype != x.dtype:
