@@ -11,8 +11,8 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout 600 python3 $R/bench.py "$@" > $OUT/bench_line.json 2> $OUT/bench.err
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --no-cpu-baseline --no-iou3d --no-fp32-leg "$@" > $OUT/bench_traced.json 2> $OUT/trace.err
-P="--steps 3 --warmup 2 --no-cpu-baseline --no-iou3d --no-fp32-leg"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --no-cpu-baseline --no-iou3d --no-fp32-leg --no-legs "$@" > $OUT/bench_traced.json 2> $OUT/trace.err
+P="--steps 3 --warmup 2 --no-cpu-baseline --no-iou3d --no-fp32-leg --no-legs"
 timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "$KRE" --output-format csv -d $OUT/pmc_FETCH_SIZE -- python3 $R/bench.py $P "$@" > /dev/null 2> $OUT/pmc_fetch.err
 timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "$KRE" --output-format csv -d $OUT/pmc_WRITE_SIZE -- python3 $R/bench.py $P "$@" > /dev/null 2> $OUT/pmc_write.err
 timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE --kernel-include-regex "$KRE" --output-format csv -d $OUT/pmc_MFMA -- python3 $R/bench.py $P "$@" > /dev/null 2> $OUT/pmc_mfma.err
