@@ -17,10 +17,14 @@ def get_points_in_boxes_mask(objects: Shape, pcl_homog, return_pcl_in_box_cosy=F
     assert pcl_homog.shape[-1] == 4 and len(pcl_homog.shape) == 2, pcl_homog.shape
     assert torch.is_tensor(pcl_homog), "device path only (the numpy branch of the reference is data-loader code)"
     assert use_double_precision, "not implemented for torch"  # reference :1912
-    if return_pcl_in_box_cosy:
-        raise NotImplementedError("return_pcl_in_box_cosy materialises [N,K,4]; not provided by the fused kernel")
     res = points_in_boxes(dense_boxes(objects)[None], pcl_homog[None, :, :3], want_mask=True, want_count=False,
                           precision=FP64_PRODUCT)
+    if return_pcl_in_box_cosy:
+        # reference :1914-1918 -- the points in every box's frame, [N,K,4] in the cloud's dtype (fp64 product, rounded once): the one
+        # caller-visible tensor of size N x K; callers that only need the mask never pay for it
+        box_T_sensor = torch.linalg.inv_ex(objects.get_poses()).inverse
+        pcl_box = torch.einsum("kij,nj->nki", box_T_sensor, pcl_homog.to(box_T_sensor.dtype)).to(pcl_homog.dtype)
+        return res["mask"][0], pcl_box
     return res["mask"][0]
 
 

@@ -66,10 +66,19 @@ class KabschDecoder(torch.nn.Module):
     def forward(self, shapes: Shape, batched_padded_points=None, batched_padded_is_valid_points=None, shape_name=None,
                 sigmoid_slope=None, obj_dim_scale=1.0, softness_func=None):
         """reference :255-326 -- soft mask probabilities [B,S,N] of every point for every box slot."""
-        if batched_padded_points is None:
-            raise NotImplementedError("BEV-grid mask rendering (no points) is outside the hot path")
         slope = sigmoid_slope if sigmoid_slope is not None else self.cfg.mask_rendering.pred_sigmoid_slope
         name = self.softness_name if softness_func is None else ("sigmoid" if softness_func is torch.sigmoid else "cauchy")
+        if batched_padded_points is None and batched_padded_is_valid_points is None:
+            # reference :274-276: no points -> the masks are rendered on the BEV grid's pillar centres, [B,S,gx,gy].  The same kernel
+            # with the grid cells as the "points" (every sample sees the same cells)
+            centers = self.pcl_bev_center_coords_homog  # [gx, gy, 4]
+            gx, gy = centers.shape[0], centers.shape[1]
+            B = shapes.pos.shape[0]
+            cells = centers[..., :3].reshape(1, gx * gy, 3).expand(B, -1, -1).contiguous()
+            valid = torch.ones((B, gx * gy), dtype=torch.bool, device=cells.device)
+            _, _, w = self._run(shapes, cells, valid, torch.zeros((B, gx * gy, 2), device=cells.device), slope, obj_dim_scale,
+                                obj_dim_scale, name, True)
+            return w.view(B, -1, gx, gy), None
         B, N = batched_padded_is_valid_points.shape
         zero_flow = torch.zeros((B, N, 2), device=batched_padded_points.device)
         _, _, w = self._run(shapes, batched_padded_points, batched_padded_is_valid_points, zero_flow, slope,

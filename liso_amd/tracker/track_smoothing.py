@@ -68,16 +68,49 @@ def minimise_jerk(observed_pos, valid_mask, max_iters=2000, learning_rate=0.1, p
     return out
 
 
+def minimise_jerk_with_loss_history(observed_pos, valid_mask, max_iters=2000, learning_rate=0.1, pos_regul_loss_weight=3.0):
+    """`return_losses=True` of the reference (:142-213): the same objective stepped by torch.optim.Adam one iteration at a time (the
+    reference's formulation as tensor ops on the device), so that the three per-track loss terms of every iteration can be recorded --
+    the one-launch kernel keeps its Adam moments in registers and records nothing.  A diagnostic path (the reference uses it for
+    plots): ~25 launches per iteration.  -> (smoothed float32 [B,T,3], list of {per_batch_jerk_loss, per_batch_loss, pos_regul})"""
+    obs = observed_pos.float()
+    first = obs[:, :1].detach()
+    rest = torch.nn.Parameter(obs[:, 1:, :].clone(), requires_grad=True)  # (the first position is fixed: BatchedSmoothTrack :36-64)
+    opt = torch.optim.Adam([rest], lr=learning_rate)
+    vm = valid_mask.float()
+    n_valid = valid_mask.sum(dim=1)
+    losses = []
+    with torch.enable_grad():
+        for _ in range(max_iters):
+            opt.zero_grad()
+            pos = torch.cat([first, rest], dim=1)
+            jerk = torch.linalg.norm(torch.diff(pos, n=3, dim=1), dim=-1)
+            jerk = torch.cat([jerk, jerk.new_zeros((jerk.shape[0], pos.shape[1] - jerk.shape[1]))], dim=1)
+            jerk_loss = (jerk * vm).sum(dim=-1) / n_valid
+            shift = ((pos - obs[:, :, :3]) ** 2).sum(dim=-1)
+            regul = pos_regul_loss_weight * (shift * vm).sum(dim=-1) / n_valid
+            per_track = jerk_loss + regul
+            per_track.mean().backward()
+            losses.append({"per_batch_jerk_loss": jerk_loss.detach().cpu().numpy(), "per_batch_loss": per_track.detach().cpu().numpy(),
+                           "pos_regul": regul.detach().cpu().numpy()})
+            opt.step()
+    return torch.cat([first, rest.detach()], dim=1), losses
+
+
 @torch.no_grad()
 def smooth_track_jerk(batched_observed_pos_m, batched_valid_mask, batched_observed_yaw_angle_rad, time_between_frames_s: float,
                       pos_regul_loss_weight=3.0, max_iters=2000, learning_rate=0.1, verbose=False, return_losses=False):
-    """same arguments and return tuple (smoothed positions, headings aligned with the direction of travel, per-frame displacement) as
-    the reference.  Like the reference, the headings are written INTO `batched_observed_yaw_angle_rad` and that tensor is returned."""
-    if return_losses:
-        raise NotImplementedError("the per-iteration loss history is not recorded by the one-launch optimisation")
-    if batched_observed_pos_m.shape[1] <= 4:  # min jerk needs more than 4 frames
+    """same arguments and return tuple (smoothed positions, headings aligned with the direction of travel, per-frame displacement
+    [, loss history with return_losses]) as the reference.  Like the reference, the headings are written INTO
+    `batched_observed_yaw_angle_rad` and that tensor is returned."""
+    if batched_observed_pos_m.shape[1] <= 4:  # min jerk needs more than 4 frames (the reference returns 3 values here either way)
         return batched_observed_pos_m, batched_observed_yaw_angle_rad, batched_displacement_from_pos(batched_observed_pos_m)
-    track_positions_m = minimise_jerk(batched_observed_pos_m, batched_valid_mask, max_iters, learning_rate, pos_regul_loss_weight)
+    losses = None
+    if return_losses:
+        track_positions_m, losses = minimise_jerk_with_loss_history(batched_observed_pos_m, batched_valid_mask, max_iters, learning_rate,
+                                                                    pos_regul_loss_weight)
+    else:
+        track_positions_m = minimise_jerk(batched_observed_pos_m, batched_valid_mask, max_iters, learning_rate, pos_regul_loss_weight)
     rot_along_track = batched_observed_yaw_angle_rad.detach()
     aligned = ~batched_valid_mask
     for num_skip in range(1, min(10, track_positions_m.shape[1] // 2) + 1):
@@ -90,6 +123,8 @@ def smooth_track_jerk(batched_observed_pos_m, batched_valid_mask, batched_observ
     batch_idx = torch.arange(batched_valid_mask.shape[0], device=rot_along_track.device)
     last = batched_valid_mask.sum(dim=1) - 1
     rot_along_track[batch_idx, last, 0] = rot_along_track[batch_idx, last - 1, 0]
+    if return_losses:
+        return track_positions_m, rot_along_track, batched_displacement_from_pos(track_positions_m)[..., None], losses
     return track_positions_m, rot_along_track, batched_displacement_from_pos(track_positions_m)[..., None]
 
 

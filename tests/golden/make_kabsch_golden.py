@@ -107,6 +107,10 @@ def main():
         point_cloud_ta=pts_nan[:1].clone(), valid_mask_ta=valid[:1], pointwise_flow_ta_tb=flow_nan[:1].clone(),
         pred_boxes_ta=far, softness_func=torch.sigmoid)
     out.update(kd_far_fgT=fgT2.numpy(), kd_far_fgc=fgc2.numpy(), kd_far_bgT=bgT2.numpy(), kd_far_bgc=bgc2.numpy())
+    # --- KabschDecoder.forward without points: masks rendered on the BEV grid's pillar centres (kabsch_mask.py:274-276) ---
+    grid_w, _ = dec(boxes, obj_dim_scale=1.25)
+    grid_ws, _ = dec(boxes, softness_func=torch.sigmoid, sigmoid_slope=7.0)
+    out.update(kd_grid_w=grid_w.numpy(), kd_grid_w_sigmoid=grid_ws.numpy())
     np.savez_compressed(os.path.join(HERE, "kabsch_reference.npz"), **out)
     print({k: v.shape for k, v in out.items()})
     print("fg cum", fgc[0, :3], "far cum", fgc2, "R22", fgT[0, :, 2, 2])

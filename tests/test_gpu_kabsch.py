@@ -142,3 +142,19 @@ def test_weighted_moments_forward_backward_vs_torch_fp64():
     gb = torch.autograd.grad((ref * go).sum(), [x, y, w])
     for a, b in zip(ga, gb):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-5 * float(b.abs().max()))
+
+
+def test_bev_grid_mask_rendering_matches_reference():
+    """KabschDecoder.forward without points (kabsch_mask.py:274-276): soft masks of every box slot on the BEV grid's pillar centres,
+    [B,S,gx,gy] -- the reference's own output for both softness functions (fixture keys kd_grid_w*)"""
+    from liso_amd.kabsch.shape_utils import Shape
+
+    g = _g()
+    dec = _decoder()
+    boxes = Shape(pos=torch.from_numpy(g["kd_pos"]).cuda(), dims=torch.from_numpy(g["kd_dims"]).cuda(), rot=torch.from_numpy(g["kd_rot"]).cuda(),
+                  probs=torch.ones(2, 7, 1, device="cuda"))
+    w, logits = dec(boxes, obj_dim_scale=1.25)
+    assert logits is None and w.shape == (2, 7, 64, 64)
+    assert float((w.cpu() - torch.from_numpy(g["kd_grid_w"])).abs().max()) <= 1e-5
+    ws, _ = dec(boxes, softness_func=torch.sigmoid, sigmoid_slope=7.0)
+    assert float((ws.cpu() - torch.from_numpy(g["kd_grid_w_sigmoid"])).abs().max()) <= 1e-5

@@ -121,3 +121,19 @@ def test_bike_model_smoothing_descends_like_the_reference(tag):
         assert got <= 1.05 * want, (got, want)
         assert torch.equal(pos[..., 2].cpu(), torch.from_numpy(BG[f"{tag}_pos"])[..., 2])  # z is carried through
     assert float((pos.detach().cpu() - torch.from_numpy(BG[f"{tag}_30_pos"])).abs().max()) <= 3.0 * float(BG[f"{tag}_sensitivity"])
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_loss_history_mode_matches_the_reference_fixture(golden_dir, tag):
+    """smooth_track_jerk(..., return_losses=True) (reference :142-213, :278-284): fourth return value = one dict of per-track loss terms
+    per iteration; the last entry after 1 / 3 / 20 iterations and the positions equal the reference's"""
+    from liso_amd.tracker.track_smoothing import smooth_track_jerk
+
+    g = np.load(f"{golden_dir}/track_smoothing_reference.npz")
+    for iters, tol in ((1, 1e-5), (3, 2e-5), (20, 1e-3)):
+        pos, valid, yaw = (torch.from_numpy(g[f"{tag}_{k}"]).cuda() for k in ("pos", "valid", "yaw"))
+        p, rot, velo, losses = smooth_track_jerk(pos, valid, yaw, 0.1, max_iters=iters, return_losses=True)
+        assert len(losses) == iters and set(losses[-1]) == {"per_batch_jerk_loss", "per_batch_loss", "pos_regul"}
+        assert np.abs(p.cpu().numpy() - g[f"{tag}_{iters}_pos"]).max() <= tol
+        assert np.allclose(losses[-1]["per_batch_loss"], g[f"{tag}_{iters}_last_loss"], rtol=1e-4, atol=1e-6)
+        assert np.allclose(losses[-1]["per_batch_jerk_loss"], g[f"{tag}_{iters}_last_jerk_loss"], rtol=1e-4, atol=1e-6)

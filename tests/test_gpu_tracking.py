@@ -47,6 +47,12 @@ def test_point_masks_match_reference_fixture(golden_dir, tag):
     m64 = get_points_in_boxes_mask(boxes, homog).cpu().numpy()
     assert m64.shape == (n, boxes.shape[0]) and m64.dtype == bool
     assert np.array_equal(m64, _unpack(g[f"{tag}_mask64"], n))  # fp64 transform: bit exact
+    # return_pcl_in_box_cosy=True (reference :1914-1935): the same mask plus the points in every box's frame [N,K,4]; the mask the
+    # reference derives from that tensor (|p_box| < dims / 2 on all three axes) is the returned one
+    m2, pcl_box = get_points_in_boxes_mask(boxes, homog, return_pcl_in_box_cosy=True)
+    assert pcl_box.shape == (n, boxes.shape[0], 4) and pcl_box.dtype == homog.dtype and torch.equal(m2.cpu(), torch.from_numpy(m64))
+    derived = torch.all(torch.abs(pcl_box[:, :, 0:3]) < 0.5 * boxes.dims[None, ...], dim=-1)
+    assert int((derived.cpu() != torch.from_numpy(m64)).sum()) <= 1  # (library inverse vs closed-form pose inverse: a face-ulp point at most)
     for key, bloat in (("mask32", 1.0), ("mask32_bloat", 1.25)):
         m32 = boxes.get_points_in_box_bool_mask(pts, box_dims_bloat_factor=bloat).cpu().numpy()
         # fp32 transform: the reference's product rounds in its BLAS's order; only a point within an ulp of a face can differ
