@@ -568,6 +568,24 @@ def main():
         for name, extra in (("slim_leg", ["--workload", "slim", "--graph"]), ("detector_leg", ["--workload", "detector"]),
                             ("stress_leg", ["--workload", "stress"])):
             legs[name] = child_leg(extra, steps=min(args.steps, 10))
+    export_cost = None
+    if args.workload == "loop" and world == 1 and rank == 0 and not args.no_legs:
+        # what a flow EXPORT costs next to the loop's inference (the miner reads flow t0 -> t1 only; liso/slim/experiment.py:363-471
+        # writes both directions): eager calls on one sweep pair incl. the pillar encoders, wall time per pair
+        def wall(fn, reps=8):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            return 1e3 * (time.perf_counter() - t0) / reps
+
+        export_cost = {"forward_direction_point_flow_ms_per_pair": wall(lambda: trainer.slim.infer_point_flow_t0_t1(s0, s1)),
+                       "both_directions_bev_maps_ms_per_pair": wall(lambda: trainer.slim.infer_export_predictions(s0, s1)),
+                       "note": "eager launches, one pair, pillar encoders included (the loop replays the one-direction form from a "
+                               "hipGraph, 4 pairs per replay); SLIM.infer_export_predictions feeds liso_amd.slim.flow_io.flow_export_dict"}
     checksums = None
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -705,6 +723,8 @@ def main():
         if args.workload == "loop":
             line["mined_boxes_last_step"] = int(trainer.last_boxes.valid.sum())
         line.update(legs)
+        if export_cost is not None:
+            line["slim_flow_export_inference"] = export_cost
         if checksums is not None:
             line["replica_param_checksums"] = checksums
             line["replicas_identical"] = all(c == checksums[0] for c in checksums)

@@ -107,6 +107,21 @@ class RAFT(nn.Module):
                                                        occupancy_t0=occ_t0)
         return out[-1], aux
 
+    def infer_both_directions(self, pcl_t0, pcl_t1, canvases=None):
+        """Inference for the flow EXPORT (liso/slim/experiment.py:363-471 writes `bev_raw_flow_t0_t1` AND `bev_raw_flow_t1_t0`): both
+        flow directions as one batch of 2B samples like forward(), last RAFT iteration only.
+        -> ([B,H,W,8] forward output, [B,H,W,8] backward output, aux)"""
+        canvases = canvases if canvases is not None else self.encode_pillars(pcl_t0, pcl_t1)
+        img_t0, occ_t0, img_t1, occ_t1 = canvases[:4]
+        aux = {"t0": {"bev_net_input_dbg": occ_t0}, "t1": {"bev_net_input_dbg": occ_t1}}
+        B = img_t0.shape[0]
+        imgs = canvases[4] if len(canvases) > 4 else torch.cat([img_t0, img_t1], dim=0)
+        occ = (canvases[5] if len(canvases) > 5 else torch.cat([occ_t0, occ_t1], dim=0)) if imgs.is_cuda else None
+        fmap = self.fnet(imgs, occupancy=occ)
+        out = self.predict_single_flow_map_and_classes(imgs, fmap, torch.cat([fmap[B:], fmap[:B]], dim=0), self.head_decoder_fw,
+                                                       only_last=True, occupancy_t0=occ)
+        return out[-1][:B], out[-1][B:], aux
+
     def predict_single_flow_map_and_classes(self, img_t0, fmap_t0, fmap_t1, decoder, only_last=False, fused_dirs=None,
                                             occupancy_t0=None):
         """reference :124-259.  `only_last` (extension, inference): upsample / assemble the network output of the last

@@ -72,6 +72,29 @@ class SLIM(nn.Module):
             aggregated_flow_only=True)
         return pred.aggregated_flow
 
+    @torch.no_grad()
+    def infer_export_predictions(self, sample_data_t0, sample_data_t1):
+        """What the flow export consumes (liso/slim/experiment.py:363-471: `bev_raw_flow_t0_t1`, `bev_raw_flow_t1_t0`,
+        `bev_dynamicness_*` of the LAST RAFT iteration): both flow directions in one batched network pass, one dense decode per
+        direction -> (pred_fw, pred_bw) with `.modified_network_output.{static_flow, dynamicness}` like forward()'s preds[-1];
+        `liso_amd.slim.flow_io.flow_export_dict([pred_fw], [pred_bw], threshold, bev_range_m)` turns them into the file's arrays.
+        The training forward decodes 12 outputs for the same two."""
+        dev = next(self.raft_network.parameters()).device
+        net_fw, net_bw, aux = self.raft_network.infer_both_directions(
+            get_network_input_pcls(self.cfg, sample_data_t0, "ta", to_device=dev),
+            get_network_input_pcls(self.cfg, sample_data_t1, "ta", to_device=dev))
+        thr = self.moving_dynamicness_threshold.value()
+        common = dict(dynamicness_threshold=thr, summaries=None, gt_flow_bev=None, ohe_gt_stat_dyn_ground_label_bev_map=None,
+                      dynamic_flow_is_non_rigid_flow=self.slim_cfg.model.dynamic_flow_is_non_rigid_flow)
+        preds = []
+        for net, dec, sa, sb, occ in ((net_fw, self.head_decoder_fw, sample_data_t0, sample_data_t1, aux["t0"]["bev_net_input_dbg"]),
+                                      (net_bw, self.head_decoder_bw, sample_data_t1, sample_data_t0, aux["t1"]["bev_net_input_dbg"])):
+            pa = sa["pcl_ta"]
+            preds.append(dec(net, pointwise_valid_mask=pa["pcl_is_valid"].to(dev), pointwise_voxel_coordinates=pa["pillar_coors"].to(dev),
+                             pc=pa["pcl"].to(dev), filled_pillar_mask=torch.squeeze(occ > 0.5, dim=1),
+                             odom=sa["gt"]["odom_ta_tb"].to(dev), inv_odom=sb["gt"]["odom_ta_tb"].to(dev), **common))
+        return preds[0], preds[1]
+
     def build_gather_plan(self, sample_data_t0, sample_data_t1, n_it, grid_hw):
         """point -> BEV cell lists of the batch the decoder sees in forward(): [forward samples x n_it | backward samples x n_it].
         Depends on the sweeps only (a large device sort): callers that replay forward() from a hipGraph build it eagerly."""

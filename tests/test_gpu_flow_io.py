@@ -57,3 +57,29 @@ def test_device_ingest_matches_the_reference_fixture():
         got = flow_io.point_flow_from_bev(torch.from_numpy(fx[f"ingest_pcl_{a}"]).to(dev), torch.from_numpy(fx[f"ingest_bev_{a}_{b}"]).to(dev),
                                           fx["ingest_bev_range_m"])
         assert np.allclose(got.cpu().numpy(), fx[f"ingest_flow_{a}_{b}"], rtol=1e-5, atol=1e-6)
+
+
+def test_two_direction_export_inference_equals_the_full_forward():
+    """SLIM.infer_export_predictions (both flow directions as one batch, last RAFT iteration, one dense decode per direction) gives the
+    arrays of the reference's export -- bev_raw_flow_t0_t1 AND bev_raw_flow_t1_t0, dynamicness both ways (experiment.py:389-404) --
+    exactly as the evaluation forward's last iteration does"""
+    from liso_amd.datasets.synthetic import slim_pair
+    from liso_amd.slim.flow_io import flow_export_dict
+    from liso_amd.slim.model.slim import SLIM
+    from liso_amd.utils.config import default_cfg
+
+    dev = torch.device("cuda")
+    torch.manual_seed(4)
+    cfg = default_cfg(grid=256, bev_range_m=50.0)
+    net = SLIM(cfg, 100).to(dev).eval()
+    s0, s1 = slim_pair(21, dev, n_points=30000, grid=256, bev_range_m=50.0)
+    with torch.no_grad():
+        fw, bw = net(s0, s1, None)
+        efw, ebw = net.infer_export_predictions(s0, s1)
+    thr = net.moving_dynamicness_threshold.value()
+    full = flow_export_dict(fw, bw, thr, cfg.data.bev_range_m)
+    fast = flow_export_dict([efw], [ebw], thr, cfg.data.bev_range_m)
+    assert set(full) == set(fast) and {"bev_raw_flow_t0_t1", "bev_raw_flow_t1_t0", "bev_dynamicness_t0_t1", "bev_dynamicness_t1_t0"} <= set(fast)
+    for k in full:
+        a, b = np.asarray(full[k], np.float64), np.asarray(fast[k], np.float64)
+        assert a.shape == b.shape and np.abs(a - b).max() <= 1e-5 * max(np.abs(a).max(), 1e-6), k
