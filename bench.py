@@ -151,10 +151,11 @@ KERNELS = {  # timer name -> (kernel description, bound, unit of `units`)
     "conv_bf16_fwd": ("conv_igemm_kernel<bf16> forward (NHWC implicit GEMM on v_mfma_f32_32x32x16_bf16, fused BN-apply "
                       "prologue / bias+ReLU+BN-statistics epilogue)", "mfma", "flop"),
     "conv_bf16_dgrad": ("conv_igemm_kernel<bf16> data gradient", "mfma", "flop"),
-    "conv_bf16_wgrad": ("conv_wgrad_kernel<bf16> weight gradient (transposed LDS reads, split over pixels)", "mfma", "flop"),
+    "conv_bf16_wgrad": ("conv_wgrad_rs3_kernel<bf16> (3x3 / stride 1: all taps per block, row-stationary fragments, loader + MFMA waves) "
+                        "and conv_wgrad_kernel<bf16> (other geometries): weight gradient, split over pixels", "mfma", "flop"),
     "conv_f32x3_fwd": ("conv_igemm_kernel<bf16x3> forward (fp32 tensors, hi/lo bf16 split, 3 MFMAs per product)", "mfma", "flop"),
     "conv_f32x3_dgrad": ("conv_igemm_kernel<bf16x3> data gradient", "mfma", "flop"),
-    "conv_f32x3_wgrad": ("conv_wgrad_kernel<bf16x3> weight gradient", "mfma", "flop"),
+    "conv_f32x3_wgrad": ("conv_wgrad_rs3_kernel<bf16x3> / conv_wgrad_kernel<bf16x3> weight gradient", "mfma", "flop"),
     "conv_f32_fwd": ("conv_igemm_kernel<f32> forward (exact fp32 on v_mfma_f32_32x32x2_f32)", "mfma", "flop"),
     "conv_f32_dgrad": ("conv_igemm_kernel<f32> data gradient (exact fp32)", "mfma", "flop"),
     "conv_f32_wgrad": ("conv_wgrad_kernel<f32> weight gradient (exact fp32)", "mfma", "flop"),
@@ -204,7 +205,9 @@ def pmc_traffic(workload, patterns):
         for pat in patterns:
             for kind, factor in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
                 path = os.path.join(ROOT, "profiles", f"{rnd}_{workload}_pmc_{kind}.csv")
-                rows = [r for r in csv.DictReader(open(path)) if pat in r["Kernel_Name"]] if os.path.exists(path) else []
+                # (a pattern "a|b" pools the launches of several kernels of ONE family into one weighted mean; separate list entries
+                # are kernels that run once each per unit and are summed)
+                rows = [r for r in csv.DictReader(open(path)) if any(q in r["Kernel_Name"] for q in pat.split("|"))] if os.path.exists(path) else []
                 if not rows:
                     ok = False
                     break
@@ -219,8 +222,8 @@ def pmc_traffic(workload, patterns):
 
 
 # (template argument 1 of the convolution kernels = arithmetic: 0 bf16, 1 f32x3; forward and data gradient share the kernel)
-PMC_PATTERNS = {"conv_bf16_fwd": ["conv_igemm_kernel<0,"], "conv_bf16_dgrad": ["conv_igemm_kernel<0,"], "conv_bf16_wgrad": ["conv_wgrad_kernel<0,"],
-                "conv_f32x3_fwd": ["conv_igemm_kernel<1,"], "conv_f32x3_dgrad": ["conv_igemm_kernel<1,"], "conv_f32x3_wgrad": ["conv_wgrad_kernel<1,"],
+PMC_PATTERNS = {"conv_bf16_fwd": ["conv_igemm_kernel<0,"], "conv_bf16_dgrad": ["conv_igemm_kernel<0,"], "conv_bf16_wgrad": ["conv_wgrad_kernel<0,|conv_wgrad_rs3_kernel<0,"],
+                "conv_f32x3_fwd": ["conv_igemm_kernel<1,"], "conv_f32x3_dgrad": ["conv_igemm_kernel<1,"], "conv_f32x3_wgrad": ["conv_wgrad_kernel<1,|conv_wgrad_rs3_kernel<1,"],
                 "conv_f32_fwd": ["conv_igemm_kernel<2,"], "conv_f32_dgrad": ["conv_igemm_kernel<2,"], "conv_f32_wgrad": ["conv_wgrad_kernel<2,"],
                 "knn_query": ["knn_query_kernel"], "corr_lookup_fwd": ["corr_lookup_fwd_kernel"],
                 "pfn_forward_scatter": ["pfn_forward_kernel"],
