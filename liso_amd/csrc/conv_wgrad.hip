@@ -501,17 +501,22 @@ constexpr int RPS = 128;  // LDS bytes per pixel and plane (64 bf16 channels)
 
 // MODE = LISO_CONV_BF16 (TH = 8 | 4) or LISO_CONV_F32X3 (fp32 tensors split into bf16 hi + lo planes while they are staged, three
 // MFMAs per product; TH = 3: two buffers of two planes fit 160 KB)
-template <int MODE, int TH>
+// S = 1 | 2: the convolution's stride (3x3, padding 1).  S = 2: the halo tile holds (2 TH + 1) x 65 input pixels; a fragment's 16
+// pixels are every second pixel of a row, so pixel pairs (2, 3), (6, 7), ... swap their LDS slots and the 64-B half swap follows bit 2
+// (the four pixels of a transposing read then again fall into four different 16-bank ranges); input rows 2o and 2o + 2 of the tile
+// serve kernel rows 0 and 2 of neighbouring output rows from the same fragments.
+template <int MODE, int TH, int S>
 __global__ __launch_bounds__(kRsThreads, 1) void conv_wgrad_rs3_kernel(const liso_conv_desc d, const WgArgs a) {
     constexpr bool X3 = MODE == LISO_CONV_F32X3;
     constexpr int PLANES = X3 ? 2 : 1;
-    constexpr int IW = TW + 2, IH = TH + 2;         // halo tile (padding 1)
+    constexpr int IW = (TW - 1) * S + 3, IH = (TH - 1) * S + 3;  // halo tile (padding 1)
     constexpr int NPX = IH * IW;                     // halo pixels
+    constexpr int NSLOT = (NPX + 3) / 4 * 4;         // LDS pixel slots (S = 2 swaps pixel pairs: the last pair may reach NPX)
     constexpr int CPP = X3 ? 16 : 8;                 // 16-B global chunks per pixel (64 channels)
     constexpr int PSL = 256 / CPP;                   // pixel slots of the 256 loader threads
     constexpr int XB = (NPX + PSL - 1) / PSL;        // chunks per loader thread
     constexpr int YB = TH * TW / PSL;                // dy: TH x 32 pixels
-    constexpr int X_PLANE = NPX * RPS, Y_PLANE = TH * TW * RPS;
+    constexpr int X_PLANE = NSLOT * RPS, Y_PLANE = TH * TW * RPS;
     constexpr int X_BYTES = PLANES * X_PLANE;
     constexpr int BUF = X_BYTES + PLANES * Y_PLANE;
     constexpr int NE = X3 ? 4 : 8;                   // channels per chunk
@@ -561,7 +566,7 @@ __global__ __launch_bounds__(kRsThreads, 1) void conv_wgrad_rs3_kernel(const lis
             const int tx = tile % a.tiles_x;
             const int tq = tile / a.tiles_x;
             const int ty = tq % a.tiles_y, b = tq / a.tiles_y;
-            const int iy0 = ty * TH - 1, ix0 = tx * TW - 1;
+            const int iy0 = ty * TH * S - 1, ix0 = tx * TW * S - 1;
             const long xbase = (long)b * d.hi * d.wi * d.x_pix_stride + ch;
             const int org = (iy0 * d.wi + ix0) * d.x_pix_stride;
             const bool inner = iy0 >= 0 && iy0 + IH <= d.hi && ix0 >= 0 && ix0 + IW <= d.wi;  // (uniform) no pixel outside the image
@@ -602,7 +607,8 @@ __global__ __launch_bounds__(kRsThreads, 1) void conv_wgrad_rs3_kernel(const lis
             for (int u = 0; u < XB; u++) {
                 const int pix = p0 + u * PSL;
                 if (pix >= NPX) continue;
-                const int swz = ((pix >> 1) & 1) << 6;
+                const int swz = S == 1 ? ((pix >> 1) & 1) << 6 : ((pix >> 2) & 1) << 6;
+                const int slot = S == 1 ? pix : pix ^ ((pix >> 1) & 1);
                 if constexpr (X3) {
                     float f[4] = {__uint_as_float(xv[u].x), __uint_as_float(xv[u].y), __uint_as_float(xv[u].z), __uint_as_float(xv[u].w)};
                     unsigned hi2[2], lo2[2];
@@ -620,8 +626,8 @@ __global__ __launch_bounds__(kRsThreads, 1) void conv_wgrad_rs3_kernel(const lis
                         hi2[e] = pack_bf16(h0, h1);
                         lo2[e] = pack_bf16(f[2 * e] - h0, f[2 * e + 1] - h1);
                     }
-                    *reinterpret_cast<uint2*>(xs + pix * RPS + ((cc * 8) ^ swz)) = make_uint2(hi2[0], hi2[1]);
-                    *reinterpret_cast<uint2*>(xs + X_PLANE + pix * RPS + ((cc * 8) ^ swz)) = make_uint2(lo2[0], lo2[1]);
+                    *reinterpret_cast<uint2*>(xs + slot * RPS + ((cc * 8) ^ swz)) = make_uint2(hi2[0], hi2[1]);
+                    *reinterpret_cast<uint2*>(xs + X_PLANE + slot * RPS + ((cc * 8) ^ swz)) = make_uint2(lo2[0], lo2[1]);
                 } else {
                     uint4 o = xv[u];
                     if (pro) {
@@ -639,7 +645,7 @@ __global__ __launch_bounds__(kRsThreads, 1) void conv_wgrad_rs3_kernel(const lis
                         o = make_uint4(w[0], w[1], w[2], w[3]);
                     }
                     if (!((xok >> u) & 1u)) o = make_uint4(0u, 0u, 0u, 0u);
-                    *reinterpret_cast<uint4*>(xs + pix * RPS + ((cc * 16) ^ swz)) = o;
+                    *reinterpret_cast<uint4*>(xs + slot * RPS + ((cc * 16) ^ swz)) = o;
                 }
             }
 #pragma unroll
@@ -707,12 +713,18 @@ __global__ __launch_bounds__(kRsThreads, 1) void conv_wgrad_rs3_kernel(const lis
     // ================================ MFMA waves ================================
     const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
     const int ci_half = wave >> 1, co_half = wave & 1;
-    // lane offsets of the transposing reads for the four alignments of a fragment's first pixel (the 64-B swap follows bit 1 of the
-    // pixel index; + 4 or + 8 pixels never change it)
-    int a_lane[4];
+    // lane offsets of the transposing reads, relative to the fragment's first pixel `base`, for every alignment of `base` that changes
+    // them.  S = 1: pixel base + 8 (g >> 1) + q, the half swap follows bit 1 (4 alignments; + 4 or + 8 pixels never change it).
+    // S = 2: pixel base + 2 (8 (g >> 1) + q), slot = pixel ^ bit 1, half swap on bit 2 (8 alignments; + 8 or + 16 change neither).
+    constexpr int NAL = S == 1 ? 4 : 8;
+    int a_lane[NAL];
 #pragma unroll
-    for (int m = 0; m < 4; m++)
-        a_lane[m] = (8 * (g >> 1) + q) * RPS + ((ci_half * 64 + 32 * (g & 1) + 8 * p) ^ ((((m + q) >> 1) & 1) << 6));
+    for (int m = 0; m < NAL; m++) {
+        const int off = S * (8 * (g >> 1) + q), pm = m + S * q;  // (pixel offset; the pixel's low bits)
+        const int slot_off = S == 1 ? off : (off + ((pm ^ ((pm >> 1) & 1)) - pm));
+        const int swz = S == 1 ? ((pm >> 1) & 1) << 6 : ((pm >> 2) & 1) << 6;
+        a_lane[m] = slot_off * RPS + ((ci_half * 64 + 32 * (g & 1) + 8 * p) ^ swz);
+    }
     const int b_lane = (8 * (g >> 1) + q) * RPS + ((co_half * 64 + 32 * (g & 1) + 8 * p) ^ (((q >> 1) & 1) << 6));
 
     f16v acc[9];
@@ -720,6 +732,14 @@ __global__ __launch_bounds__(kRsThreads, 1) void conv_wgrad_rs3_kernel(const lis
     for (int i = 0; i < 9; i++)
 #pragma unroll
         for (int e = 0; e < 16; e++) acc[i][e] = 0.0f;
+
+    auto mma = [&](int i, const bf8& ah, const bf8& al, const bf8& bh, const bf8& bl) {
+        if constexpr (X3) {
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i], 0, 0, 0);
+        }
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i], 0, 0, 0);
+    };
 
     __syncthreads();  // (A)
     for (int k = 0; k < n_mine; k++) {
@@ -733,28 +753,26 @@ __global__ __launch_bounds__(kRsThreads, 1) void conv_wgrad_rs3_kernel(const lis
                 bf8 af[3], al[3];
 #pragma unroll
                 for (int kx = 0; kx < 3; kx++) {
-                    const int base = r * IW + 16 * c + kx;
-                    const unsigned char* ap = xs + base * RPS + a_lane[base & 3];
-                    af[kx] = tr_pair(ap, ap + 4 * RPS);
-                    if constexpr (X3) al[kx] = tr_pair(ap + X_PLANE, ap + X_PLANE + 4 * RPS);
+                    const int base = r * IW + 16 * S * c + kx;
+                    const unsigned char* ap = xs + base * RPS + a_lane[base & (NAL - 1)];
+                    af[kx] = tr_pair(ap, ap + 4 * S * RPS);
+                    if constexpr (X3) al[kx] = tr_pair(ap + X_PLANE, ap + X_PLANE + 4 * S * RPS);
                 }
-                if (r < TH) {
-                    const unsigned char* bp = ys + (r * TW + 16 * c) * RPS + b_lane;
-                    bf[r % 3] = tr_pair(bp, bp + 4 * RPS);
-                    if constexpr (X3) bl[r % 3] = tr_pair(bp + Y_PLANE, bp + Y_PLANE + 4 * RPS);
+                // the output row whose fragments enter the registers with this input row: S = 1: row r; S = 2: row r / 2 at even r
+                if ((S == 1 && r < TH) || (S == 2 && (r & 1) == 0 && r / 2 < TH)) {
+                    const int o = r / S;
+                    const unsigned char* bp = ys + (o * TW + 16 * c) * RPS + b_lane;
+                    bf[o % 3] = tr_pair(bp, bp + 4 * RPS);
+                    if constexpr (X3) bl[o % 3] = tr_pair(bp + Y_PLANE, bp + Y_PLANE + 4 * RPS);
                 }
 #pragma unroll
                 for (int ky = 0; ky < 3; ky++) {
-                    const int o = r - ky;
-                    if (o >= 0 && o < TH) {
+                    // input row r is row ky of output row o when r = S o + ky
+                    if ((r - ky) % S != 0) continue;
+                    const int o = (r - ky) / S;
+                    if (r - ky >= 0 && o < TH) {
 #pragma unroll
-                        for (int kx = 0; kx < 3; kx++) {
-                            if constexpr (X3) {
-                                acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[kx], bf[o % 3], acc[ky * 3 + kx], 0, 0, 0);
-                                acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kx], bl[o % 3], acc[ky * 3 + kx], 0, 0, 0);
-                            }
-                            acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kx], bf[o % 3], acc[ky * 3 + kx], 0, 0, 0);
-                        }
+                        for (int kx = 0; kx < 3; kx++) mma(ky * 3 + kx, af[kx], al[kx], bf[o % 3], bl[o % 3]);
                     }
                 }
             }
@@ -1219,7 +1237,7 @@ bool sparse_ok(const liso_conv_desc& d) {
 
 // ---- plan of the row-stationary 3x3 kernel ----------------------------------------------------------------------------------------
 struct Rs3Plan {
-    int th, lds, blocks;
+    int th, stride, lds, blocks;
     size_t slab_bytes, bias_bytes;
     WgArgs a;
 };
@@ -1230,8 +1248,10 @@ bool make_rs3_plan(const liso_conv_desc& d, Rs3Plan* p) {
     if ((d.mode != LISO_CONV_BF16 && d.mode != LISO_CONV_F32X3) || d.n_classes != 1 || d.n_taps != 9 || d.w_taps != 9) return false;
     const bool x3 = d.mode == LISO_CONV_F32X3;
     const int vec = x3 ? 4 : 8;
-    if (d.isy != 1 || d.isx != 1 || d.osy != 1 || d.osx != 1 || d.in_affine_batch_stride != 0) return false;
-    if (d.hv != d.ho || d.wv != d.wo || d.hi != d.ho || d.wi != d.wo || d.batch <= 0) return false;
+    const int S = d.isy;  // 3x3, padding 1, stride 1 or 2 (stride 2: bf16 only -- two buffers of two planes would not fit)
+    if ((S != 1 && S != 2) || d.isx != S || d.osy != 1 || d.osx != 1 || d.in_affine_batch_stride != 0) return false;
+    if (S == 2 && (x3 || getenv("LISO_WGRAD_RS3_S2_OFF"))) return false;
+    if (d.hv != d.ho || d.wv != d.wo || d.ho != (d.hi - 1) / S + 1 || d.wo != (d.wi - 1) / S + 1 || d.batch <= 0) return false;
     if (d.ci % vec || d.co % vec || d.x_pix_stride % vec || d.class_tap_begin[0] != 0 || d.class_tap_begin[1] != 9) return false;
     for (int t = 0; t < 9; t++)
         if (d.tap_dy[t] != t / 3 - 1 || d.tap_dx[t] != t % 3 - 1 || d.tap_w[t] < 0 || d.tap_w[t] >= 9) return false;
@@ -1246,7 +1266,8 @@ bool make_rs3_plan(const liso_conv_desc& d, Rs3Plan* p) {
     const long tiles8 = (long)d.batch * ((d.ho + 7) / 8) * a.tiles_x;
     int th = tiles8 >= 4 * want ? 8 : 4;
     if (const char* e = getenv("LISO_WGRAD_TH")) th = atoi(e) == 8 ? 8 : atoi(e) == 4 ? 4 : th;  // experiments
-    if (x3) th = 3;  // (two planes per operand: two buffers of a 3-row tile fit the LDS)
+    if (x3 || S == 2) th = 3;  // (two planes per operand / the (2 TH + 1) x 65 halo of stride 2: two buffers of a 3-row tile fit the LDS)
+    p->stride = S;
     a.th = th;
     a.tiles_y = (d.ho + th - 1) / th;
     a.n_tiles = d.batch * a.tiles_y * a.tiles_x;
@@ -1257,21 +1278,23 @@ bool make_rs3_plan(const liso_conv_desc& d, Rs3Plan* p) {
     a.n_groups = 1;
     p->th = th;
     p->blocks = (int)(cc * s);
-    p->lds = 2 * (x3 ? 2 : 1) * ((th + 2) * (TW + 2) + th * TW) * RPS;  // two tile buffers (of two planes each for F32X3)
+    const int npx = ((th - 1) * S + 3) * ((TW - 1) * S + 3);
+    p->lds = 2 * (x3 ? 2 : 1) * ((npx + 3) / 4 * 4 + th * TW) * RPS;  // two tile buffers (of two planes each for F32X3)
     p->slab_bytes = (size_t)s * 9 * a.ci_t * CT * a.co_t * CT * sizeof(float);
     p->bias_bytes = (size_t)s * a.co_t * CT * sizeof(float);
     return true;
 }
 
-template <int MODE, int TH>
+template <int MODE, int TH, int S>
 int launch_rs3(const liso_conv_desc& d, const Rs3Plan& p, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)conv_wgrad_rs3_kernel<MODE, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)conv_wgrad_rs3_kernel<MODE, TH, S>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
+            hipSuccess)
             return LISO_ELAUNCH;
         attr_set = true;
     }
-    conv_wgrad_rs3_kernel<MODE, TH><<<p.blocks, kRsThreads, p.lds, st>>>(d, p.a);
+    conv_wgrad_rs3_kernel<MODE, TH, S><<<p.blocks, kRsThreads, p.lds, st>>>(d, p.a);
     return hipGetLastError() == hipSuccess ? LISO_OK : LISO_ELAUNCH;
 }
 
@@ -1344,9 +1367,10 @@ int liso_conv_wgrad(const liso_conv_desc* d, const void* x, const float* in_scal
         r3.a.slab = (float*)workspace;
         r3.a.bias_slab = dbias ? (float*)((char*)workspace + r3.slab_bytes) : nullptr;
         hipStream_t st3 = (hipStream_t)stream;
-        const int rc3 = d->mode == LISO_CONV_F32X3 ? launch_rs3<LISO_CONV_F32X3, 3>(*d, r3, st3)
-                        : r3.th == 8           ? launch_rs3<LISO_CONV_BF16, 8>(*d, r3, st3)
-                                               : launch_rs3<LISO_CONV_BF16, 4>(*d, r3, st3);
+        const int rc3 = d->mode == LISO_CONV_F32X3 ? launch_rs3<LISO_CONV_F32X3, 3, 1>(*d, r3, st3)
+                        : r3.stride == 2       ? launch_rs3<LISO_CONV_BF16, 3, 2>(*d, r3, st3)
+                        : r3.th == 8           ? launch_rs3<LISO_CONV_BF16, 8, 1>(*d, r3, st3)
+                                               : launch_rs3<LISO_CONV_BF16, 4, 1>(*d, r3, st3);
         if (rc3 != LISO_OK) return rc3;
         const int co_w3 = d->wgrad_co > 0 ? d->wgrad_co : d->co;
         return launch_reduce(r3.a.slab, r3.a.bias_slab, r3.a.splits, r3.a.splits, d->w_taps, d->ci, co_w3, (long)r3.a.ci_t * CT,
