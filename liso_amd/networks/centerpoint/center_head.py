@@ -10,6 +10,35 @@ from liso_amd.networks.centerpoint.rpn import conv_bn_relu
 from liso_amd.networks.centerpoint.weight_init import kaiming_init
 
 
+class _BlockDiagonalFilters(torch.autograd.Function):
+    """The output convolutions of the heads -- same geometry, each on its own 64-channel slice of the merged hidden map -- as ONE
+    convolution: filters [sum co_k, sum ci_k, kh, kw] with head k's filter in its diagonal block and zeros elsewhere, biases
+    concatenated.  One forward, one data-gradient and one weight-gradient launch instead of four of each on 1-3 output channels
+    (launch-bound: 9 + 21 + 28 us per head at B = 4).  Backward: the diagonal blocks of the dense weight gradient."""
+
+    @staticmethod
+    def forward(ctx, n, *wb):
+        ws, bs = wb[:n], wb[n:]
+        co = [w.shape[0] for w in ws]
+        ci = [w.shape[1] for w in ws]
+        W = ws[0].new_zeros((sum(co), sum(ci)) + tuple(ws[0].shape[2:]))
+        o = c = 0
+        for w, a, b in zip(ws, co, ci):
+            W[o:o + a, c:c + b] = w
+            o, c = o + a, c + b
+        ctx.co, ctx.ci = co, ci
+        return W, torch.cat(bs)
+
+    @staticmethod
+    def backward(ctx, gW, gb):
+        gws, gbs, o, c = [], [], 0, 0
+        for a, b in zip(ctx.co, ctx.ci):
+            gws.append(gW[o:o + a, c:c + b].contiguous() if gW is not None else None)
+            gbs.append(gb[o:o + a] if gb is not None else None)
+            o, c = o + a, c + b
+        return (None, *gws, *gbs)
+
+
 class SepHead(nn.Module):
     def __init__(self, in_channels, heads, norm_cfg, head_conv=64, final_kernel=1, bn=False, **kwargs):
         super().__init__(**kwargs)
@@ -38,6 +67,17 @@ class SepHead(nn.Module):
         if not all(len(q) == 4 and isinstance(q[1], nn.BatchNorm2d) for q in seqs):
             return None
         hid, hfold = MC.fused_conv(x_raw, fold, [q[0] for q in seqs], out_bn=[q[1] for q in seqs])
+        lasts = [q[3] for q in seqs]
+        same = all(l.kernel_size == lasts[0].kernel_size and l.stride == lasts[0].stride and l.padding == lasts[0].padding and
+                   l.bias is not None for l in lasts)
+        if same and getattr(self, "merge_output_convs", True):
+            # the heads' output convolutions as one block-diagonal convolution on the whole hidden map (see _BlockDiagonalFilters);
+            # every head reads its channels of the result (a split: its backward is one concatenation of the heads' gradients)
+            import types
+
+            W, b = _BlockDiagonalFilters.apply(len(lasts), *[l.weight for l in lasts], *[l.bias for l in lasts])
+            y, _ = MC.fused_conv(hid, hfold, types.SimpleNamespace(weight=W, bias=b), out_dtype=torch.float32, spec=MC.ConvSpec.of(lasts[0]))
+            return dict(zip(self.heads, torch.split(y, [l.out_channels for l in lasts], dim=1)))
         # (split, not four slices: the backward of split is ONE concatenation of the heads' input gradients, the backward of each
         # slice a zero-filled full-width map + a copy, and autograd then adds the four maps)
         parts = torch.split(hid, [q[0].out_channels for q in seqs], dim=1)

@@ -345,3 +345,33 @@ def test_two_graph_step_with_the_backward_pass_cut_behind_block0_equals_the_one_
         out.append((losses, torch.cat([p.detach().float().flatten() for p in tr.net.parameters()]).cpu()))
     assert out[0][0] == out[1][0], (out[0][0], out[1][0])
     assert torch.equal(out[0][1], out[1][1])
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_merged_output_convolutions_of_the_heads_equal_the_four_separate_ones(dtype):
+    """SepHead.forward_fused runs the four output convolutions (64 -> 3 / 3 / 2 / 1 on their slices of the merged hidden map) as ONE
+    convolution with block-diagonal filters (center_head.py:_BlockDiagonalFilters).  Zeros off the diagonal add exact zeros: logits
+    and every gradient equal the four-launch path to fp32 summation order."""
+    tr, pcls, targets = _setup(128, 100.0, 2, 20000, dtype, seed=13)
+    head = tr.net.model.center_head.tasks[0]
+    res = []
+    for merged in (False, True):
+        head.merge_output_convs = merged
+        tr.net.zero_grad(set_to_none=True)
+        tr.optimizer.zero_grad()
+        tr.model.train()
+        with torch.no_grad():  # (same BatchNorm buffers for both passes)
+            buf = {k: v.clone() for k, v in tr.net.state_dict().items()}
+        _, _, raw, _ = tr.net(None, pcls, None, decode=False)
+        loss = sum((v.float() * torch.linspace(-1, 1, v.numel(), device=v.device).view_as(v)).sum() for v in raw.values())
+        loss.backward()
+        res.append(({k: v.detach().float().clone() for k, v in raw.items()},
+                    {n: p.grad.detach().float().clone() for n, p in tr.net.named_parameters() if p.grad is not None and "center_head" in n}))
+        tr.net.load_state_dict(buf)
+    head.merge_output_convs = True
+    for h in HEADS:
+        assert res[0][0][h].shape == res[1][0][h].shape and _rel(res[1][0][h], res[0][0][h]) <= 2e-6, (h, _rel(res[1][0][h], res[0][0][h]))
+    assert set(res[0][1]) == set(res[1][1]) and len(res[0][1]) >= 20
+    for n in res[0][1]:
+        lim = 2e-2 if dtype == torch.bfloat16 else 1e-4  # (bf16: the data gradient of the hidden map is rounded once more or less)
+        assert _rel(res[1][1][n], res[0][1][n]) <= lim, (n, _rel(res[1][1][n], res[0][1][n]))
