@@ -616,14 +616,19 @@ def _bn_backward(g, x_raw, fold):
     if len(fold.groups) == 1:
         dx, gg, gb = _bn_backward_group(g, x_raw, fold.groups[0], fold.relu, fold.training)
         return dx, [gg, gb]
-    dxs, grads, a = [], [], 0
-    for grp in fold.groups:
-        C = grp["gamma"].shape[0]
-        dx, gg, gb = _bn_backward_group(g[:, a:a + C], x_raw[:, a:a + C], grp, fold.relu, fold.training)
-        dxs.append(dx)
-        grads += [gg, gb]
-        a += C
-    return torch.cat(dxs, dim=1), grads
+    # several BatchNorms over consecutive channel ranges of one raw tensor (the deblocks' concatenation in front of the head's shared
+    # convolution, the four heads' hidden maps): BatchNorm is per channel, so ONE backward over all channels with the groups'
+    # gamma / statistics concatenated (two small launches) replaces a slice copy of x and g, three kernels per group and the
+    # concatenation of the partial results; the per-group parameter gradients are slices of its two output vectors
+    Cs = [grp["gamma"].shape[0] for grp in fold.groups]
+    gam = torch.cat([grp["gamma"].detach() for grp in fold.groups])
+    stats = torch.cat([grp["stats"][k * c:(k + 1) * c] for k in range(4) for grp, c in zip(fold.groups, Cs)])  # scale | shift | mean | invstd
+    dx, gg, gb = _bn_backward_group(g, x_raw, {"gamma": gam, "stats": stats}, fold.relu, fold.training)
+    grads, a = [], 0
+    for c in Cs:
+        grads += [gg[a:a + c], gb[a:a + c]]
+        a += c
+    return dx, grads
 
 
 class _FusedConv(torch.autograd.Function):
