@@ -623,7 +623,7 @@ def _bn_backward(g, x_raw, fold):
     Cs = [grp["gamma"].shape[0] for grp in fold.groups]
     gam = torch.cat([grp["gamma"].detach() for grp in fold.groups])
     stats = torch.cat([grp["stats"][k * c:(k + 1) * c] for k in range(4) for grp, c in zip(fold.groups, Cs)])  # scale | shift | mean | invstd
-    dx, gg, gb = _bn_backward_group(g, x_raw, {"gamma": gam, "stats": stats}, fold.relu, fold.training)
+    dx, gg, gb = _bn_backward_group(g, x_raw, {"gamma": gam, "beta": None, "stats": stats}, fold.relu, fold.training)
     grads, a = [], 0
     for c in Cs:
         grads += [gg[a:a + c], gb[a:a + c]]
