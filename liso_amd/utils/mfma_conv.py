@@ -621,6 +621,15 @@ def _bn_backward(g, x_raw, fold):
     # gamma / statistics concatenated (two small launches) replaces a slice copy of x and g, three kernels per group and the
     # concatenation of the partial results; the per-group parameter gradients are slices of its two output vectors
     Cs = [grp["gamma"].shape[0] for grp in fold.groups]
+    if sum(Cs) > 256:  # (the BatchNorm kernels take up to 256 channels per call: e.g. the deblocks' 3 x 128-channel concatenation)
+        dxs, grads, a = [], [], 0
+        for grp in fold.groups:
+            C = grp["gamma"].shape[0]
+            dx, gg, gb = _bn_backward_group(g[:, a:a + C], x_raw[:, a:a + C], grp, fold.relu, fold.training)
+            dxs.append(dx)
+            grads += [gg, gb]
+            a += C
+        return torch.cat(dxs, dim=1), grads
     gam = torch.cat([grp["gamma"].detach() for grp in fold.groups])
     stats = torch.cat([grp["stats"][k * c:(k + 1) * c] for k in range(4) for grp, c in zip(fold.groups, Cs)])  # scale | shift | mean | invstd
     dx, gg, gb = _bn_backward_group(g, x_raw, {"gamma": gam, "beta": None, "stats": stats}, fold.relu, fold.training)
