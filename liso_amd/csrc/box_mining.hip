@@ -288,12 +288,16 @@ __global__ __launch_bounds__(64) void nms_prepare_kernel(int k, int pre_nms_max,
     }
     __syncthreads();  // (one wavefront: orders the scratch stores before the reads of other lanes)
     for (int i = lane; i < k; i += 64) {
-        // position in the stable descending order of key = valid ? probs : -inf
+        // position in the stable descending order of key = valid ? probs : -inf.  A NaN confidence (a diverging detector) compares
+        // false both ways and would give several slots one rank -- slots overwritten, others stale: NaN ranks as -inf (behind every
+        // number, stable among themselves), so the order stays a permutation like the reference's torch.argsort
         const bool vi = sc[i].valid != 0;
-        const float ki = vi ? (float)sc[i].probs : -INFINITY;
+        float ki = vi ? (float)sc[i].probs : -INFINITY;
+        ki = ki != ki ? -INFINITY : ki;
         int rank = 0;
         for (int j = 0; j < k; j++) {
-            const float kj = sc[j].valid ? (float)sc[j].probs : -INFINITY;
+            float kj = sc[j].valid ? (float)sc[j].probs : -INFINITY;
+            kj = kj != kj ? -INFINITY : kj;
             rank += (kj > ki || (kj == ki && j < i)) ? 1 : 0;
         }
         const Slot s = sc[i];

@@ -76,6 +76,16 @@ def test_padded_device_nms_keeps_the_same_boxes_as_the_reference_schedule():
         assert r.shape == o.shape, (b, r.shape, o.shape)
         assert torch.equal(r.pos, o.pos) and torch.equal(r.probs, o.probs) and torch.equal(r.rot, o.rot)
     assert int(got.valid[2].sum()) == 0 and int(got.valid[0].sum()) > 5
+    # NaN confidences on valid slots (a diverging detector): the rank-by-counting order must stay a permutation -- every surviving
+    # box is one of the inputs, none twice, and the boxes with real confidences are selected as if the NaN boxes came last
+    probs_nan = probs.clone()
+    probs_nan[0, 5:12, 0] = float("nan")
+    boxes_nan = Shape(pos=pos.cuda(), dims=dims.cuda(), rot=rot.cuda(), probs=probs_nan.cuda(), valid=valid.cuda())
+    out = perform_nms_on_shapes_padded(boxes_nan.clone(), max_num_boxes=40, overlap_threshold=0.1, pre_nms_max_num_boxes=200)
+    kept = out[0].drop_padding_boxes()
+    src = pos[0].cuda()
+    idx = [int(torch.nonzero((src == p).all(dim=-1))[0, 0]) for p in kept.pos.float()]
+    assert len(set(idx)) == len(idx) and all(bool(valid[0, i]) for i in idx)
 
 
 def test_liso_loop_full_size_120k_512_bf16():
