@@ -1183,6 +1183,15 @@ bool make_plan(const liso_conv_desc& d, Plan* p) {
         // without a block -> 32-channel panels double the block count (the tile is re-staged from L2 by twice as many blocks)
         const long tiles4 = (long)d.n_classes * d.batch * ((d.hv + 3) / 4) * ((d.wv + 31) / 32);
         if (p->nj == 2 && tiles4 * ((d.co + 63) / 64) < 160) p->nj = 1;
+        if (p->nj == 2 && x3) {
+            // F32X3 launches of a few hundred blocks are bound by the MFMA stream of the busiest CU: blocks per CU x work per block.
+            // 64-channel panels on 384 blocks (ConvGRU z|r, 4 pairs: 128 tiles x 3 panels) give half the CUs two blocks of work 2;
+            // 32-channel panels give every CU three blocks of work 1 (+ the tile staged twice as often: charged as 0.3 per block)
+            const long b2 = tiles4 * ((d.co + 63) / 64), b1 = tiles4 * ((d.co + 31) / 32);
+            const double c2 = (double)((b2 + 255) / 256) * 2.3, c1 = (double)((b1 + 255) / 256) * 1.3;
+            static const bool auto_nj = getenv("LISO_CONV_NJ_AUTO") == nullptr || atoi(getenv("LISO_CONV_NJ_AUTO")) != 0;
+            if (auto_nj && b1 <= 2048 && c1 < c2) p->nj = 1;
+        }
         if (const char* e = getenv("LISO_CONV_NJ")) {  // experiments: 1 | 2 force the panel width
             if (atoi(e) == 1) p->nj = 1;
             if (atoi(e) == 2 && d.co > 32) p->nj = 2;
