@@ -1189,7 +1189,8 @@ bool make_plan(const liso_conv_desc& d, Plan* p) {
             // 32-channel panels give every CU three blocks of work 1 (+ the tile staged twice as often: charged as 0.3 per block)
             const long b2 = tiles4 * ((d.co + 63) / 64), b1 = tiles4 * ((d.co + 31) / 32);
             const double c2 = (double)((b2 + 255) / 256) * 2.3, c1 = (double)((b1 + 255) / 256) * 1.3;
-            static const bool auto_nj = getenv("LISO_CONV_NJ_AUTO") == nullptr || atoi(getenv("LISO_CONV_NJ_AUTO")) != 0;
+            // MEASURED (round 4): no gain in the loop (5.70 vs 5.69 ms), SLIM train step slower (15.5 vs 14.9 ms): off unless asked for
+            static const bool auto_nj = getenv("LISO_CONV_NJ_AUTO") != nullptr && atoi(getenv("LISO_CONV_NJ_AUTO")) != 0;
             if (auto_nj && b1 <= 2048 && c1 < c2) p->nj = 1;
         }
         if (const char* e = getenv("LISO_CONV_NJ")) {  // experiments: 1 | 2 force the panel width
