@@ -45,6 +45,9 @@ class _CorrFeatures(torch.autograd.Function):
         if dvol is None:
             return (None, torch.zeros_like(fmap1)) + tuple(torch.zeros_like(l) for l in levels)
         B, hw, D = fmap1.shape
+        own = _own_gemms(fmap1, dvol, levels)
+        if own is not None:
+            return (None, own[0]) + tuple(own[1])
         g1 = None
         g2 = []
         for dv, f2 in zip(dvol, levels):
@@ -52,6 +55,41 @@ class _CorrFeatures(torch.autograd.Function):
             g1 = torch.bmm(dv, f2m) if g1 is None else torch.baddbmm(g1, dv, f2m)
             g2.append(torch.bmm(dv.transpose(1, 2), fmap1).view_as(f2))
         return (None, g1) + tuple(g2)
+
+
+def _own_gemms(fmap1, dvol, levels):
+    """The two dense contractions of the correlation backward (liso/slim/model/raft_code/corr.py:48-56 is `fmap1^T fmap2`; its adjoint
+    per level: d fmap1 += dvol . fmap2_l and d fmap2_l = dvol^T . fmap1) on the own MFMA kernels instead of rocBLAS batched GEMMs:
+    per sample, `dvol . fmap2_l` is a 1x1 convolution over the hw query pixels with HW_l input channels and the pooled feature map as
+    its [D, HW_l] filter, and `dvol^T . fmap1` is that convolution's WEIGHT gradient (sum over the query pixels of dvol[pixel, :]
+    x fmap1[pixel, :]) -- fp32 tensors on the arithmetic of the process (F32X3 or exact fp32).  -> (g1 [B,hw,D], [g2_l like level l])
+    or None when the kernels do not cover the shapes (channel counts must be multiples of 4)."""
+    from liso_amd.utils import mfma_conv as MC
+
+    B, hw, D = fmap1.shape
+    if not fmap1.is_cuda or MC.backend() != "mfma" or fmap1.dtype != torch.float32 or D % 4 or hw % 32:
+        return None
+    rows = hw // 32  # (a 1x1 convolution does not care how the query pixels are arranged: rows of 32 = the kernels' tile width)
+    if any(dv.shape[2] % 4 for dv in dvol):
+        return None
+    spec = MC.ConvSpec(1, 1, 1, 0, False)
+    g1 = torch.empty_like(fmap1)
+    g2 = [torch.empty_like(f2) for f2 in levels]
+    for lvl, (dv, f2, out2) in enumerate(zip(dvol, levels, g2)):
+        n = dv.shape[2]  # HW_l
+        f2m = f2.reshape(B, n, D)
+        for b in range(B):
+            x = dv[b].view(1, rows, 32, n).permute(0, 3, 1, 2)                   # logical [1, C = HW_l, hw / 32, 32], channels last
+            w = f2m[b].t().reshape(D, n, 1, 1).contiguous()                      # filter [D, HW_l, 1, 1]
+            y, _ = MC.conv_forward(x, w, None, spec)                             # [1, D, hw / 32, 32], stored [1, hw / 32, 32, D]
+            yb = y.permute(0, 2, 3, 1).reshape(hw, D)
+            g1[b].copy_(yb) if lvl == 0 else g1[b].add_(yb)
+            dyv = fmap1[b].view(1, rows, 32, D).permute(0, 3, 1, 2)              # "dy" [1, D, hw / 32, 32]
+            res = MC.conv_wgrad(x, dyv, (D, n, 1, 1), spec, want_bias=False)     # dW[d, c] = sum_pixels dy[pixel, d] x[pixel, c]
+            if res is None:
+                return None
+            out2.view(B, n, D)[b].copy_(res[0].view(D, n).t())
+    return g1, g2
 
 
 class _CorrLookup(torch.autograd.Function):
