@@ -10,6 +10,8 @@ into feature gradients with two GEMMs per level, once per CorrBlock instead of o
 """
 import ctypes
 
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -68,6 +70,11 @@ def _own_gemms(fmap1, dvol, levels):
 
     B, hw, D = fmap1.shape
     if not fmap1.is_cuda or MC.backend() != "mfma" or fmap1.dtype != torch.float32 or D % 4 or hw % 32:
+        return None
+    if os.environ.get("LISO_CORR_OWN_GEMM", "0") != "1":
+        # measured on the SLIM step (120k points, 512^2): 15.6 ms with these launches vs 14.8 ms with the library's batched GEMMs --
+        # a [4096 x 4096] . [4096 x 128] product as a 1x1 convolution is 64 blocks walking 128 channel slabs each; rocBLAS is 0.7 %
+        # of the step.  Kept as a tested option (LISO_CORR_OWN_GEMM=1: no rocBLAS kernel in the step), off by default.
         return None
     rows = hw // 32  # (a 1x1 convolution does not care how the query pixels are arranged: rows of 32 = the kernels' tile width)
     if any(dv.shape[2] % 4 for dv in dvol):

@@ -58,15 +58,22 @@ def test_corr_lookup_vs_explicit_volume(h, w, B):
     assert _rel(out, ref.cpu().numpy()) < 1e-4
 
 
-def test_corr_lookup_backward_accumulates_over_lookups():
+@pytest.mark.parametrize("own_gemms,h,w", [(False, 24, 40), (True, 32, 32)])
+def test_corr_lookup_backward_accumulates_over_lookups(own_gemms, h, w, monkeypatch):
     """three lookups (RAFT iterations) through ONE CorrBlock: the deferred dense-volume backward must equal autograd
-    through the reference's explicit volume + avg_pool2d + grid_sample path (corr.py:6-46), and be bit reproducible"""
+    through the reference's explicit volume + avg_pool2d + grid_sample path (corr.py:6-46), and be bit reproducible.
+    `own_gemms`: the two contractions per level on the own MFMA kernels (LISO_CORR_OWN_GEMM=1) instead of the library's GEMMs"""
     import torch.nn.functional as F
 
+    from liso_amd.slim.model.raft_code import corr as corr_mod
     from liso_amd.slim.model.raft_code.corr import CorrBlock
     from liso_amd.slim.model.raft_code.utils import bilinear_sampler, coords_grid
 
-    B, h, w = 2, 24, 40
+    monkeypatch.setenv("LISO_CORR_OWN_GEMM", "1" if own_gemms else "0")
+    taken = []
+    inner = corr_mod._own_gemms
+    monkeypatch.setattr(corr_mod, "_own_gemms", lambda *a: taken.append(inner(*a)) or taken[-1])
+    B = 2
     torch.manual_seed(5)
     f1 = torch.randn(B, 128, h, w, device="cuda", requires_grad=True)
     f2 = torch.randn(B, 128, h, w, device="cuda", requires_grad=True)
@@ -95,6 +102,7 @@ def test_corr_lookup_backward_accumulates_over_lookups():
     (a1, a2), (b1, b2), (e1, e2) = ours(), ours(), explicit()
     assert torch.equal(a1, b1) and torch.equal(a2, b2)  # no float atomics anywhere
     assert _rel(a1, e1.cpu().numpy()) < 1e-4 and _rel(a2, e2.cpu().numpy()) < 1e-4
+    assert len(taken) == 2 and all((t is not None) == own_gemms for t in taken)
 
 
 def _build(seed=1234):
