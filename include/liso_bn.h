@@ -38,6 +38,13 @@ int liso_bn_relu_bwd(const void* dy, const void* x, int is_bf16, long m, int c, 
                      int training, int relu, void* dx, float* grad_gamma, float* grad_beta, void* workspace,
                      size_t workspace_bytes, void* stream);
 
+/* The same backward in TWO launches instead of three: the last block of the reduction to finish also turns the partial sums into
+ * grad_gamma / grad_beta / the dx coefficients.  `ticket`: one device-resident unsigned that is ZERO on entry and zero again on
+ * return (the caller keeps one per BatchNorm layer, zeroed once; two calls in flight at the same time must not share it). */
+int liso_bn_relu_bwd_ticket(const void* dy, const void* x, int is_bf16, long m, int c, const float* gamma, const float* stats,
+                            int training, int relu, void* dx, float* grad_gamma, float* grad_beta, void* workspace,
+                            size_t workspace_bytes, unsigned* ticket, void* stream);
+
 /* ---- InstanceNorm2d(+ReLU), training: the same passes with one set of statistics per sample ---------------------------------
  * Replaces `nn.InstanceNorm2d(affine=True)` + `ReLU` of the SLIM encoders in training (liso/slim/model/extractor.py:24-38,
  * 219-230; norm_fn "instance" / "instance_affine"), which PyTorch runs through the BatchNorm kernels on a [1, B*C, H, W] view

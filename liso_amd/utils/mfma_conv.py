@@ -582,6 +582,32 @@ def _direct_target(p):
     return g
 
 
+_BN_TICKETS = {}  # device index -> [int32 zeros, {layer key: slot}]
+
+
+def _bn_ticket(key, device):
+    """the layer's persistent device counter for liso_bn_relu_bwd_ticket (zero between calls), or None: the pool of a device is
+    created on the first EAGER call (memory allocated while a graph is being captured belongs to that graph's pool) and, like every
+    trainer here, a captured step is preceded by an eager warm-up pass; LISO_BN_TICKET=1 enables it"""
+    if os.environ.get("LISO_BN_TICKET", "0") != "1":
+        # MEASURED (round 4): slower than the separate finalize launch it saves -- detector step 4.57-4.63 vs 4.46 ms, loop 5.66 vs
+        # 5.65 ms (with plain stores + __threadfence(): 4.84 / 6.03 ms -- a device-scope release fence writes back the XCD's L2).
+        # Inside a hipGraph the extra launch costs ~2 us of stream time; the last block's 256-thread finalize over L2-bypassing
+        # loads costs more.  Off unless asked for.
+        return None
+    ent = _BN_TICKETS.get(device.index)
+    if ent is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        ent = _BN_TICKETS[device.index] = [torch.zeros(4096, dtype=torch.int32, device=device), {}]
+    slot = ent[1].get(key)
+    if slot is None:
+        if len(ent[1]) >= ent[0].numel():
+            return None
+        slot = ent[1][key] = len(ent[1])
+    return ent[0][slot:slot + 1]
+
+
 def _bn_backward_group(g, x_raw, grp, relu, training):
     """gradient through relu?(bn(x_raw)) of ONE BatchNorm given g = dL/d(output): -> (dx_raw, dgamma, dbeta);
     g, x_raw logical NCHW (channel slices are copied: the kernels of include/liso_bn.h take dense [M, C] rows)"""
@@ -603,11 +629,16 @@ def _bn_backward_group(g, x_raw, grp, relu, training):
     gb = tb if direct else torch.empty(C, dtype=torch.float32, device=xv.device)
     nbytes = lib.liso_bn_workspace_bytes(C)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=xv.device)
+    ticket = _bn_ticket(grp.get("ticket_key", id(grp["gamma"])), xv.device)
+    args = (L.ptr(gv), L.ptr(xv), int(xv.dtype == torch.bfloat16), M, C, L.ptr(grp["gamma"]), L.ptr(grp["stats"]), int(training),
+            int(relu), L.ptr(dx), L.ptr(gg), L.ptr(gb), L.ptr(ws), nbytes)
     with torch.cuda.device(xv.device):
-        L.check(L.TIMER.launch("bn_bwd", lambda: lib.liso_bn_relu_bwd(
-            L.ptr(gv), L.ptr(xv), int(xv.dtype == torch.bfloat16), M, C, L.ptr(grp["gamma"]), L.ptr(grp["stats"]), int(training),
-            int(relu), L.ptr(dx), L.ptr(gg), L.ptr(gb), L.ptr(ws), nbytes, L.stream_ptr()),
-            units=5 * M * C * xv.element_size()), "bn_relu_bwd")
+        if ticket is not None:  # two launches: the reduction's last block also finalises (include/liso_bn.h)
+            L.check(L.TIMER.launch("bn_bwd", lambda: lib.liso_bn_relu_bwd_ticket(*args, L.ptr(ticket), L.stream_ptr()),
+                                   units=5 * M * C * xv.element_size()), "bn_relu_bwd_ticket")
+        else:
+            L.check(L.TIMER.launch("bn_bwd", lambda: lib.liso_bn_relu_bwd(*args, L.stream_ptr()),
+                                   units=5 * M * C * xv.element_size()), "bn_relu_bwd")
     return dx.permute(0, 3, 1, 2), (None if direct else gg), (None if direct else gb)
 
 
@@ -632,7 +663,8 @@ def _bn_backward(g, x_raw, fold):
         return torch.cat(dxs, dim=1), grads
     gam = torch.cat([grp["gamma"].detach() for grp in fold.groups])
     stats = torch.cat([grp["stats"][k * c:(k + 1) * c] for k in range(4) for grp, c in zip(fold.groups, Cs)])  # scale | shift | mean | invstd
-    dx, gg, gb = _bn_backward_group(g, x_raw, {"gamma": gam, "beta": None, "stats": stats}, fold.relu, fold.training)
+    dx, gg, gb = _bn_backward_group(g, x_raw, {"gamma": gam, "beta": None, "stats": stats, "ticket_key": id(fold.groups[0]["gamma"])},
+                                    fold.relu, fold.training)
     grads, a = [], 0
     for c in Cs:
         grads += [gg[a:a + c], gb[a:a + c]]

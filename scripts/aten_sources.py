@@ -17,6 +17,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from liso_amd.utils.config import apply_slim_simple_knn_training, default_cfg  # noqa: E402
 
 what = sys.argv[1] if len(sys.argv) > 1 else "loop"
+GRAPH = what.endswith("-graph")  # the pipelined / captured step instead of the eager pass: ops inside captures + eager ops of a late step
+what = what.replace("-graph", "")
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 cfg = default_cfg(grid=512, bev_range_m=100.0)
@@ -25,9 +27,17 @@ if what == "loop":
     from liso_amd.trainer import LisoLoopTrainer
 
     cfg = apply_slim_simple_knn_training(cfg)
-    tr = LisoLoopTrainer(cfg, dev, compute_dtype=torch.bfloat16, total_steps=16, use_graph=False, overlap=False)
-    pairs = [slim_pair(2 + 100 * i, dev, n_points=120000, grid=512, bev_range_m=100.0) for i in range(2)]
-    run = lambda: tr.eager_pass_batch(pairs)  # noqa: E731
+    tr = LisoLoopTrainer(cfg, dev, compute_dtype=torch.bfloat16, total_steps=64, use_graph=GRAPH, overlap=GRAPH, infer_batch=4, flow_ahead=2)
+    pairs = [slim_pair(2 + 100 * i, dev, n_points=120000, grid=512, bev_range_m=100.0) for i in range(16 if GRAPH else 2)]
+    if GRAPH:
+        ctr = [0]
+
+        def run():
+            i = ctr[0] * 2
+            ctr[0] += 1
+            return tr.step_batch([pairs[(i + k) % 16] for k in range(2)], upcoming=tuple(pairs[(i + k) % 16] for k in range(2, 2 + 11)))
+    else:
+        run = lambda: tr.eager_pass_batch(pairs)  # noqa: E731
 elif what == "slim":
     from liso_amd.datasets.synthetic import slim_pair
     from liso_amd.trainer import SlimTrainer
@@ -40,12 +50,13 @@ else:
     from liso_amd.datasets.synthetic import detector_batch
     from liso_amd.trainer import DetectorTrainer
 
-    tr = DetectorTrainer(cfg, dev, compute_dtype=torch.bfloat16, total_steps=16, use_graph=False)
+    tr = DetectorTrainer(cfg, dev, compute_dtype=torch.bfloat16, total_steps=64, use_graph=GRAPH)
     pcls, targets = detector_batch(seed=1, batch=4, device=dev, n_points=120000, grid=512, bev_range_m=100.0)
-    run = lambda: tr.eager_pass(pcls, targets)  # noqa: E731
+    run = (lambda: tr.step(pcls, targets)) if GRAPH else (lambda: tr.eager_pass(pcls, targets))  # noqa: E731
 
-for _ in range(2):
-    run()
+if not GRAPH:
+    for _ in range(2):
+        run()
 torch.cuda.synchronize()
 import traceback  # noqa: E402
 
@@ -85,12 +96,23 @@ class Count(TorchDispatchMode):
             if "/liso_amd/" in fs.filename or fs.filename.endswith("bench.py"):
                 frame = f"{fs.filename.split(ROOT + '/')[-1]}:{fs.lineno} {fs.name}"
                 break
+        if GRAPH:
+            if torch.cuda.is_current_stream_capturing():
+                frame = "[in graph] " + frame
+            elif STEP[0] < LAST:
+                return out  # (eager ops of the early steps: warm-up passes in front of the captures)
         agg[(frame, name)] += 1
         return out
 
 
+STEP, LAST = [0], 11
 with Count():
-    run()
+    if GRAPH:  # every capture happens within the first steps; the eager-side ops are those of the last one
+        for k in range(LAST + 1):
+            STEP[0] = k
+            run()
+    else:
+        run()
 torch.cuda.synchronize()
 print(f"# {what}: {sum(agg.values())} framework ops that launch kernels in one eager pass")
 by_frame = collections.defaultdict(lambda: [0, []])

@@ -106,3 +106,31 @@ def test_instance_norm_relu_matches_fp64_module(C, H, W, B, affine, relu, dtype)
     assert _rel(xg.grad, xd.grad) < tb
     if affine:
         assert _rel(norm.weight.grad, ref.weight.grad) < tb and _rel(norm.bias.grad, ref.bias.grad) < tb
+
+
+@pytest.mark.parametrize("C,HW,N,dtype", [(64, 256, 2, torch.bfloat16), (128, 64, 4, torch.float32), (256, 32, 1, torch.bfloat16),
+                                          (64, 8, 1, torch.float32)])
+def test_bn_backward_with_last_block_finalize_equals_three_launch_form(C, HW, N, dtype, monkeypatch):
+    """liso_bn_relu_bwd_ticket (the reduction's last block finalises: 2 launches) against liso_bn_relu_bwd (3 launches) on the same
+    tensors: same dx / dgamma / dbeta (fp64 merge of the same partial sums, different chunking), the layer's counter is zero again
+    after every call, and repeated calls reuse it"""
+    from liso_amd.utils import mfma_conv as MC
+
+    torch.manual_seed(C + HW)
+    x = (torch.randn(N, C, HW, HW, device="cuda") * 0.5 + 0.2).to(dtype).contiguous(memory_format=torch.channels_last)
+    g = torch.randn(N, C, HW, HW, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)
+    gamma = torch.nn.Parameter(torch.rand(C, device="cuda") + 0.5)
+    mean = x.float().mean(dim=(0, 2, 3))
+    invstd = (x.float().var(dim=(0, 2, 3), unbiased=False) + 1e-3).rsqrt()
+    beta = torch.randn(C, device="cuda") * 0.1
+    stats = torch.cat([gamma.detach() * invstd, beta - mean * gamma.detach() * invstd, mean, invstd]).contiguous()
+    grp = {"gamma": gamma, "beta": None, "stats": stats}
+    monkeypatch.setenv("LISO_BN_TICKET", "0")
+    dx0, gg0, gb0 = MC._bn_backward_group(g, x, grp, True, True)
+    monkeypatch.setenv("LISO_BN_TICKET", "1")
+    for _ in range(3):
+        dx1, gg1, gb1 = MC._bn_backward_group(g, x, grp, True, True)
+        pool, slots = MC._BN_TICKETS[x.device.index]
+        assert id(gamma) in slots and int(pool.abs().sum()) == 0
+        assert _rel(gg1, gg0) < 1e-6 and _rel(gb1, gb0) < 1e-6
+        assert _rel(dx1.float(), dx0.float()) < (1e-6 if dtype == torch.float32 else 1e-2)
