@@ -486,6 +486,11 @@ def main():
             torch.manual_seed(0)
             trainer = SlimTrainer(cfg, dev, use_graph=False)
             step = lambda: trainer.step(s0, s1)  # noqa: E731
+    main_stream = None
+    if os.environ.get("LISO_MAIN_PRIORITY"):  # experiment: the detector step's stream above the SLIM inference stream
+        torch.cuda.synchronize()
+        main_stream = torch.cuda.Stream(device=dev, priority=int(os.environ["LISO_MAIN_PRIORITY"]))
+        torch.cuda.set_stream(main_stream)
     for _ in range(args.warmup):
         step()
 

@@ -38,6 +38,14 @@ int liso_adamw_step_f32(float* param, const float* grad, float* exp_avg, float* 
 int liso_adamw_step_scaled_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr, double beta1,
                                double beta2, double eps, double weight_decay, double grad_scale, long step, void* stream);
 
+/* `count` fp32 arrays copied into their destinations by ONE launch per LISO_GATHER_MAX jobs: dst[k][0 .. numel[k]) = src[k][...].
+ * The detector step uses it for the parameter gradients that autograd hands back as tensors of their own (merged / sliced
+ * parameters whose gradient no kernel can write in place): with `.grad = None` autograd keeps those tensors instead of launching one
+ * `add_` per parameter into the zeroed flat buffer (torch/csrc/autograd/functions/accumulate_grad.h), and this call moves all of
+ * them into their flat-buffer slices.  src / dst / numel are HOST arrays of device pointers / element counts (baked into the launch). */
+#define LISO_GATHER_MAX 48
+int liso_gather_f32(int count, const void* const* src, void* const* dst, const size_t* numel, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

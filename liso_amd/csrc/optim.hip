@@ -54,7 +54,41 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, 
     }
 }
 
+// ---- gradients that autograd produced outside the flat buffer: one launch moves all of them into their slices ----------------------
+struct GatherTable {
+    const float* src[LISO_GATHER_MAX];
+    float* dst[LISO_GATHER_MAX];
+    unsigned n[LISO_GATHER_MAX];
+};
+
+__global__ __launch_bounds__(256) void gather_f32_kernel(GatherTable t) {
+    const float* __restrict__ s = t.src[blockIdx.y];
+    float* __restrict__ d = t.dst[blockIdx.y];
+    const unsigned n = t.n[blockIdx.y];
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) d[i] = s[i];
+}
+
 }  // namespace
+
+extern "C" int liso_gather_f32(int count, const void* const* src, void* const* dst, const size_t* numel, void* stream) {
+    if (count < 0 || (count > 0 && (!src || !dst || !numel))) return LISO_EINVAL;
+    for (int base = 0; base < count; base += LISO_GATHER_MAX) {
+        GatherTable t;
+        const int m = count - base < LISO_GATHER_MAX ? count - base : LISO_GATHER_MAX;
+        size_t longest = 0;
+        for (int k = 0; k < m; k++) {
+            if (!src[base + k] || !dst[base + k] || numel[base + k] > 0xffffffffull) return LISO_EINVAL;
+            t.src[k] = (const float*)src[base + k];
+            t.dst[k] = (float*)dst[base + k];
+            t.n[k] = (unsigned)numel[base + k];
+            longest = numel[base + k] > longest ? numel[base + k] : longest;
+        }
+        size_t bx = (longest + 1023) / 1024;  // (4 elements per thread and pass)
+        bx = bx < 1 ? 1 : (bx > 64 ? 64 : bx);
+        hipLaunchKernelGGL(gather_f32_kernel, dim3((unsigned)bx, (unsigned)m), dim3(256), 0, (hipStream_t)stream, t);
+    }
+    return hipGetLastError() == hipSuccess ? LISO_OK : LISO_ELAUNCH;
+}
 
 extern "C" int liso_adamw_step_scaled_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr,
                                           double beta1, double beta2, double eps, double weight_decay, double grad_scale, long step,

@@ -23,6 +23,20 @@ def change_flow_convention_from_raft2usfl(flow, resolution_adapter):
     return torch.flip(flow, dims=[1]) * resolution_adapter
 
 
+def _in_passes(net, x, occ, images_per_pass, half=False):
+    """encoder `net` on the batch `x` in passes of at most `images_per_pass` images (None: one pass).  Inference batches of many
+    sweep pairs: the update block gains from every extra pair per launch, the encoders' 256^2 x 32-channel fp32 activations
+    (8.4 MB per image and tensor) stop fitting the 256-MB Infinity Cache beyond ~8 images per pass.  Per-sample normalisation
+    (InstanceNorm) or none: the result does not depend on the split."""
+    n = images_per_pass
+    if n is not None and half:
+        n = max(1, n // 2)
+    if n is None or x.shape[0] <= n:
+        return net(x, occupancy=occ) if occ is not None else net(x)
+    outs = [net(x[k:k + n], occupancy=occ[k:k + n]) if occ is not None else net(x[k:k + n]) for k in range(0, x.shape[0], n)]
+    return torch.cat(outs, dim=0)
+
+
 class RAFT(nn.Module):
     def __init__(self, cfg, head_decoder_fw, head_decoder_bw, **kwargs):
         super().__init__(**kwargs)
@@ -102,7 +116,8 @@ class RAFT(nn.Module):
         B = img_t0.shape[0]
         # (canvases[4] / [5]: both sweeps stacked along the batch axis and their occupancy maps, when the caller holds them that way)
         occ_all = canvases[5] if len(canvases) > 5 else None
-        fmap = self.fnet(canvases[4] if len(canvases) > 4 else torch.cat([img_t0, img_t1], dim=0), occupancy=occ_all)
+        fmap = _in_passes(self.fnet, canvases[4] if len(canvases) > 4 else torch.cat([img_t0, img_t1], dim=0), occ_all,
+                          getattr(self, "encoder_images_per_pass", None))
         out = self.predict_single_flow_map_and_classes(img_t0, fmap[:B], fmap[B:], self.head_decoder_fw, only_last=True,
                                                        occupancy_t0=occ_t0)
         return out[-1], aux
@@ -139,7 +154,10 @@ class RAFT(nn.Module):
         use_w = m.predict_weight_for_static_aggregation is not False
         wl = torch.zeros((b, 1, h, w), dtype=torch.float32, device=img_t0.device) if use_w else None
         correlation = CorrBlock(fmap_t0, fmap_t1, num_levels=m.corr_cfg.num_levels, radius=m.corr_cfg.search_radius)
-        cnet = self.cnet(img_t0, occupancy=occupancy_t0) if occupancy_t0 is not None else self.cnet(img_t0)
+        if occupancy_t0 is not None:
+            cnet = _in_passes(self.cnet, img_t0, occupancy_t0, getattr(self, "encoder_images_per_pass", None) if only_last else None, half=True)
+        else:
+            cnet = self.cnet(img_t0)
         net, inp = torch.split(cnet, [self.hidden_dim, self.context_dim], dim=1)
         net, inp = torch.tanh(net), torch.relu(inp)
         # (rows, cols) metres per pixel; equal (asserted in __init__), so a python scalar does the job of the reference's

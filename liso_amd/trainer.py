@@ -255,6 +255,7 @@ class DetectorTrainer:
         from liso_amd.utils import mfma_conv as MC
 
         self._pack_jobs = None
+        self._gather_params = None
 
         cut = self._grad_cut if self.n_grad_buckets == 2 else None
         rpn = self.net.model.rpn
@@ -268,6 +269,9 @@ class DetectorTrainer:
                     self._step_packs = MC.batched_pack(self._pack_jobs)
             MC.set_step_packs(getattr(self, "_step_packs", None))
             MC.set_direct_grads(True, keep_touched=part == 2)  # gradients of conv / BatchNorm parameters land in the flat buffer without an add each
+            gathered = self._gather_params or []
+            for p_, _ in gathered:  # (autograd then KEEPS the gradient tensor it is handed instead of adding it into the zeroed slice)
+                p_.grad = None
             try:
                 if part in (None, 1):
                     rpn.grad_cut = cut
@@ -282,12 +286,22 @@ class DetectorTrainer:
             finally:
                 MC.set_step_packs(None)
                 MC.set_direct_grads(False, keep_touched=True)
+                self._gather_gradients(gathered, add=part == 2)
             return self._body_loss
 
+        self._gather_params = None
         with torch.cuda.stream(side):  # warm-up off the capture: lazy initialisations, allocator pools
             MC.record_pack_jobs(True)
             body()
             self._pack_jobs = MC.record_pack_jobs(False)
+            if os.environ.get("LISO_GATHER_GRADS", "1") != "0":
+                # parameters whose gradient no kernel wrote in place during that pass (merged head convolutions, sliced BatchNorm
+                # vectors, block-diagonal filters): autograd would launch one `add_` each into the zeroed flat buffer -- instead
+                # their gradient tensors are collected behind the backward pass by ONE launch (liso_gather_f32)
+                in_place = MC.direct_touched()
+                outside = {id(p_) for p_ in self.net.model.pfn.parameters()}  # (the pillar encoder's backward runs outside the graph)
+                self._gather_params = [(p_, p_.grad) for p_ in self.net.parameters()
+                                       if p_.requires_grad and p_.grad is not None and id(p_) not in in_place and id(p_) not in outside]
             body()
         torch.cuda.current_stream(dev).wait_stream(side)
         with torch.no_grad():  # the warm-up passes must not count as training steps (BatchNorm statistics / counters)
@@ -312,6 +326,33 @@ class DetectorTrainer:
                     v.copy_(buffers[k])
         if quiet:
             torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(True)
+
+    def _gather_gradients(self, params, add=False):
+        """`params`: (parameter, its flat-buffer gradient view) whose `.grad` was None during the backward pass.  Their gradient
+        tensors -> the flat views by one launch; `.grad` is the flat view again afterwards.  `add`: the second half of a split backward
+        pass adds (nothing arrives there for these parameters today)."""
+        from liso_amd import _lib as L
+        import ctypes
+
+        jobs = []
+        for p_, flat in params:
+            g = p_.grad
+            p_.grad = flat
+            if g is None or g is flat:
+                continue
+            if add or g.dtype != torch.float32 or g.stride() != flat.stride() or g.shape != flat.shape:
+                flat.add_(g) if add else flat.copy_(g)
+                continue
+            jobs.append((g, flat))
+        if not jobs:
+            return
+        n = len(jobs)
+        src = (ctypes.c_void_p * n)(*[g.data_ptr() for g, _ in jobs])
+        dst = (ctypes.c_void_p * n)(*[f.data_ptr() for _, f in jobs])
+        cnt = (ctypes.c_size_t * n)(*[g.numel() for g, _ in jobs])
+        with torch.cuda.device(self.device):
+            L.check(L.lib().liso_gather_f32(n, src, dst, cnt, L.stream_ptr()), "gather_f32")
+        self._gather_keepalive = [g for g, _ in jobs]  # (read by the launch above: released with the next pass / the graph's pool)
 
     def _graph_step(self, pcls, targets):
         # what the graph consumes: the [B, 64, gx, gy] canvas (batch size; grid and dtype are fixed per trainer) and the target maps.
@@ -770,6 +811,8 @@ class LisoLoopTrainer:
         if slim_state_dict is not None:
             self.slim.load_state_dict(slim_state_dict)
         self.slim.eval()
+        if os.environ.get("LISO_ENC_IMAGES"):  # experiment: encoder passes of at most this many images inside an inference batch
+            self.slim.raft_network.encoder_images_per_pass = int(os.environ["LISO_ENC_IMAGES"])
         for p_ in self.slim.parameters():  # frozen: its packed convolution panels are built once and never re-packed
             p_.requires_grad_(False)
         self.cluster_detector = FlowClusterDetector(cfg).to(device)

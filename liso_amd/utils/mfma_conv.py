@@ -571,6 +571,11 @@ def set_direct_grads(on, keep_touched=False):
         _DIRECT_TOUCHED.clear()
 
 
+def direct_touched():
+    """ids of the parameters whose gradient was written in place since the last `set_direct_grads(True)`"""
+    return set(_DIRECT_TOUCHED)
+
+
 def _direct_target(p):
     """the dense fp32 .grad buffer of leaf parameter `p`, or None"""
     if not _DIRECT_GRADS or not isinstance(p, torch.nn.Parameter):
