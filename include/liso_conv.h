@@ -123,6 +123,16 @@ size_t liso_conv_wgrad_sparse_workspace_bytes(const liso_conv_desc* d);
 int liso_conv_wgrad_sparse_f32(const liso_conv_desc* d, const float* x, const float* occupancy, const float* dy, int dy_pix_stride,
                                float* dw, float* dbias, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Weight gradient of a k x k (k = 3 | 5 | 7), stride-1, padding k/2 convolution whose fp32 input has at most FOUR channels: the motion
+ * encoder's `conv_flow1` / `conv_class1` on the flow / the class logits (liso/slim/model/update.py:57,66; autograd's
+ * convolution_backward for the weights in the reference).  x: NHWC with 4 stored channels per pixel (a 2- or 3-channel input is
+ * zero-padded by the caller; the gradient rows of the padding are zeros), pixel stride `x_pix_stride` floats (a multiple of 4, 16-B
+ * aligned base); dy: NHWC [batch, h, w, co], pixel stride `dy_pix_stride`.  dw fp32 [co][4][k][k] (torch's layout), dbias [co] or
+ * NULL.  Exact fp32 FMAs, fixed summation order.  0 bytes from the workspace query = geometry not covered. */
+size_t liso_conv_wgrad_smallci_workspace_bytes(int batch, int h, int w, int co, int k);
+int liso_conv_wgrad_smallci_f32(const float* x, long x_pix_stride, const float* dy, long dy_pix_stride, int batch, int h, int w, int co,
+                                int k, float* dw, float* dbias, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Weight gradient of the convolution described by `d` (a FORWARD descriptor: x = layer input, with the same optional
  * prologue, dy = gradient of the layer output [batch, ho, wo, co] with pixel stride dy_pix_stride):
  *   dw[co][ci][kh][kw] (torch layout of nn.Conv2d; transposed != 0: [ci][co][kh][kw]) = sum over pixels, overwritten;

@@ -1300,6 +1300,138 @@ int launch_rs3(const liso_conv_desc& d, const Rs3Plan& p, hipStream_t st) {
 
 }  // namespace
 
+// ---- weight gradient of a k x k / stride-1 convolution with at most FOUR input channels (fp32) -----------------------------------
+// The motion encoder's 7x7 layers read the 2-channel flow / 4-channel class logits (liso/slim/model/update.py:57,66).  As an MFMA
+// problem that is a [196 x pixels] . [pixels x 64] product whose 196 rows are shifted copies of 4 numbers per pixel: padding it to
+// the 64-channel tiles of the kernels above costs 0.33 ms.  Here a wave owns ONE input channel and its 64 lanes are 64 output
+// channels; the lane keeps the k x k accumulators of its (ci, co) pair and a k x k window of the input around the current pixel in
+// registers, and walks a row: per pixel k new window values (wave-uniform LDS reads), one dy value (coalesced 256-B row) and k*k
+// exact fp32 FMAs -- no tile padding, no im2col.  Blocks own whole rows; their partial filters are summed in block order by a second
+// launch (bitwise reproducible).  0.6 GFLOP for the deferred batch of 12 maps at 64^2.
+constexpr int kSmallCi = 4;
+
+template <int K>
+__global__ __launch_bounds__(256) void wgrad_smallci_kernel(const float* __restrict__ x, long xps, const float* __restrict__ dy, long gps,
+                                                            int batch, int h, int w, int co, int rows_per_block,
+                                                            float* __restrict__ partial, float* __restrict__ bias_partial) {
+    extern __shared__ float4 xs[];  // [K][w + K - 1] pixels x 4 channels, zero outside the map; then the dy row [w][64]
+    constexpr int P = K / 2;
+    const int lane = threadIdx.x & 63, ci = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + lane;  // output channel of this lane
+    const int wp = w + K - 1;
+    float* gs = reinterpret_cast<float*>(xs + K * wp);
+    float acc[K][K];
+#pragma unroll
+    for (int a = 0; a < K; a++)
+#pragma unroll
+        for (int b = 0; b < K; b++) acc[a][b] = 0.f;
+    float bsum = 0.f;
+    const long rows = (long)batch * h;
+    const long r0 = (long)blockIdx.x * rows_per_block, r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    const float* xs_f = reinterpret_cast<const float*>(xs);
+    for (long r = r0; r < r1; r++) {
+        const int b = (int)(r / h), y = (int)(r % h);
+        __syncthreads();
+        // (both stagings are independent loads: one round trip per row, not one per window step)
+        const float* g = dy + (((long)b * h + y) * w) * gps;
+        for (int i = threadIdx.x; i < w * 64; i += 256) {
+            const int px = i >> 6, cc = blockIdx.y * 64 + (i & 63);
+            gs[i] = cc < co ? g[(long)px * gps + cc] : 0.f;
+        }
+        for (int i = threadIdx.x; i < K * wp; i += 256) {
+            const int ky = i / wp, px = i % wp;
+            const int yy = y + ky - P, xx = px - P;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (yy >= 0 && yy < h && xx >= 0 && xx < w) v = *reinterpret_cast<const float4*>(x + (((long)b * h + yy) * w + xx) * xps);
+            xs[i] = v;
+        }
+        __syncthreads();
+        float win[K][K];  // win[ky][slot]: padded column col lives in slot col % K
+#pragma unroll
+        for (int ky = 0; ky < K; ky++)
+#pragma unroll
+            for (int col = 0; col < K - 1; col++) win[ky][col] = xs_f[(ky * wp + col) * 4 + ci];
+        for (int px0 = 0; px0 < w; px0 += K) {
+#pragma unroll
+            for (int j = 0; j < K; j++) {
+                const int col = px0 + j + K - 1;  // the column that enters the window of pixel px0 + j; px0 is a multiple of K
+                const int cc = col < wp ? col : wp - 1;  // (beyond the row: its products meet a zero below)
+                const float gv = px0 + j < w ? gs[(px0 + j) * 64 + lane] : 0.f;
+#pragma unroll
+                for (int ky = 0; ky < K; ky++) win[ky][(j + K - 1) % K] = xs_f[(ky * wp + cc) * 4 + ci];
+#pragma unroll
+                for (int ky = 0; ky < K; ky++)
+#pragma unroll
+                    for (int kx = 0; kx < K; kx++) acc[ky][kx] = fmaf(win[ky][(j + kx) % K], gv, acc[ky][kx]);
+                bsum += gv;
+            }
+        }
+    }
+    const int cop = gridDim.y * 64;
+    float* pt = partial + (((size_t)blockIdx.x * kSmallCi + ci) * K * K) * cop + c;
+#pragma unroll
+    for (int ky = 0; ky < K; ky++)
+#pragma unroll
+        for (int kx = 0; kx < K; kx++) pt[(size_t)(ky * K + kx) * cop] = acc[ky][kx];
+    if (ci == 0 && bias_partial) bias_partial[(size_t)blockIdx.x * cop + c] = bsum;
+}
+
+// dw[co][ci][k][k] = sum over blocks of partial[block][ci][tap][co]; the bias likewise.  64 outputs x 8 block groups per workgroup:
+// group q adds the blocks q, q + 8, ... (8 independent loads in flight per thread), the groups' sums are added in group order
+// through LDS -- a fixed order, and 8 x 8 loads deep instead of one dependent chain over all blocks (measured: 384 blocks in one
+// chain per output took longer than the gradient kernel itself).
+__global__ __launch_bounds__(512) void wgrad_smallci_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bias_partial,
+                                                                   int nblk, int kk, int co, int cop, float* __restrict__ dw,
+                                                                   float* __restrict__ db) {
+    __shared__ float sm[8][64];
+    const int i = blockIdx.x * 64 + threadIdx.x, q = threadIdx.y;
+    const int n = kSmallCi * kk * cop;
+    const float* src = nullptr;
+    size_t stride = 0;
+    if (i < n) { src = partial + i; stride = (size_t)n; }
+    else if (bias_partial && i - n < cop) { src = bias_partial + (i - n); stride = (size_t)cop; }
+    float s = 0.f;
+    if (src) {
+        int b = q;
+        for (; b + 56 < nblk; b += 64) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = src[(size_t)(b + 8 * u) * stride];
+#pragma unroll
+            for (int u = 0; u < 8; u++) s += v[u];
+        }
+        for (; b < nblk; b += 8) s += src[(size_t)b * stride];
+    }
+    sm[q][threadIdx.x] = s;
+    __syncthreads();
+    if (q != 0 || !src) return;
+    s = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; u++) s += sm[u][threadIdx.x];
+    if (i < n) {
+        const int c = i % cop, t = (i / cop) % kk, ci = i / (cop * kk);
+        if (c < co) dw[((size_t)c * kSmallCi + ci) * kk + t] = s;
+    } else if (db && i - n < co) {
+        db[i - n] = s;
+    }
+}
+
+inline bool smallci_layout(int batch, int h, int w, int co, int k, int* nblk, int* rpb, size_t* part_bytes, size_t* bias_bytes, int* lds) {
+    if (batch < 1 || h < 1 || w < 1 || co < 1 || co > 1024 || (k != 3 && k != 5 && k != 7)) return false;
+    const long rows = (long)batch * h;
+    long nb = rows < 512 ? rows : 512;  // (24 KB of LDS and 158 VGPRs: several blocks per CU hide each other's staging)
+    const long per = (rows + nb - 1) / nb;
+    nb = (rows + per - 1) / per;
+    const int cop = (co + 63) / 64 * 64;
+    *nblk = (int)nb;
+    *rpb = (int)per;
+    *part_bytes = (size_t)nb * kSmallCi * k * k * cop * sizeof(float);
+    *bias_bytes = (size_t)nb * cop * sizeof(float);
+    *lds = k * (w + k - 1) * (int)sizeof(float4) + w * 64 * (int)sizeof(float);
+    return *lds <= 64 * 1024;
+}
+
+
 extern "C" {
 
 size_t liso_conv_wgrad_workspace_bytes(const liso_conv_desc* d) {
@@ -1404,6 +1536,37 @@ int liso_conv_wgrad(const liso_conv_desc* d, const void* x, const float* in_scal
     const int co_w = d->wgrad_co > 0 ? d->wgrad_co : d->co;  // channels written (dy may carry zero-padded channels beyond)
     return launch_reduce(p.a.slab, p.a.bias_slab, p.splits, p.splits * d->n_classes, d->w_taps, d->ci, co_w, (long)p.a.ci_t * CT,
                          (long)p.a.co_t * CT, transposed, dw, dbias, st);
+}
+
+size_t liso_conv_wgrad_smallci_workspace_bytes(int batch, int h, int w, int co, int k) {
+    int nblk, rpb, lds;
+    size_t pb, bb;
+    if (!smallci_layout(batch, h, w, co, k, &nblk, &rpb, &pb, &bb, &lds)) return 0;
+    return pb + bb;
+}
+
+int liso_conv_wgrad_smallci_f32(const float* x, long x_pix_stride, const float* dy, long dy_pix_stride, int batch, int h, int w, int co,
+                                int k, float* dw, float* dbias, void* workspace, size_t workspace_bytes, void* stream) {
+    int nblk, rpb, lds;
+    size_t pb, bb;
+    if (!x || !dy || !dw || !workspace || x_pix_stride < kSmallCi || dy_pix_stride < co || (((uintptr_t)x) & 15) || (x_pix_stride & 3))
+        return LISO_EINVAL;
+    if (!smallci_layout(batch, h, w, co, k, &nblk, &rpb, &pb, &bb, &lds)) return LISO_EINVAL;
+    if (workspace_bytes < pb + bb) return LISO_EWORKSPACE;
+    float* partial = (float*)workspace;
+    float* bias_partial = dbias ? (float*)((char*)workspace + pb) : nullptr;
+    const int tiles = (co + 63) / 64, cop = tiles * 64;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)nblk, (unsigned)tiles);
+#define LISO_SMALLCI(K) \
+    hipLaunchKernelGGL(wgrad_smallci_kernel<K>, grid, dim3(256), lds, st, x, x_pix_stride, dy, dy_pix_stride, batch, h, w, co, rpb, partial, bias_partial)
+    if (k == 7) LISO_SMALLCI(7);
+    else if (k == 5) LISO_SMALLCI(5);
+    else LISO_SMALLCI(3);
+#undef LISO_SMALLCI
+    const int n = kSmallCi * k * k * cop + (dbias ? cop : 0);
+    hipLaunchKernelGGL(wgrad_smallci_reduce_kernel, dim3((n + 63) / 64), dim3(64, 8), 0, st, partial, bias_partial, nblk, k * k, co, cop, dw, dbias);
+    return hipGetLastError() == hipSuccess ? LISO_OK : LISO_ELAUNCH;
 }
 
 }  // extern "C"

@@ -408,11 +408,18 @@ def conv_wgrad(x, dy, weight_shape, spec, in_scale=None, in_shift=None, in_relu=
     """-> (dw fp32 in torch's layout `weight_shape`, dbias fp32 [Co] | None); None if the geometry is not supported by the
     kernel (caller falls back to ATen's weight gradient).  `out_dw` / `out_db`: dense fp32 tensors to write into (overwritten)."""
     L.require_cuda(x, dy)
+    if (x.shape[1] == 4 and x.dtype == torch.float32 and not spec.transposed and spec.stride == 1 and spec.kh == spec.kw and spec.kh in (5, 7)
+            and spec.padding == spec.kh // 2 and in_scale is None and tuple(weight_shape[1:]) == (4, spec.kh, spec.kw)
+            and os.environ.get("LISO_WGRAD_SMALLCI", "1") != "0"):
+        res = _conv_wgrad_smallci(x, dy, weight_shape, spec, want_bias, out_dw, out_db, co_true)
+        if res is not None:
+            return res
     if spec.kh * spec.kw > 9 and not os.environ.get("LISO_WGRAD_7X7"):
-        # 7x7 kernels on DENSE inputs: the row-of-taps kernel re-stages the halo tile once per kernel row and pads 2-4 input channels
-        # to a 64-channel tile -- measured 0.33 ms vs 0.05 ms for the library's kernel on the motion encoder's 7x7 convolutions
-        # (update.py:57,66), 1.9 ms vs 0.31 ms on the encoders' stem.  The stem's canvas is sparse and takes conv_wgrad_sparse
-        # (0.11 ms); the motion encoder's two layers stay on the library.  LISO_WGRAD_7X7=1 forces the own kernel (tests).
+        # 7x7 kernels on DENSE inputs with many channels: the row-of-taps MFMA kernel re-stages the halo tile once per kernel row --
+        # measured 1.9 ms vs 0.31 ms for the library's kernel on the encoders' stem.  None of the networks' layers gets here: the
+        # stem's canvas is sparse and takes conv_wgrad_sparse (0.11 ms), the motion encoder's 2-4-channel layers (update.py:57,66)
+        # take _conv_wgrad_smallci above (25 / 55 us at batch 2 / 12, the library: 29 / 45 us).  LISO_WGRAD_7X7=1 forces the MFMA
+        # kernel (tests).
         return None
     mode = _mode(x.dtype)
     if dy.dtype != x.dtype:
@@ -441,6 +448,31 @@ def conv_wgrad(x, dy, weight_shape, spec, in_scale=None, in_shift=None, in_relu=
             ctypes.byref(d), L.ptr(xv), L.ptr(in_scale) if in_scale is not None else None,
             L.ptr(in_shift) if in_shift is not None else None, L.ptr(gv), gps, int(spec.transposed), L.ptr(dw),
             L.ptr(db) if db is not None else None, L.ptr(ws), nbytes, L.stream_ptr()), units=_flops(d), nbytes=_bytes(d, True)), "conv_wgrad")
+    return dw, db
+
+
+def _conv_wgrad_smallci(x, dy, weight_shape, spec, want_bias, out_dw, out_db, co_true):
+    """the motion encoder's 7x7 layers on 2-4 input channels (update.py:57,66): liso_conv_wgrad_smallci_f32 -- a wave per input channel,
+    a lane per output channel, the filter's k x k accumulators and a sliding input window in registers (no 64-channel tile padding)"""
+    if dy.dtype != torch.float32:
+        dy = dy.float()
+    xv, xps = as_nhwc(x, 4)
+    gv, gps = as_nhwc(dy, 4)
+    B, hi, wi, _ = xv.shape
+    co = co_true if co_true is not None else gv.shape[3]
+    if gv.shape[1:3] != (hi, wi) or weight_shape[0] != co:
+        return None
+    lib = L.lib()
+    nbytes = lib.liso_conv_wgrad_smallci_workspace_bytes(B, hi, wi, co, spec.kh)
+    if nbytes == 0:
+        return None
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    dw = out_dw if out_dw is not None else torch.empty(weight_shape, dtype=torch.float32, device=x.device)
+    db = (out_db if out_db is not None else torch.empty(co, dtype=torch.float32, device=x.device)) if want_bias else None
+    with torch.cuda.device(x.device):
+        L.check(L.TIMER.launch("conv_wgrad_smallci", lambda: lib.liso_conv_wgrad_smallci_f32(
+            L.ptr(xv), xps, L.ptr(gv), gps, B, hi, wi, co, spec.kh, L.ptr(dw), L.ptr(db) if db is not None else None, L.ptr(ws), nbytes,
+            L.stream_ptr()), units=2.0 * B * hi * wi * co * 4 * spec.kh * spec.kw), "conv_wgrad_smallci")
     return dw, db
 
 

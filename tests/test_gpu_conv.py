@@ -325,3 +325,28 @@ def test_stem_convolution_with_occupancy_trains_like_the_dense_path():
         outs.append((y.detach(), layer.weight.grad.clone(), layer.bias.grad.clone(), xi.grad.clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][3], outs[1][3])
     assert _rel(outs[1][1], outs[0][1]) <= 1e-4 and _rel(outs[1][2], outs[0][2]) <= 1e-4
+
+
+@pytest.mark.parametrize("B,ci_true,co,H,W,k", [(2, 4, 64, 64, 64, 7), (3, 2, 64, 17, 23, 7), (1, 3, 80, 9, 70, 7), (2, 4, 32, 16, 16, 5),
+                                                 (12, 4, 64, 64, 64, 7)])
+def test_small_channel_7x7_weight_gradient_matches_fp64(B, ci_true, co, H, W, k):
+    """liso_conv_wgrad_smallci_f32 (the motion encoder's conv_flow1 / conv_class1, update.py:57,66: 7x7 on 2-4 channels) against
+    torch's weight gradient in fp64: maps whose width is not a multiple of the window walk, output channel counts beside the
+    64-lane tile, zero-padded input channels (their gradient rows must be exact zeros), bias gradient, bitwise repeatability"""
+    from liso_amd.utils import mfma_conv as MC
+
+    torch.manual_seed(B * 100 + W)
+    x = torch.randn(B, 4, H, W, device="cuda")
+    x[:, ci_true:] = 0
+    x = x.contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(B, co, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
+    spec = MC.ConvSpec(k, k, 1, k // 2, False)
+    dw, db = MC.conv_wgrad(x, dy, (co, 4, k, k), spec, want_bias=True)
+    dw2, db2 = MC.conv_wgrad(x, dy, (co, 4, k, k), spec, want_bias=True)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
+    ref = torch.nn.grad.conv2d_weight(x.double(), (co, 4, k, k), dy.double(), stride=1, padding=k // 2)
+    scale = float(ref.abs().max())
+    assert float((dw.double() - ref).abs().max()) <= 2e-6 * scale * max(1.0, (B * H * W) ** 0.5 / 30)
+    assert float(dw[:, ci_true:].abs().max() if ci_true < 4 else 0.0) == 0.0
+    refb = dy.double().sum(dim=(0, 2, 3))
+    assert float((db.double() - refb).abs().max()) <= 1e-5 * float(refb.abs().max())
