@@ -204,18 +204,19 @@ def conv2d(layer: nn.Conv2d, x, relu=False):
     return y
 
 
-def conv2d_pair(layer_a: nn.Conv2d, layer_b: nn.Conv2d, x):
-    """cat([layer_a(x), layer_b(x)], dim=1) as one convolution (same input, same geometry)"""
+def conv2d_pair(layer_a: nn.Conv2d, layer_b: nn.Conv2d, x, relu=False):
+    """relu?(cat([layer_a(x), layer_b(x)], dim=1)) as one convolution (same input, same geometry)"""
     st = _ACTIVE
     key = (id(layer_a), id(layer_b))
     if st is None or key not in st.index:
         from liso_amd.utils import mfma_conv as MC
 
         if x.is_cuda and MC.backend() == "mfma" and MC.supported(x, layer_a.weight, MC.ConvSpec.of(layer_a)):
-            return MC.fused_conv(x, None, [layer_a, layer_b])[0]
+            return MC.fused_conv(x, None, [layer_a, layer_b], out_relu=relu)[0]
         w = torch.cat([layer_a.weight, layer_b.weight], dim=0)
         b = torch.cat([layer_a.bias, layer_b.bias], dim=0)
-        return F.conv2d(x, w, b, layer_a.stride, layer_a.padding, layer_a.dilation)
+        y = F.conv2d(x, w, b, layer_a.stride, layer_a.padding, layer_a.dilation)
+        return torch.relu(y) if relu else y
     li = st.index[key]
-    y, st.token = _ConvDeferred.apply(x, st.token, *st.weights(li), st, li, False)
+    y, st.token = _ConvDeferred.apply(x, st.token, *st.weights(li), st, li, relu)
     return y

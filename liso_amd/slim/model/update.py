@@ -85,6 +85,11 @@ class SmallUpdateBlock(nn.Module):
         self.static_flow_head = FlowOrClassificationHead(input_dim=filters, hidden_dim=128, out_dims=flow_ch)
         self.classification_head = (FlowOrClassificationHead(input_dim=filters, hidden_dim=128, out_dims=4)
                                     if self.predict_logits else None)
+        # both heads read the hidden state through a 3x3 convolution of the same geometry: ONE convolution with 2 x 128 filters
+        # (one staging of `net`, one data gradient instead of two and their sum); every head's output convolution then reads its
+        # 128-channel slice of that map
+        self.merged_convs = [(self.static_flow_head.conv1, self.classification_head.conv1)] if self.predict_logits else []
+        self.merge_head_convs = True
 
     def forward(self, net, inp, corr, flow, logits, weight_logits_for_static_aggregation):
         """reference :130-164"""
@@ -94,10 +99,17 @@ class SmallUpdateBlock(nn.Module):
             assert weight_logits_for_static_aggregation is None
             mf = self.motion_encoder(flow, corr, logits)
         net = self.gru(net, torch.cat([inp, mf], dim=1))
-        if self.cfg.model.predict_weight_for_static_aggregation:
+        if self.merged_convs and self.merge_head_convs and net.is_cuda:
+            fh, ch = self.static_flow_head, self.classification_head
+            hid = conv2d_pair(fh.conv1, ch.conv1, net, relu=True)
+            # (split, not two slices: its backward is one concatenation of the heads' input gradients)
+            hid_f, hid_c = torch.split(hid, [fh.conv1.out_channels, ch.conv1.out_channels], dim=1)
+            delta, delta_logits = conv2d(fh.conv2, hid_f), conv2d(ch.conv2, hid_c)
+        else:
             delta = self.static_flow_head(net)
+            delta_logits = self.classification_head(net) if self.predict_logits else None
+        if self.cfg.model.predict_weight_for_static_aggregation:
             delta_static_flow, delta_weights = delta[:, 0:2, ...], delta[:, -1:, ...]
         else:
-            delta_static_flow, delta_weights = self.static_flow_head(net), None
-        delta_logits = self.classification_head(net) if self.predict_logits else None
+            delta_static_flow, delta_weights = delta, None
         return net, delta_static_flow, delta_logits, delta_weights
