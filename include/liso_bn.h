@@ -56,6 +56,10 @@ int liso_in_relu_fwd(const void* x, int is_bf16, int groups, long m, int c, cons
                      void* y, float* stats, void* workspace, size_t workspace_bytes, void* stream);
 int liso_in_relu_bwd(const void* dy, const void* x, int is_bf16, int groups, long m, int c, const float* gamma, const float* stats,
                      int relu, void* dx, float* grad_gamma, float* grad_beta, void* workspace, size_t workspace_bytes, void* stream);
+/* The same backward with grad_gamma / grad_beta fp32 [C] = the SUM over the samples (what the shared affine parameters receive),
+ * added in sample order inside the finalize launch: no [groups, C] intermediate, no reduction launches behind the call. */
+int liso_in_relu_bwd_sum(const void* dy, const void* x, int is_bf16, int groups, long m, int c, const float* gamma, const float* stats,
+                         int relu, void* dx, float* grad_gamma, float* grad_beta, void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

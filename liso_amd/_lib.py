@@ -155,6 +155,7 @@ SIGNATURES = {
     "liso_in_workspace_bytes": (_sz, [_i, _i]),
     "liso_in_relu_fwd": (_i, [_vp, _i, _i, ctypes.c_long, _i, _vp, _vp, _f, _i, _vp, _vp, _vp, _sz, _vp]),
     "liso_in_relu_bwd": (_i, [_vp, _vp, _i, _i, ctypes.c_long, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "liso_in_relu_bwd_sum": (_i, [_vp, _vp, _i, _i, ctypes.c_long, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "liso_bn_relu_bwd": (_i, [_vp, _vp, _i, ctypes.c_long, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "liso_bn_relu_bwd_ticket": (_i, [_vp, _vp, _i, ctypes.c_long, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "liso_knn_workspace_bytes": (_sz, [_vp, _i]),

@@ -379,6 +379,51 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
     }
 }
 
+// InstanceNorm: the affine parameters are shared by all samples -> one block walks the groups (samples) in order, writes every
+// group's dx coefficients and the SUM of the per-sample parameter gradients (fixed order): no [groups, C] intermediate and no
+// reduction launches behind the call
+__global__ __launch_bounds__(1024) void in_bwd_finalize_sum_kernel(const float* __restrict__ partial, int groups, int nblk, long m, int c,
+                                                                   const float* __restrict__ gamma, const float* __restrict__ stats,
+                                                                   float* __restrict__ grad_gamma, float* __restrict__ grad_beta,
+                                                                   float* __restrict__ coef) {
+    __shared__ double sh_a[1024], sh_b[1024];
+    const int tid = threadIdx.x;
+    const int chunks = 1024 / c > 0 ? 1024 / c : 1;
+    const int ch = tid % c, chunk = tid / c;
+    double sum_a = 0.0, sum_b = 0.0;
+    for (int g = 0; g < groups; g++) {
+        const float* part = partial + (size_t)g * nblk * 2 * c;
+        double a = 0.0, b = 0.0;
+        if (chunk < chunks) {
+            const int per = (nblk + chunks - 1) / chunks;
+            const int lo = chunk * per, hi = lo + per < nblk ? lo + per : nblk;
+            int q = lo;
+            for (; q + 8 <= hi; q += 8) {
+                float va[8], vb[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) { va[j] = part[(size_t)(q + j) * 2 * c + ch]; vb[j] = part[(size_t)(q + j) * 2 * c + c + ch]; }
+#pragma unroll
+                for (int j = 0; j < 8; j++) { a += (double)va[j]; b += (double)vb[j]; }
+            }
+            for (; q < hi; q++) { a += (double)part[(size_t)q * 2 * c + ch]; b += (double)part[(size_t)q * 2 * c + c + ch]; }
+        }
+        __syncthreads();  // (the previous group's reads of sh_a / sh_b)
+        sh_a[tid] = a; sh_b[tid] = b;
+        __syncthreads();
+        if (tid < c) {
+            a = 0.0; b = 0.0;
+            for (int q = 0; q < chunks; q++) { a += sh_a[q * c + tid]; b += sh_b[q * c + tid]; }
+            // (the per-sample values rounded to fp32 first, then added: what `grad[groups, C].sum(0)` of the three-step form computes)
+            sum_a += (double)(float)a; sum_b += (double)(float)b;
+            float* cf = coef + (size_t)g * 3 * c;
+            cf[tid] = gamma[tid] * stats[(size_t)g * 4 * c + 3 * c + tid];
+            cf[c + tid] = (float)(a / (double)m);
+            cf[2 * c + tid] = (float)(b / (double)m);
+        }
+    }
+    if (tid < c) { grad_beta[tid] = (float)sum_a; grad_gamma[tid] = (float)sum_b; }
+}
+
 template <typename T, bool RELU>
 __global__ __launch_bounds__(kThreads) void bn_bwd_dx_kernel(const T* __restrict__ dy, const T* __restrict__ x, long m, int c,
                                                              Geom g, const float* __restrict__ stats,
@@ -540,8 +585,8 @@ int liso_in_relu_fwd(const void* x, int is_bf16, int groups, long m, int c, cons
     return check_launch();
 }
 
-int liso_in_relu_bwd(const void* dy, const void* x, int is_bf16, int groups, long m, int c, const float* gamma, const float* stats,
-                     int relu, void* dx, float* grad_gamma, float* grad_beta, void* workspace, size_t workspace_bytes, void* stream) {
+static int in_relu_bwd(const void* dy, const void* x, int is_bf16, int groups, long m, int c, const float* gamma, const float* stats,
+                     int relu, void* dx, float* grad_gamma, float* grad_beta, void* workspace, size_t workspace_bytes, int summed, void* stream) {
     Geom g;
     int nblk;
     if (groups < 1 || m <= 0 || !geom(c, is_bf16 ? 8 : 4, m, &g, &nblk)) return LISO_EINVAL;
@@ -554,13 +599,26 @@ int liso_in_relu_bwd(const void* dy, const void* x, int is_bf16, int groups, lon
 #define LISO_BWD(T, R)                                                                                                     \
     do {                                                                                                                   \
         bn_bwd_reduce_kernel<T, R><<<gs, kThreads, 0, st>>>((const T*)dy, (const T*)x, m, c, g, stats, partial, BwdFinal{}); \
-        bn_bwd_finalize_kernel<<<groups, 1024, 0, st>>>(partial, nblk, m, c, gamma, stats, 1, grad_gamma, grad_beta, coef); \
+        if (summed)                                                                                                        \
+            in_bwd_finalize_sum_kernel<<<1, 1024, 0, st>>>(partial, groups, nblk, m, c, gamma, stats, grad_gamma, grad_beta, coef); \
+        else                                                                                                               \
+            bn_bwd_finalize_kernel<<<groups, 1024, 0, st>>>(partial, nblk, m, c, gamma, stats, 1, grad_gamma, grad_beta, coef); \
         bn_bwd_dx_kernel<T, R><<<ga, kThreads, 0, st>>>((const T*)dy, (const T*)x, m, c, g, stats, coef, (T*)dx);            \
     } while (0)
     if (is_bf16) { if (relu) LISO_BWD(__hip_bfloat16, true); else LISO_BWD(__hip_bfloat16, false); }
     else { if (relu) LISO_BWD(float, true); else LISO_BWD(float, false); }
 #undef LISO_BWD
     return check_launch();
+}
+
+int liso_in_relu_bwd(const void* dy, const void* x, int is_bf16, int groups, long m, int c, const float* gamma, const float* stats,
+                     int relu, void* dx, float* grad_gamma, float* grad_beta, void* workspace, size_t workspace_bytes, void* stream) {
+    return in_relu_bwd(dy, x, is_bf16, groups, m, c, gamma, stats, relu, dx, grad_gamma, grad_beta, workspace, workspace_bytes, 0, stream);
+}
+
+int liso_in_relu_bwd_sum(const void* dy, const void* x, int is_bf16, int groups, long m, int c, const float* gamma, const float* stats,
+                         int relu, void* dx, float* grad_gamma, float* grad_beta, void* workspace, size_t workspace_bytes, void* stream) {
+    return in_relu_bwd(dy, x, is_bf16, groups, m, c, gamma, stats, relu, dx, grad_gamma, grad_beta, workspace, workspace_bytes, 1, stream);
 }
 
 }  // extern "C"

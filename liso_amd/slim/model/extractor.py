@@ -69,7 +69,9 @@ class ResidualBlock(nn.Module):
             y = in_act(conv2d(self.conv2, y), self.norm2)
         if self.downsample is not None:
             x = in_act(conv2d(self.downsample[0], x), self.downsample[1], relu=False)
-        return self.relu(x + y)
+        from liso_amd.utils.mfma_conv import add_relu
+
+        return add_relu(x, y)  # (one launch on the GPU; torch.relu(x + y) elsewhere)
 
 
 class SmallEncoder(nn.Module):

@@ -60,16 +60,16 @@ class _InAct(torch.autograd.Function):
             g = g.contiguous()
         lib = L.lib()
         dx = torch.empty_like(xc)
-        gg = torch.empty((B, C), dtype=torch.float32, device=xc.device)
-        gb = torch.empty((B, C), dtype=torch.float32, device=xc.device)
+        gg = torch.empty(C, dtype=torch.float32, device=xc.device)  # (summed over the samples inside the finalize launch)
+        gb = torch.empty(C, dtype=torch.float32, device=xc.device)
         nbytes = lib.liso_in_workspace_bytes(B, C)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=xc.device)
         with torch.cuda.device(xc.device):
-            L.check(L.TIMER.launch("in_bwd", lambda: lib.liso_in_relu_bwd(
+            L.check(L.TIMER.launch("in_bwd", lambda: lib.liso_in_relu_bwd_sum(
                 L.ptr(g), L.ptr(xc), int(xc.dtype == torch.bfloat16), B, H * W, C, L.ptr(gamma), L.ptr(stats), int(ctx.relu), L.ptr(dx),
                 L.ptr(gg), L.ptr(gb), L.ptr(ws), nbytes, L.stream_ptr()), units=5 * xc.numel() * xc.element_size()), "in_relu_bwd")
         need = ctx.needs_input_grad
-        return dx.permute(0, 3, 1, 2), (gg.sum(dim=0) if need[1] else None), (gb.sum(dim=0) if need[2] else None), None, None
+        return dx.permute(0, 3, 1, 2), (gg if need[1] else None), (gb if need[2] else None), None, None
 
 
 def in_act(x, norm, relu=True):

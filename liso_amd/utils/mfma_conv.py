@@ -906,6 +906,30 @@ def residual_relu(a_raw, a_fold, b_raw, b_fold):
     return out.permute(0, 3, 1, 2)
 
 
+class _AddRelu(torch.autograd.Function):
+    """relu(a + b) of two fp32 channels-last maps as ONE launch (the tail of a residual block in training: `self.relu(x + y)`,
+    liso/slim/model/extractor.py:38); backward: the ReLU mask from the stored output, the same tensor for both branches"""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        out = residual_relu(a, None, b, None)
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (out,) = ctx.saved_tensors
+        gm = torch.ops.aten.threshold_backward(g, out, 0.0)
+        return gm, gm
+
+
+def add_relu(a, b):
+    if (a.is_cuda and backend() == "mfma" and a.dtype == torch.float32 and b.dtype == torch.float32 and a.shape == b.shape and a.dim() == 4
+            and a.shape[1] % 4 == 0):
+        return _AddRelu.apply(a, b)
+    return torch.relu(a + b)
+
+
 class _Materialize(torch.autograd.Function):
     """relu?(bn(x_raw)) as a tensor, for consumers that are not convolutions (API parity: RPN.forward returns a tensor)"""
 
