@@ -11,7 +11,10 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout 600 python3 $R/bench.py "$@" > $OUT/bench_line.json 2> $OUT/bench.err
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --no-cpu-baseline --no-iou3d --no-fp32-leg --no-legs "$@" > $OUT/bench_traced.json 2> $OUT/trace.err
+# (100 timed steps: the statistics are then those of the steady state -- the synthetic sweeps are generated on the GPU with framework
+# kernels, which at 20 steps are a fifth of all framework launches of the process)
+rm -rf $OUT/trace
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --no-cpu-baseline --no-iou3d --no-fp32-leg --no-legs --steps ${TRACE_STEPS:-100} --warmup 5 "$@" > $OUT/bench_traced.json 2> $OUT/trace.err
 P="--steps 3 --warmup 2 --no-cpu-baseline --no-iou3d --no-fp32-leg --no-legs"
 timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "$KRE" --output-format csv -d $OUT/pmc_FETCH_SIZE -- python3 $R/bench.py $P "$@" > /dev/null 2> $OUT/pmc_fetch.err
 timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "$KRE" --output-format csv -d $OUT/pmc_WRITE_SIZE -- python3 $R/bench.py $P "$@" > /dev/null 2> $OUT/pmc_write.err
