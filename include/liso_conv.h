@@ -178,6 +178,21 @@ int liso_residual_affine_relu_f32(const float* a, const float* a_scale, const fl
 #define LISO_CONV_OPT_SHARED_GPU 1
 int liso_conv_set_option(int option, int value);
 
+/* ---- sparse form of the SLIM encoders' first convolution --------------------------------------------------------------------------
+ * y = relu?(conv7x7 / stride 2 / padding 3, 64 -> 32 channels (x) + bias) for an fp32 pillar canvas `x` (NHWC [batch, hi, wi, 64],
+ * pixel stride `x_pix_stride` floats) with its occupancy map (fp32 [batch, hi, wi], 0 = the cell is exactly zero in every channel):
+ * liso/slim/model/extractor.py:230-232,283-286 on the canvas of pillar_scatter.py:62-102.  Only the occupied cells are multiplied
+ * (F32X3 arithmetic on the matrix cores, `w_packed` = liso_conv_pack_weights(..., LISO_CONV_F32X3) of the [32, 64, 7, 7] filter);
+ * every output pixel [batch, hi / 2, wi / 2, 32] is written once.  `stats_partial` != NULL: per-block sums / sums of squares of the
+ * output, [batch * (hi / 2) * (wi / 2) / 32][2][32] floats, for liso_conv_in_finalize (rows_per_sample = (hi / 2) * (wi / 2) / 32,
+ * co_pad = 32).  `max_cells_per_sample`: capacity of the cell lists (the voxeliser's max_voxels); if a batch holds more occupied
+ * cells than batch * max_cells_per_sample the surplus is dropped and *overflow (device int, may be NULL) is set to 1.
+ * hi even, wi a multiple of 64.  Same results as liso_conv_forward up to the fp32 summation order. */
+size_t liso_sparse_stem_workspace_bytes(int batch, int hi, int wi, int max_cells_per_sample);
+int liso_sparse_stem_forward_f32(const float* x, long x_pix_stride, const float* occupancy, const void* w_packed, const float* bias,
+                                 int batch, int hi, int wi, int max_cells_per_sample, int relu, float* y, float* stats_partial,
+                                 int* overflow, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

