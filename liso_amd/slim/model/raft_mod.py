@@ -73,9 +73,10 @@ class RAFT(nn.Module):
             img_t1, occ_t1 = self.pp_layer(pcl_t1)
         aux = {"t0": {"bev_net_input_dbg": occ_t0}, "t1": {"bev_net_input_dbg": occ_t1}}
         if not getattr(self, "batch_directions", True):  # the reference's schedule: two sequential passes (:95-121)
-            fmap_t0, fmap_t1 = self.fnet(img_t0), self.fnet(img_t1)
-            fw = self.predict_single_flow_map_and_classes(img_t0, fmap_t0, fmap_t1, self.head_decoder_fw)
-            bw = self.predict_single_flow_map_and_classes(img_t1, fmap_t1, fmap_t0, self.head_decoder_bw)
+            o0, o1 = (occ_t0, occ_t1) if img_t0.is_cuda else (None, None)  # (the same sparse-canvas stem as the batched schedule)
+            fmap_t0, fmap_t1 = self.fnet(img_t0, occupancy=o0), self.fnet(img_t1, occupancy=o1)
+            fw = self.predict_single_flow_map_and_classes(img_t0, fmap_t0, fmap_t1, self.head_decoder_fw, occupancy_t0=o0)
+            bw = self.predict_single_flow_map_and_classes(img_t1, fmap_t1, fmap_t0, self.head_decoder_bw, occupancy_t0=o1)
             return fw, bw, aux
         B = img_t0.shape[0]
         imgs = torch.cat([img_t0, img_t1], dim=0)

@@ -717,10 +717,17 @@ class _FusedConv(torch.autograd.Function):
         meta['stats_partial']"""
         spec, fold = meta["spec"], meta["fold"]
         sc, sh = fold.scale_shift() if fold is not None else (None, None)
-        occ = meta.get("occupancy") if fold is None else None  # (sparse pillar canvas: tile skipping forward, cell list backward)
-        y, part = conv_forward(x_raw, weight, bias, spec, sc, sh, in_relu=fold.relu if fold is not None else False,
-                               out_relu=meta.get("out_relu", False), out_dtype=meta.get("out_dtype"),
-                               want_stats=meta.get("want_stats", False), stats_shift=meta.get("stats_shift"), occupancy=occ)
+        occ = meta.get("occupancy") if fold is None else None  # (sparse pillar canvas: sparse / tile-skipping forward, cell list backward)
+        res = None
+        if occ is not None and not meta.get("want_stats", False) and meta.get("out_dtype") in (None, torch.float32):
+            # the encoders' stem on the pillar canvas: only occupied cells are multiplied (liso_sparse_stem_forward_f32)
+            res = _sparse_stem(x_raw, occ, weight, bias, spec, "none", meta.get("out_relu", False))
+        if res is not None:
+            y, part = res[0], None
+        else:
+            y, part = conv_forward(x_raw, weight, bias, spec, sc, sh, in_relu=fold.relu if fold is not None else False,
+                                   out_relu=meta.get("out_relu", False), out_dtype=meta.get("out_dtype"),
+                                   want_stats=meta.get("want_stats", False), stats_shift=meta.get("stats_shift"), occupancy=occ)
         meta["stats_partial"] = part
         relu = bool(meta.get("out_relu", False))
         ctx.save_for_backward(x_raw, weight, y if relu else None)
@@ -875,7 +882,7 @@ def conv_in(x_raw, fold, conv, norm, relu=True, spec=None, occupancy=None):
     if fold is not None:
         kw = dict(in_scale=fold.scale, in_shift=fold.shift, in_relu=fold.relu, affine_batch_stride=fold.stride)
     if fold is None and occupancy is not None:
-        res = _sparse_stem(x_raw, occupancy, conv, spec, kind, relu)
+        res = _sparse_stem(x_raw, occupancy, conv.weight, conv.bias, spec, kind, relu)
         if res is not None:
             y, part = res
             if kind == "none":
@@ -911,16 +918,16 @@ def sparse_stem_overflowed(device):
     return bool(t is not None and int(t.item()) != 0)
 
 
-def _sparse_stem(x_raw, occupancy, conv, spec, kind, relu):
+def _sparse_stem(x_raw, occupancy, weight, bias, spec, kind, relu):
     """The encoders' first convolution on the pillar canvas in its sparse form (liso_sparse_stem_forward_f32): only occupied cells are
     multiplied.  Inference, fp32 tensors in F32X3 arithmetic, 7x7 / 2 / 3, 64 -> 32 channels, a canvas with even height and a width
     that is a multiple of 64.  -> (y logical NCHW, statistics partial sums | None) or None (the caller takes the dense kernel)."""
     if os.environ.get("LISO_SPARSE_STEM", "1") == "0" or x_raw.dtype != torch.float32 or fp32_mode() != "x3":
         return None
     B, C, H, W = x_raw.shape
-    if (spec.kh, spec.kw, spec.stride, spec.padding, spec.transposed) != (7, 7, 2, 3, False) or C != 64 or conv.weight.shape[0] != 32:
+    if (spec.kh, spec.kw, spec.stride, spec.padding, spec.transposed) != (7, 7, 2, 3, False) or C != 64 or weight.shape[0] != 32:
         return None
-    if H % 2 or W % 64 or conv.bias is None or torch.is_grad_enabled() and (conv.weight.requires_grad or x_raw.requires_grad):
+    if H % 2 or W % 64 or bias is None:
         return None
     occ = occupancy if occupancy.dtype == torch.float32 else occupancy.float()
     occ = occ.contiguous()
@@ -938,14 +945,14 @@ def _sparse_stem(x_raw, occupancy, conv, spec, kind, relu):
         if torch.cuda.is_current_stream_capturing():
             return None  # (first use inside a capture: the persistent flag cannot be created here; the warm-up pass creates it)
         flag = _SPARSE_OVERFLOW[dev.index] = torch.zeros(1, dtype=torch.int32, device=dev)
-    packed = pack_weights(conv.weight, spec, False, L.CONV_F32X3)
+    packed = pack_weights(weight, spec, False, L.CONV_F32X3)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     ho, wo = H // 2, W // 2
     y = torch.empty((B, ho, wo, 32), dtype=torch.float32, device=dev)
     part = torch.empty((B * ho * wo // 32, 2, 32), dtype=torch.float32, device=dev) if kind == "instance" else None
     with torch.cuda.device(dev):
         L.check(L.TIMER.launch("conv_sparse_stem", lambda: lib.liso_sparse_stem_forward_f32(
-            L.ptr(xv), xps, L.ptr(occ), L.ptr(packed), L.ptr(conv.bias), B, H, W, cap, int(bool(relu) and kind == "none"), L.ptr(y),
+            L.ptr(xv), xps, L.ptr(occ), L.ptr(packed), L.ptr(bias), B, H, W, cap, int(bool(relu) and kind == "none"), L.ptr(y),
             L.ptr(part) if part is not None else None, L.ptr(flag), L.ptr(ws), nbytes, L.stream_ptr()),
             units=2.0 * B * ho * wo * 32 * 64 * 49), "sparse_stem_forward")
     return y.permute(0, 3, 1, 2), part

@@ -307,9 +307,12 @@ def test_sparse_canvas_weight_gradient_matches_fp64(geom, density):
     assert torch.equal(dw, dw2) and torch.equal(db, db2)
 
 
-def test_stem_convolution_with_occupancy_trains_like_the_dense_path():
-    """mfma_conv.conv2d(layer, canvas, occupancy=...) in training: forward bit-identical to the dense call (tile skipping), weight /
-    bias gradients from the sparse kernel within fp32 rounding of the dense F32X3 kernel's, input gradient unchanged"""
+@pytest.mark.parametrize("relu", [False, True])
+def test_stem_convolution_with_occupancy_trains_like_the_dense_path(relu):
+    """mfma_conv.conv2d(layer, canvas, occupancy=...) in training: forward from the sparse stem kernel = the dense call up to the fp32
+    summation order, weight / bias gradients from the sparse cell-list kernel within fp32 rounding of the dense F32X3 kernel's, input
+    gradient (the dense data-gradient kernel either way) unchanged -- bit for bit without the ReLU, whose mask may flip where the
+    output is within rounding of zero"""
     from liso_amd.utils import mfma_conv as MC
 
     g = torch.Generator().manual_seed(5)
@@ -320,11 +323,16 @@ def test_stem_convolution_with_occupancy_trains_like_the_dense_path():
         torch.manual_seed(1)
         layer = torch.nn.Conv2d(64, 32, 7, stride=2, padding=3).cuda()
         xi = x.clone().requires_grad_(True)
-        y = MC.conv2d(layer, xi, relu=True, occupancy=occ if use_occ else None)
+        y = MC.conv2d(layer, xi, relu=relu, occupancy=occ if use_occ else None)
         (y * torch.linspace(-1, 1, y.numel(), device="cuda").view_as(y)).sum().backward()
         outs.append((y.detach(), layer.weight.grad.clone(), layer.bias.grad.clone(), xi.grad.clone()))
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][3], outs[1][3])
-    assert _rel(outs[1][1], outs[0][1]) <= 1e-4 and _rel(outs[1][2], outs[0][2]) <= 1e-4
+    assert float((outs[0][0] - outs[1][0]).abs().max()) <= 2e-6 * float(outs[0][0].abs().max())
+    if relu:
+        assert _rel(outs[1][3], outs[0][3]) <= 1e-3
+    else:
+        assert torch.equal(outs[0][3], outs[1][3])
+    tol = 1e-3 if relu else 1e-4
+    assert _rel(outs[1][1], outs[0][1]) <= tol and _rel(outs[1][2], outs[0][2]) <= tol
 
 
 @pytest.mark.parametrize("B,ci_true,co,H,W,k", [(2, 4, 64, 64, 64, 7), (3, 2, 64, 17, 23, 7), (1, 3, 80, 9, 70, 7), (2, 4, 32, 16, 16, 5),
