@@ -560,7 +560,7 @@ class SlimTrainer:
         self._static_canv = tuple(c.detach().clone() for c in canv)
         for i in (0, 2):
             self._static_canv[i].requires_grad_(True)
-            self._static_canv[i].grad = torch.zeros_like(self._static_canv[i])
+            self._static_canv[i].grad = None
         quiet = hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch")
         if quiet:
             # the flat gradient views are created on the default stream, warm-up and capture run on side streams
@@ -594,8 +594,8 @@ class SlimTrainer:
 
         def body():
             self._flat_grad.zero_()
-            for i in (0, 2):
-                self._static_canv[i].grad.zero_()
+            for i in (0, 2):  # (autograd keeps the stems' data gradients as the canvases' gradients: no fill, one add less)
+                self._static_canv[i].grad = None
             if self._pack_jobs:  # every layer's forward / data-gradient panels from ONE launch (recorded in the warm-up)
                 MC.set_step_packs(MC.batched_pack(self._pack_jobs))
             thr._defer = [] if defer else None
