@@ -184,10 +184,26 @@ int liso_conv_set_option(int option, int value);
  * liso/slim/model/extractor.py:230-232,283-286 on the canvas of pillar_scatter.py:62-102.  Only the occupied cells are multiplied
  * (F32X3 arithmetic on the matrix cores, `w_packed` = liso_conv_pack_weights(..., LISO_CONV_F32X3) of the [32, 64, 7, 7] filter);
  * every output pixel [batch, hi / 2, wi / 2, 32] is written once.  `stats_partial` != NULL: per-block sums / sums of squares of the
- * output, [batch * (hi / 2) * (wi / 2) / 32][2][32] floats, for liso_conv_in_finalize (rows_per_sample = (hi / 2) * (wi / 2) / 32,
- * co_pad = 32).  `max_cells_per_sample`: capacity of the cell lists (the voxeliser's max_voxels); if a batch holds more occupied
+ * output, [blocks][2][32] floats with blocks = batch * (hi / 2) * (wi / 2) / (128 * liso_sparse_conv_stat_groups(hi, wi, 32)), for
+ * liso_conv_in_finalize (rows_per_sample = blocks / batch, co_pad = 32).  `max_cells_per_sample`: capacity of the cell lists (the voxeliser's max_voxels); if a batch holds more occupied
  * cells than batch * max_cells_per_sample the surplus is dropped and *overflow (device int, may be NULL) is set to 1.
  * hi even, wi a multiple of 64.  Same results as liso_conv_forward up to the fp32 summation order. */
+/* The general entry points behind it: k x k (k = 3 | 7), stride 2, padding k / 2, 64 input channels, co = 64 (k = 3: the detector's
+ * first RPN layer, liso/networks/centerpoint/rpn.py:113-131 on the canvas of pillar_scatter.py) or 32 (k = 7: the SLIM stem); bf16
+ * tensors (is_bf16, one MFMA per product) or fp32 tensors in F32X3 arithmetic; y has the dtype of x; `stats_partial` [blocks][2][co]
+ * holds sums of (y - stats_shift[c]) and their squares (y as stored) for liso_conv_bn_finalize / liso_conv_in_finalize, blocks =
+ * batch * (hi / 2) * (wi / 2) / ((4096 / co) * liso_sparse_conv_stat_groups(hi, wi, co)).  liso_sparse_conv_dgrad: the data gradient of that convolution AT THE OCCUPIED CELLS
+ * (dx rows of other cells are not written: the caller zero-fills dx; the pillar encoder's backward reads occupied cells only);
+ * `w_packed_dgrad` = liso_conv_pack_weights(..., for_dgrad = 1, ...).  Workspace query: for_dgrad != 0 omits the product buffer. */
+int liso_sparse_conv_stat_groups(int hi, int wi, int co);
+size_t liso_sparse_conv_workspace_bytes(int batch, int hi, int wi, int k, int co, int max_cells_per_sample, int for_dgrad);
+int liso_sparse_conv_forward(const void* x, long x_pix_stride, int is_bf16, const float* occupancy, const void* w_packed,
+                             const float* bias, int batch, int hi, int wi, int k, int co, int max_cells_per_sample, int relu, void* y,
+                             float* stats_partial, const float* stats_shift, int* overflow, void* workspace, size_t workspace_bytes,
+                             void* stream);
+int liso_sparse_conv_dgrad(const void* dy, long dy_pix_stride, int is_bf16, const float* occupancy, const void* w_packed_dgrad, int batch,
+                           int hi, int wi, int k, int co, int max_cells_per_sample, void* dx, long dx_pix_stride, int* overflow,
+                           void* workspace, size_t workspace_bytes, void* stream);
 size_t liso_sparse_stem_workspace_bytes(int batch, int hi, int wi, int max_cells_per_sample);
 int liso_sparse_stem_forward_f32(const float* x, long x_pix_stride, const float* occupancy, const void* w_packed, const float* bias,
                                  int batch, int hi, int wi, int max_cells_per_sample, int relu, float* y, float* stats_partial,

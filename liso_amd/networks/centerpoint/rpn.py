@@ -85,14 +85,14 @@ class RPN(nn.Module):
             if isinstance(m, nn.Conv2d):
                 xavier_init(m, distribution="uniform")
 
-    def forward(self, x, lazy=False):
+    def forward(self, x, lazy=False, occupancy=None):
         """reference :137-146.  On the GPU every convolution runs on the own MFMA kernels with the BatchNorm+ReLU of layer k
         folded into the prologue of layer k+1 (liso_amd/utils/mfma_conv.py); `lazy=True` (CenterPointStyleNet) returns
         (raw concatenated maps, BnFold) for CenterHead instead of materialising the normalised feature map."""
         from liso_amd.utils import mfma_conv as MC
 
         if x.is_cuda and MC.backend() == "mfma" and x.dtype in (torch.bfloat16, torch.float32):
-            raw, fold = self._forward_fused(x, MC)
+            raw, fold = self._forward_fused(x, MC, occupancy)
             return (raw, fold) if lazy else MC.materialize(raw, fold)
         ups = []
         for i, block in enumerate(self.blocks):
@@ -107,12 +107,14 @@ class RPN(nn.Module):
             x = torch.cat(ups, dim=1)
         return x
 
-    def _forward_fused(self, x, MC):
+    def _forward_fused(self, x, MC, occupancy=None):
+        """`occupancy` (extension): the pillar canvas's occupancy map [B,1,H,W] -- the first layer then runs its sparse form"""
         fold, ups = None, []
         for i, block in enumerate(self.blocks):
             mods = list(block)
             st = mods[1].stride[0]
-            x, fold = MC.fused_conv(x, fold, mods[1], out_bn=mods[2], spec=MC.ConvSpec(3, 3, st, 1))  # ZeroPad2d(1) + conv(pad 0)
+            x, fold = MC.fused_conv(x, fold, mods[1], out_bn=mods[2], spec=MC.ConvSpec(3, 3, st, 1),  # ZeroPad2d(1) + conv(pad 0)
+                                    occupancy=occupancy if (i == 0 and fold is None) else None)
             for j in range(4, len(mods), 3):
                 x, fold = MC.fused_conv(x, fold, mods[j], out_bn=mods[j + 1])
             cut = getattr(self, "grad_cut", None)

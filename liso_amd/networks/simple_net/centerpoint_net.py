@@ -54,5 +54,6 @@ class CenterPointStyleNet(torch.nn.Module):
         hipGraph keep the pillar encoder outside of it"""
         bev_enc, bev_occupancy_map = canvas if canvas is not None else self.pfn(pcl_t0=pcls, img_t0=img_t0)
         aux_outputs = {"bev_net_input_dbg": bev_occupancy_map}
-        pred_dict = self.center_head(self.rpn(bev_enc, lazy=True))
+        # (the occupancy map lets the first RPN layer multiply occupied pillar cells only: liso_amd/utils/mfma_conv.py `_sparse_stem`)
+        pred_dict = self.center_head(self.rpn(bev_enc, lazy=True, occupancy=bev_occupancy_map))
         return {k: v.permute(0, 2, 3, 1) for k, v in pred_dict.items()}, aux_outputs  # reference :111

@@ -719,11 +719,12 @@ class _FusedConv(torch.autograd.Function):
         sc, sh = fold.scale_shift() if fold is not None else (None, None)
         occ = meta.get("occupancy") if fold is None else None  # (sparse pillar canvas: sparse / tile-skipping forward, cell list backward)
         res = None
-        if occ is not None and not meta.get("want_stats", False) and meta.get("out_dtype") in (None, torch.float32):
-            # the encoders' stem on the pillar canvas: only occupied cells are multiplied (liso_sparse_stem_forward_f32)
-            res = _sparse_stem(x_raw, occ, weight, bias, spec, "none", meta.get("out_relu", False))
+        if occ is not None and meta.get("out_dtype") in (None, x_raw.dtype):
+            # a stride-2 convolution on the pillar canvas (SLIM stem, the detector's first layer): only occupied cells are multiplied
+            res = _sparse_stem(x_raw, occ, weight, bias, spec, "batch" if meta.get("want_stats", False) else "none",
+                               meta.get("out_relu", False), stats_shift=meta.get("stats_shift"))
         if res is not None:
-            y, part = res[0], None
+            y, part = res
         else:
             y, part = conv_forward(x_raw, weight, bias, spec, sc, sh, in_relu=fold.relu if fold is not None else False,
                                    out_relu=meta.get("out_relu", False), out_dtype=meta.get("out_dtype"),
@@ -772,7 +773,11 @@ class _FusedConv(torch.autograd.Function):
             if db is not None:
                 db = db.to(weight.dtype)
         if ctx.needs_input_grad[0] or any(ctx.needs_input_grad[4:]):
-            g = conv_dgrad(dy, weight, spec, tuple(x_raw.shape))
+            g = None
+            if ctx.meta.get("occupancy") is not None and fold is None and co_true == dy.shape[1]:
+                g = _sparse_dgrad(dy, ctx.meta["occupancy"], weight, spec, tuple(x_raw.shape), x_raw.dtype)
+            if g is None:
+                g = conv_dgrad(dy, weight, spec, tuple(x_raw.shape))
             if fold is not None:
                 dx, fold_grads = _bn_backward(g, x_raw, fold)
             else:
@@ -918,44 +923,119 @@ def sparse_stem_overflowed(device):
     return bool(t is not None and int(t.item()) != 0)
 
 
-def _sparse_stem(x_raw, occupancy, weight, bias, spec, kind, relu):
-    """The encoders' first convolution on the pillar canvas in its sparse form (liso_sparse_stem_forward_f32): only occupied cells are
-    multiplied.  Inference, fp32 tensors in F32X3 arithmetic, 7x7 / 2 / 3, 64 -> 32 channels, a canvas with even height and a width
-    that is a multiple of 64.  -> (y logical NCHW, statistics partial sums | None) or None (the caller takes the dense kernel)."""
-    if os.environ.get("LISO_SPARSE_STEM", "1") == "0" or x_raw.dtype != torch.float32 or fp32_mode() != "x3":
+def _sparse_geometry(x_raw, weight, spec):
+    """(is_bf16, k, co) if the sparse-canvas kernels cover this convolution, else None: 7x7 / 2 / 3 with 32 filters on fp32 tensors (the
+    SLIM stem) or 3x3 / 2 / 1 with 64 filters on bf16 / fp32 tensors (the detector's first layer), 64 input channels, an even canvas
+    height and a width that is a multiple of 64; fp32 tensors only in F32X3 arithmetic (the exact-fp32 mode keeps the dense kernels)"""
+    if os.environ.get("LISO_SPARSE_STEM", "1") == "0" or spec.transposed or x_raw.dim() != 4:
         return None
     B, C, H, W = x_raw.shape
-    if (spec.kh, spec.kw, spec.stride, spec.padding, spec.transposed) != (7, 7, 2, 3, False) or C != 64 or weight.shape[0] != 32:
+    geo = (spec.kh, spec.kw, spec.stride, spec.padding, weight.shape[0])
+    bf = x_raw.dtype == torch.bfloat16
+    if C != 64 or tuple(weight.shape[1:]) != (64, spec.kh, spec.kw) or H % 2 or W % 64:
         return None
-    if H % 2 or W % 64 or bias is None:
-        return None
-    occ = occupancy if occupancy.dtype == torch.float32 else occupancy.float()
-    occ = occ.contiguous()
-    if occ.numel() != B * H * W:
-        return None
-    xv, xps = as_nhwc(x_raw, 4)
-    lib = L.lib()
-    cap = min(SPARSE_STEM_MAX_CELLS, H * W)
-    nbytes = lib.liso_sparse_stem_workspace_bytes(B, H, W, cap)
-    if nbytes == 0:
-        return None
-    dev = x_raw.device
+    if geo == (7, 7, 2, 3, 32) and x_raw.dtype == torch.float32 and fp32_mode() == "x3":
+        return False, 7, 32
+    if geo == (3, 3, 2, 1, 64) and (bf or (x_raw.dtype == torch.float32 and fp32_mode() == "x3")):
+        return bf, 3, 64
+    return None
+
+
+def _sparse_flag(dev):
     flag = _SPARSE_OVERFLOW.get(dev.index)
     if flag is None:
         if torch.cuda.is_current_stream_capturing():
-            return None  # (first use inside a capture: the persistent flag cannot be created here; the warm-up pass creates it)
+            return None  # (first use inside a capture: the persistent flag cannot be created here; a warm-up pass creates it)
         flag = _SPARSE_OVERFLOW[dev.index] = torch.zeros(1, dtype=torch.int32, device=dev)
-    packed = pack_weights(weight, spec, False, L.CONV_F32X3)
+    return flag
+
+
+def _occupancy_f32(occupancy, n):
+    occ = occupancy if occupancy.dtype == torch.float32 else occupancy.float()
+    occ = occ.contiguous()
+    return occ if occ.numel() == n else None
+
+
+def _sparse_stem(x_raw, occupancy, weight, bias, spec, kind, relu, stats_shift=None):
+    """A stride-2 convolution on the pillar canvas in its sparse form (liso_sparse_conv_forward): only occupied cells are multiplied.
+    `kind`: "none" (no statistics; `relu` in the epilogue) | "instance" / "batch" (raw output + per-block statistics partial sums,
+    shifted by `stats_shift`).  -> (y logical NCHW, partial sums [blocks, 2, co] | None) or None (the caller takes the dense kernel)."""
+    geo = _sparse_geometry(x_raw, weight, spec)
+    if geo is None:
+        return None
+    bf, k, co = geo
+    B, C, H, W = x_raw.shape
+    occ = _occupancy_f32(occupancy, B * H * W)
+    dev = x_raw.device
+    flag = _sparse_flag(dev)
+    if occ is None or flag is None:
+        return None
+    xv, xps = as_nhwc(x_raw, 8 if bf else 4)
+    lib = L.lib()
+    cap = min(SPARSE_STEM_MAX_CELLS, H * W)
+    nbytes = lib.liso_sparse_conv_workspace_bytes(B, H, W, k, co, cap, 0)
+    if nbytes == 0:
+        return None
+    mode = L.CONV_BF16 if bf else L.CONV_F32X3
+    packed = pack_weights(weight, spec, False, mode)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     ho, wo = H // 2, W // 2
-    y = torch.empty((B, ho, wo, 32), dtype=torch.float32, device=dev)
-    part = torch.empty((B * ho * wo // 32, 2, 32), dtype=torch.float32, device=dev) if kind == "instance" else None
+    y = torch.empty((B, ho, wo, co), dtype=x_raw.dtype, device=dev)
+    groups = lib.liso_sparse_conv_stat_groups(H, W, co)
+    if groups <= 0:
+        return None
+    part = torch.empty((B * ho * wo * co // (4096 * groups), 2, co), dtype=torch.float32, device=dev) if kind != "none" else None
     with torch.cuda.device(dev):
-        L.check(L.TIMER.launch("conv_sparse_stem", lambda: lib.liso_sparse_stem_forward_f32(
-            L.ptr(xv), xps, L.ptr(occ), L.ptr(packed), L.ptr(bias), B, H, W, cap, int(bool(relu) and kind == "none"), L.ptr(y),
-            L.ptr(part) if part is not None else None, L.ptr(flag), L.ptr(ws), nbytes, L.stream_ptr()),
-            units=2.0 * B * ho * wo * 32 * 64 * 49), "sparse_stem_forward")
+        L.check(L.TIMER.launch("conv_sparse_stem", lambda: lib.liso_sparse_conv_forward(
+            L.ptr(xv), xps, int(bf), L.ptr(occ), L.ptr(packed), L.ptr(bias) if bias is not None else None, B, H, W, k, co, cap,
+            int(bool(relu) and kind == "none"), L.ptr(y), L.ptr(part) if part is not None else None,
+            L.ptr(stats_shift) if (stats_shift is not None and part is not None) else None, L.ptr(flag), L.ptr(ws), nbytes, L.stream_ptr()),
+            units=2.0 * B * ho * wo * co * 64 * k * k), "sparse_conv_forward")
     return y.permute(0, 3, 1, 2), part
+
+
+def _sparse_dgrad(dy, occupancy, weight, spec, x_shape, x_dtype):
+    """data gradient of that convolution at the occupied cells (zeros elsewhere: nothing reads them -- the pillar encoder's backward
+    gathers the canvas gradient at its pillars) -> dx logical NCHW, or None (dense data gradient)"""
+    B, C, H, W = x_shape
+    if dy.dtype != x_dtype:
+        return None
+    fake = _SparseShape(x_shape, x_dtype)
+    geo = _sparse_geometry(fake, weight, spec)
+    if geo is None:
+        return None
+    bf, k, co = geo
+    occ = _occupancy_f32(occupancy, B * H * W)
+    dev = dy.device
+    flag = _sparse_flag(dev)
+    if occ is None or flag is None:
+        return None
+    gv, gps = as_nhwc(dy, 8 if bf else 4)
+    if gv.shape[1:3] != (H // 2, W // 2) or gv.shape[3] != co:
+        return None
+    lib = L.lib()
+    cap = min(SPARSE_STEM_MAX_CELLS, H * W)
+    nbytes = lib.liso_sparse_conv_workspace_bytes(B, H, W, k, co, cap, 1)
+    if nbytes == 0:
+        return None
+    packed = pack_weights(weight, spec, True, L.CONV_BF16 if bf else L.CONV_F32X3)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    dx = torch.zeros((B, H, W, C), dtype=x_dtype, device=dev)
+    with torch.cuda.device(dev):
+        L.check(L.TIMER.launch("conv_sparse_dgrad", lambda: lib.liso_sparse_conv_dgrad(
+            L.ptr(gv), gps, int(bf), L.ptr(occ), L.ptr(packed), B, H, W, k, co, cap, L.ptr(dx), C, L.ptr(flag), L.ptr(ws), nbytes,
+            L.stream_ptr()), units=2.0 * B * (H // 2) * (W // 2) * co * 64 * k * k), "sparse_conv_dgrad")
+    return dx.permute(0, 3, 1, 2)
+
+
+class _SparseShape:
+    """shape / dtype stand-in for `_sparse_geometry` where only the input's shape is at hand (backward)"""
+
+    def __init__(self, shape, dtype):
+        self.shape, self.dtype = tuple(shape), dtype
+
+    def dim(self):
+        return len(self.shape)
 
 
 @torch.no_grad()

@@ -113,7 +113,10 @@ def _two_detector_steps(fx, fmode, DetectorTrainer):
         total, _, _ = tr.loss(pcls, targets)
         total.backward()
         ref_loss = float(fx[f"step{step}_loss"])
-        assert abs(float(total) - ref_loss) <= 1e-3 * abs(ref_loss), (step, float(total), ref_loss)
+        # (step 1 in F32X3: the trajectories have separated -- see below -- and the loss follows the flipped ReLUs: 1.4e-3 measured with
+        # the sparse first layer, whose per-tap summation order differs from the dense kernel's; 9e-4 with the dense one)
+        lim_loss = 1e-3 if (step == 0 or fmode == "exact") else 3e-3
+        assert abs(float(total) - ref_loss) <= lim_loss * abs(ref_loss), (step, float(total), ref_loss)
         gn = np.array([float(named[k].grad.norm()) for k in keys])
         ref_gn = fx[f"step{step}_grad_norms"]
         big = ref_gn > 1e-4 * ref_gn.max()  # conv biases in front of a BatchNorm have a true gradient of 0
