@@ -194,7 +194,9 @@ int liso_conv_set_option(int option, int value);
  * holds sums of (y - stats_shift[c]) and their squares (y as stored) for liso_conv_bn_finalize / liso_conv_in_finalize, blocks =
  * batch * (hi / 2) * (wi / 2) / ((4096 / co) * liso_sparse_conv_stat_groups(hi, wi, co)).  liso_sparse_conv_dgrad: the data gradient of that convolution AT THE OCCUPIED CELLS
  * (dx rows of other cells are not written: the caller zero-fills dx; the pillar encoder's backward reads occupied cells only);
- * `w_packed_dgrad` = liso_conv_pack_weights(..., for_dgrad = 1, ...).  Workspace query: for_dgrad != 0 omits the product buffer. */
+ * `w_packed_dgrad` = liso_conv_pack_weights(..., for_dgrad = 1, ...).  Workspace query: for_dgrad != 0 omits the product buffer.
+ * reuse_lists != 0: `workspace` is the (unmodified) workspace of the liso_sparse_conv_forward call on the same canvas -- its cell
+ * lists are used as they are (occupancy may be NULL) instead of being rebuilt. */
 int liso_sparse_conv_stat_groups(int hi, int wi, int co);
 size_t liso_sparse_conv_workspace_bytes(int batch, int hi, int wi, int k, int co, int max_cells_per_sample, int for_dgrad);
 int liso_sparse_conv_forward(const void* x, long x_pix_stride, int is_bf16, const float* occupancy, const void* w_packed,
@@ -203,7 +205,7 @@ int liso_sparse_conv_forward(const void* x, long x_pix_stride, int is_bf16, cons
                              void* stream);
 int liso_sparse_conv_dgrad(const void* dy, long dy_pix_stride, int is_bf16, const float* occupancy, const void* w_packed_dgrad, int batch,
                            int hi, int wi, int k, int co, int max_cells_per_sample, void* dx, long dx_pix_stride, int* overflow,
-                           void* workspace, size_t workspace_bytes, void* stream);
+                           void* workspace, size_t workspace_bytes, int reuse_lists, void* stream);
 size_t liso_sparse_stem_workspace_bytes(int batch, int hi, int wi, int max_cells_per_sample);
 int liso_sparse_stem_forward_f32(const float* x, long x_pix_stride, const float* occupancy, const void* w_packed, const float* bias,
                                  int batch, int hi, int wi, int max_cells_per_sample, int relu, float* y, float* stats_partial,

@@ -178,7 +178,7 @@ SIGNATURES = {
     "liso_sparse_conv_stat_groups": (_i, [_i, _i, _i]),
     "liso_sparse_conv_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "liso_sparse_conv_forward": (_i, [_vp, ctypes.c_long, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "liso_sparse_conv_dgrad": (_i, [_vp, ctypes.c_long, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, ctypes.c_long, _vp, _vp, _sz, _vp]),
+    "liso_sparse_conv_dgrad": (_i, [_vp, ctypes.c_long, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, ctypes.c_long, _vp, _vp, _sz, _i, _vp]),
     "liso_sparse_stem_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "liso_sparse_stem_forward_f32": (_i, [_vp, ctypes.c_long, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "liso_conv_bn_finalize": (_i, [_vp, _i, _i, _i, ctypes.c_long, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp]),

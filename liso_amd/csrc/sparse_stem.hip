@@ -17,6 +17,7 @@
 // Cost: products of ~4k cells per sweep instead of 65k output pixels x 49 taps; the dense output (8.4 MB per sweep) is the floor.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/liso_conv.h"
 #include "../../include/liso_iou3d.h"
@@ -77,8 +78,13 @@ __global__ __launch_bounds__(1024) void cells_scan_kernel(const int* __restrict_
     const int per = (n_rows + 255) / 256;
     const int b0 = t * per;
     int s = 0;
-    for (int i = 0; i < per; i++)
-        if (b0 + i < n_rows) s += c[b0 + i];
+    for (int i0 = 0; i0 < per; i0 += 8) {  // (8 independent loads in flight: one dependent chain per row otherwise)
+        int v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = (i0 + u < per && b0 + i0 + u < n_rows) ? c[b0 + i0 + u] : 0;
+#pragma unroll
+        for (int u = 0; u < 8; u++) s += v[u];
+    }
     part[cls][t] = s;
     __syncthreads();
     for (int o = 1; o < 256; o <<= 1) {  // Hillis-Steele inclusive scan of the 256 partial sums of every class
@@ -88,11 +94,17 @@ __global__ __launch_bounds__(1024) void cells_scan_kernel(const int* __restrict_
         __syncthreads();
     }
     int run = t > 0 ? part[cls][t - 1] : 0;
-    for (int i = 0; i < per; i++)
-        if (b0 + i < n_rows) {
-            off4[(size_t)cls * n_rows + b0 + i] = run;  // relative to the class base (added by the consumers)
-            run += c[b0 + i];
-        }
+    for (int i0 = 0; i0 < per; i0 += 8) {
+        int v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = (i0 + u < per && b0 + i0 + u < n_rows) ? c[b0 + i0 + u] : 0;
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (i0 + u < per && b0 + i0 + u < n_rows) {
+                off4[(size_t)cls * n_rows + b0 + i0 + u] = run;  // relative to the class base (added by the consumers)
+                run += v[u];
+            }
+    }
     if (t == 255) cls_total[cls] = part[cls][255];
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -251,10 +263,11 @@ __global__ __launch_bounds__(256) void stem_gather_kernel(const unsigned* __rest
         s2[e] = 0.f;
     }
     // a block walks `groups` passes of PPB consecutive pixels (the pixels of a sample are a multiple of PPB * groups): one statistics
-    // row per block, about a thousand rows per launch like the dense kernel's
+    // row per block.  (Fetching the window bits of all passes and kernel rows up front -- independent loads -- was measured: 43.6
+    // instead of 35.5 us, the registers cost more occupancy than the shorter chain gains.)
     for (int g = 0; g < groups; g++) {
         const unsigned pixu = (blockIdx.x * (unsigned)groups + (unsigned)g) * PPB + pl;  // (sample, oy, ox) flattened (< 2^30: layout())
-        const unsigned rowu = pixu / (unsigned)wo;                                         // (32-bit divisions: 64-bit ones cost ~100 instructions each)
+        const unsigned rowu = pixu / (unsigned)wo;                                         // (32-bit divisions)
         const int ox = (int)(pixu - rowu * (unsigned)wo), b = (int)(rowu / (unsigned)ho), oy = (int)(rowu - (unsigned)b * (unsigned)ho);
         const long pix = (long)pixu;
         float acc[CPL];
@@ -455,6 +468,7 @@ int liso_sparse_conv_stat_groups(int hi, int wi, int co) {
     const long per_sample = (long)(hi / 2) * (wi / 2);
     const int ppb = 256 / (co / 16);
     int g = 4;
+    if (const char* e = getenv("LISO_SPARSE_GROUPS")) g = atoi(e) >= 1 && atoi(e) <= 4 ? atoi(e) : 4;  // experiments
     while (g > 1 && per_sample % (ppb * g)) g >>= 1;
     return per_sample % (ppb * g) ? 0 : g;
 }
@@ -504,9 +518,9 @@ int liso_sparse_conv_forward(const void* x, long x_pix_stride, int is_bf16, cons
 
 int liso_sparse_conv_dgrad(const void* dy, long dy_pix_stride, int is_bf16, const float* occupancy, const void* w_packed_dgrad, int batch,
                            int hi, int wi, int k, int co, int max_cells_per_sample, void* dx, long dx_pix_stride, int* overflow,
-                           void* workspace, size_t workspace_bytes, void* stream) {
+                           void* workspace, size_t workspace_bytes, int reuse_lists, void* stream) {
     Layout l;
-    if (!dy || !occupancy || !w_packed_dgrad || !dx || !workspace) return LISO_EINVAL;
+    if (!dy || (!occupancy && !reuse_lists) || !w_packed_dgrad || !dx || !workspace) return LISO_EINVAL;
     const int vec = is_bf16 ? 8 : 4;
     if (dy_pix_stride < co || (dy_pix_stride % vec) || dx_pix_stride < CI || (((uintptr_t)dy | (uintptr_t)w_packed_dgrad | (uintptr_t)workspace) & 15))
         return LISO_EINVAL;
@@ -515,7 +529,7 @@ int liso_sparse_conv_dgrad(const void* dy, long dy_pix_stride, int is_bf16, cons
     const int ho = hi / 2, wo = wi / 2;
     char* ws = (char*)workspace;
     hipStream_t st = (hipStream_t)stream;
-    cell_lists(occupancy, wi, l, ws, overflow, st);
+    if (!reuse_lists) cell_lists(occupancy, wi, l, ws, overflow, st);  // (else: the workspace of the forward call on the same canvas)
     const int* cells = (const int*)(ws + l.cells);
     const int* seg = (const int*)(ws + l.seg);
     const unsigned tb = (unsigned)(l.cap / 128);

@@ -723,8 +723,9 @@ class _FusedConv(torch.autograd.Function):
             # a stride-2 convolution on the pillar canvas (SLIM stem, the detector's first layer): only occupied cells are multiplied
             res = _sparse_stem(x_raw, occ, weight, bias, spec, "batch" if meta.get("want_stats", False) else "none",
                                meta.get("out_relu", False), stats_shift=meta.get("stats_shift"))
+        sparse_ws = None
         if res is not None:
-            y, part = res
+            y, part, sparse_ws = res
         else:
             y, part = conv_forward(x_raw, weight, bias, spec, sc, sh, in_relu=fold.relu if fold is not None else False,
                                    out_relu=meta.get("out_relu", False), out_dtype=meta.get("out_dtype"),
@@ -733,7 +734,7 @@ class _FusedConv(torch.autograd.Function):
         relu = bool(meta.get("out_relu", False))
         ctx.save_for_backward(x_raw, weight, y if relu else None)
         ctx.meta = {"spec": spec, "fold": fold, "has_bias": bias is not None, "n_fold_params": len(fold_params), "relu": relu,
-                    "bias_param": bias if isinstance(bias, torch.nn.Parameter) else None, "occupancy": occ}
+                    "bias_param": bias if isinstance(bias, torch.nn.Parameter) else None, "occupancy": occ, "sparse_ws": sparse_ws}
         return y
 
     @staticmethod
@@ -775,7 +776,7 @@ class _FusedConv(torch.autograd.Function):
         if ctx.needs_input_grad[0] or any(ctx.needs_input_grad[4:]):
             g = None
             if ctx.meta.get("occupancy") is not None and fold is None and co_true == dy.shape[1]:
-                g = _sparse_dgrad(dy, ctx.meta["occupancy"], weight, spec, tuple(x_raw.shape), x_raw.dtype)
+                g = _sparse_dgrad(dy, ctx.meta["occupancy"], weight, spec, tuple(x_raw.shape), x_raw.dtype, lists=ctx.meta.get("sparse_ws"))
             if g is None:
                 g = conv_dgrad(dy, weight, spec, tuple(x_raw.shape))
             if fold is not None:
@@ -889,7 +890,7 @@ def conv_in(x_raw, fold, conv, norm, relu=True, spec=None, occupancy=None):
     if fold is None and occupancy is not None:
         res = _sparse_stem(x_raw, occupancy, conv.weight, conv.bias, spec, kind, relu)
         if res is not None:
-            y, part = res
+            y, part, _ = res
             if kind == "none":
                 return y, None
             return y, _in_fold_from_partial(y, part, norm, relu)
@@ -991,10 +992,10 @@ def _sparse_stem(x_raw, occupancy, weight, bias, spec, kind, relu, stats_shift=N
             int(bool(relu) and kind == "none"), L.ptr(y), L.ptr(part) if part is not None else None,
             L.ptr(stats_shift) if (stats_shift is not None and part is not None) else None, L.ptr(flag), L.ptr(ws), nbytes, L.stream_ptr()),
             units=2.0 * B * ho * wo * co * 64 * k * k), "sparse_conv_forward")
-    return y.permute(0, 3, 1, 2), part
+    return y.permute(0, 3, 1, 2), part, ws
 
 
-def _sparse_dgrad(dy, occupancy, weight, spec, x_shape, x_dtype):
+def _sparse_dgrad(dy, occupancy, weight, spec, x_shape, x_dtype, lists=None):
     """data gradient of that convolution at the occupied cells (zeros elsewhere: nothing reads them -- the pillar encoder's backward
     gathers the canvas gradient at its pillars) -> dx logical NCHW, or None (dense data gradient)"""
     B, C, H, W = x_shape
@@ -1019,12 +1020,13 @@ def _sparse_dgrad(dy, occupancy, weight, spec, x_shape, x_dtype):
     if nbytes == 0:
         return None
     packed = pack_weights(weight, spec, True, L.CONV_BF16 if bf else L.CONV_F32X3)
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    reuse = lists is not None and lists.numel() >= nbytes  # (the forward call's workspace on this canvas: its cell lists are reused)
+    ws = lists if reuse else torch.empty(nbytes, dtype=torch.uint8, device=dev)
     dx = torch.zeros((B, H, W, C), dtype=x_dtype, device=dev)
     with torch.cuda.device(dev):
         L.check(L.TIMER.launch("conv_sparse_dgrad", lambda: lib.liso_sparse_conv_dgrad(
-            L.ptr(gv), gps, int(bf), L.ptr(occ), L.ptr(packed), B, H, W, k, co, cap, L.ptr(dx), C, L.ptr(flag), L.ptr(ws), nbytes,
-            L.stream_ptr()), units=2.0 * B * (H // 2) * (W // 2) * co * 64 * k * k), "sparse_conv_dgrad")
+            L.ptr(gv), gps, int(bf), L.ptr(occ), L.ptr(packed), B, H, W, k, co, cap, L.ptr(dx), C, L.ptr(flag), L.ptr(ws), ws.numel(),
+            int(reuse), L.stream_ptr()), units=2.0 * B * (H // 2) * (W // 2) * co * 64 * k * k), "sparse_conv_dgrad")
     return dx.permute(0, 3, 1, 2)
 
 
