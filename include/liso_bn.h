@@ -38,6 +38,14 @@ int liso_bn_relu_bwd(const void* dy, const void* x, int is_bf16, long m, int c, 
                      int training, int relu, void* dx, float* grad_gamma, float* grad_beta, void* workspace,
                      size_t workspace_bytes, void* stream);
 
+/* The same backward on rows that are CHANNEL SLICES of wider channels-last tensors: row r of dy / x / dx starts dy_stride / x_stride /
+ * dx_stride elements after row r - 1 (>= C, multiples of 16 bytes; the pointers address the slice's first channel).  The BatchNorms
+ * behind a channel concatenation (the three deblocks in front of the head, liso/networks/centerpoint/rpn.py:140-146) then read and
+ * write the concatenated tensors in place: no slice copies, no concatenation of the partial input gradients. */
+int liso_bn_relu_bwd_strided(const void* dy, long dy_stride, const void* x, long x_stride, int is_bf16, long m, int c, const float* gamma,
+                             const float* stats, int training, int relu, void* dx, long dx_stride, float* grad_gamma, float* grad_beta,
+                             void* workspace, size_t workspace_bytes, void* stream);
+
 /* The same backward in TWO launches instead of three: the last block of the reduction to finish also turns the partial sums into
  * grad_gamma / grad_beta / the dx coefficients.  `ticket`: one device-resident unsigned that is ZERO on entry and zero again on
  * return (the caller keeps one per BatchNorm layer, zeroed once; two calls in flight at the same time must not share it). */

@@ -157,6 +157,7 @@ SIGNATURES = {
     "liso_in_relu_bwd": (_i, [_vp, _vp, _i, _i, ctypes.c_long, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "liso_in_relu_bwd_sum": (_i, [_vp, _vp, _i, _i, ctypes.c_long, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "liso_bn_relu_bwd": (_i, [_vp, _vp, _i, ctypes.c_long, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "liso_bn_relu_bwd_strided": (_i, [_vp, ctypes.c_long, _vp, ctypes.c_long, _i, ctypes.c_long, _i, _vp, _vp, _i, _i, _vp, ctypes.c_long, _vp, _vp, _vp, _sz, _vp]),
     "liso_bn_relu_bwd_ticket": (_i, [_vp, _vp, _i, ctypes.c_long, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "liso_knn_workspace_bytes": (_sz, [_vp, _i]),
     "liso_knn_build_f32": (_i, [_vp, _vp, _i, _i, _vp, _sz, _vp]),

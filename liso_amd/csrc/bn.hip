@@ -58,6 +58,8 @@ struct Geom {
     int cg;        // column groups = C / V
     int rl;        // row lanes per block = 256 / cg
     long rows_per_block;
+    long xs, gs, ds;  // backward passes: elements between consecutive rows of x, dy and dx (C for dense [M, C] rows; wider when the
+                      // rows are a channel slice of a wider channels-last tensor)
 };
 
 // ---- forward statistics ------------------------------------------------------------------------------------------------
@@ -278,7 +280,7 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(const T* __rest
     constexpr int V = Vec<T>::V;
     __shared__ float s_a[kThreads][V + 1];
     __shared__ float s_b[kThreads][V + 1];
-    x += (size_t)blockIdx.y * m * c; dy += (size_t)blockIdx.y * m * c; stats += (size_t)blockIdx.y * 4 * c;
+    x += (size_t)blockIdx.y * m * g.xs; dy += (size_t)blockIdx.y * m * g.gs; stats += (size_t)blockIdx.y * 4 * c;
     partial += (size_t)blockIdx.y * gridDim.x * 2 * c;
     const int tid = threadIdx.x;
     const int col = tid % g.cg, rlane = tid / g.cg;
@@ -294,8 +296,8 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(const T* __rest
 #pragma unroll 4
     for (long r = rlane < g.rl ? r0 + rlane : r1; r < r1; r += g.rl) {
         float vx[V], vg[V];
-        Vec<T>::load(x + r * c + col * V, vx);
-        Vec<T>::load(dy + r * c + col * V, vg);
+        Vec<T>::load(x + r * g.xs + col * V, vx);
+        Vec<T>::load(dy + r * g.gs + col * V, vg);
 #pragma unroll
         for (int j = 0; j < V; j++) {
             float dz = vg[j];
@@ -430,7 +432,7 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_dx_kernel(const T* __restrict
                                                              const float* __restrict__ coef, T* __restrict__ dx) {
     constexpr int V = Vec<T>::V;
     const int col = threadIdx.x % g.cg, rlane = threadIdx.x / g.cg;
-    x += (size_t)blockIdx.y * m * c; dy += (size_t)blockIdx.y * m * c; dx += (size_t)blockIdx.y * m * c;
+    x += (size_t)blockIdx.y * m * g.xs; dy += (size_t)blockIdx.y * m * g.gs; dx += (size_t)blockIdx.y * m * g.ds;
     stats += (size_t)blockIdx.y * 4 * c; coef += (size_t)blockIdx.y * 3 * c;
     float sc[V], sh[V], mu[V], is[V], A[V], Bc[V], Cc[V];
 #pragma unroll
@@ -442,15 +444,15 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_dx_kernel(const T* __restrict
     const long stride = (long)gridDim.x * g.rl;
     for (long r = rlane < g.rl ? (long)blockIdx.x * g.rl + rlane : m; r < m; r += stride) {
         float vx[V], vg[V];
-        Vec<T>::load(x + r * c + col * V, vx);
-        Vec<T>::load(dy + r * c + col * V, vg);
+        Vec<T>::load(x + r * g.xs + col * V, vx);
+        Vec<T>::load(dy + r * g.gs + col * V, vg);
 #pragma unroll
         for (int j = 0; j < V; j++) {
             float dz = vg[j];
             if (RELU && !(fmaf(vx[j], sc[j], sh[j]) > 0.f)) dz = 0.f;
             vg[j] = A[j] * (dz - Bc[j] - (vx[j] - mu[j]) * is[j] * Cc[j]);
         }
-        Vec<T>::store(dx + r * c + col * V, vg);
+        Vec<T>::store(dx + r * g.ds + col * V, vg);
     }
 }
 
@@ -468,6 +470,7 @@ inline bool geom(int c, int v, long m, Geom* g, int* nblk) {
     long nb = (m + rpb - 1) / rpb;
     if (nb > kMaxBlocks) { rpb = (m + kMaxBlocks - 1) / kMaxBlocks; nb = (m + rpb - 1) / rpb; }
     g->rows_per_block = rpb;
+    g->xs = g->gs = g->ds = c;
     *nblk = (int)(nb > 0 ? nb : 1);
     return true;
 }
@@ -519,10 +522,16 @@ int liso_bn_relu_fwd(const void* x, int is_bf16, long m, int c, const float* gam
 
 static int bn_relu_bwd(const void* dy, const void* x, int is_bf16, long m, int c, const float* gamma, const float* stats,
                        int training, int relu, void* dx, float* grad_gamma, float* grad_beta, void* workspace,
-                       size_t workspace_bytes, unsigned* ticket, void* stream) {
+                       size_t workspace_bytes, unsigned* ticket, void* stream, long dy_stride = 0, long x_stride = 0, long dx_stride = 0) {
     Geom g;
     int nblk;
     if (m <= 0 || !geom(c, is_bf16 ? 8 : 4, m, &g, &nblk)) return LISO_EINVAL;
+    if (dy_stride || x_stride || dx_stride) {  // rows that are channel slices of wider channels-last tensors
+        const int v = is_bf16 ? 8 : 4;
+        if (dy_stride < c || x_stride < c || dx_stride < c || dy_stride % v || x_stride % v || dx_stride % v) return LISO_EINVAL;
+        if ((((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx) & 15) != 0) return LISO_EINVAL;
+        g.gs = dy_stride; g.xs = x_stride; g.ds = dx_stride;
+    }
     if (!dy || !x || !gamma || !stats || !dx || !grad_gamma || !grad_beta || !workspace) return LISO_EINVAL;
     if (workspace_bytes < liso_bn_workspace_bytes(c)) return LISO_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
@@ -548,6 +557,14 @@ int liso_bn_relu_bwd(const void* dy, const void* x, int is_bf16, long m, int c, 
                      size_t workspace_bytes, void* stream) {
     return bn_relu_bwd(dy, x, is_bf16, m, c, gamma, stats, training, relu, dx, grad_gamma, grad_beta, workspace, workspace_bytes,
                        nullptr, stream);
+}
+
+int liso_bn_relu_bwd_strided(const void* dy, long dy_stride, const void* x, long x_stride, int is_bf16, long m, int c, const float* gamma,
+                             const float* stats, int training, int relu, void* dx, long dx_stride, float* grad_gamma, float* grad_beta,
+                             void* workspace, size_t workspace_bytes, void* stream) {
+    if (dy_stride <= 0 || x_stride <= 0 || dx_stride <= 0) return LISO_EINVAL;
+    return bn_relu_bwd(dy, x, is_bf16, m, c, gamma, stats, training, relu, dx, grad_gamma, grad_beta, workspace, workspace_bytes,
+                       nullptr, stream, dy_stride, x_stride, dx_stride);
 }
 
 int liso_bn_relu_bwd_ticket(const void* dy, const void* x, int is_bf16, long m, int c, const float* gamma, const float* stats,

@@ -109,7 +109,7 @@ class RPN(nn.Module):
 
     def _forward_fused(self, x, MC, occupancy=None):
         """`occupancy` (extension): the pillar canvas's occupancy map [B,1,H,W] -- the first layer then runs its sparse form"""
-        fold, ups = None, []
+        fold, taps = None, []
         for i, block in enumerate(self.blocks):
             mods = list(block)
             st = mods[1].stride[0]
@@ -121,10 +121,28 @@ class RPN(nn.Module):
             if cut is not None and i == 0:  # (extension) behind block 0, in front of its two consumers: see mfma_conv.GradCut
                 x = cut.split(x)
             if i - self._upsample_start_idx >= 0:
-                d = self.deblocks[i - self._upsample_start_idx]
-                ups.append(MC.fused_conv(x, fold, d[0], out_bn=d[1]))
-        if len(ups) == 0:
+                taps.append((x, fold, self.deblocks[i - self._upsample_start_idx]))
+        if len(taps) == 0:
             return x, fold
-        if len(ups) == 1:
-            return ups[0]
-        return torch.cat([u[0] for u in ups], dim=1), MC.BnFold.cat([u[1] for u in ups])
+        if len(taps) == 1:
+            xi, fi, d = taps[0]
+            return MC.fused_conv(xi, fi, d[0], out_bn=d[1])
+        # the up-sampling branches write their raw maps straight into the channel ranges of ONE buffer (reference :140-146:
+        # torch.cat(ups, dim=1)): no concatenation pass forward, channel-slice views of the gradient backward
+        specs = [MC.ConvSpec.of(d[0]) for _, _, d in taps]
+        sizes = [s_.out_hw(xi.shape[2], xi.shape[3]) for s_, (xi, _, _) in zip(specs, taps)]
+        chans = [d[0].out_channels for _, _, d in taps]
+        vec = 8 if x.dtype == torch.bfloat16 else 4
+        ups = []
+        if len(set(sizes)) == 1 and all(c % 8 == 0 for c in chans) and sum(chans) % vec == 0:
+            (ho, wo), B = sizes[0], x.shape[0]
+            buf = torch.empty((B, ho, wo, sum(chans)), dtype=x.dtype, device=x.device)
+            off = 0
+            for (xi, fi, d), c in zip(taps, chans):
+                ups.append(MC.fused_conv(xi, fi, d[0], out_bn=d[1], out=(buf, off)))
+                off += c
+            raw = MC.slice_cat(buf.permute(0, 3, 1, 2), [u[0] for u in ups])
+        else:
+            ups = [MC.fused_conv(xi, fi, d[0], out_bn=d[1]) for xi, fi, d in taps]
+            raw = torch.cat([u[0] for u in ups], dim=1)
+        return raw, MC.BnFold.cat([u[1] for u in ups])

@@ -315,7 +315,7 @@ def _bytes(d, wgrad=False):
 
 
 def conv_forward(x, weight, bias, spec, in_scale=None, in_shift=None, in_relu=False, out_relu=False, out_dtype=None,
-                 want_stats=False, stats_shift=None, packed=None, affine_batch_stride=0, occupancy=None):
+                 want_stats=False, stats_shift=None, packed=None, affine_batch_stride=0, occupancy=None, out=None):
     """x: logical [B,Ci,H,W] (channels-last storage preferred) -> (y logical [B,Co,Ho,Wo] channels-last, stats_partial | None).
     `affine_batch_stride` > 0: in_scale / in_shift hold one vector per sample, that many elements apart (InstanceNorm).
     `occupancy`: fp32 [B,1,H,W] / [B,H,W], 0 where x is exactly zero in every channel (the pillar canvas's occupancy map): blocks
@@ -330,9 +330,20 @@ def conv_forward(x, weight, bias, spec, in_scale=None, in_shift=None, in_relu=Fa
     if mode != L.CONV_BF16:
         assert out_dtype == torch.float32
     out_f32 = out_dtype == torch.float32
-    y = torch.empty((B, ho, wo, co), dtype=out_dtype, device=x.device)
+    if out is not None:
+        # `out` = (channels-last buffer [B, ho, wo, C_total], first channel): the result becomes channels [first, first + co) of that
+        # buffer -- several convolutions write one concatenated map without a concatenation pass
+        buf, y_off = out
+        assert buf.is_contiguous() and tuple(buf.shape[:3]) == (B, ho, wo) and buf.dtype == out_dtype and y_off + co <= buf.shape[3], \
+            (tuple(buf.shape), (B, ho, wo, co), y_off)
+        y_ps = buf.shape[3]
+        assert y_ps % _vec(mode) == 0 and y_off % 8 == 0
+        y_base, y = buf, buf[..., y_off:y_off + co]
+    else:
+        y = torch.empty((B, ho, wo, co), dtype=out_dtype, device=x.device)
+        y_base, y_ps, y_off = y, co, 0
     build = scatter_desc if spec.transposed else gather_desc
-    d = build(spec, B, hi, wi, ci, xps, ho, wo, co, co, 0, mode, out_f32, in_relu, out_relu)
+    d = build(spec, B, hi, wi, ci, xps, ho, wo, co, y_ps, y_off, mode, out_f32, in_relu, out_relu)
     if affine_batch_stride:
         d = L.ConvDesc.from_buffer_copy(d)  # (descriptors are cached and shared: never edit them in place)
         d.in_affine_batch_stride = int(affine_batch_stride)
@@ -355,7 +366,7 @@ def conv_forward(x, weight, bias, spec, in_scale=None, in_shift=None, in_relu=Fa
     with torch.cuda.device(x.device):
         L.check(L.TIMER.launch(_timer_name(mode, "fwd"), lambda: lib.liso_conv_forward_sparse(
             ctypes.byref(d), L.ptr(xv), L.ptr(packed), L.ptr(b) if b is not None else None,
-            L.ptr(in_scale) if in_scale is not None else None, L.ptr(in_shift) if in_shift is not None else None, L.ptr(y),
+            L.ptr(in_scale) if in_scale is not None else None, L.ptr(in_shift) if in_shift is not None else None, L.ptr(y_base),
             L.ptr(stats) if stats is not None else None, L.ptr(stats_shift) if stats_shift is not None else None,
             L.ptr(occ) if occ is not None else None, L.stream_ptr()),
             units=_flops(d), nbytes=_bytes(d)), "conv_forward")
@@ -645,38 +656,59 @@ def _bn_ticket(key, device):
     return ent[0][slot:slot + 1]
 
 
-def _bn_backward_group(g, x_raw, grp, relu, training):
-    """gradient through relu?(bn(x_raw)) of ONE BatchNorm given g = dL/d(output): -> (dx_raw, dgamma, dbeta);
-    g, x_raw logical NCHW (channel slices are copied: the kernels of include/liso_bn.h take dense [M, C] rows)"""
+def _rows_view(t, vec):
+    """physical [B,H,W,C] view of a logical-NCHW tensor whose (pixel, channel) rows are regular -- dense, or a channel slice of a wider
+    channels-last tensor -- and its row stride in elements; (None, 0) otherwise"""
+    v = t.permute(0, 2, 3, 1)
+    B, H, W, C = v.shape
+    ps = _pix_stride(v)
+    regular = (v.stride(3) == 1 or C == 1) and ps >= C and (W == 1 or v.stride(2) == ps) and (H == 1 or v.stride(1) == W * ps) and \
+        (B == 1 or v.stride(0) == H * W * ps) and ps % vec == 0 and v.data_ptr() % 16 == 0
+    return (v, ps) if regular else (None, 0)
+
+
+def _bn_backward_group(g, x_raw, grp, relu, training, out=None):
+    """gradient through relu?(bn(x_raw)) of ONE BatchNorm given g = dL/d(output): -> (dx_raw, dgamma, dbeta); g, x_raw logical NCHW.
+    Channel slices of wider channels-last tensors are read in place (liso_bn_relu_bwd_strided); `out`: a logical-NCHW tensor (e.g. the
+    group's channel slice of the concatenated input gradient) to write dx_raw into."""
     C = grp["gamma"].shape[0]
-    xv = x_raw.permute(0, 2, 3, 1)
-    gv = g.permute(0, 2, 3, 1)
-    if not xv.is_contiguous():
-        xv = xv.contiguous()
-    if gv.dtype != xv.dtype:
-        gv = gv.to(xv.dtype)
-    if not gv.is_contiguous():
-        gv = gv.contiguous()
+    vec = 8 if x_raw.dtype == torch.bfloat16 else 4
+    xv, xs = _rows_view(x_raw, vec)
+    if xv is None:
+        xv, xs = x_raw.permute(0, 2, 3, 1).contiguous(), C
+    if g.dtype != xv.dtype:
+        g = g.to(xv.dtype)
+    gv, gs = _rows_view(g, vec)
+    if gv is None:
+        gv, gs = g.permute(0, 2, 3, 1).contiguous(), C
     M = xv.numel() // C
     lib = L.lib()
-    dx = torch.empty_like(xv)
+    dxv, ds = _rows_view(out, vec) if out is not None else (None, 0)
+    if dxv is None:
+        dxv, ds = torch.empty(xv.shape, dtype=xv.dtype, device=xv.device), C
     tg, tb = _direct_target(grp["gamma"]), _direct_target(grp["beta"])
     direct = tg is not None and tb is not None
     gg = tg if direct else torch.empty(C, dtype=torch.float32, device=xv.device)
     gb = tb if direct else torch.empty(C, dtype=torch.float32, device=xv.device)
     nbytes = lib.liso_bn_workspace_bytes(C)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=xv.device)
-    ticket = _bn_ticket(grp.get("ticket_key", id(grp["gamma"])), xv.device)
-    args = (L.ptr(gv), L.ptr(xv), int(xv.dtype == torch.bfloat16), M, C, L.ptr(grp["gamma"]), L.ptr(grp["stats"]), int(training),
-            int(relu), L.ptr(dx), L.ptr(gg), L.ptr(gb), L.ptr(ws), nbytes)
+    bf = int(xv.dtype == torch.bfloat16)
+    units = 5 * M * C * xv.element_size()
     with torch.cuda.device(xv.device):
-        if ticket is not None:  # two launches: the reduction's last block also finalises (include/liso_bn.h)
-            L.check(L.TIMER.launch("bn_bwd", lambda: lib.liso_bn_relu_bwd_ticket(*args, L.ptr(ticket), L.stream_ptr()),
-                                   units=5 * M * C * xv.element_size()), "bn_relu_bwd_ticket")
+        if (xs, gs, ds) != (C, C, C):
+            L.check(L.TIMER.launch("bn_bwd", lambda: lib.liso_bn_relu_bwd_strided(
+                L.ptr(gv), gs, L.ptr(xv), xs, bf, M, C, L.ptr(grp["gamma"]), L.ptr(grp["stats"]), int(training), int(relu), L.ptr(dxv), ds,
+                L.ptr(gg), L.ptr(gb), L.ptr(ws), nbytes, L.stream_ptr()), units=units), "bn_relu_bwd_strided")
         else:
-            L.check(L.TIMER.launch("bn_bwd", lambda: lib.liso_bn_relu_bwd(*args, L.stream_ptr()),
-                                   units=5 * M * C * xv.element_size()), "bn_relu_bwd")
-    return dx.permute(0, 3, 1, 2), (None if direct else gg), (None if direct else gb)
+            args = (L.ptr(gv), L.ptr(xv), bf, M, C, L.ptr(grp["gamma"]), L.ptr(grp["stats"]), int(training), int(relu), L.ptr(dxv), L.ptr(gg),
+                    L.ptr(gb), L.ptr(ws), nbytes)
+            ticket = _bn_ticket(grp.get("ticket_key", id(grp["gamma"])), xv.device)
+            if ticket is not None:  # two launches: the reduction's last block also finalises (include/liso_bn.h)
+                L.check(L.TIMER.launch("bn_bwd", lambda: lib.liso_bn_relu_bwd_ticket(*args, L.ptr(ticket), L.stream_ptr()), units=units),
+                        "bn_relu_bwd_ticket")
+            else:
+                L.check(L.TIMER.launch("bn_bwd", lambda: lib.liso_bn_relu_bwd(*args, L.stream_ptr()), units=units), "bn_relu_bwd")
+    return dxv.permute(0, 3, 1, 2), (None if direct else gg), (None if direct else gb)
 
 
 def _bn_backward(g, x_raw, fold):
@@ -690,14 +722,19 @@ def _bn_backward(g, x_raw, fold):
     # concatenation of the partial results; the per-group parameter gradients are slices of its two output vectors
     Cs = [grp["gamma"].shape[0] for grp in fold.groups]
     if sum(Cs) > 256:  # (the BatchNorm kernels take up to 256 channels per call: e.g. the deblocks' 3 x 128-channel concatenation)
-        dxs, grads, a = [], [], 0
+        # every group reads its channel slice of g / x_raw in place and writes its slice of ONE input-gradient tensor: no slice
+        # copies, no concatenation
+        B, _, H, W = x_raw.shape
+        dx_full = torch.empty((B, H, W, sum(Cs)), dtype=x_raw.dtype, device=x_raw.device).permute(0, 3, 1, 2)
+        grads, a = [], 0
         for grp in fold.groups:
             C = grp["gamma"].shape[0]
-            dx, gg, gb = _bn_backward_group(g[:, a:a + C], x_raw[:, a:a + C], grp, fold.relu, fold.training)
-            dxs.append(dx)
+            dx, gg, gb = _bn_backward_group(g[:, a:a + C], x_raw[:, a:a + C], grp, fold.relu, fold.training, out=dx_full[:, a:a + C])
+            if dx.data_ptr() != dx_full[:, a:a + C].data_ptr():  # (irregular layout: the group wrote a tensor of its own)
+                dx_full[:, a:a + C].copy_(dx)
             grads += [gg, gb]
             a += C
-        return torch.cat(dxs, dim=1), grads
+        return dx_full, grads
     gam = torch.cat([grp["gamma"].detach() for grp in fold.groups])
     stats = torch.cat([grp["stats"][k * c:(k + 1) * c] for k in range(4) for grp, c in zip(fold.groups, Cs)])  # scale | shift | mean | invstd
     dx, gg, gb = _bn_backward_group(g, x_raw, {"gamma": gam, "beta": None, "stats": stats, "ticket_key": id(fold.groups[0]["gamma"])},
@@ -729,7 +766,8 @@ class _FusedConv(torch.autograd.Function):
         else:
             y, part = conv_forward(x_raw, weight, bias, spec, sc, sh, in_relu=fold.relu if fold is not None else False,
                                    out_relu=meta.get("out_relu", False), out_dtype=meta.get("out_dtype"),
-                                   want_stats=meta.get("want_stats", False), stats_shift=meta.get("stats_shift"), occupancy=occ)
+                                   want_stats=meta.get("want_stats", False), stats_shift=meta.get("stats_shift"), occupancy=occ,
+                                   out=meta.get("out"))
         meta["stats_partial"] = part
         relu = bool(meta.get("out_relu", False))
         ctx.save_for_backward(x_raw, weight, y if relu else None)
@@ -802,7 +840,7 @@ def _aten_wgrad(x_raw, dy, weight, spec, fold, has_bias):
     return gw.float(), (gb.float() if has_bias else None)
 
 
-def fused_conv(x_raw, fold, conv, out_bn=None, out_dtype=None, out_relu=False, spec=None, occupancy=None):
+def fused_conv(x_raw, fold, conv, out_bn=None, out_dtype=None, out_relu=False, spec=None, occupancy=None, out=None):
     """y_raw = conv(relu?(bn(x_raw))) (+ bias).  `fold`: BnFold pending on x_raw or None.  `conv`: one nn.Conv2d /
     nn.ConvTranspose2d, or a list of nn.Conv2d with the same geometry and input (run as ONE convolution with the filters
     concatenated along the output channels).  `out_bn`: the BatchNorm2d (list: one per convolution of the list) that follows
@@ -825,7 +863,9 @@ def fused_conv(x_raw, fold, conv, out_bn=None, out_dtype=None, out_relu=False, s
             hit = convs[0]._liso_merged_weights = (key, w, b)
         weight, bias = hit[1], hit[2]
     training_bn = bns is not None and (bns[0].training or not bns[0].track_running_stats)
-    meta = {"spec": spec, "fold": fold, "out_dtype": out_dtype, "want_stats": training_bn, "out_relu": out_relu, "occupancy": occupancy}
+    # (`out`: (channels-last buffer, first channel) the raw output is written into, see conv_forward)
+    meta = {"spec": spec, "fold": fold, "out_dtype": out_dtype, "want_stats": training_bn, "out_relu": out_relu, "occupancy": occupancy,
+            "out": out if occupancy is None else None}
     if training_bn and len(bns) == 1 and bns[0].track_running_stats:
         # any per-channel constant close to the mean keeps the sums well conditioned: the running mean.  (The finalize kernel
         # reads stats_shift[c] before the same thread updates running_mean[c]: passing the live buffer is safe.)
@@ -1104,6 +1144,27 @@ def materialize(x_raw, fold):
     if fold is None:
         return x_raw
     return _Materialize.apply(x_raw, fold, *fold.params())
+
+
+class _SliceCat(torch.autograd.Function):
+    """`full` [B, sum C_k, H, W] already holds the maps `parts` in consecutive channel ranges (their convolutions wrote them there:
+    conv_forward(out=...)): the concatenation without a copy.  Backward: the channel slices of the gradient, as views."""
+
+    @staticmethod
+    def forward(ctx, full, *parts):
+        ctx.sizes = [p.shape[1] for p in parts]
+        return full.detach()
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None, *torch.split(g, ctx.sizes, dim=1))
+
+
+def slice_cat(full, parts):
+    """the concatenated map `full` whose channel ranges `parts` were written in place, connected to the parts' autograd history"""
+    if torch.is_grad_enabled() and any(p.requires_grad for p in parts):
+        return _SliceCat.apply(full, *parts)
+    return full
 
 
 class GradCut:
