@@ -593,7 +593,7 @@ def main():
         export_cost = {"forward_direction_point_flow_ms_per_pair": wall(lambda: trainer.slim.infer_point_flow_t0_t1(s0, s1)),
                        "both_directions_bev_maps_ms_per_pair": wall(lambda: trainer.slim.infer_export_predictions(s0, s1)),
                        "note": "eager launches, one pair, pillar encoders included (the loop replays the one-direction form from a "
-                               "hipGraph, 4 pairs per replay); SLIM.infer_export_predictions feeds liso_amd.slim.flow_io.flow_export_dict"}
+                               "hipGraph, several pairs per replay); SLIM.infer_export_predictions feeds liso_amd.slim.flow_io.flow_export_dict"}
     checksums = None
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
