@@ -109,7 +109,7 @@ class _ParamGate(torch.autograd.Function):
             with torch.no_grad():
                 for src, g in zip(st.params, grads):
                     if src.grad is None:
-                        src.grad = g.clone()
+                        src.grad = g  # (a fresh tensor of this launch, or a slice of one: the trainer gathers it into its flat buffer)
                     else:
                         src.grad.add_(g)
             return (None,) * (1 + len(params))

@@ -59,6 +59,35 @@ def get_slim_optimizer_scheduler(slim_cfg, params):
     return opt, sched
 
 
+def gather_gradients(device, params, add=False):
+    """`params`: (parameter, its flat-buffer gradient view) whose `.grad` was None during the backward pass.  Their gradient
+    tensors -> the flat views by one launch per 48 tensors (liso_gather_f32); `.grad` is the flat view again afterwards.  `add`: the
+    second half of a split backward pass adds (nothing arrives there for these parameters today).  -> the source tensors (keep them
+    alive until the launch has run: inside a capture they belong to the graph's pool anyway)."""
+    from liso_amd import _lib as L
+    import ctypes
+
+    jobs = []
+    for p_, flat in params:
+        g = p_.grad
+        p_.grad = flat
+        if g is None or g is flat:
+            continue
+        if add or g.dtype != torch.float32 or g.stride() != flat.stride() or g.shape != flat.shape:
+            flat.add_(g) if add else flat.copy_(g)
+            continue
+        jobs.append((g, flat))
+    if not jobs:
+        return []
+    n = len(jobs)
+    src = (ctypes.c_void_p * n)(*[g.data_ptr() for g, _ in jobs])
+    dst = (ctypes.c_void_p * n)(*[f.data_ptr() for _, f in jobs])
+    cnt = (ctypes.c_size_t * n)(*[g.numel() for g, _ in jobs])
+    with torch.cuda.device(device):
+        L.check(L.lib().liso_gather_f32(n, src, dst, cnt, L.stream_ptr()), "gather_f32")
+    return [g for g, _ in jobs]
+
+
 class DetectorTrainer:
     def __init__(self, cfg, device, compute_dtype=torch.float32, total_steps=None, fused_loss=None, use_graph=False, exact=None,
                  grad_buckets=None):
@@ -330,31 +359,7 @@ class DetectorTrainer:
             torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(True)
 
     def _gather_gradients(self, params, add=False):
-        """`params`: (parameter, its flat-buffer gradient view) whose `.grad` was None during the backward pass.  Their gradient
-        tensors -> the flat views by one launch; `.grad` is the flat view again afterwards.  `add`: the second half of a split backward
-        pass adds (nothing arrives there for these parameters today)."""
-        from liso_amd import _lib as L
-        import ctypes
-
-        jobs = []
-        for p_, flat in params:
-            g = p_.grad
-            p_.grad = flat
-            if g is None or g is flat:
-                continue
-            if add or g.dtype != torch.float32 or g.stride() != flat.stride() or g.shape != flat.shape:
-                flat.add_(g) if add else flat.copy_(g)
-                continue
-            jobs.append((g, flat))
-        if not jobs:
-            return
-        n = len(jobs)
-        src = (ctypes.c_void_p * n)(*[g.data_ptr() for g, _ in jobs])
-        dst = (ctypes.c_void_p * n)(*[f.data_ptr() for _, f in jobs])
-        cnt = (ctypes.c_size_t * n)(*[g.numel() for g, _ in jobs])
-        with torch.cuda.device(self.device):
-            L.check(L.lib().liso_gather_f32(n, src, dst, cnt, L.stream_ptr()), "gather_f32")
-        self._gather_keepalive = [g for g, _ in jobs]  # (read by the launch above: released with the next pass / the graph's pool)
+        self._gather_keepalive = gather_gradients(self.device, params, add)
 
     def _graph_step(self, pcls, targets):
         # what the graph consumes: the [B, 64, gx, gy] canvas (batch size; grid and dtype are fixed per trainer) and the target maps.
@@ -445,6 +450,13 @@ class SlimTrainer:
             for p in params:  # gradients are views into one flat buffer: one memset, one all-reduce
                 p.grad = self._flat_grad[off:off + p.numel()].view_as(p)
                 off += p.numel()
+            # parameters whose gradients are produced INSIDE the captured step (everything but the pillar encoder, whose backward
+            # runs eagerly behind the replay): with .grad = None during the captured backward pass autograd keeps the gradient
+            # tensors instead of launching one add_ per parameter into the zeroed flat buffer (~100 launches per step), and one
+            # gather launch per 48 tensors moves them into their slices (DetectorTrainer does the same for its few such parameters)
+            outside = {id(p) for p in self.net.raft_network.pp_layer.parameters()} if hasattr(self.net.raft_network, "pp_layer") else set()
+            self._gather_params = [(p, p.grad) for p in params if id(p) not in outside] \
+                if os.environ.get("LISO_GATHER_GRADS", "1") != "0" else []
             if self.world > 1:  # replicas start identical (what the DDP constructor would do)
                 for t in list(self.net.parameters()) + list(self.net.buffers()):
                     dist.broadcast(t.data, src=0)
@@ -599,12 +611,15 @@ class SlimTrainer:
             if self._pack_jobs:  # every layer's forward / data-gradient panels from ONE launch (recorded in the warm-up)
                 MC.set_step_packs(MC.batched_pack(self._pack_jobs))
             thr._defer = [] if defer else None
+            for p_, _ in self._gather_params:
+                p_.grad = None
             try:
                 total, _, _ = self.loss(s0, s1, all_valid, canvases=self._static_canv, gather_plan=self._static_plan)
                 total.backward()
             finally:
                 MC.set_step_packs(None)
                 self._thr_items, thr._defer = thr._defer, None
+                self._gather_keepalive = gather_gradients(self.device, self._gather_params)
             return total.detach()
 
         with torch.cuda.stream(side):  # warm-up off the capture: MIOpen / rocBLAS pick their kernels, caches fill
