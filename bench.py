@@ -493,6 +493,9 @@ def main():
         torch.cuda.set_stream(main_stream)
     for _ in range(args.warmup):
         step()
+    captures_after_warmup = None
+    if args.workload == "loop" and not args.eager:  # (reported: a capture inside the timed region would be part of `value`)
+        captures_after_warmup = (len(trainer._infer_graphs), trainer.mine_captures)
 
     graphed = (args.workload == "slim" and args.graph) or (args.workload in ("loop", "detector", "stress") and not args.eager)
     if not graphed:  # per-launch HIP events on the launch stream, inside the timed region
@@ -676,6 +679,8 @@ def main():
                        **({"points_per_cloud_ring": [min(counts), max(counts)], "sweep_pairs_in_rotation": len(pairs),
                            "point_bucket_rows": trainer.infer_point_bucket,
                            "graph_captures": {"inference": len(trainer._infer_graphs), "box_mining": trainer.mine_captures,
+                                              "inside_timed_region": (len(trainer._infer_graphs) - captures_after_warmup[0]) +
+                                              (trainer.mine_captures - captures_after_warmup[1]),
                                               "box_mining_eager_fallbacks": trainer.mine_eager_fallbacks}}
                           if args.workload == "loop" else {}),
                        "launch": ("eager" if not graphed else "hipGraph replay of fwd+loss+bwd, eager RMSprop" if args.workload == "slim"
