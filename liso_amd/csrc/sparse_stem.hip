@@ -184,14 +184,14 @@ __global__ __launch_bounds__(256) void stem_taps_kernel(const void* __restrict__
                                                         float* __restrict__ prod) {
     using G = Geo<K>;
     constexpr int ROWF = G::SLOTS * CO, NT = CO / 32, KP8 = CI / 8;
-    const int pos0 = blockIdx.x * 128;
-    const int cls = class_of_block(seg, pos0);
+    // 32 cells per block; the taps of the cells' class are dealt to the four waves (a block of 128 cells with every wave walking all
+    // 16 taps of the 7x7 kernel took 46 us for 8 sweeps: one dependent load -> MFMA -> store chain per tap)
+    const int row0 = blockIdx.x * 32;
+    const int cls = class_of_block(seg, row0);
     if (cls < 0) return;
     const int end = seg[4 + cls];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = lane & 31, h = lane >> 5;
-    const int row0 = pos0 + wave * 32;
-    if (row0 >= end) return;
     // A fragments: the features of cell row0 + r, channels ks * 16 + h * 8 .. + 7
     uint4 ah[4], al[4];
     {
@@ -208,8 +208,10 @@ __global__ __launch_bounds__(256) void stem_taps_kernel(const void* __restrict__
         }
     }
     const int cy = cls >> 1, cx = cls & 1;
+    int ti = 0;
     for (int ky = cy; ky < K; ky += 2) {
-        for (int kx = cx; kx < K; kx += 2) {
+        for (int kx = cx; kx < K; kx += 2, ti++) {
+            if ((ti & 3) != wave) continue;
             const int tap = ky * K + kx;
             const int slot = (ky >> 1) * G::SX + (kx >> 1);
 #pragma unroll
@@ -263,7 +265,8 @@ __global__ __launch_bounds__(256) void stem_gather_kernel(const unsigned* __rest
         s2[e] = 0.f;
     }
     // a block walks `groups` passes of PPB consecutive pixels (the pixels of a sample are a multiple of PPB * groups): one statistics
-    // row per block.  (Fetching the window bits of all passes and kernel rows up front -- independent loads -- was measured: 43.6
+    // row per block.  (Also measured: one 64-bit window mask per output pixel, set by OR atomics in cells_fill_kernel, instead of the
+    // row bitmaps -- the gather went 74 -> 64 us on 8 sweeps, the fill 5 -> 25 us: no gain.)  (Fetching the window bits of all passes and kernel rows up front -- independent loads -- was measured: 43.6
     // instead of 35.5 us, the registers cost more occupancy than the shorter chain gains.)
     for (int g = 0; g < groups; g++) {
         const unsigned pixu = (blockIdx.x * (unsigned)groups + (unsigned)g) * PPB + pl;  // (sample, oy, ox) flattened (< 2^30: layout())
@@ -501,7 +504,7 @@ int liso_sparse_conv_forward(const void* x, long x_pix_stride, int is_bf16, cons
     const unsigned* bitmap = (const unsigned*)(ws + l.bitmap);
     const int* cell_pos = (const int*)(ws + l.cell_pos);
     float* prod = (float*)(ws + l.prod);
-    const unsigned tb = (unsigned)(l.cap / 128), gb = (unsigned)((long)batch * ho * wo / ((long)ppb * groups));
+    const unsigned tb = (unsigned)(l.cap / 32), gb = (unsigned)((long)batch * ho * wo / ((long)ppb * groups));
 #define LISO_SPARSE_FWD(K, CO, BF)                                                                                                     \
     do {                                                                                                                                \
         stem_taps_kernel<K, CO, BF><<<tb, 256, 0, st>>>(x, x_pix_stride, cells, seg, (const uint4*)w_packed, prod);                     \
