@@ -324,6 +324,12 @@ def bench_iou3d(dev, torch, with_cpu=True):
     return out
 
 
+def _sparse_overflow(dev):
+    from liso_amd.utils import mfma_conv as MC
+
+    return bool(MC.sparse_stem_overflowed(dev))
+
+
 def child_leg(extra, steps=10, warmup=3, timeout_s=420):
     """one bounded run of another workload of this script as a CHILD process (started, never exec'ed, from this GPU process; the
     parent idles meanwhile) -> its JSON line trimmed to the numbers a reader of the default line needs"""
@@ -688,7 +694,11 @@ def main():
                                        "flow clustering / AdamW" + (f"; 3-stage pipeline on 3 HIP streams: SLIM inference {max(1, args.lookahead - 1 - args.flow_ahead)} pairs per replay | "
                                                                     "clustering+NMS+targets 1-2 pairs ahead (fixed box slots, no host reads) | "
                                                                     "detector step on pair i" if args.workload == "loop" and overlap else "")),
-                       "convolutions": "MIOpen (--miopen-convs)" if args.miopen_convs else "own MFMA implicit-GEMM kernels"},
+                       "convolutions": "MIOpen (--miopen-convs)" if args.miopen_convs else "own MFMA implicit-GEMM kernels",
+                       # the stride-2 layers that read a pillar canvas multiply occupied cells only; True here would mean a batch held
+                       # more occupied cells than the cell lists' capacity and some were dropped (never, with the voxeliser's 40000 cap)
+                       "sparse_canvas_convolutions": {"enabled": os.environ.get("LISO_SPARSE_STEM", "1") != "0",
+                                                      "cell_capacity_exceeded": _sparse_overflow(dev)}},
             "final_loss": float(loss),
             "roofline": {"kernel": kname, "bound": bound, "achieved": achieved, "peak": peak, "unit": runit,
                          "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,

@@ -110,6 +110,9 @@ class DetectorTrainer:
         from liso_amd.losses import fused_centerpoint
 
         self.cfg, self.device = cfg, device
+        if device.type == "cuda":  # (persistent device flag of the sparse canvas convolutions: must exist before the first capture)
+            from liso_amd.utils import mfma_conv as _MC
+            _MC._sparse_flag(device)
         self.use_graph = bool(use_graph) and device.type == "cuda"
         self._graph, self._graph2, self._graph_sig, self._capture_stream = None, None, None, None
         self.fused_loss = (fused_centerpoint.supports(cfg) and device.type == "cuda") if fused_loss is None else fused_loss
@@ -419,6 +422,9 @@ class SlimTrainer:
             from liso_amd.utils import mfma_conv as MC
             MC.set_fp32_mode("exact" if exact else "x3")
         self.cfg, self.slim_cfg, self.device = cfg, cfg.SLIM, device
+        if device.type == "cuda":  # (persistent device flag of the sparse canvas convolutions: must exist before the first capture)
+            from liso_amd.utils import mfma_conv as _MC
+            _MC._sparse_flag(device)
         self.net = SLIM(cfg, num_train_samples=num_train_samples).to(device)
         if channels_last:  # measured slower than NCHW filters on gfx950 (65 vs 59 ms per step): MIOpen's fp32 Winograd is NCHW
             # the pillar canvas is channels-last storage; keep filters in the same layout so MIOpen's NHWC kernels run
@@ -798,6 +804,9 @@ class LisoLoopTrainer:
         if exact is not None:  # arithmetic of the fp32 convolutions (SLIM; the detector too when compute_dtype is float32)
             from liso_amd.utils import mfma_conv as MC
             MC.set_fp32_mode("exact" if exact else "x3")
+        if device.type == "cuda":  # (persistent device flag of the sparse canvas convolutions: must exist before the first capture)
+            from liso_amd.utils import mfma_conv as _MC
+            _MC._sparse_flag(device)
         self.use_graph = bool(use_graph) and device.type == "cuda"
         self._graph_infer = self.use_graph and use_graph in (True, "infer")
         self._graph_det = self.use_graph and use_graph in (True, "detector")
