@@ -134,3 +134,39 @@ def test_bn_backward_with_last_block_finalize_equals_three_launch_form(C, HW, N,
         assert id(gamma) in slots and int(pool.abs().sum()) == 0
         assert _rel(gg1, gg0) < 1e-6 and _rel(gb1, gb0) < 1e-6
         assert _rel(dx1.float(), dx0.float()) < (1e-6 if dtype == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_bn_backward_on_channel_slices_equals_the_dense_call(dtype):
+    """liso_bn_relu_bwd_strided: the BatchNorms behind a channel concatenation (3 x 128 channels in front of the detector's head) read
+    their slices of g / x and write their slice of dx in place: same dx / dgamma / dbeta as the call on contiguous copies of the slices,
+    bit for bit (same kernels, other row strides), and nothing outside the slice is touched"""
+    from liso_amd.utils import mfma_conv as MC
+
+    torch.manual_seed(3)
+    B, H, W, Cs = 2, 32, 48, [128, 64, 128]
+    Ct = sum(Cs)
+    x = (torch.randn(B, H, W, Ct, device="cuda") * 0.5 + 0.1).to(dtype).permute(0, 3, 1, 2)      # logical NCHW, channels-last storage
+    g = torch.randn(B, H, W, Ct, device="cuda").to(dtype).permute(0, 3, 1, 2)
+    dx_full = torch.full((B, H, W, Ct), float("nan"), device="cuda").to(dtype).permute(0, 3, 1, 2)
+    a = 0
+    for C in Cs:
+        gamma = torch.nn.Parameter(torch.rand(C, device="cuda") + 0.5)
+        xs = x[:, a:a + C].float()
+        mean, invstd = xs.mean(dim=(0, 2, 3)), (xs.var(dim=(0, 2, 3), unbiased=False) + 1e-3).rsqrt()
+        beta = torch.randn(C, device="cuda") * 0.1
+        grp = {"gamma": gamma, "beta": None, "stats": torch.cat([gamma.detach() * invstd, beta - mean * gamma.detach() * invstd, mean, invstd]).contiguous()}
+        dx_s, gg_s, gb_s = MC._bn_backward_group(g[:, a:a + C], x[:, a:a + C], grp, True, True, out=dx_full[:, a:a + C])
+        dx_d, gg_d, gb_d = MC._bn_backward_group(g[:, a:a + C].contiguous(memory_format=torch.channels_last),
+                                                 x[:, a:a + C].contiguous(memory_format=torch.channels_last), grp, True, True)
+        assert dx_s.data_ptr() == dx_full[:, a:a + C].data_ptr()  # (written in place)
+        assert torch.equal(dx_s, dx_d) and torch.equal(gg_s, gg_d) and torch.equal(gb_s, gb_d)
+        a += C
+    assert not bool(torch.isnan(dx_full).any())  # every slice was written ...
+    # ... and only its own channels: the neighbours of the middle group are intact after it is recomputed
+    before = dx_full.clone()
+    C0, C1 = Cs[0], Cs[1]
+    gamma = torch.nn.Parameter(torch.ones(C1, device="cuda"))
+    grp = {"gamma": gamma, "beta": None, "stats": torch.cat([torch.ones(C1), torch.zeros(C1), torch.zeros(C1), torch.ones(C1)]).cuda()}
+    MC._bn_backward_group(g[:, C0:C0 + C1], x[:, C0:C0 + C1], grp, False, True, out=dx_full[:, C0:C0 + C1])
+    assert torch.equal(dx_full[:, :C0], before[:, :C0]) and torch.equal(dx_full[:, C0 + C1:], before[:, C0 + C1:])

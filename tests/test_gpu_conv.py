@@ -459,3 +459,42 @@ def test_sparse_first_rpn_layer_equals_the_dense_kernels(B, H, W, density, dtype
     assert float((gs - gd)[m].abs().max() if density > 0 else 0.0) <= tol * max(float(gd.abs().max()), 1.0)
     assert float(gs[~m].abs().max() if (~m).any() else 0.0) == 0.0
     assert _rel(ws, wd) <= 1e-2 if dtype == torch.bfloat16 else _rel(ws, wd) <= 1e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_convolutions_writing_channel_ranges_of_one_buffer_and_slice_cat(dtype):
+    """fused_conv(..., out=(buffer, first_channel)): three convolutions (3x3, 1x1, transposed 2x2 -- the deblock geometries of
+    rpn.py:52-63) write one concatenated map without a concatenation pass; `slice_cat` connects it to autograd: same values as
+    torch.cat of the stand-alone outputs, same input / weight gradients"""
+    from liso_amd.utils import mfma_conv as MC
+
+    torch.manual_seed(9)
+    B = 2
+    xs = [torch.randn(B, 64, 32, 32, device="cuda"), torch.randn(B, 128, 32, 32, device="cuda"), torch.randn(B, 64, 16, 16, device="cuda")]
+    xs = [t.to(dtype).contiguous(memory_format=torch.channels_last) for t in xs]
+    convs = [torch.nn.Conv2d(64, 128, 3, padding=1, bias=False).cuda(), torch.nn.Conv2d(128, 64, 1, bias=False).cuda(),
+             torch.nn.ConvTranspose2d(64, 128, 2, stride=2, bias=False).cuda()]
+    chans = [128, 64, 128]
+    w = torch.randn(B, sum(chans), 32, 32, device="cuda")
+    res = []
+    for in_place in (False, True):
+        ins = [t.clone().requires_grad_(True) for t in xs]
+        for c in convs:
+            c.weight.grad = None
+        if in_place:
+            buf = torch.full((B, 32, 32, sum(chans)), float("nan"), dtype=dtype, device="cuda")
+            parts, off = [], 0
+            for t, c, n in zip(ins, convs, chans):
+                parts.append(MC.fused_conv(t, None, c, out=(buf, off))[0])
+                off += n
+            y = MC.slice_cat(buf.permute(0, 3, 1, 2), parts)
+        else:
+            y = torch.cat([MC.fused_conv(t, None, c)[0] for t, c in zip(ins, convs)], dim=1)
+        (y.float() * w).sum().backward()
+        res.append((y.detach().float(), [t.grad.float() for t in ins], [c.weight.grad.clone() for c in convs]))
+    (y0, gx0, gw0), (y1, gx1, gw1) = res
+    assert torch.equal(y0, y1)
+    for a, b in zip(gx0, gx1):
+        assert torch.equal(a, b)
+    for a, b in zip(gw0, gw1):
+        assert torch.equal(a, b)

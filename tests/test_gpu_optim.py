@@ -100,3 +100,25 @@ def test_adamw_rejects_bad_arguments():
     assert lib.liso_adamw_step_f32(L.ptr(x), L.ptr(x), L.ptr(x), L.ptr(x), 64, 1e-3, 0.9, 0.999, 1e-8, 0.01, 0, L.stream_ptr()) == -1
     assert lib.liso_adamw_step_f32(L.ptr(x[1:]), L.ptr(x), L.ptr(x), L.ptr(x), 60, 1e-3, 0.9, 0.999, 1e-8, 0.01, 1, L.stream_ptr()) == -1
     assert lib.liso_adamw_step_f32(L.ptr(x), L.ptr(x), L.ptr(x), L.ptr(x), 0, 1e-3, 0.9, 0.999, 1e-8, 0.01, 1, L.stream_ptr()) == 0
+
+
+def test_batched_gradient_gather_moves_every_tensor():
+    """liso_gather_f32: more tensors than one launch's table (48) of odd sizes -> their destinations inside one flat buffer"""
+    import ctypes
+
+    from liso_amd import _lib as L
+
+    torch.manual_seed(2)
+    sizes = [1, 3, 64, 1152, 36864, 7, 128] * 9  # 63 tensors
+    srcs = [torch.randn(n, device="cuda") for n in sizes]
+    flat = torch.zeros(sum(sizes) + 5, device="cuda")
+    dsts, off = [], 0
+    for n in sizes:
+        dsts.append(flat[off:off + n])
+        off += n
+    n = len(sizes)
+    src = (ctypes.c_void_p * n)(*[t.data_ptr() for t in srcs])
+    dst = (ctypes.c_void_p * n)(*[t.data_ptr() for t in dsts])
+    cnt = (ctypes.c_size_t * n)(*sizes)
+    L.check(L.lib().liso_gather_f32(n, src, dst, cnt, L.stream_ptr()), "gather")
+    assert torch.equal(flat[:off], torch.cat(srcs)) and float(flat[off:].abs().max()) == 0.0
