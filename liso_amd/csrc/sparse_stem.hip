@@ -266,7 +266,8 @@ __global__ __launch_bounds__(256) void stem_gather_kernel(const unsigned* __rest
     }
     // a block walks `groups` passes of PPB consecutive pixels (the pixels of a sample are a multiple of PPB * groups): one statistics
     // row per block.  (Also measured: one 64-bit window mask per output pixel, set by OR atomics in cells_fill_kernel, instead of the
-    // row bitmaps -- the gather went 74 -> 64 us on 8 sweeps, the fill 5 -> 25 us: no gain.)  (Fetching the window bits of all passes and kernel rows up front -- independent loads -- was measured: 43.6
+    // row bitmaps -- the gather went 74 -> 64 us on 8 sweeps, the fill 5 -> 25 us: no gain; two contributions in flight per row: 68 us;
+    // the pass's output staged through LDS and stored 16 B per lane back to back: 89 us.)  (Fetching the window bits of all passes and kernel rows up front -- independent loads -- was measured: 43.6
     // instead of 35.5 us, the registers cost more occupancy than the shorter chain gains.)
     for (int g = 0; g < groups; g++) {
         const unsigned pixu = (blockIdx.x * (unsigned)groups + (unsigned)g) * PPB + pl;  // (sample, oy, ox) flattened (< 2^30: layout())
