@@ -178,6 +178,14 @@ int liso_gru_out_fwd_f32(long n, const float* cq, const float* z, const float* h
 int liso_gru_out_bwd_f32(long n, const float* cq, const float* z, const float* h, const float* g_out, float* g_cq, float* g_z,
                          float* g_h, void* stream);
 
+/* The same gate arithmetic at inference on PIXEL ROWS that are channel slices of wider channels-last buffers (strides in floats
+ * between consecutive pixels): z[n_pix, ch] = sigmoid(zr[:, :ch]), rh = sigmoid(zr[:, ch:2ch]) * h;  h <- (1 - z) h + z tanh(cq) in
+ * place.  With them the update block keeps [h | inp | out | class | flow | r*h] in ONE buffer (the convolutions write their channel
+ * ranges, liso_conv.h): none of the four concatenations of liso/slim/model/update.py:29-37,84-96,139-141 per iteration. */
+int liso_gru_in_rows_f32(long n_pix, int ch, const float* zr, long zr_stride, const float* h, long h_stride, float* z, float* rh,
+                         long rh_stride, void* stream);
+int liso_gru_out_rows_f32(long n_pix, int ch, const float* cq, long cq_stride, const float* z, float* h, long h_stride, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

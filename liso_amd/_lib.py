@@ -125,6 +125,8 @@ SIGNATURES = {
     "liso_gru_in_bwd_f32": (_i, [_vp, _vp, ctypes.c_long, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_long, _vp, _vp]),
     "liso_gru_out_fwd_f32": (_i, [ctypes.c_long, _vp, _vp, _vp, _vp, _vp]),
     "liso_gru_out_bwd_f32": (_i, [ctypes.c_long, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "liso_gru_in_rows_f32": (_i, [ctypes.c_long, _i, _vp, ctypes.c_long, _vp, ctypes.c_long, _vp, _vp, ctypes.c_long, _vp]),
+    "liso_gru_out_rows_f32": (_i, [ctypes.c_long, _i, _vp, ctypes.c_long, _vp, _vp, ctypes.c_long, _vp]),
     "liso_raft_upsample_scratch_bytes": (_sz, [_vp]),
     "liso_raft_upsample_outputs_fwd_f32": (_i, [_vp] * 5),
     "liso_raft_upsample_outputs_bwd_f32": (_i, [_vp, _vp, _vp, _sz, _vp, _vp, _vp]),

@@ -65,6 +65,28 @@ __global__ void gru_out_bwd_kernel(long n, const float* __restrict__ cq, const f
     g_h[i] = g * (1.f - zv);
 }
 
+// ---- inference on pixel rows that are channel slices of wider channels-last buffers --------------------------------------------------
+// (the update block's inputs [h | inp | out | class | flow | r*h] live in ONE buffer at inference: no concatenation passes)
+__global__ void gru_in_rows_kernel(long n_pix, int ch, const float* __restrict__ zr, long zr_stride, const float* __restrict__ h,
+                                   long h_stride, float* __restrict__ z, float* __restrict__ rh, long rh_stride) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pix * ch) return;
+    const long p = i / ch;
+    const int c = (int)(i - p * ch);
+    z[i] = sigmoidf(zr[p * zr_stride + c]);
+    rh[p * rh_stride + c] = sigmoidf(zr[p * zr_stride + ch + c]) * h[p * h_stride + c];
+}
+
+__global__ void gru_out_rows_kernel(long n_pix, int ch, const float* __restrict__ cq, long cq_stride, const float* __restrict__ z,
+                                    float* __restrict__ h, long h_stride) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pix * ch) return;
+    const long p = i / ch;
+    const int c = (int)(i - p * ch);
+    const float zv = z[i], hv = h[p * h_stride + c];
+    h[p * h_stride + c] = (1.f - zv) * hv + zv * tanhf(cq[p * cq_stride + c]);
+}
+
 inline bool bad(const liso_gru_cfg* c) { return c == nullptr || c->batch <= 0 || c->ch <= 0 || c->cx < 0 || c->hw <= 0; }
 inline int done() { return hipGetLastError() == hipSuccess ? LISO_OK : LISO_ELAUNCH; }
 
@@ -102,5 +124,26 @@ extern "C" int liso_gru_out_bwd_f32(long n, const float* cq, const float* z, con
     if (n == 0) return LISO_OK;
     hipLaunchKernelGGL(gru_out_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, cq, z, h, g_out,
                        g_cq, g_z, g_h);
+    return done();
+}
+
+extern "C" int liso_gru_in_rows_f32(long n_pix, int ch, const float* zr, long zr_stride, const float* h, long h_stride, float* z, float* rh,
+                                    long rh_stride, void* stream) {
+    if (n_pix < 0 || ch <= 0 || zr_stride < 2 * ch || h_stride < ch || rh_stride < ch || (n_pix > 0 && (!zr || !h || !z || !rh)))
+        return LISO_EINVAL;
+    if (n_pix == 0) return LISO_OK;
+    const long n = n_pix * ch;
+    hipLaunchKernelGGL(gru_in_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n_pix, ch, zr, zr_stride,
+                       h, h_stride, z, rh, rh_stride);
+    return done();
+}
+
+extern "C" int liso_gru_out_rows_f32(long n_pix, int ch, const float* cq, long cq_stride, const float* z, float* h, long h_stride,
+                                     void* stream) {
+    if (n_pix < 0 || ch <= 0 || cq_stride < ch || h_stride < ch || (n_pix > 0 && (!cq || !z || !h))) return LISO_EINVAL;
+    if (n_pix == 0) return LISO_OK;
+    const long n = n_pix * ch;
+    hipLaunchKernelGGL(gru_out_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n_pix, ch, cq, cq_stride,
+                       z, h, h_stride);
     return done();
 }

@@ -170,6 +170,7 @@ class RAFT(nn.Module):
         lowres_flows, lowres_logits = [], []
         # weight gradients of the update block: one convolution per layer over all iterations (deferred_wgrad.py)
         mode = getattr(self, "defer_update_block_wgrad", True)  # True | False | "direct" (hipGraph capture, see trainer.py)
+        infer = self.update_block.inference_state(net, inp) if (only_last and not use_w) else None  # (inference: no concatenations)
         with deferred_weight_gradients(self.update_block, enabled=self.training and bool(mode), direct_accumulate=mode == "direct"):
             for it in range(m.num_iters):
                 coords1 = coords1.detach()
@@ -179,7 +180,10 @@ class RAFT(nn.Module):
                     wl = wl.detach()
                 corr = correlation(coords1)
                 flow = coords1 - coords0
-                net, d_flow, d_logits, d_w = self.update_block(net, inp, corr, flow, logits, wl)
+                if infer is not None:
+                    net, d_flow, d_logits, d_w = self.update_block.forward_inference(infer, corr, flow, logits)
+                else:
+                    net, d_flow, d_logits, d_w = self.update_block(net, inp, corr, flow, logits, wl)
                 coords1 = coords1 + d_flow
                 if not vanilla:
                     logits = logits + d_logits

@@ -1,5 +1,7 @@
 """RAFT update operator of SLIM.  Mirror of liso/slim/model/update.py:6-164 (same classes, constructor arguments and
 attribute names -> same state_dict keys)."""
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -90,6 +92,80 @@ class SmallUpdateBlock(nn.Module):
         # 128-channel slice of that map
         self.merged_convs = [(self.static_flow_head.conv1, self.classification_head.conv1)] if self.predict_logits else []
         self.merge_head_convs = True
+
+    # ---- inference without concatenations ------------------------------------------------------------------------------------------
+    def inference_state(self, net, inp):
+        """Buffers of `forward_inference` for one RAFT loop (no autograd): ONE channels-last buffer holds
+        [h 96 | inp 64 | out 80 | class 32 | flow 32 | r*h 96] -- channels [0, 304) are the ConvGRU's `hx`, [96, 400) its `[x, r*h]`
+        (convq runs on filters whose input channels are permuted accordingly) -- and a second one the motion encoder's
+        [corr 96 | class 32 | flow 32].  The convolutions write their channel ranges (mfma_conv.conv2d(out=...)): none of the four
+        concatenations of reference :29-37,84-96,139-141 per iteration, and the gates update h in place.  None when not applicable."""
+        from liso_amd.utils import mfma_conv as MC
+
+        if (torch.is_grad_enabled() or not net.is_cuda or MC.backend() != "mfma" or net.dtype != torch.float32 or not self.predict_logits
+                or self.cfg.model.predict_weight_for_static_aggregation or os.environ.get("LISO_UPDATE_SLICES", "1") == "0"):
+            return None
+        me, gru = self.motion_encoder, self.gru
+        ch, ci = net.shape[1], inp.shape[1]
+        co, cc, cf = me.conv.out_channels, me.conv_class2.out_channels, me.conv_flow2.out_channels
+        cq = me.conv_stat_corr1.out_channels
+        if gru.convz.in_channels != ch + ci + co + cc + cf or me.conv.in_channels != cq + cf + cc or any(c % 8 for c in (ch, ci, co, cc, cf, cq)):
+            return None
+        B, _, H, W = net.shape
+        big = torch.empty((B, H, W, 2 * ch + ci + co + cc + cf), dtype=torch.float32, device=net.device)
+        m = torch.empty((B, H, W, cq + cc + cf), dtype=torch.float32, device=net.device)
+        big[..., :ch].copy_(net.permute(0, 2, 3, 1))
+        big[..., ch:ch + ci].copy_(inp.permute(0, 2, 3, 1))
+        x0, x1 = ch, ch + ci + co + cc + cf  # channels of x = (inp, out, class, flow)
+        key = (me.conv.weight._version, me.conv.weight.data_ptr(), gru.convq.weight._version, gru.convq.weight.data_ptr())
+        hit = getattr(self, "_infer_perm", None)
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                wc, wq = me.conv.weight, gru.convq.weight
+                # `conv` reads (corr, class, flow) instead of the reference's (corr, flow, class); `convq` reads (x, r*h) instead of (r*h, x)
+                w_conv = torch.nn.Parameter(torch.cat([wc[:, :cq], wc[:, cq + cf:cq + cf + cc], wc[:, cq:cq + cf]], dim=1).contiguous(),
+                                            requires_grad=False)
+                w_q = torch.nn.Parameter(torch.cat([wq[:, ch:], wq[:, :ch]], dim=1).contiguous(), requires_grad=False)
+            hit = self._infer_perm = (key, w_conv, w_q)
+        return {"big": big, "m": m, "ch": ch, "ci": ci, "co": co, "cc": cc, "cf": cf, "cq": cq, "x0": x0, "x1": x1,
+                "w_conv": hit[1], "w_q": hit[2], "z": torch.empty((B, H, W, ch), dtype=torch.float32, device=net.device)}
+
+    def forward_inference(self, st, corr, flow, logits):
+        """one update iteration on the buffers of `inference_state` -> (net view, delta_static_flow, delta_logits, None)"""
+        import ctypes
+        import types
+
+        from liso_amd import _lib as L
+        from liso_amd.utils import mfma_conv as MC
+
+        me, gru = self.motion_encoder, self.gru
+        big, m = st["big"], st["m"]
+        ch, ci, co, cc, cf, cq = st["ch"], st["ci"], st["co"], st["cc"], st["cf"], st["cq"]
+        o_out, o_cls, o_flow, o_rh = ch + ci, ch + ci + co, ch + ci + co + cc, st["x1"]
+        bign, mn = big.permute(0, 3, 1, 2), m.permute(0, 3, 1, 2)
+        MC.conv2d(me.conv_stat_corr1, corr, relu=True, out=(m, 0))
+        MC.conv2d(me.conv_flow2, MC.conv2d(me.conv_flow1, flow, relu=True), relu=True, out=(big, o_flow))
+        MC.conv2d(me.conv_class2, MC.conv2d(me.conv_class1, logits, relu=True), relu=True, out=(big, o_cls))
+        m[..., cq:].copy_(big[..., o_cls:o_rh])  # (class, flow): the one copy left, 64 of the 656 channels the concatenations moved
+        MC.fused_conv(mn, None, types.SimpleNamespace(weight=st["w_conv"], bias=me.conv.bias), out_relu=True, spec=MC.ConvSpec.of(me.conv),
+                      out=(big, o_out))
+        zr, _ = MC.fused_conv(bign[:, :o_rh], None, [gru.convz, gru.convr])
+        zrv, zps = MC.as_nhwc(zr, 4)
+        n_pix, wt = big.shape[0] * big.shape[1] * big.shape[2], big.shape[3]
+        z = st["z"]
+        lib = L.lib()
+        with torch.cuda.device(big.device):
+            L.check(lib.liso_gru_in_rows_f32(n_pix, ch, L.ptr(zrv), zps, L.ptr(big), wt, L.ptr(z), ctypes.c_void_p(big.data_ptr() + 4 * o_rh),
+                                             wt, L.stream_ptr()), "gru_in_rows")
+        cqv, _ = MC.fused_conv(bign[:, ch:], None, types.SimpleNamespace(weight=st["w_q"], bias=gru.convq.bias), spec=MC.ConvSpec.of(gru.convq))
+        cqn, cps = MC.as_nhwc(cqv, 4)
+        with torch.cuda.device(big.device):
+            L.check(lib.liso_gru_out_rows_f32(n_pix, ch, L.ptr(cqn), cps, L.ptr(z), L.ptr(big), wt, L.stream_ptr()), "gru_out_rows")
+        net = bign[:, :ch]
+        fh, hd = self.static_flow_head, self.classification_head
+        hid = conv2d_pair(fh.conv1, hd.conv1, net, relu=True)
+        hid_f, hid_c = torch.split(hid, [fh.conv1.out_channels, hd.conv1.out_channels], dim=1)
+        return net, conv2d(fh.conv2, hid_f), conv2d(hd.conv2, hid_c), None
 
     def forward(self, net, inp, corr, flow, logits, weight_logits_for_static_aggregation):
         """reference :130-164"""

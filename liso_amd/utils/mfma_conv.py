@@ -1189,13 +1189,14 @@ class GradCut:
             up.backward(leaf.grad)
 
 
-def conv2d(layer, x, relu=False, occupancy=None):
+def conv2d(layer, x, relu=False, occupancy=None, out=None):
     """relu?(layer(x)) for an nn.Conv2d / nn.ConvTranspose2d on the own kernels (torch's convolution when the geometry or the
     device is not covered: CPU tensors in host-logic tests, 2-3 input channels).  `occupancy`: fp32 [B,1,H,W] / [B,H,W] map with 0
     where x is zero in every channel (the pillar canvas): empty tiles are skipped forward, the weight gradient walks occupied cells"""
     spec = ConvSpec.of(layer)
     if x.is_cuda and backend() == "mfma" and supported(x, layer.weight, spec):
-        return fused_conv(x, None, layer, out_relu=relu, spec=spec, occupancy=occupancy if x.dtype == torch.float32 else None)[0]
+        return fused_conv(x, None, layer, out_relu=relu, spec=spec, occupancy=occupancy if x.dtype == torch.float32 else None, out=out)[0]
+    assert out is None, "conv2d(out=...): only on the own kernels"
     if x.is_cuda and backend() == "mfma" and x.dtype in (torch.bfloat16, torch.float32) and not spec.transposed:
         # 1-3 (7) input channels -- the motion encoder's conv_flow1: 7x7 on the 2-channel flow, liso/slim/model/update.py:53-60 --
         # the kernels read channels in 16-B groups: zero channels (and zero filter slices) up to one group, then the own kernel
