@@ -402,8 +402,11 @@ def conv_dgrad(dy, weight, spec, x_shape, out_dtype=None, packed=None):
     build = gather_desc if spec.transposed else scatter_desc
     d = build(spec, B, ho, wo, co, gps, hi, wi, ci, ci, 0, mode, out_f32, False, False)
     alloc = torch.zeros if getattr(d, "sparse_output", False) else torch.empty
-    if not spec.transposed and ((hi + 2 * spec.padding - spec.kh) % spec.stride or (wi + 2 * spec.padding - spec.kw) % spec.stride):
-        alloc = torch.zeros  # trailing input rows / columns no output window covers: gradient 0
+    if not spec.transposed and ((ho - 1) * spec.stride - spec.padding + spec.kh < hi or (wo - 1) * spec.stride - spec.padding + spec.kw < wi):
+        # trailing input rows / columns that no output window reaches: gradient 0.  (The last window ends at input row
+        # (ho - 1) s - p + kh - 1; a non-zero remainder of (hi + 2p - kh) / s alone does not mean uncovered rows -- 3x3 / 2 / 1 on an
+        # even map reaches every row -- and the fill it used to trigger was a pass over the whole gradient.)
+        alloc = torch.zeros
     dx = alloc((B, hi, wi, ci), dtype=out_dtype, device=dy.device)
     if packed is None:
         packed = pack_weights(weight, spec, True, mode)
