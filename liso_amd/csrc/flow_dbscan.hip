@@ -233,13 +233,16 @@ __global__ void dbscan_label_kernel(Cfg c, const uint8_t* __restrict__ dyn, cons
 // cell, which serialised on the few dozen label rows (243 us at 512 x 512).  Integer sums: any order gives the same bits.
 __global__ __launch_bounds__(256) void region_moments_kernel(const int* __restrict__ labels, int batch, int gx, int gy, int max_labels,
                                                              unsigned long long* __restrict__ mom) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t per = (size_t)gx * gy;
+    // (32-bit index arithmetic: batch * gx * gy < 2^31 is checked by the caller; three 64-bit divisions per cell were most of this
+    // kernel's instructions)
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned per = (unsigned)gx * (unsigned)gy;
     const int lane = threadIdx.x & 63;
-    int l = i < per * batch ? labels[i] : 0;
+    int l = i < per * (unsigned)batch ? labels[i] : 0;
     if (l > max_labels) l = 0;
-    const long key = l > 0 ? (long)(i / per) * max_labels + (l - 1) : -1;
-    const unsigned long long r = (i % per) / gy, col = i % gy;
+    const unsigned bi = i / per, rem = i - bi * per, ri = rem / (unsigned)gy;
+    const long key = l > 0 ? (long)bi * max_labels + (l - 1) : -1;
+    const unsigned long long r = ri, col = rem - ri * (unsigned)gy;
     unsigned long long todo = __ballot(key >= 0);
     while (todo) {
         const int src = __ffsll((long long)todo) - 1;
@@ -330,6 +333,7 @@ int liso_dbscan_labels(const liso_dbscan_cfg* cfg, const uint8_t* dynamic_mask, 
 int liso_region_props(const int32_t* labels, int batch, int gx, int gy, int max_labels, uint64_t* moments, double* props,
                       void* stream) {
     if (!labels || batch < 1 || gx < 1 || gy < 1 || max_labels < 1 || !moments || !props) return LISO_EINVAL;
+    if ((size_t)batch * gx * gy >= (1ull << 31)) return LISO_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const size_t total = (size_t)batch * gx * gy;
     const long regions = (long)batch * max_labels;
