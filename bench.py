@@ -172,6 +172,10 @@ KERNELS = {  # timer name -> (kernel description, bound, unit of `units`)
     "region_props": ("region_moments_kernel + region_props_kernel", "hbm", "bytes"),
     "kabsch_trafos": ("kabsch_moments_kernel + kabsch_solve_kernel (soft masks + weighted Kabsch)", "hbm", "bytes"),
     "fit_box_z": ("fit_z_kernel (points-in-box z extent)", "hbm", "bytes"),
+    "conv_sparse_stem": ("cells_* + stem_taps_kernel + stem_gather_kernel (stride-2 convolution on the pillar canvas, occupied cells only; "
+                         "bytes = the dense output written once + the occupancy map)", "hbm", "bytes"),
+    "conv_sparse_dgrad": ("stem_dgrad_kernel (data gradient of that convolution at the occupied cells; bytes = the zero-filled canvas gradient)",
+                          "hbm", "bytes"),
     "bn_fwd": ("bn_stats/finalize/apply kernels (BatchNorm2d+ReLU forward)", "hbm", "bytes"),
     "bn_bwd": ("bn_bwd_reduce/finalize/dx kernels (BatchNorm2d+ReLU backward)", "hbm", "bytes"),
 }

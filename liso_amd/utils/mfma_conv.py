@@ -1034,7 +1034,7 @@ def _sparse_stem(x_raw, occupancy, weight, bias, spec, kind, relu, stats_shift=N
             L.ptr(xv), xps, int(bf), L.ptr(occ), L.ptr(packed), L.ptr(bias) if bias is not None else None, B, H, W, k, co, cap,
             int(bool(relu) and kind == "none"), L.ptr(y), L.ptr(part) if part is not None else None,
             L.ptr(stats_shift) if (stats_shift is not None and part is not None) else None, L.ptr(flag), L.ptr(ws), nbytes, L.stream_ptr()),
-            units=2.0 * B * ho * wo * co * 64 * k * k), "sparse_conv_forward")
+            units=B * ho * wo * co * y.element_size() + B * H * W * 4), "sparse_conv_forward")  # (bytes: the dense output written once + the occupancy map)
     return y.permute(0, 3, 1, 2), part, ws
 
 
@@ -1069,7 +1069,7 @@ def _sparse_dgrad(dy, occupancy, weight, spec, x_shape, x_dtype, lists=None):
     with torch.cuda.device(dev):
         L.check(L.TIMER.launch("conv_sparse_dgrad", lambda: lib.liso_sparse_conv_dgrad(
             L.ptr(gv), gps, int(bf), L.ptr(occ), L.ptr(packed), B, H, W, k, co, cap, L.ptr(dx), C, L.ptr(flag), L.ptr(ws), ws.numel(),
-            int(reuse), L.stream_ptr()), units=2.0 * B * (H // 2) * (W // 2) * co * 64 * k * k), "sparse_conv_dgrad")
+            int(reuse), L.stream_ptr()), units=B * H * W * C * dx.element_size()), "sparse_conv_dgrad")  # (bytes: the zero-filled canvas gradient)
     return dx.permute(0, 3, 1, 2)
 
 
