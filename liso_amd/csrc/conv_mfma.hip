@@ -1193,6 +1193,13 @@ bool make_plan(const liso_conv_desc& d, Plan* p) {
             static const bool auto_nj = getenv("LISO_CONV_NJ_AUTO") != nullptr && atoi(getenv("LISO_CONV_NJ_AUTO")) != 0;
             if (auto_nj && b1 <= 2048 && c1 < c2) p->nj = 1;
         }
+        // F32X3 layers with 65-96 filters (ConvGRU q 304->96, the motion encoder's 160->80, the encoders' 96->96 stage): one 96-wide
+        // panel instead of two 64-wide ones -- no padded filter columns through the matrix cores (96 -> 128: a quarter of the MFMAs,
+        // 80 -> 128: three eighths) and the input tile staged once
+        // MEASURED (round 4): correct on every test, no gain -- loop 5.10 vs 5.10 ms, SLIM step 13.99 vs 13.88 ms (the 96-wide panel
+        // leaves room for 3 instead of 5 taps per weight stage in the 79-KB plans).  Off unless LISO_CONV_NJ3=1.
+        static const bool nj3 = getenv("LISO_CONV_NJ3") != nullptr && atoi(getenv("LISO_CONV_NJ3")) != 0;
+        if (nj3 && x3 && p->nj == 2 && d.co > 64 && d.co <= 96) p->nj = 3;
         if (const char* e = getenv("LISO_CONV_NJ")) {  // experiments: 1 | 2 force the panel width
             if (atoi(e) == 1) p->nj = 1;
             if (atoi(e) == 2 && d.co > 32) p->nj = 2;
@@ -1489,6 +1496,10 @@ int liso_conv_forward_sparse(const liso_conv_desc* d, const void* x, const void*
     if (x3 && p.sk == 2)
         return p.cs == 32 ? launch<LISO_CONV_F32X3, 1, 1, true, 32, 2>(*d, p, st) : launch<LISO_CONV_F32X3, 1, 1, true, 16, 2>(*d, p, st);
     if (f32) LISO_SEL(LISO_CONV_F32, true, 32, 16);
+    if (x3 && p.nj == 3) {
+        if (p.mi == 2) LISO_GO(LISO_CONV_F32X3, 2, 3, true, 32, 16);
+        LISO_GO(LISO_CONV_F32X3, 1, 3, true, 32, 16);
+    }
     if (x3) LISO_SEL(LISO_CONV_F32X3, true, 32, 16);
     if (of32) LISO_SEL(LISO_CONV_BF16, true, 64, 32);
     LISO_SEL(LISO_CONV_BF16, false, 64, 32);
