@@ -573,8 +573,9 @@ def main():
             el = time.perf_counter() - t0
             legs[name] = {"dtype": label, "steps": nl, "warmup": wl, "ms_per_step": 1e3 * el / nl, "value": 2 * batch * nl / el,
                           "unit": "frames/s", "final_loss": float(ll),
-                          "meets_north_star_1e-3": True,
-                          "certified_by": ["tests/test_gpu_parity_full_size.py::test_detector_logits_and_loss_at_full_size_match_fp64_oracle"
+                          # (nothing in this leg measures parity: these are the tests that compare this arithmetic with the CPU
+                          # oracle at this size, bar 1e-3)
+                          "parity_tests": ["tests/test_gpu_parity_full_size.py::test_detector_logits_and_loss_at_full_size_match_fp64_oracle"
                                            f"[{'exact' if exact else 'x3'}]",
                                            "tests/test_gpu_parity_full_size.py::test_slim_last_iteration_flow_at_full_size_matches_cpu_oracle"
                                            f"[{'exact' if exact else 'x3'}]"],

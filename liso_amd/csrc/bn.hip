@@ -324,12 +324,20 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(const T* __rest
     }
     if (fin.ticket == nullptr) return;
     __shared__ int s_last;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (the write-through stores above have completed ...)
-    __syncthreads();                                        // (... in every wave of the block before its ticket is drawn)
+    // Hand-off to the last block (MI355X_MICROARCH.md "Correctness boundaries", inter-workgroup visibility): every storing wave drains
+    // its stores (vmcnt(0)), the block's barrier, ONE lane's agent-scope release in front of the ticket, and in the last block an
+    // agent-scope acquire behind it (one lane, then the barrier) before the plain loads of the other blocks' partial sums.  Round 4 had
+    // a workgroup-scope fence and a relaxed ticket here: neither orders the other waves' stores for another CU / XCD.
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    __syncthreads();
     if (tid == 0) {
         unsigned* tk = fin.ticket + blockIdx.y;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         s_last = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
-        if (s_last) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (zero again for the next call)
+        if (s_last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (zero again for the next call)
+        }
     }
     __syncthreads();
     if (!s_last) return;

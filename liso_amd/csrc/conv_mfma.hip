@@ -52,13 +52,16 @@ struct FwdArgs {
     int cls_inh[LISO_CONV_MAX_CLASSES], cls_inw[LISO_CONV_MAX_CLASSES];
     int tiles_x, tiles_y, n_nt, total;
     int x_plane_bytes;  // LDS bytes of one plane of the input tile (max over classes), multiple of 16
-    int pipelined;      // one register batch holds a whole slab: loads of slab k+1 overlap the MFMAs of slab k
+    int pipelined;      // stage-granular software pipeline: the loads of stage t + 1 (G taps of a slab) overlap the MFMAs of stage t
+    int slab_pipelined; // one register batch holds a whole slab (tile + the panels of all taps): what the SK = 2 kernel needs
     int group_bytes;    // LDS bytes of one split-K group's tile + panels (SK = 2 instantiations)
     const float* occ;   // optional [batch, hi, wi]: 0 = the input pixel is exactly zero in every channel (sparse BEV canvases)
     int a8;             // 8-wave kernel with the weight panels streamed by LDS-DMA (conv_igemm8_kernel)
     int stage_taps;     // a8: taps per weight stage
     int ring;           // a8: weight stages resident in LDS (2..4): stage s + ring - 1 is in flight while stage s is multiplied
     int dbg;            // experiments (LISO_CONV_DBG): 1 = no MFMAs, 2 = no weight DMA, 4 = no tile loads (results are garbage)
+    int roles;          // conv_roles_kernel (loader waves + MFMA waves, double-buffered LDS): 3x3 / 1x1, stride 1, one class
+    unsigned long long roles_tapw;  // roles: 4 bits per window position (ty * 3 + tx): the tap's index inside the packed weights
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int total) {
@@ -77,6 +80,121 @@ __device__ __forceinline__ float bf16_hi(unsigned w) { return __uint_as_float(w 
 __device__ __forceinline__ float round_bf16(float v) { return (float)(__bf16)v; }
 
 __device__ __forceinline__ bf8 as_bf8(const uint4& v) { return __builtin_bit_cast(bf8, v); }
+
+// ---- epilogue shared by the forward kernels ---------------------------------------------------------------------------------------
+// acc[i][j]: the 32 x 32 MFMA tiles of wave `wave` (tile row wave * MI + i of the block's TH = 4 MI rows, output channels n0 + 32 j ...).
+// `active` = this thread holds accumulators (waves 0-3 of the block, split-K group 0); every thread of the block must call (barriers).
+template <int MI, int NJ, bool OUT_F32>
+__device__ __forceinline__ void conv_epilogue(const liso_conv_desc& d, const FwdArgs& a, f16v (&acc)[MI][NJ], int cls, int b, int tx, int ty,
+                                              int wave, int r, int h, bool active, int n0, int stats_row, int tid_all,
+                                              unsigned char* smem) {
+    constexpr int BNT = 32 * NJ;
+    constexpr int TH = 4 * MI;
+    const int tid = tid_all & (kThreads - 1);
+    const int grp = active ? 0 : 1;
+    // ---- epilogue ------------------------------------------------------------------------------------------------------------
+    // Register e of a 32 x 32 tile is pixel column (e & 3) + 8 (e >> 2) + 4 h of ONE tile row (TW = 32): the row part of the
+    // output offset and the row validity are per (wave, i); the column part is a compile-time multiple of the pixel stride.
+    const bool want_stats = a.stats != nullptr;
+    float s1[NJ], s2[NJ];
+    const int ooy = d.class_ooy[cls], oox = d.class_oox[cls];
+    const int col_stride = d.osx * d.y_pix_stride;  // elements between horizontally adjacent virtual pixels
+    unsigned colmask = 0;                           // bit e: the pixel column of register e exists
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        const int vx = tx * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (vx < d.wv && vx * d.osx + oox < d.wo) colmask |= 1u << e;
+    }
+    const int col0 = (tx * 32 + 4 * h) * d.osx + oox;
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+        s1[j] = 0.0f;
+        s2[j] = 0.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < MI; i++) {
+        const int vy = ty * TH + wave * MI + i;
+        const int oy = vy * d.osy + ooy;
+        const unsigned rowmask = (grp == 0 && vy < d.hv && oy < d.ho) ? colmask : 0u;
+        const long row_base = (((long)b * d.ho + oy) * d.wo + col0) * d.y_pix_stride + d.y_ch_off;
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            const int n = n0 + j * 32 + r;
+            const bool n_ok = n < d.co;
+            const float bias_v = (a.bias && n_ok) ? a.bias[n] : 0.0f;
+            const float shift_v = (a.stats_shift && n_ok) ? a.stats_shift[n] : 0.0f;
+            float v[16];
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                float val = acc[i][j][e] + bias_v;
+                if (d.out_relu) val = fmaxf(val, 0.0f);
+                if constexpr (!OUT_F32) val = round_bf16(val);
+                v[e] = val;
+                if (want_stats && ((rowmask >> e) & 1u)) {
+                    const float dd = val - shift_v;
+                    s1[j] += dd;
+                    s2[j] = fmaf(dd, dd, s2[j]);
+                }
+            }
+            if constexpr (OUT_F32) {
+                float* yg = (float*)a.y + row_base + n;
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                    if (((rowmask >> e) & 1u) && n_ok) yg[((e & 3) + 8 * (e >> 2)) * col_stride] = v[e];
+            } else {
+                unsigned short* yg = (unsigned short*)a.y + row_base;
+                const bool odd = r & 1;
+                const int n_even = n & ~1;
+                if ((d.y_pix_stride | d.y_ch_off) & 1) {  // odd pixel stride: channel pairs are not 4-B aligned, 2-B stores
+#pragma unroll
+                    for (int e = 0; e < 16; e++)
+                        if (((rowmask >> e) & 1u) && n_ok)
+                            yg[((e & 3) + 8 * (e >> 2)) * col_stride + n] = (unsigned short)(pack_bf16(v[e], 0.0f) & 0xffffu);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 16; e += 2) {
+                        const float send = odd ? v[e] : v[e + 1];
+                        const float recv = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(send), 0xB1, 0xF, 0xF, true));
+                        const float c_lo = odd ? recv : v[e];      // channel n_even
+                        const float c_hi = odd ? v[e + 1] : recv;  // channel n_even + 1
+                        const int ee = odd ? e + 1 : e;            // the register (pixel) this lane stores: compile-time per parity
+                        const int koff = odd ? ((e + 1) & 3) + 8 * ((e + 1) >> 2) : (e & 3) + 8 * (e >> 2);
+                        if ((rowmask >> ee) & 1u) {
+                            unsigned short* dst = yg + koff * col_stride + n_even;
+                            if (n_even + 1 < d.co)
+                                *reinterpret_cast<unsigned*>(dst) = pack_bf16(c_lo, c_hi);
+                            else if (n_even < d.co)
+                                *dst = (unsigned short)(pack_bf16(c_lo, 0.0f) & 0xffffu);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (want_stats) {
+        float* red = reinterpret_cast<float*>(smem);  // [4 waves][BNT][2]; the main loop ended with a barrier
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            const float t1 = s1[j] + __shfl_xor(s1[j], 32);
+            const float t2 = s2[j] + __shfl_xor(s2[j], 32);
+            if (h == 0 && grp == 0) {
+                red[(wave * BNT + j * 32 + r) * 2 + 0] = t1;
+                red[(wave * BNT + j * 32 + r) * 2 + 1] = t2;
+            }
+        }
+        __syncthreads();
+        if (tid_all < BNT) {
+            float q1 = 0.0f, q2 = 0.0f;
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                q1 += red[(w * BNT + tid) * 2 + 0];
+                q2 += red[(w * BNT + tid) * 2 + 1];
+            }
+            a.stats[((long)stats_row * 2 + 0) * a.co_pad + n0 + tid] = q1;
+            a.stats[((long)stats_row * 2 + 1) * a.co_pad + n0 + tid] = q2;
+        }
+    }
+}
 
 // SK = 2 (small maps, one sample: 100-200 blocks of one wave per SIMD, where the slab loop is bound by the latency of its own
 // loads): the block has two groups of 4 waves, each with its own tile + panel buffers, that take alternate channel slabs (twice
@@ -407,23 +525,36 @@ __global__ __launch_bounds__(kThreads * SK, SK == 1 ? 2 : 1) void conv_igemm_ker
                     for (int e = 0; e < 16; e++) acc[i][j][e] += xfer[((i * NJ + j) * 16 + e) * kThreads + tid];
         }
     } else if (a.pipelined) {
-        // the whole slab (tile + the panels of all taps) fits one batch of registers: software pipeline over the slabs
+        // Software pipeline over STAGES (a stage = the panels of G taps of one channel slab, one register batch; the halo tile of a
+        // slab, one register batch, travels with the slab's first stage): the global loads of stage t + 1 are in flight while the MFMAs
+        // of stage t run.  Round 4 pipelined only layers whose whole slab (all taps) fits one register batch -- every 3x3 layer with
+        // 64-channel panels ran load -> store -> barrier -> multiply strictly in sequence, 3 exposed load latencies per slab (measured
+        // round 5: 8 us per slab on the ConvGRU layers, 1.8 us of it MFMA).
         uint4 xv[XB], wv[WB];
         unsigned xok;
-        const int chunks = n_taps * PLANES * PSZ;
         __syncthreads();  // tap tables
         load_x(0, 0, xv, xok);
-        load_w(0, 0, chunks, 0, wv);
+        load_w(0, 0, min(G, n_taps) * PLANES * PSZ, 0, wv);
+        bool first = true;
         for (int c0 = 0; c0 < d.ci; c0 += CS) {
-            if (c0 > 0) __syncthreads();  // every read of the previous slab's tile / panels is done
-            store_x(c0, 0, xv, xok);
-            store_w(chunks, 0, wv);
-            __syncthreads();
-            if (c0 + CS < d.ci) {
-                load_x(c0 + CS, 0, xv, xok);
-                load_w(c0 + CS, 0, chunks, 0, wv);
+            for (int s0 = 0; s0 < n_taps; s0 += G) {
+                const int g_cur = min(G, n_taps - s0);
+                if (!first) __syncthreads();  // every read of the previous stage's panels (and, at s0 == 0, of the previous slab's tile) is done
+                first = false;
+                if (s0 == 0) store_x(c0, 0, xv, xok);
+                store_w(g_cur * PLANES * PSZ, 0, wv);
+                __syncthreads();
+                int ns0 = s0 + G, nc0 = c0;
+                if (ns0 >= n_taps) {
+                    ns0 = 0;
+                    nc0 = c0 + CS;
+                }
+                if (nc0 < d.ci) {
+                    if (ns0 == 0) load_x(nc0, 0, xv, xok);
+                    load_w(nc0, ns0, min(G, n_taps - ns0) * PLANES * PSZ, 0, wv);
+                }
+                mfma_taps(s0, g_cur);
             }
-            mfma_taps(0, n_taps);
         }
     } else {
         for (int c0 = 0; c0 < d.ci; c0 += CS) {
@@ -450,108 +581,371 @@ __global__ __launch_bounds__(kThreads * SK, SK == 1 ? 2 : 1) void conv_igemm_ker
     }
     __syncthreads();
 
-    // ---- epilogue ------------------------------------------------------------------------------------------------------------
-    // Register e of a 32 x 32 tile is pixel column (e & 3) + 8 (e >> 2) + 4 h of ONE tile row (TW = 32): the row part of the
-    // output offset and the row validity are per (wave, i); the column part is a compile-time multiple of the pixel stride.
-    const bool want_stats = a.stats != nullptr;
-    float s1[NJ], s2[NJ];
-    const int ooy = d.class_ooy[cls], oox = d.class_oox[cls];
-    const int col_stride = d.osx * d.y_pix_stride;  // elements between horizontally adjacent virtual pixels
-    unsigned colmask = 0;                           // bit e: the pixel column of register e exists
+    conv_epilogue<MI, NJ, OUT_F32>(d, a, acc, cls, b, tx, ty, wave, r, h, grp == 0, n0, stats_row, tid_all, smem);
+}
+
+// ---- loader waves + MFMA waves, double-buffered LDS: 3x3 (and 1x1) / stride 1 / one tap class -------------------------------------------
+// Round-5 PMC of conv_igemm_kernel on the ConvGRU layer (304 -> 192 at 4 x 64 x 64, F32X3): waves parked at s_waitcnt / s_barrier
+// 47 % of their cycles, 7 150 non-MFMA vector instructions per wave beside 1 080 MFMAs (address arithmetic and the hi / lo split are
+// re-done by the waves that multiply, in phases that alternate with the MFMA phases), MFMA pipe 18 % busy -- and prefetching the
+// global loads one stage ahead changed nothing (94 vs 98 us): the kernel is bound by its own phase structure, not by load latency.
+// Here the two jobs run side by side in one block of 8 waves (one block per CU):
+//   * waves 4-7 LOAD: global -> registers (two stages in flight: the loads of stage k + 2 are issued before the registers of stage
+//     k + 1 are converted and written to LDS buffer (k + 1) & 1) -- input halo tile of one channel slab (prologue, hi / lo split) and
+//     the weight panels of ALL taps of that slab; per-thread addresses are computed once, a slab only adds a stride;
+//   * waves 0-3 MULTIPLY on buffer k & 1: the taps are unrolled with compile-time LDS offsets (the loaders store the panels in
+//     window order), fragments of tap t + 1 are read while the MFMAs of tap t issue; nothing but ds_read_b128 and v_mfma in the loop;
+//   * one raw s_barrier per slab (LDS counters drained, vector-memory loads left in flight).
+// CS = 16 channels per slab for fp32 tensors (F32X3: two bf16 planes), 32 for bf16 tensors: (tile + 9 panels) x 2 buffers = 113 KB at
+// 64-channel panels, 150 KB at 96.  LDS images as in conv_igemm_kernel (pixel stride CS * 2 + 16 B: conflict-free ds_read_b128).
+template <int MODE, int MI, int NJ, bool OUT_F32, int NTAPS, bool PRO>
+__global__ __launch_bounds__(512, 1) void conv_roles_kernel(const liso_conv_desc d, const FwdArgs a) {
+    constexpr bool X3 = MODE == LISO_CONV_F32X3;
+    constexpr int PLANES = X3 ? 2 : 1;
+    constexpr int CS = X3 ? 16 : 32;
+    constexpr int BNT = 32 * NJ;
+    constexpr int TH = 4 * MI;
+    constexpr int PS = CS * 2 + 16;
+    constexpr int KS = CS / 16;
+    constexpr int K8 = CS / 8;
+    constexpr int PSZ = K8 * BNT;        // 16-B chunks of one panel (one tap, one plane)
+    constexpr int WTAP = PSZ * 16;       // bytes of one panel
+    constexpr int KW = NTAPS == 9 ? 3 : 1;
+    constexpr int IN_W = 32 + KW - 1, IN_H = TH + KW - 1, NPIX = IN_H * IN_W;
+    constexpr int XPLANE = NPIX * PS;    // bytes of one plane of the tile
+    constexpr int WSTAGE = NTAPS * PLANES * WTAP;
+    constexpr int BUF = (XPLANE * PLANES + WSTAGE + 15) / 16 * 16;
+    constexpr int CPP = 4;               // 16-B chunks per tile pixel on the global side (fp32: 16 ch / 4, bf16: 32 ch / 8)
+    constexpr int CHN = X3 ? 4 : 8;      // channels per chunk
+    constexpr int PSTEP = 256 / CPP;
+    constexpr int XB = (NPIX * CPP + 255) / 256;
+    constexpr int WCH = NTAPS * PLANES * PSZ;  // weight chunks per stage
+    constexpr int WB = (WCH + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid_all = threadIdx.x, wave_all = tid_all >> 6, lane = tid_all & 63, r = lane & 31, h = lane >> 5;
+    const bool loader = wave_all >= 4;
+    const int wave = wave_all & 3;
+    int t = xcd_remap(blockIdx.x, a.total);
+    const int nt = t % a.n_nt;
+    t /= a.n_nt;
+    const int tx = t % a.tiles_x;
+    t /= a.tiles_x;
+    const int ty = t % a.tiles_y;
+    const int b = t / a.tiles_y;
+    const int stats_row = (b * a.tiles_y + ty) * a.tiles_x + tx;
+    const int n0 = nt * BNT;
+    const int dy0 = a.cls_dy0[0], dx0 = a.cls_dx0[0];
+    const int iy0 = ty * TH + dy0, ix0 = tx * 32 + dx0;
+    const int nslab = (d.ci + CS - 1) / CS;
+    unsigned char* base = smem + 512;  // (the statistics epilogue reuses the front; keep the layout of conv_igemm_kernel)
+
+    f16v acc[MI][NJ];
 #pragma unroll
-    for (int e = 0; e < 16; e++) {
-        const int vx = tx * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (vx < d.wv && vx * d.osx + oox < d.wo) colmask |= 1u << e;
-    }
-    const int col0 = (tx * 32 + 4 * h) * d.osx + oox;
+    for (int i = 0; i < MI; i++)
 #pragma unroll
-    for (int j = 0; j < NJ; j++) {
-        s1[j] = 0.0f;
-        s2[j] = 0.0f;
-    }
+        for (int j = 0; j < NJ; j++)
 #pragma unroll
-    for (int i = 0; i < MI; i++) {
-        const int vy = ty * TH + wave * MI + i;
-        const int oy = vy * d.osy + ooy;
-        const unsigned rowmask = (grp == 0 && vy < d.hv && oy < d.ho) ? colmask : 0u;
-        const long row_base = (((long)b * d.ho + oy) * d.wo + col0) * d.y_pix_stride + d.y_ch_off;
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
+
+    if (loader) {
+        const int tid = tid_all - 256;
+        const int cx = tid % CPP, p0 = tid / CPP;
+        constexpr bool pro = PRO;  // (a template parameter: a run-time branch around the prologue's loads makes hipcc's s_waitcnt insertion
+                                   // drain ALL loads in front of the first LDS store of a stage -- measured: loads and stores then add up)
+        const int aff_off = b * d.in_affine_batch_stride;
+        const unsigned char* xbase = (const unsigned char*)a.x + (long)b * d.hi * d.wi * d.x_pix_stride * (X3 ? 4 : 2);
+        const unsigned short* wg = (const unsigned short*)a.w;
+        const int kgroups_total = a.ci_pad >> 3;
+        const long plane_elems = (long)d.w_taps * kgroups_total * a.co_pad * 8;
+        // per-thread constants of the tile chunks: element offset of the pixel (channel 0 of the tensor's channel slice), validity, LDS byte
+        int x_off[XB], x_lds[XB];
+        unsigned xmask = 0u;
 #pragma unroll
-        for (int j = 0; j < NJ; j++) {
-            const int n = n0 + j * 32 + r;
-            const bool n_ok = n < d.co;
-            const float bias_v = (a.bias && n_ok) ? a.bias[n] : 0.0f;
-            const float shift_v = (a.stats_shift && n_ok) ? a.stats_shift[n] : 0.0f;
-            float v[16];
+        for (int u = 0; u < XB; u++) {
+            const int pix = p0 + u * PSTEP;
+            const int ly = pix / IN_W, lx = pix - ly * IN_W;
+            const int iy = iy0 + ly, ix = ix0 + lx;
+            const bool ok = pix < NPIX && (unsigned)iy < (unsigned)d.hi && (unsigned)ix < (unsigned)d.wi;
+            xmask |= ok ? (1u << u) : 0u;
+            x_off[u] = ok ? (iy * d.wi + ix) * d.x_pix_stride + cx * CHN : 0;
+            x_lds[u] = pix < NPIX ? pix * PS + cx * (X3 ? 8 : 16) : -1;
+        }
+        // ... and of the weight chunks: chunk q = (window position g, plane, 8-channel group c8, output channel n) in LDS order
+        int w_off[WB];
+        unsigned wmask = 0u;   // bit u: the chunk exists (inside the stage and the padded filter range)
 #pragma unroll
-            for (int e = 0; e < 16; e++) {
-                float val = acc[i][j][e] + bias_v;
-                if (d.out_relu) val = fmaxf(val, 0.0f);
-                if constexpr (!OUT_F32) val = round_bf16(val);
-                v[e] = val;
-                if (want_stats && ((rowmask >> e) & 1u)) {
-                    const float dd = val - shift_v;
-                    s1[j] += dd;
-                    s2[j] = fmaf(dd, dd, s2[j]);
+        for (int u = 0; u < WB; u++) {
+            const int q = tid + u * 256;
+            const int panel = q / PSZ, inner = q % PSZ;
+            const int g = panel / PLANES, plane = panel % PLANES;
+            const int c8 = inner / BNT, n = inner % BNT;
+            const bool ok = q < WCH && n0 + n < a.co_pad;
+            wmask |= ok ? (1u << u) : 0u;
+            const int tw = (int)((a.roles_tapw >> (4 * g)) & 15ull);  // (a packed word: indexing a kernel-argument array by a register goes through scratch)
+            w_off[u] = ok ? (int)(plane * plane_elems) + ((tw * kgroups_total + c8) * a.co_pad + n0 + n) * 8 : 0;
+        }
+        const int w_slab = K8 * a.co_pad * 8;  // elements between consecutive slabs of one tap
+        const int last = nslab - 1;
+
+        struct Regs {
+            uint4 x[XB];
+            uint4 w[WB];
+            float sc[CHN], sh[CHN];
+        };
+        // The loads of one stage and the conversion + LDS stores of the previous one are INTERLEAVED chunk by chunk (step()): round-5
+        // stamps showed the loader waves 3 200 cycles per slab in the issue of 18 loads (the vector-memory pipe is full: ~23 B / clk / CU
+        // from L2) and then 1 700 in the stores -- one after the other they held the MFMA waves at the barrier a third of the time.
+        // Loads are nothing but loads (no select on a loaded value: that would wait for it right there) from addresses that always exist;
+        // what must be zero is zeroed when it is stored.  Slabs beyond the last one are clamped: the loop body has no branch around a
+        // load, so hipcc's s_waitcnt insertion counts the younger stage's loads instead of draining everything.
+        struct Ctx {
+            int c0, cadd, kadd, cc;
+            bool ch_ok;
+        };
+        auto ctx_of = [&](int slab_req) {
+            Ctx c;
+            const int slab = slab_req < last ? slab_req : last;
+            c.c0 = slab * CS;
+            const int chx = c.c0 + cx * CHN;
+            c.ch_ok = chx < d.ci;
+            c.cadd = c.ch_ok ? c.c0 : 0;  // (a channel chunk beyond ci: any readable address, zeroed when stored)
+            c.kadd = slab * w_slab;       // (bf16 layers take this kernel only when ci is a multiple of the 32-channel slab)
+            c.cc = c.ch_ok ? aff_off + chx : 0;
+            return c;
+        };
+        auto load_w1 = [&](const Ctx& c, Regs& R, int u) {
+            // (non-temporal loads of the panels -- so that the tile's 128-B lines, asked for in two 64-B halves by consecutive fp32 slabs,
+            // survive in the vector L1 -- measured: no change)
+            R.w[u] = *reinterpret_cast<const uint4*>(wg + w_off[u] + (((wmask >> u) & 1u) ? c.kadd : 0));
+        };
+        auto load_x1 = [&](const Ctx& c, Regs& R, int u) {
+            R.x[u] = *reinterpret_cast<const uint4*>(xbase + (long)(x_off[u] + (((xmask >> u) & 1u) ? c.cadd : 0)) * (X3 ? 4 : 2));
+        };
+        auto load_aff = [&](const Ctx& c, Regs& R) {
+            if constexpr (pro) {
+#pragma unroll
+                for (int e = 0; e < CHN; e++) {
+                    R.sc[e] = a.in_scale[c.cc + e];
+                    R.sh[e] = a.in_shift[c.cc + e];
                 }
             }
-            if constexpr (OUT_F32) {
-                float* yg = (float*)a.y + row_base + n;
+        };
+        auto store_w1 = [&](const Regs& R, unsigned char* buf, int u) {
+            const int q = tid + u * 256;
+            if (q < WCH) *reinterpret_cast<uint4*>(buf + XPLANE * PLANES + q * 16) = ((wmask >> u) & 1u) ? R.w[u] : make_uint4(0u, 0u, 0u, 0u);
+        };
+        auto store_x1 = [&](const Ctx& c, const Regs& R, unsigned char* xs, int u) {
+            if (x_lds[u] < 0) return;
+            const bool ok = ((xmask >> u) & 1u) && c.ch_ok;
+            if constexpr (!X3) {
+                uint4 o = R.x[u];
+                if constexpr (pro) {
+                    unsigned w[4] = {o.x, o.y, o.z, o.w};
 #pragma unroll
-                for (int e = 0; e < 16; e++)
-                    if (((rowmask >> e) & 1u) && n_ok) yg[((e & 3) + 8 * (e >> 2)) * col_stride] = v[e];
-            } else {
-                unsigned short* yg = (unsigned short*)a.y + row_base;
-                const bool odd = r & 1;
-                const int n_even = n & ~1;
-                if ((d.y_pix_stride | d.y_ch_off) & 1) {  // odd pixel stride: channel pairs are not 4-B aligned, 2-B stores
-#pragma unroll
-                    for (int e = 0; e < 16; e++)
-                        if (((rowmask >> e) & 1u) && n_ok)
-                            yg[((e & 3) + 8 * (e >> 2)) * col_stride + n] = (unsigned short)(pack_bf16(v[e], 0.0f) & 0xffffu);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 16; e += 2) {
-                        const float send = odd ? v[e] : v[e + 1];
-                        const float recv = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(send), 0xB1, 0xF, 0xF, true));
-                        const float c_lo = odd ? recv : v[e];      // channel n_even
-                        const float c_hi = odd ? v[e + 1] : recv;  // channel n_even + 1
-                        const int ee = odd ? e + 1 : e;            // the register (pixel) this lane stores: compile-time per parity
-                        const int koff = odd ? ((e + 1) & 3) + 8 * ((e + 1) >> 2) : (e & 3) + 8 * (e >> 2);
-                        if ((rowmask >> ee) & 1u) {
-                            unsigned short* dst = yg + koff * col_stride + n_even;
-                            if (n_even + 1 < d.co)
-                                *reinterpret_cast<unsigned*>(dst) = pack_bf16(c_lo, c_hi);
-                            else if (n_even < d.co)
-                                *dst = (unsigned short)(pack_bf16(c_lo, 0.0f) & 0xffffu);
+                    for (int e = 0; e < 4; e++) {
+                        float f0 = fmaf(bf16_lo(w[e]), R.sc[2 * e], R.sh[2 * e]);
+                        float f1 = fmaf(bf16_hi(w[e]), R.sc[2 * e + 1], R.sh[2 * e + 1]);
+                        if (d.in_relu) {
+                            f0 = fmaxf(f0, 0.0f);
+                            f1 = fmaxf(f1, 0.0f);
                         }
+                        w[e] = pack_bf16(f0, f1);
                     }
+                    o = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+                if (!ok) o = make_uint4(0u, 0u, 0u, 0u);
+                *reinterpret_cast<uint4*>(xs + x_lds[u]) = o;
+            } else {
+                float f[4] = {__uint_as_float(R.x[u].x), __uint_as_float(R.x[u].y), __uint_as_float(R.x[u].z), __uint_as_float(R.x[u].w)};
+                unsigned hi2[2], lo2[2];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    if constexpr (pro) {
+                        f[e] = fmaf(f[e], R.sc[e], R.sh[e]);
+                        if (d.in_relu) f[e] = fmaxf(f[e], 0.0f);
+                    }
+                    if (!ok) f[e] = 0.0f;
+                }
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    const float h0 = round_bf16(f[2 * e]), h1 = round_bf16(f[2 * e + 1]);
+                    hi2[e] = pack_bf16(h0, h1);
+                    lo2[e] = pack_bf16(f[2 * e] - h0, f[2 * e + 1] - h1);
+                }
+                *reinterpret_cast<uint2*>(xs + x_lds[u]) = make_uint2(hi2[0], hi2[1]);
+                *reinterpret_cast<uint2*>(xs + XPLANE + x_lds[u]) = make_uint2(lo2[0], lo2[1]);
+            }
+        };
+        auto issue = [&](int slab_req, Regs& R) {
+            const Ctx c = ctx_of(slab_req);
+#pragma unroll
+            for (int u = 0; u < XB; u++) load_x1(c, R, u);
+            load_aff(c, R);
+#pragma unroll
+            for (int u = 0; u < WB; u++) load_w1(c, R, u);
+        };
+        auto store = [&](int slab, const Regs& R, unsigned char* buf) {
+            const Ctx c = ctx_of(slab);
+#pragma unroll
+            for (int u = 0; u < XB; u++) store_x1(c, R, buf, u);
+#pragma unroll
+            for (int u = 0; u < WB; u++) store_w1(R, buf, u);
+        };
+        // loads of slab `next` -> RN, registers RC (slab `cur`) -> buf; do_store = false: loads only
+        auto step = [&](int next, Regs& RN, int cur, const Regs& RC, unsigned char* buf, bool do_store) {
+            const Ctx cn = ctx_of(next), cc = ctx_of(cur);
+            constexpr int NMAX = XB > WB ? XB : WB;
+#pragma unroll
+            for (int u = 0; u < XB; u++) {
+                load_x1(cn, RN, u);
+                if (u == 0) load_aff(cn, RN);
+                if (do_store) store_x1(cc, RC, buf, u);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int u = 0; u < NMAX; u++) {
+                if (u < WB) {
+                    load_w1(cn, RN, u);
+                    if (do_store) store_w1(RC, buf, u);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
+        };
+        // raw barrier: the LDS stores have landed (lgkmcnt), the vector-memory loads of the next stage stay in flight
+        auto barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+#ifdef LISO_ROLES_STAMPS
+        unsigned long long st_issue = 0, st_store = 0, st_bar = 0, st_t;
+#define STAMP_BEGIN st_t = __builtin_amdgcn_s_memtime();
+#define STAMP_END(acc) { const unsigned long long st_n = __builtin_amdgcn_s_memtime(); acc += st_n - st_t; st_t = st_n; }
+        const unsigned long long st_k0 = __builtin_amdgcn_s_memtime();
+#else
+#define STAMP_BEGIN
+#define STAMP_END(acc)
+#endif
+        Regs RA, RB;
+        issue(0, RA);
+        issue(1, RB);
+        store(0, RA, base);
+        barrier();  // buffer 0 is ready
+#ifdef LISO_ROLES_STAMPS
+        const unsigned long long st_k1 = __builtin_amdgcn_s_memtime();
+#endif
+        // iteration k: the MFMA waves multiply buffer k & 1; here: loads of slab k + 2 -> the register set that was just stored,
+        // registers of slab k + 1 -> buffer (k + 1) & 1 (its readers finished before the previous barrier).  nslab barriers in all.
+        int k = 0;
+        for (; k + 1 < nslab; k += 2) {
+            STAMP_BEGIN
+            step(k + 2, RA, k + 1, RB, base + BUF, true);
+            STAMP_END(st_issue)
+            barrier();
+            STAMP_END(st_bar)
+            step(k + 3, RB, k + 2, RA, base, k + 2 < nslab);
+            STAMP_END(st_store)
+            barrier();
+            STAMP_END(st_bar)
         }
-    }
-    if (want_stats) {
-        float* red = reinterpret_cast<float*>(smem);  // [4 waves][BNT][2]; the main loop ended with a barrier
+        if (k < nslab) barrier();  // (odd slab count: the last multiplication)
+#ifdef LISO_ROLES_STAMPS
+        if (a.stats && tid == 0) {
+            unsigned long long* o = reinterpret_cast<unsigned long long*>(a.stats) + (size_t)blockIdx.x * 16 + 8;
+            o[0] = st_k1 - st_k0; o[1] = st_issue; o[2] = st_store; o[3] = st_bar;
+        }
+#endif
+    } else {
+        int a_off[MI];
 #pragma unroll
-        for (int j = 0; j < NJ; j++) {
-            const float t1 = s1[j] + __shfl_xor(s1[j], 32);
-            const float t2 = s2[j] + __shfl_xor(s2[j], 32);
-            if (h == 0 && grp == 0) {
-                red[(wave * BNT + j * 32 + r) * 2 + 0] = t1;
-                red[(wave * BNT + j * 32 + r) * 2 + 1] = t2;
-            }
-        }
-        __syncthreads();
-        if (tid_all < BNT) {
-            float q1 = 0.0f, q2 = 0.0f;
+        for (int i = 0; i < MI; i++) a_off[i] = ((wave * MI + i) * IN_W + r) * PS + h * 16;
+        const int b_off = XPLANE * PLANES + (h * BNT + r) * 16;
+        auto barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+        struct Frag {
+            uint4 ah[KS][MI], bh[KS][NJ];
+            uint4 al[X3 ? KS : 1][X3 ? MI : 1], bl[X3 ? KS : 1][X3 ? NJ : 1];
+        };
+        auto read = [&](const unsigned char* buf, int tap, Frag& F) {
+            const int toff = ((tap / KW) * IN_W + (tap % KW)) * PS;
+            const int woff = tap * PLANES * WTAP;
 #pragma unroll
-            for (int w = 0; w < 4; w++) {
-                q1 += red[(w * BNT + tid) * 2 + 0];
-                q2 += red[(w * BNT + tid) * 2 + 1];
+            for (int kk = 0; kk < KS; kk++) {
+#pragma unroll
+                for (int i = 0; i < MI; i++) {
+                    F.ah[kk][i] = *reinterpret_cast<const uint4*>(buf + a_off[i] + toff + kk * 32);
+                    if constexpr (X3) F.al[kk][i] = *reinterpret_cast<const uint4*>(buf + XPLANE + a_off[i] + toff + kk * 32);
+                }
+#pragma unroll
+                for (int j = 0; j < NJ; j++) {
+                    F.bh[kk][j] = *reinterpret_cast<const uint4*>(buf + b_off + woff + j * 512 + kk * (2 * BNT * 16));
+                    if constexpr (X3) F.bl[kk][j] = *reinterpret_cast<const uint4*>(buf + b_off + woff + WTAP + j * 512 + kk * (2 * BNT * 16));
+                }
             }
-            a.stats[((long)stats_row * 2 + 0) * a.co_pad + n0 + tid] = q1;
-            a.stats[((long)stats_row * 2 + 1) * a.co_pad + n0 + tid] = q2;
+        };
+        auto mul = [&](const Frag& F) {
+#pragma unroll
+            for (int kk = 0; kk < KS; kk++)
+#pragma unroll
+                for (int i = 0; i < MI; i++)
+#pragma unroll
+                    for (int j = 0; j < NJ; j++) {
+                        if constexpr (X3) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(F.al[kk][i]), as_bf8(F.bh[kk][j]), acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(F.ah[kk][i]), as_bf8(F.bl[kk][j]), acc[i][j], 0, 0, 0);
+                        }
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(F.ah[kk][i]), as_bf8(F.bh[kk][j]), acc[i][j], 0, 0, 0);
+                    }
+        };
+#ifdef LISO_ROLES_STAMPS
+        unsigned long long st_mul = 0, st_bar = 0, st_t;
+        const unsigned long long st_k0 = __builtin_amdgcn_s_memtime();
+#endif
+        barrier();  // buffer 0 is ready
+#ifdef LISO_ROLES_STAMPS
+        const unsigned long long st_k1 = __builtin_amdgcn_s_memtime();
+#endif
+        __builtin_amdgcn_s_setprio(2);  // the loader waves' vector instructions fill the MFMA shadows, never the other way round
+        for (int k = 0; k < nslab; k++) {
+            const unsigned char* buf = base + (k & 1) * BUF;
+            // fragments of tap t + 1 are requested before the MFMAs of tap t issue (the scheduling barriers keep hipcc from sinking the
+            // reads to their first use: it then waits for each group right after asking for it)
+            Frag F0, F1;
+            STAMP_BEGIN
+            read(buf, 0, F0);
+#pragma unroll
+            for (int tp = 0; tp < NTAPS; tp += 2) {
+                if (tp + 1 < NTAPS) read(buf, tp + 1, F1);
+                __builtin_amdgcn_sched_barrier(0);
+                mul(F0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (tp + 1 < NTAPS) {
+                    if (tp + 2 < NTAPS) read(buf, tp + 2, F0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mul(F1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            STAMP_END(st_mul)
+            barrier();
+            STAMP_END(st_bar)
         }
+        __builtin_amdgcn_s_setprio(0);
+#ifdef LISO_ROLES_STAMPS
+        if (a.stats && tid_all == 0) {
+            unsigned long long* o = reinterpret_cast<unsigned long long*>(a.stats) + (size_t)blockIdx.x * 16;
+            o[0] = st_k1 - st_k0; o[1] = st_mul; o[2] = st_bar; o[3] = __builtin_amdgcn_s_memtime() - st_k0;
+        }
+#endif
     }
+#ifdef LISO_ROLES_STAMPS
+    FwdArgs a2 = a;
+    a2.stats = nullptr;
+    __syncthreads();
+    const unsigned long long st_e0 = __builtin_amdgcn_s_memtime();
+    conv_epilogue<MI, NJ, OUT_F32>(d, a2, acc, 0, b, tx, ty, wave, r, h, !loader, n0, stats_row, tid_all, smem);
+    if (a.stats && tid_all == 0) reinterpret_cast<unsigned long long*>(a.stats)[(size_t)blockIdx.x * 16 + 4] = __builtin_amdgcn_s_memtime() - st_e0;
+    return;
+#endif
+    __syncthreads();
+    conv_epilogue<MI, NJ, OUT_F32>(d, a, acc, 0, b, tx, ty, wave, r, h, !loader, n0, stats_row, tid_all, smem);
 }
 
 // ---- 8 waves, weight panels by LDS-DMA ------------------------------------------------------------------------------------------------
@@ -1163,6 +1557,77 @@ struct Plan {
 
 int g_shared_gpu = 0;  // liso_conv_set_option(LISO_CONV_OPT_SHARED_GPU)
 
+// conv_roles_kernel: 3x3 windows (any tap order: forward and mirrored data-gradient taps), stride 1, one class, bf16 / F32X3.
+// Tile shape (MI, NJ) by a cycle model of one block per CU: rounds of 256 blocks x slabs x max(MFMA cycles, loader cycles per slab).
+void plan_roles(const liso_conv_desc& d, Plan* p) {
+    FwdArgs& a = p->a;
+    a.roles = 0;
+    static const int roles_env = getenv("LISO_CONV_ROLES") ? atoi(getenv("LISO_CONV_ROLES")) : 1;
+    if (!roles_env || a.a8 || d.mode == LISO_CONV_F32) return;
+    if (d.n_classes != 1 || d.isy != 1 || d.isx != 1 || d.osy != 1 || d.osx != 1 || d.n_taps != 9) return;
+    const bool x3 = d.mode == LISO_CONV_F32X3;
+    if (!x3 && d.ci % 32) return;  // (bf16 slabs are 32 channels: no half-filled last slab in the loaders' branch-free loop)
+    int y0 = 1 << 30, x0 = 1 << 30, y1 = -(1 << 30), x1 = -(1 << 30);
+    for (int t = 0; t < 9; t++) {
+        y0 = d.tap_dy[t] < y0 ? d.tap_dy[t] : y0;
+        y1 = d.tap_dy[t] > y1 ? d.tap_dy[t] : y1;
+        x0 = d.tap_dx[t] < x0 ? d.tap_dx[t] : x0;
+        x1 = d.tap_dx[t] > x1 ? d.tap_dx[t] : x1;
+    }
+    if (y1 - y0 != 2 || x1 - x0 != 2) return;
+    int seen = 0;
+    a.roles_tapw = 0ull;
+    for (int t = 0; t < 9; t++) {
+        const int pos = (d.tap_dy[t] - y0) * 3 + (d.tap_dx[t] - x0);
+        if (d.tap_w[t] < 0 || d.tap_w[t] > 15) return;
+        seen |= 1 << pos;
+        a.roles_tapw |= (unsigned long long)d.tap_w[t] << (4 * pos);
+    }
+    if (seen != 0x1ff) return;
+    const int cs = x3 ? 16 : 32, ks = cs / 16, nslab = (d.ci + cs - 1) / cs;
+    // shallow layers (a block's prologue and epilogue are not overlapped with anything at one block per CU): measured round 5,
+    // 32 -> 32 at 8 x 256^2 F32X3: 76 vs 67 us, bf16 64 -> 64 at 2 x 256^2: 27 vs 25 us; from 4 slabs on this kernel is ahead
+    static const int min_slabs = getenv("LISO_ROLES_MIN_SLABS") ? atoi(getenv("LISO_ROLES_MIN_SLABS")) : 4;
+    if (nslab < min_slabs) return;
+    static const int force_mi = getenv("LISO_ROLES_MI") ? atoi(getenv("LISO_ROLES_MI")) : 0;
+    static const int force_nj = getenv("LISO_ROLES_NJ") ? atoi(getenv("LISO_ROLES_NJ")) : 0;
+    double best = 1e300;
+    int bmi = 0, bnj = 0;
+    for (int mi = 1; mi <= 2; mi++)
+        for (int nj = 1; nj <= (x3 ? 3 : 2); nj++) {
+            if (mi == 2 && nj == 3) continue;  // (two buffers would not fit 160 KB)
+            if ((force_mi && mi != force_mi) || (force_nj && nj != force_nj)) continue;
+            const long blocks = (long)d.batch * ((d.hv + 4 * mi - 1) / (4 * mi)) * ((d.wv + 31) / 32) * ((d.co + 32 * nj - 1) / (32 * nj));
+            const long rounds = (blocks + 255) / 256;
+            const int npix = (4 * mi + 2) * 34, xb = (npix * 4 + 255) / 256, wb = (9 * (x3 ? 2 : 1) * (cs / 8) * 32 * nj + 255) / 256;
+            const double mfma = 9.0 * ks * mi * nj * (x3 ? 3 : 1) * 32.0;
+            const double load = 40.0 * (xb * (x3 ? 6 : 2) + wb * 2) + 200.0;
+            const double cost = (double)rounds * (nslab * (mfma > load ? mfma : load) + 3000.0) - 1e-3 * mi * nj;
+            if (cost < best) {
+                best = cost;
+                bmi = mi;
+                bnj = nj;
+            }
+        }
+    if (!bmi) return;
+    a.roles = 1;
+    p->mi = bmi;
+    p->nj = bnj;
+    p->sk = 1;
+    p->cs = cs;
+    a.cs = cs;
+    a.cls_dy0[0] = y0;
+    a.cls_dx0[0] = x0;
+    const int bnt = 32 * bnj, th = 4 * bmi;
+    a.n_nt = (d.co + bnt - 1) / bnt;
+    a.tiles_x = (d.wv + 31) / 32;
+    a.tiles_y = (d.hv + th - 1) / th;
+    a.total = d.batch * a.tiles_y * a.tiles_x * a.n_nt;
+    const int planes = x3 ? 2 : 1;
+    const int buf = ((th + 2) * 34 * (cs * 2 + 16) * planes + 9 * planes * (cs / 8) * bnt * 16 + 15) / 16 * 16;
+    p->lds = 512 + 2 * buf;
+}
+
 bool make_plan(const liso_conv_desc& d, Plan* p) {
     if (d.batch <= 0 || d.ci <= 0 || d.co <= 0 || d.n_classes < 1 || d.n_classes > LISO_CONV_MAX_CLASSES) return false;
     if (d.n_taps < 1 || d.n_taps > LISO_CONV_MAX_TAPS || d.class_tap_begin[0] != 0 || d.class_tap_begin[d.n_classes] != d.n_taps)
@@ -1295,8 +1760,24 @@ bool make_plan(const liso_conv_desc& d, Plan* p) {
         const int cpp = fin ? p->cs / 4 : p->cs / 8;
         const int x_chunks = (max_pix * cpp + kThreads - 1) / kThreads;          // per thread
         const int w_chunks = (max_taps * (panel_bytes(p->cs, bnt) / 16) + kThreads - 1) / kThreads;
-        a.pipelined = (p->g >= max_taps && x_chunks <= 12 && w_chunks <= 10) ? 1 : 0;
-        if (const char* e = getenv("LISO_CONV_PIPE")) a.pipelined = a.pipelined && atoi(e) != 0;  // experiments
+        // stage-granular software pipeline: the halo tile within one register batch (12 x 16 B per thread) and a weight stage within
+        // one (10 x 16 B per thread = 40 KB): the stage shrinks to the taps that fit
+        const int panel = panel_bytes(p->cs, bnt);
+        int g_pipe = (10 * kThreads * 16) / panel;
+        g_pipe = g_pipe > p->g ? p->g : g_pipe;
+        a.slab_pipelined = (p->g >= max_taps && x_chunks <= 12 && w_chunks <= 10) ? 1 : 0;  // (round 4's condition: the SK = 2 kernel needs it)
+        a.pipelined = (x_chunks <= 12 && g_pipe >= 1) ? 1 : 0;
+        if (const char* e = getenv("LISO_CONV_PIPE")) {  // experiments: 0 = never, 1 = round 4's whole-slab condition, 2 = stage-granular (default)
+            const int v = atoi(e);
+            if (v == 0) a.pipelined = 0;
+            if (v == 1) a.pipelined = a.slab_pipelined;
+        }
+        if (a.pipelined && !(a.slab_pipelined && p->g >= max_taps)) {
+            p->g = g_pipe;
+            a.g_taps = g_pipe;
+            p->lds = 512 + a.x_plane_bytes * planes + g_pipe * panel;
+            if (p->lds < 4096) p->lds = 4096;
+        }
     }
     a.tiles_x = (d.wv + 31) / 32;
     a.tiles_y = (d.hv + th - 1) / th;
@@ -1305,7 +1786,7 @@ bool make_plan(const liso_conv_desc& d, Plan* p) {
     // anyway, at least two slabs, and both groups' buffers + the accumulator hand-over fit the CU's LDS
     p->sk = 1;
     a.group_bytes = round_up(a.x_plane_bytes * planes + max_taps * panel_bytes(p->cs, bnt), 16);
-    if (x3 && a.pipelined && p->mi == 1 && p->nj == 1 && a.total <= 256 && d.ci > p->cs && 512 + 2 * a.group_bytes <= 160 * 1024 &&
+    if (x3 && a.slab_pipelined && p->mi == 1 && p->nj == 1 && a.total <= 256 && d.ci > p->cs && 512 + 2 * a.group_bytes <= 160 * 1024 &&
         a.group_bytes >= 16 * kThreads * 4)
         p->sk = 2;
     if (const char* e = getenv("LISO_CONV_SK")) p->sk = (atoi(e) >= 2 && p->sk == 2) ? 2 : 1;  // experiments
@@ -1359,6 +1840,7 @@ bool make_plan(const liso_conv_desc& d, Plan* p) {
             a.total = (int)blocks8;
         }
     }
+    plan_roles(d, p);
     return true;
 }
 
@@ -1373,6 +1855,24 @@ int launch8(const liso_conv_desc& d, const Plan& p, hipStream_t st) {
     }
     conv_igemm8_kernel<MODE, NJ, OUT_F32, CS><<<p.a.total, 512, p.lds, st>>>(d, p.a);
     return check_launch();
+}
+
+template <int MODE, int MI, int NJ, bool OUT_F32, int NTAPS, bool PRO>
+int launch_roles_pro(const liso_conv_desc& d, const Plan& p, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)conv_roles_kernel<MODE, MI, NJ, OUT_F32, NTAPS, PRO>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess)
+            return LISO_ELAUNCH;
+        attr_set = true;
+    }
+    conv_roles_kernel<MODE, MI, NJ, OUT_F32, NTAPS, PRO><<<p.a.total, 512, p.lds, st>>>(d, p.a);
+    return check_launch();
+}
+template <int MODE, int MI, int NJ, bool OUT_F32, int NTAPS>
+int launch_roles(const liso_conv_desc& d, const Plan& p, hipStream_t st) {
+    return p.a.in_scale ? launch_roles_pro<MODE, MI, NJ, OUT_F32, NTAPS, true>(d, p, st)
+                        : launch_roles_pro<MODE, MI, NJ, OUT_F32, NTAPS, false>(d, p, st);
 }
 
 template <int MODE, int MI, int NJ, bool OUT_F32, int CS, int SK = 1>
@@ -1469,7 +1969,7 @@ int liso_conv_forward_sparse(const liso_conv_desc* d, const void* x, const void*
     p.a.stats = stats_partial;
     p.a.stats_shift = stats_shift;
     p.a.occ = occupancy;
-    if (occupancy) p.a.a8 = 0;  // (the tile-skipping test lives in the 4-wave kernel)
+    if (occupancy) p.a.a8 = 0;  // (the tile-skipping test lives in the 4-wave kernel; conv_roles_kernel computes the dense result)
     hipStream_t st = (hipStream_t)stream;
     const bool x3 = d->mode == LISO_CONV_F32X3;
     const bool of32 = x3 || d->out_f32;
@@ -1482,6 +1982,26 @@ int liso_conv_forward_sparse(const liso_conv_desc* d, const void* x, const void*
         if (p.mi == 1 && p.nj == 2) LISO_GO(MODE, 1, 2, OF, CSA, CSB); \
         LISO_GO(MODE, 1, 1, OF, CSA, CSB);            \
     } while (0)
+    if (p.a.roles) {
+        // (an occupancy map is ignored here: the dense result is bit-identical by contract)
+#define LISO_ROLES(MODE, OF)                                                                   \
+    do {                                                                                       \
+        if (p.mi == 1 && p.nj == 1) return launch_roles<MODE, 1, 1, OF, 9>(*d, p, st);         \
+        if (p.mi == 1 && p.nj == 2) return launch_roles<MODE, 1, 2, OF, 9>(*d, p, st);         \
+        if (p.mi == 2 && p.nj == 1) return launch_roles<MODE, 2, 1, OF, 9>(*d, p, st);         \
+        if (p.mi == 2 && p.nj == 2) return launch_roles<MODE, 2, 2, OF, 9>(*d, p, st);         \
+    } while (0)
+        if (x3) {
+            if (p.mi == 1 && p.nj == 3) return launch_roles<LISO_CONV_F32X3, 1, 3, true, 9>(*d, p, st);
+            LISO_ROLES(LISO_CONV_F32X3, true);
+        } else if (of32) {
+            LISO_ROLES(LISO_CONV_BF16, true);
+        } else {
+            LISO_ROLES(LISO_CONV_BF16, false);
+        }
+#undef LISO_ROLES
+        return LISO_EINVAL;
+    }
     if (p.a.a8) {
 #define LISO_GO8(MODE, OF, CSA, CSB)                                                                                  \
     do {                                                                                                              \

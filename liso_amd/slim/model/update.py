@@ -112,6 +112,16 @@ class SmallUpdateBlock(nn.Module):
         if gru.convz.in_channels != ch + ci + co + cc + cf or me.conv.in_channels != cq + cf + cc or any(c % 8 for c in (ch, ci, co, cc, cf, cq)):
             return None
         B, _, H, W = net.shape
+        # every convolution that forward_inference runs with `out=` (or on a channel slice) must be one the own kernels cover: the
+        # library path cannot write channel ranges (`assert out is None` in mfma_conv.conv2d) -- e.g. correlation planes
+        # num_levels * (2 r + 1)^2 that are not a multiple of 4
+        probe = lambda conv, c_in: MC.supported(torch.empty((1, c_in, 1, 1), dtype=torch.float32, device=net.device), conv.weight,  # noqa: E731
+                                                MC.ConvSpec.of(conv))
+        if not (probe(me.conv_stat_corr1, me.conv_stat_corr1.in_channels) and probe(me.conv_flow2, me.conv_flow2.in_channels)
+                and probe(me.conv_class2, me.conv_class2.in_channels) and probe(me.conv, cq + cc + cf)
+                and probe(gru.convz, gru.convz.in_channels) and probe(gru.convr, gru.convr.in_channels)
+                and probe(gru.convq, gru.convq.in_channels)):
+            return None
         big = torch.empty((B, H, W, 2 * ch + ci + co + cc + cf), dtype=torch.float32, device=net.device)
         m = torch.empty((B, H, W, cq + cc + cf), dtype=torch.float32, device=net.device)
         big[..., :ch].copy_(net.permute(0, 2, 3, 1))

@@ -826,7 +826,9 @@ class LisoLoopTrainer:
         # a graph whose replays may still be in flight
         self.max_mine_graphs = int(tcfg.setdefault("max_mine_graphs", 6))
         self.mine_capture_budget = int(tcfg.setdefault("mine_capture_budget", 24))
+        self.mine_capture_window = int(tcfg.setdefault("mine_capture_window", 400))
         self.mine_captures, self.mine_eager_fallbacks = 0, 0
+        self._mine_calls, self._mine_capture_calls, self._mine_fallback_warned = 0, [], False
         self._views = collections.OrderedDict()  # id(sample) -> (sample, bucket-padded view); the samples themselves are never edited
         self.overlap = bool(overlap) and device.type == "cuda"
         self.infer_batch, self.flow_ahead = int(infer_batch), int(flow_ahead)
@@ -1057,7 +1059,7 @@ class LisoLoopTrainer:
         inference graph's) and the padded flow, so sweeps of different point counts share a signature; they are copied into the
         captured inputs by one launch, inv(odom) - I is computed INSIDE the graph (liso_odom_inverse_minus_eye_f64), and all results
         come out of ONE packed buffer that is cloned behind the replay (the next replay overwrites the captured one).  Beyond
-        `mine_capture_budget` captures a new signature runs the eager fixed-slot path instead of evicting a graph.
+        `mine_capture_budget` captures per `mine_capture_window` calls a new signature runs the eager fixed-slot path instead of evicting a graph.
         -> (targets dict, boxes Shape, max cluster count int64 [1])"""
         from liso_amd.kabsch.shape_utils import Shape
 
@@ -1073,9 +1075,21 @@ class LisoLoopTrainer:
         # concurrently and must not share buffers)
         sig = (side.cuda_stream,) + tuple((k, tuple(t.shape), t.dtype) for k, t in ins.items())
         st = self._mine_graphs.get(sig)
-        if st is None and self.mine_captures >= self.mine_capture_budget:
+        # the budget is a RATE -- at most `mine_capture_budget` captures per `mine_capture_window` mining calls -- so a signature that
+        # was evicted from the LRU can be captured again later; a lifetime budget (round 4) left every non-resident signature on the
+        # eager path for the rest of a long run
+        self._mine_calls += 1
+        while self._mine_capture_calls and self._mine_capture_calls[0] <= self._mine_calls - self.mine_capture_window:
+            self._mine_capture_calls.pop(0)
+        if st is None and len(self._mine_capture_calls) >= self.mine_capture_budget:
             # too many different signatures (bucket too fine for this data): same kernels, launched eagerly, nothing evicted
             self.mine_eager_fallbacks += 1
+            if not self._mine_fallback_warned:
+                self._mine_fallback_warned = True
+                import warnings
+                warnings.warn(f"LisoLoopTrainer: {self.mine_capture_budget} box-mining graph captures within {self.mine_capture_window} "
+                              "calls -- new point-count signatures run stage B eagerly until the rate drops (raise "
+                              "infer_point_bucket or max_mine_graphs)")
             targets, boxes = self._targets_from_flow(sample_t0, flow, capacity=self.box_capacity)
             return targets, boxes, self.cluster_detector.last_num_labels.max().reshape(1)
         if st is not None:
@@ -1093,6 +1107,7 @@ class LisoLoopTrainer:
             while len(self._mine_graphs) >= max(self.max_mine_graphs, 1):
                 self._mine_graphs.popitem(last=False)[1].clear()
             self.mine_captures += 1
+            self._mine_capture_calls.append(self._mine_calls)
             st = self._mine_graphs[sig] = _packed_inputs(ins)
             si = st["in"]
             sample = {"pcl_ta": {"pcl": si["pcl"], "pcl_is_valid": si["valid"], "pillar_coors": si["coors"]},

@@ -963,8 +963,13 @@ _SPARSE_OVERFLOW = {}           # device index -> int32 [1]: set by the kernels 
 
 def sparse_stem_overflowed(device):
     """did any sparse stem convolution on `device` drop cells since the process started (one device -> host read)?"""
-    t = _SPARSE_OVERFLOW.get(torch.device(device).index)
+    t = _SPARSE_OVERFLOW.get(_dev_index(torch.device(device)))
     return bool(t is not None and int(t.item()) != 0)
+
+
+def _dev_index(dev):
+    """torch.device('cuda') has index None: the flag table is keyed by the index the kernels' tensors report"""
+    return dev.index if dev.index is not None else torch.cuda.current_device()
 
 
 def _sparse_geometry(x_raw, weight, spec):
@@ -986,11 +991,12 @@ def _sparse_geometry(x_raw, weight, spec):
 
 
 def _sparse_flag(dev):
-    flag = _SPARSE_OVERFLOW.get(dev.index)
+    idx = _dev_index(dev)
+    flag = _SPARSE_OVERFLOW.get(idx)
     if flag is None:
         if torch.cuda.is_current_stream_capturing():
             return None  # (first use inside a capture: the persistent flag cannot be created here; a warm-up pass creates it)
-        flag = _SPARSE_OVERFLOW[dev.index] = torch.zeros(1, dtype=torch.int32, device=dev)
+        flag = _SPARSE_OVERFLOW[idx] = torch.zeros(1, dtype=torch.int32, device=torch.device("cuda", idx))
     return flag
 
 
@@ -1069,7 +1075,9 @@ def _sparse_dgrad(dy, occupancy, weight, spec, x_shape, x_dtype, lists=None):
     with torch.cuda.device(dev):
         L.check(L.TIMER.launch("conv_sparse_dgrad", lambda: lib.liso_sparse_conv_dgrad(
             L.ptr(gv), gps, int(bf), L.ptr(occ), L.ptr(packed), B, H, W, k, co, cap, L.ptr(dx), C, L.ptr(flag), L.ptr(ws), ws.numel(),
-            int(reuse), L.stream_ptr()), units=B * H * W * C * dx.element_size()), "sparse_conv_dgrad")  # (bytes: the zero-filled canvas gradient)
+            int(reuse), L.stream_ptr()), units=gv.numel() * gv.element_size()), "sparse_conv_dgrad")
+        # (bytes the LAUNCH moves, lower bound: dy read once; the rows it writes at the occupied cells are not counted -- their number
+        # is only known on the device -- and the zero fill of the canvas gradient is torch.zeros above, outside the timed launch)
     return dx.permute(0, 3, 1, 2)
 
 

@@ -1,5 +1,6 @@
 """micro-benchmark of the own convolution kernels on the detector's layer shapes: forward / dgrad / wgrad, TFLOP/s"""
-import sys
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from liso_amd.utils import mfma_conv as MC
 
