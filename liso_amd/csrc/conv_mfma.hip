@@ -84,7 +84,7 @@ __device__ __forceinline__ bf8 as_bf8(const uint4& v) { return __builtin_bit_cas
 // ---- epilogue shared by the forward kernels ---------------------------------------------------------------------------------------
 // acc[i][j]: the 32 x 32 MFMA tiles of wave `wave` (tile row wave * MI + i of the block's TH = 4 MI rows, output channels n0 + 32 j ...).
 // `active` = this thread holds accumulators (waves 0-3 of the block, split-K group 0); every thread of the block must call (barriers).
-template <int MI, int NJ, bool OUT_F32>
+template <int MI, int NJ, bool OUT_F32, bool WAVE_STATS = false>
 __device__ __forceinline__ void conv_epilogue(const liso_conv_desc& d, const FwdArgs& a, f16v (&acc)[MI][NJ], int cls, int b, int tx, int ty,
                                               int wave, int r, int h, bool active, int n0, int stats_row, int tid_all,
                                               unsigned char* smem) {
@@ -116,6 +116,13 @@ __device__ __forceinline__ void conv_epilogue(const liso_conv_desc& d, const Fwd
         const int vy = ty * TH + wave * MI + i;
         const int oy = vy * d.osy + ooy;
         const unsigned rowmask = (grp == 0 && vy < d.hv && oy < d.ho) ? colmask : 0u;
+        if constexpr (WAVE_STATS) {
+#pragma unroll
+            for (int j = 0; j < NJ; j++) {
+                s1[j] = 0.0f;
+                s2[j] = 0.0f;
+            }
+        }
         const long row_base = (((long)b * d.ho + oy) * d.wo + col0) * d.y_pix_stride + d.y_ch_off;
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
@@ -130,10 +137,32 @@ __device__ __forceinline__ void conv_epilogue(const liso_conv_desc& d, const Fwd
                 if (d.out_relu) val = fmaxf(val, 0.0f);
                 if constexpr (!OUT_F32) val = round_bf16(val);
                 v[e] = val;
-                if (want_stats && ((rowmask >> e) & 1u)) {
-                    const float dd = val - shift_v;
-                    s1[j] += dd;
-                    s2[j] = fmaf(dd, dd, s2[j]);
+                if constexpr (!WAVE_STATS) {
+                    if (want_stats && ((rowmask >> e) & 1u)) {
+                        const float dd = val - shift_v;
+                        s1[j] += dd;
+                        s2[j] = fmaf(dd, dd, s2[j]);
+                    }
+                }
+            }
+            if constexpr (WAVE_STATS) {
+                if (want_stats) {  // pairwise sums over the lane's 16 pixels (error grows with log n, not n)
+                    float q1[16], q2[16];
+#pragma unroll
+                    for (int e = 0; e < 16; e++) {
+                        const float dd = ((rowmask >> e) & 1u) ? v[e] - shift_v : 0.0f;
+                        q1[e] = dd;
+                        q2[e] = dd * dd;
+                    }
+#pragma unroll
+                    for (int w = 8; w >= 1; w >>= 1)
+#pragma unroll
+                        for (int e = 0; e < w; e++) {
+                            q1[e] += q1[e + w];
+                            q2[e] += q2[e + w];
+                        }
+                    s1[j] = q1[0];
+                    s2[j] = q2[0];
                 }
             }
             if constexpr (OUT_F32) {
@@ -170,8 +199,25 @@ __device__ __forceinline__ void conv_epilogue(const liso_conv_desc& d, const Fwd
                 }
             }
         }
+        if constexpr (WAVE_STATS) {
+            if (want_stats) {  // sums of tile row (wave * MI + i) -> LDS [TH][BNT][2]
+                float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+                for (int j = 0; j < NJ; j++) {
+                    const float t1 = s1[j] + __shfl_xor(s1[j], 32);
+                    const float t2 = s2[j] + __shfl_xor(s2[j], 32);
+                    if (h == 0) {
+                        red[((wave * MI + i) * BNT + j * 32 + r) * 2 + 0] = t1;
+                        red[((wave * MI + i) * BNT + j * 32 + r) * 2 + 1] = t2;
+                    }
+                }
+            }
+        }
     }
-    if (want_stats) {
+    if constexpr (WAVE_STATS) {
+        // (conv_roles_kernel: the sums of every 32-pixel tile row went to LDS inside the row loop; roles_flush_stats adds them behind
+        // the block's next barrier)
+    } else if (want_stats) {
         float* red = reinterpret_cast<float*>(smem);  // [4 waves][BNT][2]; the main loop ended with a barrier
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
@@ -584,20 +630,46 @@ __global__ __launch_bounds__(kThreads * SK, SK == 1 ? 2 : 1) void conv_igemm_ker
     conv_epilogue<MI, NJ, OUT_F32>(d, a, acc, cls, b, tx, ty, wave, r, h, grp == 0, n0, stats_row, tid_all, smem);
 }
 
-// ---- loader waves + MFMA waves, double-buffered LDS: 3x3 (and 1x1) / stride 1 / one tap class -------------------------------------------
+// BatchNorm / InstanceNorm partial sums of conv_roles_kernel: one statistics row per 4 tile rows x 32 pixels = sum of the four 32-pixel row
+// sums the epilogue left in LDS, ((r0 + r1) + (r2 + r3)) -- a fixed tree over fixed pixel sets, whatever the tile shape, the panel width
+// or the tile -> block map (results do not change with the batch size the plan was made for).  Rows: ((b * tiles_y + ty) * MI + g) * tiles_x + tx.
+template <int MI, int NJ>
+__device__ __forceinline__ void roles_flush_stats(const FwdArgs& a, int b, int ty, int tx, int n0, int tid_all, const unsigned char* smem) {
+    constexpr int BNT = 32 * NJ;
+    if (tid_all >= BNT) return;
+    const float* red = reinterpret_cast<const float*>(smem);
+#pragma unroll
+    for (int g = 0; g < MI; g++) {
+        const long row = ((long)(b * a.tiles_y + ty) * MI + g) * a.tiles_x + tx;
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const float p0 = red[((4 * g + 0) * BNT + tid_all) * 2 + q], p1 = red[((4 * g + 1) * BNT + tid_all) * 2 + q];
+            const float p2 = red[((4 * g + 2) * BNT + tid_all) * 2 + q], p3 = red[((4 * g + 3) * BNT + tid_all) * 2 + q];
+            a.stats[(row * 2 + q) * a.co_pad + n0 + tid_all] = (p0 + p1) + (p2 + p3);
+        }
+    }
+}
+
+// ---- loader waves + MFMA waves, double-buffered LDS, persistent blocks: 3x3 / stride 1 / one tap class -----------------------------------
 // Round-5 PMC of conv_igemm_kernel on the ConvGRU layer (304 -> 192 at 4 x 64 x 64, F32X3): waves parked at s_waitcnt / s_barrier
 // 47 % of their cycles, 7 150 non-MFMA vector instructions per wave beside 1 080 MFMAs (address arithmetic and the hi / lo split are
 // re-done by the waves that multiply, in phases that alternate with the MFMA phases), MFMA pipe 18 % busy -- and prefetching the
 // global loads one stage ahead changed nothing (94 vs 98 us): the kernel is bound by its own phase structure, not by load latency.
-// Here the two jobs run side by side in one block of 8 waves (one block per CU):
-//   * waves 4-7 LOAD: global -> registers (two stages in flight: the loads of stage k + 2 are issued before the registers of stage
-//     k + 1 are converted and written to LDS buffer (k + 1) & 1) -- input halo tile of one channel slab (prologue, hi / lo split) and
-//     the weight panels of ALL taps of that slab; per-thread addresses are computed once, a slab only adds a stride;
-//   * waves 0-3 MULTIPLY on buffer k & 1: the taps are unrolled with compile-time LDS offsets (the loaders store the panels in
-//     window order), fragments of tap t + 1 are read while the MFMAs of tap t issue; nothing but ds_read_b128 and v_mfma in the loop;
-//   * one raw s_barrier per slab (LDS counters drained, vector-memory loads left in flight).
+// Here the two jobs run side by side in one block of 8 waves (one block per CU, at most one block per CU in the grid):
+//   * waves 4-7 LOAD: global -> registers (two stages in flight) -> [prologue, hi / lo split] -> LDS buffer (k + 1) & 1: the input halo
+//     tile of one channel slab and the weight panels of ALL taps of that slab.  The loads of stage k + 2 and the stores of stage k + 1
+//     are interleaved chunk by chunk; per-thread addresses are computed once per tile, a slab only adds a stride;
+//   * waves 0-3 MULTIPLY on buffer k & 1: taps unrolled with compile-time LDS offsets (the loaders store the panels in window order),
+//     fragments of tap t + 1 are requested before the MFMAs of tap t issue; nothing but ds_read_b128 and v_mfma in the loop;
+//   * one raw s_barrier per slab (LDS counters drained, vector-memory loads left in flight);
+//   * a block walks tiles blockIdx, blockIdx + gridDim, ...: the stages of all its tiles form ONE stream, so the loaders stage the next
+//     tile's first slabs while the MFMA waves run the epilogue of the previous one (bias / ReLU / stores / BatchNorm sums: one statistics
+//     row per (tile, wave), no LDS and no barrier in the epilogue).
 // CS = 16 channels per slab for fp32 tensors (F32X3: two bf16 planes), 32 for bf16 tensors: (tile + 9 panels) x 2 buffers = 113 KB at
 // 64-channel panels, 150 KB at 96.  LDS images as in conv_igemm_kernel (pixel stride CS * 2 + 16 B: conflict-free ds_read_b128).
+// Measured (in-kernel s_memtime stamps, `make STAMPS=1` + scripts/roles_stamps.py): the loaders move ~17-19 B / clk / CU from L2 whatever
+// the instruction mix -- a 4-row tile with 96-channel panels (73 KB per slab) is bound by them (4 300 cycles per slab against 2 600 of
+// MFMA), 8-row tiles with 64-channel panels are balanced.
 template <int MODE, int MI, int NJ, bool OUT_F32, int NTAPS, bool PRO>
 __global__ __launch_bounds__(512, 1) void conv_roles_kernel(const liso_conv_desc d, const FwdArgs a) {
     constexpr bool X3 = MODE == LISO_CONV_F32X3;
@@ -626,101 +698,131 @@ __global__ __launch_bounds__(512, 1) void conv_roles_kernel(const liso_conv_desc
     const int tid_all = threadIdx.x, wave_all = tid_all >> 6, lane = tid_all & 63, r = lane & 31, h = lane >> 5;
     const bool loader = wave_all >= 4;
     const int wave = wave_all & 3;
-    int t = xcd_remap(blockIdx.x, a.total);
-    const int nt = t % a.n_nt;
-    t /= a.n_nt;
-    const int tx = t % a.tiles_x;
-    t /= a.tiles_x;
-    const int ty = t % a.tiles_y;
-    const int b = t / a.tiles_y;
-    const int stats_row = (b * a.tiles_y + ty) * a.tiles_x + tx;
-    const int n0 = nt * BNT;
-    const int dy0 = a.cls_dy0[0], dx0 = a.cls_dx0[0];
-    const int iy0 = ty * TH + dy0, ix0 = tx * 32 + dx0;
     const int nslab = (d.ci + CS - 1) / CS;
-    unsigned char* base = smem + 512;  // (the statistics epilogue reuses the front; keep the layout of conv_igemm_kernel)
-
-    f16v acc[MI][NJ];
-#pragma unroll
-    for (int i = 0; i < MI; i++)
-#pragma unroll
-        for (int j = 0; j < NJ; j++)
-#pragma unroll
-            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
+    const int dy0 = a.cls_dy0[0], dx0 = a.cls_dx0[0];
+    unsigned char* base = smem + 4096;  // (front: the epilogue's row sums [TH][BNT][2] fp32)
+    // tiles of this block: logical ids j * G + chunk(blockIdx) -- within a round of G blocks every XCD (blocks b, b + 8, ... share one)
+    // gets a contiguous range of tiles (its L2 holds the halo rows and the panels they share)
+    const int G = gridDim.x;
+    const int bid = blockIdx.x;
+    const int chunked = (G & 7) == 0 ? (bid & 7) * (G >> 3) + (bid >> 3) : xcd_remap(bid, G);
+    const int my_tiles = chunked < a.total ? (a.total - 1 - chunked) / G + 1 : 0;
+    const int S = my_tiles * nslab;  // stages of this block
+    struct Tile {
+        int b, ty, tx, n0, row;
+    };
+    auto tile_of = [&](int j) {
+        int t = j * G + chunked;
+        Tile T;
+        const int nt = t % a.n_nt;
+        t /= a.n_nt;
+        T.tx = t % a.tiles_x;
+        t /= a.tiles_x;
+        T.ty = t % a.tiles_y;
+        T.b = t / a.tiles_y;
+        T.n0 = nt * BNT;
+        T.row = (T.b * a.tiles_y + T.ty) * a.tiles_x + T.tx;
+        return T;
+    };
+    auto barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    if (S == 0) return;
 
     if (loader) {
         const int tid = tid_all - 256;
         const int cx = tid % CPP, p0 = tid / CPP;
         constexpr bool pro = PRO;  // (a template parameter: a run-time branch around the prologue's loads makes hipcc's s_waitcnt insertion
                                    // drain ALL loads in front of the first LDS store of a stage -- measured: loads and stores then add up)
-        const int aff_off = b * d.in_affine_batch_stride;
-        const unsigned char* xbase = (const unsigned char*)a.x + (long)b * d.hi * d.wi * d.x_pix_stride * (X3 ? 4 : 2);
         const unsigned short* wg = (const unsigned short*)a.w;
         const int kgroups_total = a.ci_pad >> 3;
         const long plane_elems = (long)d.w_taps * kgroups_total * a.co_pad * 8;
-        // per-thread constants of the tile chunks: element offset of the pixel (channel 0 of the tensor's channel slice), validity, LDS byte
-        int x_off[XB], x_lds[XB];
-        unsigned xmask = 0u;
+        const int w_slab = K8 * a.co_pad * 8;  // elements between consecutive slabs of one tap
+        // tile-independent per-thread constants: LDS byte of every tile chunk; weight chunk q = (window position g, plane, 8-channel
+        // group c8, output channel n) in LDS order -> element offset at n0 = 0 and the chunk's output channel
+        int x_lds[XB], w_off[WB], w_n[WB];
 #pragma unroll
         for (int u = 0; u < XB; u++) {
             const int pix = p0 + u * PSTEP;
-            const int ly = pix / IN_W, lx = pix - ly * IN_W;
-            const int iy = iy0 + ly, ix = ix0 + lx;
-            const bool ok = pix < NPIX && (unsigned)iy < (unsigned)d.hi && (unsigned)ix < (unsigned)d.wi;
-            xmask |= ok ? (1u << u) : 0u;
-            x_off[u] = ok ? (iy * d.wi + ix) * d.x_pix_stride + cx * CHN : 0;
             x_lds[u] = pix < NPIX ? pix * PS + cx * (X3 ? 8 : 16) : -1;
         }
-        // ... and of the weight chunks: chunk q = (window position g, plane, 8-channel group c8, output channel n) in LDS order
-        int w_off[WB];
-        unsigned wmask = 0u;   // bit u: the chunk exists (inside the stage and the padded filter range)
 #pragma unroll
         for (int u = 0; u < WB; u++) {
             const int q = tid + u * 256;
             const int panel = q / PSZ, inner = q % PSZ;
             const int g = panel / PLANES, plane = panel % PLANES;
             const int c8 = inner / BNT, n = inner % BNT;
-            const bool ok = q < WCH && n0 + n < a.co_pad;
-            wmask |= ok ? (1u << u) : 0u;
-            const int tw = (int)((a.roles_tapw >> (4 * g)) & 15ull);  // (a packed word: indexing a kernel-argument array by a register goes through scratch)
-            w_off[u] = ok ? (int)(plane * plane_elems) + ((tw * kgroups_total + c8) * a.co_pad + n0 + n) * 8 : 0;
+            const bool ok = q < WCH;
+            const int tw = (int)((a.roles_tapw >> (4 * (ok ? g : 0))) & 15ull);  // (a packed word: indexing a kernel-argument array by a register goes through scratch)
+            w_off[u] = ok ? (int)(plane * plane_elems) + ((tw * kgroups_total + c8) * a.co_pad + n) * 8 : 0;
+            w_n[u] = ok ? n : (1 << 30);
         }
-        const int w_slab = K8 * a.co_pad * 8;  // elements between consecutive slabs of one tap
-        const int last = nslab - 1;
+        // the ISSUE stream's position and the per-tile constants of its tile
+        int is_tile = 0, is_slab = 0;
+        int x_off[XB];
+        unsigned xmask = 0u, wmask = 0u;
+        int n0e = 0, aff_off = 0;
+        const unsigned char* xbase = nullptr;
+        auto enter_tile = [&](int j) {
+            const Tile T = tile_of(j);
+            const int iy0 = T.ty * TH + dy0, ix0 = T.tx * 32 + dx0;
+            xbase = (const unsigned char*)a.x + (long)T.b * d.hi * d.wi * d.x_pix_stride * (X3 ? 4 : 2);
+            aff_off = T.b * d.in_affine_batch_stride;
+            n0e = T.n0 * 8;
+            xmask = 0u;
+            wmask = 0u;
+#pragma unroll
+            for (int u = 0; u < XB; u++) {
+                const int pix = p0 + u * PSTEP;
+                const int ly = pix / IN_W, lx = pix - ly * IN_W;
+                const int iy = iy0 + ly, ix = ix0 + lx;
+                const bool ok = pix < NPIX && (unsigned)iy < (unsigned)d.hi && (unsigned)ix < (unsigned)d.wi;
+                xmask |= ok ? (1u << u) : 0u;
+                x_off[u] = ok ? (iy * d.wi + ix) * d.x_pix_stride + cx * CHN : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < WB; u++) wmask |= (T.n0 + w_n[u] < a.co_pad) ? (1u << u) : 0u;
+        };
+        enter_tile(0);
 
         struct Regs {
             uint4 x[XB];
             uint4 w[WB];
             float sc[CHN], sh[CHN];
-        };
-        // The loads of one stage and the conversion + LDS stores of the previous one are INTERLEAVED chunk by chunk (step()): round-5
-        // stamps showed the loader waves 3 200 cycles per slab in the issue of 18 loads (the vector-memory pipe is full: ~23 B / clk / CU
-        // from L2) and then 1 700 in the stores -- one after the other they held the MFMA waves at the barrier a third of the time.
-        // Loads are nothing but loads (no select on a loaded value: that would wait for it right there) from addresses that always exist;
-        // what must be zero is zeroed when it is stored.  Slabs beyond the last one are clamped: the loop body has no branch around a
-        // load, so hipcc's s_waitcnt insertion counts the younger stage's loads instead of draining everything.
-        struct Ctx {
-            int c0, cadd, kadd, cc;
+            unsigned xmask, wmask;  // of the stage these registers hold (the issue stream may already be in the next tile)
             bool ch_ok;
         };
-        auto ctx_of = [&](int slab_req) {
+        // Loads are nothing but loads (no select on a loaded value: that would wait for it right there) from addresses that always exist;
+        // what must be zero is zeroed when it is stored.  Beyond the last stage the stream stays where it is (redundant loads): the loop
+        // body has no branch around a load, so hipcc's s_waitcnt insertion counts the younger stage's loads instead of draining everything.
+        struct Ctx {
+            int cadd, kadd, cc;
+        };
+        auto begin_stage = [&](Regs& R) {
             Ctx c;
-            const int slab = slab_req < last ? slab_req : last;
-            c.c0 = slab * CS;
-            const int chx = c.c0 + cx * CHN;
-            c.ch_ok = chx < d.ci;
-            c.cadd = c.ch_ok ? c.c0 : 0;  // (a channel chunk beyond ci: any readable address, zeroed when stored)
-            c.kadd = slab * w_slab;       // (bf16 layers take this kernel only when ci is a multiple of the 32-channel slab)
-            c.cc = c.ch_ok ? aff_off + chx : 0;
+            const int c0 = is_slab * CS;
+            const int chx = c0 + cx * CHN;
+            R.ch_ok = chx < d.ci;
+            R.xmask = xmask;
+            R.wmask = wmask;
+            c.cadd = R.ch_ok ? c0 : -1;       // (a channel chunk beyond ci: the tensor's first bytes, zeroed when stored)
+            c.kadd = is_slab * w_slab + n0e;  // (bf16 layers take this kernel only when ci is a multiple of the 32-channel slab)
+            c.cc = R.ch_ok ? aff_off + chx : 0;
             return c;
         };
+        auto advance = [&]() {  // (VALU only: no memory operation inside the branch)
+            if (is_slab + 1 < nslab) {
+                is_slab++;
+            } else if (is_tile + 1 < my_tiles) {
+                is_tile++;
+                is_slab = 0;
+                enter_tile(is_tile);
+            }
+        };
         auto load_w1 = [&](const Ctx& c, Regs& R, int u) {
-            // (non-temporal loads of the panels -- so that the tile's 128-B lines, asked for in two 64-B halves by consecutive fp32 slabs,
-            // survive in the vector L1 -- measured: no change)
             R.w[u] = *reinterpret_cast<const uint4*>(wg + w_off[u] + (((wmask >> u) & 1u) ? c.kadd : 0));
         };
         auto load_x1 = [&](const Ctx& c, Regs& R, int u) {
-            R.x[u] = *reinterpret_cast<const uint4*>(xbase + (long)(x_off[u] + (((xmask >> u) & 1u) ? c.cadd : 0)) * (X3 ? 4 : 2));
+            const bool ok = ((xmask >> u) & 1u) && c.cadd >= 0;
+            R.x[u] = *reinterpret_cast<const uint4*>(xbase + (long)(ok ? x_off[u] + c.cadd : 0) * (X3 ? 4 : 2));
         };
         auto load_aff = [&](const Ctx& c, Regs& R) {
             if constexpr (pro) {
@@ -733,11 +835,11 @@ __global__ __launch_bounds__(512, 1) void conv_roles_kernel(const liso_conv_desc
         };
         auto store_w1 = [&](const Regs& R, unsigned char* buf, int u) {
             const int q = tid + u * 256;
-            if (q < WCH) *reinterpret_cast<uint4*>(buf + XPLANE * PLANES + q * 16) = ((wmask >> u) & 1u) ? R.w[u] : make_uint4(0u, 0u, 0u, 0u);
+            if (q < WCH) *reinterpret_cast<uint4*>(buf + XPLANE * PLANES + q * 16) = ((R.wmask >> u) & 1u) ? R.w[u] : make_uint4(0u, 0u, 0u, 0u);
         };
-        auto store_x1 = [&](const Ctx& c, const Regs& R, unsigned char* xs, int u) {
+        auto store_x1 = [&](const Regs& R, unsigned char* xs, int u) {
             if (x_lds[u] < 0) return;
-            const bool ok = ((xmask >> u) & 1u) && c.ch_ok;
+            const bool ok = ((R.xmask >> u) & 1u) && R.ch_ok;
             if constexpr (!X3) {
                 uint4 o = R.x[u];
                 if constexpr (pro) {
@@ -777,43 +879,39 @@ __global__ __launch_bounds__(512, 1) void conv_roles_kernel(const liso_conv_desc
                 *reinterpret_cast<uint2*>(xs + XPLANE + x_lds[u]) = make_uint2(lo2[0], lo2[1]);
             }
         };
-        auto issue = [&](int slab_req, Regs& R) {
-            const Ctx c = ctx_of(slab_req);
+        auto issue = [&](Regs& R) {  // the loads of the stream's current stage -> R; the stream moves on
+            const Ctx c = begin_stage(R);
 #pragma unroll
             for (int u = 0; u < XB; u++) load_x1(c, R, u);
             load_aff(c, R);
 #pragma unroll
             for (int u = 0; u < WB; u++) load_w1(c, R, u);
+            advance();
         };
-        auto store = [&](int slab, const Regs& R, unsigned char* buf) {
-            const Ctx c = ctx_of(slab);
+        auto store = [&](const Regs& R, unsigned char* buf) {
 #pragma unroll
-            for (int u = 0; u < XB; u++) store_x1(c, R, buf, u);
+            for (int u = 0; u < XB; u++) store_x1(R, buf, u);
 #pragma unroll
             for (int u = 0; u < WB; u++) store_w1(R, buf, u);
         };
-        // loads of slab `next` -> RN, registers RC (slab `cur`) -> buf; do_store = false: loads only
-        auto step = [&](int next, Regs& RN, int cur, const Regs& RC, unsigned char* buf, bool do_store) {
-            const Ctx cn = ctx_of(next), cc = ctx_of(cur);
-            constexpr int NMAX = XB > WB ? XB : WB;
+        // loads of the stream's current stage -> RN interleaved with: registers RC -> buf (do_store = false: loads only)
+        auto step = [&](Regs& RN, const Regs& RC, unsigned char* buf, bool do_store) {
+            const Ctx cn = begin_stage(RN);
 #pragma unroll
             for (int u = 0; u < XB; u++) {
                 load_x1(cn, RN, u);
                 if (u == 0) load_aff(cn, RN);
-                if (do_store) store_x1(cc, RC, buf, u);
+                if (do_store) store_x1(RC, buf, u);
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
-            for (int u = 0; u < NMAX; u++) {
-                if (u < WB) {
-                    load_w1(cn, RN, u);
-                    if (do_store) store_w1(RC, buf, u);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+            for (int u = 0; u < WB; u++) {
+                load_w1(cn, RN, u);
+                if (do_store) store_w1(RC, buf, u);
+                __builtin_amdgcn_sched_barrier(0);
             }
+            advance();
         };
-        // raw barrier: the LDS stores have landed (lgkmcnt), the vector-memory loads of the next stage stay in flight
-        auto barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
 #ifdef LISO_ROLES_STAMPS
         unsigned long long st_issue = 0, st_store = 0, st_bar = 0, st_t;
@@ -825,28 +923,29 @@ __global__ __launch_bounds__(512, 1) void conv_roles_kernel(const liso_conv_desc
 #define STAMP_END(acc)
 #endif
         Regs RA, RB;
-        issue(0, RA);
-        issue(1, RB);
-        store(0, RA, base);
+        issue(RA);  // stage 0
+        issue(RB);  // stage 1 (or stage 0 again)
+        store(RA, base);
         barrier();  // buffer 0 is ready
 #ifdef LISO_ROLES_STAMPS
         const unsigned long long st_k1 = __builtin_amdgcn_s_memtime();
 #endif
-        // iteration k: the MFMA waves multiply buffer k & 1; here: loads of slab k + 2 -> the register set that was just stored,
-        // registers of slab k + 1 -> buffer (k + 1) & 1 (its readers finished before the previous barrier).  nslab barriers in all.
+        // iteration k: the MFMA waves multiply buffer k & 1; here: loads of stage k + 2 -> the register set that was just stored,
+        // registers of stage k + 1 -> buffer (k + 1) & 1 (its readers finished before the previous barrier).  S barriers in all.
         int k = 0;
-        for (; k + 1 < nslab; k += 2) {
+        for (; k + 1 < S; k += 2) {
             STAMP_BEGIN
-            step(k + 2, RA, k + 1, RB, base + BUF, true);
+            step(RA, RB, base + BUF, true);
             STAMP_END(st_issue)
             barrier();
             STAMP_END(st_bar)
-            step(k + 3, RB, k + 2, RA, base, k + 2 < nslab);
+            step(RB, RA, base, k + 2 < S);
             STAMP_END(st_store)
             barrier();
             STAMP_END(st_bar)
         }
-        if (k < nslab) barrier();  // (odd slab count: the last multiplication)
+        if (k < S) barrier();  // (odd stage count: the last multiplication)
+        if (a.stats) barrier();  // (the MFMA waves' last statistics rows: roles_flush_stats)
 #ifdef LISO_ROLES_STAMPS
         if (a.stats && tid == 0) {
             unsigned long long* o = reinterpret_cast<unsigned long long*>(a.stats) + (size_t)blockIdx.x * 16 + 8;
@@ -858,11 +957,11 @@ __global__ __launch_bounds__(512, 1) void conv_roles_kernel(const liso_conv_desc
 #pragma unroll
         for (int i = 0; i < MI; i++) a_off[i] = ((wave * MI + i) * IN_W + r) * PS + h * 16;
         const int b_off = XPLANE * PLANES + (h * BNT + r) * 16;
-        auto barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
         struct Frag {
             uint4 ah[KS][MI], bh[KS][NJ];
             uint4 al[X3 ? KS : 1][X3 ? MI : 1], bl[X3 ? KS : 1][X3 ? NJ : 1];
         };
+        f16v acc[MI][NJ];
         auto read = [&](const unsigned char* buf, int tap, Frag& F) {
             const int toff = ((tap / KW) * IN_W + (tap % KW)) * PS;
             const int woff = tap * PLANES * WTAP;
@@ -895,57 +994,79 @@ __global__ __launch_bounds__(512, 1) void conv_roles_kernel(const liso_conv_desc
                     }
         };
 #ifdef LISO_ROLES_STAMPS
-        unsigned long long st_mul = 0, st_bar = 0, st_t;
+        unsigned long long st_mul = 0, st_bar = 0, st_epi = 0, st_t;
         const unsigned long long st_k0 = __builtin_amdgcn_s_memtime();
 #endif
         barrier();  // buffer 0 is ready
 #ifdef LISO_ROLES_STAMPS
         const unsigned long long st_k1 = __builtin_amdgcn_s_memtime();
 #endif
-        __builtin_amdgcn_s_setprio(2);  // the loader waves' vector instructions fill the MFMA shadows, never the other way round
-        for (int k = 0; k < nslab; k++) {
-            const unsigned char* buf = base + (k & 1) * BUF;
-            // fragments of tap t + 1 are requested before the MFMAs of tap t issue (the scheduling barriers keep hipcc from sinking the
-            // reads to their first use: it then waits for each group right after asking for it)
-            Frag F0, F1;
-            STAMP_BEGIN
-            read(buf, 0, F0);
+        int k = 0;  // stage counter of the block
+        for (int j = 0; j < my_tiles; j++) {
 #pragma unroll
-            for (int tp = 0; tp < NTAPS; tp += 2) {
-                if (tp + 1 < NTAPS) read(buf, tp + 1, F1);
-                __builtin_amdgcn_sched_barrier(0);
-                mul(F0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (tp + 1 < NTAPS) {
-                    if (tp + 2 < NTAPS) read(buf, tp + 2, F0);
+            for (int i = 0; i < MI; i++)
+#pragma unroll
+                for (int jj = 0; jj < NJ; jj++)
+#pragma unroll
+                    for (int e = 0; e < 16; e++) acc[i][jj][e] = 0.0f;
+            __builtin_amdgcn_s_setprio(2);  // the loader waves' vector instructions fill the MFMA shadows, never the other way round
+            for (int sl = 0; sl < nslab; sl++, k++) {
+                const unsigned char* buf = base + (k & 1) * BUF;
+                // fragments of tap t + 1 are requested before the MFMAs of tap t issue (the scheduling barriers keep hipcc from sinking
+                // the reads to their first use: it then waits for each group right after asking for it)
+                Frag F0, F1;
+                STAMP_BEGIN
+                read(buf, 0, F0);
+#pragma unroll
+                for (int tp = 0; tp < NTAPS; tp += 2) {
+                    if (tp + 1 < NTAPS) read(buf, tp + 1, F1);
                     __builtin_amdgcn_sched_barrier(0);
-                    mul(F1);
+                    mul(F0);
                     __builtin_amdgcn_sched_barrier(0);
+                    if (tp + 1 < NTAPS) {
+                        if (tp + 2 < NTAPS) read(buf, tp + 2, F0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        mul(F1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
+                STAMP_END(st_mul)
+                barrier();
+                STAMP_END(st_bar)
+#ifndef LISO_ROLES_STAMPS
+                if (sl == 0 && j > 0 && a.stats) {  // the previous tile's row sums are complete in LDS (written before this barrier)
+                    const Tile P = tile_of(j - 1);
+                    roles_flush_stats<MI, NJ>(a, P.b, P.ty, P.tx, P.n0, tid_all, smem);
+                }
+#endif
             }
-            STAMP_END(st_mul)
-            barrier();
-            STAMP_END(st_bar)
+            __builtin_amdgcn_s_setprio(0);
+            const Tile T = tile_of(j);
+#ifdef LISO_ROLES_STAMPS
+            FwdArgs a2 = a;
+            a2.stats = nullptr;
+            conv_epilogue<MI, NJ, OUT_F32, true>(d, a2, acc, 0, T.b, T.tx, T.ty, wave, r, h, true, T.n0, T.row, tid_all, smem);
+            STAMP_END(st_epi)
+#else
+            conv_epilogue<MI, NJ, OUT_F32, true>(d, a, acc, 0, T.b, T.tx, T.ty, wave, r, h, true, T.n0, T.row, tid_all, smem);
+#endif
         }
-        __builtin_amdgcn_s_setprio(0);
+#ifndef LISO_ROLES_STAMPS
+        if (a.stats) {
+            barrier();
+            const Tile P = tile_of(my_tiles - 1);
+            roles_flush_stats<MI, NJ>(a, P.b, P.ty, P.tx, P.n0, tid_all, smem);
+        }
+#else
+        if (a.stats) barrier();
+#endif
 #ifdef LISO_ROLES_STAMPS
         if (a.stats && tid_all == 0) {
             unsigned long long* o = reinterpret_cast<unsigned long long*>(a.stats) + (size_t)blockIdx.x * 16;
-            o[0] = st_k1 - st_k0; o[1] = st_mul; o[2] = st_bar; o[3] = __builtin_amdgcn_s_memtime() - st_k0;
+            o[0] = st_k1 - st_k0; o[1] = st_mul; o[2] = st_bar; o[3] = __builtin_amdgcn_s_memtime() - st_k0; o[4] = st_epi;
         }
 #endif
     }
-#ifdef LISO_ROLES_STAMPS
-    FwdArgs a2 = a;
-    a2.stats = nullptr;
-    __syncthreads();
-    const unsigned long long st_e0 = __builtin_amdgcn_s_memtime();
-    conv_epilogue<MI, NJ, OUT_F32>(d, a2, acc, 0, b, tx, ty, wave, r, h, !loader, n0, stats_row, tid_all, smem);
-    if (a.stats && tid_all == 0) reinterpret_cast<unsigned long long*>(a.stats)[(size_t)blockIdx.x * 16 + 4] = __builtin_amdgcn_s_memtime() - st_e0;
-    return;
-#endif
-    __syncthreads();
-    conv_epilogue<MI, NJ, OUT_F32>(d, a, acc, 0, b, tx, ty, wave, r, h, !loader, n0, stats_row, tid_all, smem);
 }
 
 // ---- 8 waves, weight panels by LDS-DMA ------------------------------------------------------------------------------------------------
@@ -1585,10 +1706,10 @@ void plan_roles(const liso_conv_desc& d, Plan* p) {
     }
     if (seen != 0x1ff) return;
     const int cs = x3 ? 16 : 32, ks = cs / 16, nslab = (d.ci + cs - 1) / cs;
-    // shallow layers (a block's prologue and epilogue are not overlapped with anything at one block per CU): measured round 5,
-    // 32 -> 32 at 8 x 256^2 F32X3: 76 vs 67 us, bf16 64 -> 64 at 2 x 256^2: 27 vs 25 us; from 4 slabs on this kernel is ahead
-    static const int min_slabs = getenv("LISO_ROLES_MIN_SLABS") ? atoi(getenv("LISO_ROLES_MIN_SLABS")) : 4;
-    if (nslab < min_slabs) return;
+    // (round 5, before the blocks became persistent: shallow layers -- 2 slabs -- lost to conv_igemm_kernel, 76 vs 67 us on 32 -> 32 at
+    // 8 x 256^2; with the next tile staged under the epilogue: 58 vs 65 us.  LISO_ROLES_MIN_SLABS: experiments)
+    static const int min_slabs = getenv("LISO_ROLES_MIN_SLABS") ? atoi(getenv("LISO_ROLES_MIN_SLABS")) : 1;
+    if (nslab < min_slabs || nslab < 2) return;  // (one slab per tile: the deferred statistics flush would race with the next epilogue)
     static const int force_mi = getenv("LISO_ROLES_MI") ? atoi(getenv("LISO_ROLES_MI")) : 0;
     static const int force_nj = getenv("LISO_ROLES_NJ") ? atoi(getenv("LISO_ROLES_NJ")) : 0;
     double best = 1e300;
@@ -1625,7 +1746,7 @@ void plan_roles(const liso_conv_desc& d, Plan* p) {
     a.total = d.batch * a.tiles_y * a.tiles_x * a.n_nt;
     const int planes = x3 ? 2 : 1;
     const int buf = ((th + 2) * 34 * (cs * 2 + 16) * planes + 9 * planes * (cs / 8) * bnt * 16 + 15) / 16 * 16;
-    p->lds = 512 + 2 * buf;
+    p->lds = 4096 + 2 * buf;
 }
 
 bool make_plan(const liso_conv_desc& d, Plan* p) {
@@ -1866,7 +1987,15 @@ int launch_roles_pro(const liso_conv_desc& d, const Plan& p, hipStream_t st) {
             return LISO_ELAUNCH;
         attr_set = true;
     }
-    conv_roles_kernel<MODE, MI, NJ, OUT_F32, NTAPS, PRO><<<p.a.total, 512, p.lds, st>>>(d, p.a);
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return LISO_ELAUNCH;
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const int grid = p.a.total < n_cu ? p.a.total : n_cu;
+    conv_roles_kernel<MODE, MI, NJ, OUT_F32, NTAPS, PRO><<<grid, 512, p.lds, st>>>(d, p.a);
     return check_launch();
 }
 template <int MODE, int MI, int NJ, bool OUT_F32, int NTAPS>
@@ -1943,7 +2072,7 @@ int liso_conv_pack_weights_batched(const liso_conv_pack_job* jobs, int n_jobs, v
 int liso_conv_stats_rows(const liso_conv_desc* d) {
     Plan p;
     if (!d || !make_plan(*d, &p)) return -1;
-    return d->n_classes * d->batch * p.a.tiles_y * p.a.tiles_x;
+    return d->n_classes * d->batch * p.a.tiles_y * p.a.tiles_x * (p.a.roles ? p.mi : 1);  // (conv_roles_kernel: one row per 4 x 32 pixels)
 }
 
 int liso_conv_forward(const liso_conv_desc* d, const void* x, const void* w_packed, const float* bias, const float* in_scale,
