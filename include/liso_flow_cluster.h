@@ -86,6 +86,15 @@ int liso_dbscan_labels(const liso_dbscan_cfg* cfg, const uint8_t* dynamic_mask, 
 int liso_region_props(const int32_t* labels, int batch, int gx, int gy, int max_labels, uint64_t* moments, double* props,
                       void* stream);
 
+/* The same results (bit for bit: the moments are integers) without global atomics: per-block sums in LDS, written to
+ * workspace[batch][blocks][max_labels][6] and added per region by a second launch.  For label maps whose labelled cells are scattered
+ * over the grid (round 5: 4 306 labelled pillars of an untrained flow network's output in 30 clusters -> 75 us through the atomics of
+ * liso_region_props, 26 k of them on 180 addresses; here ~10 us).  0 bytes from the query (more than 1024 labels): the call forwards to
+ * liso_region_props. */
+size_t liso_region_props_workspace_bytes(int batch, int gx, int gy, int max_labels);
+int liso_region_props_ws(const int32_t* labels, int batch, int gx, int gy, int max_labels, uint64_t* moments, double* props,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -48,6 +48,17 @@ int liso_kabsch_trafos_f32(const liso_kabsch_cfg* cfg, const float* points, cons
                            const float* box_pos, const float* box_dims, const float* box_rot, double* trafos,
                            float* cum_wts, float* fg_weights, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same for callers with a FIXED number of slots of which only the first slot_count[b] (int32 [B], device) hold boxes (the LISO
+ * loop's box mining: 64 slots, 15-30 boxes; the other slots are parked where their soft mask is 0 in fp32).  The parked slots are not
+ * evaluated -- 7.7 M box-mask evaluations (3 atan each) per 120k-point cloud at 64 slots, the kernel is bound by them -- and the lanes
+ * are re-dealt over the boxes that exist.  Every output is what liso_kabsch_trafos_f32 gives for the parked arrangement (a parked slot
+ * is a factor of exactly 1 in the background product and its moments fall under the 1e-12 rule above), except fg_weights of parked
+ * slots: exact zeros instead of ~1e-23.  slot_count == NULL: all n_slots slots hold boxes. */
+int liso_kabsch_trafos_counted_f32(const liso_kabsch_cfg* cfg, const float* points, const uint8_t* valid, const float* flow,
+                                   const float* box_pos, const float* box_dims, const float* box_rot, const int32_t* slot_count,
+                                   double* trafos, float* cum_wts, float* fg_weights, void* workspace, size_t workspace_bytes,
+                                   void* stream);
+
 /* SymmetricOrthogonalization.forward for n 3x3 matrices (row-major fp64): R = U Vh; U, Vh, D are saved for backward. */
 int liso_symm_ortho_fwd_f64(const double* a, int n, double* r, double* u, double* vh, double* d, void* stream);
 

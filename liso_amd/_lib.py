@@ -89,6 +89,7 @@ SIGNATURES = {
     # include/liso_kabsch.h
     "liso_kabsch_workspace_bytes": (_sz, [_vp]),
     "liso_kabsch_trafos_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "liso_kabsch_trafos_counted_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "liso_symm_ortho_fwd_f64": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "liso_symm_ortho_bwd_f64": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "liso_weighted_moments_workspace_bytes": (_sz, [_i]),
@@ -103,6 +104,8 @@ SIGNATURES = {
     "liso_dbscan_components": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "liso_dbscan_labels": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "liso_region_props": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "liso_region_props_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "liso_region_props_ws": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     # include/liso_slim.h
     "liso_corr_lookup_fwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "liso_corr_lookup_bwd_dvol_f32": (_i, [_vp, _vp, _vp, _vp, _vp]),

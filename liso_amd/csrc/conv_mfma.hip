@@ -61,6 +61,7 @@ struct FwdArgs {
     int ring;           // a8: weight stages resident in LDS (2..4): stage s + ring - 1 is in flight while stage s is multiplied
     int dbg;            // experiments (LISO_CONV_DBG): 1 = no MFMAs, 2 = no weight DMA, 4 = no tile loads (results are garbage)
     int roles;          // conv_roles_kernel (loader waves + MFMA waves, double-buffered LDS): 3x3 / 1x1, stride 1, one class
+    int wide_out;       // roles: 16-byte output stores through an LDS patch (channel count and strides allow them)
     unsigned long long roles_tapw;  // roles: 4 bits per window position (ty * 3 + tx): the tap's index inside the packed weights
 };
 
@@ -650,6 +651,105 @@ __device__ __forceinline__ void roles_flush_stats(const FwdArgs& a, int b, int t
     }
 }
 
+// Epilogue of conv_roles_kernel with WIDE stores: the 32 x 32 MFMA tile layout (lane = output channel, register = pixel) gives one
+// dword (fp32) or one channel pair (bf16) per lane and store instruction -- 16 / 8 store instructions per tile, and the s_memtime stamps
+// of round 5 showed the epilogue at 10-15 k cycles per tile, more than the multiplications of a shallow layer.  Here every wave turns its
+// tile round through a private 2-KB LDS patch, 16 pixels at a time ([pixel][32 channels], written as it lies in the registers, read back
+// as 16 bytes per lane): 4 (fp32) or 2 (bf16) 16-byte store instructions per tile, whole 128-B / 64-B runs per pixel.  No barrier: a wave
+// only reads what it wrote.  Bias, ReLU, rounding and the statistics sums (pairwise per lane, one LDS row per 32-pixel tile row: see
+// roles_flush_stats) as in conv_epilogue.  `wide` false (channel counts / strides that do not allow 16-byte stores): conv_epilogue.
+template <int MI, int NJ, bool OUT_F32>
+__device__ __forceinline__ void roles_epilogue(const liso_conv_desc& d, const FwdArgs& a, f16v (&acc)[MI][NJ], int b, int tx, int ty, int wave,
+                                               int lane, int n0, unsigned char* smem, unsigned char* patch) {
+    constexpr int BNT = 32 * NJ;
+    constexpr int TH = 4 * MI;
+    const int r = lane & 31, h = lane >> 5;
+    const bool want_stats = a.stats != nullptr;
+    const int ooy = d.class_ooy[0], oox = d.class_oox[0];
+    float* red = reinterpret_cast<float*>(smem);
+    constexpr int ROWB = OUT_F32 ? 128 : 64;   // bytes of one pixel's 32 channels in the patch
+    constexpr int CPR = ROWB / 16;             // 16-byte chunks per pixel
+    constexpr int PPI = 64 / CPR;              // pixels one store instruction covers (8 | 16)
+    constexpr int ES = OUT_F32 ? 4 : 2;
+#pragma unroll
+    for (int i = 0; i < MI; i++) {
+        const int vy = ty * TH + wave * MI + i;
+        const int oy = vy + ooy;
+        const bool row_ok = vy < d.hv && oy < d.ho;
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            const int n = n0 + j * 32 + r;
+            const bool n_ok = n < d.co;
+            const float bias_v = (a.bias && n_ok) ? a.bias[n] : 0.0f;
+            const float shift_v = (a.stats_shift && n_ok) ? a.stats_shift[n] : 0.0f;
+            float v[16], q1[16], q2[16];
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                float val = acc[i][j][e] + bias_v;
+                if (d.out_relu) val = fmaxf(val, 0.0f);
+                if constexpr (!OUT_F32) val = round_bf16(val);
+                v[e] = val;
+                const int vx = tx * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                const float dd = (row_ok && vx < d.wv && vx + oox < d.wo) ? val - shift_v : 0.0f;
+                q1[e] = dd;
+                q2[e] = dd * dd;
+            }
+            if (want_stats) {
+#pragma unroll
+                for (int w = 8; w >= 1; w >>= 1)
+#pragma unroll
+                    for (int e = 0; e < w; e++) {
+                        q1[e] += q1[e + w];
+                        q2[e] += q2[e + w];
+                    }
+                const float t1 = q1[0] + __shfl_xor(q1[0], 32), t2 = q2[0] + __shfl_xor(q2[0], 32);
+                if (h == 0) {
+                    red[((wave * MI + i) * BNT + j * 32 + r) * 2 + 0] = t1;
+                    red[((wave * MI + i) * BNT + j * 32 + r) * 2 + 1] = t2;
+                }
+            }
+            // two halves of 16 pixels: registers e with (e >> 3) == half hold pixel columns 16 half + (e & 3) + 8 ((e >> 2) & 1) + 4 h
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                if constexpr (OUT_F32) {
+#pragma unroll
+                    for (int e8 = 0; e8 < 8; e8++) {
+                        const int px = (e8 & 3) + 8 * (e8 >> 2) + 4 * h;
+                        *reinterpret_cast<float*>(patch + px * ROWB + r * 4) = v[half * 8 + e8];
+                    }
+                } else {
+                    // neighbouring lanes exchange one value per register pair (DPP quad_perm 1,0,3,2): even lanes keep the pixel of
+                    // register e, odd lanes that of e + 1, both as the channel pair (r & ~1, r | 1)
+                    const bool odd = r & 1;
+#pragma unroll
+                    for (int e8 = 0; e8 < 8; e8 += 2) {
+                        const int e = half * 8 + e8;
+                        const float send = odd ? v[e] : v[e + 1];
+                        const float recv = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(send), 0xB1, 0xF, 0xF, true));
+                        const float c_lo = odd ? recv : v[e], c_hi = odd ? v[e + 1] : recv;
+                        const int ee = odd ? e8 + 1 : e8;
+                        const int px = (ee & 3) + 8 * (ee >> 2) + 4 * h;
+                        *reinterpret_cast<unsigned*>(patch + px * ROWB + (r >> 1) * 4) = pack_bf16(c_lo, c_hi);
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int q = 0; q < 16 / PPI; q++) {
+                    const int px = q * PPI + lane / CPR, ck = lane % CPR;
+                    const uint4 val = *reinterpret_cast<const uint4*>(patch + px * ROWB + ck * 16);
+                    const int vx = tx * 32 + half * 16 + px;
+                    const int ch = n0 + j * 32 + ck * (16 / ES);
+                    if (row_ok && vx < d.wv && vx + oox < d.wo && ch < d.co) {
+                        const long off = (((long)b * d.ho + oy) * d.wo + vx + oox) * d.y_pix_stride + d.y_ch_off + ch;
+                        *reinterpret_cast<uint4*>((unsigned char*)a.y + off * ES) = val;
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the patch is rewritten by the next half)
+            }
+        }
+    }
+}
+
 // ---- loader waves + MFMA waves, double-buffered LDS, persistent blocks: 3x3 / stride 1 / one tap class -----------------------------------
 // Round-5 PMC of conv_igemm_kernel on the ConvGRU layer (304 -> 192 at 4 x 64 x 64, F32X3): waves parked at s_waitcnt / s_barrier
 // 47 % of their cycles, 7 150 non-MFMA vector instructions per wave beside 1 080 MFMAs (address arithmetic and the hi / lo split are
@@ -1048,7 +1148,10 @@ __global__ __launch_bounds__(512, 1) void conv_roles_kernel(const liso_conv_desc
             conv_epilogue<MI, NJ, OUT_F32, true>(d, a2, acc, 0, T.b, T.tx, T.ty, wave, r, h, true, T.n0, T.row, tid_all, smem);
             STAMP_END(st_epi)
 #else
-            conv_epilogue<MI, NJ, OUT_F32, true>(d, a, acc, 0, T.b, T.tx, T.ty, wave, r, h, true, T.n0, T.row, tid_all, smem);
+            if (a.wide_out)
+                roles_epilogue<MI, NJ, OUT_F32>(d, a, acc, T.b, T.tx, T.ty, wave, lane, T.n0, smem, base + 2 * BUF + wave * 2048);
+            else
+                conv_epilogue<MI, NJ, OUT_F32, true>(d, a, acc, 0, T.b, T.tx, T.ty, wave, r, h, true, T.n0, T.row, tid_all, smem);
 #endif
         }
 #ifndef LISO_ROLES_STAMPS
@@ -1746,7 +1849,11 @@ void plan_roles(const liso_conv_desc& d, Plan* p) {
     a.total = d.batch * a.tiles_y * a.tiles_x * a.n_nt;
     const int planes = x3 ? 2 : 1;
     const int buf = ((th + 2) * 34 * (cs * 2 + 16) * planes + 9 * planes * (cs / 8) * bnt * 16 + 15) / 16 * 16;
-    p->lds = 4096 + 2 * buf;
+    p->lds = 4096 + 2 * buf + 4 * 2048;  // (+ the epilogue's 2-KB patch per MFMA wave)
+    const bool of32 = x3 || d.out_f32;
+    const int cv = of32 ? 4 : 8;  // channels per 16-byte store
+    static const int wide_env = getenv("LISO_ROLES_WIDE") ? atoi(getenv("LISO_ROLES_WIDE")) : 1;
+    a.wide_out = (wide_env && d.co % cv == 0 && d.y_pix_stride % cv == 0 && d.y_ch_off % cv == 0) ? 1 : 0;
 }
 
 bool make_plan(const liso_conv_desc& d, Plan* p) {

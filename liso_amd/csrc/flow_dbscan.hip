@@ -25,6 +25,7 @@
 #include "zero_fill.h"
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/liso_flow_cluster.h"
 #include "../../include/liso_iou3d.h"
@@ -190,6 +191,134 @@ __global__ __launch_bounds__(256) void dbscan_union_kernel(Cfg c, const uint8_t*
     }
 }
 
+// ---- union-find in two levels: LDS inside a tile (+ halo), global atomics for one edge per cell ----------------------------------------
+// dbscan_union_kernel hooks every (core cell, smaller core eps-neighbour) pair with device-scope atomics on the global parent array: a
+// blob of 150 cells is ~10 000 hooks, each a chain of dependent L2 round trips (round-5 measurement on the bench's sweeps: 4 000 core
+// cells, 107 us).  Here a block owns a kTR x kTC tile: the core flags and flows of the tile and its eps halo go to LDS, every edge
+// (x in the tile, y in x's window, y < x) is hooked in an LDS parent array (values = per-sample cell indices, so local roots are the
+// smallest cell of the local component, the order the global forest uses), and then every core cell of the region is hooked ONCE in
+// the global array: with its local root.  Each eps edge lies inside the region of the tile that holds its larger end, so the global
+// forest connects exactly the components of the core graph; tiles without a core cell (almost all of them) leave after one load.
+constexpr int kTR = 16, kTC = 32, kUfThreads = 256, kMaxWin = 8;
+constexpr int kRegMax = (kTR + 2 * kMaxWin) * (kTC + 2 * kMaxWin);
+
+__device__ __forceinline__ int lds_find(const int* par, int l, int r0, int c0, int RW, int gy) {
+    // par[l] = per-sample cell index of the parent; a root points at itself
+    while (true) {
+        const int me = (r0 + l / RW) * gy + (c0 + l % RW);
+        const int p = par[l];
+        if (p == me) return l;
+        l = (p / gy - r0) * RW + (p % gy - c0);
+    }
+}
+
+__global__ __launch_bounds__(kUfThreads) void dbscan_union_tiled_kernel(Cfg c, const uint8_t* __restrict__ dyn,
+                                                                        const uint8_t* __restrict__ core, const float* __restrict__ xs,
+                                                                        const float* __restrict__ ys, const float* __restrict__ flow,
+                                                                        int* __restrict__ parent, int tiles_r, int tiles_c) {
+    __shared__ int s_par[kRegMax];
+    __shared__ float s_f[kRegMax][3];
+    __shared__ uint8_t s_core[kRegMax];
+    __shared__ int s_any;
+    const int b = blockIdx.y;
+    const int tr = blockIdx.x / tiles_c, tc = blockIdx.x % tiles_c;
+    const int tid = threadIdx.x;
+    const size_t per = (size_t)c.gx * c.gy, base = (size_t)b * per;
+    // does the TILE hold a core cell?
+    if (tid == 0) s_any = 0;
+    __syncthreads();
+    int any = 0;
+    for (int q = tid; q < kTR * kTC; q += kUfThreads) {
+        const int r = tr * kTR + q / kTC, col = tc * kTC + q % kTC;
+        if (r < c.gx && col < c.gy && core[base + (size_t)r * c.gy + col]) any = 1;
+    }
+    if (any) s_any = 1;
+    __syncthreads();
+    if (!s_any) return;
+    // region = tile + halo, clipped to the grid
+    const int r0 = max(tr * kTR - c.win, 0), r1 = min(tr * kTR + kTR + c.win, c.gx);
+    const int c0 = max(tc * kTC - c.win, 0), c1 = min(tc * kTC + kTC + c.win, c.gy);
+    const int RW = c1 - c0, RH = r1 - r0, RN = RW * RH;
+    for (int l = tid; l < RN; l += kUfThreads) {
+        const int r = r0 + l / RW, col = c0 + l % RW;
+        const size_t g = base + (size_t)r * c.gy + col;
+        const uint8_t co = core[g];
+        s_core[l] = co;
+        s_par[l] = r * c.gy + col;
+        if (co) {
+            s_f[l][0] = c.flow_weight * flow[3 * g + 0];
+            s_f[l][1] = c.flow_weight * flow[3 * g + 1];
+            s_f[l][2] = c.flow_weight * flow[3 * g + 2];
+        }
+    }
+    __syncthreads();
+    // local hooks: every core cell of the tile with its smaller core eps-neighbours.  The tile's core cells are listed first; a wave takes
+    // a cell at a time and its 64 lanes share the cell's window (the half with smaller indices: <= (2 win + 1) win + win cells)
+    __shared__ int s_list[kTR * kTC];
+    __shared__ int s_n;
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    for (int q = tid; q < kTR * kTC; q += kUfThreads) {
+        const int r = tr * kTR + q / kTC, col = tc * kTC + q % kTC;
+        if (r < c.gx && col < c.gy && s_core[(r - r0) * RW + (col - c0)]) s_list[atomicAdd(&s_n, 1)] = q;
+    }
+    __syncthreads();
+    const int n_list = s_n, lane = tid & 63, wave = tid >> 6;
+    const int ww = 2 * c.win + 1;
+    for (int e = wave; e < n_list; e += kUfThreads / 64) {
+        const int q = s_list[e];
+        const int r = tr * kTR + q / kTC, col = tc * kTC + q % kTC;
+        const int lx = (r - r0) * RW + (col - c0);
+        const int me = r * c.gy + col;
+        const double x0 = (double)xs[r], y0 = (double)ys[col];
+        const double f0 = (double)s_f[lx][0], f1 = (double)s_f[lx][1], f2 = (double)s_f[lx][2];
+        const int n_win = c.win * ww + c.win;  // window cells in front of the centre, row-major
+        for (int k = lane; k < n_win; k += 64) {
+            const int rr = r - c.win + k / ww, cc = col - c.win + k % ww;
+            if (rr < 0 || cc < 0 || cc >= c.gy) continue;  // (rr <= r < gx)
+            const int ly = (rr - r0) * RW + (cc - c0);
+            if (!s_core[ly]) continue;
+            // the 5-D distance exactly as dist_sqr builds it (fp32 features promoted to fp64, summed in feature order)
+            const double d0 = x0 - (double)xs[rr], d1 = y0 - (double)ys[cc];
+            const double d2 = f0 - (double)s_f[ly][0], d3 = f1 - (double)s_f[ly][1], d4 = f2 - (double)s_f[ly][2];
+            if (d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3 + d4 * d4 > c.eps_sqr) continue;
+            int a = lx, bq = ly;
+            while (true) {
+                a = lds_find(s_par, a, r0, c0, RW, c.gy);
+                bq = lds_find(s_par, bq, r0, c0, RW, c.gy);
+                if (a == bq) break;
+                const int ga = (r0 + a / RW) * c.gy + (c0 + a % RW), gb = (r0 + bq / RW) * c.gy + (c0 + bq % RW);
+                int hi = a, lo_g = gb, hi_g = ga;
+                if (ga < gb) { hi = bq; lo_g = ga; hi_g = gb; }
+                const int old = atomicMin(&s_par[hi], lo_g);  // the larger root under the smaller one
+                if (old == hi_g) break;                       // it was still a root: linked
+                a = hi;                                       // somebody re-parented it meanwhile: walk on from there
+                bq = (lo_g / c.gy - r0) * RW + (lo_g % c.gy - c0);
+            }
+        }
+    }
+    __syncthreads();
+    // one global hook per core cell of the region: the cell with its local root
+    int* par = parent + base;
+    for (int l = tid; l < RN; l += kUfThreads) {
+        if (!s_core[l]) continue;
+        const int me = (r0 + l / RW) * c.gy + (c0 + l % RW);
+        const int lr = lds_find(s_par, l, r0, c0, RW, c.gy);
+        const int root = (r0 + lr / RW) * c.gy + (c0 + lr % RW);
+        if (root == me) continue;
+        int x = me, y = root;
+        while (true) {
+            x = find_root_compress(par, x);
+            y = find_root_compress(par, y);
+            if (x == y) break;
+            if (x < y) { const int t = x; x = y; y = t; }
+            const int old = atomicMin(&par[x], y);
+            if (old == x) break;
+            x = old;
+        }
+    }
+}
+
 __global__ void dbscan_flatten_kernel(Cfg c, const uint8_t* __restrict__ core, int* __restrict__ parent,
                                       int* __restrict__ is_root) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -263,6 +392,58 @@ __global__ __launch_bounds__(256) void region_moments_kernel(const int* __restri
     }
 }
 
+// The same sums without global atomics, for label maps whose labelled cells are SCATTERED (a frozen flow network on real data gives
+// blobs; an untrained one marks single pillars all over the map): round-5 measurement on the bench's sweeps -- 4 306 labelled cells in
+// 30 clusters, nearly every one in a wave of its own -> 26 k 64-bit atomics on 180 addresses, 75 us; 30 compact blobs of the same
+// area: 4 us.  Here a block owns kRmCells consecutive cells of one sample, adds into LDS ([max_labels][6] u64, ds_add_u64) and writes
+// its rows to partial[sample][block][label][6] (plain stores, zeros included: no fill pass); region_props_kernel adds the blocks'
+// rows (integers: any order gives the same bits) before it evaluates the moments.
+constexpr int kRmCells = 2048, kRmThreads = 256, kRmMaxLabels = 1024;
+__global__ __launch_bounds__(kRmThreads) void region_moments_lds_kernel(const int* __restrict__ labels, int gx, int gy, int max_labels,
+                                                                         int blocks_per_sample, unsigned long long* __restrict__ partial) {
+    extern __shared__ unsigned long long s_mom[];  // [max_labels][6]
+    const int b = blockIdx.y, blk = blockIdx.x;
+    const unsigned per = (unsigned)gx * (unsigned)gy;
+    for (int q = threadIdx.x; q < max_labels * 6; q += kRmThreads) s_mom[q] = 0ull;
+    __syncthreads();
+    const unsigned c0 = (unsigned)blk * kRmCells;
+    for (unsigned c = c0 + threadIdx.x; c < c0 + kRmCells && c < per; c += kRmThreads) {
+        int l = labels[(size_t)b * per + c];
+        if (l <= 0 || l > max_labels) continue;
+        const unsigned long long r = c / (unsigned)gy, col = c - (unsigned)r * (unsigned)gy;
+        unsigned long long* m = s_mom + (size_t)(l - 1) * 6;
+        atomicAdd(m + 0, 1ull); atomicAdd(m + 1, r); atomicAdd(m + 2, col);
+        atomicAdd(m + 3, r * r); atomicAdd(m + 4, col * col); atomicAdd(m + 5, r * col);
+    }
+    __syncthreads();
+    unsigned long long* out = partial + ((size_t)b * blocks_per_sample + blk) * max_labels * 6;
+    for (int q = threadIdx.x; q < max_labels * 6; q += kRmThreads) out[q] = s_mom[q];
+}
+
+// mom[region][6] = sum over the sample's blocks of partial[sample][block][label][6]: one wave per region, lanes stride over the blocks
+__global__ __launch_bounds__(256) void region_moments_sum_kernel(const unsigned long long* __restrict__ partial, int batch, int max_labels,
+                                                                 int blocks_per_sample, unsigned long long* __restrict__ mom) {
+    const int region = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (region >= batch * max_labels) return;
+    const int b = region / max_labels, l = region - b * max_labels;
+    unsigned long long v[6] = {0, 0, 0, 0, 0, 0};
+    for (int blk = lane; blk < blocks_per_sample; blk += 64) {
+        const unsigned long long* p = partial + (((size_t)b * blocks_per_sample + blk) * max_labels + l) * 6;
+#pragma unroll
+        for (int q = 0; q < 6; q++) v[q] += p[q];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int q = 0; q < 6; q++) v[q] += __shfl_xor(v[q], o);
+    if (lane < 6) {
+        unsigned long long w = v[0];
+#pragma unroll
+        for (int q = 1; q < 6; q++) w = lane == q ? v[q] : w;
+        mom[(size_t)region * 6 + lane] = w;
+    }
+}
+
 __global__ void region_props_kernel(const unsigned long long* __restrict__ mom, long n_regions, double* __restrict__ props) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_regions) return;
@@ -313,7 +494,14 @@ int liso_dbscan_components(const liso_dbscan_cfg* cfg, const uint8_t* dynamic_ma
     const unsigned blocks = (unsigned)((total + 255) / 256);
     hipStream_t st = (hipStream_t)stream;
     dbscan_core_kernel<<<blocks, 256, 0, st>>>(c, dynamic_mask, row_coords, col_coords, flow, core, parent);
-    dbscan_union_kernel<<<blocks, 256, 0, st>>>(c, dynamic_mask, core, row_coords, col_coords, flow, parent);
+    static const bool flat_union = getenv("LISO_DBSCAN_FLAT_UNION") != nullptr && atoi(getenv("LISO_DBSCAN_FLAT_UNION")) != 0;
+    if (c.win <= kMaxWin && !flat_union) {
+        const int tiles_r = (c.gx + kTR - 1) / kTR, tiles_c = (c.gy + kTC - 1) / kTC;
+        dbscan_union_tiled_kernel<<<dim3(tiles_r * tiles_c, c.batch), kUfThreads, 0, st>>>(c, dynamic_mask, core, row_coords, col_coords,
+                                                                                         flow, parent, tiles_r, tiles_c);
+    } else {
+        dbscan_union_kernel<<<blocks, 256, 0, st>>>(c, dynamic_mask, core, row_coords, col_coords, flow, parent);
+    }
     dbscan_flatten_kernel<<<blocks, 256, 0, st>>>(c, core, parent, is_root);
     return check_launch();
 }
@@ -340,6 +528,31 @@ int liso_region_props(const int32_t* labels, int batch, int gx, int gy, int max_
     if (liso_zero::zero_async(moments, (size_t)regions * 6 * sizeof(uint64_t), st) != hipSuccess) return LISO_ELAUNCH;
     region_moments_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(labels, batch, gx, gy, max_labels,
                                                                           (unsigned long long*)moments);
+    region_props_kernel<<<(unsigned)((regions + 255) / 256), 256, 0, st>>>((const unsigned long long*)moments, regions, props);
+    return check_launch();
+}
+
+size_t liso_region_props_workspace_bytes(int batch, int gx, int gy, int max_labels) {
+    if (batch < 1 || gx < 1 || gy < 1 || max_labels < 1 || max_labels > kRmMaxLabels) return 0;
+    const size_t per = (size_t)gx * gy;
+    if (per * batch >= (1ull << 31)) return 0;
+    const size_t blocks = (per + kRmCells - 1) / kRmCells;
+    return (size_t)batch * blocks * max_labels * 6 * sizeof(uint64_t);
+}
+
+int liso_region_props_ws(const int32_t* labels, int batch, int gx, int gy, int max_labels, uint64_t* moments, double* props,
+                         void* workspace, size_t workspace_bytes, void* stream) {
+    if (!labels || batch < 1 || gx < 1 || gy < 1 || max_labels < 1 || !moments || !props) return LISO_EINVAL;
+    const size_t need = liso_region_props_workspace_bytes(batch, gx, gy, max_labels);
+    if (need == 0) return liso_region_props(labels, batch, gx, gy, max_labels, moments, props, stream);  // (> 1024 labels: atomics path)
+    if (!workspace || workspace_bytes < need) return LISO_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int blocks = (int)(((size_t)gx * gy + kRmCells - 1) / kRmCells);
+    const long regions = (long)batch * max_labels;
+    region_moments_lds_kernel<<<dim3(blocks, batch), kRmThreads, (size_t)max_labels * 6 * sizeof(uint64_t), st>>>(
+        labels, gx, gy, max_labels, blocks, (unsigned long long*)workspace);
+    region_moments_sum_kernel<<<(unsigned)((regions + 3) / 4), 256, 0, st>>>((const unsigned long long*)workspace, batch, max_labels,
+                                                                            blocks, (unsigned long long*)moments);
     region_props_kernel<<<(unsigned)((regions + 255) / 256), 256, 0, st>>>((const unsigned long long*)moments, regions, props);
     return check_launch();
 }

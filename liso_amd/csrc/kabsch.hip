@@ -23,7 +23,8 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kTile = 128;            // points per tile (32 per wave in phase B)
 constexpr int kPtsPerWave = kTile / 4;
-constexpr int kMaxBlocks = 1024;      // point blocks per sample (one 128-point tile per block up to 131k points: fills 256 CUs at B = 1)
+constexpr int kMaxBlocks = 512;       // point blocks per sample (round 5: 1024 -> 512; 256: the moments kernel itself slows down; one wave per slot of kabsch_solve_kernel walks the
+                                      // blocks' partial sums: 938 rows of 36 B per slot took 38 us, more than the moments of 18 boxes)
 constexpr int NM = LISO_KABSCH_NMOM;
 constexpr float kPi = 3.14159265358979323846f;
 
@@ -66,8 +67,10 @@ __device__ __forceinline__ void accumulate(float* acc, float w, float x0, float 
     acc[7] = fmaf(wy1, x0, acc[7]); acc[8] = fmaf(wy1, x1, acc[8]);
 }
 
+constexpr int kBgCache = 128;  // background-scale boxes of the first slots, kept in LDS (the rest are rebuilt from global memory)
 struct MomLds {
     float px[kTile], py[kTile], pz[kTile], fx[kTile], fy[kTile], ok[kTile];
+    BoxP bg[kBgCache];
     float wbuf[4][64][kPtsPerWave + 1];
     float red[4][NM][64];
     float red2[2][NM][kTile];
@@ -80,18 +83,32 @@ __global__ __launch_bounds__(kThreads) void kabsch_moments_kernel(liso_kabsch_cf
                                                                   const float* __restrict__ box_dims,
                                                                   const float* __restrict__ box_rot,
                                                                   float* __restrict__ fg_weights,
-                                                                  float* __restrict__ partials, int tiles_per_block) {
+                                                                  float* __restrict__ partials, int tiles_per_block,
+                                                                  const int* __restrict__ slot_count) {
     __shared__ MomLds L;
     const int b = blockIdx.y, chunk = blockIdx.z;
     const int N = cfg.n_points, S = cfg.n_slots;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int slot = chunk * 64 + lane;
-    const bool has_slot = slot < S;
+    // `slot_count` (fixed-slot callers): only the first cnt slots of the sample hold boxes; the others are parked where their mask is 0
+    // in fp32 -- a factor of exactly 1 in the background product, moments below the epsilon rule's 1e-12 (kabsch_solve_kernel then
+    // ignores them): skipping them changes no output bit, and the lanes are re-dealt: SV slots x (64 / SV) point sub-lanes per wave
+    int cnt = S;
+    if (slot_count) {
+        cnt = slot_count[b];
+        cnt = cnt < 0 ? 0 : (cnt > S ? S : cnt);
+    }
+    const int cnt_chunk = cnt - chunk * 64 < 0 ? 0 : (cnt - chunk * 64 > 64 ? 64 : cnt - chunk * 64);
+    const int SV = cnt_chunk <= 16 ? 16 : (cnt_chunk <= 32 ? 32 : 64), NP = 64 / SV;
+    const int slot_l = lane % SV, psub = lane / SV;
+    const int slot = chunk * 64 + slot_l;
+    const bool has_slot = slot < cnt;
     const float* bpos = box_pos + (size_t)b * S * 3;
     const float* bdim = box_dims + (size_t)b * S * 3;
     const float* brot = box_rot + (size_t)b * S;
     BoxP mybox = {};
     if (has_slot) mybox = load_box(bpos, bdim, brot, slot, cfg.scale_fg);
+    if (chunk == 0)
+        for (int q = tid; q < cnt && q < kBgCache; q += kThreads) L.bg[q] = load_box(bpos, bdim, brot, q, cfg.scale_bg);
     float acc[NM], accbg[NM], accuni[NM];
 #pragma unroll
     for (int k = 0; k < NM; k++) acc[k] = accbg[k] = accuni[k] = 0.f;
@@ -119,8 +136,8 @@ __global__ __launch_bounds__(kThreads) void kabsch_moments_kernel(liso_kabsch_cf
             if (okf > 0.f) {
                 const float px = L.px[tid], py = L.py[tid], pz = L.pz[tid];
                 float prod = 1.f;
-                for (int s = 0; s < S; s++) {
-                    const BoxP bb = load_box(bpos, bdim, brot, s, cfg.scale_bg);
+                for (int s = 0; s < cnt; s++) {
+                    const BoxP bb = s < kBgCache ? L.bg[s] : load_box(bpos, bdim, brot, s, cfg.scale_bg);
                     prod *= 1.0f - box_weight(bb, px, py, pz, cfg.slope, cfg.softness);
                 }
                 // mask_fusing.py:4-6 then kabsch_mask.py:370-372: bg = 1 - (1 - prod)
@@ -134,7 +151,10 @@ __global__ __launch_bounds__(kThreads) void kabsch_moments_kernel(liso_kabsch_cf
         // ---- phase B: foreground slots, lanes = slots ---------------------------------------------------------------
         {
             const int p0 = wave * kPtsPerWave;
-            for (int i = 0; i < kPtsPerWave; i++) {
+            if (fg_weights && NP > 1)  // (lanes that hold no slot leave their rows of the staging buffer unwritten: zeros go out)
+                for (int i = 0; i < kPtsPerWave; i++) L.wbuf[wave][lane][i] = 0.f;
+            for (int ii = psub; ii < kPtsPerWave; ii += NP) {
+                const int i = ii;
                 const int p = p0 + i;
                 const float okf = L.ok[p];
                 float w = 0.f;
@@ -148,7 +168,7 @@ __global__ __launch_bounds__(kThreads) void kabsch_moments_kernel(liso_kabsch_cf
                         accumulate(acc, w, x0, x1, x0 + L.fx[p], x1 + L.fy[p]);
                     }
                 }
-                if (fg_weights) L.wbuf[wave][lane][i] = w;
+                if (fg_weights && (has_slot || NP == 1)) L.wbuf[wave][slot_l][i] = w;
             }
             if (fg_weights) {
                 __builtin_amdgcn_wave_barrier();
@@ -164,8 +184,21 @@ __global__ __launch_bounds__(kThreads) void kabsch_moments_kernel(liso_kabsch_cf
         __syncthreads();
     }
     // ---- block reduction (fixed order) -----------------------------------------------------------------------------
+    // the point sub-lanes of a slot: fixed-order butterfly (lanes slot, slot + SV, ...); slots without a box: zeros
 #pragma unroll
-    for (int k = 0; k < NM; k++) L.red[wave][k][lane] = acc[k];
+    for (int k = 0; k < NM; k++) {
+        float v = acc[k];
+        for (int o = SV; o < 64; o <<= 1) v += __shfl_xor(v, o);
+        acc[k] = has_slot ? v : 0.f;
+    }
+    if (lane < SV) {
+#pragma unroll
+        for (int k = 0; k < NM; k++) L.red[wave][k][lane] = acc[k];
+    }
+    for (int l = SV + lane; l < 64 && lane < 64; l += 64) {
+#pragma unroll
+        for (int k = 0; k < NM; k++) L.red[wave][k][l] = 0.f;
+    }
     if (tid < kTile) {
 #pragma unroll
         for (int k = 0; k < NM; k++) { L.red2[0][k][tid] = accbg[k]; L.red2[1][k][tid] = accuni[k]; }
@@ -381,6 +414,14 @@ size_t liso_kabsch_workspace_bytes(const liso_kabsch_cfg* cfg) {
 int liso_kabsch_trafos_f32(const liso_kabsch_cfg* cfg, const float* points, const uint8_t* valid, const float* flow,
                            const float* box_pos, const float* box_dims, const float* box_rot, double* trafos,
                            float* cum_wts, float* fg_weights, void* workspace, size_t workspace_bytes, void* stream) {
+    return liso_kabsch_trafos_counted_f32(cfg, points, valid, flow, box_pos, box_dims, box_rot, nullptr, trafos, cum_wts, fg_weights,
+                                          workspace, workspace_bytes, stream);
+}
+
+int liso_kabsch_trafos_counted_f32(const liso_kabsch_cfg* cfg, const float* points, const uint8_t* valid, const float* flow,
+                                   const float* box_pos, const float* box_dims, const float* box_rot, const int32_t* slot_count,
+                                   double* trafos, float* cum_wts, float* fg_weights, void* workspace, size_t workspace_bytes,
+                                   void* stream) {
     if (!cfg_ok(cfg) || !trafos || !cum_wts || !workspace) return LISO_EINVAL;
     if (cfg->n_points > 0 && (!points || !valid || !flow)) return LISO_EINVAL;
     if (cfg->n_slots > 0 && (!box_pos || !box_dims || !box_rot)) return LISO_EINVAL;
@@ -392,7 +433,7 @@ int liso_kabsch_trafos_f32(const liso_kabsch_cfg* cfg, const float* points, cons
     const int chunks = (cfg->n_slots + 63) / 64 > 0 ? (cfg->n_slots + 63) / 64 : 1;
     kabsch_moments_kernel<<<dim3(nblk, cfg->batch, chunks), kThreads, 0, st>>>(*cfg, points, valid, flow, box_pos,
                                                                                box_dims, box_rot, fg_weights,
-                                                                               (float*)workspace, tpb);
+                                                                               (float*)workspace, tpb, slot_count);
     kabsch_solve_kernel<<<dim3(cfg->n_slots + 1, cfg->batch), 64, 0, st>>>(*cfg, (const float*)workspace, nblk, box_pos,
                                                                            trafos, cum_wts);
     return check_launch();

@@ -37,7 +37,7 @@ class KabschDecoder(torch.nn.Module):
         self.softness_name = cfg.mask_rendering.softness_fun
         self.softness_fun = get_mask_softness_fun(self.softness_name)
 
-    def _run(self, shapes: Shape, points, valid, flow, slope, scale_fg, scale_bg, softness_name, want_weights):
+    def _run(self, shapes: Shape, points, valid, flow, slope, scale_fg, scale_bg, softness_name, want_weights, slot_count=None):
         L.require_cuda(points, shapes.pos)
         B, N = valid.shape
         S = shapes.pos.shape[1]
@@ -57,8 +57,11 @@ class KabschDecoder(torch.nn.Module):
         nbytes = lib.liso_kabsch_workspace_bytes(ctypes.byref(c))
         ws = torch.empty(max(nbytes, 8), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
-            L.check(L.TIMER.launch("kabsch_trafos", lambda: lib.liso_kabsch_trafos_f32(
-                ctypes.byref(c), L.ptr(pts), L.ptr(val), L.ptr(fl), L.ptr(pos), L.ptr(dims), L.ptr(rot), L.ptr(T),
+            if slot_count is not None:
+                assert slot_count.dtype == torch.int32 and slot_count.is_contiguous() and slot_count.numel() == B and slot_count.is_cuda
+            L.check(L.TIMER.launch("kabsch_trafos", lambda: lib.liso_kabsch_trafos_counted_f32(
+                ctypes.byref(c), L.ptr(pts), L.ptr(val), L.ptr(fl), L.ptr(pos), L.ptr(dims), L.ptr(rot),
+                L.ptr(slot_count) if slot_count is not None else None, L.ptr(T),
                 L.ptr(cum), L.ptr(w) if w is not None else None, L.ptr(ws), nbytes, L.stream_ptr())), "kabsch_trafos")
         return T, cum, w
 
@@ -101,12 +104,14 @@ class KabschDecoder(torch.nn.Module):
 
     @torch.no_grad()
     def trafos_from_point_flow_packed(self, *, point_cloud_ta, valid_mask_ta, pointwise_flow_ta_tb, pred_boxes_ta: Shape,
-                                      sigmoid_slope=None, obj_dim_scale_buffer=None, softness_func=None):
+                                      sigmoid_slope=None, obj_dim_scale_buffer=None, softness_func=None, slot_count=None):
         """get_kabsch_trafos_from_point_flow without the weight map, as ONE tensor fp64 [B, S+1, 4, 4]: slots 0..S-1 the per-box
         transforms, slot S the background transform (what liso_mine_box_motion of include/liso_box_mining.h takes)"""
         slope = sigmoid_slope if sigmoid_slope is not None else self.cfg.mask_rendering.pred_sigmoid_slope
         buf = obj_dim_scale_buffer if obj_dim_scale_buffer is not None else self.cfg.mask_rendering.obj_dim_scale_buffer
         name = self.softness_name if softness_func is None else ("sigmoid" if softness_func is torch.sigmoid else "cauchy")
         # (the kernel reads x, y, z / flow x, y with the row strides: no [..., :3] / [..., 0:2] copies)
-        T, _, _ = self._run(pred_boxes_ta, point_cloud_ta, valid_mask_ta, pointwise_flow_ta_tb, slope, 1.0 - buf, 1.0 + buf, name, False)
+        # `slot_count` (int32 [B], device): only the first slot_count[b] slots hold boxes, the rest are parked (liso_kabsch_trafos_counted_f32)
+        T, _, _ = self._run(pred_boxes_ta, point_cloud_ta, valid_mask_ta, pointwise_flow_ta_tb, slope, 1.0 - buf, 1.0 + buf, name, False,
+                            slot_count=slot_count)
         return T

@@ -80,9 +80,12 @@ def label_region_props(labels, max_labels):
     lab = labels.to(torch.int32).contiguous()
     mom = torch.empty((B, max_labels, 6), dtype=torch.int64, device=lab.device)
     props = torch.empty((B, max_labels, 5), dtype=torch.float64, device=lab.device)
+    lib = L.lib()
+    nbytes = lib.liso_region_props_workspace_bytes(B, gx, gy, max_labels)  # (0: more labels than the LDS path holds -> atomics path)
+    ws = torch.empty(max(nbytes, 8), dtype=torch.uint8, device=lab.device)
     with torch.cuda.device(lab.device):
-        L.check(L.TIMER.launch("region_props", lambda: L.lib().liso_region_props(
-            L.ptr(lab), B, gx, gy, max_labels, L.ptr(mom), L.ptr(props), L.stream_ptr())), "region_props")
+        L.check(L.TIMER.launch("region_props", lambda: lib.liso_region_props_ws(
+            L.ptr(lab), B, gx, gy, max_labels, L.ptr(mom), L.ptr(props), L.ptr(ws), nbytes, L.stream_ptr())), "region_props")
     return props
 
 
@@ -201,8 +204,10 @@ class FlowClusterDetector(torch.nn.Module):
             # mask is exactly 0 in fp32 and the background weight prod_s (1 - w_s) does not see them
             kboxes = _Shape(pos=cut(arr["kabsch_pos"]), dims=cut(arr["kabsch_dims"]), rot=cut(arr["kabsch_rot"])[..., None],
                             probs=boxes.probs, valid=keep)
+            # (fixed slots: the kernel skips the parked ones -- same outputs, a quarter of the mask evaluations at 18 boxes in 64 slots)
             trafos = self.kabsch_decoder.trafos_from_point_flow_packed(
-                point_cloud_ta=pcl, valid_mask_ta=pcl_is_valid, pointwise_flow_ta_tb=point_flow, pred_boxes_ta=kboxes)
+                point_cloud_ta=pcl, valid_mask_ta=pcl_is_valid, pointwise_flow_ta_tb=point_flow, pred_boxes_ta=kboxes,
+                slot_count=arr["counts"] if capacity else None)
             MO.box_motion(trafos, boxes.pos, boxes.rot, boxes.velo)  # heading += atan2(t_y, t_x), speed = |t|, one launch
         if not is_batched:
             boxes = boxes[0]
