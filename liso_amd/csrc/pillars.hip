@@ -7,16 +7,16 @@
 //       tile_count  per 1024-point tile: how many points are the first of their cell
 //       rank        voxel ordinal = exclusive prefix of "is first" in point order (the reference's voxel order),
 //                   voxels >= max_voxels dropped, coors / num_points / cell->row written
-//       sort        STABLE radix sort of (cell, point index) pairs (rocPRIM): inside a cell the points stay in arrival order;
-//       run_heads / place_slots: the first max_points entries of every cell's run are the pillar's slots
+//       cell_scan / seg_fill / seg_place: every cell owns a segment of point indices (exclusive prefix of the counts); a point's
+//                   slot is its arrival rank = the number of smaller indices in its cell's segment (no sort, no library call)
 //       (an earlier atomicMin insertion cascade cost 290 us at B = 4: adjacent LiDAR rays hit the same pillar together)
 //   * the PFN never materialises voxels[P,20,C], [P,20,10] or [P,20,64]: `pfn_decorate` walks count -> slot indices -> points once
 //     (32 lanes per pillar) and writes 12-float feature rows in pillar order (CSR); statistics / forward / backward stream those
 //     rows: a wave stages the rows of 4 consecutive pillars in LDS, the 64 lanes ARE the 64 output channels (running max in a
 //     register, one coalesced 64-channel store per pillar into the channels-last canvas; empty cells are zero-filled by other
 //     blocks of the same launch: every canvas cell is written exactly once, no memset pass).
-//   * no hipMemsetAsync anywhere (zero_fill.h): memset nodes do not survive hipGraph replays on this runtime; the radix sort does
-//     memset internally, so callers that replay from a graph keep this encoder in front of the graph (liso_amd/utils/graph_safety.py).
+//   * no hipMemsetAsync anywhere (zero_fill.h): memset nodes do not survive hipGraph replays on this runtime.  (Until round 4 rocPRIM's
+//     radix sort, which does memset internally, kept this encoder in front of every graph: liso_amd/utils/graph_safety.py.)
 //   * BatchNorm1d batch statistics come from the second moments of the 10-vector (sum f f^T in fp64, 66 numbers)
 //     instead of 2x64 per-channel sums over [P*20, 64]; the same moments give the BN backward terms in closed form.
 //   * all cross-workgroup reductions are two-stage with fixed order (no float atomics): results are reproducible.
@@ -24,9 +24,6 @@
 #include <stdlib.h>
 #include "zero_fill.h"
 #include <cstring>
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/iterator/counting_iterator.hpp>
-#include <rocprim/iterator/transform_iterator.hpp>
 #include <hip/hip_bf16.h>
 #include <limits.h>
 #include <stdint.h>
@@ -163,34 +160,77 @@ __global__ __launch_bounds__(kTile) void rank_kernel(const int* __restrict__ cel
     }
 }
 
-// voxel_generator.py:275-278 keeps the first max_points points of a voxel.  The points are sorted by cell with a STABLE
-// radix sort (rocPRIM; keys = cell, values = point index), so inside every cell they stay in arrival order; the run of
-// a cell starts at first_pos[cell] and the first max_points entries of the run are the pillar's slots.  (The earlier
-// atomicMin insertion cascade cost 290 us at B=4: adjacent LiDAR rays hit the same pillar at the same time.)
-struct CellKey {  // dropped points (cell < 0) sort behind every real cell
-    unsigned n_cells;
-    __host__ __device__ unsigned operator()(int cell) const { return cell < 0 ? n_cells : (unsigned)cell; }
-};
-
-__global__ void run_heads_kernel(const unsigned* __restrict__ sorted_cell, int n_total, unsigned n_cells,
-                                 int* __restrict__ first_pos) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n_total) return;
-    const unsigned c = sorted_cell[j];
-    if (c < n_cells && (j == 0 || sorted_cell[j - 1] != c)) first_pos[c] = j;
+// voxel_generator.py:275-278 keeps the first max_points points of a voxel, in arrival order.  Until round 4 the (cell, point) pairs went
+// through rocPRIM's stable radix sort: ~20 launches of its merge passes per call, memset nodes inside (the encoder had to stay in front
+// of every hipGraph) and 2.7 % of the loop's kernel time.  No sort is needed:
+//   cell_scan_*   exclusive prefix of the per-cell point counts (assign_kernel has them) -> every cell owns a segment of `seg`
+//   seg_fill      every point drops its index into its cell's segment (atomic cursor: arbitrary order inside the segment)
+//   seg_place     every point of a kept pillar counts the smaller indices in its segment = its arrival rank r; r < max_points ->
+//                 slots[v][r] = index.  The scan stops at max_points smaller indices (the point is dropped anyway), which bounds the
+//                 work of a crowded cell by ~20 n ln(n / 20) reads instead of n^2 (all points in one pillar: still milliseconds apart
+//                 from seconds).  Ranks are a property of the index set: the result does not depend on the order the atomics ran in.
+constexpr int kScanTile = 1024;
+__global__ __launch_bounds__(kScanTile) void cell_scan_block_kernel(const int* __restrict__ count, size_t cells, int* __restrict__ seg_off,
+                                                                    int* __restrict__ block_tot) {
+    __shared__ int wsum[kScanTile / 64];
+    const size_t i = (size_t)blockIdx.x * kScanTile + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int v = i < cells ? count[i] : 0;
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; w++) base += wsum[w];
+    if (i < cells) seg_off[i] = base + incl - v;
+    if (threadIdx.x == kScanTile - 1) block_tot[blockIdx.x] = base + incl;
 }
 
-__global__ void place_slots_kernel(const unsigned* __restrict__ sorted_cell, const int* __restrict__ sorted_idx, int n_total,
-                                   unsigned n_cells, const int* __restrict__ first_pos, const int* __restrict__ cell_to_voxel,
-                                   int max_points, int* __restrict__ slots) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n_total) return;
-    const unsigned c = sorted_cell[j];
-    if (c >= n_cells) return;
+// one block: exclusive prefix of the block totals (<= 4096 blocks = 4 M cells)
+__global__ __launch_bounds__(1024) void cell_scan_tot_kernel(int* __restrict__ block_tot, int nblk) {
+    __shared__ int s[4096];
+    for (int q = threadIdx.x; q < 4096; q += 1024) s[q] = q < nblk ? block_tot[q] : 0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int q = 0; q < nblk; q++) { const int t = s[q]; s[q] = run; run += t; }
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < nblk; q += 1024) block_tot[q] = s[q];
+}
+
+__global__ __launch_bounds__(256) void seg_fill_kernel(const int* __restrict__ cell_of_point, int n_total, const int* __restrict__ seg_off,
+                                                       const int* __restrict__ block_tot, int* __restrict__ cursor,
+                                                       int* __restrict__ seg) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_total) return;
+    const int c = cell_of_point[i];
+    if (c < 0) return;
+    const int pos = seg_off[c] + block_tot[c / kScanTile] + atomicAdd(&cursor[c], 1);
+    seg[pos] = i;
+}
+
+__global__ __launch_bounds__(256) void seg_place_kernel(const int* __restrict__ cell_of_point, int n_total, const int* __restrict__ seg_off,
+                                                        const int* __restrict__ block_tot, const int* __restrict__ count,
+                                                        const int* __restrict__ seg, const int* __restrict__ cell_to_voxel,
+                                                        int max_points, int* __restrict__ slots) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_total) return;
+    const int c = cell_of_point[i];
+    if (c < 0) return;
     const int v = cell_to_voxel[c] - 1;
     if (v < 0) return;  // the pillar fell beyond max_voxels
-    const int r = j - first_pos[c];
-    if (r < max_points) slots[(size_t)v * max_points + r] = sorted_idx[j];
+    const int off = seg_off[c] + block_tot[c / kScanTile], n = count[c];
+    int r = 0;
+    for (int j = 0; j < n; j++) {
+        r += seg[off + j] < i ? 1 : 0;
+        if (r >= max_points) return;  // max_points earlier arrivals: this point is not kept
+    }
+    slots[(size_t)v * max_points + r] = i;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -726,26 +766,13 @@ inline int pfn_grid(int rows) {
 
 extern "C" {
 
-static int key_bits(size_t cells) {
-    int bits = 1;
-    while (((size_t)1 << bits) <= cells) bits++;  // keys 0 .. cells (cells = "dropped")
-    return bits;
-}
-
-static size_t sort_temp_bytes(size_t cells, int n_total) {
-    size_t bytes = 0;
-    if (n_total > 0)
-        (void)rocprim::radix_sort_pairs(nullptr, bytes, (const unsigned*)nullptr, (unsigned*)nullptr, (const int*)nullptr, (int*)nullptr,
-                                  (size_t)n_total, 0, key_bits(cells), (hipStream_t)0);
-    return (bytes + 255) & ~(size_t)255;
-}
-
 size_t liso_pillars_voxelize_workspace_bytes(const liso_pillar_cfg* cfg, int batch, int n_total) {
     if (!cfg_ok(cfg, batch) || n_total < 0) return 0;
     const size_t cells = (size_t)batch * cfg->gx * cfg->gy;
     const size_t tiles = (size_t)(n_total + kTile - 1) / kTile + batch;
-    // count | first_enc | first_pos [cells each], cell_of_point | sorted_cell | sorted_idx [n each], tile counts, sort temp
-    return (3 * cells + 3 * (size_t)n_total + tiles + 64) * sizeof(int) + 256 + sort_temp_bytes(cells, n_total);
+    // count | first_enc | seg_off | cursor [cells each], cell_of_point | seg [n each], tile counts, scan block totals
+    if (cells > (size_t)4096 * kScanTile) return 0;  // (the one-block pass over the scan's block totals holds 4096 of them: 4 M cells)
+    return (4 * cells + 2 * (size_t)n_total + tiles + 64 + 4096) * sizeof(int) + 256;
 }
 
 int liso_pillars_voxelize_f32(const float* points, const int* offsets_host, int batch, const liso_pillar_cfg* cfg,
@@ -758,6 +785,7 @@ int liso_pillars_voxelize_f32(const float* points, const int* offsets_host, int 
         if (offsets_host[b + 1] < offsets_host[b]) return LISO_EINVAL;
     if (!coors || !num_points || !slots || !num_voxels || !cell_to_voxel || !workspace || (n_total > 0 && !points))
         return LISO_EINVAL;
+    if ((size_t)batch * cfg->gx * cfg->gy > (size_t)4096 * kScanTile) return LISO_EINVAL;  // (see liso_pillars_voxelize_workspace_bytes)
     if (workspace_bytes < liso_pillars_voxelize_workspace_bytes(cfg, batch, n_total)) return LISO_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const size_t cells = (size_t)batch * cfg->gx * cfg->gy;
@@ -766,14 +794,14 @@ int liso_pillars_voxelize_f32(const float* points, const int* offsets_host, int 
     int* cell_of_point = first_enc + cells;
     int* tile_count = cell_of_point + n_total;
     const size_t tiles_cap = (size_t)(n_total + kTile - 1) / kTile + batch;
-    int* first_pos = tile_count + tiles_cap + 32;
-    unsigned* sorted_cell = (unsigned*)(first_pos + cells);
-    int* sorted_idx = (int*)(sorted_cell + n_total);
-    void* sort_temp = (void*)(((uintptr_t)(sorted_idx + n_total) + 255) & ~(uintptr_t)255);
-    size_t sort_bytes = sort_temp_bytes(cells, n_total);
+    int* seg_off = tile_count + tiles_cap + 32;
+    int* cursor = seg_off + cells;
+    int* seg = cursor + cells;
+    int* block_tot = seg + n_total;
     const BatchInfo bi = make_batch(offsets_host, batch);
     const int tiles = bi.tile_off[batch];
     if (liso_zero::zero_async(count, 2 * cells * sizeof(int), st) != hipSuccess) return LISO_ELAUNCH;
+    if (liso_zero::zero_async(cursor, cells * sizeof(int), st) != hipSuccess) return LISO_ELAUNCH;
     if (liso_zero::zero_async(cell_to_voxel, cells * sizeof(int), st) != hipSuccess) return LISO_ELAUNCH;
     if (liso_zero::zero_async(num_voxels, batch * sizeof(int), st) != hipSuccess) return LISO_ELAUNCH;
     if (n_total == 0) return LISO_OK;
@@ -784,16 +812,11 @@ int liso_pillars_voxelize_f32(const float* points, const int* offsets_host, int 
                        tile_count);
     hipLaunchKernelGGL(rank_kernel, dim3(tiles), dim3(kTile), 0, st, cell_of_point, first_enc, count, bi, batch, *cfg,
                        tile_count, coors, num_points, cell_to_voxel, num_voxels);
-    {
-        auto keys_in = rocprim::make_transform_iterator(cell_of_point, CellKey{(unsigned)cells});
-        auto vals_in = rocprim::make_counting_iterator<int>(0);
-        if (rocprim::radix_sort_pairs(sort_temp, sort_bytes, keys_in, sorted_cell, vals_in, sorted_idx, (size_t)n_total, 0,
-                                      key_bits(cells), st) != hipSuccess)
-            return LISO_ELAUNCH;
-    }
-    run_heads_kernel<<<nb, 256, 0, st>>>(sorted_cell, n_total, (unsigned)cells, first_pos);
-    place_slots_kernel<<<nb, 256, 0, st>>>(sorted_cell, sorted_idx, n_total, (unsigned)cells, first_pos, cell_to_voxel,
-                                           cfg->max_points, slots);
+    const int scan_blocks = (int)((cells + kScanTile - 1) / kScanTile);
+    cell_scan_block_kernel<<<scan_blocks, kScanTile, 0, st>>>(count, cells, seg_off, block_tot);
+    cell_scan_tot_kernel<<<1, 1024, 0, st>>>(block_tot, scan_blocks);
+    seg_fill_kernel<<<nb, 256, 0, st>>>(cell_of_point, n_total, seg_off, block_tot, cursor, seg);
+    seg_place_kernel<<<nb, 256, 0, st>>>(cell_of_point, n_total, seg_off, block_tot, count, seg, cell_to_voxel, cfg->max_points, slots);
     return check_launch();
 }
 
