@@ -39,11 +39,12 @@ sys.path.insert(0, ROOT)
 
 def _seed_miopen_user_db():
     """MIOpen keeps the solver picks / tuning parameters it finds in a per-user database; a fresh machine starts from
-    heuristics and only reaches the tuned state after several processes have run.  liso_amd/miopen_db/ holds that
-    database as harvested on an MI355X with this ROCm image (for the layers that still go through MIOpen); every
-    process works on a private copy.  Must run before MIOpen initialises."""
-    src = os.path.join(ROOT, "liso_amd", "miopen_db")
-    if "MIOPEN_USER_DB_PATH" in os.environ or not os.path.isdir(src) or "--no-miopen-db" in sys.argv:
+    heuristics and only reaches the tuned state after several processes have run.  scripts/miopen_db/ holds that
+    database as harvested on an MI355X with this ROCm image, for `--miopen-convs` (the library-backed comparison: no product
+    path uses MIOpen); every process works on a private copy.  Must run before MIOpen initialises."""
+    src = os.path.join(ROOT, "scripts", "miopen_db")
+    # only the library-backed comparison leg reaches MIOpen: the default run never touches the database
+    if "--miopen-convs" not in sys.argv or "MIOPEN_USER_DB_PATH" in os.environ or not os.path.isdir(src) or "--no-miopen-db" in sys.argv:
         return
     import shutil
     import tempfile
@@ -107,7 +108,7 @@ def parse():
                     help="loop / detector workloads: launch every kernel eagerly (default: SLIM inference and the detector's "
                          "backbone + head + loss fwd/bwd replay from hipGraphs; bit-identical results)")
     ap.add_argument("--conv-benchmark", action="store_true", help="torch.backends.cudnn.benchmark = True (MIOpen layers only)")
-    ap.add_argument("--no-miopen-db", action="store_true", help="do not seed MIOpen's user database from liso_amd/miopen_db/")
+    ap.add_argument("--no-miopen-db", action="store_true", help="--miopen-convs: do not seed MIOpen's user database from scripts/miopen_db/")
     ap.add_argument("--miopen-convs", action="store_true",
                     help="route every convolution through MIOpen instead of the own MFMA kernels (comparison runs)")
     return ap.parse_args()
@@ -677,7 +678,9 @@ def main():
                       "`parity_leg` (f32 via bf16x3 MFMA everywhere) and `fp32_exact_leg`, not by the bf16 detector"
                       if args.workload == "loop" and args.dtype == "bf16" else
                       "f32 (exact: native fp32 MFMA v_mfma_f32_32x32x2_f32)" if args.dtype == "fp32" and args.workload != "slim" else
-                      "f32 via bf16x3 MFMA" if args.workload == "slim" or args.dtype == "f32x3" else args.dtype),
+                      "f32 via bf16x3 MFMA" if args.workload == "slim" or args.dtype == "f32x3" else
+                      "bf16 (BASELINE configs[4] names fp16: the same MFMA rate and storage width; the kernels take bf16 / fp32 tensors only)"
+                      if args.workload == "stress" and args.dtype == "bf16" else args.dtype),
             "data": "synthetic",
             "config": {"workload": workload, "points_per_cloud": N_POINTS, "bev_grid": GRID, "batch_per_gpu": batch,
                        "frames_per_step_per_gpu": frames_per_step, "parallelism": f"dp{world}",

@@ -2,9 +2,13 @@
 same state_dict keys `blocks.{i}.{j}.*`, `deblocks.{i}.{j}.*`, including the ZeroPad2d at index 0, rpn.py:113-129).
 
 MI355X notes: tensors stay channels-last (the pillar scatter already produces NHWC storage) and in the dtype they
-arrive in (bf16 for the perf configuration, fp32 for parity); convolutions go to MIOpen's NHWC implicit-GEMM
-(MFMA) kernels, BatchNorm+ReLU is the fused gfx950 kernel pair of include/liso_bn.h (fp32 statistics).  forward() is functional so ZeroPad2d+conv(pad=0) becomes one
-padded conv (identical arithmetic, one HBM round trip less per stage).
+arrive in (bf16 for the perf configuration, fp32 for parity); every convolution -- forward, data gradient, weight
+gradient -- runs on the library's own MFMA implicit-GEMM kernels (include/liso_conv.h: conv_roles_kernel for the
+3x3 / stride-1 layers, conv_igemm_kernel for the rest, the sparse-canvas kernels for the first layer), with the
+BatchNorm-apply + ReLU of the producing layer as the consumer's prologue and the batch statistics as the producer's
+epilogue (fp32 statistics; include/liso_bn.h for the backward passes).  forward() is functional so ZeroPad2d +
+conv(pad=0) becomes one padded conv (identical arithmetic, one HBM round trip less per stage).  MIOpen is only reached
+with LISO_CONV_BACKEND=miopen (`bench.py --miopen-convs`: the library-backed comparison leg).
 """
 import numpy as np
 import torch
