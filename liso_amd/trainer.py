@@ -258,9 +258,14 @@ class DetectorTrainer:
 
     # ---- hipGraph path ----------------------------------------------------------------------------------------------
     # The graph holds backbone + head + fused loss, forward and backward (~95 % of the step's launches).  The pillar encoder
-    # (voxelise + PFN + scatter; 10 launches) runs eagerly around it: replaying ITS launches from a graph while other pillar-
-    # encoder calls run eagerly in the same process (the LISO loop's SLIM inference) ends in a GPU memory fault -- bisected
-    # to exactly that combination (scripts/try_loop_graph3.py), root cause not found; the other kernels replay cleanly.
+    # (voxelise + PFN + scatter; 10 launches) runs eagerly around it.  Rounds 2-4: replaying ITS launches from a graph while other
+    # pillar-encoder calls ran eagerly in the same process (the LISO loop's SLIM inference) ended in a GPU memory fault, bisected to
+    # exactly that combination (scripts/try_loop_graph3.py PART=pfn).  Cause (round 5): rocPRIM's radix sort inside the voxeliser --
+    # the same library path whose captured launches fault for > 1 M keys (see _capture_slim below) and whose memset nodes do not
+    # survive replays (utils/graph_safety.py).  The voxeliser no longer sorts (csrc/pillars.hip: per-cell segments + arrival rank):
+    # the reproducer replays cleanly, and the guard-band runs of tests/test_gpu_canaries.py find no out-of-bounds write in any kernel
+    # of the encoder, at and beyond its capacities.  The encoder still runs eagerly for a different reason: its launches carry the
+    # raw clouds' lengths (host offsets) as kernel arguments, which a captured graph would freeze.
     def _pillars(self, pcls, out=None):
         """`out`: (canvas rows [B, gx, gy, 64], occupancy) to write into -- the graph's static inputs (no copy afterwards)"""
         bev, occ = self.net.model.pfn(pcl_t0=pcls, img_t0=None, out=out)
