@@ -24,6 +24,20 @@ for i in range(10):
     losses.append(float(tr.step_batch(cur, upcoming=up)))
     dist.all_reduce(tr.detector._flat_grad)  # what a second rank would add after every replay
 torch.cuda.synchronize()
+# launch + completion cost of the gradient all-reduce on this 1-rank communicator (no data leaves the GPU: a lower bound of what every
+# step adds before any byte crosses xGMI) -- DESIGN.md 9 uses it in the labelled-unmeasured 8-GPU estimate
+g = tr.detector._flat_grad
+a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+for _ in range(5):
+    dist.all_reduce(g)
+torch.cuda.synchronize()
+a.record()
+for _ in range(50):
+    dist.all_reduce(g)
+b.record()
+torch.cuda.synchronize()
+print(f"all_reduce of the flat gradient buffer ({g.numel() * g.element_size() / 1e6:.1f} MB) on the 1-rank RCCL group: "
+      f"{a.elapsed_time(b) / 50 * 1e3:.1f} us per call")
 dist.barrier()
 print("ok: 10 loop steps with captures + replays next to a live RCCL process group; losses", [round(v, 3) for v in losses[:4]], "...")
 dist.destroy_process_group()

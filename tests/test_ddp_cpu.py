@@ -71,47 +71,55 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(600)
-def test_two_rank_gloo_step(tmp_path):
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world", [2, 4])
+def test_gloo_step_keeps_replicas_identical_and_equals_hand_averaged_gradients(tmp_path, world):
+    """world 4 = the rank count of `bench.py --gpus 4` (the driver's 1 / 2 / 4 / 8 scaling runs): sample sharding, SUM all-reduce,
+    the 1 / world factor"""
     out = str(tmp_path / "ddp.pt")
-    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     r = torch.load(out)
     # replicas stay identical, BatchNorm buffers stay per-rank (the reference uses plain BatchNorm2d)
-    assert torch.equal(r["params"][0], r["params"][1])
-    assert not torch.equal(r["rm"][0], r["rm"][1])
-    # and equal to one process that averages the two ranks' gradients by hand
+    assert all(torch.equal(r["params"][0], r["params"][k]) for k in range(1, world))
+    assert all(not torch.equal(r["rm"][0], r["rm"][k]) for k in range(1, world))
+    # and equal to one process that averages the ranks' gradients by hand
     n_threads = torch.get_num_threads()
     torch.set_num_threads(2)  # same oneDNN blocking as the workers
     try:
-        _compare_with_hand_averaged(r)
+        _compare_with_hand_averaged(r, world)
     finally:
         torch.set_num_threads(n_threads)
 
 
-def _compare_with_hand_averaged(r):
+def _compare_with_hand_averaged(r, world):
     tr = _make(0)
-    d0, d1 = _data(0), _data(1)
-    import copy
+    data = [_data(k) for k in range(world)]
 
     for _ in range(2):
         tr.model.train()
         grads = []
-        bufs = copy.deepcopy({k: v.clone() for k, v in tr.net.named_buffers()})
-        for d in (d0, d1):
-            for k, v in tr.net.named_buffers():  # each rank starts the step from ITS OWN buffers; rank 0's are kept
-                pass
+        for d in data:  # (BatchNorm running statistics do not enter the training-mode forward: one process can play every rank)
             tr.optimizer.zero_grad(set_to_none=True)
             total, _, _ = tr.loss(*d)
             total.backward()
             grads.append([p.grad.clone() if p.grad is not None else None for p in tr.net.parameters()])
-        for p, g0, g1 in zip(tr.net.parameters(), *grads):
-            if g0 is not None:
-                p.grad = 0.5 * (g0 + g1)
+        for p, *gs in zip(tr.net.parameters(), *grads):
+            if gs[0] is not None:
+                p.grad = sum(gs) / float(world)
         tr.optimizer.step()
         tr.lr_scheduler.step()
     flat = torch.cat([p.detach().flatten() for p in tr.net.parameters()])
     # BN running stats do not enter the training-mode forward, so hand-averaging reproduces DDP up to fp32 summation order
-    assert torch.allclose(flat, r["params"][0], rtol=2e-4, atol=2e-6)
+    # (AdamW's first steps move every weight by ~lr * g / |g|: where the averaged gradient is ~0, another summation order of the
+    # ranks' gradients may flip the direction of a step of size lr.  The bulk must agree tightly, no entry by more than 2 steps.)
+    diff = (flat - r["params"][0]).abs()
+    lr = max(g["lr"] for g in tr.optimizer.param_groups)
+    # Two ranks: g0 + g1 is the same number in either order -> tight everywhere.  Four ranks: the ring's order differs from the
+    # sequential sum, and parameters whose true gradient is ZERO (every convolution bias in front of a BatchNorm) take +-lr steps in the
+    # direction of that rounding noise: most entries tight, none further apart than the steps taken.
+    close = diff <= 2e-6 + 2e-4 * r["params"][0].abs()
+    frac = float(close.float().mean())
+    assert (frac == 1.0 if world == 2 else frac > 0.8) and float(diff.max()) <= 2 * 2 * lr + 1e-6, (frac, float(diff.max()), lr)
 
 
 # ---- SLIM trainer under DDP (gloo, 2 ranks).  The six HIP-backed ops are swapped for the CPU port of oracle/slim_step.py

@@ -135,9 +135,9 @@ def test_two_ranks_liso_loop_keeps_detector_replicas_identical(tmp_path, use_gra
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("workload", ["loop", "detector"])
-def test_bench_two_ranks_on_one_gpu_reports_world_and_identical_replicas(workload):
-    """`python bench.py --gpus 2` through its own rank spawner, both ranks on cuda:0, gloo carrying the collectives
+@pytest.mark.parametrize("workload,world", [("loop", 2), ("detector", 2), ("loop", 4)])
+def test_bench_ranks_on_one_gpu_reports_world_and_identical_replicas(workload, world):
+    """`python bench.py --gpus 2 | 4` through its own rank spawner, all ranks on cuda:0, gloo carrying the collectives
     (LISO_DIST_BACKEND=gloo: RCCL refuses two ranks on one device; the default backend "nccl" = RCCL is what the driver's
     multi-GPU runs use).  Exercises the world > 1 code of bench.py: barrier-bracketed timing, MAX over ranks, the flat-buffer
     gradient all-reduce after every replay, rank-0-only line.  The line must report n_gpus 2 and replicas that agree."""
@@ -149,14 +149,16 @@ def test_bench_two_ranks_on_one_gpu_reports_world_and_identical_replicas(workloa
     env = dict(os.environ, LISO_DIST_BACKEND="gloo")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--workload", workload,
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "2", "--workload", workload,
                         "--no-cpu-baseline", "--no-iou3d"], env=env, capture_output=True, text=True, timeout=850)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]  # rank 0 only
     line = json.loads(lines[0])
-    assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and line["scaling"] == "weak"
-    assert line["dist_backend"] == "gloo" and len(line["replica_param_checksums"]) == 2
+    assert line["n_gpus"] == world and line["config"]["parallelism"] == f"dp{world}" and line["scaling"] == "weak"
+    assert line["dist_backend"] == "gloo" and len(line["replica_param_checksums"]) == world
+    if workload == "loop":  # the bucketed schedule: two graphs, the large bucket's all-reduce between them (trainer.py)
+        assert line["config"]["dist"]["gradient_buckets"] == 2 and line["config"]["dist"]["world_size"] == world
     assert line["replicas_identical"] is True
     assert line["value"] > 0 and line["final_loss"] == line["final_loss"]
 
