@@ -57,7 +57,7 @@ __device__ __forceinline__ int sample_of(const BatchInfo& bi, int batch, int i) 
 // voxel_generator.py:257-264: c = floor((p - range_min) / voxel_size) per axis, dropped if c < 0 or c >= grid
 __global__ void assign_kernel(const float* __restrict__ pts, int n_total, int C, BatchInfo bi, int batch,
                               liso_pillar_cfg cfg, int* __restrict__ cell_of_point, int* __restrict__ count,
-                              int* __restrict__ first_enc) {
+                              int* __restrict__ first_enc, int* __restrict__ pos_in_cell) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     int cell = -1;
     if (i < n_total) {
@@ -70,20 +70,25 @@ __global__ void assign_kernel(const float* __restrict__ pts, int n_total, int C,
         if (ok) cell = (sample_of(bi, batch, i) * cfg.gx + (int)cx) * cfg.gy + (int)cy;
         cell_of_point[i] = cell;
     }
-    // adjacent LiDAR returns hit the same pillar: one pair of atomics per (wave, pillar) instead of one per point.  The first
-    // lane of a group of equal cells is the group's smallest point index (lanes are in point order).
+    // Adjacent LiDAR returns hit the same pillar: one pair of atomics per RUN of equal cells in the wave, all runs in ONE atomic
+    // instruction (round 4 walked the distinct cells of the wave one after the other: 64 single-lane atomic instructions per wave on
+    // clouds in random point order, 69 us per call).  The returning add gives every run a private range of its cell's segment:
+    // pos_in_cell = range start + offset inside the run -- unique per point, which is all seg_fill_kernel needs (arrival order is
+    // restored by seg_place_kernel from the indices themselves).
     const int lane = threadIdx.x & 63;
-    unsigned long long todo = __ballot(cell >= 0);
-    while (todo) {
-        const int src = __ffsll((long long)todo) - 1;
-        const int k = __shfl(cell, src);
-        const unsigned long long same = __ballot(cell == k);
-        if (lane == src) {
-            atomicAdd(&count[k], __popcll(same));
-            atomicMax(&first_enc[k], INT_MAX - i);  // == atomicMin over i with a zero-initialised array
-        }
-        todo &= ~same;
+    const int prev = __shfl_up(cell, 1);
+    const unsigned long long heads = __ballot(lane == 0 || cell != prev);
+    const unsigned long long below = heads & ((2ull << lane) - 1ull);        // heads at or below this lane (never empty: lane 0 is one)
+    const int head_lane = 63 - __builtin_clzll(below);
+    const unsigned long long above = lane == 63 ? 0ull : heads & ~((2ull << lane) - 1ull);
+    const int next_head = above ? __ffsll((long long)above) - 1 : 64;
+    int base = 0;
+    if (cell >= 0 && head_lane == lane) {
+        base = atomicAdd(&count[cell], next_head - lane);  // (the run ends in front of the next head)
+        atomicMax(&first_enc[cell], INT_MAX - i);          // == atomicMin over i with a zero-initialised array (the head is the run's smallest i)
     }
+    base = __shfl(base, head_lane);
+    if (i < n_total) pos_in_cell[i] = cell >= 0 ? base + (lane - head_lane) : 0;
 }
 
 __device__ __forceinline__ bool is_first(const int* cell_of_point, const int* first_enc, int i) {
@@ -164,11 +169,10 @@ __global__ __launch_bounds__(kTile) void rank_kernel(const int* __restrict__ cel
 // through rocPRIM's stable radix sort: ~20 launches of its merge passes per call, memset nodes inside (the encoder had to stay in front
 // of every hipGraph) and 2.7 % of the loop's kernel time.  No sort is needed:
 //   cell_scan_*   exclusive prefix of the per-cell point counts (assign_kernel has them) -> every cell owns a segment of `seg`
-//   seg_fill      every point drops its index into its cell's segment (atomic cursor: arbitrary order inside the segment)
-//   seg_place     every point of a kept pillar counts the smaller indices in its segment = its arrival rank r; r < max_points ->
-//                 slots[v][r] = index.  The scan stops at max_points smaller indices (the point is dropped anyway), which bounds the
-//                 work of a crowded cell by ~20 n ln(n / 20) reads instead of n^2 (all points in one pillar: still milliseconds apart
-//                 from seconds).  Ranks are a property of the index set: the result does not depend on the order the atomics ran in.
+//   seg_fill      every point drops its index into its cell's segment at the position assign_kernel's returning add gave it (arbitrary
+//                 order inside the segment, no atomic)
+//   voxel_slots   one wave per kept pillar: the max_points smallest indices of its segment in ascending order = its slots (arrival
+//                 order).  A property of the index set: the result does not depend on the order the atomics ran in.
 constexpr int kScanTile = 1024;
 __global__ __launch_bounds__(kScanTile) void cell_scan_block_kernel(const int* __restrict__ count, size_t cells, int* __restrict__ seg_off,
                                                                     int* __restrict__ block_tot) {
@@ -204,33 +208,51 @@ __global__ __launch_bounds__(1024) void cell_scan_tot_kernel(int* __restrict__ b
 }
 
 __global__ __launch_bounds__(256) void seg_fill_kernel(const int* __restrict__ cell_of_point, int n_total, const int* __restrict__ seg_off,
-                                                       const int* __restrict__ block_tot, int* __restrict__ cursor,
+                                                       const int* __restrict__ block_tot, const int* __restrict__ pos_in_cell,
                                                        int* __restrict__ seg) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_total) return;
     const int c = cell_of_point[i];
     if (c < 0) return;
-    const int pos = seg_off[c] + block_tot[c / kScanTile] + atomicAdd(&cursor[c], 1);
-    seg[pos] = i;
+    seg[seg_off[c] + block_tot[c / kScanTile] + pos_in_cell[i]] = i;  // (positions come from assign_kernel's returning adds: no atomic here)
 }
 
-__global__ __launch_bounds__(256) void seg_place_kernel(const int* __restrict__ cell_of_point, int n_total, const int* __restrict__ seg_off,
-                                                        const int* __restrict__ block_tot, const int* __restrict__ count,
-                                                        const int* __restrict__ seg, const int* __restrict__ cell_to_voxel,
-                                                        int max_points, int* __restrict__ slots) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_total) return;
-    const int c = cell_of_point[i];
-    if (c < 0) return;
-    const int v = cell_to_voxel[c] - 1;
-    if (v < 0) return;  // the pillar fell beyond max_voxels
+// One wave per kept pillar: the max_points smallest indices of its segment, in ascending order = its slots.  n <= 64: every lane holds
+// one index and counts the smaller ones (its arrival rank).  Crowded pillars: max_points rounds of "smallest index above the last one"
+// over the whole segment (coalesced re-reads of a cached segment; 1 000 points: 16 loads per lane and round).  (A thread per POINT that
+// walks its cell's segment -- the first form of this kernel -- took 144-165 us on the bench's clouds: the few pillars next to the sensor
+// hold hundreds of points and every lane of their waves walks them all.)
+__global__ __launch_bounds__(256) void voxel_slots_kernel(const int* __restrict__ coors, const int* __restrict__ num_voxels, int max_voxels,
+                                                          int batch, int gx, int gy, const int* __restrict__ seg_off,
+                                                          const int* __restrict__ block_tot, const int* __restrict__ count,
+                                                          const int* __restrict__ seg, int max_points, int* __restrict__ slots) {
+    const int lane = threadIdx.x & 63;
+    const long v = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (v >= (long)batch * max_voxels) return;
+    const int b = (int)(v / max_voxels), ord = (int)(v % max_voxels);
+    if (ord >= num_voxels[b]) return;
+    const int c = (b * gx + coors[v * 4 + 2]) * gy + coors[v * 4 + 3];
     const int off = seg_off[c] + block_tot[c / kScanTile], n = count[c];
-    int r = 0;
-    for (int j = 0; j < n; j++) {
-        r += seg[off + j] < i ? 1 : 0;
-        if (r >= max_points) return;  // max_points earlier arrivals: this point is not kept
+    int* out = slots + (size_t)v * max_points;
+    if (n <= 64) {
+        const int e = lane < n ? seg[off + lane] : 0x7fffffff;
+        int r = 0;
+        for (int k = 0; k < n; k++) r += __shfl(e, k) < e ? 1 : 0;
+        if (lane < n && r < max_points) out[r] = e;
+        return;
     }
-    slots[(size_t)v * max_points + r] = i;
+    int last = -1;
+    for (int r = 0; r < max_points; r++) {
+        int m = 0x7fffffff;
+        for (int j = lane; j < n; j += 64) {
+            const int x = seg[off + j];
+            m = (x > last && x < m) ? x : m;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = min(m, __shfl_xor(m, o));
+        if (lane == 0) out[r] = m;
+        last = m;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -770,9 +792,9 @@ size_t liso_pillars_voxelize_workspace_bytes(const liso_pillar_cfg* cfg, int bat
     if (!cfg_ok(cfg, batch) || n_total < 0) return 0;
     const size_t cells = (size_t)batch * cfg->gx * cfg->gy;
     const size_t tiles = (size_t)(n_total + kTile - 1) / kTile + batch;
-    // count | first_enc | seg_off | cursor [cells each], cell_of_point | seg [n each], tile counts, scan block totals
+    // count | first_enc | seg_off [cells each], cell_of_point | pos_in_cell | seg [n each], tile counts, scan block totals
     if (cells > (size_t)4096 * kScanTile) return 0;  // (the one-block pass over the scan's block totals holds 4096 of them: 4 M cells)
-    return (4 * cells + 2 * (size_t)n_total + tiles + 64 + 4096) * sizeof(int) + 256;
+    return (3 * cells + 3 * (size_t)n_total + tiles + 64 + 4096) * sizeof(int) + 256;
 }
 
 int liso_pillars_voxelize_f32(const float* points, const int* offsets_host, int batch, const liso_pillar_cfg* cfg,
@@ -795,19 +817,18 @@ int liso_pillars_voxelize_f32(const float* points, const int* offsets_host, int 
     int* tile_count = cell_of_point + n_total;
     const size_t tiles_cap = (size_t)(n_total + kTile - 1) / kTile + batch;
     int* seg_off = tile_count + tiles_cap + 32;
-    int* cursor = seg_off + cells;
-    int* seg = cursor + cells;
+    int* pos_in_cell = seg_off + cells;
+    int* seg = pos_in_cell + n_total;
     int* block_tot = seg + n_total;
     const BatchInfo bi = make_batch(offsets_host, batch);
     const int tiles = bi.tile_off[batch];
     if (liso_zero::zero_async(count, 2 * cells * sizeof(int), st) != hipSuccess) return LISO_ELAUNCH;
-    if (liso_zero::zero_async(cursor, cells * sizeof(int), st) != hipSuccess) return LISO_ELAUNCH;
     if (liso_zero::zero_async(cell_to_voxel, cells * sizeof(int), st) != hipSuccess) return LISO_ELAUNCH;
     if (liso_zero::zero_async(num_voxels, batch * sizeof(int), st) != hipSuccess) return LISO_ELAUNCH;
     if (n_total == 0) return LISO_OK;
     const int nb = (n_total + 255) / 256;
     hipLaunchKernelGGL(assign_kernel, dim3(nb), dim3(256), 0, st, points, n_total, cfg->n_channels, bi, batch, *cfg,
-                       cell_of_point, count, first_enc);
+                       cell_of_point, count, first_enc, pos_in_cell);
     hipLaunchKernelGGL(tile_count_kernel, dim3(tiles), dim3(kTile), 0, st, cell_of_point, first_enc, bi, batch,
                        tile_count);
     hipLaunchKernelGGL(rank_kernel, dim3(tiles), dim3(kTile), 0, st, cell_of_point, first_enc, count, bi, batch, *cfg,
@@ -815,8 +836,10 @@ int liso_pillars_voxelize_f32(const float* points, const int* offsets_host, int 
     const int scan_blocks = (int)((cells + kScanTile - 1) / kScanTile);
     cell_scan_block_kernel<<<scan_blocks, kScanTile, 0, st>>>(count, cells, seg_off, block_tot);
     cell_scan_tot_kernel<<<1, 1024, 0, st>>>(block_tot, scan_blocks);
-    seg_fill_kernel<<<nb, 256, 0, st>>>(cell_of_point, n_total, seg_off, block_tot, cursor, seg);
-    seg_place_kernel<<<nb, 256, 0, st>>>(cell_of_point, n_total, seg_off, block_tot, count, seg, cell_to_voxel, cfg->max_points, slots);
+    seg_fill_kernel<<<nb, 256, 0, st>>>(cell_of_point, n_total, seg_off, block_tot, pos_in_cell, seg);
+    const long n_wave = (long)batch * cfg->max_voxels;
+    voxel_slots_kernel<<<(unsigned)((n_wave + 3) / 4), 256, 0, st>>>(coors, num_voxels, cfg->max_voxels, batch, cfg->gx, cfg->gy, seg_off,
+                                                                   block_tot, count, seg, cfg->max_points, slots);
     return check_launch();
 }
 
