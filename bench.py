@@ -155,6 +155,12 @@ KERNELS = {  # timer name -> (kernel description, bound, unit of `units`)
     "conv_bf16_wgrad": ("conv_wgrad_rs3_kernel<bf16> (3x3 / stride 1: all taps per block, row-stationary fragments, loader + MFMA waves) "
                         "and conv_wgrad_kernel<bf16> (other geometries): weight gradient, split over pixels", "mfma", "flop"),
     "conv_f32x3_fwd": ("conv_igemm_kernel<bf16x3> forward (fp32 tensors, hi/lo bf16 split, 3 MFMAs per product)", "mfma", "flop"),
+    "conv_f32x3_fwd_roles": ("conv_roles_kernel<bf16x3> forward (3x3 / stride 1: loader waves + MFMA waves on double-buffered LDS, persistent "
+                             "blocks; fp32 tensors, hi/lo bf16 split, 3 MFMAs per product)", "mfma", "flop"),
+    "conv_f32x3_dgrad_roles": ("conv_roles_kernel<bf16x3> data gradient (3x3 / stride 1, mirrored taps)", "mfma", "flop"),
+    "conv_bf16_fwd_roles": ("conv_roles_kernel<bf16> forward (3x3 / stride 1: loader waves + MFMA waves on double-buffered LDS, persistent "
+                            "blocks; fused BN-apply prologue / bias+ReLU+BN-statistics epilogue)", "mfma", "flop"),
+    "conv_bf16_dgrad_roles": ("conv_roles_kernel<bf16> data gradient (3x3 / stride 1, mirrored taps)", "mfma", "flop"),
     "conv_f32x3_dgrad": ("conv_igemm_kernel<bf16x3> data gradient", "mfma", "flop"),
     "conv_f32x3_wgrad": ("conv_wgrad_rs3_kernel<bf16x3> / conv_wgrad_kernel<bf16x3> weight gradient", "mfma", "flop"),
     "conv_f32_fwd": ("conv_igemm_kernel<f32> forward (exact fp32 on v_mfma_f32_32x32x2_f32)", "mfma", "flop"),
@@ -227,12 +233,14 @@ def pmc_traffic(workload, patterns):
 
 
 # (template argument 1 of the convolution kernels = arithmetic: 0 bf16, 1 f32x3; forward and data gradient share the kernel)
-PMC_PATTERNS = {"conv_bf16_fwd": ["conv_igemm_kernel<0,"], "conv_bf16_dgrad": ["conv_igemm_kernel<0,"], "conv_bf16_wgrad": ["conv_wgrad_kernel<0,|conv_wgrad_rs3_kernel<0,"],
+PMC_PATTERNS = {"conv_f32x3_fwd_roles": ["conv_roles_kernel<1,"], "conv_f32x3_dgrad_roles": ["conv_roles_kernel<1,"],
+                "conv_bf16_fwd_roles": ["conv_roles_kernel<0,"], "conv_bf16_dgrad_roles": ["conv_roles_kernel<0,"],
+                "conv_bf16_fwd": ["conv_igemm_kernel<0,"], "conv_bf16_dgrad": ["conv_igemm_kernel<0,"], "conv_bf16_wgrad": ["conv_wgrad_kernel<0,|conv_wgrad_rs3_kernel<0,"],
                 "conv_f32x3_fwd": ["conv_igemm_kernel<1,"], "conv_f32x3_dgrad": ["conv_igemm_kernel<1,"], "conv_f32x3_wgrad": ["conv_wgrad_kernel<1,|conv_wgrad_rs3_kernel<1,"],
                 "conv_f32_fwd": ["conv_igemm_kernel<2,"], "conv_f32_dgrad": ["conv_igemm_kernel<2,"], "conv_f32_wgrad": ["conv_wgrad_kernel<2,"],
                 "knn_query": ["knn_query_kernel"], "corr_lookup_fwd": ["corr_lookup_fwd_kernel"],
                 "pfn_forward_scatter": ["pfn_forward_kernel"],
-                "dbscan_components": ["dbscan_core_kernel", "dbscan_union_kernel", "dbscan_flatten_kernel"]}
+                "dbscan_components": ["dbscan_core_kernel", "dbscan_union_tiled_kernel", "dbscan_flatten_kernel"]}
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -172,6 +172,7 @@ SIGNATURES = {
     "liso_conv_packed_bytes": (_sz, [_i, _i, _i, _i]),
     "liso_conv_pack_weights": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "liso_conv_stats_rows": (_i, [_vp]),
+    "liso_conv_kernel_kind": (_i, [_vp]),
     "liso_conv_forward": (_i, [_vp] * 10),
     "liso_conv_set_option": (_i, [_i, _i]),
     "liso_conv_forward_sparse": (_i, [_vp] * 11),

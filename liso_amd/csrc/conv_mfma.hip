@@ -1846,6 +1846,12 @@ int liso_conv_pack_weights_batched(const liso_conv_pack_job* jobs, int n_jobs, v
     return check_launch();
 }
 
+int liso_conv_kernel_kind(const liso_conv_desc* d) {
+    Plan p;
+    if (!d || !make_plan(*d, &p)) return -1;
+    return p.a.roles ? 1 : (p.a.a8 ? 2 : 0);
+}
+
 int liso_conv_stats_rows(const liso_conv_desc* d) {
     Plan p;
     if (!d || !make_plan(*d, &p)) return -1;

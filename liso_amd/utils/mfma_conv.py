@@ -294,8 +294,13 @@ def _vec(mode):
     return 8 if mode == L.CONV_BF16 else 4
 
 
-def _timer_name(mode, kind):
-    return ("conv_bf16_" if mode == L.CONV_BF16 else "conv_f32x3_" if mode == L.CONV_F32X3 else "conv_f32_") + kind
+def _timer_name(mode, kind, d=None):
+    """timer family of a launch; forward / data-gradient launches of conv_roles_kernel get their own families (bench.py's `roofline`
+    is about ONE kernel: rocprofv3 lists conv_roles_kernel and conv_igemm_kernel separately, so does the timer)"""
+    name = ("conv_bf16_" if mode == L.CONV_BF16 else "conv_f32x3_" if mode == L.CONV_F32X3 else "conv_f32_") + kind
+    if d is not None and L.TIMER.enabled and L.lib().liso_conv_kernel_kind(ctypes.byref(d)) == 1:
+        name += "_roles"
+    return name
 
 
 def _flops(d):
@@ -364,7 +369,7 @@ def conv_forward(x, weight, bias, spec, in_scale=None, in_shift=None, in_relu=Fa
         occ = occupancy
         assert occ.dtype == torch.float32 and occ.is_contiguous() and occ.numel() == B * hi * wi, (occ.shape, occ.dtype)
     with torch.cuda.device(x.device):
-        L.check(L.TIMER.launch(_timer_name(mode, "fwd"), lambda: lib.liso_conv_forward_sparse(
+        L.check(L.TIMER.launch(_timer_name(mode, "fwd", d), lambda: lib.liso_conv_forward_sparse(
             ctypes.byref(d), L.ptr(xv), L.ptr(packed), L.ptr(b) if b is not None else None,
             L.ptr(in_scale) if in_scale is not None else None, L.ptr(in_shift) if in_shift is not None else None, L.ptr(y_base),
             L.ptr(stats) if stats is not None else None, L.ptr(stats_shift) if stats_shift is not None else None,
@@ -411,7 +416,7 @@ def conv_dgrad(dy, weight, spec, x_shape, out_dtype=None, packed=None):
     if packed is None:
         packed = pack_weights(weight, spec, True, mode)
     with torch.cuda.device(dy.device):
-        L.check(L.TIMER.launch(_timer_name(mode, "dgrad"), lambda: L.lib().liso_conv_forward(
+        L.check(L.TIMER.launch(_timer_name(mode, "dgrad", d), lambda: L.lib().liso_conv_forward(
             ctypes.byref(d), L.ptr(gv), L.ptr(packed), None, None, None, L.ptr(dx), None, None, L.stream_ptr()), units=_flops(d), nbytes=_bytes(d)),
             "conv_dgrad")
     return dx.permute(0, 3, 1, 2)
