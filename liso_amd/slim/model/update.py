@@ -127,7 +127,10 @@ class SmallUpdateBlock(nn.Module):
         big[..., :ch].copy_(net.permute(0, 2, 3, 1))
         big[..., ch:ch + ci].copy_(inp.permute(0, 2, 3, 1))
         x0, x1 = ch, ch + ci + co + cc + cf  # channels of x = (inp, out, class, flow)
-        key = (me.conv.weight._version, me.conv.weight.data_ptr(), gru.convq.weight._version, gru.convq.weight.data_ptr())
+        fh, hd = self.static_flow_head, self.classification_head
+        tracked = (me.conv.weight, gru.convq.weight, me.conv_flow2.weight, me.conv_class2.weight, me.conv_flow2.bias, me.conv_class2.bias,
+                   fh.conv2.weight, hd.conv2.weight, fh.conv2.bias, hd.conv2.bias)
+        key = tuple((t._version, t.data_ptr()) for t in tracked)
         hit = getattr(self, "_infer_perm", None)
         if hit is None or hit[0] != key:
             with torch.no_grad():
@@ -136,9 +139,29 @@ class SmallUpdateBlock(nn.Module):
                 w_conv = torch.nn.Parameter(torch.cat([wc[:, :cq], wc[:, cq + cf:cq + cf + cc], wc[:, cq:cq + cf]], dim=1).contiguous(),
                                             requires_grad=False)
                 w_q = torch.nn.Parameter(torch.cat([wq[:, ch:], wq[:, :ch]], dim=1).contiguous(), requires_grad=False)
-            hit = self._infer_perm = (key, w_conv, w_q)
+                # block-diagonal pairs: ONE launch for conv_class2 | conv_flow2 on the (class1 | flow1) map, ONE for the two heads' output
+                # convolutions on the merged hidden map.  The added products are exact zeros and every filter still sees its own
+                # channels in their own order: results are bit for bit those of the separate convolutions.
+                c1c, c1f = me.conv_class2.in_channels, me.conv_flow2.in_channels
+                w_cf = torch.zeros((cc + cf, c1c + c1f, 3, 3), dtype=wc.dtype, device=wc.device)
+                w_cf[:cc, :c1c] = me.conv_class2.weight
+                w_cf[cc:, c1c:] = me.conv_flow2.weight
+                b_cf = torch.cat([me.conv_class2.bias, me.conv_flow2.bias])
+                of, oc, hf, hc = fh.conv2.out_channels, hd.conv2.out_channels, fh.conv2.in_channels, hd.conv2.in_channels
+                w_hd = torch.zeros((of + oc, hf + hc, 3, 3), dtype=wc.dtype, device=wc.device)
+                w_hd[:of, :hf] = fh.conv2.weight
+                w_hd[of:, hf:] = hd.conv2.weight
+                b_hd = torch.cat([fh.conv2.bias, hd.conv2.bias])
+                P = lambda t: torch.nn.Parameter(t.contiguous(), requires_grad=False)  # noqa: E731
+            hit = self._infer_perm = (key, w_conv, w_q, P(w_cf), P(b_cf), P(w_hd), P(b_hd))
+        merged = (os.environ.get("LISO_UPDATE_MERGED", "1") != "0" and tuple(me.conv_class2.kernel_size) == (3, 3)
+                  and tuple(me.conv_flow2.kernel_size) == (3, 3) and tuple(fh.conv2.kernel_size) == (3, 3) and tuple(hd.conv2.kernel_size) == (3, 3)
+                  and me.conv_class1.out_channels % 8 == 0 and me.conv_flow1.out_channels % 8 == 0)
         return {"big": big, "m": m, "ch": ch, "ci": ci, "co": co, "cc": cc, "cf": cf, "cq": cq, "x0": x0, "x1": x1,
-                "w_conv": hit[1], "w_q": hit[2], "z": torch.empty((B, H, W, ch), dtype=torch.float32, device=net.device)}
+                "w_conv": hit[1], "w_q": hit[2], "w_cf": hit[3], "b_cf": hit[4], "w_hd": hit[5], "b_hd": hit[6], "merged": merged,
+                "c1": torch.empty((B, H, W, me.conv_class1.out_channels + me.conv_flow1.out_channels), dtype=torch.float32, device=net.device)
+                if merged else None,
+                "z": torch.empty((B, H, W, ch), dtype=torch.float32, device=net.device)}
 
     def forward_inference(self, st, corr, flow, logits):
         """one update iteration on the buffers of `inference_state` -> (net view, delta_static_flow, delta_logits, None)"""
@@ -154,8 +177,16 @@ class SmallUpdateBlock(nn.Module):
         o_out, o_cls, o_flow, o_rh = ch + ci, ch + ci + co, ch + ci + co + cc, st["x1"]
         bign, mn = big.permute(0, 3, 1, 2), m.permute(0, 3, 1, 2)
         MC.conv2d(me.conv_stat_corr1, corr, relu=True, out=(m, 0))
-        MC.conv2d(me.conv_flow2, MC.conv2d(me.conv_flow1, flow, relu=True), relu=True, out=(big, o_flow))
-        MC.conv2d(me.conv_class2, MC.conv2d(me.conv_class1, logits, relu=True), relu=True, out=(big, o_cls))
+        if st["merged"]:  # (class1 | flow1) into one map, then conv_class2 | conv_flow2 as ONE block-diagonal launch -> big[class | flow]
+            c1 = st["c1"]
+            k1 = me.conv_class1.out_channels
+            MC.conv2d(me.conv_class1, logits, relu=True, out=(c1, 0))
+            MC.conv2d(me.conv_flow1, flow, relu=True, out=(c1, k1))
+            MC.fused_conv(c1.permute(0, 3, 1, 2), None, types.SimpleNamespace(weight=st["w_cf"], bias=st["b_cf"]), out_relu=True,
+                          spec=MC.ConvSpec.of(me.conv_class2), out=(big, o_cls))
+        else:
+            MC.conv2d(me.conv_flow2, MC.conv2d(me.conv_flow1, flow, relu=True), relu=True, out=(big, o_flow))
+            MC.conv2d(me.conv_class2, MC.conv2d(me.conv_class1, logits, relu=True), relu=True, out=(big, o_cls))
         m[..., cq:].copy_(big[..., o_cls:o_rh])  # (class, flow): the one copy left, 64 of the 656 channels the concatenations moved
         MC.fused_conv(mn, None, types.SimpleNamespace(weight=st["w_conv"], bias=me.conv.bias), out_relu=True, spec=MC.ConvSpec.of(me.conv),
                       out=(big, o_out))
@@ -174,6 +205,10 @@ class SmallUpdateBlock(nn.Module):
         net = bign[:, :ch]
         fh, hd = self.static_flow_head, self.classification_head
         hid = conv2d_pair(fh.conv1, hd.conv1, net, relu=True)
+        if st["merged"]:  # both heads' output convolutions as ONE block-diagonal launch on the merged hidden map
+            both, _ = MC.fused_conv(hid, None, types.SimpleNamespace(weight=st["w_hd"], bias=st["b_hd"]), spec=MC.ConvSpec.of(fh.conv2))
+            of = fh.conv2.out_channels
+            return net, both[:, :of], both[:, of:], None
         hid_f, hid_c = torch.split(hid, [fh.conv1.out_channels, hd.conv1.out_channels], dim=1)
         return net, conv2d(fh.conv2, hid_f), conv2d(hd.conv2, hid_c), None
 

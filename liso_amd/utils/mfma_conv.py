@@ -1212,7 +1212,6 @@ def conv2d(layer, x, relu=False, occupancy=None, out=None):
     spec = ConvSpec.of(layer)
     if x.is_cuda and backend() == "mfma" and supported(x, layer.weight, spec):
         return fused_conv(x, None, layer, out_relu=relu, spec=spec, occupancy=occupancy if x.dtype == torch.float32 else None, out=out)[0]
-    assert out is None, "conv2d(out=...): only on the own kernels"
     if x.is_cuda and backend() == "mfma" and x.dtype in (torch.bfloat16, torch.float32) and not spec.transposed:
         # 1-3 (7) input channels -- the motion encoder's conv_flow1: 7x7 on the 2-channel flow, liso/slim/model/update.py:53-60 --
         # the kernels read channels in 16-B groups: zero channels (and zero filter slices) up to one group, then the own kernel
@@ -1229,6 +1228,7 @@ def conv2d(layer, x, relu=False, occupancy=None, out=None):
             wp = layer._liso_padded_weight[1]
         if supported(xp, wp, spec):
             import types
-            return fused_conv(xp, None, types.SimpleNamespace(weight=wp, bias=layer.bias), out_relu=relu, spec=spec)[0]
+            return fused_conv(xp, None, types.SimpleNamespace(weight=wp, bias=layer.bias), out_relu=relu, spec=spec, out=out)[0]
+    assert out is None, "conv2d(out=...): only on the own kernels"
     y = layer(x)
     return torch.relu(y) if relu else y
