@@ -1,5 +1,6 @@
-mkdir -p gpurun_out/r6l
-python -m pytest tests/test_gpu_slim.py tests/test_gpu_liso_loop.py tests/test_gpu_flow_io.py tests/test_gpu_parity_full_size.py -q -m gpu > gpurun_out/r6l/tests.txt 2>&1
-python scripts/stage_alone_times.py > gpurun_out/r6l/stages.txt 2>&1
-python bench.py --no-legs --no-cpu-baseline --no-iou3d --no-fp32-leg > gpurun_out/r6l/bench.txt 2>&1
-LISO_UPDATE_MERGED=0 python bench.py --no-legs --no-cpu-baseline --no-iou3d --no-fp32-leg > gpurun_out/r6l/bench_unmerged.txt 2>&1
+KRE="conv_roles_kernel|conv_igemm_kernel|conv_wgrad|pfn_|corr_lookup|knn_query|dbscan"
+bash scripts/profile_round.sh r05_loop "$KRE" > /dev/null 2>&1
+bash scripts/profile_round.sh r05_detector "$KRE" --workload detector > /dev/null 2>&1
+bash scripts/profile_round.sh r05_slim "$KRE" --workload slim --graph > /dev/null 2>&1
+bash scripts/profile_round.sh r05_stress "$KRE" --workload stress > /dev/null 2>&1
+du -sh gpurun_out/r05_*
