@@ -607,7 +607,9 @@ __global__ __launch_bounds__(kThreads * SK, SK == 1 ? 2 : 1) void conv_igemm_ker
 template <int MI, int NJ>
 __device__ __forceinline__ void roles_flush_stats(const FwdArgs& a, int b, int ty, int tx, int n0, int tid_all, const unsigned char* smem) {
     constexpr int BNT = 32 * NJ;
-    if (tid_all >= BNT) return;
+    // (a 96-channel panel may reach beyond the padded filter count -- co = 64: co_pad = 64 -- where the statistics rows have no columns:
+    // found by tests/test_gpu_conv_roles.py with a forced tile shape; the planner's own choices never had such a panel write statistics)
+    if (tid_all >= BNT || n0 + tid_all >= a.co_pad) return;
     const float* red = reinterpret_cast<const float*>(smem);
 #pragma unroll
     for (int g = 0; g < MI; g++) {
