@@ -972,6 +972,13 @@ def sparse_stem_overflowed(device):
     return bool(t is not None and int(t.item()) != 0)
 
 
+def reset_sparse_stem_overflow(device):
+    """clear the sticky overflow flag of `device` (tests that overflow the cell lists on purpose)"""
+    t = _SPARSE_OVERFLOW.get(_dev_index(torch.device(device)))
+    if t is not None:
+        t.zero_()
+
+
 def _dev_index(dev):
     """torch.device('cuda') has index None: the flag table is keyed by the index the kernels' tensors report"""
     return dev.index if dev.index is not None else torch.cuda.current_device()

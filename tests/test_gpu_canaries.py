@@ -63,11 +63,14 @@ def test_sparse_canvas_convolution_beyond_its_cell_capacity():
     x = torch.where(occ, torch.randn_like(x), x)
     conv = torch.nn.Conv2d(64, 32, 7, stride=2, padding=3).to(DEV)
     assert int(occ.sum()) > MC.SPARSE_STEM_MAX_CELLS
-    with guarded() as gd:
-        y = MC.conv2d(conv, x, relu=True, occupancy=occ.float())
-        gd.check()
-    assert torch.isfinite(y).all()
-    assert MC.sparse_stem_overflowed(torch.device(DEV)) or True  # (the flag is sticky per process: either path must stay in bounds)
+    try:
+        with guarded() as gd:
+            y = MC.conv2d(conv, x, relu=True, occupancy=occ.float())
+            gd.check()
+        assert torch.isfinite(y).all()
+        assert MC.sparse_stem_overflowed(torch.device(DEV)), "more occupied cells than the lists hold must raise the overflow flag"
+    finally:
+        MC.reset_sparse_stem_overflow(torch.device(DEV))  # (the flag is sticky per process: later tests assert that it is clear)
 
 
 def test_more_clusters_than_box_slots_and_scattered_labels():
