@@ -1144,437 +1144,6 @@ __global__ __launch_bounds__(512, 1) void conv_roles_kernel(const liso_conv_desc
     }
 }
 
-// ---- 8 waves, weight panels by LDS-DMA ------------------------------------------------------------------------------------------------
-// The kernel above stages BOTH operands through registers and, whenever the panels of a slab do not fit one register batch (every 3x3
-// layer with 64-channel panels), runs load -> store -> barrier -> multiply strictly one after the other: at one block per CU nothing
-// overlaps and a slab costs 3-4 load latencies (measured 7-8 us per slab on the ConvGRU layers, 1.4 us of it MFMA).  This kernel:
-//   * 512 threads = 8 waves = an 8 x 32 pixel tile (one row per wave) x BNT channels: two waves per SIMD, half the weight re-reads
-//     of the 4-row tile;
-//   * the pre-packed weight panels need no transformation on the way to LDS -> they are streamed by LDS-DMA (global_load_lds_dwordx4:
-//     no VGPRs, asynchronous) into a ring of `ring` stages of `stage_taps` taps; the DMA of stage s + ring - 1 is issued before the
-//     MFMAs of stage s and waited for with a COUNTED vmcnt right before the barrier that precedes its first read (a raw s_barrier:
-//     __syncthreads() would drain the ring);
-//   * the input halo tile of the next slab (prologue / hi-lo split on the way: registers) is loaded during the first stage of a slab
-//     and written to LDS behind the last one.
-template <int MODE, int NJ, bool OUT_F32, int CS>
-__global__ __launch_bounds__(512, 1) void conv_igemm8_kernel(const liso_conv_desc d, const FwdArgs a) {
-    constexpr int NT = 512, TH = 8;
-    constexpr int BNT = 32 * NJ;
-    constexpr bool X3 = MODE == LISO_CONV_F32X3;
-    constexpr int PLANES = X3 ? 2 : 1;
-    constexpr int PS = CS * 2 + 16;
-    constexpr int KS = CS / 16;
-    constexpr int K8 = CS / 8;
-    constexpr int PSZ = K8 * BNT;   // 16-B chunks of one panel (one tap, one plane): a multiple of 64
-    constexpr int WTAP = PSZ * 16;
-    static_assert(PSZ % 64 == 0, "a DMA instruction moves 64 chunks");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    typedef __attribute__((address_space(3))) void* lds_ptr_t;
-    typedef const __attribute__((address_space(1))) void* glb_ptr_t;
-
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
-    int t = xcd_remap(blockIdx.x, a.total);
-    const int nt = t % a.n_nt;
-    t /= a.n_nt;
-    const int tx = t % a.tiles_x;
-    t /= a.tiles_x;
-    const int ty = t % a.tiles_y;
-    t /= a.tiles_y;
-    const int b = t % d.batch;
-    const int cls = t / d.batch;
-    const int stats_row = ((cls * d.batch + b) * a.tiles_y + ty) * a.tiles_x + tx;
-    const int n0 = nt * BNT;
-    const int tb = d.class_tap_begin[cls], te = d.class_tap_begin[cls + 1];
-    const int dy0 = a.cls_dy0[cls], dx0 = a.cls_dx0[cls], in_h = a.cls_inh[cls], in_w = a.cls_inw[cls];
-    const int npix = in_h * in_w;
-    const float inv_w = 1.0f / (float)in_w;
-    const int iy0 = ty * TH * d.isy + dy0, ix0 = tx * 32 * d.isx + dx0;
-
-    int* s_toff = reinterpret_cast<int*>(smem);
-    int* s_tapw = s_toff + 64;
-    unsigned char* xs = smem + 512;
-    unsigned char* wring = xs + a.x_plane_bytes * PLANES;
-    const int G = a.stage_taps, R = a.ring;
-    const int stage_bytes = G * PLANES * WTAP;
-    // per-tap constants live in registers: lane i of every wave holds tap i (<= 49 taps), fetched with v_readlane -- an LDS table
-    // would put a dependent LDS read (and its in-order lgkmcnt wait) in front of every fragment read
-    int v_toff = 0, v_tapw = 0;
-    if (lane < te - tb) {
-        v_toff = ((d.tap_dy[tb + lane] - dy0) * in_w + (d.tap_dx[tb + lane] - dx0)) * PS;
-        v_tapw = d.tap_w[tb + lane];
-    }
-    (void)s_toff;
-    (void)s_tapw;
-    const int a_off = ((wave * d.isy) * in_w + r * d.isx) * PS + h * 16;
-    int b_off[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; j++) b_off[j] = (h * BNT + j * 32 + r) * 16;
-    f16v acc[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; j++)
-#pragma unroll
-        for (int e = 0; e < 16; e++) acc[j][e] = 0.0f;
-
-    const int n_taps = te - tb;
-    const int kgroups_total = a.ci_pad >> 3;
-    const long x_img = (long)b * d.hi * d.wi;
-    const unsigned short* wg = (const unsigned short*)a.w;
-    const long plane_elems = (long)d.w_taps * kgroups_total * a.co_pad * 8;
-
-    constexpr int CPP = X3 ? CS / 4 : K8;
-    constexpr int CHN = X3 ? 4 : 8;
-    constexpr int pstep = NT / CPP;
-    constexpr int XB = 6;  // 16-B loads per thread: the plan guarantees that the halo tile of one slab fits (npix * CPP <= XB * NT)
-    const int cx = tid % CPP, p0 = tid / CPP;
-    const int step_y = pstep / in_w, step_x = pstep - step_y * in_w;
-    const unsigned char* xbase = (const unsigned char*)a.x + x_img * d.x_pix_stride * (X3 ? 4 : 2);
-    const bool pro = a.in_scale != nullptr;
-    const int aff_off = b * d.in_affine_batch_stride;
-
-    uint4 xv[XB];
-    unsigned xok = 0u;
-    auto load_x = [&](int c0) {
-        const int ch = c0 + cx * CHN;
-        const bool ch_ok = ch < d.ci;
-        int ly = (int)(((float)p0 + 0.5f) * inv_w);
-        int lx = p0 - ly * in_w;
-        xok = 0u;
-#pragma unroll
-        for (int u = 0; u < XB; u++) {
-            const int pix = p0 + u * pstep;
-            const int iy = iy0 + ly, ix = ix0 + lx;
-            const bool ok = pix < npix && ch_ok && (unsigned)iy < (unsigned)d.hi && (unsigned)ix < (unsigned)d.wi;
-            xok |= ok ? (1u << u) : 0u;
-            const int off = ok ? (iy * d.wi + ix) * d.x_pix_stride + ch : 0;
-            xv[u] = *reinterpret_cast<const uint4*>(xbase + (long)off * (X3 ? 4 : 2));
-            lx += step_x;
-            ly += step_y;
-            if (lx >= in_w) {
-                lx -= in_w;
-                ly++;
-            }
-        }
-    };
-    auto store_x = [&](int c0) {
-        const int ch = c0 + cx * CHN;
-        const bool ch_ok = ch < d.ci;
-        float sc[CHN], sh[CHN];
-        if (pro) {
-#pragma unroll
-            for (int e = 0; e < CHN; e++) {
-                sc[e] = ch_ok ? a.in_scale[aff_off + ch + e] : 0.0f;
-                sh[e] = ch_ok ? a.in_shift[aff_off + ch + e] : 0.0f;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < XB; u++) {
-            const int pix = p0 + u * pstep;
-            if (pix >= npix) continue;
-            const bool ok = (xok >> u) & 1u;
-            if constexpr (!X3) {
-                uint4 o = xv[u];
-                if (pro) {
-                    unsigned w[4] = {o.x, o.y, o.z, o.w};
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        float f0 = fmaf(bf16_lo(w[e]), sc[2 * e], sh[2 * e]);
-                        float f1 = fmaf(bf16_hi(w[e]), sc[2 * e + 1], sh[2 * e + 1]);
-                        if (d.in_relu) {
-                            f0 = fmaxf(f0, 0.0f);
-                            f1 = fmaxf(f1, 0.0f);
-                        }
-                        w[e] = pack_bf16(f0, f1);
-                    }
-                    o = make_uint4(w[0], w[1], w[2], w[3]);
-                }
-                if (!ok) o = make_uint4(0u, 0u, 0u, 0u);
-                *reinterpret_cast<uint4*>(xs + pix * PS + cx * 16) = o;
-            } else {
-                float f[4] = {__uint_as_float(xv[u].x), __uint_as_float(xv[u].y), __uint_as_float(xv[u].z), __uint_as_float(xv[u].w)};
-                unsigned hi2[2], lo2[2];
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    if (pro) {
-                        f[e] = fmaf(f[e], sc[e], sh[e]);
-                        if (d.in_relu) f[e] = fmaxf(f[e], 0.0f);
-                    }
-                    if (!ok) f[e] = 0.0f;
-                }
-#pragma unroll
-                for (int e = 0; e < 2; e++) {
-                    const float h0 = round_bf16(f[2 * e]), h1 = round_bf16(f[2 * e + 1]);
-                    hi2[e] = pack_bf16(h0, h1);
-                    lo2[e] = pack_bf16(f[2 * e] - h0, f[2 * e + 1] - h1);
-                }
-                *reinterpret_cast<uint2*>(xs + pix * PS + cx * 8) = make_uint2(hi2[0], hi2[1]);
-                *reinterpret_cast<uint2*>(xs + a.x_plane_bytes + pix * PS + cx * 8) = make_uint2(lo2[0], lo2[1]);
-            }
-        }
-    };
-
-    const int ngrp = (n_taps + G - 1) / G;
-    const int nslab = (d.ci + CS - 1) / CS;
-    const int NS = nslab * ngrp;
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);  // (scalar: the per-stage bookkeeping below stays on the scalar unit)
-    // DMA of one weight stage: 16-B chunk q of the stage = (tap g, plane, 8-channel group c8, output channel n); one instruction
-    // moves chunks [i * 64, i * 64 + 64) to LDS bytes [i * 1024, ...): wave w issues instructions w, w + 8, ...
-    // Stages are identified by (slab, group); every group but the last of a slab has G taps.  No division inside the loop.
-    const int g_last = n_taps - (ngrp - 1) * G;
-    const int chunks_full = G * PLANES * PSZ, chunks_last = g_last * PLANES * PSZ;
-    auto count_of = [&](int chunks) { return chunks > wave_u * 64 ? (chunks - wave_u * 64 + NT - 1) / NT : 0; };
-    const int cnt_full = count_of(chunks_full), cnt_last = count_of(chunks_last);  // instructions THIS wave issues per stage
-    // per-lane part of a DMA source address: the 64 chunks of one instruction lie inside ONE panel (PSZ % 64 == 0) and cover
-    // 64 / BNT consecutive channel groups x BNT output channels
-    const int lane_c8 = lane / BNT, lane_n = lane % BNT;
-    const long lane_elems = ((long)lane_c8 * a.co_pad + lane_n) * 8;
-    auto dma_stage = [&](int slab, int grp, int ring_idx) {
-        const int s0 = grp * G, c0 = slab * CS;
-        const int chunks = grp == ngrp - 1 ? chunks_last : chunks_full;
-        unsigned char* buf = wring + ring_idx * stage_bytes;
-        for (int q0 = wave_u * 64; q0 < chunks; q0 += NT) {  // (scalar loop: q0 is wave-uniform)
-            const int panel = q0 / PSZ, inner0 = q0 % PSZ;
-            const int g = panel / PLANES, plane = panel % PLANES;
-            const int kg0 = (c0 >> 3) + inner0 / BNT;
-            const int tw = __builtin_amdgcn_readlane(v_tapw, s0 + g);
-            const long base = (long)plane * plane_elems + ((long)(tw * kgroups_total + kg0) * a.co_pad + n0) * 8;
-            if (kg0 + lane_c8 < kgroups_total) {
-                // LDS-DMA as inline asm: through the builtin hipcc treats every later ds_read as a possible alias of the DMA's LDS
-                // write and drains the whole ring with s_waitcnt vmcnt(0) in front of each stage's first fragment read.  Here the
-                // waits are counted by hand (wait_vm below) and the "memory" clobber keeps LDS accesses on their side of it.
-                const unsigned lds_dst = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(lds_ptr_t)(buf + q0 * 16));
-                const unsigned short* gsrc = wg + base + lane_elems;
-                unsigned keep;
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep)
-                             : "v"(gsrc), "s"(lds_dst)
-                             : "memory");
-            } else  // channel groups beyond the (padded) input channels: zeros (the staged x is 0 there, but 0 x garbage may be NaN)
-                *reinterpret_cast<uint4*>(buf + (q0 + lane) * 16) = make_uint4(0u, 0u, 0u, 0u);
-        }
-    };
-    auto wait_vm = [&](int n) {  // s_waitcnt vmcnt(<= n) lgkmcnt(0): the operand is an immediate
-        if (n >= 24) asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)" ::: "memory");
-        else if (n >= 16) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
-        else if (n >= 12) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
-        else if (n >= 9) asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");
-        else if (n >= 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-        else if (n >= 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-        else if (n >= 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
-        else if (n >= 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-        else if (n >= 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
-        else if (n >= 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-        else if (n >= 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    };
-    // one (tap, 16-channel k-step) of the stage: the A fragment of this wave's pixel row and the NJ B fragments (hi | lo planes)
-    struct Frag {
-        uint4 ah, al, bh[NJ], bl[NJ];
-    };
-    auto mfma_stage = [&](int grp, int ring_idx) {
-        const int s0 = grp * G, g_cur = grp == ngrp - 1 ? g_last : G;
-        const unsigned char* buf = wring + ring_idx * stage_bytes;
-        const int total = g_cur * KS;
-        auto ldf = [&](int st, Frag& f) {
-            if (a.dbg & 32) return;  // (experiments: MFMAs on whatever the registers hold)
-            const int g = st / KS, kk = st % KS;  // (KS is a power of two)
-            const unsigned char* xa = xs + a_off + __builtin_amdgcn_readlane(v_toff, s0 + g) + kk * 32;
-            const unsigned char* wt = buf + g * (PLANES * WTAP) + kk * (2 * BNT * 16);
-            f.ah = *reinterpret_cast<const uint4*>(xa);
-#pragma unroll
-            for (int j = 0; j < NJ; j++) f.bh[j] = *reinterpret_cast<const uint4*>(wt + b_off[j]);
-            if constexpr (X3) {
-                f.al = *reinterpret_cast<const uint4*>(xa + a.x_plane_bytes);
-#pragma unroll
-                for (int j = 0; j < NJ; j++) f.bl[j] = *reinterpret_cast<const uint4*>(wt + WTAP + b_off[j]);
-            }
-        };
-        auto mma = [&](const Frag& f) {
-#pragma unroll
-            for (int j = 0; j < NJ; j++) {
-                if constexpr (X3) {
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(f.al), as_bf8(f.bh[j]), acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(f.ah), as_bf8(f.bl[j]), acc[j], 0, 0, 0);
-                }
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(f.ah), as_bf8(f.bh[j]), acc[j], 0, 0, 0);
-            }
-        };
-        // fragments of step st + 1 are read from LDS while the matrix cores work on step st (two register sets)
-        // (every read below is unconditional -- the index is clamped instead -- so that hipcc can count the reads in flight and wait
-        // with lgkmcnt(n) for the older set only; behind a branch it falls back to lgkmcnt(0) and the prefetch buys nothing)
-        Frag f0, f1;
-        if (a.dbg & 32) {
-            f0.ah = f0.al = f1.ah = f1.al = make_uint4(tid, tid * 3, tid * 5, tid * 7);
-#pragma unroll
-            for (int j = 0; j < NJ; j++) f0.bh[j] = f0.bl[j] = f1.bh[j] = f1.bl[j] = make_uint4(tid + j, tid * 9, tid * 11, tid * 13);
-        }
-        ldf(0, f0);
-        const int last = total - 1;
-        // sched_barrier: hipcc otherwise sinks every read to just in front of its MFMA (distance 1-2 MFMAs < the LDS latency with 8
-        // waves reading at once) and the matrix pipe idles half of the time (measured: 47 % busy in the compute-only variant)
-        __builtin_amdgcn_sched_barrier(0);
-        for (int pr2 = 0; pr2 < (total >> 1); pr2++) {
-            ldf(2 * pr2 + 1, f1);
-            __builtin_amdgcn_sched_barrier(0);
-            mma(f0);
-            __builtin_amdgcn_sched_barrier(0);
-            ldf(min(2 * pr2 + 2, last), f0);
-            __builtin_amdgcn_sched_barrier(0);
-            mma(f1);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (total & 1) mma(f0);
-    };
-
-    // ---- main loop --------------------------------------------------------------------------------------------------------------
-    // (slab, grp) of the stage being multiplied: cs / cg, ring slot cr; of the next stage to prefetch: ps / pg / pr
-    __syncthreads();  // tap tables
-    load_x(0);
-    int ps = 0, pg = 0, pr = 0, issued = 0;
-    auto advance_prefetch = [&]() {
-        if (++pg == ngrp) {
-            pg = 0;
-            ps++;
-        }
-        if (++pr == R) pr = 0;
-        issued++;
-    };
-    for (; issued < R - 1 && issued < NS;) {
-        dma_stage(ps, pg, pr);
-        advance_prefetch();
-    }
-    store_x(0);
-    __syncthreads();  // (drains everything: the tile of slab 0 and the first stages are in LDS)
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), visible to hipcc's wait-count bookkeeping: no load is pending from here on
-    int cr = 0, s = 0;
-    for (int slab = 0; slab < nslab; slab++) {
-        const bool more_slabs = slab + 1 < nslab;
-        for (int grp = 0; grp < ngrp; grp++, s++) {
-            if (issued < NS && !(a.dbg & 2)) {  // stage s + R - 1, into the buffer stage s - 1 was read from (barrier at its end)
-                dma_stage(ps, pg, pr);
-                advance_prefetch();
-            } else if (issued < NS) {
-                advance_prefetch();
-            }
-            if (grp == 0 && more_slabs && !(a.dbg & 4)) load_x((slab + 1) * CS);  // registers until the last stage of this slab
-            if (!(a.dbg & 1)) mfma_stage(grp, cr);
-            if (++cr == R) cr = 0;
-            if (grp == ngrp - 1 && more_slabs) {
-                __syncthreads();          // every wave is done with this slab's tile
-                if (!(a.dbg & 8)) store_x((slab + 1) * CS);
-                __syncthreads();          // (full drain once per slab: the tile and every stage in flight have landed)
-                __builtin_amdgcn_s_waitcnt(0x0F70);
-            } else if (s + 1 < NS) {
-                // stage s + 1 must have landed: younger than its DMA are the stages s + 2 .. s + R - 1 (as far as they exist) and, while
-                // they are younger than DMA(s + 1), the XB tile loads of this slab
-                int younger = 0, gj = grp + 1;  // group index of stage s + 1 (same slab: grp < ngrp - 1, or no more slabs)
-                for (int k = s + 2; k <= s + R - 1 && k < NS; k++) {
-                    if (++gj >= ngrp) gj -= ngrp;
-                    younger += gj == ngrp - 1 ? cnt_last : cnt_full;
-                }
-                if (more_slabs && s + 2 - R <= s - grp) younger += XB;
-                wait_vm(younger);
-                __builtin_amdgcn_s_barrier();
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- epilogue (one tile row per wave; see conv_igemm_kernel) ------------------------------------------------------------------
-    const bool want_stats = a.stats != nullptr;
-    float s1[NJ], s2[NJ];
-    const int ooy = d.class_ooy[cls], oox = d.class_oox[cls];
-    const int col_stride = d.osx * d.y_pix_stride;
-    unsigned colmask = 0;
-#pragma unroll
-    for (int e = 0; e < 16; e++) {
-        const int vx = tx * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (vx < d.wv && vx * d.osx + oox < d.wo) colmask |= 1u << e;
-    }
-    const int col0 = (tx * 32 + 4 * h) * d.osx + oox;
-    const int vy = ty * TH + wave;
-    const int oy = vy * d.osy + ooy;
-    const unsigned rowmask = (vy < d.hv && oy < d.ho && !(a.dbg & 16)) ? colmask : 0u;
-    const long row_base = (((long)b * d.ho + oy) * d.wo + col0) * d.y_pix_stride + d.y_ch_off;
-#pragma unroll
-    for (int j = 0; j < NJ; j++) {
-        s1[j] = 0.0f;
-        s2[j] = 0.0f;
-        const int n = n0 + j * 32 + r;
-        const bool n_ok = n < d.co;
-        const float bias_v = (a.bias && n_ok) ? a.bias[n] : 0.0f;
-        const float shift_v = (a.stats_shift && n_ok) ? a.stats_shift[n] : 0.0f;
-        float v[16];
-#pragma unroll
-        for (int e = 0; e < 16; e++) {
-            float val = acc[j][e] + bias_v;
-            if (d.out_relu) val = fmaxf(val, 0.0f);
-            if constexpr (!OUT_F32) val = round_bf16(val);
-            v[e] = val;
-            if (want_stats && ((rowmask >> e) & 1u)) {
-                const float dd = val - shift_v;
-                s1[j] += dd;
-                s2[j] = fmaf(dd, dd, s2[j]);
-            }
-        }
-        if constexpr (OUT_F32) {
-            float* yg = (float*)a.y + row_base + n;
-#pragma unroll
-            for (int e = 0; e < 16; e++)
-                if (((rowmask >> e) & 1u) && n_ok) yg[((e & 3) + 8 * (e >> 2)) * col_stride] = v[e];
-        } else {
-            unsigned short* yg = (unsigned short*)a.y + row_base;
-            const bool odd = r & 1;
-            const int n_even = n & ~1;
-            if ((d.y_pix_stride | d.y_ch_off) & 1) {
-#pragma unroll
-                for (int e = 0; e < 16; e++)
-                    if (((rowmask >> e) & 1u) && n_ok)
-                        yg[((e & 3) + 8 * (e >> 2)) * col_stride + n] = (unsigned short)(pack_bf16(v[e], 0.0f) & 0xffffu);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 16; e += 2) {
-                    const float send = odd ? v[e] : v[e + 1];
-                    const float recv = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(send), 0xB1, 0xF, 0xF, true));
-                    const float c_lo = odd ? recv : v[e];
-                    const float c_hi = odd ? v[e + 1] : recv;
-                    const int ee = odd ? e + 1 : e;
-                    const int koff = odd ? ((e + 1) & 3) + 8 * ((e + 1) >> 2) : (e & 3) + 8 * (e >> 2);
-                    if ((rowmask >> ee) & 1u) {
-                        unsigned short* dst = yg + koff * col_stride + n_even;
-                        if (n_even + 1 < d.co)
-                            *reinterpret_cast<unsigned*>(dst) = pack_bf16(c_lo, c_hi);
-                        else if (n_even < d.co)
-                            *dst = (unsigned short)(pack_bf16(c_lo, 0.0f) & 0xffffu);
-                    }
-                }
-            }
-        }
-    }
-    if (want_stats) {
-        float* red = reinterpret_cast<float*>(smem);  // [8 waves][BNT][2]
-#pragma unroll
-        for (int j = 0; j < NJ; j++) {
-            const float t1 = s1[j] + __shfl_xor(s1[j], 32);
-            const float t2 = s2[j] + __shfl_xor(s2[j], 32);
-            if (h == 0) {
-                red[(wave * BNT + j * 32 + r) * 2 + 0] = t1;
-                red[(wave * BNT + j * 32 + r) * 2 + 1] = t2;
-            }
-        }
-        __syncthreads();
-        if (tid < BNT) {
-            float q1 = 0.0f, q2 = 0.0f;
-#pragma unroll
-            for (int w = 0; w < 8; w++) {
-                q1 += red[(w * BNT + tid) * 2 + 0];
-                q2 += red[(w * BNT + tid) * 2 + 1];
-            }
-            a.stats[((long)stats_row * 2 + 0) * a.co_pad + n0 + tid] = q1;
-            a.stats[((long)stats_row * 2 + 1) * a.co_pad + n0 + tid] = q2;
-        }
-    }
-}
-
 // ---- weight packing ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void pack_chunk(const float* __restrict__ src, int d1, int taps, int swap_ab, int K, int N, int Kp, int Np,
                                            int f32, unsigned short* __restrict__ dst, long q);
@@ -1744,19 +1313,6 @@ __global__ __launch_bounds__(256) void residual_affine_relu_kernel(const float4*
 
 int check_launch() { return hipGetLastError() == hipSuccess ? LISO_OK : LISO_ELAUNCH; }
 
-template <int MODE, int NJ, bool OUT_F32, int CS>
-int launch8(const liso_conv_desc& d, const Plan& p, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)conv_igemm8_kernel<MODE, NJ, OUT_F32, CS>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024) != hipSuccess)
-            return LISO_ELAUNCH;
-        attr_set = true;
-    }
-    conv_igemm8_kernel<MODE, NJ, OUT_F32, CS><<<p.a.total, 512, p.lds, st>>>(d, p.a);
-    return check_launch();
-}
-
 template <int MODE, int MI, int NJ, bool OUT_F32, int NTAPS, bool PRO>
 int launch_roles_pro(const liso_conv_desc& d, const Plan& p, hipStream_t st) {
     static bool attr_set = false;
@@ -1851,7 +1407,7 @@ int liso_conv_pack_weights_batched(const liso_conv_pack_job* jobs, int n_jobs, v
 int liso_conv_kernel_kind(const liso_conv_desc* d) {
     Plan p;
     if (!d || !make_plan(*d, &p)) return -1;
-    return p.a.roles ? 1 : (p.a.a8 ? 2 : 0);
+    return p.a.roles ? 1 : 0;
 }
 
 int liso_conv_stats_rows(const liso_conv_desc* d) {
@@ -1883,7 +1439,6 @@ int liso_conv_forward_sparse(const liso_conv_desc* d, const void* x, const void*
     p.a.stats = stats_partial;
     p.a.stats_shift = stats_shift;
     p.a.occ = occupancy;
-    if (occupancy) p.a.a8 = 0;  // (the tile-skipping test lives in the 4-wave kernel; conv_roles_kernel computes the dense result)
     hipStream_t st = (hipStream_t)stream;
     const bool x3 = d->mode == LISO_CONV_F32X3;
     const bool of32 = x3 || d->out_f32;
@@ -1915,17 +1470,6 @@ int liso_conv_forward_sparse(const liso_conv_desc* d, const void* x, const void*
         }
 #undef LISO_ROLES
         return LISO_EINVAL;
-    }
-    if (p.a.a8) {
-#define LISO_GO8(MODE, OF, CSA, CSB)                                                                                  \
-    do {                                                                                                              \
-        if (p.nj == 2) return p.cs == CSA ? launch8<MODE, 2, OF, CSA>(*d, p, st) : launch8<MODE, 2, OF, CSB>(*d, p, st); \
-        return p.cs == CSA ? launch8<MODE, 1, OF, CSA>(*d, p, st) : launch8<MODE, 1, OF, CSB>(*d, p, st);               \
-    } while (0)
-        if (x3) LISO_GO8(LISO_CONV_F32X3, true, 32, 16);
-        if (of32) LISO_GO8(LISO_CONV_BF16, true, 64, 32);
-        LISO_GO8(LISO_CONV_BF16, false, 64, 32);
-#undef LISO_GO8
     }
     if (x3 && p.sk == 2)
         return p.cs == 32 ? launch<LISO_CONV_F32X3, 1, 1, true, 32, 2>(*d, p, st) : launch<LISO_CONV_F32X3, 1, 1, true, 16, 2>(*d, p, st);

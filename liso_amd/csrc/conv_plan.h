@@ -32,10 +32,7 @@ struct FwdArgs {
     int slab_pipelined; // one register batch holds a whole slab (tile + the panels of all taps): what the SK = 2 kernel needs
     int group_bytes;    // LDS bytes of one split-K group's tile + panels (SK = 2 instantiations)
     const float* occ;   // optional [batch, hi, wi]: 0 = the input pixel is exactly zero in every channel (sparse BEV canvases)
-    int a8;             // 8-wave kernel with the weight panels streamed by LDS-DMA (conv_igemm8_kernel)
-    int stage_taps;     // a8: taps per weight stage
-    int ring;           // a8: weight stages resident in LDS (2..4): stage s + ring - 1 is in flight while stage s is multiplied
-    int dbg;            // experiments (LISO_CONV_DBG): 1 = no MFMAs, 2 = no weight DMA, 4 = no tile loads (results are garbage)
+    int dbg;            // (unused: experiment switches of removed kernels)
     int roles;          // conv_roles_kernel (loader waves + MFMA waves, double-buffered LDS): 3x3 / 1x1, stride 1, one class
     int wide_out;       // roles: 16-byte output stores through an LDS patch (channel count and strides allow them)
     unsigned long long roles_tapw;  // roles: 4 bits per window position (ty * 3 + tx): the tap's index inside the packed weights
@@ -56,7 +53,7 @@ void plan_roles(const liso_conv_desc& d, Plan* p) {
     FwdArgs& a = p->a;
     a.roles = 0;
     static const int roles_env = getenv("LISO_CONV_ROLES") ? atoi(getenv("LISO_CONV_ROLES")) : 1;
-    if (!roles_env || a.a8 || d.mode == LISO_CONV_F32) return;
+    if (!roles_env || d.mode == LISO_CONV_F32) return;
     if (d.n_classes != 1 || d.isy != 1 || d.isx != 1 || d.osy != 1 || d.osx != 1 || d.n_taps != 9) return;
     const bool x3 = d.mode == LISO_CONV_F32X3;
     if (!x3 && d.ci % 32) return;  // (bf16 slabs are 32 channels: no half-filled last slab in the loaders' branch-free loop)
@@ -288,55 +285,9 @@ bool make_plan(const liso_conv_desc& d, Plan* p) {
         p->sk = 2;
     if (const char* e = getenv("LISO_CONV_SK")) p->sk = (atoi(e) >= 2 && p->sk == 2) ? 2 : 1;  // experiments
     if (p->sk == 2) p->lds = 512 + 2 * a.group_bytes;
-    // ---- 8-wave kernel with LDS-DMA weight stages (conv_igemm8_kernel): 8-row tiles, >= 2 taps, the halo tile of one slab within
-    // one register batch (6 x 16 B per thread), >= 2 weight stages in LDS, and enough tiles to occupy the chip
-    // MEASURED (round 3, scripts/bench_conv.py with LISO_CONV_A8=0 | 1): correct on every geometry of tests/test_gpu_conv.py, but
-    // not faster than the 4-wave kernel above -- ConvGRU 400->192 at B = 4: 115 vs 119 us, most 3x3 layers of the detector 5-30 %
-    // SLOWER (one block per CU: the per-block prologue / epilogue is no longer hidden by a second resident block).  The ablations
-    // behind it (LISO_CONV_DBG) showed why the "latency floor" reading of round 2 was wrong: with loads, LDS reads and stores all
-    // switched off the bare MFMA stream of that layer still takes 72 us on 192 CUs = 1.26 PFLOP/s chip-equivalent -- the matrix
-    // cores sustain about half of the 2.5 PFLOP/s paper peak on random data (clock under load), so the 4-wave kernel already runs
-    // at 45-60 % of the practical ceiling on the large layers.  Off unless LISO_CONV_A8=1.
-    a.a8 = 0;
-    int want8 = 0;
-    if (const char* e = getenv("LISO_CONV_A8")) want8 = atoi(e);  // experiments: 1 whenever possible, 2 automatic
-    if (want8 && !f32 && max_taps >= 2) {
-        int inh[LISO_CONV_MAX_CLASSES], inw[LISO_CONV_MAX_CLASSES], y0s[LISO_CONV_MAX_CLASSES], x0s[LISO_CONV_MAX_CLASSES];
-        const int max_pix8 = tile_pixels(8, inh, inw, y0s, x0s);
-        const int cs8 = a.ci_pad > cs_opts[1] ? cs_opts[0] : cs_opts[1];
-        const int cpp8 = fin ? cs8 / 4 : cs8 / 8;
-        const int xb8 = round_up(max_pix8 * pix_bytes(cs8), 16);
-        const int g8 = max_taps >= 49 ? 7 : (max_taps >= 9 ? 3 : max_taps);
-        const int stage8 = g8 * panel_bytes(cs8, bnt);
-        int ring8 = (159 * 1024 - 512 - xb8 * planes) / stage8;
-        ring8 = ring8 > 4 ? 4 : ring8;
-        const int nstages = ((d.ci + cs8 - 1) / cs8) * ((max_taps + g8 - 1) / g8);
-        ring8 = ring8 > nstages + 1 ? nstages + 1 : ring8;
-        const long blocks8 = blocks(8);
-        const bool fits = max_pix8 * cpp8 <= 6 * 512 && ring8 >= 2;
-        if (fits && (want8 == 1 || (blocks8 >= 96 && d.hv >= 6))) {
-            a.a8 = 1;
-            a.dbg = 0;
-            if (const char* e = getenv("LISO_CONV_DBG")) a.dbg = atoi(e);
-            a.stage_taps = g8;
-            a.ring = ring8;
-            p->mi = 1;
-            p->cs = cs8;
-            p->sk = 1;
-            a.cs = cs8;
-            a.x_plane_bytes = xb8;
-            p->lds = 512 + xb8 * planes + ring8 * stage8;
-            if (p->lds < 8192) p->lds = 8192;  // the statistics epilogue reuses the front of the buffer ([8][64][2] floats)
-            for (int c = 0; c < d.n_classes; c++) {
-                a.cls_dy0[c] = y0s[c];
-                a.cls_dx0[c] = x0s[c];
-                a.cls_inh[c] = inh[c];
-                a.cls_inw[c] = inw[c];
-            }
-            a.tiles_y = (d.hv + 7) / 8;
-            a.total = (int)blocks8;
-        }
-    }
+    // (rounds 3-4 kept an 8-wave variant with LDS-DMA weight stages, conv_igemm8_kernel, behind LISO_CONV_A8: correct, never faster
+    // than this kernel -- one block per CU, every wave both loads and multiplies; round 5's conv_roles_kernel is the role-split form
+    // that works, and the experiment was removed)
     plan_roles(d, p);
     return true;
 }

@@ -14,7 +14,7 @@ static int rnd(int n) {
 
 static int check(const liso_conv_desc& d, const Plan& p, long it) {
     const FwdArgs& a = p.a;
-    const int bnt = 32 * p.nj, th = a.a8 ? 8 : 4 * p.mi;
+    const int bnt = 32 * p.nj, th = 4 * p.mi;
 #define REQUIRE(c)                                                                     \
     if (!(c)) {                                                                        \
         printf("FAIL descriptor %ld: %s (mi %d nj %d cs %d lds %d roles %d)\n", it, #c, p.mi, p.nj, p.cs, p.lds, a.roles); \
@@ -31,7 +31,7 @@ static int check(const liso_conv_desc& d, const Plan& p, long it) {
         REQUIRE(d.n_taps == 9 && d.n_classes == 1);
         for (int pos = 0; pos < 9; pos++) REQUIRE((int)((a.roles_tapw >> (4 * pos)) & 15ull) < d.w_taps);
         REQUIRE(a.cs == (d.mode == LISO_CONV_F32X3 ? 16 : 32));
-    } else if (!a.a8) {
+    } else {
         REQUIRE(a.g_taps >= 1 && a.x_plane_bytes % 16 == 0 && a.x_plane_bytes > 0);
     }
     return 0;

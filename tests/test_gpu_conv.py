@@ -220,34 +220,6 @@ def test_fused_conv_autograd_chain_matches_torch_modules(beta_lo, beta_hi, fmode
         assert int(bns[i].num_batches_tracked) == 1
 
 
-@pytest.mark.parametrize("geom", [GEOMS[0], GEOMS[2], GEOMS[7], GEOMS[10], GEOMS[15]])
-@pytest.mark.parametrize("arith", ARITH[:2])
-def test_eight_wave_dma_kernel_matches_fp64(geom, arith, monkeypatch):
-    """conv_igemm8_kernel (8 waves, weight panels streamed by LDS-DMA with counted waits; off by default, LISO_CONV_A8=1): forward and
-    data gradient against torch in fp64 on the geometries it accepts"""
-    from liso_amd.utils import mfma_conv as MC
-
-    monkeypatch.setenv("LISO_CONV_A8", "1")
-    dtype, fmode = arith
-    MC.set_fp32_mode(fmode)
-    B, Ci, Co, H, W, k, s, p, tr = geom
-    x, w, b = _mk(geom, dtype)
-    spec = MC.ConvSpec(k, k, s, p, tr)
-    xd = x.to(dtype).cuda().contiguous(memory_format=torch.channels_last)
-    y, _ = MC.conv_forward(xd, w.cuda(), b.cuda(), spec, out_dtype=torch.float32)
-    ref = _ref_conv(x, w, b, s, p, tr)
-    tol = 2e-5 if dtype == torch.bfloat16 else 6e-5
-    assert _rel(y, ref) <= tol, _rel(y, ref)
-    g = torch.Generator().manual_seed(7)
-    dy = torch.randn(ref.shape, generator=g)
-    if dtype == torch.bfloat16:
-        dy = dy.bfloat16().float()
-    x64 = x.double().requires_grad_(True)
-    gx, = torch.autograd.grad(_ref_conv(x64, w, b, s, p, tr), [x64], dy.double())
-    dx = MC.conv_dgrad(dy.to(dtype).cuda().contiguous(memory_format=torch.channels_last), w.cuda(), spec, tuple(x.shape), out_dtype=torch.float32)
-    assert _rel(dx, gx) <= tol, _rel(dx, gx)
-
-
 @pytest.mark.parametrize("arith", ARITH[:2])
 def test_sparse_input_tile_skipping_is_bit_identical(arith):
     """liso_conv_forward_sparse: with the occupancy map of a sparse canvas (3 % of the cells occupied, clustered) the blocks whose
