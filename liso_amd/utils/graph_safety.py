@@ -21,7 +21,8 @@ Rules the captured regions of this package follow:
   2. global reductions inside a captured region go through `two_stage_amax / two_stage_amin / two_stage_sum` below (every stage
      is reduced by one block per output: no semaphores, no memset);
   3. device sorts / scans whose input depends on the sweeps only are computed eagerly and copied in (BevGatherPlan, the
-     dynamicness threshold, the pillar encoder's radix sort);
+     dynamicness threshold; until round 4 also the pillar encoder's rocPRIM radix sort -- the voxeliser no longer sorts or calls any
+     library, csrc/pillars.hip);
   4. a region that cannot follow 1-3 (the SLIM *training* graph: autograd's reductions) is only captured when
      DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 is set: `require_node_replay()` raises otherwise.
 """
