@@ -144,7 +144,7 @@ def slim_algorithmic_bytes(batch, n_points, grid, levels=4, radius=3, directions
     w2 = (2 * radius + 1) ** 2
     lookup = directions * batch * (levels * hw * w2 * 4 * 4 + hw * levels * w2 * 4)
     outputs = 6 * directions * batch * (grid * grid * 8 * 4 + hw * 6 * 4)
-    return {"corr_lookup_fwd": lookup, "corr_lookup_bwd": lookup, "knn_query": 2 * n_points * 12 + n_points * 8,
+    return {"corr_lookup_fwd": lookup, "corr_lookup_fwd_tiled": lookup, "corr_lookup_bwd": lookup, "knn_query": 2 * n_points * 12 + n_points * 8,
             "raft_outputs_fwd": outputs, "raft_outputs_bwd": outputs}
 
 
@@ -169,6 +169,7 @@ KERNELS = {  # timer name -> (kernel description, bound, unit of `units`)
     "pfn_forward_scatter": ("pfn_forward_kernel (Linear+BN+ReLU+max + dense scatter from CSR feature rows)", "hbm", "bytes"),
     "pfn_decorate": ("pfn_decorate_kernel (+3 scan kernels)", "hbm", "bytes"),
     "corr_lookup_fwd": ("corr_lookup_fwd_kernel (on-the-fly 4-level correlation + bilinear lookup)", "hbm", "bytes"),
+    "corr_lookup_fwd_tiled": ("corr_lookup_tiled_kernel (4 x 8 queries share the rows they correlate with: bf16x3 MFMA + bilinear lookup from LDS)", "hbm", "bytes"),
     "corr_lookup_bwd": ("corr_lookup_bwd_kernel (adjoint of the lookup into the dense volume gradient)", "hbm", "bytes"),
     "knn_query": ("knn_query_kernel (exact 1-NN, two-level bucket grid with z bins, 16 lanes per query)", "hbm", "bytes"),
     "raft_outputs_fwd": ("upsample_fwd_kernel (x8 bilinear upsampling + flow convention + concat of all RAFT iterations)", "hbm", "bytes"),
@@ -238,7 +239,7 @@ PMC_PATTERNS = {"conv_f32x3_fwd_roles": ["conv_roles_kernel<1,"], "conv_f32x3_dg
                 "conv_bf16_fwd": ["conv_igemm_kernel<0,"], "conv_bf16_dgrad": ["conv_igemm_kernel<0,"], "conv_bf16_wgrad": ["conv_wgrad_kernel<0,|conv_wgrad_rs3_kernel<0,"],
                 "conv_f32x3_fwd": ["conv_igemm_kernel<1,"], "conv_f32x3_dgrad": ["conv_igemm_kernel<1,"], "conv_f32x3_wgrad": ["conv_wgrad_kernel<1,|conv_wgrad_rs3_kernel<1,"],
                 "conv_f32_fwd": ["conv_igemm_kernel<2,"], "conv_f32_dgrad": ["conv_igemm_kernel<2,"], "conv_f32_wgrad": ["conv_wgrad_kernel<2,"],
-                "knn_query": ["knn_query_kernel"], "corr_lookup_fwd": ["corr_lookup_fwd_kernel"],
+                "knn_query": ["knn_query_kernel"], "corr_lookup_fwd": ["corr_lookup_fwd_kernel"], "corr_lookup_fwd_tiled": ["corr_lookup_tiled_kernel"],
                 "pfn_forward_scatter": ["pfn_forward_kernel"],
                 "dbscan_components": ["dbscan_core_kernel", "dbscan_union_tiled_kernel", "dbscan_flatten_kernel"]}
 

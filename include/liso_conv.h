@@ -104,6 +104,11 @@ int liso_conv_stats_rows(const liso_conv_desc* d);
  * attributes launch times to kernels (bench.py's `roofline`); the choice itself is internal. */
 int liso_conv_kernel_kind(const liso_conv_desc* d);
 
+/* the launch plan of liso_conv_forward for `d` (tests, measurement scripts): info = {kernel kind as above, tile rows / 4, panel width / 32,
+ * wave groups that share the channel slabs of a block (conv_igemm_kernel; 1 otherwise), blocks (conv_roles_kernel: tiles, walked by at
+ * most one persistent block per compute unit), LDS bytes per block, channels per slab, taps per weight stage} */
+int liso_conv_plan_info(const liso_conv_desc* d, int info[8]);
+
 /* y = conv(x') (+ bias) ; bias / in_scale / in_shift / stats_partial / stats_shift may be NULL */
 int liso_conv_forward(const liso_conv_desc* d, const void* x, const void* w_packed, const float* bias,
                       const float* in_scale, const float* in_shift, void* y, float* stats_partial,

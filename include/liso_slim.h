@@ -35,6 +35,14 @@ typedef struct {
 int liso_corr_lookup_fwd_f32(const liso_corr_cfg* cfg, const float* fmap1, const float* const* fmap2_levels,
                              const float* coords, float* out, void* stream);
 
+/* The same lookup with the rows of fmap2 shared by 4 x 8 neighbouring query pixels: one block stages the region their windows cover
+ * (clipped to the map, <= 256 rows; blocks whose queries lie further apart take the per-query path above) once and multiplies it with
+ * the block's 32 query rows on the matrix cores, fp32 operands as bf16 hi / lo pairs (hi hi + hi lo + lo hi: the arithmetic of the
+ * F32X3 convolutions of include/liso_conv.h; relative error ~2^-16 of |f1| |f2| per product, against the fp32 FMAs of
+ * liso_corr_lookup_fwd_f32).  fmap1 and every level 16-byte aligned.  Same arguments, same output layout. */
+int liso_corr_lookup_fwd_tiled_f32(const liso_corr_cfg* cfg, const float* fmap1, const float* const* fmap2_levels,
+                                   const float* coords, float* out, void* stream);
+
 /* Backward, step 1 of 2.  grad_out has the layout of `out`.  dvol_levels[i] is a dense fp32 matrix
  * [B, h*w, H_i*W_i] (zero-filled by the caller before the first call): the gradient with respect to the pooled
  * correlation volume of level i, into which this call ADDS the adjoint of its bilinear 7x7 windows (<= 64 entries per
@@ -185,6 +193,15 @@ int liso_gru_out_bwd_f32(long n, const float* cq, const float* z, const float* h
 int liso_gru_in_rows_f32(long n_pix, int ch, const float* zr, long zr_stride, const float* h, long h_stride, float* z, float* rh,
                          long rh_stride, void* stream);
 int liso_gru_out_rows_f32(long n_pix, int ch, const float* cq, long cq_stride, const float* z, float* h, long h_stride, void* stream);
+
+/* The RAFT loop's state update at inference (liso/slim/model/raft.py:199-216: coords1 = coords1 + delta_flow, logits = logits +
+ * delta_logits, and the next iteration's flow = coords1 - coords0) as ONE launch, the same fp32 operations in the same order.
+ * delta: batch * hw pixels of (flow x, flow y, logit 0..3) at `delta_stride` floats per pixel (the heads' merged output);
+ * coords0 / coords1: [batch, 2, hw] (coords1 updated in place: the correlation lookup reads it);
+ * state8: [batch * hw][8] = (flow x, flow y, logit 0..3, 0, 0), 16-byte aligned: flow overwritten, logits accumulated -- the
+ * channels-last input of the motion encoder's 7x7 convolutions (update.py:54-59 on one map). */
+int liso_raft_state_step_f32(int batch, int hw, const float* delta, long delta_stride, const float* coords0, float* coords1,
+                             float* state8, void* stream);
 
 #ifdef __cplusplus
 }

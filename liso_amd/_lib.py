@@ -108,6 +108,7 @@ SIGNATURES = {
     "liso_region_props_ws": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     # include/liso_slim.h
     "liso_corr_lookup_fwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "liso_corr_lookup_fwd_tiled_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "liso_corr_lookup_bwd_dvol_f32": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "liso_nearest_point_loss_fwd_f32": (_i, [_vp] * 8),
     "liso_nearest_point_loss_bwd_f32": (_i, [_vp] * 9),
@@ -130,6 +131,7 @@ SIGNATURES = {
     "liso_gru_out_bwd_f32": (_i, [ctypes.c_long, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "liso_gru_in_rows_f32": (_i, [ctypes.c_long, _i, _vp, ctypes.c_long, _vp, ctypes.c_long, _vp, _vp, ctypes.c_long, _vp]),
     "liso_gru_out_rows_f32": (_i, [ctypes.c_long, _i, _vp, ctypes.c_long, _vp, _vp, ctypes.c_long, _vp]),
+    "liso_raft_state_step_f32": (_i, [_i, _i, _vp, ctypes.c_long, _vp, _vp, _vp, _vp]),
     "liso_raft_upsample_scratch_bytes": (_sz, [_vp]),
     "liso_raft_upsample_outputs_fwd_f32": (_i, [_vp] * 5),
     "liso_raft_upsample_outputs_bwd_f32": (_i, [_vp, _vp, _vp, _sz, _vp, _vp, _vp]),
@@ -176,6 +178,7 @@ SIGNATURES = {
     "liso_conv_forward": (_i, [_vp] * 10),
     "liso_conv_set_option": (_i, [_i, _i]),
     "liso_conv_forward_sparse": (_i, [_vp] * 11),
+    "liso_conv_plan_info": (_i, [_vp, _vp]),
     "liso_conv_wgrad_workspace_bytes": (_sz, [_vp]),
     "liso_conv_wgrad": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "liso_conv_wgrad_sparse_workspace_bytes": (_sz, [_vp]),

@@ -1410,6 +1410,20 @@ int liso_conv_kernel_kind(const liso_conv_desc* d) {
     return p.a.roles ? 1 : 0;
 }
 
+int liso_conv_plan_info(const liso_conv_desc* d, int info[8]) {
+    Plan p;
+    if (!d || !info || !make_plan(*d, &p)) return LISO_EINVAL;
+    info[0] = p.a.roles;
+    info[1] = p.mi;
+    info[2] = p.nj;
+    info[3] = p.sk;
+    info[4] = p.a.total;
+    info[5] = p.lds;
+    info[6] = p.cs;
+    info[7] = p.a.roles ? 9 : p.g;
+    return LISO_OK;
+}
+
 int liso_conv_stats_rows(const liso_conv_desc* d) {
     Plan p;
     if (!d || !make_plan(*d, &p)) return -1;

@@ -43,27 +43,12 @@ __device__ __forceinline__ Patch patch_of(const liso_corr_cfg& c, const float* _
     return p;
 }
 
+// one (query pixel, level) by one wavefront; Pw: 64 floats, Tw: 64 x kTransposeStride floats of LDS owned by the wave
 template <int VEC>  // VEC float4 per lane: D = 128 * VEC
-__global__ __launch_bounds__(64 * kWavesPerBlock) void corr_lookup_fwd_kernel(liso_corr_cfg c,
-                                                                              const float* __restrict__ fmap1,
-                                                                              LevelPtrs lp, const float* __restrict__ coords,
-                                                                              float* __restrict__ out) {
-    __shared__ float P[kWavesPerBlock][64];
-    __shared__ float T[kWavesPerBlock][64][kTransposeStride];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__device__ __forceinline__ void lookup_one(const liso_corr_cfg& c, const float* __restrict__ fmap1, const LevelPtrs& lp,
+                                           const float* __restrict__ coords, float* __restrict__ out, int b, int pix, int lvl, int lane,
+                                           float* Pw, float (*Tw)[kTransposeStride]) {
     const int hw = c.h * c.w;
-    // XCD-aware block order: the hardware deals consecutive workgroups round-robin to the 8 XCDs, each with its own 4 MB
-    // L2.  Logical block = (physical % 8) * (blocks / 8) + physical / 8 gives every XCD one contiguous eighth of the
-    // (sample, pixel) range: its level-0 working set is then ~1/4 of one sample's feature map (0.5 MB + halo) instead of
-    // all 5.3 MB of both samples' pyramids, i.e. L2 resident.  (gridDim.x is a multiple of 8.)
-    const long per_xcd = gridDim.x / 8;
-    const long block = (long)(blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
-    const long item = block * kWavesPerBlock + wave;  // (b, pix, lvl)
-    const long total = (long)c.batch * hw * c.levels;
-    if (item >= total) return;
-    const int lvl = (int)(item % c.levels);
-    const int pix = (int)((item / c.levels) % hw);
-    const int b = (int)(item / ((long)c.levels * hw));
     const Patch pt = patch_of(c, coords, b, pix, lvl);
     const int g = lane & 31, half = lane >> 5;
     const int D = c.dim;
@@ -102,26 +87,263 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void corr_lookup_fwd_kernel(li
     // LDS (8 x 16-B writes per lane, then 32 conflict-free 4-B reads down a column; rows padded to 36 floats).  The
     // 31-shuffle butterfly this replaces (ds_bpermute) took 97 of the kernel's 123 us: measured 26 us without it.
     {
-        float4* wrow = reinterpret_cast<float4*>(&T[wave][lane][0]);
+        float4* wrow = reinterpret_cast<float4*>(&Tw[lane][0]);
 #pragma unroll
         for (int k = 0; k < 8; k++) wrow[k] = make_float4(acc[4 * k], acc[4 * k + 1], acc[4 * k + 2], acc[4 * k + 3]);
     }
     __builtin_amdgcn_wave_barrier();
     float tot = 0.f;
 #pragma unroll
-    for (int j = 0; j < 32; j++) tot += T[wave][half * 32 + j][g];  // fixed order: bit reproducible
-    P[wave][2 * g + half] = tot;
+    for (int j = 0; j < 32; j++) tot += Tw[half * 32 + j][g];  // fixed order: bit reproducible
+    Pw[2 * g + half] = tot;
     __builtin_amdgcn_wave_barrier();
     const int W7 = 2 * c.radius + 1;
     const int a = lane / W7, bb = lane % W7;  // a: x offset index, bb: y offset index (corr.py:31-35 order)
     if (lane < W7 * W7) {
         const float inv = 1.0f / sqrtf((float)D);  // corr.py:56
-        const float p00 = P[wave][bb * 8 + a], p10 = P[wave][bb * 8 + a + 1];
-        const float p01 = P[wave][(bb + 1) * 8 + a], p11 = P[wave][(bb + 1) * 8 + a + 1];
+        const float p00 = Pw[bb * 8 + a], p10 = Pw[bb * 8 + a + 1];
+        const float p01 = Pw[(bb + 1) * 8 + a], p11 = Pw[(bb + 1) * 8 + a + 1];
         const float v = (1.f - pt.fx) * (1.f - pt.fy) * p00 + pt.fx * (1.f - pt.fy) * p10 + (1.f - pt.fx) * pt.fy * p01 +
                         pt.fx * pt.fy * p11;
         const int C = c.levels * W7 * W7;
         out[((size_t)b * hw + pix) * C + lvl * W7 * W7 + lane] = v * inv;
+    }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void corr_lookup_fwd_kernel(liso_corr_cfg c, const float* __restrict__ fmap1, LevelPtrs lp,
+                                                                              const float* __restrict__ coords, float* __restrict__ out) {
+    __shared__ float P[kWavesPerBlock][64];
+    __shared__ float T[kWavesPerBlock][64][kTransposeStride];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hw = c.h * c.w;
+    // XCD-aware block order: the hardware deals consecutive workgroups round-robin to the 8 XCDs, each with its own 4 MB
+    // L2.  Logical block = (physical % 8) * (blocks / 8) + physical / 8 gives every XCD one contiguous eighth of the
+    // (sample, pixel) range: its level-0 working set is then ~1/4 of one sample's feature map (0.5 MB + halo) instead of
+    // all 5.3 MB of both samples' pyramids, i.e. L2 resident.  (gridDim.x is a multiple of 8.)
+    const long per_xcd = gridDim.x / 8;
+    const long block = (long)(blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    const long item = block * kWavesPerBlock + wave;  // (b, pix, lvl)
+    const long total = (long)c.batch * hw * c.levels;
+    if (item >= total) return;
+    const int lvl = (int)(item % c.levels);
+    const int pix = (int)((item / c.levels) % hw);
+    const int b = (int)(item / ((long)c.levels * hw));
+    lookup_one<VEC>(c, fmap1, lp, coords, out, b, pix, lvl, lane, P[wave], T[wave]);
+}
+
+// ---- tiled form: 4 x 8 neighbouring query pixels of one level share the feature rows they correlate with ---------------------------------
+// The per-query kernel above reads an 8 x 8 patch of D-channel rows per (query, level): 32 KB (D = 128) through L1 / L2 for 16 K flops,
+// 2.1 GB per lookup of 4 x 64 x 64 queries x 4 levels (84 us: the largest single kernel of the SLIM inference replay).  Neighbouring queries
+// have neighbouring centres -- the flow field is smooth at 1/8 resolution --, so the patches of a 4 x 8 block of queries cover a region of
+// (4 + 7 + spread) x (8 + 7 + spread) rows, 165 at level 0 and fewer on the pooled levels: this kernel stages that region ONCE per block,
+//     C[q][p] = < f1[q] , f2[p] >   for the block's 32 queries x the region's <= 256 rows
+// on the matrix cores (fp32 operands as bf16 hi / lo pairs, hi hi + hi lo + lo hi: the arithmetic of the F32X3 convolutions around it), and
+// every query then reads its own 8 x 8 window out of C in LDS for the 49 bilinear samples (same formula as above).  Rows outside the
+// map are zero (grid_sample's padding); the region is clipped to the map.  A block whose region would exceed 256 rows (queries whose
+// centres lie far apart: garbage flow, never seen on real sweeps) takes the per-query path, one wave per query.
+// LDS: A planes 2 x 4 KB ([k8][query][8 bf16]) | B planes 2 x 32 KB ([k8][row][8 bf16]) per 64-channel chunk; C (32 x 260 fp32) and the
+// fallback's transpose buffers alias the B planes.
+constexpr int kTQW = 8, kTQH = 4, kTQ = kTQW * kTQH, kTRMax = 256, kTKC = 64, kTCStride = kTRMax + 4;
+constexpr int kTLdsA = 2 * (kTKC / 8) * kTQ * 16;        // 8 KB
+constexpr int kTLdsB = 2 * (kTKC / 8) * kTRMax * 16;     // 64 KB
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 cbf8;
+typedef __attribute__((__vector_size__(16 * sizeof(float)))) float cf16v;
+
+__device__ __forceinline__ unsigned corr_pack_bf16(float a, float b) {  // round to nearest even, like the convolutions' split
+    unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
+    ua = (ua + 0x7fffu + ((ua >> 16) & 1u)) >> 16;
+    ub = (ub + 0x7fffu + ((ub >> 16) & 1u)) >> 16;
+    return ua | (ub << 16);
+}
+__device__ __forceinline__ float corr_round_bf16(float a) {
+    unsigned u = __float_as_uint(a);
+    u = (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;
+    return __uint_as_float(u);
+}
+// 4 floats -> 8 B of the hi plane + 8 B of the lo plane
+__device__ __forceinline__ void corr_split4(const float4 v, uint2* hi, uint2* lo) {
+    const float h0 = corr_round_bf16(v.x), h1 = corr_round_bf16(v.y), h2 = corr_round_bf16(v.z), h3 = corr_round_bf16(v.w);
+    *hi = make_uint2(corr_pack_bf16(h0, h1), corr_pack_bf16(h2, h3));
+    *lo = make_uint2(corr_pack_bf16(v.x - h0, v.y - h1), corr_pack_bf16(v.z - h2, v.w - h3));
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void corr_lookup_tiled_kernel(liso_corr_cfg c, const float* __restrict__ fmap1, LevelPtrs lp,
+                                                                const float* __restrict__ coords, float* __restrict__ out, int tiles_x,
+                                                                int tiles_y) {
+    constexpr int D = 128 * VEC;
+    __shared__ int q_x0[kTQ], q_y0[kTQ], q_pix[kTQ];
+    __shared__ float q_fx[kTQ], q_fy[kTQ];
+    __shared__ int reg[4];  // region: x0, y0, width, height
+    __shared__ float Pf[kWavesPerBlock][64];
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // kTLdsA + kTLdsB bytes
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hw = c.h * c.w;
+    const long per_xcd = gridDim.x / 8;
+    long item = (long)(blockIdx.x % 8) * per_xcd + blockIdx.x / 8;  // ((b, lvl), ty, tx): an XCD walks neighbouring tiles of one level
+    const long total = (long)c.batch * c.levels * tiles_y * tiles_x;
+    if (item >= total) return;
+    const int tx = (int)(item % tiles_x);
+    item /= tiles_x;
+    const int ty = (int)(item % tiles_y);
+    item /= tiles_y;
+    const int lvl = (int)(item % c.levels), b = (int)(item / c.levels);
+    const int H = c.h >> lvl, W = c.w >> lvl;
+    const int PS = 2 * c.radius + 2;  // side of the integer patch under a (2 r + 1)^2 window of bilinear samples
+    if (tid < kTQ) {
+        const int qy = ty * kTQH + tid / kTQW, qx = tx * kTQW + tid % kTQW;
+        const bool ok = qy < c.h && qx < c.w;
+        int pix = -1, x0 = 0, y0 = 0;
+        float fx = 0.f, fy = 0.f;
+        if (ok) {
+            pix = qy * c.w + qx;
+            const Patch pt = patch_of(c, coords, b, pix, lvl);
+            x0 = pt.x0; y0 = pt.y0; fx = pt.fx; fy = pt.fy;
+        }
+        q_pix[tid] = pix; q_x0[tid] = x0; q_y0[tid] = y0; q_fx[tid] = fx; q_fy[tid] = fy;
+        // bounding box of the patches, clipped to the map (rows outside are zero and are never staged): wave 0, lanes 0-31
+        // (a patch that lies outside the map altogether contributes zeros and no rows)
+        const bool some = ok && x0 < W && y0 < H && x0 > -PS && y0 > -PS;
+        int lo_x = some ? max(x0, 0) : (1 << 30), lo_y = some ? max(y0, 0) : (1 << 30);
+        int hi_x = some ? min(x0 + PS, W) : -(1 << 30), hi_y = some ? min(y0 + PS, H) : -(1 << 30);
+#pragma unroll
+        for (int m = 16; m >= 1; m >>= 1) {
+            lo_x = min(lo_x, __shfl_xor(lo_x, m));
+            lo_y = min(lo_y, __shfl_xor(lo_y, m));
+            hi_x = max(hi_x, __shfl_xor(hi_x, m));
+            hi_y = max(hi_y, __shfl_xor(hi_y, m));
+        }
+        if (tid == 0) {
+            reg[0] = lo_x; reg[1] = lo_y;
+            reg[2] = hi_x > lo_x ? hi_x - lo_x : 0;
+            reg[3] = hi_y > lo_y ? hi_y - lo_y : 0;
+        }
+    }
+    __syncthreads();
+    const int rx0 = reg[0], ry0 = reg[1], rw = reg[2], rh = reg[3];
+    const long R = (long)rw * rh;
+    const int C = c.levels * (PS - 1) * (PS - 1);
+    if (R > kTRMax) {  // per-query path (block-uniform branch)
+        float (*Tw)[kTransposeStride] = reinterpret_cast<float (*)[kTransposeStride]>(lds + (size_t)wave * 64 * kTransposeStride * sizeof(float));
+        for (int q = wave; q < kTQ; q += kWavesPerBlock) {
+            const int pix = q_pix[q];
+            if (pix >= 0) lookup_one<VEC>(c, fmap1, lp, coords, out, b, pix, lvl, lane, Pf[wave], Tw);
+            __builtin_amdgcn_wave_barrier();
+        }
+        return;
+    }
+    const int W7 = PS - 1;
+    if (R == 0) {  // every patch lies outside the map: zeros
+        for (int idx = tid; idx < kTQ * W7 * W7; idx += 256) {
+            const int q = idx / (W7 * W7), tap = idx - q * (W7 * W7);
+            if (q_pix[q] >= 0) out[((size_t)b * hw + q_pix[q]) * C + lvl * W7 * W7 + tap] = 0.f;
+        }
+        return;
+    }
+    unsigned char* A_hi = lds;
+    unsigned char* A_lo = lds + kTLdsA / 2;
+    unsigned char* B_hi = lds + kTLdsA;
+    unsigned char* B_lo = B_hi + kTLdsB / 2;
+    const float* f2 = lp.f2[lvl] + (size_t)b * H * W * D;
+    const int Rn = (int)R, n_tiles = (Rn + 31) / 32;
+    // per-thread row offsets of the region's 16-B chunks (one K chunk = 16 chunks of 4 floats per row): the same for every K chunk
+    constexpr int CPR = kTKC / 4;                       // 16
+    constexpr int NB = kTRMax * CPR / 256;              // 16 chunks per thread
+    int b_off[NB];
+#pragma unroll
+    for (int u = 0; u < NB; u++) {
+        const int i = tid + u * 256, p = i / CPR, c4 = i % CPR;
+        const int py = p / rw, px = p - py * rw;
+        b_off[u] = p < Rn ? ((ry0 + py) * W + rx0 + px) * D + c4 * 4 : -1;
+    }
+    int a_off[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int i = tid + u * 256, q = i / CPR, c4 = i % CPR;
+        a_off[u] = q_pix[q] >= 0 ? q_pix[q] * D + c4 * 4 : -1;
+    }
+    const float* f1 = fmap1 + (size_t)b * hw * D;
+    const int r = lane & 31, h = lane >> 5;
+    cf16v acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[j][e] = 0.f;
+    for (int kc = 0; kc < D; kc += kTKC) {
+        float4 va[2], vb[NB];
+#pragma unroll
+        for (int u = 0; u < 2; u++) va[u] = a_off[u] >= 0 ? *reinterpret_cast<const float4*>(f1 + a_off[u] + kc) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < NB; u++)
+            vb[u] = b_off[u] >= 0 ? *reinterpret_cast<const float4*>(f2 + b_off[u] + kc) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (kc > 0) __syncthreads();  // the previous chunk's fragments have been read
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int i = tid + u * 256, q = i / CPR, c4 = i % CPR;
+            uint2 hi, lo;
+            corr_split4(va[u], &hi, &lo);
+            const int o = ((c4 >> 1) * kTQ + q) * 16 + (c4 & 1) * 8;
+            *reinterpret_cast<uint2*>(A_hi + o) = hi;
+            *reinterpret_cast<uint2*>(A_lo + o) = lo;
+        }
+#pragma unroll
+        for (int u = 0; u < NB; u++) {
+            const int i = tid + u * 256, p = i / CPR, c4 = i % CPR;
+            if (p < n_tiles * 32) {  // (rows of the last 32-row tile beyond the region: zeros)
+                uint2 hi, lo;
+                corr_split4(vb[u], &hi, &lo);
+                const int o = ((c4 >> 1) * kTRMax + p) * 16 + (c4 & 1) * 8;
+                *reinterpret_cast<uint2*>(B_hi + o) = hi;
+                *reinterpret_cast<uint2*>(B_lo + o) = lo;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < kTKC / 16; kk++) {
+            const int k8 = kk * 2 + h;
+            const uint4 ah = *reinterpret_cast<const uint4*>(A_hi + (k8 * kTQ + r) * 16);
+            const uint4 al = *reinterpret_cast<const uint4*>(A_lo + (k8 * kTQ + r) * 16);
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int nt = wave * 2 + j;
+                if (nt < n_tiles) {
+                    const uint4 bh = *reinterpret_cast<const uint4*>(B_hi + (k8 * kTRMax + nt * 32 + r) * 16);
+                    const uint4 bl = *reinterpret_cast<const uint4*>(B_lo + (k8 * kTRMax + nt * 32 + r) * 16);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const cbf8*>(&al), *reinterpret_cast<const cbf8*>(&bh), acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const cbf8*>(&ah), *reinterpret_cast<const cbf8*>(&bl), acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const cbf8*>(&ah), *reinterpret_cast<const cbf8*>(&bh), acc[j], 0, 0, 0);
+                }
+            }
+        }
+    }
+    __syncthreads();  // every fragment read is done: C takes the place of the B planes
+    float* Cm = reinterpret_cast<float*>(B_hi);
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int nt = wave * 2 + j;
+        if (nt < n_tiles) {
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int q = (e & 3) + 8 * (e >> 2) + 4 * h;  // row of the 32 x 32 result held by register e
+                Cm[q * kTCStride + nt * 32 + r] = acc[j][e];
+            }
+        }
+    }
+    __syncthreads();
+    const float inv = 1.0f / sqrtf((float)D);  // corr.py:56
+    for (int idx = tid; idx < kTQ * W7 * W7; idx += 256) {
+        const int q = idx / (W7 * W7), tap = idx - q * (W7 * W7);
+        const int pix = q_pix[q];
+        if (pix < 0) continue;
+        const int a = tap / W7, bb = tap - a * W7;  // a: x offset index, bb: y offset index (corr.py:31-35 order)
+        const int lx = q_x0[q] - rx0 + a, ly = q_y0[q] - ry0 + bb;
+        const float* row = Cm + q * kTCStride;
+        auto at = [&](int x, int y) { return ((unsigned)x < (unsigned)rw && (unsigned)y < (unsigned)rh) ? row[y * rw + x] : 0.f; };
+        const float p00 = at(lx, ly), p10 = at(lx + 1, ly), p01 = at(lx, ly + 1), p11 = at(lx + 1, ly + 1);
+        const float fx = q_fx[q], fy = q_fy[q];
+        const float v = (1.f - fx) * (1.f - fy) * p00 + fx * (1.f - fy) * p10 + (1.f - fx) * fy * p01 + fx * fy * p11;
+        out[((size_t)b * hw + pix) * C + lvl * W7 * W7 + tap] = v * inv;
     }
 }
 
@@ -185,6 +407,33 @@ int liso_corr_lookup_fwd_f32(const liso_corr_cfg* cfg, const float* fmap1, const
         corr_lookup_fwd_kernel<1><<<grid, 64 * kWavesPerBlock, 0, st>>>(*cfg, fmap1, lp, coords, out);
     else
         corr_lookup_fwd_kernel<2><<<grid, 64 * kWavesPerBlock, 0, st>>>(*cfg, fmap1, lp, coords, out);
+    return check_launch();
+}
+
+int liso_corr_lookup_fwd_tiled_f32(const liso_corr_cfg* cfg, const float* fmap1, const float* const* fmap2_levels, const float* coords,
+                                   float* out, void* stream) {
+    if (!cfg_ok(cfg) || !fmap1 || !fmap2_levels || !coords || !out) return LISO_EINVAL;
+    if ((((uintptr_t)fmap1) & 15) != 0) return LISO_EINVAL;
+    LevelPtrs lp = {};
+    for (int i = 0; i < cfg->levels; i++) {
+        if (!fmap2_levels[i] || (((uintptr_t)fmap2_levels[i]) & 15) != 0) return LISO_EINVAL;
+        lp.f2[i] = fmap2_levels[i];
+    }
+    const int tiles_x = (cfg->w + kTQW - 1) / kTQW, tiles_y = (cfg->h + kTQH - 1) / kTQH;
+    const long total = (long)cfg->batch * cfg->levels * tiles_y * tiles_x;
+    const unsigned grid = (unsigned)((total + 7) / 8 * 8);  // XCD-aware order
+    hipStream_t st = (hipStream_t)stream;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)corr_lookup_tiled_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kTLdsA + kTLdsB) != hipSuccess ||
+            hipFuncSetAttribute((const void*)corr_lookup_tiled_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kTLdsA + kTLdsB) != hipSuccess)
+            return LISO_ELAUNCH;
+        attr_set = true;
+    }
+    if (cfg->dim == 128)
+        corr_lookup_tiled_kernel<1><<<grid, 256, kTLdsA + kTLdsB, st>>>(*cfg, fmap1, lp, coords, out, tiles_x, tiles_y);
+    else
+        corr_lookup_tiled_kernel<2><<<grid, 256, kTLdsA + kTLdsB, st>>>(*cfg, fmap1, lp, coords, out, tiles_x, tiles_y);
     return check_launch();
 }
 

@@ -147,3 +147,37 @@ extern "C" int liso_gru_out_rows_f32(long n_pix, int ch, const float* cq, long c
                        z, h, h_stride);
     return done();
 }
+
+// ---- RAFT loop state at inference: one launch instead of `coords1 + d_flow`, `logits + d_logits`, `coords1 - coords0` ---------------------
+// (liso/slim/model/raft.py:199-216: coords1 = coords1 + delta_flow; logits = logits + delta_logits; next iteration: flow = coords1 - coords0)
+// The same three fp32 operations per pixel, in the same order; the results land where the next iteration reads them: coords1 [B,2,hw] for
+// the correlation lookup, (flow | logits | 0 0) as ONE channels-last pixel of 8 floats for the motion encoder's merged 7x7 convolution.
+namespace {
+__global__ __launch_bounds__(256) void raft_state_step_kernel(int batch, int hw, const float* __restrict__ delta, long delta_stride,
+                                                              const float* __restrict__ coords0, float* __restrict__ coords1,
+                                                              float* __restrict__ state8) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)batch * hw) return;
+    const int b = (int)(i / hw), p = (int)(i - (long)b * hw);
+    const float* dl = delta + i * delta_stride;
+    const long cx = ((long)b * 2) * hw + p, cy = cx + hw;
+    const float c1x = coords1[cx] + dl[0], c1y = coords1[cy] + dl[1];
+    coords1[cx] = c1x;
+    coords1[cy] = c1y;
+    float4* s = reinterpret_cast<float4*>(state8 + i * 8);
+    const float4 lo = s[0], hi = s[1];
+    s[0] = make_float4(c1x - coords0[cx], c1y - coords0[cy], lo.z + dl[2], lo.w + dl[3]);
+    s[1] = make_float4(hi.x + dl[4], hi.y + dl[5], 0.0f, 0.0f);
+}
+}  // namespace
+
+extern "C" int liso_raft_state_step_f32(int batch, int hw, const float* delta, long delta_stride, const float* coords0, float* coords1,
+                                        float* state8, void* stream) {
+    if (batch < 0 || hw < 0 || delta_stride < 6) return LISO_EINVAL;
+    const long n = (long)batch * hw;
+    if (n == 0) return LISO_OK;
+    if (!delta || !coords0 || !coords1 || !state8 || ((uintptr_t)state8 & 15)) return LISO_EINVAL;
+    hipLaunchKernelGGL(raft_state_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, batch, hw, delta,
+                       delta_stride, coords0, coords1, state8);
+    return done();
+}

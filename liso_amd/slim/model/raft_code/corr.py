@@ -109,8 +109,14 @@ class _CorrLookup(torch.autograd.Function):
         W7 = 2 * radius + 1
         coords = coords.detach().float().contiguous()
         out = torch.empty((B, h, w, len(fmap2_levels) * W7 * W7), dtype=torch.float32, device=fmap1.device)
+        # the arithmetic of the process's fp32 convolutions: bf16 hi / lo pairs on the matrix cores ("x3": the tiled kernel, 4 x 8 queries
+        # share the rows they correlate with) or fp32 FMAs ("exact": one wavefront per query and level)
+        from liso_amd.utils import mfma_conv as MC
+
+        tiled = MC.fp32_mode() == "x3" and os.environ.get("LISO_CORR_TILED", "1") != "0"
+        fn = L.lib().liso_corr_lookup_fwd_tiled_f32 if tiled else L.lib().liso_corr_lookup_fwd_f32
         with torch.cuda.device(fmap1.device):
-            L.check(L.TIMER.launch("corr_lookup_fwd", lambda: L.lib().liso_corr_lookup_fwd_f32(
+            L.check(L.TIMER.launch("corr_lookup_fwd_tiled" if tiled else "corr_lookup_fwd", lambda: fn(
                 ctypes.byref(cfg), L.ptr(fmap1), _ptr_array(fmap2_levels), L.ptr(coords), L.ptr(out), L.stream_ptr())),
                 "corr_lookup_fwd")
         ctx.save_for_backward(coords)

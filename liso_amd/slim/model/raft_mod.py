@@ -171,6 +171,9 @@ class RAFT(nn.Module):
         # weight gradients of the update block: one convolution per layer over all iterations (deferred_wgrad.py)
         mode = getattr(self, "defer_update_block_wgrad", True)  # True | False | "direct" (hipGraph capture, see trainer.py)
         infer = self.update_block.inference_state(net, inp) if (only_last and not use_w) else None  # (inference: no concatenations)
+        packed = infer is not None and infer["packed"] and not vanilla  # (flow | logits) in one state pixel, one update launch per iteration
+        if packed:
+            coords0, coords1 = coords0.contiguous(), coords1.contiguous().clone()
         with deferred_weight_gradients(self.update_block, enabled=self.training and bool(mode), direct_accumulate=mode == "direct"):
             for it in range(m.num_iters):
                 coords1 = coords1.detach()
@@ -179,16 +182,23 @@ class RAFT(nn.Module):
                 if use_w:
                     wl = wl.detach()
                 corr = correlation(coords1)
-                flow = coords1 - coords0
-                if infer is not None:
-                    net, d_flow, d_logits, d_w = self.update_block.forward_inference(infer, corr, flow, logits)
+                if packed:
+                    net, both = self.update_block.forward_inference(infer, corr, None, None)
+                    logits = self.update_block.state_step(infer, both, coords0, coords1)
+                    if it + 1 < m.num_iters:
+                        continue
+                    logits = logits.contiguous()
                 else:
-                    net, d_flow, d_logits, d_w = self.update_block(net, inp, corr, flow, logits, wl)
-                coords1 = coords1 + d_flow
-                if not vanilla:
-                    logits = logits + d_logits
-                if use_w:
-                    wl = wl + d_w
+                    flow = coords1 - coords0
+                    if infer is not None:
+                        net, d_flow, d_logits, d_w = self.update_block.forward_inference(infer, corr, flow, logits)
+                    else:
+                        net, d_flow, d_logits, d_w = self.update_block(net, inp, corr, flow, logits, wl)
+                    coords1 = coords1 + d_flow
+                    if not vanilla:
+                        logits = logits + d_logits
+                    if use_w:
+                        wl = wl + d_w
                 if only_last and it + 1 < m.num_iters:
                     continue
                 if fuse:

@@ -129,7 +129,8 @@ class SmallUpdateBlock(nn.Module):
         x0, x1 = ch, ch + ci + co + cc + cf  # channels of x = (inp, out, class, flow)
         fh, hd = self.static_flow_head, self.classification_head
         tracked = (me.conv.weight, gru.convq.weight, me.conv_flow2.weight, me.conv_class2.weight, me.conv_flow2.bias, me.conv_class2.bias,
-                   fh.conv2.weight, hd.conv2.weight, fh.conv2.bias, hd.conv2.bias)
+                   fh.conv2.weight, hd.conv2.weight, fh.conv2.bias, hd.conv2.bias, me.conv_flow1.weight, me.conv_class1.weight,
+                   me.conv_flow1.bias, me.conv_class1.bias)
         key = tuple((t._version, t.data_ptr()) for t in tracked)
         hit = getattr(self, "_infer_perm", None)
         if hit is None or hit[0] != key:
@@ -152,19 +153,51 @@ class SmallUpdateBlock(nn.Module):
                 w_hd[:of, :hf] = fh.conv2.weight
                 w_hd[of:, hf:] = hd.conv2.weight
                 b_hd = torch.cat([fh.conv2.bias, hd.conv2.bias])
-                P = lambda t: torch.nn.Parameter(t.contiguous(), requires_grad=False)  # noqa: E731
-            hit = self._infer_perm = (key, w_conv, w_q, P(w_cf), P(b_cf), P(w_hd), P(b_hd))
+                # conv_class1 | conv_flow1 (7x7 on 4 / 2 channels, :54-59) as ONE launch on the loop's packed state pixel
+                # (flow x, flow y, logit 0..3, 0, 0): the kernels pad 2-4 input channels to a 16-channel slab anyway
+                w_71 = b_71 = None
+                if (tuple(me.conv_class1.weight.shape[1:]) == (4, 7, 7) and tuple(me.conv_flow1.weight.shape[1:]) == (2, 7, 7)
+                        and me.conv_class1.padding == me.conv_flow1.padding and of == 2 and oc == 4):
+                    k1c, k1f = me.conv_class1.out_channels, me.conv_flow1.out_channels
+                    w_71 = torch.zeros((k1c + k1f, 8, 7, 7), dtype=wc.dtype, device=wc.device)
+                    w_71[:k1c, 2:6] = me.conv_class1.weight
+                    w_71[k1c:, 0:2] = me.conv_flow1.weight
+                    b_71 = torch.cat([me.conv_class1.bias, me.conv_flow1.bias])
+                P = lambda t: None if t is None else torch.nn.Parameter(t.contiguous(), requires_grad=False)  # noqa: E731
+            hit = self._infer_perm = (key, w_conv, w_q, P(w_cf), P(b_cf), P(w_hd), P(b_hd), P(w_71), P(b_71))
         merged = (os.environ.get("LISO_UPDATE_MERGED", "1") != "0" and tuple(me.conv_class2.kernel_size) == (3, 3)
                   and tuple(me.conv_flow2.kernel_size) == (3, 3) and tuple(fh.conv2.kernel_size) == (3, 3) and tuple(hd.conv2.kernel_size) == (3, 3)
                   and me.conv_class1.out_channels % 8 == 0 and me.conv_flow1.out_channels % 8 == 0)
+        # the loop's (flow | logits) state as one channels-last pixel of 8 floats, updated by ONE launch per iteration (state_step)
+        packed = merged and hit[7] is not None and os.environ.get("LISO_UPDATE_PACKED_STATE", "1") != "0"
         return {"big": big, "m": m, "ch": ch, "ci": ci, "co": co, "cc": cc, "cf": cf, "cq": cq, "x0": x0, "x1": x1,
                 "w_conv": hit[1], "w_q": hit[2], "w_cf": hit[3], "b_cf": hit[4], "w_hd": hit[5], "b_hd": hit[6], "merged": merged,
+                "w_71": hit[7], "b_71": hit[8], "packed": packed,
+                "fl8": torch.zeros((B, H, W, 8), dtype=torch.float32, device=net.device) if packed else None,
                 "c1": torch.empty((B, H, W, me.conv_class1.out_channels + me.conv_flow1.out_channels), dtype=torch.float32, device=net.device)
                 if merged else None,
                 "z": torch.empty((B, H, W, ch), dtype=torch.float32, device=net.device)}
 
+    def state_step(self, st, both, coords0, coords1):
+        """(packed state) reference raft.py:199-216 in one launch: coords1 += delta_flow (in place), logits += delta_logits and
+        flow = coords1 - coords0 into st["fl8"]; `both` = the heads' merged output [B, 2 + 4, h, w].  -> logits view [B,4,h,w]"""
+        import ctypes  # noqa: F401
+
+        from liso_amd import _lib as L
+        from liso_amd.utils import mfma_conv as MC
+
+        fl8 = st["fl8"]
+        bv, bps = MC.as_nhwc(both, 2)
+        B, H, W, _ = fl8.shape
+        assert coords0.is_contiguous() and coords1.is_contiguous() and coords1.shape == (B, 2, H, W) and both.shape[1] == 6
+        with torch.cuda.device(fl8.device):
+            L.check(L.lib().liso_raft_state_step_f32(B, H * W, L.ptr(bv), bps, L.ptr(coords0), L.ptr(coords1), L.ptr(fl8), L.stream_ptr()),
+                    "raft_state_step")
+        return fl8[..., 2:6].permute(0, 3, 1, 2)
+
     def forward_inference(self, st, corr, flow, logits):
-        """one update iteration on the buffers of `inference_state` -> (net view, delta_static_flow, delta_logits, None)"""
+        """one update iteration on the buffers of `inference_state` -> (net view, delta_static_flow, delta_logits, None); with the
+        packed state (st["packed"]: `flow` / `logits` are read from st["fl8"]) -> (net view, merged head output [B, 2 + 4, h, w])"""
         import ctypes
         import types
 
@@ -180,8 +213,12 @@ class SmallUpdateBlock(nn.Module):
         if st["merged"]:  # (class1 | flow1) into one map, then conv_class2 | conv_flow2 as ONE block-diagonal launch -> big[class | flow]
             c1 = st["c1"]
             k1 = me.conv_class1.out_channels
-            MC.conv2d(me.conv_class1, logits, relu=True, out=(c1, 0))
-            MC.conv2d(me.conv_flow1, flow, relu=True, out=(c1, k1))
+            if st["packed"]:
+                MC.fused_conv(st["fl8"].permute(0, 3, 1, 2), None, types.SimpleNamespace(weight=st["w_71"], bias=st["b_71"]), out_relu=True,
+                              spec=MC.ConvSpec.of(me.conv_class1), out=(c1, 0))
+            else:
+                MC.conv2d(me.conv_class1, logits, relu=True, out=(c1, 0))
+                MC.conv2d(me.conv_flow1, flow, relu=True, out=(c1, k1))
             MC.fused_conv(c1.permute(0, 3, 1, 2), None, types.SimpleNamespace(weight=st["w_cf"], bias=st["b_cf"]), out_relu=True,
                           spec=MC.ConvSpec.of(me.conv_class2), out=(big, o_cls))
         else:
@@ -207,6 +244,8 @@ class SmallUpdateBlock(nn.Module):
         hid = conv2d_pair(fh.conv1, hd.conv1, net, relu=True)
         if st["merged"]:  # both heads' output convolutions as ONE block-diagonal launch on the merged hidden map
             both, _ = MC.fused_conv(hid, None, types.SimpleNamespace(weight=st["w_hd"], bias=st["b_hd"]), spec=MC.ConvSpec.of(fh.conv2))
+            if st["packed"]:
+                return net, both
             of = fh.conv2.out_channels
             return net, both[:, :of], both[:, of:], None
         hid_f, hid_c = torch.split(hid, [fh.conv1.out_channels, hd.conv1.out_channels], dim=1)

@@ -53,6 +53,52 @@ def test_inference_flow_equals_the_training_forward():
     assert float((a - b).abs().max()) <= 1e-4 * max(float(a.abs().max()), 1e-6)
 
 
+def test_packed_raft_state_equals_separate_flow_and_logit_tensors(monkeypatch):
+    """inference with the loop's (flow | logits) state in one 8-float pixel (one merged 7x7 launch + liso_raft_state_step_f32 per
+    iteration) vs separate tensors and framework additions: the state step is the same fp32 arithmetic; the merged 7x7 convolution
+    moves the logits to other positions of the 16-channel slab (another summation order inside the matrix instruction)"""
+    from liso_amd.datasets.synthetic import slim_pair
+    from liso_amd.slim.model.slim import SLIM
+    from liso_amd.utils.config import default_cfg
+
+    dev = torch.device("cuda")
+    torch.manual_seed(2)
+    net = SLIM(default_cfg(grid=256, bev_range_m=50.0), 100).to(dev).eval()
+    s0, s1 = slim_pair(13, dev, n_points=30000, grid=256, bev_range_m=50.0)
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("LISO_UPDATE_PACKED_STATE", flag)
+        with torch.no_grad():
+            outs.append(net.infer_point_flow_t0_t1(s0, s1).clone())
+    a, b = outs
+    assert float(a.abs().max()) > 0
+    assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()), float((a - b).abs().max()) / float(a.abs().max())
+
+
+def test_raft_state_step_is_the_reference_arithmetic():
+    import ctypes  # noqa: F401
+
+    from liso_amd import _lib as L
+
+    g = torch.Generator().manual_seed(3)
+    B, H, W = 2, 5, 7
+    wide = torch.randn(B, H, W, 8, generator=g).cuda()  # the heads' output as a channel slice of a wider pixel
+    delta = wide[..., 1:7]
+    c0 = (torch.rand(B, 2, H, W, generator=g) * 64).cuda()
+    c1 = (c0 + torch.randn(B, 2, H, W, generator=g).cuda()).contiguous()
+    st = torch.randn(B, H, W, 8, generator=g).cuda()
+    st[..., 6:] = 0
+    c1_ref = c1 + delta[..., 0:2].permute(0, 3, 1, 2)
+    flow_ref = c1_ref - c0
+    logit_ref = st[..., 2:6] + delta[..., 2:6]
+    L.check(L.lib().liso_raft_state_step_f32(B, H * W, ctypes.c_void_p(delta.data_ptr()), 8, L.ptr(c0), L.ptr(c1), L.ptr(st), L.stream_ptr()), "step")
+    torch.cuda.synchronize()
+    assert torch.equal(c1, c1_ref)
+    assert torch.equal(st[..., 0:2], flow_ref.permute(0, 2, 3, 1))
+    assert torch.equal(st[..., 2:6], logit_ref)
+    assert float(st[..., 6:].abs().max()) == 0.0
+
+
 def test_padded_device_nms_keeps_the_same_boxes_as_the_reference_schedule():
     """perform_nms_on_shapes_padded (no host round trips) vs perform_nms_on_shapes (nms_iou.py:23-66): same survivors per
     sample, in the same order"""

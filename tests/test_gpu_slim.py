@@ -698,3 +698,48 @@ def test_fused_decoder_and_losses_equal_torch_formulation(variant):
         assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-12, float((a - b).abs().max())
     for k in ta:
         assert torch.allclose(ta[k].double(), tb[k].double(), rtol=1e-5, atol=1e-7), k
+
+
+@pytest.mark.parametrize("B,h,w,D,levels,radius,spread", [(2, 64, 64, 128, 4, 3, 1.0), (1, 33, 45, 128, 3, 3, 0.5), (1, 16, 24, 256, 2, 2, 2.0),
+                                                          (1, 64, 64, 128, 4, 3, 40.0), (3, 8, 8, 128, 1, 1, 0.0)])
+def test_tiled_corr_lookup_equals_the_per_query_kernel(B, h, w, D, levels, radius, spread):
+    """liso_corr_lookup_fwd_tiled_f32 (4 x 8 queries share their rows of fmap2; bf16 hi / lo products on the matrix cores) against
+    liso_corr_lookup_fwd_f32 (fp32 FMAs, one wavefront per query and level) on smooth flow + noise of `spread` pixels: partial tiles,
+    windows across every map border, centres far outside the map, and -- spread 40 -- blocks whose queries lie too far apart for one
+    256-row region (the per-query path inside the tiled kernel: bit-identical there)."""
+    import ctypes
+
+    from liso_amd import _lib as L
+    from liso_amd.slim.model.raft_code.utils import coords_grid
+
+    g = torch.Generator().manual_seed(B * 100 + h)
+    f1 = torch.randn(B, h * w, D, generator=g).cuda()
+    lv = []
+    for i in range(levels):
+        lv.append(torch.randn(B, h >> i, w >> i, D, generator=g).cuda())
+    base = coords_grid(B, h, w, device="cuda")
+    smooth = torch.tensor([3.3, -2.6], device="cuda").view(1, 2, 1, 1) + 0.02 * base
+    coords = (base + smooth + spread * torch.randn(B, 2, h, w, generator=g).cuda()).contiguous()
+    coords[0, :, 0, 0] = torch.tensor([-50.0, 7.0])      # far outside: zeros
+    coords[0, :, h - 1, w - 1] = torch.tensor([w + 30.0, h + 30.0])
+    cfg = L.CorrCfg(B, h, w, D, levels, radius)
+    W7 = 2 * radius + 1
+    outs = []
+    ptrs = (ctypes.c_void_p * levels)(*[t.data_ptr() for t in lv])
+    for fn in (L.lib().liso_corr_lookup_fwd_f32, L.lib().liso_corr_lookup_fwd_tiled_f32):
+        out = torch.full((B, h, w, levels * W7 * W7), float("nan"), device="cuda")
+        L.check(fn(ctypes.byref(cfg), L.ptr(f1), ptrs, L.ptr(coords), L.ptr(out), L.stream_ptr()), "corr")
+        torch.cuda.synchronize()
+        outs.append(out)
+    ref, got = outs
+    assert torch.isfinite(got).all()
+    scale = float(ref.abs().max())
+    err = float((ref - got).abs().max())
+    assert err <= 3e-5 * scale, (err, scale)
+    if spread >= 40.0:  # nearly every block takes the per-query path: the same instructions as the reference kernel
+        assert float((ref != got).float().mean()) < 0.2
+    # run to run: bit for bit
+    out2 = torch.empty_like(got)
+    L.check(L.lib().liso_corr_lookup_fwd_tiled_f32(ctypes.byref(cfg), L.ptr(f1), ptrs, L.ptr(coords), L.ptr(out2), L.stream_ptr()), "corr")
+    torch.cuda.synchronize()
+    assert torch.equal(got, out2)
