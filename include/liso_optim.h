@@ -46,6 +46,13 @@ int liso_adamw_step_scaled_f32(float* param, const float* grad, float* exp_avg, 
 #define LISO_GATHER_MAX 48
 int liso_gather_f32(int count, const void* const* src, void* const* dst, const size_t* numel, void* stream);
 
+/* `n` device-to-device copies of any type in ONE launch per LISO_MULTI_COPY_MAX segments: dst[k][0 .. bytes[k]) = src[k][...]
+ * (16-byte vectors where both pointers allow).  dst / src / bytes are HOST arrays (baked into the launch); segments must not overlap.
+ * The training steps stage the inputs of their captured hipGraphs with it (10 target tensors per detector step, the cloud tensors of a
+ * SLIM inference replay): one launch instead of one runtime buffer copy per tensor. */
+#define LISO_MULTI_COPY_MAX 24
+int liso_multi_copy(int n, void* const* dst, const void* const* src, const size_t* bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -131,6 +131,10 @@ int liso_nearest_point_loss_bwd_f32(const liso_nploss_cfg* cfg, const float* clo
  */
 int liso_bev_gather_fwd_f32(const float* grid, const int* lin, long n_rows, int c, float default_value, float* out,
                             void* stream);
+/* `lin` of a batch of clouds: coors int32 / int64 [batch, n, 2] = (row, col) of every point on the h x w grid, valid uint8 / bool
+ * [batch, n] -> lin int32 [batch * n] = (b h + row) w + col, -1 for invalid points. */
+int liso_bev_lin_index(const void* coors, int coors_are_int64, const unsigned char* valid, int batch, long n, int h, int w, int* lin,
+                       void* stream);
 int liso_bev_gather_bwd_f32(const float* grad_out, const int* sorted_lin, const int* order, const int* seg_rank, long n_rows,
                             int c, float* partial, float* grad_grid, void* stream);
 

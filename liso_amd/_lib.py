@@ -60,6 +60,31 @@ def ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+def multi_copy(pairs):
+    """dst.copy_(src) for every (dst, src) of `pairs`, the device-resident, contiguous, same-dtype ones of one device as ONE launch
+    (include/liso_optim.h: liso_multi_copy) on the current stream; everything else (host sources, dtype changes, strided views) by
+    `copy_(non_blocking=True)`."""
+    import torch
+
+    fast = []
+    for d, s_ in pairs:
+        if (d.is_cuda and s_.is_cuda and d.device == s_.device and d.dtype == s_.dtype and d.shape == s_.shape and d.is_contiguous()
+                and s_.is_contiguous() and (not fast or fast[0][0].device == d.device)):
+            if d.numel() and d.data_ptr() != s_.data_ptr():
+                fast.append((d, s_))
+        else:
+            d.copy_(s_, non_blocking=True)
+    if len(fast) == 1:
+        fast[0][0].copy_(fast[0][1], non_blocking=True)
+    elif fast:
+        n = len(fast)
+        dst = (ctypes.c_void_p * n)(*[d.data_ptr() for d, _ in fast])
+        src = (ctypes.c_void_p * n)(*[s_.data_ptr() for _, s_ in fast])
+        nb = (ctypes.c_size_t * n)(*[d.numel() * d.element_size() for d, _ in fast])
+        with torch.cuda.device(fast[0][0].device):
+            check(lib().liso_multi_copy(n, dst, src, nb, stream_ptr()), "multi_copy")
+
+
 def require_cuda(*tensors):
     for t in tensors:
         if not t.is_cuda:
@@ -131,6 +156,8 @@ SIGNATURES = {
     "liso_gru_out_bwd_f32": (_i, [ctypes.c_long, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "liso_gru_in_rows_f32": (_i, [ctypes.c_long, _i, _vp, ctypes.c_long, _vp, ctypes.c_long, _vp, _vp, ctypes.c_long, _vp]),
     "liso_gru_out_rows_f32": (_i, [ctypes.c_long, _i, _vp, ctypes.c_long, _vp, _vp, ctypes.c_long, _vp]),
+    "liso_multi_copy": (_i, [_i, _vp, _vp, _vp, _vp]),
+    "liso_bev_lin_index": (_i, [_vp, _i, _vp, _i, ctypes.c_long, _i, _i, _vp, _vp]),
     "liso_raft_state_step_f32": (_i, [_i, _i, _vp, ctypes.c_long, _vp, _vp, _vp, _vp]),
     "liso_raft_upsample_scratch_bytes": (_sz, [_vp]),
     "liso_raft_upsample_outputs_fwd_f32": (_i, [_vp] * 5),

@@ -150,26 +150,22 @@ constexpr int kTLdsB = 2 * (kTKC / 8) * kTRMax * 16;     // 64 KB
 typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 cbf8;
 typedef __attribute__((__vector_size__(16 * sizeof(float)))) float cf16v;
 
-__device__ __forceinline__ unsigned corr_pack_bf16(float a, float b) {  // round to nearest even, like the convolutions' split
-    unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
-    ua = (ua + 0x7fffu + ((ua >> 16) & 1u)) >> 16;
-    ub = (ub + 0x7fffu + ((ub >> 16) & 1u)) >> 16;
-    return ua | (ub << 16);
-}
-__device__ __forceinline__ float corr_round_bf16(float a) {
-    unsigned u = __float_as_uint(a);
-    u = (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;
-    return __uint_as_float(u);
+// (native conversions: v_cvt_pk_bf16_f32, round to nearest even -- the convolutions' split; bit arithmetic here made the split the
+// kernel's bottleneck: ~70 vector instructions per 16 bytes against ~14)
+__device__ __forceinline__ unsigned corr_pack_bf16(float a, float b) {
+    const __bf16 x = (__bf16)a, y = (__bf16)b;
+    return (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
 }
 // 4 floats -> 8 B of the hi plane + 8 B of the lo plane
 __device__ __forceinline__ void corr_split4(const float4 v, uint2* hi, uint2* lo) {
-    const float h0 = corr_round_bf16(v.x), h1 = corr_round_bf16(v.y), h2 = corr_round_bf16(v.z), h3 = corr_round_bf16(v.w);
-    *hi = make_uint2(corr_pack_bf16(h0, h1), corr_pack_bf16(h2, h3));
-    *lo = make_uint2(corr_pack_bf16(v.x - h0, v.y - h1), corr_pack_bf16(v.z - h2, v.w - h3));
+    const unsigned p0 = corr_pack_bf16(v.x, v.y), p1 = corr_pack_bf16(v.z, v.w);
+    *hi = make_uint2(p0, p1);
+    *lo = make_uint2(corr_pack_bf16(v.x - __uint_as_float(p0 << 16), v.y - __uint_as_float(p0 & 0xffff0000u)),
+                     corr_pack_bf16(v.z - __uint_as_float(p1 << 16), v.w - __uint_as_float(p1 & 0xffff0000u)));
 }
 
 template <int VEC>
-__global__ __launch_bounds__(256) void corr_lookup_tiled_kernel(liso_corr_cfg c, const float* __restrict__ fmap1, LevelPtrs lp,
+__global__ __launch_bounds__(256, 2) void corr_lookup_tiled_kernel(liso_corr_cfg c, const float* __restrict__ fmap1, LevelPtrs lp,
                                                                 const float* __restrict__ coords, float* __restrict__ out, int tiles_x,
                                                                 int tiles_y) {
     constexpr int D = 128 * VEC;
@@ -251,10 +247,14 @@ __global__ __launch_bounds__(256) void corr_lookup_tiled_kernel(liso_corr_cfg c,
     constexpr int CPR = kTKC / 4;                       // 16
     constexpr int NB = kTRMax * CPR / 256;              // 16 chunks per thread
     int b_off[NB];
+    const float inv_rw = 1.0f / (float)rw;
 #pragma unroll
     for (int u = 0; u < NB; u++) {
         const int i = tid + u * 256, p = i / CPR, c4 = i % CPR;
-        const int py = p / rw, px = p - py * rw;
+        int py = (int)(((float)p + 0.5f) * inv_rw);  // p / rw for p < 256 (a float reciprocal, corrected: no integer division per chunk)
+        py -= (py * rw > p) ? 1 : 0;
+        py += ((py + 1) * rw <= p) ? 1 : 0;
+        const int px = p - py * rw;
         b_off[u] = p < Rn ? ((ry0 + py) * W + rx0 + px) * D + c4 * 4 : -1;
     }
     int a_off[2];
@@ -270,19 +270,27 @@ __global__ __launch_bounds__(256) void corr_lookup_tiled_kernel(liso_corr_cfg c,
     for (int j = 0; j < 2; j++)
 #pragma unroll
         for (int e = 0; e < 16; e++) acc[j][e] = 0.f;
-    for (int kc = 0; kc < D; kc += kTKC) {
-        float4 va[2], vb[NB];
+    // (prefetching chunk k + 1 under chunk k needs a second register set: 288 registers, one block per CU -- measured 103 vs 66 us)
+    constexpr int NCH = D / kTKC;
+    float4 va[1][2], vb[1][NB];
+    auto load_chunk = [&](int kc, float4 (&xa)[2], float4 (&xb)[NB]) {
 #pragma unroll
-        for (int u = 0; u < 2; u++) va[u] = a_off[u] >= 0 ? *reinterpret_cast<const float4*>(f1 + a_off[u] + kc) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int u = 0; u < 2; u++) xa[u] = a_off[u] >= 0 ? *reinterpret_cast<const float4*>(f1 + a_off[u] + kc) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int u = 0; u < NB; u++)
-            vb[u] = b_off[u] >= 0 ? *reinterpret_cast<const float4*>(f2 + b_off[u] + kc) : make_float4(0.f, 0.f, 0.f, 0.f);
-        if (kc > 0) __syncthreads();  // the previous chunk's fragments have been read
+            xb[u] = b_off[u] >= 0 ? *reinterpret_cast<const float4*>(f2 + b_off[u] + kc) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+#pragma unroll
+    for (int ch = 0; ch < NCH; ch++) {
+        float4 (&xa)[2] = va[0];
+        float4 (&xb)[NB] = vb[0];
+        load_chunk(ch * kTKC, xa, xb);
+        if (ch > 0) __syncthreads();  // the previous chunk's fragments have been read
 #pragma unroll
         for (int u = 0; u < 2; u++) {
             const int i = tid + u * 256, q = i / CPR, c4 = i % CPR;
             uint2 hi, lo;
-            corr_split4(va[u], &hi, &lo);
+            corr_split4(xa[u], &hi, &lo);
             const int o = ((c4 >> 1) * kTQ + q) * 16 + (c4 & 1) * 8;
             *reinterpret_cast<uint2*>(A_hi + o) = hi;
             *reinterpret_cast<uint2*>(A_lo + o) = lo;
@@ -292,7 +300,7 @@ __global__ __launch_bounds__(256) void corr_lookup_tiled_kernel(liso_corr_cfg c,
             const int i = tid + u * 256, p = i / CPR, c4 = i % CPR;
             if (p < n_tiles * 32) {  // (rows of the last 32-row tile beyond the region: zeros)
                 uint2 hi, lo;
-                corr_split4(vb[u], &hi, &lo);
+                corr_split4(xb[u], &hi, &lo);
                 const int o = ((c4 >> 1) * kTRMax + p) * 16 + (c4 & 1) * 8;
                 *reinterpret_cast<uint2*>(B_hi + o) = hi;
                 *reinterpret_cast<uint2*>(B_lo + o) = lo;

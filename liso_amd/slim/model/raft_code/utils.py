@@ -25,10 +25,22 @@ def bilinear_sampler(img, coords, mode="bilinear", mask=False):
     return img
 
 
+_GRIDS = {}
+
+
 def coords_grid(batch, ht, wd, device):
-    """reference :31-36 -- [B,2,ht,wd] with channel 0 = x (column), channel 1 = y (row)"""
-    ys, xs = torch.meshgrid(torch.arange(ht, device=device), torch.arange(wd, device=device), indexing="ij")
-    return torch.stack([xs, ys], dim=0).float()[None].repeat(batch, 1, 1, 1)
+    """reference :31-36 -- [B,2,ht,wd] with channel 0 = x (column), channel 1 = y (row).  A constant of (batch, ht, wd, device): built
+    once (5 framework launches) and cloned per call (1) -- callers update their grid (coords1) or hold on to it (coords0)."""
+    device = torch.device(device)
+    key = (int(batch), int(ht), int(wd), device.type, device.index if device.index is not None else (torch.cuda.current_device() if device.type == "cuda" else -1))
+    g = _GRIDS.get(key)
+    if g is None:
+        if device.type == "cuda" and torch.cuda.is_current_stream_capturing():  # (no constant born inside a capture is kept beyond it)
+            ys, xs = torch.meshgrid(torch.arange(ht, device=device), torch.arange(wd, device=device), indexing="ij")
+            return torch.stack([xs, ys], dim=0).float()[None].repeat(batch, 1, 1, 1)
+        ys, xs = torch.meshgrid(torch.arange(ht, device=device), torch.arange(wd, device=device), indexing="ij")
+        g = _GRIDS[key] = torch.stack([xs, ys], dim=0).float()[None].repeat(batch, 1, 1, 1).contiguous()
+    return g.clone()
 
 
 def initialize_flow(img, downscale_factor=8):

@@ -173,7 +173,7 @@ class RAFT(nn.Module):
         infer = self.update_block.inference_state(net, inp) if (only_last and not use_w) else None  # (inference: no concatenations)
         packed = infer is not None and infer["packed"] and not vanilla  # (flow | logits) in one state pixel, one update launch per iteration
         if packed:
-            coords0, coords1 = coords0.contiguous(), coords1.contiguous().clone()
+            coords0, coords1 = coords0.contiguous(), coords1.contiguous()  # (coords_grid returns fresh tensors: coords1 is updated in place)
         with deferred_weight_gradients(self.update_block, enabled=self.training and bool(mode), direct_accumulate=mode == "direct"):
             for it in range(m.num_iters):
                 coords1 = coords1.detach()

@@ -13,10 +13,18 @@ class BevGatherPlan:
     def __init__(self, pointwise_voxel_coordinates_fs, pointwise_valid_mask, grid_hw):
         H, W = int(grid_hw[0]), int(grid_hw[1])
         B, N = pointwise_valid_mask.shape
-        c = pointwise_voxel_coordinates_fs.long()
-        b = torch.arange(B, device=c.device)[:, None]
-        lin = (b * H + c[..., 0]) * W + c[..., 1]
-        self.lin = torch.where(pointwise_valid_mask, lin, -1).to(torch.int32).reshape(-1).contiguous()
+        c, v = pointwise_voxel_coordinates_fs, pointwise_valid_mask
+        if (c.is_cuda and c.dtype in (torch.int32, torch.int64) and v.dtype in (torch.bool, torch.uint8) and c.is_contiguous()
+                and v.is_contiguous() and tuple(c.shape) == (B, N, 2)):
+            self.lin = torch.empty(B * N, dtype=torch.int32, device=c.device)  # one launch (include/liso_slim.h: liso_bev_lin_index)
+            with torch.cuda.device(c.device):
+                L.check(L.lib().liso_bev_lin_index(L.ptr(c), int(c.dtype == torch.int64), L.ptr(v), B, N, H, W, L.ptr(self.lin), L.stream_ptr()),
+                        "bev_lin_index")
+        else:
+            c = c.long()
+            b = torch.arange(B, device=c.device)[:, None]
+            lin = (b * H + c[..., 0]) * W + c[..., 1]
+            self.lin = torch.where(pointwise_valid_mask, lin, -1).to(torch.int32).reshape(-1).contiguous()
         self.shape = (B, N, H, W)
         self._sorted = None
 

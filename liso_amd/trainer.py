@@ -12,6 +12,8 @@ import os
 import torch
 import torch.distributed as dist
 
+from liso_amd import _lib as L
+
 from liso_amd.losses.centerpoint_loss import centerpoint_loss, rotation_vec_on_unit_circle
 from liso_amd.networks.simple_net.simple_net import BoxLearner
 
@@ -381,16 +383,18 @@ class DetectorTrainer:
         # the eager pillar encoder writes straight into the graph's input buffers (its own backward runs on saved feature rows)
         bev, occ = self._pillars(pcls, out=(self._static_bev.detach().permute(0, 2, 3, 1), self._static_occ))
         with torch.no_grad():
+            stage = []  # (one launch for all target tensors: _lib.multi_copy)
             if isinstance(targets, _BatchedTargets):
                 off = {}
                 for t in targets.per_sample:  # (running offset per key: samples may carry more than one row)
                     for k, v in t.items():
                         o = off.get(k, 0)
-                        self._static_targets[k][o:o + v.shape[0]].copy_(v, non_blocking=True)
+                        stage.append((self._static_targets[k][o:o + v.shape[0]], v))
                         off[k] = o + v.shape[0]
             else:
                 for k, v in targets.items():
-                    self._static_targets[k].copy_(v, non_blocking=True)
+                    stage.append((self._static_targets[k], v))
+            L.multi_copy(stage)
         self._graph.replay()
 
         def rest_of_backward():
@@ -553,15 +557,20 @@ class SlimTrainer:
         return obj
 
     @staticmethod
-    def _copy_tensors(dst, src):
+    def _copy_tensors(dst, src, _acc=None):
+        """dst <- src over a tree of tensors: the device-to-device ones as ONE launch (_lib.multi_copy)"""
+        top = _acc is None
+        acc = [] if top else _acc
         if torch.is_tensor(dst):
-            dst.copy_(src, non_blocking=True)
+            acc.append((dst, src))
         elif isinstance(dst, dict):
             for k in dst:
-                SlimTrainer._copy_tensors(dst[k], src[k])
+                SlimTrainer._copy_tensors(dst[k], src[k], acc)
         elif isinstance(dst, (list, tuple)):
             for d, s in zip(dst, src):
-                SlimTrainer._copy_tensors(d, s)
+                SlimTrainer._copy_tensors(d, s, acc)
+        if top and acc:
+            L.multi_copy(acc)
 
     def _signature(self, sample_t0, sample_t1, all_valid):
         shapes = []

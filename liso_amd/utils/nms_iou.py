@@ -141,7 +141,7 @@ def perform_nms_on_shapes_padded(boxes: Shape, max_num_boxes: int, overlap_thres
     want = {"pos": torch.float32, "dims": torch.float64, "rot": torch.float64, "probs": torch.float64, "velo": torch.float64,
             "class_id": torch.int32, "difficulty": torch.int32}
     orig = {k: getattr(boxes, k).dtype for k in want}
-    arrays = {}
+    arrays, fresh = {}, []  # fresh: (new buffer, caller's tensor) pairs copied by ONE launch (_lib.multi_copy)
     for k, dt in want.items():
         v = getattr(boxes, k)
         if k in ("pos", "dims"):
@@ -149,12 +149,20 @@ def perform_nms_on_shapes_padded(boxes: Shape, max_num_boxes: int, overlap_thres
         if k == "velo" and v.shape[-1] != 1:
             raise NotImplementedError("padded NMS: velo with more than one component")
         v = v.to(dt)
-        arrays[k] = v.clone() if v.data_ptr() == getattr(boxes, k).data_ptr() else v.contiguous()  # (permuted in place: never the caller's memory)
+        if v.data_ptr() == getattr(boxes, k).data_ptr() and v.is_contiguous() and v.is_cuda:  # (permuted in place: never the caller's memory)
+            arrays[k] = torch.empty_like(v)
+            fresh.append((arrays[k], v))
+        else:
+            arrays[k] = v.clone() if v.data_ptr() == getattr(boxes, k).data_ptr() else v.contiguous()
         if not arrays[k].is_contiguous():
             arrays[k] = arrays[k].contiguous()
     arrays["valid"] = boxes.valid.to(torch.uint8).contiguous()
     if arrays["valid"].data_ptr() == boxes.valid.data_ptr():
         arrays["valid"] = arrays["valid"].clone()
+    if fresh:
+        from liso_amd import _lib as L
+
+        L.multi_copy(fresh)
     t_arrays = MO.nms_select(arrays, max_num_boxes, overlap_threshold, pre_nms_max_num_boxes)
     out = Shape(pos=arrays["pos"].to(orig["pos"]), dims=arrays["dims"].to(orig["dims"]), rot=arrays["rot"].to(orig["rot"]),
                 probs=arrays["probs"].to(orig["probs"]), velo=arrays["velo"].to(orig["velo"]), valid=arrays["valid"].view(torch.bool),

@@ -122,3 +122,36 @@ def test_batched_gradient_gather_moves_every_tensor():
     cnt = (ctypes.c_size_t * n)(*sizes)
     L.check(L.lib().liso_gather_f32(n, src, dst, cnt, L.stream_ptr()), "gather")
     assert torch.equal(flat[:off], torch.cat(srcs)) and float(flat[off:].abs().max()) == 0.0
+
+
+def test_multi_copy_equals_tensor_copies():
+    """_lib.multi_copy: many device-to-device copies in one launch (include/liso_optim.h: liso_multi_copy) -- every dtype the staging
+    code moves, odd byte counts, misaligned slices, empty tensors, more segments than one launch takes, and the pairs it must leave to
+    copy_ (host sources, dtype changes, strided views)."""
+    import torch
+
+    from liso_amd import _lib as L
+
+    g = torch.Generator().manual_seed(0)
+    pairs, want = [], []
+    for k in range(60):
+        dt = [torch.float32, torch.int32, torch.uint8, torch.float64, torch.bool, torch.bfloat16, torch.int64][k % 7]
+        n = [0, 1, 3, 17, 255, 4096, 100003][k % 7 if k % 5 else (k // 5) % 7]
+        src = (torch.rand(n + 3, generator=g) * 100).to(dt).cuda()
+        dst = torch.zeros(n + 5, dtype=dt, device="cuda")
+        s_, d_ = src[3:], dst[1:1 + n]  # (misaligned starts)
+        pairs.append((d_, s_))
+        want.append((dst, torch.cat([dst[:1].clone(), s_.clone(), dst[1 + n:].clone()])))
+    host = torch.arange(10, dtype=torch.float32)
+    d_host = torch.zeros(10, device="cuda")
+    pairs.append((d_host, host))                                   # host source
+    d_cast = torch.zeros(6, device="cuda", dtype=torch.float64)
+    pairs.append((d_cast, torch.arange(6, device="cuda", dtype=torch.float32)))  # dtype change
+    base = torch.zeros(8, 4, device="cuda")
+    pairs.append((base[:, 1], torch.arange(8, device="cuda", dtype=torch.float32)))  # strided destination
+    L.multi_copy(pairs)
+    torch.cuda.synchronize()
+    for dst, exp in want:
+        assert torch.equal(dst, exp)
+    assert torch.equal(d_host.cpu(), host) and torch.equal(d_cast.cpu(), torch.arange(6, dtype=torch.float64))
+    assert torch.equal(base[:, 1].cpu(), torch.arange(8, dtype=torch.float32)) and float(base[:, 0].abs().max()) == 0
