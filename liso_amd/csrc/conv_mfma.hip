@@ -1144,6 +1144,141 @@ __global__ __launch_bounds__(512, 1) void conv_roles_kernel(const liso_conv_desc
     }
 }
 
+// ---- 1x1 convolutions (any stride), F32X3: fragments straight from global memory ------------------------------------------------
+// Tile geometry, epilogue and statistics rows as conv_igemm_kernel (4 waves x MI rows of 32 pixels x 32 NJ filters per block), but no
+// staging: lane (r, h) of a wave reads channels [k0 + 8 h, k0 + 8 h + 8) of ITS pixel r -- two 16-byte loads, the pending BatchNorm /
+// InstanceNorm + ReLU of the producer applied in registers, split into bf16 hi / lo -- and the weight fragments come packed in fragment
+// order ([tap][k8][n][8]: 16 bytes per lane, 512 contiguous bytes per lane half).  The loads of k-step t + 1 are in flight under the
+// MFMAs of step t.  Measured (round 5, scripts/slim_infer_layers.py): see DESIGN.md section 4.
+template <int MI, int NJ, bool PRO>
+__global__ __launch_bounds__(kThreads, 2) void conv_1x1_kernel(const liso_conv_desc d, const FwdArgs a) {
+    constexpr int BNT = 32 * NJ;
+    constexpr int TH = 4 * MI;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 96 * 2 * 4];
+    const int tid_all = threadIdx.x, wave = tid_all >> 6, lane = tid_all & 63, r = lane & 31, h = lane >> 5;
+    int t = xcd_remap(blockIdx.x, a.total);
+    const int nt = t % a.n_nt;
+    t /= a.n_nt;
+    const int tx = t % a.tiles_x;
+    t /= a.tiles_x;
+    const int ty = t % a.tiles_y;
+    const int b = t / a.tiles_y;
+    const int stats_row = (b * a.tiles_y + ty) * a.tiles_x + tx;
+    const int n0 = nt * BNT;
+    // the lane's pixel per tile row
+    const float* xp[MI];
+    bool okp[MI];
+#pragma unroll
+    for (int i = 0; i < MI; i++) {
+        const int vy = ty * TH + wave * MI + i, vx = tx * 32 + r;
+        const int iy = vy * d.isy + d.tap_dy[0], ix = vx * d.isx + d.tap_dx[0];
+        okp[i] = vy < d.hv && vx < d.wv && (unsigned)iy < (unsigned)d.hi && (unsigned)ix < (unsigned)d.wi;
+        xp[i] = (const float*)a.x + (okp[i] ? (((long)b * d.hi + iy) * d.wi + ix) * d.x_pix_stride : 0);
+    }
+    const unsigned short* wg = (const unsigned short*)a.w;
+    const int kgroups = a.ci_pad >> 3;
+    const long plane_elems = (long)d.w_taps * kgroups * a.co_pad * 8;
+    const unsigned short* wl[NJ];
+    bool okn[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+        const int n = n0 + j * 32 + r;
+        okn[j] = n < a.co_pad;
+        wl[j] = wg + ((long)d.tap_w[0] * kgroups * a.co_pad + (okn[j] ? n : 0)) * 8;
+    }
+    const int aff = b * d.in_affine_batch_stride;
+    struct Frag {
+        float4 x[MI][2];
+        float4 sc[2], sh[2];
+        uint4 bh[NJ], bl[NJ];
+    };
+    auto load = [&](int k0, Frag& F) {  // k0: first channel of the 16-channel step (clamped: the last step may be issued twice)
+        const int c = k0 + 8 * h;       // this lane's 8 channels
+        const int c_lo = c < d.ci ? c : 0, c_hi = c + 4 < d.ci ? c + 4 : 0;  // (ci is a multiple of 4: a 16-byte chunk is whole or absent)
+#pragma unroll
+        for (int i = 0; i < MI; i++) {
+            F.x[i][0] = *reinterpret_cast<const float4*>(xp[i] + c_lo);
+            F.x[i][1] = *reinterpret_cast<const float4*>(xp[i] + c_hi);
+        }
+        if constexpr (PRO) {
+            F.sc[0] = *reinterpret_cast<const float4*>(a.in_scale + aff + c_lo);
+            F.sc[1] = *reinterpret_cast<const float4*>(a.in_scale + aff + c_hi);
+            F.sh[0] = *reinterpret_cast<const float4*>(a.in_shift + aff + c_lo);
+            F.sh[1] = *reinterpret_cast<const float4*>(a.in_shift + aff + c_hi);
+        }
+        const long ko = (long)((k0 >> 3) + h) * a.co_pad * 8;
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            F.bh[j] = *reinterpret_cast<const uint4*>(wl[j] + ko);
+            F.bl[j] = *reinterpret_cast<const uint4*>(wl[j] + plane_elems + ko);
+        }
+    };
+    f16v acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; i++)
+#pragma unroll
+        for (int j = 0; j < NJ; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
+    auto mul = [&](int k0, const Frag& F) {
+        const int c = k0 + 8 * h;
+        const bool v0 = c < d.ci, v1 = c + 4 < d.ci;
+        uint4 ah[MI], al[MI];
+#pragma unroll
+        for (int i = 0; i < MI; i++) {
+            float f[8] = {F.x[i][0].x, F.x[i][0].y, F.x[i][0].z, F.x[i][0].w, F.x[i][1].x, F.x[i][1].y, F.x[i][1].z, F.x[i][1].w};
+            if constexpr (PRO) {
+                const float sc[8] = {F.sc[0].x, F.sc[0].y, F.sc[0].z, F.sc[0].w, F.sc[1].x, F.sc[1].y, F.sc[1].z, F.sc[1].w};
+                const float sh[8] = {F.sh[0].x, F.sh[0].y, F.sh[0].z, F.sh[0].w, F.sh[1].x, F.sh[1].y, F.sh[1].z, F.sh[1].w};
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    f[e] = fmaf(f[e], sc[e], sh[e]);
+                    if (d.in_relu) f[e] = fmaxf(f[e], 0.0f);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; e++)
+                if (!(okp[i] && (e < 4 ? v0 : v1))) f[e] = 0.0f;
+            unsigned hi[4], lo[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                hi[e] = pack_bf16(f[2 * e], f[2 * e + 1]);
+                lo[e] = pack_bf16(f[2 * e] - bf16_lo(hi[e]), f[2 * e + 1] - bf16_hi(hi[e]));
+            }
+            ah[i] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+            al[i] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            const uint4 bh = okn[j] ? F.bh[j] : make_uint4(0u, 0u, 0u, 0u), bl = okn[j] ? F.bl[j] : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+            for (int i = 0; i < MI; i++) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(al[i]), as_bf8(bh), acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(ah[i]), as_bf8(bl), acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(ah[i]), as_bf8(bh), acc[i][j], 0, 0, 0);
+            }
+        }
+    };
+    const int K = a.ci_pad;  // multiple of 16
+    Frag F0, F1;
+    load(0, F0);
+    for (int k0 = 0; k0 < K; k0 += 32) {
+        const int k1 = k0 + 16 < K ? k0 + 16 : k0;  // (beyond the end: the same step again, not multiplied)
+        load(k1, F1);
+        __builtin_amdgcn_sched_barrier(0);
+        mul(k0, F0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (k0 + 16 < K) {
+            const int k2 = k0 + 32 < K ? k0 + 32 : k0;
+            load(k2, F0);
+            __builtin_amdgcn_sched_barrier(0);
+            mul(k0 + 16, F1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    conv_epilogue<MI, NJ, true>(d, a, acc, 0, b, tx, ty, wave, r, h, true, n0, stats_row, tid_all, smem);
+}
+
 // ---- weight packing ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void pack_chunk(const float* __restrict__ src, int d1, int taps, int swap_ab, int K, int N, int Kp, int Np,
                                            int f32, unsigned short* __restrict__ dst, long q);
@@ -1339,6 +1474,15 @@ int launch_roles(const liso_conv_desc& d, const Plan& p, hipStream_t st) {
                         : launch_roles_pro<MODE, MI, NJ, OUT_F32, NTAPS, false>(d, p, st);
 }
 
+template <int MI, int NJ>
+int launch_1x1(const liso_conv_desc& d, const Plan& p, hipStream_t st) {
+    if (p.a.in_scale)
+        conv_1x1_kernel<MI, NJ, true><<<p.a.total, kThreads, 0, st>>>(d, p.a);
+    else
+        conv_1x1_kernel<MI, NJ, false><<<p.a.total, kThreads, 0, st>>>(d, p.a);
+    return check_launch();
+}
+
 template <int MODE, int MI, int NJ, bool OUT_F32, int CS, int SK = 1>
 int launch(const liso_conv_desc& d, const Plan& p, hipStream_t st) {
     static bool attr_set = false;
@@ -1407,13 +1551,13 @@ int liso_conv_pack_weights_batched(const liso_conv_pack_job* jobs, int n_jobs, v
 int liso_conv_kernel_kind(const liso_conv_desc* d) {
     Plan p;
     if (!d || !make_plan(*d, &p)) return -1;
-    return p.a.roles ? 1 : 0;
+    return p.a.roles ? 1 : p.a.direct1x1 ? 2 : 0;
 }
 
 int liso_conv_plan_info(const liso_conv_desc* d, int info[8]) {
     Plan p;
     if (!d || !info || !make_plan(*d, &p)) return LISO_EINVAL;
-    info[0] = p.a.roles;
+    info[0] = p.a.roles ? 1 : p.a.direct1x1 ? 2 : 0;
     info[1] = p.mi;
     info[2] = p.nj;
     info[3] = p.sk;
@@ -1483,6 +1627,16 @@ int liso_conv_forward_sparse(const liso_conv_desc* d, const void* x, const void*
             LISO_ROLES(LISO_CONV_BF16, false);
         }
 #undef LISO_ROLES
+        return LISO_EINVAL;
+    }
+    if (p.a.direct1x1) {
+        if (((uintptr_t)in_scale | (uintptr_t)in_shift) & 15) return LISO_EINVAL;
+        if (p.mi == 1 && p.nj == 1) return launch_1x1<1, 1>(*d, p, st);
+        if (p.mi == 1 && p.nj == 2) return launch_1x1<1, 2>(*d, p, st);
+        if (p.mi == 1 && p.nj == 3) return launch_1x1<1, 3>(*d, p, st);
+        if (p.mi == 2 && p.nj == 1) return launch_1x1<2, 1>(*d, p, st);
+        if (p.mi == 2 && p.nj == 2) return launch_1x1<2, 2>(*d, p, st);
+        if (p.mi == 2 && p.nj == 3) return launch_1x1<2, 3>(*d, p, st);
         return LISO_EINVAL;
     }
     if (x3 && p.sk == 2)

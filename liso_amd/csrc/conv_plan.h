@@ -36,6 +36,7 @@ struct FwdArgs {
     int roles;          // conv_roles_kernel (loader waves + MFMA waves, double-buffered LDS): 3x3 / 1x1, stride 1, one class
     int wide_out;       // roles: 16-byte output stores through an LDS patch (channel count and strides allow them)
     unsigned long long roles_tapw;  // roles: 4 bits per window position (ty * 3 + tx): the tap's index inside the packed weights
+    int direct1x1;      // conv_1x1_kernel: one tap, fragments straight from global memory (no LDS staging, no barrier in the reduction)
 };
 
 int round_up(int v, int m) { return (v + m - 1) / m * m; }
@@ -120,6 +121,30 @@ void plan_roles(const liso_conv_desc& d, Plan* p) {
     const int cv = of32 ? 4 : 8;  // channels per 16-byte store
     static const int wide_env = getenv("LISO_ROLES_WIDE") ? atoi(getenv("LISO_ROLES_WIDE")) : 1;
     a.wide_out = (wide_env && d.co % cv == 0 && d.y_pix_stride % cv == 0 && d.y_ch_off % cv == 0) ? 1 : 0;
+}
+
+// conv_1x1_kernel: F32X3, one class, ONE tap (1x1 convolutions of any stride: the residual shortcuts of liso/slim/model/extractor.py and
+// conv_stat_corr1 of update.py:49).  conv_igemm_kernel runs them as 3-13 channel slabs of load -> LDS -> barrier -> one tap of MFMAs ->
+// barrier (14-29 us for 0.1-0.9 GFLOP); here every wave reads its A fragments (32 pixels x 8 channels per lane half) and the weight
+// fragments (packed in fragment order already) straight from global memory, one k-step ahead, and nothing synchronises before the epilogue.
+void plan_1x1(const liso_conv_desc& d, Plan* p) {
+    FwdArgs& a = p->a;
+    a.direct1x1 = 0;
+    static const int env = getenv("LISO_CONV_1X1") ? atoi(getenv("LISO_CONV_1X1")) : 1;
+    if (!env || a.roles || d.mode != LISO_CONV_F32X3 || d.n_classes != 1 || d.n_taps != 1 || d.osy != 1 || d.osx != 1) return;
+    if (d.tap_w[0] < 0 || d.tap_w[0] >= d.w_taps || (d.in_affine_batch_stride & 3)) return;
+    const int nj = d.co <= 32 ? 1 : d.co <= 64 ? 2 : (d.co + 95) / 96 <= (d.co + 63) / 64 ? 3 : 2;
+    const long tiles4 = (long)d.batch * ((d.hv + 3) / 4) * ((d.wv + 31) / 32) * ((d.co + 32 * nj - 1) / (32 * nj));
+    const int mi = tiles4 >= 1024 ? 2 : 1;  // (8-row tiles once 4-row tiles would give every CU four blocks anyway)
+    a.direct1x1 = 1;
+    p->mi = mi;
+    p->nj = nj;
+    p->sk = 1;
+    const int bnt = 32 * nj, th = 4 * mi;
+    a.n_nt = (d.co + bnt - 1) / bnt;
+    a.tiles_x = (d.wv + 31) / 32;
+    a.tiles_y = (d.hv + th - 1) / th;
+    a.total = d.batch * a.tiles_y * a.tiles_x * a.n_nt;
 }
 
 bool make_plan(const liso_conv_desc& d, Plan* p) {
@@ -289,6 +314,7 @@ bool make_plan(const liso_conv_desc& d, Plan* p) {
     // than this kernel -- one block per CU, every wave both loads and multiplies; round 5's conv_roles_kernel is the role-split form
     // that works, and the experiment was removed)
     plan_roles(d, p);
+    plan_1x1(d, p);
     return true;
 }
 
