@@ -200,7 +200,7 @@ __device__ __forceinline__ void conv_epilogue(const liso_conv_desc& d, const Fwd
             }
         }
         __syncthreads();
-        if (tid_all < BNT) {
+        if (tid_all < BNT && n0 + tid < a.co_pad) {  // (a 96-filter panel may reach beyond the padded filter count: no statistics columns there)
             float q1 = 0.0f, q2 = 0.0f;
 #pragma unroll
             for (int w = 0; w < 4; w++) {
