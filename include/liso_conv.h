@@ -100,8 +100,9 @@ int liso_conv_pack_weights_batched(const liso_conv_pack_job* jobs, int n_jobs, v
 int liso_conv_stats_rows(const liso_conv_desc* d);
 
 /* which kernel liso_conv_forward launches for `d`: 0 = conv_igemm_kernel, 1 = conv_roles_kernel (3x3 / stride 1 / one tap class: loader
- * waves + MFMA waves, persistent blocks), -1 = geometry not covered.  For measurement code that
- * attributes launch times to kernels (bench.py's `roofline`); the choice itself is internal. */
+ * waves + MFMA waves, persistent blocks), 2 = conv_1x1_kernel (one tap, fp32 tensors: fragments straight from global memory),
+ * 3 = conv_taps_kernel (any window on <= 8 fp32 input channels: two taps per MFMA step), -1 = geometry not covered.  For measurement
+ * code that attributes launch times to kernels (bench.py's `roofline`) and for tests; the choice itself is internal. */
 int liso_conv_kernel_kind(const liso_conv_desc* d);
 
 /* the launch plan of liso_conv_forward for `d` (tests, measurement scripts): info = {kernel kind as above, tile rows / 4, panel width / 32,

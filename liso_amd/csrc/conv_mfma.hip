@@ -1279,6 +1279,139 @@ __global__ __launch_bounds__(kThreads, 2) void conv_1x1_kernel(const liso_conv_d
     conv_epilogue<MI, NJ, true>(d, a, acc, 0, b, tx, ty, wave, r, h, true, n0, stats_row, tid_all, smem);
 }
 
+// ---- windows on 2-8 input channels, F32X3: two taps per MFMA step, fragments straight from global memory ---------------------------
+// (plan_taps, conv_plan.h.)  Lane (r, h) of step s reads the <= 8 channels of pixel r SHIFTED by tap 2 s + h (zero outside the map and
+// for the odd tap count's last half step) and the weight fragment of that tap (packed [tap][k8 = 0][n][8]: its channels 8-15 are the
+// padding that conv_igemm_kernel multiplies).  Tile geometry, epilogue and statistics rows as conv_igemm_kernel with 4-row tiles.
+template <int NJ, bool PRO>
+__global__ __launch_bounds__(kThreads, 2) void conv_taps_kernel(const liso_conv_desc d, const FwdArgs a) {
+    constexpr int BNT = 32 * NJ;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 96 * 2 * 4];
+    __shared__ int s_dy[LISO_CONV_MAX_TAPS + 1], s_dx[LISO_CONV_MAX_TAPS + 1], s_w[LISO_CONV_MAX_TAPS + 1];
+    const int tid_all = threadIdx.x, wave = tid_all >> 6, lane = tid_all & 63, r = lane & 31, h = lane >> 5;
+    if (tid_all <= d.n_taps && tid_all <= LISO_CONV_MAX_TAPS) {  // (entry n_taps: the odd count's missing tap -- far outside every map)
+        const bool real = tid_all < d.n_taps;
+        s_dy[tid_all] = real ? d.tap_dy[tid_all] : (1 << 28);
+        s_dx[tid_all] = real ? d.tap_dx[tid_all] : (1 << 28);
+        s_w[tid_all] = real ? d.tap_w[tid_all] : 0;
+    }
+    int t = xcd_remap(blockIdx.x, a.total);
+    const int nt = t % a.n_nt;
+    t /= a.n_nt;
+    const int tx = t % a.tiles_x;
+    t /= a.tiles_x;
+    const int ty = t % a.tiles_y;
+    const int b = t / a.tiles_y;
+    const int stats_row = (b * a.tiles_y + ty) * a.tiles_x + tx;
+    const int n0 = nt * BNT;
+    const int vy = ty * 4 + wave, vx = tx * 32 + r;
+    const bool okv = vy < d.hv && vx < d.wv;
+    const int by = vy * d.isy, bx = vx * d.isx;
+    const float* xb = (const float*)a.x + (long)b * d.hi * d.wi * d.x_pix_stride;
+    const unsigned short* wg = (const unsigned short*)a.w;
+    const int kgroups = a.ci_pad >> 3;
+    const long plane_elems = (long)d.w_taps * kgroups * a.co_pad * 8;
+    int wn[NJ];
+    bool okn[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+        const int n = n0 + j * 32 + r;
+        okn[j] = n < a.co_pad;
+        wn[j] = (okn[j] ? n : 0) * 8;
+    }
+    const bool c1 = d.ci > 4;  // (ci is a multiple of 4: the second 16-byte chunk of the lane's 8 channels exists or not)
+    float sc[8], sh[8];
+    if constexpr (PRO) {
+        const int aff = b * d.in_affine_batch_stride;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const bool ok = e < d.ci;
+            sc[e] = ok ? a.in_scale[aff + e] : 0.0f;
+            sh[e] = ok ? a.in_shift[aff + e] : 0.0f;
+        }
+    }
+    __syncthreads();
+    struct Frag {
+        float4 x[2];
+        uint4 bh[NJ], bl[NJ];
+        bool ok;
+    };
+    const int NS = (d.n_taps + 1) >> 1;
+    auto load = [&](int s_, Frag& F) {
+        const int tap = 2 * s_ + h;
+        const int iy = by + s_dy[tap], ix = bx + s_dx[tap];
+        F.ok = okv && (unsigned)iy < (unsigned)d.hi && (unsigned)ix < (unsigned)d.wi;
+        const float* px = xb + (F.ok ? ((long)iy * d.wi + ix) * d.x_pix_stride : 0);
+        F.x[0] = *reinterpret_cast<const float4*>(px);
+        F.x[1] = *reinterpret_cast<const float4*>(px + (c1 ? 4 : 0));
+        const long ko = (long)s_w[tap] * kgroups * a.co_pad * 8;
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            F.bh[j] = *reinterpret_cast<const uint4*>(wg + ko + wn[j]);
+            F.bl[j] = *reinterpret_cast<const uint4*>(wg + plane_elems + ko + wn[j]);
+        }
+    };
+    f16v acc[1][NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; j++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[0][j][e] = 0.0f;
+    auto mul = [&](int s_, const Frag& F) {
+        const bool real = 2 * s_ + h < d.n_taps;
+        float f[8] = {F.x[0].x, F.x[0].y, F.x[0].z, F.x[0].w, F.x[1].x, F.x[1].y, F.x[1].z, F.x[1].w};
+        if constexpr (PRO) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                f[e] = fmaf(f[e], sc[e], sh[e]);
+                if (d.in_relu) f[e] = fmaxf(f[e], 0.0f);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; e++)
+            if (!(F.ok && real && (e < 4 || c1))) f[e] = 0.0f;
+        unsigned hi[4], lo[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            hi[e] = pack_bf16(f[2 * e], f[2 * e + 1]);
+            lo[e] = pack_bf16(f[2 * e] - bf16_lo(hi[e]), f[2 * e + 1] - bf16_hi(hi[e]));
+        }
+        const uint4 ah = make_uint4(hi[0], hi[1], hi[2], hi[3]), al = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            const bool okb = okn[j] && real;
+            const uint4 bh = okb ? F.bh[j] : make_uint4(0u, 0u, 0u, 0u), bl = okb ? F.bl[j] : make_uint4(0u, 0u, 0u, 0u);
+            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(al), as_bf8(bh), acc[0][j], 0, 0, 0);
+            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(ah), as_bf8(bl), acc[0][j], 0, 0, 0);
+            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(ah), as_bf8(bh), acc[0][j], 0, 0, 0);
+        }
+    };
+    // three steps in the air: the loads of steps s + 1 and s + 2 are in flight under the MFMAs of step s (beyond the end: the last
+    // step again, never multiplied -- no branch around a load)
+    Frag F0, F1, F2;
+    auto at = [&](int s_) { return s_ < NS ? s_ : NS - 1; };
+    load(0, F0);
+    load(at(1), F1);
+    for (int s_ = 0; s_ < NS; s_ += 3) {
+        load(at(s_ + 2), F2);
+        __builtin_amdgcn_sched_barrier(0);
+        mul(s_, F0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s_ + 1 < NS) {
+            load(at(s_ + 3), F0);
+            __builtin_amdgcn_sched_barrier(0);
+            mul(s_ + 1, F1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (s_ + 2 < NS) {
+            load(at(s_ + 4), F1);
+            __builtin_amdgcn_sched_barrier(0);
+            mul(s_ + 2, F2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    conv_epilogue<1, NJ, true>(d, a, acc, 0, b, tx, ty, wave, r, h, true, n0, stats_row, tid_all, smem);
+}
+
 // ---- weight packing ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void pack_chunk(const float* __restrict__ src, int d1, int taps, int swap_ab, int K, int N, int Kp, int Np,
                                            int f32, unsigned short* __restrict__ dst, long q);
@@ -1483,6 +1616,15 @@ int launch_1x1(const liso_conv_desc& d, const Plan& p, hipStream_t st) {
     return check_launch();
 }
 
+template <int NJ>
+int launch_taps(const liso_conv_desc& d, const Plan& p, hipStream_t st) {
+    if (p.a.in_scale)
+        conv_taps_kernel<NJ, true><<<p.a.total, kThreads, 0, st>>>(d, p.a);
+    else
+        conv_taps_kernel<NJ, false><<<p.a.total, kThreads, 0, st>>>(d, p.a);
+    return check_launch();
+}
+
 template <int MODE, int MI, int NJ, bool OUT_F32, int CS, int SK = 1>
 int launch(const liso_conv_desc& d, const Plan& p, hipStream_t st) {
     static bool attr_set = false;
@@ -1551,13 +1693,13 @@ int liso_conv_pack_weights_batched(const liso_conv_pack_job* jobs, int n_jobs, v
 int liso_conv_kernel_kind(const liso_conv_desc* d) {
     Plan p;
     if (!d || !make_plan(*d, &p)) return -1;
-    return p.a.roles ? 1 : p.a.direct1x1 ? 2 : 0;
+    return p.a.roles ? 1 : p.a.direct1x1 ? 2 : p.a.direct_taps ? 3 : 0;
 }
 
 int liso_conv_plan_info(const liso_conv_desc* d, int info[8]) {
     Plan p;
     if (!d || !info || !make_plan(*d, &p)) return LISO_EINVAL;
-    info[0] = p.a.roles ? 1 : p.a.direct1x1 ? 2 : 0;
+    info[0] = p.a.roles ? 1 : p.a.direct1x1 ? 2 : p.a.direct_taps ? 3 : 0;
     info[1] = p.mi;
     info[2] = p.nj;
     info[3] = p.sk;
@@ -1637,6 +1779,12 @@ int liso_conv_forward_sparse(const liso_conv_desc* d, const void* x, const void*
         if (p.mi == 2 && p.nj == 1) return launch_1x1<2, 1>(*d, p, st);
         if (p.mi == 2 && p.nj == 2) return launch_1x1<2, 2>(*d, p, st);
         if (p.mi == 2 && p.nj == 3) return launch_1x1<2, 3>(*d, p, st);
+        return LISO_EINVAL;
+    }
+    if (p.a.direct_taps) {
+        if (p.nj == 1) return launch_taps<1>(*d, p, st);
+        if (p.nj == 2) return launch_taps<2>(*d, p, st);
+        if (p.nj == 3) return launch_taps<3>(*d, p, st);
         return LISO_EINVAL;
     }
     if (x3 && p.sk == 2)

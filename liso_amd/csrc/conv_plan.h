@@ -37,6 +37,7 @@ struct FwdArgs {
     int wide_out;       // roles: 16-byte output stores through an LDS patch (channel count and strides allow them)
     unsigned long long roles_tapw;  // roles: 4 bits per window position (ty * 3 + tx): the tap's index inside the packed weights
     int direct1x1;      // conv_1x1_kernel: one tap, fragments straight from global memory (no LDS staging, no barrier in the reduction)
+    int direct_taps;    // conv_taps_kernel: <= 8 input channels, any window: two taps per 16-wide MFMA step, fragments from global memory
 };
 
 int round_up(int v, int m) { return (v + m - 1) / m * m; }
@@ -123,6 +124,20 @@ void plan_roles(const liso_conv_desc& d, Plan* p) {
     a.wide_out = (wide_env && d.co % cv == 0 && d.y_pix_stride % cv == 0 && d.y_ch_off % cv == 0) ? 1 : 0;
 }
 
+// panel width (in 32-filter tiles) of the direct kernels: the fewest (blocks per pixel tile) x (per-step cost ~ 2 + nj): 128 filters as
+// 2 x 64 rather than 96 + 32 (the block of the narrow remainder pays the same A loads and the same latency per step)
+inline int direct_panel_width(int co) {
+    int best = 1, best_cost = 1 << 30;
+    for (int nj = 1; nj <= 3; nj++) {
+        const int cost = ((co + 32 * nj - 1) / (32 * nj)) * (2 + nj);
+        if (cost < best_cost) {
+            best_cost = cost;
+            best = nj;
+        }
+    }
+    return best;
+}
+
 // conv_1x1_kernel: F32X3, one class, ONE tap (1x1 convolutions of any stride: the residual shortcuts of liso/slim/model/extractor.py and
 // conv_stat_corr1 of update.py:49).  conv_igemm_kernel runs them as 3-13 channel slabs of load -> LDS -> barrier -> one tap of MFMAs ->
 // barrier (14-29 us for 0.1-0.9 GFLOP); here every wave reads its A fragments (32 pixels x 8 channels per lane half) and the weight
@@ -133,7 +148,7 @@ void plan_1x1(const liso_conv_desc& d, Plan* p) {
     static const int env = getenv("LISO_CONV_1X1") ? atoi(getenv("LISO_CONV_1X1")) : 1;
     if (!env || a.roles || d.mode != LISO_CONV_F32X3 || d.n_classes != 1 || d.n_taps != 1 || d.osy != 1 || d.osx != 1) return;
     if (d.tap_w[0] < 0 || d.tap_w[0] >= d.w_taps || (d.in_affine_batch_stride & 3)) return;
-    const int nj = d.co <= 32 ? 1 : d.co <= 64 ? 2 : (d.co + 95) / 96 <= (d.co + 63) / 64 ? 3 : 2;
+    const int nj = direct_panel_width(d.co);
     const long tiles4 = (long)d.batch * ((d.hv + 3) / 4) * ((d.wv + 31) / 32) * ((d.co + 32 * nj - 1) / (32 * nj));
     const int mi = tiles4 >= 1024 ? 2 : 1;  // (8-row tiles once 4-row tiles would give every CU four blocks anyway)
     a.direct1x1 = 1;
@@ -144,6 +159,31 @@ void plan_1x1(const liso_conv_desc& d, Plan* p) {
     a.n_nt = (d.co + bnt - 1) / bnt;
     a.tiles_x = (d.wv + 31) / 32;
     a.tiles_y = (d.hv + th - 1) / th;
+    a.total = d.batch * a.tiles_y * a.tiles_x * a.n_nt;
+}
+
+// conv_taps_kernel: F32X3, one class, at most 8 input channels, 2+ taps (the motion encoder's 7x7 convolutions on flow / logits,
+// update.py:54-59: 2-8 channels).  conv_igemm_kernel pads the channels to a 16-channel slab per tap -- half (8 channels) to seven
+// eighths (2) of every MFMA multiply zeros, 49 tap stages of load -> LDS -> barrier each; here one 16-wide MFMA step holds TWO taps x 8
+// channels (lane half h takes tap 2 s + h: its pixel is shifted by that tap), fragments straight from global memory.
+void plan_taps(const liso_conv_desc& d, Plan* p) {
+    FwdArgs& a = p->a;
+    a.direct_taps = 0;
+    static const int env = getenv("LISO_CONV_TAPS") ? atoi(getenv("LISO_CONV_TAPS")) : 1;
+    if (!env || a.roles || a.direct1x1 || d.mode != LISO_CONV_F32X3 || d.n_classes != 1 || d.n_taps < 2 || d.ci > 8 || d.osy != 1 || d.osx != 1)
+        return;
+    if (d.in_affine_batch_stride & 3) return;
+    for (int t = 0; t < d.n_taps; t++)
+        if (d.tap_w[t] < 0 || d.tap_w[t] >= d.w_taps) return;
+    const int nj = direct_panel_width(d.co);
+    a.direct_taps = 1;
+    p->mi = 1;
+    p->nj = nj;
+    p->sk = 1;
+    const int bnt = 32 * nj;
+    a.n_nt = (d.co + bnt - 1) / bnt;
+    a.tiles_x = (d.wv + 31) / 32;
+    a.tiles_y = (d.hv + 3) / 4;
     a.total = d.batch * a.tiles_y * a.tiles_x * a.n_nt;
 }
 
@@ -315,6 +355,7 @@ bool make_plan(const liso_conv_desc& d, Plan* p) {
     // that works, and the experiment was removed)
     plan_roles(d, p);
     plan_1x1(d, p);
+    plan_taps(d, p);
     return true;
 }
 

@@ -128,3 +128,51 @@ def test_run_to_run_bitwise_and_not_a_number_free_padding():
     assert torch.equal(y1.cpu().nan_to_num(1234.0), y2.cpu().nan_to_num(1234.0))
     bad = torch.isnan(y1).any(dim=1)
     assert int(bad.sum()) == 1 and bool(bad[0, 0, 0])  # only the poisoned pixel's own outputs
+
+
+# ---- conv_taps_kernel: windows on 2-8 input channels (two taps per MFMA step) -----------------------------------------------------------
+# (B, Ci, Co, H, W, k, stride)
+TAP_SHAPES = [
+    (4, 8, 128, 64, 64, 7, 1),    # the motion encoder's merged conv_class1 | conv_flow1 on the packed state pixel (update.py:54-59)
+    (2, 4, 64, 33, 45, 7, 1),     # conv_class1 alone, partial tiles
+    (1, 4, 32, 16, 16, 5, 1),
+    (3, 8, 100, 20, 70, 3, 1),    # 9 taps: the odd count's last half step
+    (2, 8, 40, 31, 47, 3, 2),     # stride 2
+    (1, 4, 7, 5, 9, 7, 1),        # one partial tile, windows larger than the map
+]
+
+
+@pytest.mark.parametrize("shape", TAP_SHAPES)
+def test_small_channel_windows(shape):
+    from liso_amd import _lib as L
+    from liso_amd.utils import mfma_conv as MC
+
+    B, Ci, Co, H, W, k, st = shape
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, k, k, generator=g) / (Ci * k * k) ** 0.5
+    b = torch.randn(Co, generator=g) * 0.3
+    spec = MC.ConvSpec(k, k, st, k // 2, False)
+    xd = x.to(DEV).contiguous(memory_format=torch.channels_last)
+    xv, xps = MC.as_nhwc(xd, 4)
+    ho, wo = spec.out_hw(H, W)
+    d = MC.gather_desc(spec, B, H, W, Ci, xps, ho, wo, Co, Co, 0, L.CONV_F32X3, True, False, False)
+    assert L.lib().liso_conv_kernel_kind(ctypes.byref(d)) == 3, "descriptor does not take conv_taps_kernel"
+    y, _ = MC.conv_forward(xd, w.to(DEV), b.to(DEV), spec, out_relu=True)
+    ref = F.relu(F.conv2d(x.double(), w.double(), b.double(), stride=st, padding=k // 2))
+    assert y.shape == ref.shape and _rel(y, ref) <= 2e-5
+    sc, sh = torch.rand(Ci, generator=g) + 0.5, torch.randn(Ci, generator=g) * 0.2
+    y2, part = MC.conv_forward(xd, w.to(DEV), None, spec, sc.to(DEV), sh.to(DEV), in_relu=True, want_stats=True)
+    xin = F.relu(x.double() * sc.double()[None, :, None, None] + sh.double()[None, :, None, None])
+    assert _rel(y2, F.conv2d(xin, w.double(), None, stride=st, padding=k // 2)) <= 2e-5
+    stored = y2.double()
+    s1, s2 = part[:, 0, :Co].double().sum(0).cpu(), part[:, 1, :Co].double().sum(0).cpu()
+    assert torch.allclose(s1, stored.sum((0, 2, 3)).cpu(), rtol=1e-4, atol=1e-3 * float(stored.abs().max()))
+    assert torch.allclose(s2, stored.square().sum((0, 2, 3)).cpu(), rtol=1e-4, atol=1e-6)
+    if Co % 8 == 0:
+        buf = torch.full((B, ho, wo, Co + 16), 7.0, dtype=torch.float32, device=DEV)
+        y3, _ = MC.conv_forward(xd, w.to(DEV), b.to(DEV), spec, out=(buf, 8))
+        assert _rel(y3, F.conv2d(x.double(), w.double(), b.double(), stride=st, padding=k // 2)) <= 2e-5
+        assert bool((buf[..., :8] == 7.0).all()) and bool((buf[..., 8 + Co:] == 7.0).all())
+    y4, _ = MC.conv_forward(xd, w.to(DEV), b.to(DEV), spec, out_relu=True)
+    assert torch.equal(y, y4)
