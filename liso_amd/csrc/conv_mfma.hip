@@ -1144,18 +1144,26 @@ __global__ __launch_bounds__(512, 1) void conv_roles_kernel(const liso_conv_desc
     }
 }
 
-// ---- 1x1 convolutions (any stride), F32X3: fragments straight from global memory ------------------------------------------------
+// ---- 1x1 convolutions (any stride) and narrow 3x3 layers, F32X3: fragments straight from global memory ---------------------------------
 // Tile geometry, epilogue and statistics rows as conv_igemm_kernel (4 waves x MI rows of 32 pixels x 32 NJ filters per block), but no
-// staging: lane (r, h) of a wave reads channels [k0 + 8 h, k0 + 8 h + 8) of ITS pixel r -- two 16-byte loads, the pending BatchNorm /
-// InstanceNorm + ReLU of the producer applied in registers, split into bf16 hi / lo -- and the weight fragments come packed in fragment
-// order ([tap][k8][n][8]: 16 bytes per lane, 512 contiguous bytes per lane half).  The loads of k-step t + 1 are in flight under the
-// MFMAs of step t.  Measured (round 5, scripts/slim_infer_layers.py): see DESIGN.md section 4.
+// staging: lane (r, h) of a wave reads channels [k0 + 8 h, k0 + 8 h + 8) of ITS pixel r shifted by the tap -- two 16-byte loads, the
+// pending BatchNorm / InstanceNorm + ReLU of the producer applied in registers, split into bf16 hi / lo -- and the weight fragments come
+// packed in fragment order ([tap][k8][n][8]: 16 bytes per lane, 512 contiguous bytes per lane half).  The steps (tap, 16 channels) form
+// one stream; the loads of step t + 1 are in flight under the MFMAs of step t; nothing synchronises before the epilogue.
+// One tap: every 1x1 layer.  The step stream walks any tap list, but several taps re-read the input per tap through L1 (32 lines per
+// load instruction): measured slower than staging even for one 32-filter panel (plan_1x1, conv_plan.h) -- experiments only.
 template <int MI, int NJ, bool PRO>
 __global__ __launch_bounds__(kThreads, 2) void conv_1x1_kernel(const liso_conv_desc d, const FwdArgs a) {
     constexpr int BNT = 32 * NJ;
     constexpr int TH = 4 * MI;
     __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 96 * 2 * 4];
+    __shared__ int s_dy[LISO_CONV_MAX_TAPS], s_dx[LISO_CONV_MAX_TAPS], s_w[LISO_CONV_MAX_TAPS];
     const int tid_all = threadIdx.x, wave = tid_all >> 6, lane = tid_all & 63, r = lane & 31, h = lane >> 5;
+    if (tid_all < d.n_taps) {
+        s_dy[tid_all] = d.tap_dy[tid_all];
+        s_dx[tid_all] = d.tap_dx[tid_all];
+        s_w[tid_all] = d.tap_w[tid_all];
+    }
     int t = xcd_remap(blockIdx.x, a.total);
     const int nt = t % a.n_nt;
     t /= a.n_nt;
@@ -1165,52 +1173,74 @@ __global__ __launch_bounds__(kThreads, 2) void conv_1x1_kernel(const liso_conv_d
     const int b = t / a.tiles_y;
     const int stats_row = (b * a.tiles_y + ty) * a.tiles_x + tx;
     const int n0 = nt * BNT;
-    // the lane's pixel per tile row
-    const float* xp[MI];
-    bool okp[MI];
+    const float* xb = (const float*)a.x + (long)b * d.hi * d.wi * d.x_pix_stride;
+    int by[MI];
+    bool okv[MI];
+    const int bx = (tx * 32 + r) * d.isx;
 #pragma unroll
     for (int i = 0; i < MI; i++) {
-        const int vy = ty * TH + wave * MI + i, vx = tx * 32 + r;
-        const int iy = vy * d.isy + d.tap_dy[0], ix = vx * d.isx + d.tap_dx[0];
-        okp[i] = vy < d.hv && vx < d.wv && (unsigned)iy < (unsigned)d.hi && (unsigned)ix < (unsigned)d.wi;
-        xp[i] = (const float*)a.x + (okp[i] ? (((long)b * d.hi + iy) * d.wi + ix) * d.x_pix_stride : 0);
+        const int vy = ty * TH + wave * MI + i;
+        okv[i] = vy < d.hv && tx * 32 + r < d.wv;
+        by[i] = vy * d.isy;
     }
     const unsigned short* wg = (const unsigned short*)a.w;
     const int kgroups = a.ci_pad >> 3;
     const long plane_elems = (long)d.w_taps * kgroups * a.co_pad * 8;
-    const unsigned short* wl[NJ];
+    int wn[NJ];
     bool okn[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; j++) {
         const int n = n0 + j * 32 + r;
         okn[j] = n < a.co_pad;
-        wl[j] = wg + ((long)d.tap_w[0] * kgroups * a.co_pad + (okn[j] ? n : 0)) * 8;
+        wn[j] = (okn[j] ? n : 0) * 8;
     }
     const int aff = b * d.in_affine_batch_stride;
+    __syncthreads();
     struct Frag {
         float4 x[MI][2];
         float4 sc[2], sh[2];
         uint4 bh[NJ], bl[NJ];
+        unsigned ok;  // bit i: the pixel of tile row i exists; bits 8 / 9: the lane's first / second 4 channels exist
     };
-    auto load = [&](int k0, Frag& F) {  // k0: first channel of the 16-channel step (clamped: the last step may be issued twice)
-        const int c = k0 + 8 * h;       // this lane's 8 channels
-        const int c_lo = c < d.ci ? c : 0, c_hi = c + 4 < d.ci ? c + 4 : 0;  // (ci is a multiple of 4: a 16-byte chunk is whole or absent)
+    // the ISSUE cursor: (tap, first channel of the step); beyond the last step it stays (the last step again, never multiplied)
+    const int K = a.ci_pad;  // multiple of 16
+    const int n_steps = d.n_taps * (K >> 4);
+    int cur_tap = 0, cur_k = 0;
+    auto load = [&](Frag& F) {
+        const int c = cur_k + 8 * h;
+        const bool v0 = c < d.ci, v1 = c + 4 < d.ci;  // (ci is a multiple of 4: a 16-byte chunk is whole or absent)
+        const int c_lo = v0 ? c : 0, c_hi = v1 ? c + 4 : 0;
+        const int dy = s_dy[cur_tap], dx = s_dx[cur_tap];
+        const int ix = bx + dx;
+        unsigned ok = (v0 ? 256u : 0u) | (v1 ? 512u : 0u);
 #pragma unroll
         for (int i = 0; i < MI; i++) {
-            F.x[i][0] = *reinterpret_cast<const float4*>(xp[i] + c_lo);
-            F.x[i][1] = *reinterpret_cast<const float4*>(xp[i] + c_hi);
+            const int iy = by[i] + dy;
+            const bool in = okv[i] && (unsigned)iy < (unsigned)d.hi && (unsigned)ix < (unsigned)d.wi;
+            ok |= in ? (1u << i) : 0u;
+            const float* px = xb + (in ? ((long)iy * d.wi + ix) * d.x_pix_stride : 0);
+            F.x[i][0] = *reinterpret_cast<const float4*>(px + c_lo);
+            F.x[i][1] = *reinterpret_cast<const float4*>(px + c_hi);
         }
+        F.ok = ok;
         if constexpr (PRO) {
             F.sc[0] = *reinterpret_cast<const float4*>(a.in_scale + aff + c_lo);
             F.sc[1] = *reinterpret_cast<const float4*>(a.in_scale + aff + c_hi);
             F.sh[0] = *reinterpret_cast<const float4*>(a.in_shift + aff + c_lo);
             F.sh[1] = *reinterpret_cast<const float4*>(a.in_shift + aff + c_hi);
         }
-        const long ko = (long)((k0 >> 3) + h) * a.co_pad * 8;
+        const long ko = ((long)s_w[cur_tap] * kgroups + (cur_k >> 3) + h) * a.co_pad * 8;
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
-            F.bh[j] = *reinterpret_cast<const uint4*>(wl[j] + ko);
-            F.bl[j] = *reinterpret_cast<const uint4*>(wl[j] + plane_elems + ko);
+            F.bh[j] = *reinterpret_cast<const uint4*>(wg + ko + wn[j]);
+            F.bl[j] = *reinterpret_cast<const uint4*>(wg + plane_elems + ko + wn[j]);
+        }
+        // advance (VALU only)
+        if (cur_k + 16 < K) {
+            cur_k += 16;
+        } else if (cur_tap + 1 < d.n_taps) {
+            cur_tap++;
+            cur_k = 0;
         }
     };
     f16v acc[MI][NJ];
@@ -1220,9 +1250,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_1x1_kernel(const liso_conv_d
         for (int j = 0; j < NJ; j++)
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
-    auto mul = [&](int k0, const Frag& F) {
-        const int c = k0 + 8 * h;
-        const bool v0 = c < d.ci, v1 = c + 4 < d.ci;
+    auto mul = [&](const Frag& F) {
+        const bool v0 = (F.ok >> 8) & 1u, v1 = (F.ok >> 9) & 1u;
         uint4 ah[MI], al[MI];
 #pragma unroll
         for (int i = 0; i < MI; i++) {
@@ -1236,9 +1265,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv_1x1_kernel(const liso_conv_d
                     if (d.in_relu) f[e] = fmaxf(f[e], 0.0f);
                 }
             }
+            const bool in = (F.ok >> i) & 1u;
 #pragma unroll
             for (int e = 0; e < 8; e++)
-                if (!(okp[i] && (e < 4 ? v0 : v1))) f[e] = 0.0f;
+                if (!(in && (e < 4 ? v0 : v1))) f[e] = 0.0f;
             unsigned hi[4], lo[4];
 #pragma unroll
             for (int e = 0; e < 4; e++) {
@@ -1259,20 +1289,17 @@ __global__ __launch_bounds__(kThreads, 2) void conv_1x1_kernel(const liso_conv_d
             }
         }
     };
-    const int K = a.ci_pad;  // multiple of 16
     Frag F0, F1;
-    load(0, F0);
-    for (int k0 = 0; k0 < K; k0 += 32) {
-        const int k1 = k0 + 16 < K ? k0 + 16 : k0;  // (beyond the end: the same step again, not multiplied)
-        load(k1, F1);
+    load(F0);
+    for (int s_ = 0; s_ < n_steps; s_ += 2) {
+        load(F1);
         __builtin_amdgcn_sched_barrier(0);
-        mul(k0, F0);
+        mul(F0);
         __builtin_amdgcn_sched_barrier(0);
-        if (k0 + 16 < K) {
-            const int k2 = k0 + 32 < K ? k0 + 32 : k0;
-            load(k2, F0);
+        if (s_ + 1 < n_steps) {
+            load(F0);
             __builtin_amdgcn_sched_barrier(0);
-            mul(k0 + 16, F1);
+            mul(F1);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
