@@ -144,9 +144,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void corr_lookup_fwd_kernel(li
 // centres lie far apart: garbage flow, never seen on real sweeps) takes the per-query path, one wave per query.
 // LDS: A planes 2 x 4 KB ([k8][query][8 bf16]) | B planes 2 x 32 KB ([k8][row][8 bf16]) per 64-channel chunk; C (32 x 260 fp32) and the
 // fallback's transpose buffers alias the B planes.
-constexpr int kTQW = 8, kTQH = 4, kTQ = kTQW * kTQH, kTRMax = 256, kTKC = 64, kTCStride = kTRMax + 4;
-constexpr int kTLdsA = 2 * (kTKC / 8) * kTQ * 16;        // 8 KB
-constexpr int kTLdsB = 2 * (kTKC / 8) * kTRMax * 16;     // 64 KB
+// MT = 32-query tiles per block: 4 x 8 queries on level 0 (MT 1, regions of <= 256 rows), 8 x 8 on the pooled levels (MT 2, <= 192 rows: at
+// half / quarter / eighth resolution 64 queries cover hardly more rows than 32, and a block per 64 queries halves the blocks, the
+// staged bytes per query and the exposed load phases of those levels).
+constexpr int kTQW = 8, kTKC = 64;
 typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 cbf8;
 typedef __attribute__((__vector_size__(16 * sizeof(float)))) float cf16v;
 
@@ -164,27 +165,25 @@ __device__ __forceinline__ void corr_split4(const float4 v, uint2* hi, uint2* lo
                      corr_pack_bf16(v.z - __uint_as_float(p1 << 16), v.w - __uint_as_float(p1 & 0xffff0000u)));
 }
 
-template <int VEC>
-__global__ __launch_bounds__(256, 2) void corr_lookup_tiled_kernel(liso_corr_cfg c, const float* __restrict__ fmap1, LevelPtrs lp,
-                                                                const float* __restrict__ coords, float* __restrict__ out, int tiles_x,
-                                                                int tiles_y) {
+template <int VEC, int MT, int RMAX>
+__device__ __forceinline__ void corr_tile_body(const liso_corr_cfg& c, const float* __restrict__ fmap1, const LevelPtrs& lp,
+                                               const float* __restrict__ coords, float* __restrict__ out, int tiles_x, int tiles_y, int lvl0,
+                                               int n_lvl, long item, unsigned char* lds) {
     constexpr int D = 128 * VEC;
+    constexpr int kTQH = 4 * MT, kTQ = 32 * MT, kTRMax = RMAX, kTCStride = RMAX + 4;
+    constexpr int kTLdsA = 2 * (kTKC / 8) * kTQ * 16, kTLdsB = 2 * (kTKC / 8) * kTRMax * 16;
+    static_assert(kTQ * kTCStride * 4 <= kTLdsA + kTLdsB, "C does not fit the operand buffers");
     __shared__ int q_x0[kTQ], q_y0[kTQ], q_pix[kTQ];
     __shared__ float q_fx[kTQ], q_fy[kTQ];
     __shared__ int reg[4];  // region: x0, y0, width, height
     __shared__ float Pf[kWavesPerBlock][64];
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // kTLdsA + kTLdsB bytes
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hw = c.h * c.w;
-    const long per_xcd = gridDim.x / 8;
-    long item = (long)(blockIdx.x % 8) * per_xcd + blockIdx.x / 8;  // ((b, lvl), ty, tx): an XCD walks neighbouring tiles of one level
-    const long total = (long)c.batch * c.levels * tiles_y * tiles_x;
-    if (item >= total) return;
     const int tx = (int)(item % tiles_x);
     item /= tiles_x;
     const int ty = (int)(item % tiles_y);
     item /= tiles_y;
-    const int lvl = (int)(item % c.levels), b = (int)(item / c.levels);
+    const int lvl = lvl0 + (int)(item % n_lvl), b = (int)(item / n_lvl);
     const int H = c.h >> lvl, W = c.w >> lvl;
     const int PS = 2 * c.radius + 2;  // side of the integer patch under a (2 r + 1)^2 window of bilinear samples
     if (tid < kTQ) {
@@ -204,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void corr_lookup_tiled_kernel(liso_corr_cfg
         int lo_x = some ? max(x0, 0) : (1 << 30), lo_y = some ? max(y0, 0) : (1 << 30);
         int hi_x = some ? min(x0 + PS, W) : -(1 << 30), hi_y = some ? min(y0 + PS, H) : -(1 << 30);
 #pragma unroll
-        for (int m = 16; m >= 1; m >>= 1) {
+        for (int m = kTQ / 2; m >= 1; m >>= 1) {
             lo_x = min(lo_x, __shfl_xor(lo_x, m));
             lo_y = min(lo_y, __shfl_xor(lo_y, m));
             hi_x = max(hi_x, __shfl_xor(hi_x, m));
@@ -257,37 +256,39 @@ __global__ __launch_bounds__(256, 2) void corr_lookup_tiled_kernel(liso_corr_cfg
         const int px = p - py * rw;
         b_off[u] = p < Rn ? ((ry0 + py) * W + rx0 + px) * D + c4 * 4 : -1;
     }
-    int a_off[2];
+    int a_off[2 * MT];
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
+    for (int u = 0; u < 2 * MT; u++) {
         const int i = tid + u * 256, q = i / CPR, c4 = i % CPR;
         a_off[u] = q_pix[q] >= 0 ? q_pix[q] * D + c4 * 4 : -1;
     }
     const float* f1 = fmap1 + (size_t)b * hw * D;
     const int r = lane & 31, h = lane >> 5;
-    cf16v acc[2];
+    cf16v acc[MT][2];
 #pragma unroll
-    for (int j = 0; j < 2; j++)
+    for (int m = 0; m < MT; m++)
 #pragma unroll
-        for (int e = 0; e < 16; e++) acc[j][e] = 0.f;
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[m][j][e] = 0.f;
     // (prefetching chunk k + 1 under chunk k needs a second register set: 288 registers, one block per CU -- measured 103 vs 66 us)
     constexpr int NCH = D / kTKC;
-    float4 va[1][2], vb[1][NB];
-    auto load_chunk = [&](int kc, float4 (&xa)[2], float4 (&xb)[NB]) {
+    float4 va[1][2 * MT], vb[1][NB];
+    auto load_chunk = [&](int kc, float4 (&xa)[2 * MT], float4 (&xb)[NB]) {
 #pragma unroll
-        for (int u = 0; u < 2; u++) xa[u] = a_off[u] >= 0 ? *reinterpret_cast<const float4*>(f1 + a_off[u] + kc) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int u = 0; u < 2 * MT; u++) xa[u] = a_off[u] >= 0 ? *reinterpret_cast<const float4*>(f1 + a_off[u] + kc) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int u = 0; u < NB; u++)
             xb[u] = b_off[u] >= 0 ? *reinterpret_cast<const float4*>(f2 + b_off[u] + kc) : make_float4(0.f, 0.f, 0.f, 0.f);
     };
 #pragma unroll
     for (int ch = 0; ch < NCH; ch++) {
-        float4 (&xa)[2] = va[0];
+        float4 (&xa)[2 * MT] = va[0];
         float4 (&xb)[NB] = vb[0];
         load_chunk(ch * kTKC, xa, xb);
         if (ch > 0) __syncthreads();  // the previous chunk's fragments have been read
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
+        for (int u = 0; u < 2 * MT; u++) {
             const int i = tid + u * 256, q = i / CPR, c4 = i % CPR;
             uint2 hi, lo;
             corr_split4(xa[u], &hi, &lo);
@@ -310,32 +311,41 @@ __global__ __launch_bounds__(256, 2) void corr_lookup_tiled_kernel(liso_corr_cfg
 #pragma unroll
         for (int kk = 0; kk < kTKC / 16; kk++) {
             const int k8 = kk * 2 + h;
-            const uint4 ah = *reinterpret_cast<const uint4*>(A_hi + (k8 * kTQ + r) * 16);
-            const uint4 al = *reinterpret_cast<const uint4*>(A_lo + (k8 * kTQ + r) * 16);
+            uint4 ah[MT], al[MT];
+#pragma unroll
+            for (int m = 0; m < MT; m++) {
+                ah[m] = *reinterpret_cast<const uint4*>(A_hi + (k8 * kTQ + m * 32 + r) * 16);
+                al[m] = *reinterpret_cast<const uint4*>(A_lo + (k8 * kTQ + m * 32 + r) * 16);
+            }
 #pragma unroll
             for (int j = 0; j < 2; j++) {
                 const int nt = wave * 2 + j;
                 if (nt < n_tiles) {
                     const uint4 bh = *reinterpret_cast<const uint4*>(B_hi + (k8 * kTRMax + nt * 32 + r) * 16);
                     const uint4 bl = *reinterpret_cast<const uint4*>(B_lo + (k8 * kTRMax + nt * 32 + r) * 16);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const cbf8*>(&al), *reinterpret_cast<const cbf8*>(&bh), acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const cbf8*>(&ah), *reinterpret_cast<const cbf8*>(&bl), acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const cbf8*>(&ah), *reinterpret_cast<const cbf8*>(&bh), acc[j], 0, 0, 0);
+#pragma unroll
+                    for (int m = 0; m < MT; m++) {
+                        acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const cbf8*>(&al[m]), *reinterpret_cast<const cbf8*>(&bh), acc[m][j], 0, 0, 0);
+                        acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const cbf8*>(&ah[m]), *reinterpret_cast<const cbf8*>(&bl), acc[m][j], 0, 0, 0);
+                        acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const cbf8*>(&ah[m]), *reinterpret_cast<const cbf8*>(&bh), acc[m][j], 0, 0, 0);
+                    }
                 }
             }
         }
     }
-    __syncthreads();  // every fragment read is done: C takes the place of the B planes
-    float* Cm = reinterpret_cast<float*>(B_hi);
+    __syncthreads();  // every fragment read is done: C takes the place of the operand planes
+    float* Cm = reinterpret_cast<float*>(lds);
 #pragma unroll
     for (int j = 0; j < 2; j++) {
         const int nt = wave * 2 + j;
         if (nt < n_tiles) {
 #pragma unroll
-            for (int e = 0; e < 16; e++) {
-                const int q = (e & 3) + 8 * (e >> 2) + 4 * h;  // row of the 32 x 32 result held by register e
-                Cm[q * kTCStride + nt * 32 + r] = acc[j][e];
-            }
+            for (int m = 0; m < MT; m++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const int q = m * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;  // row of the 32 x 32 result held by register e
+                    Cm[q * kTCStride + nt * 32 + r] = acc[m][j][e];
+                }
         }
     }
     __syncthreads();
@@ -352,6 +362,27 @@ __global__ __launch_bounds__(256, 2) void corr_lookup_tiled_kernel(liso_corr_cfg
         const float fx = q_fx[q], fy = q_fy[q];
         const float v = (1.f - fx) * (1.f - fy) * p00 + fx * (1.f - fy) * p10 + (1.f - fx) * fy * p01 + fx * fy * p11;
         out[((size_t)b * hw + pix) * C + lvl * W7 * W7 + tap] = v * inv;
+    }
+}
+
+// ONE launch: blocks [0, fine) walk `n_fine` levels with 4 x 8-query tiles, blocks [fine, fine + wide) the remaining levels with 8 x 8-query
+// tiles (both ranges multiples of 8 and dealt XCD-aware: every XCD gets a contiguous range of neighbouring tiles of one level)
+template <int VEC>
+__global__ __launch_bounds__(256, 2) void corr_lookup_tiled_kernel(liso_corr_cfg c, const float* __restrict__ fmap1, LevelPtrs lp,
+                                                                const float* __restrict__ coords, float* __restrict__ out, int tiles_x,
+                                                                int tiles_y4, int tiles_y8, int n_fine, unsigned fine_blocks, unsigned wide_blocks) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    if (blockIdx.x < fine_blocks) {
+        const long per_xcd = fine_blocks / 8;
+        const long item = (long)(blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+        if (item < (long)c.batch * n_fine * tiles_y4 * tiles_x)
+            corr_tile_body<VEC, 1, 256>(c, fmap1, lp, coords, out, tiles_x, tiles_y4, 0, n_fine, item, lds);
+    } else {
+        const unsigned bid = blockIdx.x - fine_blocks;
+        const long per_xcd = wide_blocks / 8;
+        const long item = (long)(bid % 8) * per_xcd + bid / 8;
+        if (item < (long)c.batch * (c.levels - n_fine) * tiles_y8 * tiles_x)
+            corr_tile_body<VEC, 2, 192>(c, fmap1, lp, coords, out, tiles_x, tiles_y8, n_fine, c.levels - n_fine, item, lds);
     }
 }
 
@@ -427,21 +458,30 @@ int liso_corr_lookup_fwd_tiled_f32(const liso_corr_cfg* cfg, const float* fmap1,
         if (!fmap2_levels[i] || (((uintptr_t)fmap2_levels[i]) & 15) != 0) return LISO_EINVAL;
         lp.f2[i] = fmap2_levels[i];
     }
-    const int tiles_x = (cfg->w + kTQW - 1) / kTQW, tiles_y = (cfg->h + kTQH - 1) / kTQH;
-    const long total = (long)cfg->batch * cfg->levels * tiles_y * tiles_x;
-    const unsigned grid = (unsigned)((total + 7) / 8 * 8);  // XCD-aware order
     hipStream_t st = (hipStream_t)stream;
+    const int tiles_x = (cfg->w + kTQW - 1) / kTQW, tiles_y4 = (cfg->h + 3) / 4, tiles_y8 = (cfg->h + 7) / 8;
+    constexpr int kLds = 2 * (kTKC / 8) * (32 + 256) * 16;  // = the 8 x 8-query shape's 2 * 8 * (64 + 192) * 16
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)corr_lookup_tiled_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kTLdsA + kTLdsB) != hipSuccess ||
-            hipFuncSetAttribute((const void*)corr_lookup_tiled_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kTLdsA + kTLdsB) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)corr_lookup_tiled_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds) != hipSuccess ||
+            hipFuncSetAttribute((const void*)corr_lookup_tiled_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds) != hipSuccess)
             return LISO_ELAUNCH;
         attr_set = true;
     }
+    // 8 x 8-query tiles on the pooled levels once they give every CU a block (4 / 2 samples of 64 x 64 queries: 768 / 384 such blocks,
+    // 49.8 vs 65.5 / 32.8 vs 34.5 us; one sample: 192 blocks, no gain); LISO_CORR_WIDE_TILES = 0 / 1 forces either
+    static const int wide_env = getenv("LISO_CORR_WIDE_TILES") ? atoi(getenv("LISO_CORR_WIDE_TILES")) : -1;
+    const long wide_all = (long)cfg->batch * (cfg->levels - 1) * tiles_y8 * tiles_x;
+    const bool wide = cfg->levels > 1 && (wide_env < 0 ? wide_all >= 256 : wide_env != 0);
+    const int n_fine = wide ? 1 : cfg->levels;
+    const unsigned fine_blocks = (unsigned)(((long)cfg->batch * n_fine * tiles_y4 * tiles_x + 7) / 8 * 8);
+    const unsigned wide_blocks = wide ? (unsigned)((wide_all + 7) / 8 * 8) : 0u;
     if (cfg->dim == 128)
-        corr_lookup_tiled_kernel<1><<<grid, 256, kTLdsA + kTLdsB, st>>>(*cfg, fmap1, lp, coords, out, tiles_x, tiles_y);
+        corr_lookup_tiled_kernel<1><<<fine_blocks + wide_blocks, 256, kLds, st>>>(*cfg, fmap1, lp, coords, out, tiles_x, tiles_y4, tiles_y8, n_fine,
+                                                                                fine_blocks, wide_blocks);
     else
-        corr_lookup_tiled_kernel<2><<<grid, 256, kTLdsA + kTLdsB, st>>>(*cfg, fmap1, lp, coords, out, tiles_x, tiles_y);
+        corr_lookup_tiled_kernel<2><<<fine_blocks + wide_blocks, 256, kLds, st>>>(*cfg, fmap1, lp, coords, out, tiles_x, tiles_y4, tiles_y8, n_fine,
+                                                                                fine_blocks, wide_blocks);
     return check_launch();
 }
 
