@@ -171,7 +171,10 @@ __device__ __forceinline__ void corr_tile_body(const liso_corr_cfg& c, const flo
                                                int n_lvl, long item, unsigned char* lds) {
     constexpr int D = 128 * VEC;
     constexpr int kTQH = 4 * MT, kTQ = 32 * MT, kTRMax = RMAX, kTCStride = RMAX + 4;
-    constexpr int kTLdsA = 2 * (kTKC / 8) * kTQ * 16, kTLdsB = 2 * (kTKC / 8) * kTRMax * 16;
+    // bytes of one 8-channel group of a plane: rows x 16 B + 64 B, so that the eight groups a wave's split stores touch at once start 64 B
+    // apart in the banks (unpadded they all start on the same bank: PMC round 5, 0.69 of the LDS cycles were conflict cycles)
+    constexpr int AS = kTQ * 16 + 64, BS = kTRMax * 16 + 64;
+    constexpr int kTLdsA = 2 * (kTKC / 8) * AS, kTLdsB = 2 * (kTKC / 8) * BS;
     static_assert(kTQ * kTCStride * 4 <= kTLdsA + kTLdsB, "C does not fit the operand buffers");
     __shared__ int q_x0[kTQ], q_y0[kTQ], q_pix[kTQ];
     __shared__ float q_fx[kTQ], q_fy[kTQ];
@@ -292,7 +295,7 @@ __device__ __forceinline__ void corr_tile_body(const liso_corr_cfg& c, const flo
             const int i = tid + u * 256, q = i / CPR, c4 = i % CPR;
             uint2 hi, lo;
             corr_split4(xa[u], &hi, &lo);
-            const int o = ((c4 >> 1) * kTQ + q) * 16 + (c4 & 1) * 8;
+            const int o = (c4 >> 1) * AS + q * 16 + (c4 & 1) * 8;
             *reinterpret_cast<uint2*>(A_hi + o) = hi;
             *reinterpret_cast<uint2*>(A_lo + o) = lo;
         }
@@ -302,7 +305,7 @@ __device__ __forceinline__ void corr_tile_body(const liso_corr_cfg& c, const flo
             if (p < n_tiles * 32) {  // (rows of the last 32-row tile beyond the region: zeros)
                 uint2 hi, lo;
                 corr_split4(xb[u], &hi, &lo);
-                const int o = ((c4 >> 1) * kTRMax + p) * 16 + (c4 & 1) * 8;
+                const int o = (c4 >> 1) * BS + p * 16 + (c4 & 1) * 8;
                 *reinterpret_cast<uint2*>(B_hi + o) = hi;
                 *reinterpret_cast<uint2*>(B_lo + o) = lo;
             }
@@ -314,15 +317,15 @@ __device__ __forceinline__ void corr_tile_body(const liso_corr_cfg& c, const flo
             uint4 ah[MT], al[MT];
 #pragma unroll
             for (int m = 0; m < MT; m++) {
-                ah[m] = *reinterpret_cast<const uint4*>(A_hi + (k8 * kTQ + m * 32 + r) * 16);
-                al[m] = *reinterpret_cast<const uint4*>(A_lo + (k8 * kTQ + m * 32 + r) * 16);
+                ah[m] = *reinterpret_cast<const uint4*>(A_hi + k8 * AS + (m * 32 + r) * 16);
+                al[m] = *reinterpret_cast<const uint4*>(A_lo + k8 * AS + (m * 32 + r) * 16);
             }
 #pragma unroll
             for (int j = 0; j < 2; j++) {
                 const int nt = wave * 2 + j;
                 if (nt < n_tiles) {
-                    const uint4 bh = *reinterpret_cast<const uint4*>(B_hi + (k8 * kTRMax + nt * 32 + r) * 16);
-                    const uint4 bl = *reinterpret_cast<const uint4*>(B_lo + (k8 * kTRMax + nt * 32 + r) * 16);
+                    const uint4 bh = *reinterpret_cast<const uint4*>(B_hi + k8 * BS + (nt * 32 + r) * 16);
+                    const uint4 bl = *reinterpret_cast<const uint4*>(B_lo + k8 * BS + (nt * 32 + r) * 16);
 #pragma unroll
                     for (int m = 0; m < MT; m++) {
                         acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const cbf8*>(&al[m]), *reinterpret_cast<const cbf8*>(&bh), acc[m][j], 0, 0, 0);
@@ -354,14 +357,16 @@ __device__ __forceinline__ void corr_tile_body(const liso_corr_cfg& c, const flo
         const int q = idx / (W7 * W7), tap = idx - q * (W7 * W7);
         const int pix = q_pix[q];
         if (pix < 0) continue;
-        const int a = tap / W7, bb = tap - a * W7;  // a: x offset index, bb: y offset index (corr.py:31-35 order)
+        // consecutive lanes walk a window ROW (consecutive LDS addresses); the output index is a * W7 + bb (a: x offset index, bb: y offset
+        // index, corr.py:31-35 order)
+        const int bb = tap / W7, a = tap - bb * W7;
         const int lx = q_x0[q] - rx0 + a, ly = q_y0[q] - ry0 + bb;
         const float* row = Cm + q * kTCStride;
         auto at = [&](int x, int y) { return ((unsigned)x < (unsigned)rw && (unsigned)y < (unsigned)rh) ? row[y * rw + x] : 0.f; };
         const float p00 = at(lx, ly), p10 = at(lx + 1, ly), p01 = at(lx, ly + 1), p11 = at(lx + 1, ly + 1);
         const float fx = q_fx[q], fy = q_fy[q];
         const float v = (1.f - fx) * (1.f - fy) * p00 + fx * (1.f - fy) * p10 + (1.f - fx) * fy * p01 + fx * fy * p11;
-        out[((size_t)b * hw + pix) * C + lvl * W7 * W7 + tap] = v * inv;
+        out[((size_t)b * hw + pix) * C + lvl * W7 * W7 + a * W7 + bb] = v * inv;
     }
 }
 
@@ -460,7 +465,7 @@ int liso_corr_lookup_fwd_tiled_f32(const liso_corr_cfg* cfg, const float* fmap1,
     }
     hipStream_t st = (hipStream_t)stream;
     const int tiles_x = (cfg->w + kTQW - 1) / kTQW, tiles_y4 = (cfg->h + 3) / 4, tiles_y8 = (cfg->h + 7) / 8;
-    constexpr int kLds = 2 * (kTKC / 8) * (32 + 256) * 16;  // = the 8 x 8-query shape's 2 * 8 * (64 + 192) * 16
+    constexpr int kLds = 2 * (kTKC / 8) * ((32 + 256) * 16 + 128);  // (the 8 x 8-query shape needs less: 2 * 8 * ((64 + 192) * 16 + 128) - 8 KB ... both <= this)
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)corr_lookup_tiled_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds) != hipSuccess ||
