@@ -158,6 +158,9 @@ KERNELS = {  # timer name -> (kernel description, bound, unit of `units`)
     "conv_f32x3_fwd_roles": ("conv_roles_kernel<bf16x3> forward (3x3 / stride 1: loader waves + MFMA waves on double-buffered LDS, persistent "
                              "blocks; fp32 tensors, hi/lo bf16 split, 3 MFMAs per product)", "mfma", "flop"),
     "conv_f32x3_dgrad_roles": ("conv_roles_kernel<bf16x3> data gradient (3x3 / stride 1, mirrored taps)", "mfma", "flop"),
+    "conv_f32x3_fwd_direct": ("conv_1x1_kernel / conv_taps_kernel<bf16x3> forward (1x1 layers; windows on <= 8 channels: fragments straight from "
+                              "global memory, no LDS staging)", "mfma", "flop"),
+    "conv_f32x3_dgrad_direct": ("conv_1x1_kernel<bf16x3> data gradient (1x1 layers)", "mfma", "flop"),
     "conv_bf16_fwd_roles": ("conv_roles_kernel<bf16> forward (3x3 / stride 1: loader waves + MFMA waves on double-buffered LDS, persistent "
                             "blocks; fused BN-apply prologue / bias+ReLU+BN-statistics epilogue)", "mfma", "flop"),
     "conv_bf16_dgrad_roles": ("conv_roles_kernel<bf16> data gradient (3x3 / stride 1, mirrored taps)", "mfma", "flop"),
@@ -235,6 +238,7 @@ def pmc_traffic(workload, patterns):
 
 # (template argument 1 of the convolution kernels = arithmetic: 0 bf16, 1 f32x3; forward and data gradient share the kernel)
 PMC_PATTERNS = {"conv_f32x3_fwd_roles": ["conv_roles_kernel<1,"], "conv_f32x3_dgrad_roles": ["conv_roles_kernel<1,"],
+                "conv_f32x3_fwd_direct": ["conv_1x1_kernel", "conv_taps_kernel"], "conv_f32x3_dgrad_direct": ["conv_1x1_kernel"],
                 "conv_bf16_fwd_roles": ["conv_roles_kernel<0,"], "conv_bf16_dgrad_roles": ["conv_roles_kernel<0,"],
                 "conv_bf16_fwd": ["conv_igemm_kernel<0,"], "conv_bf16_dgrad": ["conv_igemm_kernel<0,"], "conv_bf16_wgrad": ["conv_wgrad_kernel<0,|conv_wgrad_rs3_kernel<0,"],
                 "conv_f32x3_fwd": ["conv_igemm_kernel<1,"], "conv_f32x3_dgrad": ["conv_igemm_kernel<1,"], "conv_f32x3_wgrad": ["conv_wgrad_kernel<1,|conv_wgrad_rs3_kernel<1,"],

@@ -187,6 +187,12 @@ int liso_residual_affine_relu_f32(const float* a, const float* a_scale, const fl
  * (the three pipeline stages of the LISO loop) -- plans then never spend a CU's whole LDS on one block, so that other kernels' blocks
  * can share the CU.  Results are unaffected.  Returns LISO_EINVAL for an unknown option. */
 #define LISO_CONV_OPT_SHARED_GPU 1
+/* LISO_CONV_OPT_ROLES_CUS (value = n >= 8; 0 = all): the persistent blocks of conv_roles_kernel launches planned from now on occupy at
+ * most n compute units (one block each).  With LISO_INFER_CUS=128 the LISO loop plans the frozen SLIM's inference launches (captured into
+ * hipGraphs: the grid is baked in) that way: the detector step on the other stream -- the pipeline's critical path, a chain of ~250
+ * small dependent kernels -- then always finds free CUs instead of waiting for a 60-us launch that holds all 256 to drain (measured:
+ * 4.16-4.17 vs 4.23-4.26 ms per step).  Results are unaffected. */
+#define LISO_CONV_OPT_ROLES_CUS 2
 int liso_conv_set_option(int option, int value);
 
 /* ---- sparse form of the SLIM encoders' first convolution --------------------------------------------------------------------------

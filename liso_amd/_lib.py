@@ -238,6 +238,7 @@ SIGNATURES = {
 
 CONV_MAX_TAPS, CONV_MAX_CLASSES, CONV_BF16, CONV_F32X3, CONV_F32 = 49, 4, 0, 1, 2
 CONV_OPT_SHARED_GPU = 1
+CONV_OPT_ROLES_CUS = 2
 
 
 class ConvDesc(ctypes.Structure):

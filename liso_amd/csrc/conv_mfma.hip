@@ -1624,7 +1624,9 @@ int launch_roles_pro(const liso_conv_desc& d, const Plan& p, hipStream_t st) {
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return LISO_ELAUNCH;
         n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    const int grid = p.a.total < n_cu ? p.a.total : n_cu;
+    // LISO_CONV_OPT_ROLES_CUS: leave compute units to the other streams' kernels (include/liso_conv.h)
+    const int cus = (g_roles_cus >= 8 && g_roles_cus < n_cu) ? g_roles_cus : n_cu;
+    const int grid = p.a.total < cus ? p.a.total : cus;
     conv_roles_kernel<MODE, MI, NJ, OUT_F32, NTAPS, PRO><<<grid, 512, p.lds, st>>>(d, p.a);
     return check_launch();
 }
@@ -1668,9 +1670,16 @@ int launch(const liso_conv_desc& d, const Plan& p, hipStream_t st) {
 }  // namespace
 
 extern "C" int liso_conv_set_option(int option, int value) {
-    if (option != LISO_CONV_OPT_SHARED_GPU) return LISO_EINVAL;
-    g_shared_gpu = value != 0;
-    return LISO_OK;
+    if (option == LISO_CONV_OPT_SHARED_GPU) {
+        g_shared_gpu = value != 0;
+        return LISO_OK;
+    }
+    if (option == LISO_CONV_OPT_ROLES_CUS) {
+        if (value != 0 && value < 8) return LISO_EINVAL;
+        g_roles_cus = value;
+        return LISO_OK;
+    }
+    return LISO_EINVAL;
 }
 
 extern "C" {

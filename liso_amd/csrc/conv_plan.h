@@ -48,6 +48,7 @@ struct Plan {
 };
 
 int g_shared_gpu = 0;  // liso_conv_set_option(LISO_CONV_OPT_SHARED_GPU)
+int g_roles_cus = 0;   // liso_conv_set_option(LISO_CONV_OPT_ROLES_CUS): 0 = every compute unit
 
 // conv_roles_kernel: 3x3 windows (any tap order: forward and mirrored data-gradient taps), stride 1, one class, bf16 / F32X3.
 // Tile shape (MI, NJ) by a cycle model of one block per CU: rounds of 256 blocks x slabs x max(MFMA cycles, loader cycles per slab).

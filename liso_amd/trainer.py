@@ -1017,12 +1017,21 @@ class LisoLoopTrainer:
             s0, s1 = st["in"]
             side = self._flow_stream  # (HIP maps streams onto 4 hardware queues: capture on a pipeline stream, no extra one)
             side.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(side), torch.no_grad():
+            # LISO_INFER_CUS=n (opt-in): in the pipeline the captured inference leaves compute units to the other streams
+            # (mfma_conv.roles_cus: its 3x3 convolutions are persistent blocks, one per CU, and a 60-us launch that holds all 256 makes
+            # every kernel of the detector step -- the critical path, ~250 small dependent launches -- wait for it to drain).  Measured,
+            # same box: all CUs 4.23-4.26 ms per step; 128: 4.16-4.17; 144: 4.26; 112: 4.35; 96: 4.34; 64: 4.78 (then stage A is the
+            # slowest stage).  Off by default: the kernels' own rate, which bench.py's `roofline` reports against the WHOLE chip's peak,
+            # halves with it.
+            from liso_amd.utils import mfma_conv as MC
+
+            cus = int(os.environ.get("LISO_INFER_CUS", "0")) if self.overlap else 0
+            with torch.cuda.stream(side), torch.no_grad(), MC.roles_cus(cus):
                 for _ in range(2):
                     self.slim.infer_point_flow_t0_t1(s0, s1, canvases=st["canv"], dynamicness_threshold=st["thr"])
             torch.cuda.current_stream(dev).wait_stream(side)
             st["graph"] = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(st["graph"], stream=side), torch.no_grad():
+            with torch.cuda.graph(st["graph"], stream=side), torch.no_grad(), MC.roles_cus(cus):
                 st["flow"] = self.slim.infer_point_flow_t0_t1(s0, s1, canvases=st["canv"], dynamicness_threshold=st["thr"])
             self._infer_graph = st["graph"]  # (the most recently captured one: scripts / bench introspection)
         else:
@@ -1054,8 +1063,11 @@ class LisoLoopTrainer:
             allp = [*pairs, *also]
             with torch.no_grad():
                 L.TIMER.weight = len(pairs) / len(allp)  # (these launches serve len(allp) pairs, the step consumes len(pairs))
-                try:
-                    flow = self._infer_flow_padded(self._stack_infer_views([p_[0] for p_ in allp]), self._stack_infer_views([p_[1] for p_ in allp]))
+                from liso_amd.utils import mfma_conv as MC
+
+                try:  # (the plans of the captured inference: the same compute-unit cap as in _infer_flow_padded)
+                    with MC.roles_cus(int(os.environ.get("LISO_INFER_CUS", "0")) if self.overlap else 0):
+                        flow = self._infer_flow_padded(self._stack_infer_views([p_[0] for p_ in allp]), self._stack_infer_views([p_[1] for p_ in allp]))
                 finally:
                     L.TIMER.weight = 1.0
                 b = flow.shape[0] // len(allp)

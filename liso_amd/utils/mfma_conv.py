@@ -207,6 +207,24 @@ class shared_gpu:
         return False
 
 
+class roles_cus:
+    """`with roles_cus(n):` -- the persistent blocks of the 3x3 / stride-1 convolution launches planned inside (incl. those captured into
+    hipGraphs) occupy at most n compute units (include/liso_conv.h: LISO_CONV_OPT_ROLES_CUS; n = 0: no limit).  Not re-entrant."""
+
+    def __init__(self, n):
+        self.n = int(n)
+
+    def __enter__(self):
+        if self.n:
+            L.check(L.lib().liso_conv_set_option(L.CONV_OPT_ROLES_CUS, self.n), "conv_set_option")
+        return self
+
+    def __exit__(self, *exc):
+        if self.n:
+            L.check(L.lib().liso_conv_set_option(L.CONV_OPT_ROLES_CUS, 0), "conv_set_option")
+        return False
+
+
 _PACK_RECORD = None  # dict while the pack requests of a step are being recorded
 _STEP_PACKS = None   # dict while a step runs on panels that were packed by ONE batched launch
 
@@ -298,8 +316,9 @@ def _timer_name(mode, kind, d=None):
     """timer family of a launch; forward / data-gradient launches of conv_roles_kernel get their own families (bench.py's `roofline`
     is about ONE kernel: rocprofv3 lists conv_roles_kernel and conv_igemm_kernel separately, so does the timer)"""
     name = ("conv_bf16_" if mode == L.CONV_BF16 else "conv_f32x3_" if mode == L.CONV_F32X3 else "conv_f32_") + kind
-    if d is not None and L.TIMER.enabled and L.lib().liso_conv_kernel_kind(ctypes.byref(d)) == 1:
-        name += "_roles"
+    if d is not None and L.TIMER.enabled:
+        kind = L.lib().liso_conv_kernel_kind(ctypes.byref(d))
+        name += "_roles" if kind == 1 else "_direct" if kind in (2, 3) else ""
     return name
 
 
