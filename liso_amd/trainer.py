@@ -117,6 +117,7 @@ class DetectorTrainer:
             _MC._sparse_flag(device)
         self.use_graph = bool(use_graph) and device.type == "cuda"
         self._graph, self._graph2, self._graph_sig, self._capture_stream = None, None, None, None
+        self._wgrad_stream = None
         self.fused_loss = (fused_centerpoint.supports(cfg) and device.type == "cuda") if fused_loss is None else fused_loss
         self.net = BoxLearner(cfg).to(device)
         self.net.model.set_compute_dtype(compute_dtype)
@@ -288,6 +289,11 @@ class DetectorTrainer:
             torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
         if self._capture_stream is None:
             self._capture_stream = torch.cuda.Stream(device=dev)
+        # LISO_WGRAD_SIDE=1 (opt-in, measured slower): the weight gradients as a parallel branch of the captured backward pass
+        # (mfma_conv.wgrad_side) -- nothing in the backward chain reads them.  Results identical; but every fork edge of a replayed
+        # hipGraph costs ~240 us here: detector replay 7.15 vs 2.54 ms (19 forks + 1 join), loop 6.44 vs 4.38 ms per step.
+        if self._wgrad_stream is None and os.environ.get("LISO_WGRAD_SIDE", "0") == "1":
+            self._wgrad_stream = torch.cuda.Stream(device=dev)
         side = self._capture_stream  # (kept alive with the graph)
         side.wait_stream(torch.cuda.current_stream(dev))
 
@@ -320,10 +326,12 @@ class DetectorTrainer:
                         total, _, _ = self.loss(None, self._static_targets, canvas=(self._static_bev, self._static_occ))
                     finally:
                         rpn.grad_cut = None
-                    total.backward()
+                    with MC.wgrad_side(self._wgrad_stream):
+                        total.backward()
                     self._body_loss = total.detach()
                 if cut is not None and part in (None, 2):
-                    cut.finish()
+                    with MC.wgrad_side(self._wgrad_stream):
+                        cut.finish()
             finally:
                 MC.set_step_packs(None)
                 MC.set_direct_grads(False, keep_touched=True)

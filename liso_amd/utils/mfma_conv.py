@@ -207,6 +207,35 @@ class shared_gpu:
         return False
 
 
+_WGRAD_SIDE = None  # {"stream", "keep", "used"} while weight gradients are issued on a side stream (wgrad_side)
+
+
+class wgrad_side:
+    """`with wgrad_side(stream):` around a backward pass -- the weight-gradient launches of the fused convolutions (those that write
+    straight into their parameter's gradient buffer: nothing for autograd to consume) go to `stream`, forked off the backward pass's
+    stream by an event behind the gradient they read and joined when the block exits.  Nothing in the backward chain reads a weight
+    gradient: the chain (data gradient -> BatchNorm backward -> data gradient ...) no longer waits for 19 weight-gradient + slab-reduction
+    launches, which run next to it -- inside a captured hipGraph as a parallel branch.  The tensors those launches read are kept alive
+    until the join (no allocator reuse under them)."""
+
+    def __init__(self, stream):
+        self.stream = stream
+
+    def __enter__(self):
+        global _WGRAD_SIDE
+        self.prev = _WGRAD_SIDE
+        _WGRAD_SIDE = {"stream": self.stream, "keep": [], "used": False} if self.stream is not None else None
+        return self
+
+    def __exit__(self, *exc):
+        global _WGRAD_SIDE
+        st, _WGRAD_SIDE = _WGRAD_SIDE, self.prev
+        if st is not None and st["used"]:
+            torch.cuda.current_stream(st["stream"].device).wait_stream(st["stream"])
+            st["keep"].clear()
+        return False
+
+
 class roles_cus:
     """`with roles_cus(n):` -- the persistent blocks of the 3x3 / stride-1 convolution launches planned inside (incl. those captured into
     hipGraphs) occupy at most n compute units (include/liso_conv.h: LISO_CONV_OPT_ROLES_CUS; n = 0: no limit).  Not re-entrant."""
@@ -826,8 +855,19 @@ class _FusedConv(torch.autograd.Function):
                 res = conv_wgrad_sparse(x_raw, ctx.meta["occupancy"], dy, tuple(weight.shape), spec, want_bias=ctx.meta["has_bias"])
                 tw = None if res is not None else tw
             if res is None:
-                res = conv_wgrad(x_raw, dy, tuple(weight.shape), spec, sc, sh, in_relu=fold.relu if fold is not None else False,
-                                 want_bias=ctx.meta["has_bias"], out_dw=tw, out_db=tb, co_true=co_true)
+                side = _WGRAD_SIDE if (tw is not None and dy.is_cuda) else None
+                if side is not None:  # (written in place: autograd never sees the result -- see wgrad_side)
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream(dy.device))
+                    with torch.cuda.stream(side["stream"]):
+                        side["stream"].wait_event(ev)
+                        res = conv_wgrad(x_raw, dy, tuple(weight.shape), spec, sc, sh, in_relu=fold.relu if fold is not None else False,
+                                         want_bias=ctx.meta["has_bias"], out_dw=tw, out_db=tb, co_true=co_true)
+                    side["keep"].append((x_raw, dy, sc, sh))
+                    side["used"] = True
+                else:
+                    res = conv_wgrad(x_raw, dy, tuple(weight.shape), spec, sc, sh, in_relu=fold.relu if fold is not None else False,
+                                     want_bias=ctx.meta["has_bias"], out_dw=tw, out_db=tb, co_true=co_true)
             if res is None:
                 dw, db = _aten_wgrad(x_raw, dy[:, :co_true], weight, spec, fold, ctx.meta["has_bias"])
             else:
