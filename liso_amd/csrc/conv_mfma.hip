@@ -1152,10 +1152,15 @@ __global__ __launch_bounds__(512, 1) void conv_roles_kernel(const liso_conv_desc
 // one stream; the loads of step t + 1 are in flight under the MFMAs of step t; nothing synchronises before the epilogue.
 // One tap: every 1x1 layer.  The step stream walks any tap list, but several taps re-read the input per tap through L1 (32 lines per
 // load instruction): measured slower than staging even for one 32-filter panel (plan_1x1, conv_plan.h) -- experiments only.
-template <int MI, int NJ, bool PRO>
+// Tap classes (transposed convolutions with kernel = stride: every output pixel of class (oy % s, ox % s) reads ONE input pixel through
+// ONE tap): a block works on one class -- a 1x1 convolution whose epilogue scatters to that class's output pixels.
+// MODE: F32X3 (fp32 tensors, bf16 hi / lo split in registers) or BF16 (bf16 tensors: the lane's 8 channels are one 16-byte load).
+template <int MODE, int MI, int NJ, bool OUT_F32, bool PRO>
 __global__ __launch_bounds__(kThreads, 2) void conv_1x1_kernel(const liso_conv_desc d, const FwdArgs a) {
+    constexpr bool X3 = MODE == LISO_CONV_F32X3;
     constexpr int BNT = 32 * NJ;
     constexpr int TH = 4 * MI;
+    constexpr int ES = X3 ? 4 : 2;  // bytes per input element
     __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 96 * 2 * 4];
     __shared__ int s_dy[LISO_CONV_MAX_TAPS], s_dx[LISO_CONV_MAX_TAPS], s_w[LISO_CONV_MAX_TAPS];
     const int tid_all = threadIdx.x, wave = tid_all >> 6, lane = tid_all & 63, r = lane & 31, h = lane >> 5;
@@ -1170,10 +1175,14 @@ __global__ __launch_bounds__(kThreads, 2) void conv_1x1_kernel(const liso_conv_d
     const int tx = t % a.tiles_x;
     t /= a.tiles_x;
     const int ty = t % a.tiles_y;
-    const int b = t / a.tiles_y;
-    const int stats_row = (b * a.tiles_y + ty) * a.tiles_x + tx;
+    t /= a.tiles_y;
+    const int b = t % d.batch;
+    const int cls = t / d.batch;
+    const int stats_row = ((cls * d.batch + b) * a.tiles_y + ty) * a.tiles_x + tx;
     const int n0 = nt * BNT;
-    const float* xb = (const float*)a.x + (long)b * d.hi * d.wi * d.x_pix_stride;
+    // taps of this block: its class's one tap, or (one class) the whole list
+    const int tap0 = d.n_classes > 1 ? cls : 0, tap1 = d.n_classes > 1 ? cls + 1 : d.n_taps;
+    const unsigned char* xb = (const unsigned char*)a.x + (long)b * d.hi * d.wi * d.x_pix_stride * ES;
     int by[MI];
     bool okv[MI];
     const int bx = (tx * 32 + r) * d.isx;
@@ -1197,18 +1206,18 @@ __global__ __launch_bounds__(kThreads, 2) void conv_1x1_kernel(const liso_conv_d
     const int aff = b * d.in_affine_batch_stride;
     __syncthreads();
     struct Frag {
-        float4 x[MI][2];
+        uint4 x[MI][X3 ? 2 : 1];
         float4 sc[2], sh[2];
-        uint4 bh[NJ], bl[NJ];
+        uint4 bh[NJ], bl[X3 ? NJ : 1];
         unsigned ok;  // bit i: the pixel of tile row i exists; bits 8 / 9: the lane's first / second 4 channels exist
     };
     // the ISSUE cursor: (tap, first channel of the step); beyond the last step it stays (the last step again, never multiplied)
     const int K = a.ci_pad;  // multiple of 16
-    const int n_steps = d.n_taps * (K >> 4);
-    int cur_tap = 0, cur_k = 0;
+    const int n_steps = (tap1 - tap0) * (K >> 4);
+    int cur_tap = tap0, cur_k = 0;
     auto load = [&](Frag& F) {
         const int c = cur_k + 8 * h;
-        const bool v0 = c < d.ci, v1 = c + 4 < d.ci;  // (ci is a multiple of 4: a 16-byte chunk is whole or absent)
+        const bool v0 = c < d.ci, v1 = c + 4 < d.ci;  // (fp32: ci is a multiple of 4, bf16: of 8 -- a 16-byte chunk is whole or absent)
         const int c_lo = v0 ? c : 0, c_hi = v1 ? c + 4 : 0;
         const int dy = s_dy[cur_tap], dx = s_dx[cur_tap];
         const int ix = bx + dx;
@@ -1218,9 +1227,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv_1x1_kernel(const liso_conv_d
             const int iy = by[i] + dy;
             const bool in = okv[i] && (unsigned)iy < (unsigned)d.hi && (unsigned)ix < (unsigned)d.wi;
             ok |= in ? (1u << i) : 0u;
-            const float* px = xb + (in ? ((long)iy * d.wi + ix) * d.x_pix_stride : 0);
-            F.x[i][0] = *reinterpret_cast<const float4*>(px + c_lo);
-            F.x[i][1] = *reinterpret_cast<const float4*>(px + c_hi);
+            const unsigned char* px = xb + (in ? ((long)iy * d.wi + ix) * d.x_pix_stride : 0) * ES;
+            F.x[i][0] = *reinterpret_cast<const uint4*>(px + c_lo * ES);
+            if constexpr (X3) F.x[i][1] = *reinterpret_cast<const uint4*>(px + c_hi * ES);
         }
         F.ok = ok;
         if constexpr (PRO) {
@@ -1233,12 +1242,12 @@ __global__ __launch_bounds__(kThreads, 2) void conv_1x1_kernel(const liso_conv_d
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
             F.bh[j] = *reinterpret_cast<const uint4*>(wg + ko + wn[j]);
-            F.bl[j] = *reinterpret_cast<const uint4*>(wg + plane_elems + ko + wn[j]);
+            if constexpr (X3) F.bl[j] = *reinterpret_cast<const uint4*>(wg + plane_elems + ko + wn[j]);
         }
         // advance (VALU only)
         if (cur_k + 16 < K) {
             cur_k += 16;
-        } else if (cur_tap + 1 < d.n_taps) {
+        } else if (cur_tap + 1 < tap1) {
             cur_tap++;
             cur_k = 0;
         }
@@ -1252,10 +1261,25 @@ __global__ __launch_bounds__(kThreads, 2) void conv_1x1_kernel(const liso_conv_d
             for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
     auto mul = [&](const Frag& F) {
         const bool v0 = (F.ok >> 8) & 1u, v1 = (F.ok >> 9) & 1u;
-        uint4 ah[MI], al[MI];
+        uint4 ah[MI], al[X3 ? MI : 1];
 #pragma unroll
         for (int i = 0; i < MI; i++) {
-            float f[8] = {F.x[i][0].x, F.x[i][0].y, F.x[i][0].z, F.x[i][0].w, F.x[i][1].x, F.x[i][1].y, F.x[i][1].z, F.x[i][1].w};
+            const bool in = (F.ok >> i) & 1u;
+            float f[8];
+            if constexpr (X3) {
+                const uint4 q0 = F.x[i][0], q1 = F.x[i][1];
+                const unsigned w[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+                for (int e = 0; e < 8; e++) f[e] = __uint_as_float(w[e]);
+            } else {
+                const uint4 q0 = F.x[i][0];
+                const unsigned w[4] = {q0.x, q0.y, q0.z, q0.w};
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    f[2 * e] = bf16_lo(w[e]);
+                    f[2 * e + 1] = bf16_hi(w[e]);
+                }
+            }
             if constexpr (PRO) {
                 const float sc[8] = {F.sc[0].x, F.sc[0].y, F.sc[0].z, F.sc[0].w, F.sc[1].x, F.sc[1].y, F.sc[1].z, F.sc[1].w};
                 const float sh[8] = {F.sh[0].x, F.sh[0].y, F.sh[0].z, F.sh[0].w, F.sh[1].x, F.sh[1].y, F.sh[1].z, F.sh[1].w};
@@ -1265,26 +1289,31 @@ __global__ __launch_bounds__(kThreads, 2) void conv_1x1_kernel(const liso_conv_d
                     if (d.in_relu) f[e] = fmaxf(f[e], 0.0f);
                 }
             }
-            const bool in = (F.ok >> i) & 1u;
 #pragma unroll
             for (int e = 0; e < 8; e++)
                 if (!(in && (e < 4 ? v0 : v1))) f[e] = 0.0f;
-            unsigned hi[4], lo[4];
+            unsigned hi[4];
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
-                hi[e] = pack_bf16(f[2 * e], f[2 * e + 1]);
-                lo[e] = pack_bf16(f[2 * e] - bf16_lo(hi[e]), f[2 * e + 1] - bf16_hi(hi[e]));
-            }
+            for (int e = 0; e < 4; e++) hi[e] = pack_bf16(f[2 * e], f[2 * e + 1]);
             ah[i] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-            al[i] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+            if constexpr (X3) {
+                unsigned lo[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) lo[e] = pack_bf16(f[2 * e] - bf16_lo(hi[e]), f[2 * e + 1] - bf16_hi(hi[e]));
+                al[i] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+            }
         }
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
-            const uint4 bh = okn[j] ? F.bh[j] : make_uint4(0u, 0u, 0u, 0u), bl = okn[j] ? F.bl[j] : make_uint4(0u, 0u, 0u, 0u);
+            const uint4 bh = okn[j] ? F.bh[j] : make_uint4(0u, 0u, 0u, 0u);
+            uint4 bl = make_uint4(0u, 0u, 0u, 0u);
+            if constexpr (X3) bl = okn[j] ? F.bl[j] : make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
             for (int i = 0; i < MI; i++) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(al[i]), as_bf8(bh), acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(ah[i]), as_bf8(bl), acc[i][j], 0, 0, 0);
+                if constexpr (X3) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(al[i]), as_bf8(bh), acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(ah[i]), as_bf8(bl), acc[i][j], 0, 0, 0);
+                }
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(ah[i]), as_bf8(bh), acc[i][j], 0, 0, 0);
             }
         }
@@ -1303,7 +1332,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_1x1_kernel(const liso_conv_d
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    conv_epilogue<MI, NJ, true>(d, a, acc, 0, b, tx, ty, wave, r, h, true, n0, stats_row, tid_all, smem);
+    conv_epilogue<MI, NJ, OUT_F32>(d, a, acc, cls, b, tx, ty, wave, r, h, true, n0, stats_row, tid_all, smem);
 }
 
 // ---- windows on 2-8 input channels, F32X3: two taps per MFMA step, fragments straight from global memory ---------------------------
@@ -1636,12 +1665,12 @@ int launch_roles(const liso_conv_desc& d, const Plan& p, hipStream_t st) {
                         : launch_roles_pro<MODE, MI, NJ, OUT_F32, NTAPS, false>(d, p, st);
 }
 
-template <int MI, int NJ>
+template <int MODE, int MI, int NJ, bool OUT_F32>
 int launch_1x1(const liso_conv_desc& d, const Plan& p, hipStream_t st) {
     if (p.a.in_scale)
-        conv_1x1_kernel<MI, NJ, true><<<p.a.total, kThreads, 0, st>>>(d, p.a);
+        conv_1x1_kernel<MODE, MI, NJ, OUT_F32, true><<<p.a.total, kThreads, 0, st>>>(d, p.a);
     else
-        conv_1x1_kernel<MI, NJ, false><<<p.a.total, kThreads, 0, st>>>(d, p.a);
+        conv_1x1_kernel<MODE, MI, NJ, OUT_F32, false><<<p.a.total, kThreads, 0, st>>>(d, p.a);
     return check_launch();
 }
 
@@ -1809,12 +1838,19 @@ int liso_conv_forward_sparse(const liso_conv_desc* d, const void* x, const void*
     }
     if (p.a.direct1x1) {
         if (((uintptr_t)in_scale | (uintptr_t)in_shift) & 15) return LISO_EINVAL;
-        if (p.mi == 1 && p.nj == 1) return launch_1x1<1, 1>(*d, p, st);
-        if (p.mi == 1 && p.nj == 2) return launch_1x1<1, 2>(*d, p, st);
-        if (p.mi == 1 && p.nj == 3) return launch_1x1<1, 3>(*d, p, st);
-        if (p.mi == 2 && p.nj == 1) return launch_1x1<2, 1>(*d, p, st);
-        if (p.mi == 2 && p.nj == 2) return launch_1x1<2, 2>(*d, p, st);
-        if (p.mi == 2 && p.nj == 3) return launch_1x1<2, 3>(*d, p, st);
+#define LISO_D1(MODE, OF)                                                                  \
+    do {                                                                                   \
+        if (p.mi == 1 && p.nj == 1) return launch_1x1<MODE, 1, 1, OF>(*d, p, st);          \
+        if (p.mi == 1 && p.nj == 2) return launch_1x1<MODE, 1, 2, OF>(*d, p, st);          \
+        if (p.mi == 1 && p.nj == 3) return launch_1x1<MODE, 1, 3, OF>(*d, p, st);          \
+        if (p.mi == 2 && p.nj == 1) return launch_1x1<MODE, 2, 1, OF>(*d, p, st);          \
+        if (p.mi == 2 && p.nj == 2) return launch_1x1<MODE, 2, 2, OF>(*d, p, st);          \
+        if (p.mi == 2 && p.nj == 3) return launch_1x1<MODE, 2, 3, OF>(*d, p, st);          \
+    } while (0)
+        if (x3) LISO_D1(LISO_CONV_F32X3, true);
+        else if (of32) LISO_D1(LISO_CONV_BF16, true);
+        else LISO_D1(LISO_CONV_BF16, false);
+#undef LISO_D1
         return LISO_EINVAL;
     }
     if (p.a.direct_taps) {

@@ -147,19 +147,26 @@ void plan_1x1(const liso_conv_desc& d, Plan* p) {
     FwdArgs& a = p->a;
     a.direct1x1 = 0;
     static const int env = getenv("LISO_CONV_1X1") ? atoi(getenv("LISO_CONV_1X1")) : 1;
-    if (!env || d.mode != LISO_CONV_F32X3 || d.n_classes != 1 || d.osy != 1 || d.osx != 1) return;
+    if (!env || (d.mode != LISO_CONV_F32X3 && d.mode != LISO_CONV_BF16)) return;
+    if (d.n_classes > 1) {  // tap classes: transposed convolutions with kernel = stride -- one tap per class (tap index = class index)
+        if (d.n_taps != d.n_classes) return;
+        for (int c = 0; c < d.n_classes; c++)
+            if (d.class_tap_begin[c] != c) return;
+    } else if (d.osy != 1 || d.osx != 1) {
+        return;
+    }
     // (the kernel walks any tap list; measured on the heads' 256 -> 6 output layer, 3x3 at 4 x 64 x 64: 47.7 us against 21.2 us on
     // conv_roles_kernel -- re-reading the pixels per tap through L1, 32 lines per load instruction, costs more than staging the tile
     // once even for a single 32-filter panel.  LISO_CONV_1X1=3 selects it for <= 16 filters on >= 64 channels: experiments)
-    const bool narrow = env == 3 && d.n_taps >= 2 && d.n_taps <= 9 && d.co <= 16 && d.ci >= 64;
-    if (d.n_taps != 1 && !narrow) return;
+    const bool narrow = env == 3 && d.mode == LISO_CONV_F32X3 && d.n_classes == 1 && d.n_taps >= 2 && d.n_taps <= 9 && d.co <= 16 && d.ci >= 64;
+    if (d.n_classes == 1 && d.n_taps != 1 && !narrow) return;
     if (a.roles && !narrow) return;
     for (int t = 0; t < d.n_taps; t++)
         if (d.tap_w[t] < 0 || d.tap_w[t] >= d.w_taps) return;
     if (d.in_affine_batch_stride & 3) return;
     a.roles = 0;
     const int nj = direct_panel_width(d.co);
-    const long tiles4 = (long)d.batch * ((d.hv + 3) / 4) * ((d.wv + 31) / 32) * ((d.co + 32 * nj - 1) / (32 * nj));
+    const long tiles4 = (long)d.n_classes * d.batch * ((d.hv + 3) / 4) * ((d.wv + 31) / 32) * ((d.co + 32 * nj - 1) / (32 * nj));
     const int mi = tiles4 >= 1024 ? 2 : 1;  // (8-row tiles once 4-row tiles would give every CU four blocks anyway)
     a.direct1x1 = 1;
     p->mi = mi;
@@ -169,7 +176,7 @@ void plan_1x1(const liso_conv_desc& d, Plan* p) {
     a.n_nt = (d.co + bnt - 1) / bnt;
     a.tiles_x = (d.wv + 31) / 32;
     a.tiles_y = (d.hv + th - 1) / th;
-    a.total = d.batch * a.tiles_y * a.tiles_x * a.n_nt;
+    a.total = d.n_classes * d.batch * a.tiles_y * a.tiles_x * a.n_nt;
 }
 
 // conv_taps_kernel: F32X3, one class, at most 8 input channels, 2+ taps (the motion encoder's 7x7 convolutions on flow / logits,

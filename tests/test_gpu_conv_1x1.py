@@ -176,3 +176,44 @@ def test_small_channel_windows(shape):
         assert bool((buf[..., :8] == 7.0).all()) and bool((buf[..., 8 + Co:] == 7.0).all())
     y4, _ = MC.conv_forward(xd, w.to(DEV), b.to(DEV), spec, out_relu=True)
     assert torch.equal(y, y4)
+
+
+# ---- the same kernel on bf16 tensors and on tap classes (transposed convolutions with kernel = stride: rpn.py:70-104 deblocks) --------------
+@pytest.mark.parametrize("dtype", [pytest.param(torch.float32, id="f32x3"), pytest.param(torch.bfloat16, id="bf16")])
+@pytest.mark.parametrize("shape", [(2, 128, 128, 32, 32, 2), (2, 256, 128, 64, 64, 2), (1, 64, 96, 9, 37, 2), (3, 40, 72, 20, 33, 1), (2, 128, 128, 128, 128, 1)])
+def test_transposed_kernel_equals_stride_and_bf16_1x1(shape, dtype):
+    from liso_amd import _lib as L
+    from liso_amd.utils import mfma_conv as MC
+
+    B, Ci, Co, H, W, k = shape
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, Ci, H, W, generator=g)
+    transposed = k > 1
+    w = (torch.randn(Ci, Co, k, k, generator=g) if transposed else torch.randn(Co, Ci, 1, 1, generator=g)) / Ci ** 0.5
+    b = torch.randn(Co, generator=g) * 0.3
+    if dtype == torch.bfloat16:
+        x, w = x.bfloat16().float(), w.bfloat16().float()
+    spec = MC.ConvSpec(k, k, k, 0, transposed)
+    xd = x.to(DEV).to(dtype).contiguous(memory_format=torch.channels_last)
+    mode = MC._mode(dtype)
+    xv, xps = MC.as_nhwc(xd, MC._vec(mode))
+    ho, wo = spec.out_hw(H, W)
+    build = MC.scatter_desc if transposed else MC.gather_desc
+    d = build(spec, B, H, W, Ci, xps, ho, wo, Co, Co, 0, mode, dtype == torch.float32, False, False)
+    assert L.lib().liso_conv_kernel_kind(ctypes.byref(d)) == 2, "descriptor does not take conv_1x1_kernel"
+    tol = 2e-2 if dtype == torch.bfloat16 else 2e-5
+    ref_fn = (lambda xx, bb: F.conv_transpose2d(xx, w.double(), bb, stride=k)) if transposed else (lambda xx, bb: F.conv2d(xx, w.double(), bb))
+    y, _ = MC.conv_forward(xd, w.to(DEV), b.to(DEV), spec, out_relu=True)
+    ref = F.relu(ref_fn(x.double(), b.double()))
+    assert y.shape == ref.shape and _rel(y.float(), ref) <= tol
+    sc, sh = torch.rand(Ci, generator=g) + 0.5, torch.randn(Ci, generator=g) * 0.2
+    y2, part = MC.conv_forward(xd, w.to(DEV), None, spec, sc.to(DEV), sh.to(DEV), in_relu=True, want_stats=True)
+    xin = F.relu(x.double() * sc.double()[None, :, None, None] + sh.double()[None, :, None, None])
+    if dtype == torch.bfloat16:
+        xin = xin.float().bfloat16().double()
+    assert _rel(y2.float(), ref_fn(xin, None)) <= tol
+    stored = y2.float().double()
+    s1, s2 = part[:, 0, :Co].double().sum(0).cpu(), part[:, 1, :Co].double().sum(0).cpu()
+    assert torch.allclose(s1, stored.sum((0, 2, 3)).cpu(), rtol=1e-4, atol=1e-3 * float(stored.abs().max()))
+    assert torch.allclose(s2, stored.square().sum((0, 2, 3)).cpu(), rtol=1e-4, atol=1e-6)
+    assert torch.isfinite(part).all()
