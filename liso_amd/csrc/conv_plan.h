@@ -159,7 +159,18 @@ void plan_1x1(const liso_conv_desc& d, Plan* p) {
     // conv_roles_kernel -- re-reading the pixels per tap through L1, 32 lines per load instruction, costs more than staging the tile
     // once even for a single 32-filter panel.  LISO_CONV_1X1=3 selects it for <= 16 filters on >= 64 channels: experiments)
     const bool narrow = env == 3 && d.mode == LISO_CONV_F32X3 && d.n_classes == 1 && d.n_taps >= 2 && d.n_taps <= 9 && d.co <= 16 && d.ci >= 64;
-    if (d.n_classes == 1 && d.n_taps != 1 && !narrow) return;
+    // kernel = stride (the k = 2 / stride-2 deblock, rpn.py:70-104): the taps tile the input without overlap -- every input pixel is read
+    // by exactly one tap, nothing is re-read: a 1x1 problem on s * s * ci channels
+    bool cell = d.n_classes == 1 && d.n_taps > 1 && d.n_taps == d.isy * d.isx;
+    if (cell) {
+        unsigned seen = 0;
+        for (int t = 0; t < d.n_taps && cell; t++) {
+            if (d.tap_dy[t] < 0 || d.tap_dy[t] >= d.isy || d.tap_dx[t] < 0 || d.tap_dx[t] >= d.isx) cell = false;
+            else seen |= 1u << (d.tap_dy[t] * d.isx + d.tap_dx[t]);
+        }
+        cell = cell && d.n_taps <= 16 && seen == (1u << d.n_taps) - 1u;
+    }
+    if (d.n_classes == 1 && d.n_taps != 1 && !narrow && !cell) return;
     if (a.roles && !narrow) return;
     for (int t = 0; t < d.n_taps; t++)
         if (d.tap_w[t] < 0 || d.tap_w[t] >= d.w_taps) return;

@@ -217,3 +217,38 @@ def test_transposed_kernel_equals_stride_and_bf16_1x1(shape, dtype):
     assert torch.allclose(s1, stored.sum((0, 2, 3)).cpu(), rtol=1e-4, atol=1e-3 * float(stored.abs().max()))
     assert torch.allclose(s2, stored.square().sum((0, 2, 3)).cpu(), rtol=1e-4, atol=1e-6)
     assert torch.isfinite(part).all()
+
+
+@pytest.mark.parametrize("dtype", [pytest.param(torch.float32, id="f32x3"), pytest.param(torch.bfloat16, id="bf16")])
+@pytest.mark.parametrize("shape", [(2, 64, 128, 256, 256, 2), (1, 32, 40, 18, 70, 2), (2, 16, 32, 27, 27, 3)])
+def test_kernel_equals_stride_convolutions(shape, dtype):
+    """k x k / stride k (the k = 2 deblock): non-overlapping windows -- one 1x1 problem on k * k * Ci channels, no pixel read twice"""
+    from liso_amd import _lib as L
+    from liso_amd.utils import mfma_conv as MC
+
+    B, Ci, Co, H, W, k = shape
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(B, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, k, k, generator=g) / (Ci * k * k) ** 0.5
+    b = torch.randn(Co, generator=g) * 0.3
+    if dtype == torch.bfloat16:
+        x, w = x.bfloat16().float(), w.bfloat16().float()
+    spec = MC.ConvSpec(k, k, k, 0, False)
+    xd = x.to(DEV).to(dtype).contiguous(memory_format=torch.channels_last)
+    mode = MC._mode(dtype)
+    xv, xps = MC.as_nhwc(xd, MC._vec(mode))
+    ho, wo = spec.out_hw(H, W)
+    d = MC.gather_desc(spec, B, H, W, Ci, xps, ho, wo, Co, Co, 0, mode, dtype == torch.float32, False, False)
+    assert L.lib().liso_conv_kernel_kind(ctypes.byref(d)) == 2, "descriptor does not take conv_1x1_kernel"
+    tol = 2e-2 if dtype == torch.bfloat16 else 2e-5
+    y, _ = MC.conv_forward(xd, w.to(DEV), b.to(DEV), spec, out_relu=True)
+    ref = F.relu(F.conv2d(x.double(), w.double(), b.double(), stride=k))
+    assert y.shape == ref.shape and _rel(y.float(), ref) <= tol
+    sc, sh = torch.rand(Ci, generator=g) + 0.5, torch.randn(Ci, generator=g) * 0.2
+    y2, part = MC.conv_forward(xd, w.to(DEV), None, spec, sc.to(DEV), sh.to(DEV), in_relu=True, want_stats=True)
+    xin = F.relu(x.double() * sc.double()[None, :, None, None] + sh.double()[None, :, None, None])
+    if dtype == torch.bfloat16:
+        xin = xin.float().bfloat16().double()
+    assert _rel(y2.float(), F.conv2d(xin, w.double(), None, stride=k)) <= tol
+    stored = y2.float().double()
+    assert torch.allclose(part[:, 0, :Co].double().sum(0).cpu(), stored.sum((0, 2, 3)).cpu(), rtol=1e-4, atol=1e-3 * float(stored.abs().max()))
