@@ -170,7 +170,12 @@ void plan_1x1(const liso_conv_desc& d, Plan* p) {
         }
         cell = cell && d.n_taps <= 16 && seen == (1u << d.n_taps) - 1u;
     }
-    if (d.n_classes == 1 && d.n_taps != 1 && !narrow && !cell) return;
+    // 3x3 / stride-2 layers on pixels of <= 256 bytes (64 fp32 / 128 bf16 channels): every input pixel is read by 2.25 taps on average,
+    // its lines stay in L1 between them -- measured on the encoders' four such layers (4 pairs): 141 -> 105 us against conv_igemm_kernel
+    // (LISO_CONV_1X1=2: one tap only)
+    const bool strided = env != 2 && d.n_classes == 1 && d.n_taps == 9 && d.isy == 2 && d.isx == 2 && d.ci > 8 &&  // (<= 8: conv_taps_kernel)
+                         d.ci * (d.mode == LISO_CONV_F32X3 ? 4 : 2) <= 256;
+    if (d.n_classes == 1 && d.n_taps != 1 && !narrow && !cell && !strided) return;
     if (a.roles && !narrow) return;
     for (int t = 0; t < d.n_taps; t++)
         if (d.tap_w[t] < 0 || d.tap_w[t] >= d.w_taps) return;

@@ -252,3 +252,40 @@ def test_kernel_equals_stride_convolutions(shape, dtype):
     assert _rel(y2.float(), F.conv2d(xin, w.double(), None, stride=k)) <= tol
     stored = y2.float().double()
     assert torch.allclose(part[:, 0, :Co].double().sum(0).cpu(), stored.sum((0, 2, 3)).cpu(), rtol=1e-4, atol=1e-3 * float(stored.abs().max()))
+
+
+@pytest.mark.parametrize("dtype", [pytest.param(torch.float32, id="f32x3"), pytest.param(torch.bfloat16, id="bf16")])
+@pytest.mark.parametrize("shape", [(8, 32, 64, 256, 256), (4, 64, 96, 128, 128), (2, 64, 128, 37, 45), (1, 16, 24, 9, 70)])
+def test_3x3_stride_2_layers_on_small_pixels(shape, dtype):
+    """3x3 / stride 2 / padding 1 on pixels of <= 256 bytes (the encoders' downsampling layers, extractor.py:211-297; the detector's block
+    entries, rpn.py:113-131): the direct kernel re-reads each pixel 2.25 times through L1 instead of staging tiles"""
+    from liso_amd import _lib as L
+    from liso_amd.utils import mfma_conv as MC
+
+    B, Ci, Co, H, W = shape
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(B, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / (Ci * 9) ** 0.5
+    b = torch.randn(Co, generator=g) * 0.3
+    if dtype == torch.bfloat16:
+        x, w = x.bfloat16().float(), w.bfloat16().float()
+    spec = MC.ConvSpec(3, 3, 2, 1, False)
+    xd = x.to(DEV).to(dtype).contiguous(memory_format=torch.channels_last)
+    mode = MC._mode(dtype)
+    xv, xps = MC.as_nhwc(xd, MC._vec(mode))
+    ho, wo = spec.out_hw(H, W)
+    d = MC.gather_desc(spec, B, H, W, Ci, xps, ho, wo, Co, Co, 0, mode, dtype == torch.float32, False, False)
+    assert L.lib().liso_conv_kernel_kind(ctypes.byref(d)) == 2, "descriptor does not take conv_1x1_kernel"
+    tol = 2e-2 if dtype == torch.bfloat16 else 2e-5
+    y, _ = MC.conv_forward(xd, w.to(DEV), b.to(DEV), spec, out_relu=True)
+    ref = F.relu(F.conv2d(x.double(), w.double(), b.double(), stride=2, padding=1))
+    assert y.shape == ref.shape and _rel(y.float(), ref) <= tol
+    sc, sh = torch.rand(Ci, generator=g) + 0.5, torch.randn(Ci, generator=g) * 0.2
+    y2, part = MC.conv_forward(xd, w.to(DEV), None, spec, sc.to(DEV), sh.to(DEV), in_relu=True, want_stats=True)
+    xin = F.relu(x.double() * sc.double()[None, :, None, None] + sh.double()[None, :, None, None])
+    if dtype == torch.bfloat16:
+        xin = xin.float().bfloat16().double()
+    assert _rel(y2.float(), F.conv2d(xin, w.double(), None, stride=2, padding=1)) <= tol
+    stored = y2.float().double()
+    assert torch.allclose(part[:, 0, :Co].double().sum(0).cpu(), stored.sum((0, 2, 3)).cpu(), rtol=1e-4, atol=1e-3 * float(stored.abs().max()))
+    assert torch.allclose(part[:, 1, :Co].double().sum(0).cpu(), stored.square().sum((0, 2, 3)).cpu(), rtol=1e-4, atol=1e-6)
