@@ -175,8 +175,12 @@ void plan_1x1(const liso_conv_desc& d, Plan* p) {
     // (LISO_CONV_1X1=2: one tap only)
     const bool strided = env != 2 && d.n_classes == 1 && d.n_taps == 9 && d.isy == 2 && d.isx == 2 && d.ci > 8 &&  // (<= 8: conv_taps_kernel)
                          d.ci * (d.mode == LISO_CONV_F32X3 ? 4 : 2) <= 256;
-    if (d.n_classes == 1 && d.n_taps != 1 && !narrow && !cell && !strided) return;
-    if (a.roles && !narrow) return;
+    // (experiment, LISO_CONV_1X1=5: 3x3 / stride-1 layers on pixels of <= 128 bytes -- 32 fp32 channels, the encoders' first stage: 9
+    // reads per pixel through L1.  Measured 114 vs 63.7 us (8 x 256^2) and 47.7 vs 29.9 us (4 x 256^2) against conv_roles_kernel: off)
+    const bool small_px = env == 5 && d.n_classes == 1 && d.n_taps == 9 && d.isy == 1 && d.isx == 1 && d.ci > 8 &&
+                          d.ci * (d.mode == LISO_CONV_F32X3 ? 4 : 2) <= 128;
+    if (d.n_classes == 1 && d.n_taps != 1 && !narrow && !cell && !strided && !small_px) return;
+    if (a.roles && !narrow && !small_px) return;
     for (int t = 0; t < d.n_taps; t++)
         if (d.tap_w[t] < 0 || d.tap_w[t] >= d.w_taps) return;
     if (d.in_affine_batch_stride & 3) return;
