@@ -85,18 +85,29 @@ def decorate_rows(points, pcfg, B, coors, num_points, slots, num_voxels):
     return pt_off, feat, voxel_cell
 
 
+def pillar_prep(points, offsets, pcfg):
+    """The weight-independent half of the pillar encoder: hard voxelisation + decorated feature rows (CSR) of a batch of clouds
+    -> (pt_off, feat, voxel_cell, num_voxels, cell_to_voxel).  ~14 of the encoder's ~20 launches; a trainer may issue it ahead of the
+    step that consumes it, on another stream (LisoLoopTrainer: the detector's clouds of the NEXT step, next to the current one)."""
+    B = len(offsets) - 1
+    coors, num_points, slots, num_voxels, cell_to_voxel = voxelize_raw(points, offsets, pcfg)
+    pt_off, feat, voxel_cell = decorate_rows(points, pcfg, B, coors, num_points, slots, num_voxels)
+    return pt_off, feat, voxel_cell, num_voxels, cell_to_voxel
+
+
 class _PillarFeatureScatter(torch.autograd.Function):
     """voxelise (no grad) + fused PFN + scatter; differentiable w.r.t. linear.weight, norm.weight, norm.bias."""
 
     @staticmethod
     def forward(ctx, weight, gamma, beta, running_mean, running_var, points, offsets, pcfg, training, momentum, eps,
-                out_dtype, out=None):
+                out_dtype, out=None, prep=None):
         L.require_cuda(points, weight)
         lib = L.lib()
         dev = points.device
         B = len(offsets) - 1
-        coors, num_points, slots, num_voxels, cell_to_voxel = voxelize_raw(points, offsets, pcfg)
-        pt_off, feat, voxel_cell = decorate_rows(points, pcfg, B, coors, num_points, slots, num_voxels)
+        if prep is None:
+            prep = pillar_prep(points, offsets, pcfg)
+        pt_off, feat, voxel_cell, num_voxels, cell_to_voxel = prep
         weight = weight.contiguous().float()
         with torch.cuda.device(dev):
             st = L.stream_ptr()
@@ -144,7 +155,7 @@ class _PillarFeatureScatter(torch.autograd.Function):
                                           L.ptr(num_voxels), L.ptr(weight), L.ptr(gamma), L.ptr(bn_out), L.ptr(moments),
                                           int(ctx.training), L.ptr(g), int(g.dtype == torch.bfloat16), L.ptr(gw), L.ptr(gg),
                                           L.ptr(gb), L.ptr(partials), L.stream_ptr()), "pfn_backward")
-        return gw, gg, gb, None, None, None, None, None, None, None, None, None, None
+        return gw, gg, gb, None, None, None, None, None, None, None, None, None, None, None
 
 
 class PointsPillarFeatureNetWrapper(nn.Module):
@@ -215,9 +226,20 @@ class PointsPillarFeatureNetWrapper(nn.Module):
                           torch.zeros((), device=cat.device))
         return vox, num_points[rows], coors[rows]
 
-    def extract_pts_feat(self, pts, out=None):
-        """reference :86-102.  `out` (extension): (canvas rows [B, gx, gy, 64], occupancy [B, 1, gx, gy]) to write into"""
+    @torch.no_grad()
+    def prepare(self, pts):
+        """(extension) voxelisation + decorated rows of `pts` now, for a later `extract_pts_feat(pts, prep=...)` (possibly on another
+        stream: the caller orders the streams and keeps the result alive) -> opaque tuple"""
         cat, offsets = self._cat(pts)
+        return (cat, offsets, pillar_prep(cat, offsets, self._pcfg(cat.shape[1])))
+
+    def extract_pts_feat(self, pts, out=None, prep=None):
+        """reference :86-102.  `out` (extension): (canvas rows [B, gx, gy, 64], occupancy [B, 1, gx, gy]) to write into;
+        `prep` (extension): the result of `prepare(pts)` for the same clouds"""
+        if prep is not None:
+            cat, offsets, prep = prep
+        else:
+            cat, offsets = self._cat(pts)
         C = cat.shape[1]
         assert C == self.num_input_channels, (C, self.num_input_channels)
         lyr = self.pts_voxel_encoder.pfn_layers[0]
@@ -226,9 +248,9 @@ class PointsPillarFeatureNetWrapper(nn.Module):
             lyr.norm.num_batches_tracked += 1
         x, occ = _PillarFeatureScatter.apply(lyr.linear.weight, lyr.norm.weight, lyr.norm.bias, lyr.norm.running_mean,
                                              lyr.norm.running_var, cat, offsets, self._pcfg(C), training,
-                                             lyr.norm.momentum, lyr.norm.eps, self.out_dtype, out)
+                                             lyr.norm.momentum, lyr.norm.eps, self.out_dtype, out, prep)
         return x, occ
 
-    def forward(self, pcl_t0, img_t0=None, out=None):
+    def forward(self, pcl_t0, img_t0=None, out=None, prep=None):
         """reference :104-107"""
-        return self.extract_pts_feat(pcl_t0, out=out)
+        return self.extract_pts_feat(pcl_t0, out=out, prep=prep)

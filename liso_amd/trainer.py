@@ -228,10 +228,12 @@ class DetectorTrainer:
             total = total + rotation_vec_on_unit_circle(activated) * rr.regul_weight
         return total, losses, pred_boxes
 
-    def step(self, pcls, targets):
+    def step(self, pcls, targets, prep=None):
+        """`prep` (extension): `self.net.model.pfn.prepare(pcls)` issued earlier (LisoLoopTrainer: on another stream, next to the previous
+        step) -- the weight-independent half of the pillar encoder"""
         self.model.train()
         if self.use_graph:
-            return self._graph_step(pcls, targets)
+            return self._graph_step(pcls, targets, prep)
         self.optimizer.zero_grad(set_to_none=True)
         total, losses, _ = self.loss(pcls, targets)
         total.backward()
@@ -269,9 +271,9 @@ class DetectorTrainer:
     # the reproducer replays cleanly, and the guard-band runs of tests/test_gpu_canaries.py find no out-of-bounds write in any kernel
     # of the encoder, at and beyond its capacities.  The encoder still runs eagerly for a different reason: its launches carry the
     # raw clouds' lengths (host offsets) as kernel arguments, which a captured graph would freeze.
-    def _pillars(self, pcls, out=None):
+    def _pillars(self, pcls, out=None, prep=None):
         """`out`: (canvas rows [B, gx, gy, 64], occupancy) to write into -- the graph's static inputs (no copy afterwards)"""
-        bev, occ = self.net.model.pfn(pcl_t0=pcls, img_t0=None, out=out)
+        bev, occ = self.net.model.pfn(pcl_t0=pcls, img_t0=None, out=out, prep=prep)
         return bev, occ
 
     def _capture(self, pcls, targets):
@@ -379,7 +381,7 @@ class DetectorTrainer:
     def _gather_gradients(self, params, add=False):
         self._gather_keepalive = gather_gradients(self.device, params, add)
 
-    def _graph_step(self, pcls, targets):
+    def _graph_step(self, pcls, targets, prep=None):
         # what the graph consumes: the [B, 64, gx, gy] canvas (batch size; grid and dtype are fixed per trainer) and the target maps.
         # The clouds themselves never enter it (the pillar encoder runs eagerly in front): their point counts are not part of the key.
         tsig = targets.shapes() if isinstance(targets, _BatchedTargets) else tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(targets.items()))
@@ -389,7 +391,7 @@ class DetectorTrainer:
             self._capture(pcls, targets)
             self._graph_sig = sig
         # the eager pillar encoder writes straight into the graph's input buffers (its own backward runs on saved feature rows)
-        bev, occ = self._pillars(pcls, out=(self._static_bev.detach().permute(0, 2, 3, 1), self._static_occ))
+        bev, occ = self._pillars(pcls, out=(self._static_bev.detach().permute(0, 2, 3, 1), self._static_occ), prep=prep)
         with torch.no_grad():
             stage = []  # (one launch for all target tensors: _lib.multi_copy)
             if isinstance(targets, _BatchedTargets):
@@ -880,6 +882,8 @@ class LisoLoopTrainer:
             self._mine_streams = [self._mine_stream] + [torch.cuda.Stream(device=device, priority=-1) for _ in range(n_mine - 1)]
             self._mine_turn = 0
             self.detector._capture_stream = self._flow_stream
+        self._pillar_prep = None  # (clouds, pfn.prepare(clouds), event) of the next detector step
+        self._prep_ahead = os.environ.get("LISO_PREP_AHEAD", "1") != "0"
         tc = cfg.data.tracking_cfg
         self.pre_nms, self.post_nms = tc.max_num_boxes_before_nms, tc.max_num_boxes_after_nms
         self.nms_iou = cfg.setdefault("nms_iou_threshold", 0.1)
@@ -1363,7 +1367,28 @@ class LisoLoopTrainer:
         else:  # (the graph path copies each sample's maps into its slice of the captured inputs: no concatenation launch)
             targets = _BatchedTargets([m[0] for m in mined])
         pcls = [c for p_ in pairs for c in p_[0]["pcl_full_no_ground_ta"]]
-        loss = self.detector.step(pcls, targets)
+        prep = None
+        if self.overlap and cuda and self._pillar_prep is not None:
+            key, got_prep, done = self._pillar_prep
+            self._pillar_prep = None
+            if len(key) == len(pcls) and all(a is b_ for a, b_ in zip(key, pcls)):  # (matched by object identity like every prefetch)
+                cur.wait_event(done)
+                cat, _, parts = got_prep
+                for t in (cat, *parts):
+                    t.record_stream(cur)  # (allocated on the mining stream, consumed here and by the encoder's backward)
+                prep = got_prep
+        loss = self.detector.step(pcls, targets, prep=prep) if prep is not None else self.detector.step(pcls, targets)
+        if self.overlap and cuda and len(upcoming) >= len(pairs) and self._prep_ahead and self.detector.use_graph:
+            # the weight-independent half of the NEXT step's pillar encoder (voxelisation + decorated rows: ~14 of its ~20 eager
+            # launches) now, on the mining stream, next to the detector step that was just enqueued: the detector's stream is the
+            # pipeline's critical path, and these launches sat at the head of every step of it
+            nxt = [c for p_ in upcoming[:len(pairs)] for c in p_[0]["pcl_full_no_ground_ta"]]
+            side = self._mine_stream
+            with torch.cuda.stream(side):
+                got_prep = self.detector.net.model.pfn.prepare(nxt)
+                done = torch.cuda.Event()
+                done.record(side)
+            self._pillar_prep = (nxt, got_prep, done)
         if self.overlap and len(upcoming) > 0:
             ahead = nb * (1 + len(self._mine_streams))  # stage B runs this many pairs ahead (one batch more than chains in flight)
             fa = nb * self.flow_ahead
