@@ -554,75 +554,32 @@ def main():
         timed_in = f"{event_steps} eager fwd+bwd passes after the timed region (the timed steps replay a hipGraph)"
     L.TIMER.disable_all()
     legs = {}
-    if args.workload == "loop" and args.dtype == "bf16" and world == 1 and not args.no_fp32_leg and not args.miopen_convs:
+    if args.workload == "loop" and args.dtype == "bf16" and world == 1 and rank == 0 and not args.no_fp32_leg and not args.miopen_convs:
         # the same iteration in the two parity-conformant arithmetics (north_star: logits / flow within 1e-3 of the reference's fp32
-        # path; certified at this size by tests/test_gpu_parity_full_size.py), bounded legs:
-        #   parity_leg      fp32 tensors everywhere, three bf16 MFMAs per product (F32X3), SLIM and detector
-        #   fp32_exact_leg  native fp32 MFMA (v_mfma_f32_32x32x2_f32), SLIM and detector
-        from liso_amd.utils import mfma_conv as MC
-
-        prev_mode = MC.fp32_mode()
+        # path; certified at this size by tests/test_gpu_parity_full_size.py), bounded legs, each this script in a CHILD process:
+        #   parity_leg      fp32 tensors everywhere, three bf16 MFMAs per product (F32X3), SLIM and detector  (--dtype f32x3)
+        #   fp32_exact_leg  native fp32 MFMA (v_mfma_f32_32x32x2_f32), SLIM and detector                     (--dtype fp32)
+        # (Until late in round 5 the legs ran IN this process, next to the headline's trainer: a second LisoLoopTrainer brings three more
+        # streams, HIP maps streams onto 4 hardware queues, and two pipeline stages then take turns on one queue -- the leg measured
+        # 7.0-7.7 ms per step where `python bench.py --dtype f32x3` measures 5.6.  A child process has the GPU's queues to itself.)
+        torch.cuda.empty_cache()
+        common = ["--lookahead", str(args.lookahead), "--flow-ahead", str(args.flow_ahead)] + (["--no-overlap"] if args.no_overlap else []) + \
+                 (["--eager"] if args.eager else []) + (["--batch", str(args.batch)] if args.batch else [])
+        wl = 2 + 16 // max(batch, 1)  # (once around the ring of 16 sweep pairs: every graph signature captured before the timed steps)
         for name, exact, label in (("parity_leg", False, "f32 via bf16x3 MFMA (fp32 tensors, hi*hi + hi*lo + lo*hi), SLIM and detector"),
                                    ("fp32_exact_leg", True, "f32 (exact: native fp32 MFMA v_mfma_f32_32x32x2_f32, SLIM and detector)")):
-            tl = LisoLoopTrainer(cfg, dev, compute_dtype=torch.float32, total_steps=64, use_graph=not args.eager, overlap=overlap,
-                                 infer_batch=max(1, args.lookahead - 1 - args.flow_ahead), flow_ahead=args.flow_ahead, exact=exact)
-            tl.detector.net.load_state_dict(trainer.detector.net.state_dict())
-            tl.slim.load_state_dict(trainer.slim.state_dict())
-            cl = [0]
-
-            def step_leg():
-                i = cl[0] * batch
-                cl[0] += 1
-                return tl.step_batch([pairs[(i + k) % len(pairs)] for k in range(batch)],
-                                     upcoming=tuple(pairs[(i + k) % len(pairs)] for k in range(batch, batch + n_up)))
-
-            # (warm-up: once around the ring, every graph signature captured; the parity-conformant leg gets the driver's 20 timed steps)
-            nl, wl = (max(min(args.steps, 20), 1) if not exact else min(args.steps, 10)), 2 + len(pairs) // batch
-            for _ in range(wl):
-                step_leg()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(nl):
-                ll = step_leg()
-            torch.cuda.synchronize()
-            el = time.perf_counter() - t0
-            leg_roofline = None
-            if not args.eager:
-                # the leg's dominant kernel, measured like the headline's: HIP events around every C-ABI launch of two eager passes
-                # (the main line's timer state is kept aside and restored)
-                keep = (L.TIMER.events, L.TIMER.units, L.TIMER.bytes, L.TIMER.weights)
-                L.TIMER.events, L.TIMER.units, L.TIMER.bytes, L.TIMER.weights = {}, {}, {}, {}
-                L.TIMER.enable_all()
-                for _ in range(2):
-                    tl.eager_pass_batch(pairs[:batch], also=tuple(pairs[batch:max(batch, tl.infer_batch)]) if overlap else ())
-                torch.cuda.synchronize()
-                L.TIMER.disable_all()
-                per = {k: L.TIMER.weighted_total_ms(k) for k in L.TIMER.events if L.TIMER.events[k]}
-                mf = {k: v for k, v in per.items() if KERNELS.get(k, ("", "hbm", ""))[1] == "mfma" and L.TIMER.units.get(k)}
-                if mf:
-                    k = max(mf, key=mf.get)
-                    tot_ms = sum(L.TIMER.durations_ms(k))
-                    flops = float(sum(L.TIMER.units[k]))
-                    peak = MFMA_PEAK_BF16_TF / 3.0 if "f32x3" in k else VALU_PEAK_F32_TF if k.startswith("conv_f32_") else MFMA_PEAK_BF16_TF
-                    ach = flops / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
-                    leg_roofline = {"kernel": KERNELS[k][0], "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                                    "frac": ach / peak, "avg_launch_ms": tot_ms / max(len(L.TIMER.events[k]), 1),
-                                    "timed_kernels_ms_per_step": {q: round(v / 2, 4) for q, v in sorted(per.items(), key=lambda kv: -kv[1])[:8]},
-                                    "timed_in": "2 eager fwd+bwd passes after the leg's timed steps"}
-                L.TIMER.events, L.TIMER.units, L.TIMER.bytes, L.TIMER.weights = keep
-            legs[name] = {"dtype": label, "steps": nl, "warmup": wl, "ms_per_step": 1e3 * el / nl, "value": 2 * batch * nl / el,
-                          "unit": "frames/s", "final_loss": float(ll), "roofline": leg_roofline,
-                          # (nothing in this leg measures parity: these are the tests that compare this arithmetic with the CPU
-                          # oracle at this size, bar 1e-3)
-                          "parity_tests": ["tests/test_gpu_parity_full_size.py::test_detector_logits_and_loss_at_full_size_match_fp64_oracle"
-                                           f"[{'exact' if exact else 'x3'}]",
-                                           "tests/test_gpu_parity_full_size.py::test_slim_last_iteration_flow_at_full_size_matches_cpu_oracle"
-                                           f"[{'exact' if exact else 'x3'}]"],
-                          "note": "same launch structure and inputs as the headline line; `python bench.py --dtype "
-                                  f"{'fp32' if exact else 'f32x3'}` gives the full line"}
-            del tl
-            MC.set_fp32_mode(prev_mode)
-            torch.cuda.empty_cache()
+            leg = child_leg(["--dtype", "fp32" if exact else "f32x3"] + common,
+                            steps=max(min(args.steps, 20), 1) if not exact else min(args.steps, 10), warmup=wl, timeout_s=600)
+            if "error" not in leg:
+                leg["dtype"] = label
+                # (nothing in this leg measures parity: these are the tests that compare this arithmetic with the CPU oracle at this
+                # size, bar 1e-3)
+                leg["parity_tests"] = ["tests/test_gpu_parity_full_size.py::test_detector_logits_and_loss_at_full_size_match_fp64_oracle"
+                                       f"[{'exact' if exact else 'x3'}]",
+                                       "tests/test_gpu_parity_full_size.py::test_slim_last_iteration_flow_at_full_size_matches_cpu_oracle"
+                                       f"[{'exact' if exact else 'x3'}]"]
+                leg["note"] = "same launch structure and inputs as the headline line, in a child process"
+            legs[name] = leg
     if args.workload == "loop" and args.dtype == "bf16" and world == 1 and rank == 0 and not args.no_legs and not args.miopen_convs:
         # BASELINE configs[1] / [2] / [4] as bounded legs: this script with --workload slim | detector | stress in a child process
         # (the SLIM training graph needs another runtime mode, see _graph_env), its JSON line trimmed to the numbers
