@@ -37,31 +37,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-def _seed_miopen_user_db():
-    """MIOpen keeps the solver picks / tuning parameters it finds in a per-user database; a fresh machine starts from
-    heuristics and only reaches the tuned state after several processes have run.  scripts/miopen_db/ holds that
-    database as harvested on an MI355X with this ROCm image, for `--miopen-convs` (the library-backed comparison: no product
-    path uses MIOpen); every process works on a private copy.  Must run before MIOpen initialises."""
-    src = os.path.join(ROOT, "scripts", "miopen_db")
-    # only the library-backed comparison leg reaches MIOpen: the default run never touches the database
-    if "--miopen-convs" not in sys.argv or "MIOPEN_USER_DB_PATH" in os.environ or not os.path.isdir(src) or "--no-miopen-db" in sys.argv:
-        return
-    import shutil
-    import tempfile
-    dst = tempfile.mkdtemp(prefix="liso_miopen_db_")
-    for f in os.listdir(src):
-        shutil.copy(os.path.join(src, f), dst)
-    os.environ["MIOPEN_USER_DB_PATH"] = dst
-
-
 def _graph_env():
     """`--workload slim --graph` captures autograd's reductions / rocPRIM scans, whose hipMemsetAsync nodes the runtime only
     replays correctly with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 (liso_amd/utils/graph_safety.py); the loop / detector graphs hold
     no memset node and keep the default (recorded packets: 1 ms per step faster).  Must be set before HIP initialises."""
     if "--graph" in sys.argv and "slim" in sys.argv:
-        os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
-    if "--miopen-convs" in sys.argv and "--eager" not in sys.argv:
-        # MIOpen / ATen backward reductions inside the captured detector step bring memset nodes along (same rule)
         os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 
 
@@ -107,10 +87,6 @@ def parse():
     ap.add_argument("--eager", action="store_true",
                     help="loop / detector workloads: launch every kernel eagerly (default: SLIM inference and the detector's "
                          "backbone + head + loss fwd/bwd replay from hipGraphs; bit-identical results)")
-    ap.add_argument("--conv-benchmark", action="store_true", help="torch.backends.cudnn.benchmark = True (MIOpen layers only)")
-    ap.add_argument("--no-miopen-db", action="store_true", help="--miopen-convs: do not seed MIOpen's user database from scripts/miopen_db/")
-    ap.add_argument("--miopen-convs", action="store_true",
-                    help="route every convolution through MIOpen instead of the own MFMA kernels (comparison runs)")
     return ap.parse_args()
 
 
@@ -382,7 +358,6 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with matching values")
-    _seed_miopen_user_db()
     import torch
     import torch.distributed as dist
 
@@ -406,9 +381,6 @@ def main():
     from liso_amd import _lib as L
     from liso_amd.utils.config import apply_slim_simple_knn_training, default_cfg
 
-    torch.backends.cudnn.benchmark = bool(args.conv_benchmark)
-    if args.miopen_convs:
-        os.environ["LISO_CONV_BACKEND"] = "miopen"
 
     if args.workload == "iou3d":
         if rank == 0:
@@ -554,7 +526,7 @@ def main():
         timed_in = f"{event_steps} eager fwd+bwd passes after the timed region (the timed steps replay a hipGraph)"
     L.TIMER.disable_all()
     legs = {}
-    if args.workload == "loop" and args.dtype == "bf16" and world == 1 and rank == 0 and not args.no_fp32_leg and not args.miopen_convs:
+    if args.workload == "loop" and args.dtype == "bf16" and world == 1 and rank == 0 and not args.no_fp32_leg:
         # the same iteration in the two parity-conformant arithmetics (north_star: logits / flow within 1e-3 of the reference's fp32
         # path; certified at this size by tests/test_gpu_parity_full_size.py), bounded legs, each this script in a CHILD process:
         #   parity_leg      fp32 tensors everywhere, three bf16 MFMAs per product (F32X3), SLIM and detector  (--dtype f32x3)
@@ -580,7 +552,7 @@ def main():
                                        f"[{'exact' if exact else 'x3'}]"]
                 leg["note"] = "same launch structure and inputs as the headline line, in a child process"
             legs[name] = leg
-    if args.workload == "loop" and args.dtype == "bf16" and world == 1 and rank == 0 and not args.no_legs and not args.miopen_convs:
+    if args.workload == "loop" and args.dtype == "bf16" and world == 1 and rank == 0 and not args.no_legs:
         # BASELINE configs[1] / [2] / [4] as bounded legs: this script with --workload slim | detector | stress in a child process
         # (the SLIM training graph needs another runtime mode, see _graph_env), its JSON line trimmed to the numbers
         for name, extra in (("slim_leg", ["--workload", "slim", "--graph"]), ("detector_leg", ["--workload", "detector"]),
@@ -697,7 +669,7 @@ def main():
                                        "flow clustering / AdamW" + (f"; 3-stage pipeline on 3 HIP streams: SLIM inference {max(1, args.lookahead - 1 - args.flow_ahead)} pairs per replay | "
                                                                     "clustering+NMS+targets 1-2 pairs ahead (fixed box slots, no host reads) | "
                                                                     "detector step on pair i" if args.workload == "loop" and overlap else "")),
-                       "convolutions": "MIOpen (--miopen-convs)" if args.miopen_convs else "own MFMA implicit-GEMM kernels",
+                       "convolutions": "own MFMA implicit-GEMM kernels",
                        # the stride-2 layers that read a pillar canvas multiply occupied cells only; True here would mean a batch held
                        # more occupied cells than the cell lists' capacity and some were dropped (never, with the voxeliser's 40000 cap)
                        "sparse_canvas_convolutions": {"enabled": os.environ.get("LISO_SPARSE_STEM", "1") != "0",

@@ -51,9 +51,14 @@ int liso_kabsch_trafos_f32(const liso_kabsch_cfg* cfg, const float* points, cons
 /* The same for callers with a FIXED number of slots of which only the first slot_count[b] (int32 [B], device) hold boxes (the LISO
  * loop's box mining: 64 slots, 15-30 boxes; the other slots are parked where their soft mask is 0 in fp32).  The parked slots are not
  * evaluated -- 7.7 M box-mask evaluations (3 atan each) per 120k-point cloud at 64 slots, the kernel is bound by them -- and the lanes
- * are re-dealt over the boxes that exist.  Every output is what liso_kabsch_trafos_f32 gives for the parked arrangement (a parked slot
- * is a factor of exactly 1 in the background product and its moments fall under the 1e-12 rule above), except fg_weights of parked
- * slots: exact zeros instead of ~1e-23.  slot_count == NULL: all n_slots slots hold boxes. */
+ * are re-dealt over the boxes that exist (16 / 32 / 64 slot lanes x 4 / 2 / 1 point sub-lanes per wave, chosen from slot_count[b]).
+ * Skipping a parked slot changes no output bit (it is a factor of exactly 1 in the background product and its moments fall under the
+ * 1e-12 rule above; fg_weights of parked slots: exact zeros instead of ~1e-23), but the re-deal changes the ORDER in which a slot's
+ * fp32 moment sums are added: the transforms equal liso_kabsch_trafos_f32's for the parked arrangement to fp32-summation tolerance
+ * (1e-6 relative, what tests/test_gpu_kabsch.py asserts), not bitwise, and they depend bitwise on which of the three deals
+ * slot_count[b] selects.  For a fixed slot_count every output is run-to-run bitwise reproducible.
+ * slot_count == NULL: all n_slots slots hold boxes and the deal is the uncounted one (64 slot lanes), i.e. bitwise
+ * liso_kabsch_trafos_f32. */
 int liso_kabsch_trafos_counted_f32(const liso_kabsch_cfg* cfg, const float* points, const uint8_t* valid, const float* flow,
                                    const float* box_pos, const float* box_dims, const float* box_rot, const int32_t* slot_count,
                                    double* trafos, float* cum_wts, float* fg_weights, void* workspace, size_t workspace_bytes,

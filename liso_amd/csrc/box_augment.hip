@@ -16,6 +16,7 @@
 #include "../../include/liso_augment.h"
 #include "../../include/liso_iou3d.h"
 #include "zero_fill.h"
+#include "per_device.h"
 
 namespace {
 
@@ -222,12 +223,8 @@ int liso_bev_free_mask(const int32_t* pillar_coors, long n, int h, int w, int ra
     const size_t lds = (size_t)(2 * radius + 1) * words * sizeof(unsigned long long);
     if (lds > 120 * 1024) return LISO_EINVAL;  // (radius 255 on a 1024-wide grid = 65 KB)
     hipStream_t st = (hipStream_t)stream;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)free_mask_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024) != hipSuccess)
-            return LISO_ELAUNCH;
-        attr_set = true;
-    }
+    static liso_dev::PerDeviceFlag attr_set;
+    if (!liso_dev::lds_opt_in(attr_set, (const void*)free_mask_kernel, 120 * 1024)) return LISO_ELAUNCH;
     uint8_t* occ = (uint8_t*)workspace;
     if (liso_zero::zero_async(occ, liso_bev_free_mask_workspace_bytes(h, w), st) != hipSuccess) return LISO_ELAUNCH;
     if (n > 0) occupancy_bytes_kernel<<<(unsigned)((n + kThreads - 1) / kThreads), kThreads, 0, st>>>(pillar_coors, n, h, w, words * 64, occ);

@@ -29,6 +29,7 @@
 #include "../../include/liso_conv.h"
 #include "../../include/liso_iou3d.h"
 #include "conv_plan.h"
+#include "per_device.h"
 
 namespace {
 
@@ -1639,20 +1640,10 @@ int check_launch() { return hipGetLastError() == hipSuccess ? LISO_OK : LISO_ELA
 
 template <int MODE, int MI, int NJ, bool OUT_F32, int NTAPS, bool PRO>
 int launch_roles_pro(const liso_conv_desc& d, const Plan& p, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)conv_roles_kernel<MODE, MI, NJ, OUT_F32, NTAPS, PRO>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024) != hipSuccess)
-            return LISO_ELAUNCH;
-        attr_set = true;
-    }
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return LISO_ELAUNCH;
-        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    static liso_dev::PerDeviceFlag attr_set;  // (per device: per_device.h)
+    if (!liso_dev::lds_opt_in(attr_set, (const void*)conv_roles_kernel<MODE, MI, NJ, OUT_F32, NTAPS, PRO>, 160 * 1024)) return LISO_ELAUNCH;
+    const int n_cu = liso_dev::cu_count();
+    if (n_cu <= 0) return LISO_ELAUNCH;
     // LISO_CONV_OPT_ROLES_CUS: leave compute units to the other streams' kernels (include/liso_conv.h)
     const int cus = (g_roles_cus >= 8 && g_roles_cus < n_cu) ? g_roles_cus : n_cu;
     const int grid = p.a.total < cus ? p.a.total : cus;
@@ -1685,13 +1676,8 @@ int launch_taps(const liso_conv_desc& d, const Plan& p, hipStream_t st) {
 
 template <int MODE, int MI, int NJ, bool OUT_F32, int CS, int SK = 1>
 int launch(const liso_conv_desc& d, const Plan& p, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)conv_igemm_kernel<MODE, MI, NJ, OUT_F32, CS, SK>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024) != hipSuccess)
-            return LISO_ELAUNCH;
-        attr_set = true;
-    }
+    static liso_dev::PerDeviceFlag attr_set;
+    if (!liso_dev::lds_opt_in(attr_set, (const void*)conv_igemm_kernel<MODE, MI, NJ, OUT_F32, CS, SK>, 160 * 1024)) return LISO_ELAUNCH;
     conv_igemm_kernel<MODE, MI, NJ, OUT_F32, CS, SK><<<p.a.total, kThreads * SK, p.lds, st>>>(d, p.a);
     return check_launch();
 }

@@ -18,6 +18,7 @@
 
 #include "../../include/liso_conv.h"
 #include "../../include/liso_iou3d.h"
+#include "per_device.h"
 
 namespace {
 
@@ -1039,13 +1040,8 @@ bool make_plan(const liso_conv_desc& d, WgPlan* p) {
 
 template <int MODE, int TG>
 int launch(const liso_conv_desc& d, const WgPlan& p, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)conv_wgrad_kernel<MODE, TG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
-            hipSuccess)
-            return LISO_ELAUNCH;
-        attr_set = true;
-    }
+    static liso_dev::PerDeviceFlag attr_set;
+    if (!liso_dev::lds_opt_in(attr_set, (const void*)conv_wgrad_kernel<MODE, TG>, 160 * 1024)) return LISO_ELAUNCH;
     conv_wgrad_kernel<MODE, TG><<<p.blocks, kThreads, p.lds, st>>>(d, p.a);
     return hipGetLastError() == hipSuccess ? LISO_OK : LISO_ELAUNCH;
 }
@@ -1287,13 +1283,8 @@ bool make_rs3_plan(const liso_conv_desc& d, Rs3Plan* p) {
 
 template <int MODE, int TH, int S>
 int launch_rs3(const liso_conv_desc& d, const Rs3Plan& p, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)conv_wgrad_rs3_kernel<MODE, TH, S>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
-            hipSuccess)
-            return LISO_ELAUNCH;
-        attr_set = true;
-    }
+    static liso_dev::PerDeviceFlag attr_set;
+    if (!liso_dev::lds_opt_in(attr_set, (const void*)conv_wgrad_rs3_kernel<MODE, TH, S>, 160 * 1024)) return LISO_ELAUNCH;
     conv_wgrad_rs3_kernel<MODE, TH, S><<<p.blocks, kRsThreads, p.lds, st>>>(d, p.a);
     return hipGetLastError() == hipSuccess ? LISO_OK : LISO_ELAUNCH;
 }

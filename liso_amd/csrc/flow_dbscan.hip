@@ -292,7 +292,10 @@ __global__ __launch_bounds__(kUfThreads) void dbscan_union_tiled_kernel(Cfg c, c
                 if (ga < gb) { hi = bq; lo_g = ga; hi_g = gb; }
                 const int old = atomicMin(&s_par[hi], lo_g);  // the larger root under the smaller one
                 if (old == hi_g) break;                       // it was still a root: linked
-                a = hi;                                       // somebody re-parented it meanwhile: walk on from there
+                // somebody re-parented it meanwhile, to `old`.  The atomicMin has already stored min(old, lo_g) there, so when
+                // lo_g < old the edge hi -> old is GONE: go on with the pair (old, lo_g), as the global loops do with `x = old`
+                // (walking on from hi would find hi and lo_g joined and leave old's tree cut off)
+                a = (old / c.gy - r0) * RW + (old % c.gy - c0);
                 bq = (lo_g / c.gy - r0) * RW + (lo_g % c.gy - c0);
             }
         }

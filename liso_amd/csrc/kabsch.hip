@@ -98,7 +98,8 @@ __global__ __launch_bounds__(kThreads) void kabsch_moments_kernel(liso_kabsch_cf
         cnt = cnt < 0 ? 0 : (cnt > S ? S : cnt);
     }
     const int cnt_chunk = cnt - chunk * 64 < 0 ? 0 : (cnt - chunk * 64 > 64 ? 64 : cnt - chunk * 64);
-    const int SV = cnt_chunk <= 16 ? 16 : (cnt_chunk <= 32 ? 32 : 64), NP = 64 / SV;
+    // (no slot_count: the uncounted deal, one point sub-lane -- the summation order of liso_kabsch_trafos_f32 whatever n_slots is)
+    const int SV = !slot_count ? 64 : (cnt_chunk <= 16 ? 16 : (cnt_chunk <= 32 ? 32 : 64)), NP = 64 / SV;
     const int slot_l = lane % SV, psub = lane / SV;
     const int slot = chunk * 64 + slot_l;
     const bool has_slot = slot < cnt;

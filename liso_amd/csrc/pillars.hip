@@ -242,7 +242,8 @@ __global__ __launch_bounds__(256) void voxel_slots_kernel(const int* __restrict_
         return;
     }
     int last = -1;
-    for (int r = 0; r < max_points; r++) {
+    const int rounds = min(max_points, n);  // (max_points > n: the slots behind the n-th stay untouched, as on the n <= 64 path)
+    for (int r = 0; r < rounds; r++) {
         int m = 0x7fffffff;
         for (int j = lane; j < n; j += 64) {
             const int x = seg[off + j];

@@ -13,6 +13,7 @@
 
 #include "../../include/liso_iou3d.h"
 #include "../../include/liso_slim.h"
+#include "per_device.h"
 
 namespace {
 
@@ -466,13 +467,10 @@ int liso_corr_lookup_fwd_tiled_f32(const liso_corr_cfg* cfg, const float* fmap1,
     hipStream_t st = (hipStream_t)stream;
     const int tiles_x = (cfg->w + kTQW - 1) / kTQW, tiles_y4 = (cfg->h + 3) / 4, tiles_y8 = (cfg->h + 7) / 8;
     constexpr int kLds = 2 * (kTKC / 8) * ((32 + 256) * 16 + 128);  // (the 8 x 8-query shape needs less: 2 * 8 * ((64 + 192) * 16 + 128) - 8 KB ... both <= this)
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)corr_lookup_tiled_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds) != hipSuccess ||
-            hipFuncSetAttribute((const void*)corr_lookup_tiled_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds) != hipSuccess)
-            return LISO_ELAUNCH;
-        attr_set = true;
-    }
+    static liso_dev::PerDeviceFlag attr_set1, attr_set2;
+    if (!liso_dev::lds_opt_in(attr_set1, (const void*)corr_lookup_tiled_kernel<1>, kLds) ||
+        !liso_dev::lds_opt_in(attr_set2, (const void*)corr_lookup_tiled_kernel<2>, kLds))
+        return LISO_ELAUNCH;
     // 8 x 8-query tiles on the pooled levels once they give every CU a block (4 / 2 samples of 64 x 64 queries: 768 / 384 such blocks,
     // 49.8 vs 65.5 / 32.8 vs 34.5 us; one sample: 192 blocks, no gain); LISO_CORR_WIDE_TILES = 0 / 1 forces either
     static const int wide_env = getenv("LISO_CORR_WIDE_TILES") ? atoi(getenv("LISO_CORR_WIDE_TILES")) : -1;

@@ -87,6 +87,9 @@ class SepHead(nn.Module):
         return out
 
     def forward(self, x):
+        """host tensors (CPU test tier); device tensors take `forward_fused`"""
+        from liso_amd.utils import host_ops
+
         out = {}
         for head in self.heads:
             fc = list(self.__getattr__(head))
@@ -97,13 +100,11 @@ class SepHead(nn.Module):
                     y = conv_bn_relu(y, fc[i], fc[i + 1])
                     i += 3
                 else:
-                    y = torch.relu(torch.nn.functional.conv2d(y, fc[i].weight.to(y.dtype), fc[i].bias.to(y.dtype),
-                                                              padding=fc[i].padding))
+                    y = torch.relu(host_ops.conv2d(y, fc[i].weight.to(y.dtype), fc[i].bias.to(y.dtype), padding=fc[i].padding))
                     i += 2
             last = fc[-1]
             # final prediction conv: fp32 output (logits / regression targets feed an fp32 loss)
-            out[head] = torch.nn.functional.conv2d(y, last.weight.to(y.dtype), last.bias.to(y.dtype),
-                                                   padding=last.padding).float()
+            out[head] = host_ops.conv2d(y, last.weight.to(y.dtype), last.bias.to(y.dtype), padding=last.padding).float()
         return out
 
 
@@ -125,7 +126,7 @@ class CenterHead(nn.Module):
         fold = None
         if isinstance(x, tuple):  # (raw maps, BnFold) from RPN.forward(lazy=True)
             x, fold = x
-        if x.is_cuda and MC.backend() == "mfma" and x.dtype in (torch.bfloat16, torch.float32):
+        if MC.on_device(x):
             s_raw, s_fold = MC.fused_conv(x, fold, self.shared_conv[0], out_bn=self.shared_conv[1])
             assert len(self.tasks) == 1, len(self.tasks)
             ret = self.tasks[0].forward_fused(s_raw, s_fold, MC)

@@ -7,12 +7,11 @@ gradient -- runs on the library's own MFMA implicit-GEMM kernels (include/liso_c
 3x3 / stride-1 layers, conv_igemm_kernel for the rest, the sparse-canvas kernels for the first layer), with the
 BatchNorm-apply + ReLU of the producing layer as the consumer's prologue and the batch statistics as the producer's
 epilogue (fp32 statistics; include/liso_bn.h for the backward passes).  forward() is functional so ZeroPad2d +
-conv(pad=0) becomes one padded conv (identical arithmetic, one HBM round trip less per stage).  MIOpen is only reached
-with LISO_CONV_BACKEND=miopen (`bench.py --miopen-convs`: the library-backed comparison leg).
+conv(pad=0) becomes one padded conv (identical arithmetic, one HBM round trip less per stage).  Host tensors (the CPU test tier)
+step through liso_amd/utils/host_ops.py; there is no other route for a device tensor than the own kernels.
 """
 import numpy as np
 import torch
-import torch.nn.functional as F
 from torch import nn
 
 from liso_amd.networks.centerpoint.fused_bn import bn_act
@@ -21,16 +20,18 @@ from liso_amd.networks.centerpoint.weight_init import xavier_init
 
 
 def conv_bn_relu(x, conv, bn, stride=None, padding=None):
-    """conv (+bias) -> BatchNorm2d -> ReLU on a channels-last tensor; BN stats in fp32 whatever the conv dtype."""
+    """conv (+bias) -> BatchNorm2d -> ReLU on a HOST tensor (CPU test tier); BN stats in fp32 whatever the conv dtype."""
+    from liso_amd.utils import host_ops
+
     w = conv.weight
     if w.dtype != x.dtype:
         w = w.to(x.dtype)
     b = conv.bias.to(x.dtype) if conv.bias is not None else None
     if isinstance(conv, nn.ConvTranspose2d):
-        y = F.conv_transpose2d(x, w, b, stride=conv.stride)
+        y = host_ops.conv_transpose2d(x, w, b, stride=conv.stride)
     else:
-        y = F.conv2d(x, w, b, stride=conv.stride if stride is None else stride,
-                     padding=conv.padding if padding is None else padding)
+        y = host_ops.conv2d(x, w, b, stride=conv.stride if stride is None else stride,
+                            padding=conv.padding if padding is None else padding)
     return bn_act(y, bn, relu=True)
 
 
@@ -95,7 +96,7 @@ class RPN(nn.Module):
         (raw concatenated maps, BnFold) for CenterHead instead of materialising the normalised feature map."""
         from liso_amd.utils import mfma_conv as MC
 
-        if x.is_cuda and MC.backend() == "mfma" and x.dtype in (torch.bfloat16, torch.float32):
+        if MC.on_device(x):
             raw, fold = self._forward_fused(x, MC, occupancy)
             return (raw, fold) if lazy else MC.materialize(raw, fold)
         ups = []

@@ -13,8 +13,9 @@ emits the next), so autograd runs their backwards in exactly the reverse order a
 import contextlib
 
 import torch
-import torch.nn.functional as F
 from torch import nn
+
+from liso_amd.utils import host_ops
 
 _ACTIVE = None
 
@@ -119,7 +120,11 @@ class _ParamGate(torch.autograd.Function):
 def _own_kernels(x, w, layer):
     from liso_amd.utils import mfma_conv as MC
 
-    return x.is_cuda and MC.backend() == "mfma" and MC.supported(x, w, MC.ConvSpec.of(layer))
+    if not MC.on_device(x):
+        return False  # host tensor: CPU test tier
+    if not MC.supported(x, w, MC.ConvSpec.of(layer)):
+        raise NotImplementedError(f"liso_amd: no device kernel for the convolution {tuple(w.shape)} on {tuple(x.shape)} {x.dtype}")
+    return True
 
 
 class _ConvDeferred(torch.autograd.Function):
@@ -134,7 +139,7 @@ class _ConvDeferred(torch.autograd.Function):
 
             y, _ = MC.conv_forward(x, w, b, MC.ConvSpec.of(layer), out_relu=ctx.relu, packed=state.packed(li, False, x.dtype))
         else:
-            y = F.conv2d(x, w, b, layer.stride, layer.padding, layer.dilation)
+            y = host_ops.conv2d(x, w, b, layer.stride, layer.padding, layer.dilation)
             y = torch.relu(y) if ctx.relu else y
         ctx.save_for_backward(x, w, y if ctx.relu else None)
         return y, token.view_as(token)  # alias: no launch
@@ -211,11 +216,11 @@ def conv2d_pair(layer_a: nn.Conv2d, layer_b: nn.Conv2d, x, relu=False):
     if st is None or key not in st.index:
         from liso_amd.utils import mfma_conv as MC
 
-        if x.is_cuda and MC.backend() == "mfma" and MC.supported(x, layer_a.weight, MC.ConvSpec.of(layer_a)):
+        if _own_kernels(x, layer_a.weight, layer_a):
             return MC.fused_conv(x, None, [layer_a, layer_b], out_relu=relu)[0]
         w = torch.cat([layer_a.weight, layer_b.weight], dim=0)
         b = torch.cat([layer_a.bias, layer_b.bias], dim=0)
-        y = F.conv2d(x, w, b, layer_a.stride, layer_a.padding, layer_a.dilation)
+        y = host_ops.conv2d(x, w, b, layer_a.stride, layer_a.padding, layer_a.dilation)
         return torch.relu(y) if relu else y
     li = st.index[key]
     y, st.token = _ConvDeferred.apply(x, st.token, *st.weights(li), st, li, relu)

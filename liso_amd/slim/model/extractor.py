@@ -99,7 +99,7 @@ class SmallEncoder(nn.Module):
     def _fold_inference(self, x):
         from liso_amd.utils import mfma_conv as MC
 
-        if torch.is_grad_enabled() or not x.is_cuda or x.dtype != torch.float32 or MC.backend() != "mfma":
+        if torch.is_grad_enabled() or not x.is_cuda or x.dtype != torch.float32:
             return False
         if not getattr(self, "fold_inference", True) or MC._norm_kind(self.norm1) is None:
             return False

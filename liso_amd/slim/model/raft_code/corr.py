@@ -69,7 +69,7 @@ def _own_gemms(fmap1, dvol, levels):
     from liso_amd.utils import mfma_conv as MC
 
     B, hw, D = fmap1.shape
-    if not fmap1.is_cuda or MC.backend() != "mfma" or fmap1.dtype != torch.float32 or D % 4 or hw % 32:
+    if not fmap1.is_cuda or fmap1.dtype != torch.float32 or D % 4 or hw % 32:
         return None
     if os.environ.get("LISO_CORR_OWN_GEMM", "0") != "1":
         # measured on the SLIM step (120k points, 512^2): 15.6 ms with these launches vs 14.8 ms with the library's batched GEMMs --

@@ -102,7 +102,7 @@ class SmallUpdateBlock(nn.Module):
         concatenations of reference :29-37,84-96,139-141 per iteration, and the gates update h in place.  None when not applicable."""
         from liso_amd.utils import mfma_conv as MC
 
-        if (torch.is_grad_enabled() or not net.is_cuda or MC.backend() != "mfma" or net.dtype != torch.float32 or not self.predict_logits
+        if (torch.is_grad_enabled() or not net.is_cuda or net.dtype != torch.float32 or not self.predict_logits
                 or self.cfg.model.predict_weight_for_static_aggregation or os.environ.get("LISO_UPDATE_SLICES", "1") == "0"):
             return None
         me, gru = self.motion_encoder, self.gru

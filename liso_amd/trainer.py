@@ -124,18 +124,14 @@ class DetectorTrainer:
         from liso_amd.utils import mfma_conv as MC
         if exact is not None:
             MC.set_fp32_mode("exact" if exact else "x3")
-        if self.use_graph and (not self.fused_loss or MC.backend() != "mfma"):
-            # only the fused loss + own convolutions keep the captured region free of hipMemsetAsync nodes (graph_safety.py):
-            # torch's multi-block reductions (centerpoint_loss, ATen / MIOpen backward) put them into the graph
+        if self.use_graph and not self.fused_loss:
+            # only the fused loss keeps the captured region free of hipMemsetAsync nodes (graph_safety.py): torch's multi-block
+            # reductions (centerpoint_loss) put them into the graph
             from liso_amd.utils.graph_safety import require_node_replay
 
-            require_node_replay("DetectorTrainer(use_graph=True) without the fused loss / with LISO_CONV_BACKEND=miopen")
-        if compute_dtype != torch.float32 and MC.backend() != "mfma":
-            # (MIOpen comparison path only: its NHWC kernels want channels-last filters.  The own kernels pack their panels from
-            # the contiguous fp32 master weights: channels-last parameters would cost a layout copy per pack and strided
-            # gradient accumulations -- ~170 extra launches per step, measured)
-            self.net.model.rpn.to(memory_format=torch.channels_last)
-            self.net.model.center_head.to(memory_format=torch.channels_last)
+            require_node_replay("DetectorTrainer(use_graph=True) without the fused loss")
+        # (the filters stay contiguous fp32 master weights: the kernels pack their panels from them; channels-last parameters would
+        # cost a layout copy per pack and strided gradient accumulations -- ~170 extra launches per step, measured)
         self.model = self.net
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         # on the GPU the parameters, their gradients and the AdamW moments are views into four flat buffers: the update is one
@@ -168,7 +164,7 @@ class DetectorTrainer:
         rpn = self.net.model.rpn
         if grad_buckets is None:
             grad_buckets = int(os.environ.get("LISO_GRAD_BUCKETS", "2"))
-        if grad_buckets < 2 or len(rpn.blocks) < 2 or not hasattr(self.optimizer, "offsets") or MC.backend() != "mfma":
+        if grad_buckets < 2 or len(rpn.blocks) < 2 or not hasattr(self.optimizer, "offsets"):
             return
         first = next(rpn.blocks[1].parameters())
         split = self.optimizer.offsets[id(first)]
@@ -858,6 +854,7 @@ class LisoLoopTrainer:
         self.infer_batch, self.flow_ahead = int(infer_batch), int(flow_ahead)
         self.box_capacity, self.capacity_overflows = int(cfg.data.tracking_cfg.setdefault("flow_cluster_capacity", 64)), 0
         self._flow_stream, self._mine_stream, self._main_used_static = None, None, None
+        self._inputs_ready = None  # event on the caller's stream at the head of a step: the side streams' reads of `upcoming` wait on it
         self._flows, self._mined = [], []
         self.slim = SLIM(cfg, num_train_samples=1000).to(device)
         if slim_state_dict is not None:
@@ -1221,6 +1218,8 @@ class LisoLoopTrainer:
         """SLIM inference of one or several pairs in ONE batch (same shapes): every convolution of the replay then works on that many
         times the pixels -- at batch 1 they launch 100-200 blocks on 256 CUs"""
         side = self._flow_stream
+        if self._inputs_ready is not None:
+            side.wait_event(self._inputs_ready)
         if self._main_used_static is not None:  # the static inference buffers were last used on the caller's stream
             side.wait_event(self._main_used_static)
             self._main_used_static = None
@@ -1283,6 +1282,8 @@ class LisoLoopTrainer:
         side = self._mine_streams[self._mine_turn % len(self._mine_streams)]
         self._mine_turn += 1
         side.wait_event(f.done)
+        if self._inputs_ready is not None:
+            side.wait_event(self._inputs_ready)
         with torch.cuda.stream(side):
             f.flow.record_stream(side)
             # fixed number of box slots: the host only enqueues (no box-count reads).  The cluster count goes to pinned memory
@@ -1337,6 +1338,12 @@ class LisoLoopTrainer:
         `upcoming`: the pairs of the following calls in order (flat list); the pipeline keeps stage B two batches ahead."""
         cuda = self.device.type == "cuda"
         cur = torch.cuda.current_stream(self.device) if cuda else None
+        if cuda and self.overlap:
+            # whatever the caller enqueued on ITS stream before this call (host -> device uploads of the announced clouds, a device-side
+            # data pipeline) is ordered in front of the side streams' reads of `upcoming`: an event recorded here, BEFORE this step's
+            # detector work, so that the side streams do not queue behind that work (a wait_stream at their point of use would)
+            self._inputs_ready = torch.cuda.Event()
+            self._inputs_ready.record(cur)
         mined = []
         for pair in pairs:
             sample_t0, sample_t1 = pair
@@ -1384,6 +1391,7 @@ class LisoLoopTrainer:
             # pipeline's critical path, and these launches sat at the head of every step of it
             nxt = [c for p_ in upcoming[:len(pairs)] for c in p_[0]["pcl_full_no_ground_ta"]]
             side = self._mine_stream
+            side.wait_event(self._inputs_ready)
             with torch.cuda.stream(side):
                 got_prep = self.detector.net.model.pfn.prepare(nxt)
                 done = torch.cuda.Event()

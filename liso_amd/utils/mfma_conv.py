@@ -20,9 +20,15 @@ import torch
 from liso_amd import _lib as L
 
 
-def backend():
-    """'mfma' (default) or 'miopen' (LISO_CONV_BACKEND=miopen: comparison runs through torch's convolution)"""
-    return os.environ.get("LISO_CONV_BACKEND", "mfma")
+def on_device(x):
+    """True: `x` is a GPU tensor and goes through the own kernels -- and only through them: a device tensor in a dtype they do not
+    take raises here instead of reaching a library.  False: a HOST tensor (the CPU test tier steps the modules through
+    liso_amd/utils/host_ops.py)."""
+    if not x.is_cuda:
+        return False
+    if x.dtype not in (torch.bfloat16, torch.float32):
+        raise TypeError(f"liso_amd: device convolutions take bfloat16 / float32 tensors, got {x.dtype}")
+    return True
 
 
 class ConvSpec:
@@ -1196,7 +1202,7 @@ class _AddRelu(torch.autograd.Function):
 
 
 def add_relu(a, b):
-    if (a.is_cuda and backend() == "mfma" and a.dtype == torch.float32 and b.dtype == torch.float32 and a.shape == b.shape and a.dim() == 4
+    if (a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.shape == b.shape and a.dim() == 4
             and a.shape[1] % 4 == 0):
         return _AddRelu.apply(a, b)
     return torch.relu(a + b)
@@ -1272,13 +1278,13 @@ class GradCut:
 
 
 def conv2d(layer, x, relu=False, occupancy=None, out=None):
-    """relu?(layer(x)) for an nn.Conv2d / nn.ConvTranspose2d on the own kernels (torch's convolution when the geometry or the
-    device is not covered: CPU tensors in host-logic tests, 2-3 input channels).  `occupancy`: fp32 [B,1,H,W] / [B,H,W] map with 0
+    """relu?(layer(x)) for an nn.Conv2d / nn.ConvTranspose2d on the own kernels (host tensors -- the CPU test tier -- through
+    host_ops; a device tensor whose geometry the kernels do not cover raises).  `occupancy`: fp32 [B,1,H,W] / [B,H,W] map with 0
     where x is zero in every channel (the pillar canvas): empty tiles are skipped forward, the weight gradient walks occupied cells"""
     spec = ConvSpec.of(layer)
-    if x.is_cuda and backend() == "mfma" and supported(x, layer.weight, spec):
+    if on_device(x) and supported(x, layer.weight, spec):
         return fused_conv(x, None, layer, out_relu=relu, spec=spec, occupancy=occupancy if x.dtype == torch.float32 else None, out=out)[0]
-    if x.is_cuda and backend() == "mfma" and x.dtype in (torch.bfloat16, torch.float32) and not spec.transposed:
+    if x.is_cuda and not spec.transposed:
         # 1-3 (7) input channels -- the motion encoder's conv_flow1: 7x7 on the 2-channel flow, liso/slim/model/update.py:53-60 --
         # the kernels read channels in 16-B groups: zero channels (and zero filter slices) up to one group, then the own kernel
         vec = 8 if x.dtype == torch.bfloat16 else 4
@@ -1295,6 +1301,11 @@ def conv2d(layer, x, relu=False, occupancy=None, out=None):
         if supported(xp, wp, spec):
             import types
             return fused_conv(xp, None, types.SimpleNamespace(weight=wp, bias=layer.bias), out_relu=relu, spec=spec, out=out)[0]
+    if x.is_cuda:
+        raise NotImplementedError(f"liso_amd: no device kernel for {type(layer).__name__} {tuple(layer.weight.shape)} stride {spec.stride} "
+                                  f"padding {spec.padding} on {tuple(x.shape)} {x.dtype}")
     assert out is None, "conv2d(out=...): only on the own kernels"
-    y = layer(x)
+    from liso_amd.utils import host_ops
+
+    y = host_ops.module_forward(layer, x)
     return torch.relu(y) if relu else y

@@ -284,7 +284,7 @@ def test_rpn_head_on_gpu_match_reference_fixture(golden_dir, fmode):
                 assert bulk(got, g[key]) <= lim_bulk and _rel(got, torch.from_numpy(g[key])) <= lim_worst, \
                     (fmode, key, bulk(got, g[key]), _rel(got, torch.from_numpy(g[key])))
             # (the fixture's upstream gradient sums to ~0 over the map: this bias gradient is pure rounding, |g| = 3e-4)
-            assert abs(float(head.tasks[0].probs[3].bias.grad) - float(g["train_grad_head_probs_3_bias"])) <= 2e-3
+            assert abs(head.tasks[0].probs[3].bias.grad.reshape(-1)[0].item() - float(np.asarray(g["train_grad_head_probs_3_bias"]).reshape(-1)[0])) <= 2e-3
             assert _rel(rpn.blocks[0][2].running_mean, torch.from_numpy(g["train_rm_after_rpn_blocks_0_2"])) <= 1e-3
     MC.set_fp32_mode(prev_mode)
 

@@ -131,6 +131,49 @@ def test_dbscan_labels_match_sklearn_and_regionprops(G, n_blobs, noise, seed):
             np.testing.assert_allclose(props[b, :rp.shape[0]], rp, rtol=1e-9, atol=1e-9)
 
 
+def _chains(seed, G, n_chains):
+    """thin, branching, zig-zag components whose cells' roots are NOT ordered along the walk (anti-diagonals, combs, random walks that
+    turn back): the shapes on which a union that re-parents a non-root can cut a tree off"""
+    g = np.random.default_rng(seed)
+    mask = np.zeros((G, G), bool)
+    for _ in range(n_chains):
+        r, c = g.integers(4, G - 4, 2)
+        kind = g.integers(0, 3)
+        for step in range(int(g.integers(10, 60))):
+            mask[r, c] = True
+            if kind == 0:  # anti-diagonal staircase: row index falls while the column rises
+                r, c = r - (step & 1), c + 1
+            elif kind == 1:  # comb: a spine with teeth pointing to SMALLER rows
+                mask[max(r - 2, 0):r, c] = step % 2 == 0
+                c += 1
+            else:  # random walk with steps of up to 2 cells (gaps that only the window bridges)
+                r, c = r + int(g.integers(-2, 3)), c + int(g.integers(-2, 3))
+            r, c = int(np.clip(r, 0, G - 1)), int(np.clip(c, 0, G - 1))
+    flow = np.zeros((G, G, 3), np.float32)
+    flow[mask] = g.normal(0, 0.02, (int(mask.sum()), 3)).astype(np.float32)
+    return mask, flow
+
+
+@pytest.mark.parametrize("G,pitch,min_samples,seed", [(96, 0.6, 2, 0), (128, 0.45, 3, 1), (200, 0.3, 3, 2), (64, 0.95, 2, 3)])
+def test_dbscan_chain_shaped_clusters_match_sklearn(G, pitch, min_samples, seed):
+    """the LDS union-find of dbscan_union_tiled_kernel on thin chains with small windows (eps / pitch = 1..3 cells): a failed hook has
+    to go on with the displaced parent, or a sub-tree is silently cut off (round-5 advisor finding; the blob fixtures never hit it)"""
+    from liso_amd.networks.flow_cluster_detector.flow_cluster_detector import cluster_dynamic_pillars
+    from oracle.flow_cluster import dbscan_bev_labels
+
+    ax = ((np.arange(G) - G / 2 + 0.5) * pitch).astype(np.float32)
+    centers = np.stack(np.meshgrid(ax, ax, indexing="ij"), -1)
+    masks, flows = zip(*[_chains(seed * 7 + b, G, 40) for b in range(3)])
+    mask_t, flow_t = torch.from_numpy(np.stack(masks)).cuda(), torch.from_numpy(np.stack(flows)).cuda()
+    xs, ys = torch.from_numpy(ax).cuda(), torch.from_numpy(ax).cuda()
+    refs = [dbscan_bev_labels(masks[b], flows[b], centers, eps=1.0, min_samples=min_samples) for b in range(3)]
+    for _ in range(5):  # (the lost union was a race: several runs)
+        labels, num = cluster_dynamic_pillars(mask_t, flow_t, xs, ys, eps=1.0, min_samples=min_samples, pitch=pitch)
+        for b in range(3):
+            assert int(num[b]) == int(refs[b].max())
+            assert np.array_equal(labels[b].cpu().numpy(), refs[b])
+
+
 def test_flow_cluster_detector_matches_oracle_and_finds_movers():
     """FlowClusterDetector.forward (flow_cluster_detector.py:87-336) end to end on two synthetic 120k-point sweeps:
     same boxes as the CPU restatement (positions/dims exact to fp32 round-off, heading/velocity <= 1e-3), and the
