@@ -82,6 +82,10 @@ def parse():
     ap.add_argument("--uniform-clouds", action="store_true",
                     help="loop workload: every sweep with exactly 120000 loss-cloud points (default: 16 pairs of 116k-124k points, mean 120k, "
                          "so that the bucket padding and the per-signature graph caches are exercised as on real sweeps)")
+    ap.add_argument("--loader", action="store_true",
+                    help="loop workload: the sweep pairs live in PINNED HOST memory and are uploaded (H2D on a copy stream, one step before "
+                         "they enter the pipeline's announcement window) as a DataLoader-fed run would (liso_cli.py:362-380); default: all "
+                         "pairs resident in HBM (the `value` of the line)")
     ap.add_argument("--graph", action="store_true",
                     help="slim workload: replay forward+loss+backward from a hipGraph (host-independent step time)")
     ap.add_argument("--eager", action="store_true",
@@ -95,6 +99,13 @@ def spawn_ranks(args):
     process (never exec from a process that has initialised HIP) and exit with the worst of their codes."""
     import socket
 
+    if os.environ.get("LISO_DIST_BACKEND", "nccl") == "nccl":
+        import torch  # (counting devices does not initialise HIP in this process)
+
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            sys.exit(f"bench.py: --gpus {args.gpus} but this node shows {have} GPU(s); RCCL wants one device per rank "
+                     "(LISO_DIST_BACKEND=gloo shares devices between ranks: test mode only)")
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -314,6 +325,14 @@ def bench_iou3d(dev, torch, with_cpu=True):
             num = M.nms_gpu(tb, keep, 0.1)
             row.update({"cpu_oracle_nms_boxes_per_s": n / t_cpu_nms, "cpu_oracle_iou_pairs_per_s": m * m / t_cpu_iou,
                         "cpu_cores": 1, "keep_identical_to_oracle": bool(np.array_equal(keep[:num].numpy(), ref_keep))})
+            # the UNMODIFIED reference TU (iou3d_cpu.cpp compiled by oracle/Makefile into oracle/_ref) when its .so travelled with the
+            # tree: the reference's own CPU path timed beside the restatement, same boxes, same bounded sample, one core
+            t0 = time.perf_counter()
+            ref_mat = O.ref_boxes_iou_bev(b[:m], b[:m])
+            t_ref = time.perf_counter() - t0
+            if ref_mat is not None:
+                row.update({"cpu_reference_iou_pairs_per_s": m * m / t_ref, "cpu_reference_kind": "reference",
+                            "cpu_reference_sample": f"boxes_iou_bev_cpu of the compiled reference TU on {m} x {m} boxes, {t_ref:.3f} s"})
         out["sizes"][str(n)] = row
     return out
 
@@ -350,6 +369,98 @@ def child_leg(extra, steps=10, warmup=3, timeout_s=420):
     return out
 
 
+class PinnedLoader:
+    """`--loader` ("separately with a pinned-memory loader"; the reference feeds its step from DataLoader workers,
+    liso_cli.py:362-380): the ring of sweep pairs lives in PINNED HOST memory.  Every step uploads the pairs that enter the pipeline's
+    announcement window at the NEXT step -- fresh device tensors, H2D copies on a copy stream -- and the step that first announces them
+    waits for that upload's event on its own stream (the trainer orders its side streams behind the head of the step).  Device
+    tensors of a pair are dropped once its detector step is enqueued.  Nothing of a pair is resident before its upload."""
+
+    def __init__(self, pairs, dev, torch):
+        self.torch, self.dev = torch, dev
+        self.host = [tuple(self._map(smp, lambda t: t.detach().cpu().pin_memory()) for smp in pair) for pair in pairs]
+        self.bytes_per_pair = [sum(self._leaf_bytes(smp) for smp in pair) for pair in self.host]
+        self.copy_stream = torch.cuda.Stream(device=dev)
+        self.window, self.pending, self.uploaded_bytes, self.uploads = {}, None, 0, 0
+
+    @classmethod
+    def _map(cls, obj, fn):
+        import torch
+
+        if torch.is_tensor(obj):
+            return fn(obj)
+        if isinstance(obj, dict):
+            return {k: cls._map(v, fn) for k, v in obj.items()}
+        if isinstance(obj, (list, tuple)):
+            return type(obj)(cls._map(v, fn) for v in obj)
+        return obj
+
+    @classmethod
+    def _leaf_bytes(cls, obj):
+        tot = [0]
+        cls._map(obj, lambda t: tot.__setitem__(0, tot[0] + t.numel() * t.element_size()) or t)
+        return tot[0]
+
+    def _upload(self, indices):
+        """device copies of ring entries `indices` (absolute pair numbers): allocated on the caller's stream, filled on the copy stream
+        behind an event of the caller's stream (a block the allocator hands out may still be read by work queued there)"""
+        torch = self.torch
+        cur = torch.cuda.current_stream(self.dev)
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        self.copy_stream.wait_event(ready)
+        got = {}
+        for j in indices:
+            hp = self.host[j % len(self.host)]
+            dst = tuple(self._map(smp, lambda t: torch.empty(t.shape, dtype=t.dtype, device=self.dev)) for smp in hp)
+            with torch.cuda.stream(self.copy_stream):
+                def fill(d, h):
+                    if torch.is_tensor(d):
+                        d.copy_(h, non_blocking=True)
+                    elif isinstance(d, dict):
+                        for k in d:
+                            fill(d[k], h[k])
+                    elif isinstance(d, (list, tuple)):
+                        for a, b in zip(d, h):
+                            fill(a, b)
+                for d, h in zip(dst, hp):
+                    fill(d, h)
+            got[j] = dst
+            self.uploaded_bytes += self.bytes_per_pair[j % len(self.host)]
+            self.uploads += 1
+        done = torch.cuda.Event()
+        done.record(self.copy_stream)
+        return got, done
+
+    def stepper(self, trainer, batch, n_up):
+        torch = self.torch
+
+        def step():
+            cur = torch.cuda.current_stream(self.dev)
+            i = step.count * batch
+            step.count += 1
+            need = range(i, i + batch + n_up)
+            if self.pending is not None:  # uploaded during the previous step
+                got, done = self.pending
+                cur.wait_event(done)
+                self.window.update(got)
+                self.pending = None
+            missing = [j for j in need if j not in self.window]
+            if missing:  # (first step only: nothing was announced before it)
+                got, done = self._upload(missing)
+                cur.wait_event(done)
+                self.window.update(got)
+            self.pending = self._upload(range(i + batch + n_up, i + 2 * batch + n_up))  # enters the window at the next step
+            loss = trainer.step_batch([self.window[j] for j in range(i, i + batch)],
+                                      upcoming=tuple(self.window[j] for j in range(i + batch, i + batch + n_up)))
+            for j in range(i, i + batch):
+                del self.window[j]
+            return loss
+
+        step.count = 0
+        return step
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 def main():
     args = parse()
@@ -362,6 +473,7 @@ def main():
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
+    ranks_seen = 1
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("LISO_DIST_BACKEND", "nccl") != "nccl":
         local_rank = local_rank % max(torch.cuda.device_count(), 1)  # (test mode: ranks share the GPUs that exist)
@@ -374,9 +486,15 @@ def main():
         # RCCL refuses two ranks on one device) -- never used for a reported number.
         backend = os.environ.get("LISO_DIST_BACKEND", "nccl")
         if backend == "nccl":
+            assert torch.cuda.device_count() >= world, f"{world} ranks on {torch.cuda.device_count()} GPU(s): RCCL wants one device per rank"
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
             dist.init_process_group(backend=backend)
+        # what the process group REALLY spans: every rank adds a one (a scaling record must show `ranks_seen` == n_gpus)
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
+        assert ranks_seen == world, f"process group of {ranks_seen} ranks, expected {world}"
 
     from liso_amd import _lib as L
     from liso_amd.utils.config import apply_slim_simple_knn_training, default_cfg
@@ -400,16 +518,20 @@ def main():
         N_POINTS, GRID = 300000, 1024
     cfg = default_cfg(grid=GRID, bev_range_m=BEV_RANGE)
     torch.manual_seed(0)  # identical initial weights on every rank (DDP also broadcasts them)
-    s0 = s1 = pcls = targets = None
+    s0 = s1 = pcls = targets = loader = None
+    slim_exact = False
     overlap = False
     if args.workload == "slim":
         from liso_amd.datasets.synthetic import slim_pair
         from liso_amd.trainer import SlimTrainer
 
-        args.dtype = "fp32"  # the reference trains SLIM in fp32 (no autocast in slim/experiment.py)
+        # the reference trains SLIM in fp32 (no autocast in slim/experiment.py): fp32 tensors; --dtype fp32 = every convolution on the
+        # native fp32 MFMA (`slim_exact_leg`), default = three bf16 MFMAs per product (F32X3)
+        slim_exact = args.dtype == "fp32"
+        args.dtype = "fp32"
         batch = 1
         cfg = apply_slim_simple_knn_training(cfg)
-        trainer = SlimTrainer(cfg, dev, use_graph=args.graph)
+        trainer = SlimTrainer(cfg, dev, use_graph=args.graph, exact=slim_exact)
         s0, s1 = slim_pair(2 + rank, dev, n_points=N_POINTS, grid=GRID, bev_range_m=BEV_RANGE)
         step = lambda: trainer.step(s0, s1)  # noqa: E731
         frames_per_step = 2 * batch
@@ -443,6 +565,12 @@ def main():
             counter[0] += 1
             return trainer.step_batch([pairs[(i + k) % len(pairs)] for k in range(batch)],
                                       upcoming=tuple(pairs[(i + k) % len(pairs)] for k in range(batch, batch + n_up)))
+
+        if args.loader:
+            loader = PinnedLoader(pairs, dev, torch)
+            step = loader.stepper(trainer, batch, n_up)  # noqa: E731
+            pairs = pairs[:max(batch, trainer.infer_batch)]  # (the resident copies go; these few serve the eager event passes behind the timed region)
+            torch.cuda.empty_cache()
 
         frames_per_step = 2 * batch
     else:
@@ -480,7 +608,7 @@ def main():
             print(graph_note, file=sys.stderr, flush=True)
             args.graph = False
             torch.manual_seed(0)
-            trainer = SlimTrainer(cfg, dev, use_graph=False)
+            trainer = SlimTrainer(cfg, dev, use_graph=False, exact=slim_exact)
             step = lambda: trainer.step(s0, s1)  # noqa: E731
     main_stream = None
     if os.environ.get("LISO_MAIN_PRIORITY"):  # experiment: the detector step's stream above the SLIM inference stream
@@ -500,13 +628,55 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    # one event per step boundary on the caller's stream (no synchronisation, ~1 us each): the distribution of the step times next to
+    # the mean that `value` is made of.  In the pipelined loop a boundary is where the detector step of that batch ends on its stream.
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for k in range(args.steps):
         loss = step()
+        marks[k + 1].record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    step_ms = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps))
+    step_times = {"median_ms": step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2]),
+                  "p90_ms": step_ms[min(len(step_ms) - 1, int(0.9 * len(step_ms)))], "min_ms": step_ms[0], "max_ms": step_ms[-1],
+                  "mean_ms_events": sum(step_ms) / len(step_ms),
+                  "timing": f"{args.steps} hipEvent pairs on the caller's stream, one per step (ms_per_step = wall clock over the same steps between "
+                            "two synchronisations)"} if step_ms else None
+    # data parallelism: what the gradient all-reduce COSTS a step, measured: the same steps once more with the collective skipped (the
+    # replicas diverge from here on: the parameter checksums below were taken first), and the collective alone on an idle GPU
+    dist_cost = None
+    if world > 1:
+        det = getattr(trainer, "detector", trainer)
+        cs_early = torch.stack([p.detach().double().sum() for p in det.net.parameters()]).sum().reshape(1)
+        if hasattr(det, "_reduce_gradients") and det.use_graph:
+            det.skip_collective = True
+            dist.barrier()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            dist.barrier()
+            t_nocomm = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+            dist.all_reduce(t_nocomm, op=dist.ReduceOp.MAX)
+            det.skip_collective = False
+            buf = det._flat_grad
+            torch.cuda.synchronize()
+            dist.barrier()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(10):
+                dist.all_reduce(buf)
+            b.record()
+            torch.cuda.synchronize()
+            dist_cost = {"ms_per_step_without_collective": 1e3 * float(t_nocomm.item()) / args.steps,
+                         "allreduce_alone_ms": a.elapsed_time(b) / 10, "allreduce_bytes": buf.numel() * buf.element_size(),
+                         "note": "exposed all-reduce time per step = ms_per_step - ms_per_step_without_collective (same steps, collective skipped, "
+                                 "MAX over ranks); allreduce_alone_ms = the flat gradient buffer all-reduced 10 times on an otherwise idle GPU"}
     timed_in, event_steps = "the timed steps", args.steps
     if graphed:
         # the timed steps replay a hipGraph, inside which per-kernel events cannot be recorded: the same kernels are timed
@@ -555,9 +725,14 @@ def main():
     if args.workload == "loop" and args.dtype == "bf16" and world == 1 and rank == 0 and not args.no_legs:
         # BASELINE configs[1] / [2] / [4] as bounded legs: this script with --workload slim | detector | stress in a child process
         # (the SLIM training graph needs another runtime mode, see _graph_env), its JSON line trimmed to the numbers
-        for name, extra in (("slim_leg", ["--workload", "slim", "--graph"]), ("detector_leg", ["--workload", "detector"]),
-                            ("stress_leg", ["--workload", "stress"])):
+        for name, extra in (("slim_leg", ["--workload", "slim", "--graph"]), ("slim_exact_leg", ["--workload", "slim", "--graph", "--dtype", "fp32"]),
+                            ("detector_leg", ["--workload", "detector"]), ("stress_leg", ["--workload", "stress"])):
             legs[name] = child_leg(extra, steps=min(args.steps, 10))
+        # SURVEY 8d's second measurement mode: the same loop fed from pinned host memory (H2D on a copy stream), child process
+        legs["loader_leg"] = child_leg(["--loader"], steps=min(args.steps, 20), warmup=2 + 16 // max(batch, 1))
+        if "error" not in legs["loader_leg"]:
+            legs["loader_leg"]["note"] = ("the headline's iteration with the sweep pairs in PINNED HOST memory, uploaded one step before they enter "
+                                          "the pipeline (bench.py PinnedLoader); `value` of the line itself has every pair resident in HBM")
     export_cost = None
     if args.workload == "loop" and world == 1 and rank == 0 and not args.no_legs:
         # what a flow EXPORT costs next to the loop's inference (the miner reads flow t0 -> t1 only; liso/slim/experiment.py:363-471
@@ -582,8 +757,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         # data parallelism keeps the replicas identical: every rank's parameter checksum travels to rank 0 and into the line
-        net = trainer.detector.net if args.workload == "loop" else trainer.net
-        cs = torch.stack([p.detach().double().sum() for p in net.parameters()]).sum().reshape(1)
+        cs = cs_early  # (taken right behind the timed steps, before the collective-free steps of `dist_cost`)
         got = [torch.zeros_like(cs) for _ in range(world)]
         dist.all_gather(got, cs)
         checksums = [float(g.item()) for g in got]
@@ -644,7 +818,7 @@ def main():
             "dtype": ("bf16 (detector, BASELINE configs[2]) + f32 via bf16x3 MFMA (SLIM); north_star's 1e-3 on logits / flow is met by "
                       "`parity_leg` (f32 via bf16x3 MFMA everywhere) and `fp32_exact_leg`, not by the bf16 detector"
                       if args.workload == "loop" and args.dtype == "bf16" else
-                      "f32 (exact: native fp32 MFMA v_mfma_f32_32x32x2_f32)" if args.dtype == "fp32" and args.workload != "slim" else
+                      "f32 (exact: native fp32 MFMA v_mfma_f32_32x32x2_f32)" if args.dtype == "fp32" and (args.workload != "slim" or slim_exact) else
                       "f32 via bf16x3 MFMA" if args.workload == "slim" or args.dtype == "f32x3" else
                       "bf16 (BASELINE configs[4] names fp16: the same MFMA rate and storage width; the kernels take bf16 / fp32 tensors only)"
                       if args.workload == "stress" and args.dtype == "bf16" else args.dtype),
@@ -652,12 +826,13 @@ def main():
             "config": {"workload": workload, "points_per_cloud": N_POINTS, "bev_grid": GRID, "batch_per_gpu": batch,
                        "frames_per_step_per_gpu": frames_per_step, "parallelism": f"dp{world}",
                        # what the process group really looked like (a multi-GPU record shows that RCCL saw `world` ranks)
-                       "dist": {"world_size": dist.get_world_size() if world > 1 else 1,
+                       "dist": {"world_size": dist.get_world_size() if world > 1 else 1, "ranks_seen": ranks_seen,
+                                "devices_visible": torch.cuda.device_count(),
                                 "backend": dist.get_backend() if world > 1 else None,
                                 "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if world > 1 and
                                 os.environ.get("LISO_DIST_BACKEND", "nccl") == "nccl" else None,
                                 "gradient_buckets": getattr(getattr(trainer, "detector", trainer), "n_grad_buckets", 1)},
-                       **({"points_per_cloud_ring": [min(counts), max(counts)], "sweep_pairs_in_rotation": len(pairs),
+                       **({"points_per_cloud_ring": [min(counts), max(counts)], "sweep_pairs_in_rotation": n_pairs,
                            "point_bucket_rows": trainer.infer_point_bucket,
                            "graph_captures": {"inference": len(trainer._infer_graphs), "box_mining": trainer.mine_captures,
                                               "inside_timed_region": (len(trainer._infer_graphs) - captures_after_warmup[0]) +
@@ -675,6 +850,7 @@ def main():
                        "sparse_canvas_convolutions": {"enabled": os.environ.get("LISO_SPARSE_STEM", "1") != "0",
                                                       "cell_capacity_exceeded": _sparse_overflow(dev)}},
             "final_loss": float(loss),
+            "step_times": step_times,
             "roofline": {"kernel": kname, "bound": bound, "achieved": achieved, "peak": peak, "unit": runit,
                          "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_ms": 1e3 * t_total / n_launch,
@@ -689,6 +865,30 @@ def main():
                          "timed_kernels_ms_per_step": {k: round(v / max(event_steps, 1), 4) for k, v in
                                                        sorted(per_unit.items(), key=lambda kv: -kv[1])}},
         }
+        # the WHOLE step against the matrix-core roofline: algorithmic flops of every convolution launch of a step (counted at the call
+        # sites, 2 * M * N * K of the implicit GEMM; launches that serve several steps weighted by their share) / the time those flops
+        # take at the peak of the arithmetic they run in, over the measured step time.  The HBM-bound stages add nothing to the
+        # numerator: this is "how much of the step's time is accounted for by matrix math at peak".
+        def _peak_tf(k):
+            return MFMA_PEAK_BF16_TF / 3.0 if "f32x3" in k else VALU_PEAK_F32_TF if k.startswith("conv_f32_") else MFMA_PEAK_BF16_TF
+        conv_keys = [k for k in durs if KERNELS.get(k, ("", "", ""))[1] == "mfma" and len(L.TIMER.units.get(k, [])) == len(durs[k])]
+        flops_by = {k: sum(u * w for u, w in zip(L.TIMER.units[k], L.TIMER.weights.get(k, [1.0] * len(durs[k])))) / max(event_steps, 1)
+                    for k in conv_keys}
+        at_peak_ms = sum(1e3 * f / (_peak_tf(k) * 1e12) for k, f in flops_by.items())
+        line["step_roofline"] = {"bound": "mfma", "algorithmic_flop_per_step": sum(flops_by.values()),
+                                 "time_at_peak_ms": at_peak_ms, "ms_per_step": 1e3 * elapsed / args.steps,
+                                 "frac": at_peak_ms / (1e3 * elapsed / args.steps),
+                                 "peaks_tflops": {"bf16": MFMA_PEAK_BF16_TF, "f32 via bf16x3": MFMA_PEAK_BF16_TF / 3.0, "f32 exact": VALU_PEAK_F32_TF},
+                                 "flop_by_family": {k: v for k, v in sorted(flops_by.items(), key=lambda kv: -kv[1])},
+                                 "note": "sum over the step's convolution launches of flops / peak(arithmetic) divided by the measured step time"}
+        if loader is not None:
+            line["loader"] = {"pinned_host_pairs": len(loader.host), "uploads": loader.uploads, "h2d_bytes_total": loader.uploaded_bytes,
+                              "h2d_bytes_per_step": loader.uploaded_bytes / max(loader.uploads, 1) * batch,
+                              "copy": "torch non_blocking copies from pinned memory on a dedicated copy stream, issued one step ahead"}
+            line["config"]["workload"] += " -- sweep pairs fed from PINNED HOST memory (--loader)"
+        if dist_cost is not None:
+            dist_cost["exposed_allreduce_ms_per_step"] = line["ms_per_step"] - dist_cost["ms_per_step_without_collective"]
+            line["dist_cost"] = dist_cost
         if "pfn_forward_scatter" in totals:
             # the pillar path as its own HBM roofline: decorate (+ scans) and forward launches timed together over the event passes;
             # algorithmic bytes = points read once + dense canvas + occupancy written once

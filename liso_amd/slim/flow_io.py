@@ -96,3 +96,41 @@ def add_flow_to_sample(sample_content, pred_content, flow_source, src_key="ta", 
         sample_content[flow_source][f"flow_{a}_{b}"] = point_flow_from_bev(
             sample_content[f"pcl_{a}"], pred_content[f"bev_raw_flow_{fa}_{fb}"], rng)
     return sample_content
+
+
+def shard_of(sample_idx, world_size=None, worker_id=None):
+    """does this rank export sample `sample_idx`?  liso/slim/experiment.py:330-332,351-353: `sample_idx % world_size == worker_id`,
+    no communication between the ranks (every rank walks the whole loader and skips the others' samples).  world_size / worker_id
+    default to the initialised torch.distributed process group (a single process exports everything)."""
+    if world_size is None or worker_id is None:
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized():
+            world_size, worker_id = dist.get_world_size(), dist.get_rank()
+        else:
+            world_size, worker_id = 1, 0
+    assert 0 <= worker_id < max(world_size, 1), (worker_id, world_size)
+    return world_size <= 1 or sample_idx % world_size == worker_id
+
+
+def export_flow_sharded(infer, loader, target_dir, static_threshold, bev_range_m, world_size=None, worker_id=None, skip_existing=False):
+    """The inference / export pass of experiment.py:323-361 + :363-471 for the (t0, t1) pairs: every rank walks `loader` -- an iterable
+    of (sample_id, sample_t0, sample_t1) -- and runs `infer(sample_t0, sample_t1) -> (preds_fw, preds_bw)` (e.g.
+    `SLIM.infer_export_predictions`: both flow directions, last RAFT iteration) on ITS samples only, writing
+    `target_dir / sample_id.npz` in the reference's format.  The path shards by sample: no collective on it, by construction the files
+    of N ranks are the files of one rank.  `static_threshold`: a value or a callable evaluated per sample (the model's
+    `moving_dynamicness_threshold.value`).  -> the files this rank wrote."""
+    target_dir = Path(target_dir)
+    written = []
+    with torch.no_grad():
+        for sample_idx, (sample_id, sample_t0, sample_t1) in enumerate(loader):
+            if not shard_of(sample_idx, world_size, worker_id):
+                continue
+            target_file = (target_dir / str(sample_id)).with_suffix(".npz")
+            if skip_existing and target_file.exists():
+                continue
+            preds_fw, preds_bw = infer(sample_t0, sample_t1)
+            thr = static_threshold() if callable(static_threshold) else static_threshold
+            save_flow_npz(target_file, flow_export_dict(preds_fw, preds_bw, thr, bev_range_m))
+            written.append(target_file)
+    return written

@@ -93,6 +93,8 @@ class _ParamGate(torch.autograd.Function):
             if res is not None:
                 gw, gb = res
             else:
+                if x.is_cuda:
+                    raise NotImplementedError(f"liso_amd: no device weight-gradient kernel for {tuple(w.shape)} on {tuple(x.shape)} {x.dtype}")
                 _, gw, gb = torch.ops.aten.convolution_backward(gy, x, w, [b.numel()], _pair(layer.stride), _pair(layer.padding),
                                                                 _pair(layer.dilation), False, [0, 0], 1, [False, True, True])
             if len(op) == 1:
@@ -120,11 +122,9 @@ class _ParamGate(torch.autograd.Function):
 def _own_kernels(x, w, layer):
     from liso_amd.utils import mfma_conv as MC
 
-    if not MC.on_device(x):
-        return False  # host tensor: CPU test tier
-    if not MC.supported(x, w, MC.ConvSpec.of(layer)):
-        raise NotImplementedError(f"liso_amd: no device kernel for the convolution {tuple(w.shape)} on {tuple(x.shape)} {x.dtype}")
-    return True
+    # (False on the device only for geometries that `conv2d` below hands to mfma_conv.conv2d -- the 2-channel conv_flow1, zero-padded to
+    # one 16-byte channel group there; host tensors: the CPU test tier, host_ops)
+    return MC.on_device(x) and MC.supported(x, w, MC.ConvSpec.of(layer))
 
 
 class _ConvDeferred(torch.autograd.Function):

@@ -180,6 +180,9 @@ class DetectorTrainer:
         """SUM all-reduce of the flat gradient buffer over the ranks (the mean's 1 / world is applied inside the AdamW launch).
         Called behind the replay of the (first) graph; `rest_of_backward()` = what is still to run: the second graph (two buckets)
         and the pillar encoder's eager backward."""
+        if getattr(self, "skip_collective", False):  # bench.py's measurement of the collective's exposed cost (replicas diverge)
+            rest_of_backward()
+            return
         if self.n_grad_buckets < 2:
             rest_of_backward()
             dist.all_reduce(self._flat_grad)

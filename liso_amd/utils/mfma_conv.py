@@ -874,8 +874,9 @@ class _FusedConv(torch.autograd.Function):
                 else:
                     res = conv_wgrad(x_raw, dy, tuple(weight.shape), spec, sc, sh, in_relu=fold.relu if fold is not None else False,
                                      want_bias=ctx.meta["has_bias"], out_dw=tw, out_db=tb, co_true=co_true)
-            if res is None:
-                dw, db = _aten_wgrad(x_raw, dy[:, :co_true], weight, spec, fold, ctx.meta["has_bias"])
+            if res is None:  # (none of the networks' layers; there is no library route for a device tensor)
+                raise NotImplementedError(f"liso_amd: no device weight-gradient kernel for {tuple(weight.shape)} stride {spec.stride} "
+                                          f"on {tuple(x_raw.shape)} {x_raw.dtype}")
             else:
                 dw, db = res
                 if tw is not None and dw is tw:  # written in place: nothing for autograd to accumulate
@@ -895,22 +896,6 @@ class _FusedConv(torch.autograd.Function):
             else:
                 dx = g
         return (dx, dw, db, None, *fold_grads)
-
-
-def _aten_wgrad(x_raw, dy, weight, spec, fold, has_bias):
-    """weight gradient through ATen for geometries the own kernel does not cover (none of the networks' layers)"""
-    x = x_raw
-    if fold is not None:
-        sc, sh = fold.scale_shift()
-        C = x_raw.shape[1]
-        x = x_raw.float() * sc.view(1, C, 1, 1) + sh.view(1, C, 1, 1)
-        x = torch.relu(x) if fold.relu else x
-        x = x.to(x_raw.dtype)
-    s, p = [spec.stride, spec.stride], [spec.padding, spec.padding]
-    co = weight.shape[1] if spec.transposed else weight.shape[0]
-    _, gw, gb = torch.ops.aten.convolution_backward(dy, x, weight.to(x.dtype), [co] if has_bias else None, s, p, [1, 1], spec.transposed,
-                                                    [0, 0], 1, [False, True, has_bias])
-    return gw.float(), (gb.float() if has_bias else None)
 
 
 def fused_conv(x_raw, fold, conv, out_bn=None, out_dtype=None, out_relu=False, spec=None, occupancy=None, out=None):
