@@ -43,16 +43,38 @@ int liso_corr_lookup_fwd_f32(const liso_corr_cfg* cfg, const float* fmap1, const
 int liso_corr_lookup_fwd_tiled_f32(const liso_corr_cfg* cfg, const float* fmap1, const float* const* fmap2_levels,
                                    const float* coords, float* out, void* stream);
 
+/* The pooled target pyramid fmap2_levels[1 .. levels-1] from fmap2 = level 0 ([B, h, w, D] channels last): level i =
+ * avg_pool2d(level i-1, 2, stride 2) with floor semantics (H_i = H_{i-1} / 2, an odd last row / column dropped).  The reference pools
+ * the correlation volume (corr.py:20-21); pooling is linear in fmap2, so the lookups are the same numbers.  One launch for all levels;
+ * levels[0] is not written (pass anything).  All pointers 16-byte aligned. */
+int liso_corr_pyramid_fwd_f32(const liso_corr_cfg* cfg, const float* fmap2, float* const* levels, void* stream);
+/* Its adjoint in one launch: grad_fmap2 = g_0 + up(g_1 + up(g_2 + ...) / 4) / 4 with g_i = grad_levels[i] ([B, H_i, W_i, D]; NULL =
+ * zeros) and up() the replication onto the 2 x 2 pixels each pooled pixel averaged.  grad_fmap2 [B, h, w, D] is overwritten. */
+int liso_corr_pyramid_bwd_f32(const liso_corr_cfg* cfg, const float* const* grad_levels, float* grad_fmap2, void* stream);
+
 /* Backward, step 1 of 2.  grad_out has the layout of `out`.  dvol_levels[i] is a dense fp32 matrix
  * [B, h*w, H_i*W_i] (zero-filled by the caller before the first call): the gradient with respect to the pooled
  * correlation volume of level i, into which this call ADDS the adjoint of its bilinear 7x7 windows (<= 64 entries per
  * row and level).  Every entry is owned by one lane, so the update is a plain read-modify-write: no atomics, bit
  * reproducible; calls for the RAFT iterations of one direction accumulate into the same matrices (they share fmap1 and
- * fmap2).  Step 2 is two plain GEMMs per level, run once per direction by the host:
- *     grad_fmap1 = sum_i dvol_i @ fmap2_i        grad_fmap2_i = dvol_i^T @ fmap1
- * (liso_amd/slim/model/raft_code/corr.py).  coords receive no gradient (detached per iteration, raft_mod.py:189). */
+ * fmap2).  Step 2, once per direction: liso_corr_bwd_features_f32 below.  coords receive no gradient (detached per iteration,
+ * raft_mod.py:189). */
 int liso_corr_lookup_bwd_dvol_f32(const liso_corr_cfg* cfg, const float* coords, const float* grad_out,
                                   float* const* dvol_levels, void* stream);
+
+/* Backward, step 2 of 2: the adjoint of corr = fmap1^T fmap2 / sqrt(D) (liso/slim/model/raft_code/corr.py:48-56; pooled per level,
+ * :20-21 -- the 1 / sqrt(D) is already inside dvol), once per flow direction:
+ *     grad_fmap1[b]         [h*w, D]     = sum_i  dvol_i[b] [h*w, H_i*W_i]   . fmap2_levels[i][b] [H_i*W_i, D]
+ *     grad_fmap2_levels[i][b] [H_i*W_i, D] =      dvol_i[b]^T [H_i*W_i, h*w] . fmap1[b] [h*w, D]
+ * Two launches of one 128 x 128-tile matrix-core kernel (all levels in each; K split to fill the chip, partial tiles added in a fixed
+ * order by a second kernel: no float atomics, bitwise reproducible).  `mode`: LISO_CONV_F32X3 (operands split into bf16 hi / lo,
+ * three MFMAs per product: the arithmetic of the convolutions of include/liso_conv.h) or LISO_CONV_F32 (exact fp32 MFMA).  fmap1,
+ * the levels and the outputs 16-byte aligned; any h, w (levels whose H_i*W_i is not a multiple of 4 take scalar loads).  Outputs are
+ * overwritten.  workspace: liso_corr_bwd_features_workspace_bytes(cfg) bytes. */
+size_t liso_corr_bwd_features_workspace_bytes(const liso_corr_cfg* cfg);
+int liso_corr_bwd_features_f32(const liso_corr_cfg* cfg, int mode, const float* fmap1, const float* const* fmap2_levels,
+                               const float* const* dvol_levels, float* grad_fmap1, float* const* grad_fmap2_levels, void* workspace,
+                               size_t workspace_bytes, void* stream);
 
 /* ---- exact 1-nearest-neighbour search (SLIM self-supervised loss) -------------------------------------------------
  * Replaces knn_graph(x, index=ref, k=1, loop=True) (liso/slim/slim_loss/knn_graph.py:10-98), which copies both clouds

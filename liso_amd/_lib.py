@@ -135,6 +135,10 @@ SIGNATURES = {
     "liso_corr_lookup_fwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "liso_corr_lookup_fwd_tiled_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "liso_corr_lookup_bwd_dvol_f32": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "liso_corr_pyramid_fwd_f32": (_i, [_vp, _vp, _vp, _vp]),
+    "liso_corr_pyramid_bwd_f32": (_i, [_vp, _vp, _vp, _vp]),
+    "liso_corr_bwd_features_workspace_bytes": (_sz, [_vp]),
+    "liso_corr_bwd_features_f32": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "liso_nearest_point_loss_fwd_f32": (_i, [_vp] * 8),
     "liso_nearest_point_loss_bwd_f32": (_i, [_vp] * 9),
     # include/liso_slim_decode.h

@@ -269,7 +269,6 @@ __global__ __launch_bounds__(kUfThreads) void dbscan_union_tiled_kernel(Cfg c, c
         const int q = s_list[e];
         const int r = tr * kTR + q / kTC, col = tc * kTC + q % kTC;
         const int lx = (r - r0) * RW + (col - c0);
-        const int me = r * c.gy + col;
         const double x0 = (double)xs[r], y0 = (double)ys[col];
         const double f0 = (double)s_f[lx][0], f1 = (double)s_f[lx][1], f2 = (double)s_f[lx][2];
         const int n_win = c.win * ww + c.win;  // window cells in front of the centre, row-major

@@ -213,11 +213,14 @@ def conv2d_pair(layer_a: nn.Conv2d, layer_b: nn.Conv2d, x, relu=False):
     """relu?(cat([layer_a(x), layer_b(x)], dim=1)) as one convolution (same input, same geometry)"""
     st = _ACTIVE
     key = (id(layer_a), id(layer_b))
-    if st is None or key not in st.index:
+    own = _own_kernels(x, layer_a.weight, layer_a)
+    if st is None or key not in st.index or not own:
         from liso_amd.utils import mfma_conv as MC
 
-        if _own_kernels(x, layer_a.weight, layer_a):
+        if own:
             return MC.fused_conv(x, None, [layer_a, layer_b], out_relu=relu)[0]
+        if x.is_cuda:  # channel counts outside the kernels' 16-byte groups (none of the networks'): mfma_conv.conv2d pads them, per layer
+            return torch.cat([MC.conv2d(layer_a, x, relu), MC.conv2d(layer_b, x, relu)], dim=1)
         w = torch.cat([layer_a.weight, layer_b.weight], dim=0)
         b = torch.cat([layer_a.bias, layer_b.bias], dim=0)
         y = host_ops.conv2d(x, w, b, layer_a.stride, layer_a.padding, layer_a.dilation)

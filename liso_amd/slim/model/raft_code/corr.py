@@ -6,14 +6,13 @@ grid_sample four times per RAFT iteration.  Correlation, average pooling and bil
 so the same numbers are obtained from the pooled *feature maps* (2.8 MB, L2 resident) by the on-the-fly gfx950
 kernel of include/liso_slim.h: the forward never stores anything of size (hw)^2.  The backward accumulates the window
 gradients of all RAFT iterations into ONE dense volume-gradient per level (no float atomics, reproducible) and turns it
-into feature gradients with two GEMMs per level, once per CorrBlock instead of once per iteration.
+into feature gradients with two launches of the library's own batched matrix-core kernel (all levels in each), once per CorrBlock
+instead of once per iteration.  The pooled pyramid and its adjoint are one launch each.
 """
 import ctypes
-
 import os
 
 import torch
-import torch.nn.functional as F
 
 from liso_amd import _lib as L
 
@@ -46,57 +45,67 @@ class _CorrFeatures(torch.autograd.Function):
         dvol, ctx.state.dvol = ctx.state.dvol, None
         if dvol is None:
             return (None, torch.zeros_like(fmap1)) + tuple(torch.zeros_like(l) for l in levels)
-        B, hw, D = fmap1.shape
-        own = _own_gemms(fmap1, dvol, levels)
-        if own is not None:
-            return (None, own[0]) + tuple(own[1])
-        g1 = None
-        g2 = []
-        for dv, f2 in zip(dvol, levels):
-            f2m = f2.reshape(B, -1, D)
-            g1 = torch.bmm(dv, f2m) if g1 is None else torch.baddbmm(g1, dv, f2m)
-            g2.append(torch.bmm(dv.transpose(1, 2), fmap1).view_as(f2))
+        g1, g2 = corr_bwd_features(fmap1, levels, dvol)
         return (None, g1) + tuple(g2)
 
 
-def _own_gemms(fmap1, dvol, levels):
-    """The two dense contractions of the correlation backward (liso/slim/model/raft_code/corr.py:48-56 is `fmap1^T fmap2`; its adjoint
-    per level: d fmap1 += dvol . fmap2_l and d fmap2_l = dvol^T . fmap1) on the own MFMA kernels instead of rocBLAS batched GEMMs:
-    per sample, `dvol . fmap2_l` is a 1x1 convolution over the hw query pixels with HW_l input channels and the pooled feature map as
-    its [D, HW_l] filter, and `dvol^T . fmap1` is that convolution's WEIGHT gradient (sum over the query pixels of dvol[pixel, :]
-    x fmap1[pixel, :]) -- fp32 tensors on the arithmetic of the process (F32X3 or exact fp32).  -> (g1 [B,hw,D], [g2_l like level l])
-    or None when the kernels do not cover the shapes (channel counts must be multiples of 4)."""
+def corr_bwd_features(fmap1, levels, dvol):
+    """The adjoint of the correlation (liso/slim/model/raft_code/corr.py:48-56 is `fmap1^T fmap2 / sqrt(D)`, pooled per level :20-21):
+    d fmap1 = sum_l dvol_l . fmap2_l and d fmap2_l = dvol_l^T . fmap1 -- two launches of the library's own 128 x 128-tile matrix-core
+    kernel (include/liso_slim.h: liso_corr_bwd_features_f32; all levels per launch, split-K partial sums added in a fixed order) in
+    the arithmetic of the process's fp32 convolutions (F32X3 or exact fp32).  Until round 5: eight rocBLAS batched GEMMs per step.
+    fmap1 [B, hw, D], levels[l] [B, H_l, W_l, D], dvol[l] [B, hw, H_l W_l] -> (g1 like fmap1, [g2_l like levels[l]])"""
     from liso_amd.utils import mfma_conv as MC
 
+    L.require_cuda(fmap1, *levels, *dvol)
     B, hw, D = fmap1.shape
-    if not fmap1.is_cuda or fmap1.dtype != torch.float32 or D % 4 or hw % 32:
-        return None
-    if os.environ.get("LISO_CORR_OWN_GEMM", "0") != "1":
-        # measured on the SLIM step (120k points, 512^2): 15.6 ms with these launches vs 14.8 ms with the library's batched GEMMs --
-        # a [4096 x 4096] . [4096 x 128] product as a 1x1 convolution is 64 blocks walking 128 channel slabs each; rocBLAS is 0.7 %
-        # of the step.  Kept as a tested option (LISO_CORR_OWN_GEMM=1: no rocBLAS kernel in the step), off by default.
-        return None
-    rows = hw // 32  # (a 1x1 convolution does not care how the query pixels are arranged: rows of 32 = the kernels' tile width)
-    if any(dv.shape[2] % 4 for dv in dvol):
-        return None
-    spec = MC.ConvSpec(1, 1, 1, 0, False)
+    h, w = levels[0].shape[1], levels[0].shape[2]
+    assert h * w == hw and all(tuple(l.shape) == (B, h >> i, w >> i, D) for i, l in enumerate(levels)), [tuple(l.shape) for l in levels]
+    assert all(tuple(dv.shape) == (B, hw, (h >> i) * (w >> i)) for i, dv in enumerate(dvol)), [tuple(dv.shape) for dv in dvol]
+    cfg = L.CorrCfg(B, h, w, D, len(levels), 0)
+    fmap1 = fmap1.contiguous()
+    levels = [l.contiguous() for l in levels]
+    dvol = [dv.contiguous() for dv in dvol]
     g1 = torch.empty_like(fmap1)
-    g2 = [torch.empty_like(f2) for f2 in levels]
-    for lvl, (dv, f2, out2) in enumerate(zip(dvol, levels, g2)):
-        n = dv.shape[2]  # HW_l
-        f2m = f2.reshape(B, n, D)
-        for b in range(B):
-            x = dv[b].view(1, rows, 32, n).permute(0, 3, 1, 2)                   # logical [1, C = HW_l, hw / 32, 32], channels last
-            w = f2m[b].t().reshape(D, n, 1, 1).contiguous()                      # filter [D, HW_l, 1, 1]
-            y, _ = MC.conv_forward(x, w, None, spec)                             # [1, D, hw / 32, 32], stored [1, hw / 32, 32, D]
-            yb = y.permute(0, 2, 3, 1).reshape(hw, D)
-            g1[b].copy_(yb) if lvl == 0 else g1[b].add_(yb)
-            dyv = fmap1[b].view(1, rows, 32, D).permute(0, 3, 1, 2)              # "dy" [1, D, hw / 32, 32]
-            res = MC.conv_wgrad(x, dyv, (D, n, 1, 1), spec, want_bias=False)     # dW[d, c] = sum_pixels dy[pixel, d] x[pixel, c]
-            if res is None:
-                return None
-            out2.view(B, n, D)[b].copy_(res[0].view(D, n).t())
+    g2 = [torch.empty_like(l) for l in levels]
+    lib = L.lib()
+    nbytes = lib.liso_corr_bwd_features_workspace_bytes(ctypes.byref(cfg))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=fmap1.device)
+    mode = L.CONV_F32 if MC.fp32_mode() == "exact" else L.CONV_F32X3
+    flops = 2 * 2.0 * B * hw * D * sum(dv.shape[2] for dv in dvol)
+    with torch.cuda.device(fmap1.device):
+        L.check(L.TIMER.launch("corr_bwd_features", lambda: lib.liso_corr_bwd_features_f32(
+            ctypes.byref(cfg), mode, L.ptr(fmap1), _ptr_array(levels), _ptr_array(dvol), L.ptr(g1), _ptr_array(g2), L.ptr(ws), nbytes,
+            L.stream_ptr()), units=flops), "corr_bwd_features")
     return g1, g2
+
+
+class _Pyramid(torch.autograd.Function):
+    """fmap2 [B, h, w, D] (channels last, = level 0) -> the pooled levels 1 .. L-1 in ONE launch (include/liso_slim.h:
+    liso_corr_pyramid_fwd_f32; F.avg_pool2d per level until round 5); backward = one launch that folds the levels' gradients back onto
+    level 0 (liso_corr_pyramid_bwd_f32)."""
+
+    @staticmethod
+    def forward(ctx, f2, num_levels):
+        L.require_cuda(f2)
+        B, h, w, D = f2.shape
+        cfg = L.CorrCfg(B, h, w, D, num_levels, 0)
+        outs = [torch.empty((B, h >> i, w >> i, D), dtype=torch.float32, device=f2.device) for i in range(1, num_levels)]
+        with torch.cuda.device(f2.device):
+            L.check(L.lib().liso_corr_pyramid_fwd_f32(ctypes.byref(cfg), L.ptr(f2), _ptr_array([f2] + outs), L.stream_ptr()), "corr_pyramid_fwd")
+        ctx.cfg = cfg
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        cfg = ctx.cfg
+        gs = [None] + [g.contiguous() if g is not None else None for g in grads]
+        ref = next(g for g in gs if g is not None)
+        out = torch.empty((cfg.batch, cfg.h, cfg.w, cfg.dim), dtype=torch.float32, device=ref.device)
+        ptrs = (ctypes.c_void_p * len(gs))(*[g.data_ptr() if g is not None else None for g in gs])
+        with torch.cuda.device(ref.device):
+            L.check(L.lib().liso_corr_pyramid_bwd_f32(ctypes.byref(cfg), ptrs, L.ptr(out), L.stream_ptr()), "corr_pyramid_bwd")
+        return out, None
 
 
 class _CorrLookup(torch.autograd.Function):
@@ -145,12 +154,8 @@ class CorrBlock:
         # channels-last query features [B, hw, D]
         self.fmap1 = fmap1.float().permute(0, 2, 3, 1).reshape(B, h * w, D).contiguous()
         # avg_pool2d of the correlation volume over (h2, w2) (reference :20-21) == correlation with the pooled fmap2
-        self.levels = []
-        f2 = fmap2.float()
-        for i in range(num_levels):
-            if i > 0:
-                f2 = F.avg_pool2d(f2, 2, stride=2)
-            self.levels.append(f2.permute(0, 2, 3, 1).contiguous())
+        f2 = fmap2.float().permute(0, 2, 3, 1).contiguous()  # (the encoders' maps are channels last: a view)
+        self.levels = [f2] + (list(_Pyramid.apply(f2, num_levels)) if num_levels > 1 else [])
         self._state = _VolumeGradState()
         needs_grad = torch.is_grad_enabled() and (self.fmap1.requires_grad or any(l.requires_grad for l in self.levels))
         self._token = _CorrFeatures.apply(self._state, self.fmap1, *self.levels) if needs_grad else self.fmap1.new_zeros(1)

@@ -479,7 +479,7 @@ def conv_dgrad(dy, weight, spec, x_shape, out_dtype=None, packed=None):
 def conv_wgrad(x, dy, weight_shape, spec, in_scale=None, in_shift=None, in_relu=False, want_bias=True, out_dw=None, out_db=None,
                co_true=None):
     """-> (dw fp32 in torch's layout `weight_shape`, dbias fp32 [Co] | None); None if the geometry is not supported by the
-    kernel (caller falls back to ATen's weight gradient).  `out_dw` / `out_db`: dense fp32 tensors to write into (overwritten)."""
+    kernels (the caller raises: there is no library fallback).  `out_dw` / `out_db`: dense fp32 tensors to write into (overwritten)."""
     L.require_cuda(x, dy)
     if (x.shape[1] == 4 and x.dtype == torch.float32 and not spec.transposed and spec.stride == 1 and spec.kh == spec.kw and spec.kh in (5, 7)
             and spec.padding == spec.kh // 2 and in_scale is None and tuple(weight_shape[1:]) == (4, spec.kh, spec.kw)
@@ -487,13 +487,10 @@ def conv_wgrad(x, dy, weight_shape, spec, in_scale=None, in_shift=None, in_relu=
         res = _conv_wgrad_smallci(x, dy, weight_shape, spec, want_bias, out_dw, out_db, co_true)
         if res is not None:
             return res
-    if spec.kh * spec.kw > 9 and not os.environ.get("LISO_WGRAD_7X7"):
-        # 7x7 kernels on DENSE inputs with many channels: the row-of-taps MFMA kernel re-stages the halo tile once per kernel row --
-        # measured 1.9 ms vs 0.31 ms for the library's kernel on the encoders' stem.  None of the networks' layers gets here: the
-        # stem's canvas is sparse and takes conv_wgrad_sparse (0.11 ms), the motion encoder's 2-4-channel layers (update.py:57,66)
-        # take _conv_wgrad_smallci above (25 / 55 us at batch 2 / 12, the library: 29 / 45 us).  LISO_WGRAD_7X7=1 forces the MFMA
-        # kernel (tests).
-        return None
+    # (7x7 kernels on DENSE inputs with many channels run the row-of-taps MFMA kernel below, which re-stages the halo tile once per
+    # kernel row: 1.9 ms on the encoders' stem.  None of the networks' layers gets here -- the stem's canvas is sparse and takes
+    # conv_wgrad_sparse (0.11 ms), the motion encoder's 2-4-channel layers (update.py:57,66) take _conv_wgrad_smallci above -- and
+    # there is no library route for a device tensor: a caller without an occupancy map pays the slow kernel.)
     mode = _mode(x.dtype)
     if dy.dtype != x.dtype:
         dy = dy.to(x.dtype)

@@ -101,7 +101,7 @@ def test_forward_dgrad_wgrad(geom, arith, monkeypatch):
     dyd = dy.to(dtype).cuda().contiguous(memory_format=torch.channels_last)
     dx = MC.conv_dgrad(dyd, wd, spec, tuple(x.shape), out_dtype=torch.float32)
     assert _rel(dx, gx) <= tol, _rel(dx, gx)
-    monkeypatch.setenv("LISO_WGRAD_7X7", "1")  # (the 64-channel 7x7 stem defaults to the library's kernel: measured faster)
+    # (dense 64-channel 7x7 stem: the row-of-taps MFMA kernel -- the product path feeds an occupancy map and takes the sparse kernels)
     res = MC.conv_wgrad(xd, dyd, tuple(w.shape), spec)
     assert res is not None  # every geometry of the networks can run on the own kernel (7 x 7: one kernel row of taps per block)
     dw, db = res

@@ -58,21 +58,26 @@ def test_corr_lookup_vs_explicit_volume(h, w, B):
     assert _rel(out, ref.cpu().numpy()) < 1e-4
 
 
-@pytest.mark.parametrize("own_gemms,h,w", [(False, 24, 40), (True, 32, 32)])
-def test_corr_lookup_backward_accumulates_over_lookups(own_gemms, h, w, monkeypatch):
+@pytest.mark.parametrize("fmode,h,w", [("x3", 24, 40), ("exact", 32, 32), ("x3", 17, 23), ("exact", 18, 21)])  # (the last level at least 2 x 2: the reference sampler divides by W - 1)
+def test_corr_lookup_backward_accumulates_over_lookups(fmode, h, w):
     """three lookups (RAFT iterations) through ONE CorrBlock: the deferred dense-volume backward must equal autograd
     through the reference's explicit volume + avg_pool2d + grid_sample path (corr.py:6-46), and be bit reproducible.
-    `own_gemms`: the two contractions per level on the own MFMA kernels (LISO_CORR_OWN_GEMM=1) instead of the library's GEMMs"""
+    The two contractions per level run on the library's own batched matrix-core kernel (liso_corr_bwd_features_f32) in both
+    fp32 arithmetics; 24 x 40 and the odd sizes have levels whose cell count is not a multiple of 4 (scalar-load path, partial tiles)."""
     import torch.nn.functional as F
 
-    from liso_amd.slim.model.raft_code import corr as corr_mod
     from liso_amd.slim.model.raft_code.corr import CorrBlock
     from liso_amd.slim.model.raft_code.utils import bilinear_sampler, coords_grid
+    from liso_amd.utils import mfma_conv as MC
 
-    monkeypatch.setenv("LISO_CORR_OWN_GEMM", "1" if own_gemms else "0")
-    taken = []
-    inner = corr_mod._own_gemms
-    monkeypatch.setattr(corr_mod, "_own_gemms", lambda *a: taken.append(inner(*a)) or taken[-1])
+    prev_mode = MC.set_fp32_mode(fmode)
+    try:
+        _corr_backward_case(h, w, CorrBlock, bilinear_sampler, coords_grid, F)
+    finally:
+        MC.set_fp32_mode(prev_mode)
+
+
+def _corr_backward_case(h, w, CorrBlock, bilinear_sampler, coords_grid, F):
     B = 2
     torch.manual_seed(5)
     f1 = torch.randn(B, 128, h, w, device="cuda", requires_grad=True)
@@ -102,7 +107,63 @@ def test_corr_lookup_backward_accumulates_over_lookups(own_gemms, h, w, monkeypa
     (a1, a2), (b1, b2), (e1, e2) = ours(), ours(), explicit()
     assert torch.equal(a1, b1) and torch.equal(a2, b2)  # no float atomics anywhere
     assert _rel(a1, e1.cpu().numpy()) < 1e-4 and _rel(a2, e2.cpu().numpy()) < 1e-4
-    assert len(taken) == 2 and all((t is not None) == own_gemms for t in taken)
+
+
+@pytest.mark.parametrize("B,h,w,D", [(2, 64, 64, 128), (1, 64, 64, 256), (3, 20, 28, 128), (1, 7, 5, 128), (1, 128, 128, 128)])
+def test_corr_bwd_features_equal_fp64_matmuls(B, h, w, D):
+    """liso_corr_bwd_features_f32 on DENSE random volume gradients (every tile, split and K tail carries weight) against fp64 matmuls:
+    exact-fp32 MFMA at fp32 round-off, F32X3 at 2^-16 per product; bitwise reproducible; (2, 64, 64, 128) is the SLIM training step's
+    shape (120k points, 512^2 BEV, both flow directions), (1, 128, 128, 128) the 1024^2 grid's"""
+    from liso_amd.slim.model.raft_code.corr import corr_bwd_features
+    from liso_amd.utils import mfma_conv as MC
+
+    g = torch.Generator().manual_seed(B * 1000 + h)
+    hw = h * w
+    f1 = torch.randn(B, hw, D, generator=g).cuda()
+    levels = [torch.randn(B, h >> i, w >> i, D, generator=g).cuda() for i in range(4) if (h >> i) >= 1 and (w >> i) >= 1]
+    dvol = [torch.randn(B, hw, l.shape[1] * l.shape[2], generator=g).cuda() for l in levels]
+    ref1 = sum(torch.bmm(dv.double(), l.double().reshape(B, -1, D)) for dv, l in zip(dvol, levels))
+    ref2 = [torch.bmm(dv.double().transpose(1, 2), f1.double()).view_as(l) for dv, l in zip(dvol, levels)]
+    k_total = sum(dv.shape[2] for dv in dvol)  # (round-off of an fp32 accumulation grows like sqrt(K): 5440 at 64 x 64, 21760 at 128 x 128)
+    for fmode, tol in (("exact", 2e-6 * max(1.0, (k_total / 5440) ** 0.5)), ("x3", 4e-5)):
+        prev = MC.set_fp32_mode(fmode)
+        try:
+            g1, g2 = corr_bwd_features(f1, levels, dvol)
+            h1, h2 = corr_bwd_features(f1, levels, dvol)
+        finally:
+            MC.set_fp32_mode(prev)
+        assert torch.equal(g1, h1) and all(torch.equal(a, b) for a, b in zip(g2, h2))
+        assert _rel(g1, ref1.cpu().numpy()) < tol, (fmode, _rel(g1, ref1.cpu().numpy()))
+        for a, r in zip(g2, ref2):
+            assert _rel(a, r.cpu().numpy()) < tol, (fmode, tuple(a.shape), _rel(a, r.cpu().numpy()))
+
+
+@pytest.mark.parametrize("B,h,w,D", [(2, 64, 64, 128), (1, 17, 23, 128), (1, 8, 8, 256), (1, 5, 3, 128)])
+def test_corr_pyramid_equals_avg_pool2d_forward_and_backward(B, h, w, D):
+    """the one-launch pooled pyramid (liso_corr_pyramid_fwd/bwd_f32) against F.avg_pool2d level by level and its autograd: same floor
+    semantics on odd sizes, same numbers (sums of four in the same order)"""
+    import torch.nn.functional as F
+
+    from liso_amd.slim.model.raft_code.corr import _Pyramid
+
+    g = torch.Generator().manual_seed(h * 100 + w)
+    n_lvl = 1 + sum(1 for i in range(1, 4) if (h >> i) >= 1 and (w >> i) >= 1)
+    f2 = torch.randn(B, h, w, D, generator=g).cuda().requires_grad_(True)
+    lv = _Pyramid.apply(f2, n_lvl)
+    x = f2.detach().permute(0, 3, 1, 2).clone().requires_grad_(True)
+    ref, cur = [], x
+    for _ in range(1, n_lvl):
+        cur = F.avg_pool2d(cur, 2, stride=2)
+        ref.append(cur)
+    assert len(lv) == len(ref) == n_lvl - 1
+    wts = [torch.randn(r.shape, generator=g).cuda() for r in ref]
+    for a, r in zip(lv, ref):
+        assert tuple(a.shape) == (B, r.shape[2], r.shape[3], D)
+        assert torch.allclose(a.permute(0, 3, 1, 2), r, rtol=0, atol=1e-6)
+    if n_lvl > 1:
+        sum((a.permute(0, 3, 1, 2) * wt).sum() for a, wt in zip(lv, wts)).backward()
+        sum((r * wt).sum() for r, wt in zip(ref, wts)).backward()
+        assert torch.allclose(f2.grad.permute(0, 3, 1, 2), x.grad, rtol=0, atol=1e-6)
 
 
 def _build(seed=1234):
