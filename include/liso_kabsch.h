@@ -57,8 +57,8 @@ int liso_kabsch_trafos_f32(const liso_kabsch_cfg* cfg, const float* points, cons
  * fp32 moment sums are added: the transforms equal liso_kabsch_trafos_f32's for the parked arrangement to fp32-summation tolerance
  * (1e-6 relative, what tests/test_gpu_kabsch.py asserts), not bitwise, and they depend bitwise on which of the three deals
  * slot_count[b] selects.  For a fixed slot_count every output is run-to-run bitwise reproducible.
- * slot_count == NULL: all n_slots slots hold boxes and the deal is the uncounted one (64 slot lanes), i.e. bitwise
- * liso_kabsch_trafos_f32. */
+ * slot_count == NULL: all n_slots slots hold boxes; the deal is chosen from n_slots, so liso_kabsch_trafos_f32 on exactly k boxes
+ * and this call on more slots with slot_count[b] = k use the same deal and give the same bits for those boxes. */
 int liso_kabsch_trafos_counted_f32(const liso_kabsch_cfg* cfg, const float* points, const uint8_t* valid, const float* flow,
                                    const float* box_pos, const float* box_dims, const float* box_rot, const int32_t* slot_count,
                                    double* trafos, float* cum_wts, float* fg_weights, void* workspace, size_t workspace_bytes,

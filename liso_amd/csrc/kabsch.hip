@@ -98,8 +98,10 @@ __global__ __launch_bounds__(kThreads) void kabsch_moments_kernel(liso_kabsch_cf
         cnt = cnt < 0 ? 0 : (cnt > S ? S : cnt);
     }
     const int cnt_chunk = cnt - chunk * 64 < 0 ? 0 : (cnt - chunk * 64 > 64 ? 64 : cnt - chunk * 64);
-    // (no slot_count: the uncounted deal, one point sub-lane -- the summation order of liso_kabsch_trafos_f32 whatever n_slots is)
-    const int SV = !slot_count ? 64 : (cnt_chunk <= 16 ? 16 : (cnt_chunk <= 32 ? 32 : 64)), NP = 64 / SV;
+    // (the deal follows the number of boxes: without slot_count that is n_slots -- a caller that passes exactly its boxes as slots gets
+    // the deal a fixed-slot caller with the same count gets, and with it the same bits: the eager / captured box-mining paths of
+    // liso_amd/trainer.py rely on that, tests/test_gpu_liso_loop.py)
+    const int SV = cnt_chunk <= 16 ? 16 : (cnt_chunk <= 32 ? 32 : 64), NP = 64 / SV;
     const int slot_l = lane % SV, psub = lane / SV;
     const int slot = chunk * 64 + slot_l;
     const bool has_slot = slot < cnt;

@@ -90,6 +90,26 @@ def gather_gradients(device, params, add=False):
     return [g for g, _ in jobs]
 
 
+_SIDE_STREAMS = {}
+
+
+def side_stream(device, role, priority=0):
+    """The process's side stream for `role` on `device`: ONE HIP stream per (device, role), shared by every trainer of the process.
+
+    HIP binds a stream to one of a few hardware queues when it is first used, in order of first use.  A second LisoLoopTrainer that
+    CREATED three more streams next to a first, already stepped one found its streams on queues that its own caller's stream or each
+    other already occupied: its three pipeline stages took turns on a queue and its step ran at 11.3 ms instead of 4.37 (the first
+    trainer, stepped again afterwards: 4.37; either trainer without overlap: 9.1-9.4; the second with its side streams replaced by
+    fresh high-priority ones: 4.39 -- scripts/second_trainer_bisect.py, round 6; rounds 4-5 had seen it as "a trainer built second
+    is 1.5x slower, cause not found" and moved bench.py's parity legs into child processes).  Streams are queues, not state: trainers
+    of one process share them, an idle trainer leaves nothing on them, two active ones interleave on them."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), role)
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device, priority=priority)
+    return st
+
+
 class DetectorTrainer:
     def __init__(self, cfg, device, compute_dtype=torch.float32, total_steps=None, fused_loss=None, use_graph=False, exact=None,
                  grad_buckets=None):
@@ -289,12 +309,12 @@ class DetectorTrainer:
         if quiet:  # the flat gradient views are created on the default stream, warm-up and capture run on a side stream
             torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
         if self._capture_stream is None:
-            self._capture_stream = torch.cuda.Stream(device=dev)
+            self._capture_stream = side_stream(dev, "flow")  # (the loop trainer lends the same one: SLIM inference's stream)
         # LISO_WGRAD_SIDE=1 (opt-in, measured slower): the weight gradients as a parallel branch of the captured backward pass
         # (mfma_conv.wgrad_side) -- nothing in the backward chain reads them.  Results identical; but every fork edge of a replayed
         # hipGraph costs ~240 us here: detector replay 7.15 vs 2.54 ms (19 forks + 1 join), loop 6.44 vs 4.38 ms per step.
         if self._wgrad_stream is None and os.environ.get("LISO_WGRAD_SIDE", "0") == "1":
-            self._wgrad_stream = torch.cuda.Stream(device=dev)
+            self._wgrad_stream = side_stream(dev, "wgrad")
         side = self._capture_stream  # (kept alive with the graph)
         side.wait_stream(torch.cuda.current_stream(dev))
 
@@ -606,7 +626,7 @@ class SlimTrainer:
         if quiet:
             # the flat gradient views are created on the default stream, warm-up and capture run on side streams
             torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
-        side = torch.cuda.Stream(device=dev)
+        side = side_stream(dev, "flow")
         side.wait_stream(torch.cuda.current_stream(dev))
         # So does the decoder's point -> cell plan: a torch.sort of 12 x B x N (2.9 M) keys.  A captured torch.sort of more than
         # ~1 M keys is what makes the replay fault after a few thousand unrelated eager launches (scripts/debug_pillar_graph_fault.py:
@@ -872,14 +892,15 @@ class LisoLoopTrainer:
         if device.type == "cuda":
             # three streams in all (the caller's, A, B): HIP multiplexes streams onto 4 hardware queues, and two streams on one
             # queue take turns.  Graph capture / warm-up of both networks borrows stream A.
-            self._flow_stream = torch.cuda.Stream(device=device)
-            self._mine_stream = torch.cuda.Stream(device=device, priority=-1)  # many tiny kernels + host reads: dispatch first
+            # (one set per device and PROCESS, not per trainer: side_stream)
+            self._flow_stream = side_stream(device, "flow")
+            self._mine_stream = side_stream(device, "mine0", priority=-1)  # many tiny kernels + host reads: dispatch first
             # stage B is a chain of ~100 dependent small launches; under contention it is the slowest stage (the host waits ~1.4 ms
             # per step for it).  LISO_MINE_STREAMS=2 alternates consecutive pairs between two mining streams (two chains in
             # flight): 4.46-4.65 instead of 4.6-4.8 ms per step on one GPU, but that is the 4th stream -- one more (RCCL's, in a
             # multi-GPU run) and two streams share a hardware queue (measured with 3 mining streams: 6.4 ms).  Default 1.
             n_mine = max(1, int(os.environ.get("LISO_MINE_STREAMS", "1")))
-            self._mine_streams = [self._mine_stream] + [torch.cuda.Stream(device=device, priority=-1) for _ in range(n_mine - 1)]
+            self._mine_streams = [self._mine_stream] + [side_stream(device, f"mine{k}", priority=-1) for k in range(1, n_mine)]
             self._mine_turn = 0
             self.detector._capture_stream = self._flow_stream
         self._pillar_prep = None  # (clouds, pfn.prepare(clouds), event) of the next detector step

@@ -469,3 +469,51 @@ def test_mining_graph_budget_falls_back_to_eager_launches():
         if budget == 1:
             assert tr.mine_captures == 1 and tr.mine_eager_fallbacks >= 2
     assert out[0] == out[1], out
+
+
+def test_second_trainer_in_a_process_steps_as_fast_as_the_first():
+    """Two LisoLoopTrainers in one process, BASELINE size, pipelined: the one built second -- next to the first, already stepped one --
+    must step as fast.  Until round 6 it did not (4.37 vs 11.3 ms per step: each trainer created its own side streams, and HIP binds
+    streams to its few hardware queues in order of first use -- the second trainer's pipeline stages took turns on a queue;
+    scripts/second_trainer_bisect.py).  The side streams are one set per device and process now (liso_amd.trainer.side_stream)."""
+    import time
+
+    from liso_amd.datasets.synthetic import slim_pair
+    from liso_amd.trainer import LisoLoopTrainer
+    from liso_amd.utils.config import apply_slim_simple_knn_training, default_cfg
+
+    dev = torch.device("cuda")
+    cfg = apply_slim_simple_knn_training(default_cfg(grid=512, bev_range_m=100.0))
+    pairs = [slim_pair(2 + 100 * i, dev, n_points=120000 + (i % 5 - 2) * 1500, grid=512, bev_range_m=100.0) for i in range(16)]
+    batch, n_up = 2, 11
+
+    def make():
+        torch.manual_seed(0)
+        return LisoLoopTrainer(cfg, dev, compute_dtype=torch.bfloat16, total_steps=256, use_graph=True, overlap=True, infer_batch=4, flow_ahead=2)
+
+    def run(tr, steps, ctr):
+        for _ in range(steps):
+            i = ctr[0] * batch
+            ctr[0] += 1
+            tr.step_batch([pairs[(i + k) % 16] for k in range(batch)], upcoming=tuple(pairs[(i + k) % 16] for k in range(batch, batch + n_up)))
+
+    def ms_per_step(tr):
+        ctr = [0]
+        run(tr, 12, ctr)  # (once around the ring: every graph signature captured)
+        best = float("inf")
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run(tr, 16, ctr)
+            torch.cuda.synchronize()
+            best = min(best, 1e3 * (time.perf_counter() - t0) / 16)
+        return best
+
+    first = make()
+    t_first = ms_per_step(first)
+    second = make()
+    assert second._flow_stream is first._flow_stream and second._mine_stream is first._mine_stream
+    t_second = ms_per_step(second)
+    t_first_again = ms_per_step(first)
+    # (box-to-box and run-to-run noise is a few percent; the defect was a factor of 2.6)
+    assert t_second <= 1.15 * t_first and t_first_again <= 1.15 * t_first, (t_first, t_second, t_first_again)
