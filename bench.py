@@ -790,6 +790,16 @@ def main():
         else:
             achieved = alg_total / t_total / 1e9 if t_total > 0 else 0.0
             peak, runit = HBM_PEAK_GBS, "GB/s"
+        # the pipelined loop caps the persistent 3x3 convolutions of the captured SLIM inference at `infer_cus` compute units (default: half
+        # the chip, liso_amd/trainer.py) and the event passes time them under the same cap: their roofline is the peak of the CUs they may
+        # use.  (Only where the family holds nothing but those launches: the bf16 headline's F32X3 forward family; in --dtype f32x3 the
+        # detector's uncapped launches share the family and the whole chip's peak stays.)
+        cu_cap = None
+        n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+        if (args.workload == "loop" and args.dtype == "bf16" and key == "conv_f32x3_fwd_roles" and getattr(trainer, "infer_cus", 0)
+                and bound == "mfma"):
+            cu_cap = {"cus": trainer.infer_cus, "of": n_cu, "whole_chip_peak": peak, "whole_chip_frac": achieved / peak}
+            peak = peak * trainer.infer_cus / n_cu
         traffic, traffic_src = pmc_traffic(args.workload, PMC_PATTERNS[key]) if key in PMC_PATTERNS else (None, None)
         workload = {
             "loop": ("fused LISO iteration (BASELINE configs[3]): SLIM fwd (no_grad; forward flow direction t0->t1 only, only the last "
@@ -833,7 +843,7 @@ def main():
                                 os.environ.get("LISO_DIST_BACKEND", "nccl") == "nccl" else None,
                                 "gradient_buckets": getattr(getattr(trainer, "detector", trainer), "n_grad_buckets", 1)},
                        **({"points_per_cloud_ring": [min(counts), max(counts)], "sweep_pairs_in_rotation": n_pairs,
-                           "point_bucket_rows": trainer.infer_point_bucket,
+                           "point_bucket_rows": trainer.infer_point_bucket, "inference_compute_units": getattr(trainer, "infer_cus", 0) or "all",
                            "graph_captures": {"inference": len(trainer._infer_graphs), "box_mining": trainer.mine_captures,
                                               "inside_timed_region": (len(trainer._infer_graphs) - captures_after_warmup[0]) +
                                               (trainer.mine_captures - captures_after_warmup[1]),
@@ -904,9 +914,13 @@ def main():
                                         "frac": (bytes_total / t_p / 1e9 / HBM_PEAK_GBS) if t_p > 0 else 0.0,
                                         "algorithmic_bytes_per_launch_pair": bytes_total / n_p, "avg_pair_ms": 1e3 * t_p / n_p,
                                         "launch_pairs": n_p, "traffic": tr_p, "traffic_source": src_p}
+        if cu_cap is not None:
+            line["roofline"]["compute_units"] = cu_cap
         if bound == "mfma" and "f32x3" in key:
             line["roofline"]["peak_note"] = ("fp32 tensors computed as 3 bf16 MFMAs per product (hi*hi + hi*lo + lo*hi): peak = dense "
-                                             "bf16 MFMA / 3 in algorithmic fp32 flops (native f32 MFMA peak: 157.3 TFLOP/s)")
+                                             "bf16 MFMA / 3 in algorithmic fp32 flops (native f32 MFMA peak: 157.3 TFLOP/s)" +
+                                             (f"; these launches are capped at {cu_cap['cus']} of {cu_cap['of']} compute units (the pipeline's partition, "
+                                              "`compute_units`): peak scaled by that share" if cu_cap is not None else ""))
         if world == 1 and not args.no_iou3d:
             line["iou3d_nms"] = bench_iou3d(dev, torch, with_cpu=not args.no_cpu_baseline)
         if world == 1 and not args.no_cpu_baseline:

@@ -229,6 +229,36 @@ int liso_gru_out_rows_f32(long n_pix, int ch, const float* cq, long cq_stride, c
 int liso_raft_state_step_f32(int batch, int hw, const float* delta, long delta_stride, const float* coords0, float* coords1,
                              float* state8, void* stream);
 
+/* ---- the RAFT update loop's TRAINING step between its convolutions (liso_amd/slim/model/raft_loop.py: all iterations of
+ * liso/slim/model/raft.py:178-259 + update.py:29-164 as one autograd node on stacked channels-last buffers) ------------------------
+ * Rows = pixels; every pointer may address a channel slice of a wider buffer (`*_stride` = floats between consecutive pixels,
+ * multiples of 4, pointers 16-byte aligned).
+ *
+ * liso_rows_combine_f32: out[p, :] = (a[p, :] + b[p, :] + c[p, :]) * (mask[p, :] > 0), added to out when `accumulate`; b, c, mask may
+ * be NULL.  One launch for what autograd spends a gradient accumulation, a ReLU backward (threshold_backward) and a concatenation
+ * on: the masked gradient lands in the stacked buffer the layer's weight gradient reads. */
+int liso_rows_combine_f32(long n_pix, int channels, const float* a, long a_stride, const float* b, long b_stride, const float* c,
+                          long c_stride, const float* mask, long mask_stride, float* out, long out_stride, int accumulate, void* stream);
+/* ConvGRU output gate out of place (update.py:35-37): h_out = (1 - z) h_in + z tanh(cq); z [n_pix, ch] contiguous. */
+int liso_gru_out_rows_train_f32(long n_pix, int ch, const float* cq, long cq_stride, const float* z, const float* h_in, long h_in_stride,
+                                float* h_out, long h_out_stride, void* stream);
+/* its adjoint: g_cq = g z (1 - tanh(cq)^2) (strided), g_z = g (tanh(cq) - h_in), g_h = g (1 - z) (both [n_pix, ch] contiguous) */
+int liso_gru_out_rows_bwd_f32(long n_pix, int ch, const float* cq, long cq_stride, const float* z, const float* h_in, long h_in_stride,
+                              const float* g_out, long g_out_stride, float* g_cq, long g_cq_stride, float* g_z, float* g_h, void* stream);
+/* adjoint of liso_gru_in_rows_f32: zr [.., 2 ch] pre-activations of z | r; g_zr[:, :ch] = g_z z (1 - z), g_zr[:, ch:] = g_rh h r (1 - r),
+ * g_h = g_rh r ([n_pix, ch] contiguous) */
+int liso_gru_in_rows_bwd_f32(long n_pix, int ch, const float* zr, long zr_stride, const float* h, long h_stride, const float* z,
+                             const float* g_z, const float* g_rh, long g_rh_stride, float* g_zr, long g_zr_stride, float* g_h, void* stream);
+/* The loop's state update (raft.py:199-216) keeping every iteration's state.  State pixel (8 floats) = (logit 0..3, flow x, flow y, 0, 0);
+ * delta8 = the heads' merged output in the same order.  coords_out = coords_in + delta flow ([batch, 2, hw]); state_out = (state_in
+ * logits + delta logits, coords_out - coords0, 0, 0); flow_out [batch, 2, hw] / logits_out [batch, 4, hw]: the same numbers planar,
+ * what liso_raft_upsample_outputs_fwd_f32 reads. */
+int liso_raft_state_step_train_f32(int batch, int hw, const float* delta8, const float* coords0, const float* coords_in, float* coords_out,
+                                   const float* state_in, float* state_out, float* flow_out, float* logits_out, void* stream);
+/* planar output gradients (g_flow [n, 2, hw], g_logits [n, 4, hw]) -> g8 [n * hw][8] = (logits | flow | 0 0): the gradient of the heads'
+ * merged output convolution in its own layout, all iterations in one launch */
+int liso_raft_pack_output_grads_f32(long n, int hw, const float* g_flow, const float* g_logits, float* g8, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

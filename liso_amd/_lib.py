@@ -91,7 +91,7 @@ def require_cuda(*tensors):
             raise LisoHipError("device op called with a CPU tensor; liso_amd has no CPU fallback")
 
 
-_vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+_vp, _i, _f, _sz, _lg = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_long
 
 # symbol -> (restype, argtypes); mirrors include/*.h exactly (tests/test_abi.py parses the headers and checks)
 SIGNATURES = {
@@ -139,6 +139,12 @@ SIGNATURES = {
     "liso_corr_pyramid_bwd_f32": (_i, [_vp, _vp, _vp, _vp]),
     "liso_corr_bwd_features_workspace_bytes": (_sz, [_vp]),
     "liso_corr_bwd_features_f32": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "liso_rows_combine_f32": (_i, [_lg, _i, _vp, _lg, _vp, _lg, _vp, _lg, _vp, _lg, _vp, _lg, _i, _vp]),
+    "liso_gru_out_rows_train_f32": (_i, [_lg, _i, _vp, _lg, _vp, _vp, _lg, _vp, _lg, _vp]),
+    "liso_gru_out_rows_bwd_f32": (_i, [_lg, _i, _vp, _lg, _vp, _vp, _lg, _vp, _lg, _vp, _lg, _vp, _vp, _vp]),
+    "liso_gru_in_rows_bwd_f32": (_i, [_lg, _i, _vp, _lg, _vp, _lg, _vp, _vp, _vp, _lg, _vp, _lg, _vp, _vp]),
+    "liso_raft_state_step_train_f32": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "liso_raft_pack_output_grads_f32": (_i, [_lg, _i, _vp, _vp, _vp, _vp]),
     "liso_nearest_point_loss_fwd_f32": (_i, [_vp] * 8),
     "liso_nearest_point_loss_bwd_f32": (_i, [_vp] * 9),
     # include/liso_slim_decode.h

@@ -108,26 +108,47 @@ class _Pyramid(torch.autograd.Function):
         return out, None
 
 
+def lookup_forward(fmap1, fmap2_levels, coords, radius, out=None):
+    """one correlation lookup (corr.py:23-46 of the reference) on detached features: fmap1 [B, hw, D], levels [B, H_i, W_i, D],
+    coords [B, 2, h, w] (fp32, contiguous) -> out [B, h, w, L (2r+1)^2] (written into `out` when given).  -> (out, cfg)"""
+    L.require_cuda(fmap1, coords)
+    B, hw, D = fmap1.shape
+    _, _, h, w = coords.shape
+    cfg = L.CorrCfg(B, h, w, D, len(fmap2_levels), radius)
+    W7 = 2 * radius + 1
+    if out is None:
+        out = torch.empty((B, h, w, len(fmap2_levels) * W7 * W7), dtype=torch.float32, device=fmap1.device)
+    assert out.is_contiguous() and tuple(out.shape) == (B, h, w, len(fmap2_levels) * W7 * W7) and coords.is_contiguous()
+    # the arithmetic of the process's fp32 convolutions: bf16 hi / lo pairs on the matrix cores ("x3": the tiled kernel, 4 x 8 queries
+    # share the rows they correlate with) or fp32 FMAs ("exact": one wavefront per query and level)
+    from liso_amd.utils import mfma_conv as MC
+
+    tiled = MC.fp32_mode() == "x3" and os.environ.get("LISO_CORR_TILED", "1") != "0"
+    fn = L.lib().liso_corr_lookup_fwd_tiled_f32 if tiled else L.lib().liso_corr_lookup_fwd_f32
+    with torch.cuda.device(fmap1.device):
+        L.check(L.TIMER.launch("corr_lookup_fwd_tiled" if tiled else "corr_lookup_fwd", lambda: fn(
+            ctypes.byref(cfg), L.ptr(fmap1), _ptr_array(fmap2_levels), L.ptr(coords), L.ptr(out), L.stream_ptr())),
+            "corr_lookup_fwd")
+    return out, cfg
+
+
+def lookup_backward(state, cfg, level_hw, coords, grad_out):
+    """adds the adjoint of one lookup's bilinear windows to the CorrBlock's dense volume gradients `state.dvol` (created on first use);
+    grad_out [B, h, w, C] fp32 contiguous"""
+    g = grad_out
+    assert g.is_contiguous() and g.dtype == torch.float32
+    if state.dvol is None:
+        state.dvol = [torch.zeros((cfg.batch, cfg.h * cfg.w, n), dtype=torch.float32, device=g.device) for n in level_hw]
+    with torch.cuda.device(g.device):
+        L.check(L.TIMER.launch("corr_lookup_bwd", lambda: L.lib().liso_corr_lookup_bwd_dvol_f32(
+            ctypes.byref(cfg), L.ptr(coords), L.ptr(g), _ptr_array(state.dvol), L.stream_ptr())), "corr_lookup_bwd")
+
+
 class _CorrLookup(torch.autograd.Function):
     @staticmethod
     def forward(ctx, coords, radius, state, token, fmap1, *fmap2_levels):
-        L.require_cuda(fmap1, coords)
-        B, hw, D = fmap1.shape
-        _, _, h, w = coords.shape
-        cfg = L.CorrCfg(B, h, w, D, len(fmap2_levels), radius)
-        W7 = 2 * radius + 1
         coords = coords.detach().float().contiguous()
-        out = torch.empty((B, h, w, len(fmap2_levels) * W7 * W7), dtype=torch.float32, device=fmap1.device)
-        # the arithmetic of the process's fp32 convolutions: bf16 hi / lo pairs on the matrix cores ("x3": the tiled kernel, 4 x 8 queries
-        # share the rows they correlate with) or fp32 FMAs ("exact": one wavefront per query and level)
-        from liso_amd.utils import mfma_conv as MC
-
-        tiled = MC.fp32_mode() == "x3" and os.environ.get("LISO_CORR_TILED", "1") != "0"
-        fn = L.lib().liso_corr_lookup_fwd_tiled_f32 if tiled else L.lib().liso_corr_lookup_fwd_f32
-        with torch.cuda.device(fmap1.device):
-            L.check(L.TIMER.launch("corr_lookup_fwd_tiled" if tiled else "corr_lookup_fwd", lambda: fn(
-                ctypes.byref(cfg), L.ptr(fmap1), _ptr_array(fmap2_levels), L.ptr(coords), L.ptr(out), L.stream_ptr())),
-                "corr_lookup_fwd")
+        out, cfg = lookup_forward(fmap1, fmap2_levels, coords, radius)
         ctx.save_for_backward(coords)
         ctx.cfg, ctx.state = cfg, state
         ctx.level_hw = [l.shape[1] * l.shape[2] for l in fmap2_levels]
@@ -136,13 +157,9 @@ class _CorrLookup(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         (coords,) = ctx.saved_tensors
-        cfg, st = ctx.cfg, ctx.state
+        cfg = ctx.cfg
         g = grad_out.float().contiguous()
-        if st.dvol is None:
-            st.dvol = [torch.zeros((cfg.batch, cfg.h * cfg.w, n), dtype=torch.float32, device=g.device) for n in ctx.level_hw]
-        with torch.cuda.device(g.device):
-            L.check(L.TIMER.launch("corr_lookup_bwd", lambda: L.lib().liso_corr_lookup_bwd_dvol_f32(
-                ctypes.byref(cfg), L.ptr(coords), L.ptr(g), _ptr_array(st.dvol), L.stream_ptr())), "corr_lookup_bwd")
+        lookup_backward(ctx.state, cfg, ctx.level_hw, coords, g)
         return (None, None, None, g.new_zeros(1)) + (None,) * (1 + cfg.levels)
 
 

@@ -174,6 +174,15 @@ class RAFT(nn.Module):
         packed = infer is not None and infer["packed"] and not vanilla  # (flow | logits) in one state pixel, one update launch per iteration
         if packed:
             coords0, coords1 = coords0.contiguous(), coords1.contiguous()  # (coords_grid returns fresh tensors: coords1 is updated in place)
+        if fuse and infer is None and torch.is_grad_enabled():
+            # training: ALL iterations as one autograd node on stacked buffers, hand-sequenced backward (raft_loop.py); the op-by-op
+            # loop below remains for the configurations the node does not implement (and as its test oracle: LISO_RAFT_LOOP=0)
+            from liso_amd.slim.model import raft_loop as RL
+            from liso_amd.slim.model.raft_outputs import _RaftOutputs
+
+            if RL.applicable(self.update_block, net, inp, m.corr_cfg.search_radius):
+                flows, logits_all = RL.raft_loop(self.update_block, correlation, coords0, net, inp, m.num_iters, direct=mode == "direct")
+                return _RaftOutputs.apply(flows, logits_all, fused_dirs, ds, ds * float(adapter))
         with deferred_weight_gradients(self.update_block, enabled=self.training and bool(mode), direct_accumulate=mode == "direct"):
             for it in range(m.num_iters):
                 coords1 = coords1.detach()

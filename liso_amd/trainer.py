@@ -903,6 +903,14 @@ class LisoLoopTrainer:
             self._mine_streams = [self._mine_stream] + [side_stream(device, f"mine{k}", priority=-1) for k in range(1, n_mine)]
             self._mine_turn = 0
             self.detector._capture_stream = self._flow_stream
+        # compute units the captured SLIM inference's persistent 3x3 convolutions may take while the pipeline overlaps it with the
+        # detector step (0 = all): half the chip by default, see _infer_flow_padded
+        self.infer_cus = 0
+        if device.type == "cuda" and self.overlap:
+            n_cu = torch.cuda.get_device_properties(device).multi_processor_count
+            self.infer_cus = int(os.environ.get("LISO_INFER_CUS", str(n_cu // 2)))
+            if self.infer_cus >= n_cu:
+                self.infer_cus = 0
         self._pillar_prep = None  # (clouds, pfn.prepare(clouds), event) of the next detector step
         self._prep_ahead = os.environ.get("LISO_PREP_AHEAD", "1") != "0"
         tc = cfg.data.tracking_cfg
@@ -1050,15 +1058,16 @@ class LisoLoopTrainer:
             s0, s1 = st["in"]
             side = self._flow_stream  # (HIP maps streams onto 4 hardware queues: capture on a pipeline stream, no extra one)
             side.wait_stream(torch.cuda.current_stream(dev))
-            # LISO_INFER_CUS=n (opt-in): in the pipeline the captured inference leaves compute units to the other streams
-            # (mfma_conv.roles_cus: its 3x3 convolutions are persistent blocks, one per CU, and a 60-us launch that holds all 256 makes
-            # every kernel of the detector step -- the critical path, ~250 small dependent launches -- wait for it to drain).  Measured,
-            # same box: all CUs 4.23-4.26 ms per step; 128: 4.16-4.17; 144: 4.26; 112: 4.35; 96: 4.34; 64: 4.78 (then stage A is the
-            # slowest stage).  Off by default: the kernels' own rate, which bench.py's `roofline` reports against the WHOLE chip's peak,
-            # halves with it.
+            # In the pipeline the captured inference leaves compute units to the other streams (`infer_cus`, LISO_INFER_CUS=n; 0 = all;
+            # mfma_conv.roles_cus: its 3x3 convolutions are persistent blocks, one per CU, and a 60-us launch that holds all 256 makes
+            # every kernel of the detector step -- the critical path, ~250 small dependent launches -- wait for it to drain).  Measured:
+            # round 5, one box: all CUs 4.23-4.26 ms per step; 128: 4.16-4.17; 144: 4.26; 112: 4.35; 96: 4.34; 64: 4.78 (then stage A is
+            # the slowest stage); round 6, one box, 40 steps, twice each: all 4.38 / 4.40; 128: 4.25 / 4.27; 160: 4.39 / 4.40; 96: 4.33 /
+            # 4.34 (scripts/infer_cus_sweep.sh).  Default since round 6: half the chip; bench.py's `roofline` prices the capped launches
+            # against the peak of the CUs they may use.
             from liso_amd.utils import mfma_conv as MC
 
-            cus = int(os.environ.get("LISO_INFER_CUS", "0")) if self.overlap else 0
+            cus = self.infer_cus
             with torch.cuda.stream(side), torch.no_grad(), MC.roles_cus(cus):
                 for _ in range(2):
                     self.slim.infer_point_flow_t0_t1(s0, s1, canvases=st["canv"], dynamicness_threshold=st["thr"])
@@ -1099,7 +1108,7 @@ class LisoLoopTrainer:
                 from liso_amd.utils import mfma_conv as MC
 
                 try:  # (the plans of the captured inference: the same compute-unit cap as in _infer_flow_padded)
-                    with MC.roles_cus(int(os.environ.get("LISO_INFER_CUS", "0")) if self.overlap else 0):
+                    with MC.roles_cus(self.infer_cus):
                         flow = self._infer_flow_padded(self._stack_infer_views([p_[0] for p_ in allp]), self._stack_infer_views([p_[1] for p_ in allp]))
                 finally:
                     L.TIMER.weight = 1.0
