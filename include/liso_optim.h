@@ -38,6 +38,13 @@ int liso_adamw_step_f32(float* param, const float* grad, float* exp_avg, float* 
 int liso_adamw_step_scaled_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr, double beta1,
                                double beta2, double eps, double weight_decay, double grad_scale, long step, void* stream);
 
+/* RMSprop over one flat fp32 buffer (SLIM's optimizer, liso/slim/experiment.py:200-219: torch.optim.RMSprop(lr) with its defaults
+ * alpha 0.99, eps 1e-8, no momentum, not centered), the element-wise operations of torch's multi-tensor implementation:
+ *     square_avg = square_avg * alpha + (1 - alpha) * g * g;   param = param - lr * g / (sqrt(square_avg) + eps),   g = grad * grad_scale
+ * All buffers 16-byte aligned; one launch. */
+int liso_rmsprop_step_f32(float* param, const float* grad, float* square_avg, size_t n, double lr, double alpha, double eps,
+                          double grad_scale, void* stream);
+
 /* `count` fp32 arrays copied into their destinations by ONE launch per LISO_GATHER_MAX jobs: dst[k][0 .. numel[k]) = src[k][...].
  * The detector step uses it for the parameter gradients that autograd hands back as tensors of their own (merged / sliced
  * parameters whose gradient no kernel can write in place): with `.grad = None` autograd keeps those tensors instead of launching one

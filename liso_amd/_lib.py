@@ -192,6 +192,7 @@ SIGNATURES = {
     # include/liso_optim.h
     "liso_adamw_step_f32": (_i, [_vp, _vp, _vp, _vp, _sz] + [ctypes.c_double] * 5 + [ctypes.c_long, _vp]),
     "liso_adamw_step_scaled_f32": (_i, [_vp, _vp, _vp, _vp, _sz] + [ctypes.c_double] * 6 + [ctypes.c_long, _vp]),
+    "liso_rmsprop_step_f32": (_i, [_vp, _vp, _vp, _sz] + [ctypes.c_double] * 4 + [_vp]),
     "liso_gather_f32": (_i, [_i, _vp, _vp, _vp, _vp]),
     # include/liso_bn.h
     "liso_bn_workspace_bytes": (_sz, [_i]),

@@ -54,6 +54,34 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, 
     }
 }
 
+// ---- RMSprop over one flat buffer (SLIM's optimizer: liso/slim/experiment.py:200-219, torch.optim.RMSprop defaults) ---------------------
+// torch's multi-tensor form, per element: sq = sq * alpha + (1 - alpha) * g * g;  p = p - lr * g / (sqrt(sq) + eps)
+// HBM-bound: 12 B read (p, g, sq) + 8 B written (p, sq) per element, one launch instead of five foreach launches per 1-3 chunks.
+__global__ __launch_bounds__(256) void rmsprop_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ sq,
+                                                           size_t n4, size_t n, float lr, float alpha, float w, float eps, float gscale) {
+    auto one = [&](float& pp, float gg, float& ss) {
+        gg = gg * gscale;
+        ss = fmaf(w, gg * gg, ss * alpha);
+        pp = fmaf(-lr, gg / (sqrtf(ss) + eps), pp);
+    };
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 pp = reinterpret_cast<float4*>(p)[i];
+        const float4 gg = reinterpret_cast<const float4*>(g)[i];
+        float4 ss = reinterpret_cast<float4*>(sq)[i];
+        one(pp.x, gg.x, ss.x);
+        one(pp.y, gg.y, ss.y);
+        one(pp.z, gg.z, ss.z);
+        one(pp.w, gg.w, ss.w);
+        reinterpret_cast<float4*>(p)[i] = pp;
+        reinterpret_cast<float4*>(sq)[i] = ss;
+    }
+    if (blockIdx.x == 0) {
+        const size_t i = 4 * n4 + threadIdx.x;
+        if (i < n) one(p[i], g[i], sq[i]);
+    }
+}
+
 // ---- gradients that autograd produced outside the flat buffer: one launch moves all of them into their slices ----------------------
 struct GatherTable {
     const float* src[LISO_GATHER_MAX];
@@ -120,5 +148,19 @@ extern "C" int liso_adamw_step_scaled_f32(float* param, const float* grad, float
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(adamw_flat_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
                        exp_avg_sq, n4, n, s);
+    return hipGetLastError() == hipSuccess ? LISO_OK : LISO_ELAUNCH;
+}
+
+extern "C" int liso_rmsprop_step_f32(float* param, const float* grad, float* square_avg, size_t n, double lr, double alpha, double eps,
+                                     double grad_scale, void* stream) {
+    if (n == 0) return LISO_OK;
+    if (!param || !grad || !square_avg) return LISO_EINVAL;
+    if ((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)square_avg) & 15) != 0) return LISO_EINVAL;
+    const size_t n4 = n / 4;
+    size_t blocks = (n4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(rmsprop_flat_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, square_avg, n4, n,
+                       (float)lr, (float)alpha, (float)(1.0 - alpha), (float)eps, (float)grad_scale);
     return hipGetLastError() == hipSuccess ? LISO_OK : LISO_ELAUNCH;
 }

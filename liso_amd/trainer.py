@@ -44,12 +44,17 @@ def get_optimizer_scheduler(cfg, box_predictor, total_steps=None, flat=False):
     return opt, sched
 
 
-def get_slim_optimizer_scheduler(slim_cfg, params):
+def get_slim_optimizer_scheduler(slim_cfg, params, flat=False):
     """slim/experiment.py:200-219: RMSprop(lr = initial) (or Adam) + linear warm-up over `warm_up.step_length` steps, then
-    linear decay to 5 % of the initial rate at `iterations.train`."""
+    linear decay to 5 % of the initial rate at `iterations.train`.  `flat` (GPU): RMSprop over flat buffers, one update launch
+    (liso_amd/utils/flat_adamw.py: FlatRMSprop)."""
     from liso_amd.utils.learning_rate import get_polynomial_decay_schedule_with_warmup
 
-    if slim_cfg.optimizer == "rmsprop":
+    if slim_cfg.optimizer == "rmsprop" and flat:
+        from liso_amd.utils.flat_adamw import FlatRMSprop
+
+        opt = FlatRMSprop(list(params), lr=slim_cfg.learning_rate.initial)
+    elif slim_cfg.optimizer == "rmsprop":
         opt = torch.optim.RMSprop(params, lr=slim_cfg.learning_rate.initial)
     elif slim_cfg.optimizer == "adam":
         opt = torch.optim.Adam(params, lr=slim_cfg.learning_rate.initial)
@@ -475,7 +480,10 @@ class SlimTrainer:
             self.model = torch.nn.parallel.DistributedDataParallel(
                 self.net, device_ids=[device.index] if device.type == "cuda" else None, bucket_cap_mb=64,
                 broadcast_buffers=False, gradient_as_bucket_view=True)
-        self.optimizer, self.lr_scheduler = get_slim_optimizer_scheduler(self.slim_cfg, self.net.parameters())
+        # (flat buffers unless DistributedDataParallel owns the gradients as views of ITS buckets)
+        flat = device.type == "cuda" and self.model is self.net and os.environ.get("LISO_FLAT_RMSPROP", "1") != "0"
+        self.optimizer, self.lr_scheduler = get_slim_optimizer_scheduler(self.slim_cfg, self.net.parameters(), flat=flat)
+        self._flat_opt = hasattr(self.optimizer, "flat_grad")
         import numpy as np
         half = 0.5 * np.array(cfg.data.bev_range_m, dtype=np.float32)
         self.bev_extent = np.concatenate([-half, half], axis=0)
@@ -489,11 +497,14 @@ class SlimTrainer:
             # bound to the warm-up's stream -- a cross-stream hop the capture cannot contain (wrong losses / crashes, measured)
             self.net.raft_network.defer_update_block_wgrad = "direct"
             params = [p for p in self.net.parameters() if p.requires_grad]
-            self._flat_grad = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=device)
-            off = 0
-            for p in params:  # gradients are views into one flat buffer: one memset, one all-reduce
-                p.grad = self._flat_grad[off:off + p.numel()].view_as(p)
-                off += p.numel()
+            if self._flat_opt:  # the optimizer's own flat gradient buffer (parameters, gradients, square averages: one element order)
+                self._flat_grad = self.optimizer.flat_grad
+            else:
+                self._flat_grad = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=device)
+                off = 0
+                for p in params:  # gradients are views into one flat buffer: one memset, one all-reduce
+                    p.grad = self._flat_grad[off:off + p.numel()].view_as(p)
+                    off += p.numel()
             # parameters whose gradients are produced INSIDE the captured step (everything but the pillar encoder, whose backward
             # runs eagerly behind the replay): with .grad = None during the captured backward pass autograd keeps the gradient
             # tensors instead of launching one add_ per parameter into the zeroed flat buffer (~100 launches per step), and one

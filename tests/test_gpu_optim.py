@@ -155,3 +155,41 @@ def test_multi_copy_equals_tensor_copies():
         assert torch.equal(dst, exp)
     assert torch.equal(d_host.cpu(), host) and torch.equal(d_cast.cpu(), torch.arange(6, dtype=torch.float64))
     assert torch.equal(base[:, 1].cpu(), torch.arange(8, dtype=torch.float32)) and float(base[:, 0].abs().max()) == 0
+
+
+@pytest.mark.gpu
+def test_flat_rmsprop_follows_torch_rmsprop():
+    """FlatRMSprop (one liso_rmsprop_step_f32 launch over flat buffers) against torch.optim.RMSprop with the reference's settings
+    (liso/slim/experiment.py:200-219: defaults + a LambdaLR schedule): 20 steps on tensors of odd sizes and channels-last filters,
+    gradients arriving as `.grad` views, as tensors of their own (zero_grad(set_to_none=True)) and not at all for one parameter"""
+    from liso_amd.utils.flat_adamw import FlatRMSprop
+
+    g = torch.Generator().manual_seed(3)
+    shapes = [(64, 2, 7, 7), (96,), (33, 5), (192, 304, 3, 3), (7,)]
+    base = [torch.randn(s, generator=g) for s in shapes]
+    pa = [torch.nn.Parameter(t.clone().cuda()) for t in base]
+    pb = [torch.nn.Parameter(t.clone().cuda()) for t in base]
+    pb[3].data = pb[3].data.contiguous(memory_format=torch.channels_last)
+    oa = torch.optim.RMSprop(pa, lr=1e-2)
+    ob = FlatRMSprop(pb, lr=1e-2)
+    sched = lambda o: torch.optim.lr_scheduler.LambdaLR(o, lambda k: 1.0 / (1 + 0.1 * k))  # noqa: E731
+    sa, sb = sched(oa), sched(ob)
+    for step in range(20):
+        grads = [torch.randn(s, generator=g).cuda() * (10.0 ** (step % 3 - 1)) for s in shapes]
+        oa.zero_grad(set_to_none=True)
+        ob.zero_grad(set_to_none=step % 2 == 0)
+        for k, (a, b, gr) in enumerate(zip(pa, pb, grads)):
+            if k == 4 and step < 10:
+                continue  # (no gradient for this parameter during the first steps)
+            a.grad = gr.clone()
+            if step % 2 == 0:
+                b.grad = gr.clone()
+            else:
+                b.grad.copy_(gr)
+        oa.step(), ob.step()
+        sa.step(), sb.step()
+    for k, (a, b) in enumerate(zip(pa, pb)):
+        assert torch.allclose(a, b, rtol=2e-6, atol=1e-7), (k, float((a - b).abs().max()))
+    sd = ob.state_dict()
+    assert set(sd["state"][0].keys()) == {"step", "square_avg"} and float(sd["state"][0]["step"]) == 20.0
+    assert torch.allclose(oa.state_dict()["state"][0]["square_avg"], sd["state"][0]["square_avg"], rtol=2e-6, atol=1e-12)
