@@ -22,6 +22,7 @@
 // order by a second kernel: no float atomics, bitwise reproducible.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/liso_conv.h"
 #include "../../include/liso_iou3d.h"
@@ -35,7 +36,7 @@ typedef short s4 __attribute__((ext_vector_type(4)));
 typedef s4 __attribute__((address_space(3))) * lds_s4_ptr;
 
 constexpr int kBM = 128, kBN = 128, kBK = 32, kThreads = 256;
-constexpr int kMaxSplits = 8;
+constexpr int kMaxSplits = 16;
 // F32X3 planes: [k][128 bf16 + 64 B] (the four rows a transposing read touches tile the 64 banks) and, for the k-contiguous A of G1,
 // [k8][128 rows][8 bf16] + 64 B per k8 group (the eight groups a wave's split stores touch start 64 B apart)
 constexpr int kPS = kBN * 2 + 64;         // 320
@@ -430,7 +431,8 @@ struct Plan {
 };
 
 inline int pick_splits(long tiles, int slabs) {
-    int s = (int)((256 + tiles - 1) / tiles);  // fill 256 CUs
+    static const int target = getenv("LISO_CORR_BWD_BLOCKS") ? atoi(getenv("LISO_CORR_BWD_BLOCKS")) : 512;  // (two blocks per CU: 143.7 us at B = 2, 64 x 64 against 171.5 at 256 and 226.4 at 128)
+    int s = (int)((target + tiles - 1) / tiles);  // fill the CUs
     if (s > kMaxSplits) s = kMaxSplits;
     if (s > slabs) s = slabs;
     return s < 1 ? 1 : s;

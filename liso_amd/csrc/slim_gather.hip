@@ -28,12 +28,15 @@ __global__ void bev_gather_fwd_kernel(const float* __restrict__ grid, const int*
 // up its chunk heads (<= len / kChunk steps) and write the cell's gradient row.  Fixed order, no atomics.
 constexpr int kChunk = 16;
 
-// 32 lanes per sorted row: the row's cell / rank are read once per half-wave (not once per channel), lanes = channels.
+// LANES lanes per sorted row (32, or 8 for maps of <= 8 channels -- the decoder's 8-channel network output and 3-channel flow | weight
+// maps: with 32 lanes per row three quarters of every wave idled through the index loads): the row's cell / rank are read once per
+// lane group (not once per channel), lanes = channels.
+template <int LANES>
 __global__ __launch_bounds__(256) void bev_gather_bwd_chunk_kernel(const float* __restrict__ grad_out, const int* __restrict__ sorted_lin,
                                                                    const int* __restrict__ order, const int* __restrict__ seg_rank,
                                                                    long n_rows, int c, float* __restrict__ partial) {
-    const long s = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
-    const int lane = threadIdx.x & 31;
+    const long s = ((long)blockIdx.x * blockDim.x + threadIdx.x) / LANES;
+    const int lane = threadIdx.x % LANES;
     if (s >= n_rows) return;
     const int cell = sorted_lin[s];
     const int rank0 = seg_rank[s];
@@ -50,7 +53,7 @@ __global__ __launch_bounds__(256) void bev_gather_bwd_chunk_kernel(const float* 
         src[k] = in_range ? order[s + k] : 0;
         if (rows == kChunk && rk != rank0 + k) rows = k;
     }
-    for (int ch = lane; ch < c; ch += 32) {
+    for (int ch = lane; ch < c; ch += LANES) {
         float v[kChunk];
 #pragma unroll
         for (int k = 0; k < kChunk; k++) v[k] = k < rows ? grad_out[(size_t)src[k] * c + ch] : 0.f;
@@ -61,15 +64,16 @@ __global__ __launch_bounds__(256) void bev_gather_bwd_chunk_kernel(const float* 
     }
 }
 
+template <int LANES>
 __global__ __launch_bounds__(256) void bev_gather_bwd_segment_kernel(const float* __restrict__ partial, const int* __restrict__ sorted_lin,
                                                                      const int* __restrict__ seg_rank, long n_rows, int c,
                                                                      float* __restrict__ grad_grid) {
-    const long s = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
-    const int lane = threadIdx.x & 31;
+    const long s = ((long)blockIdx.x * blockDim.x + threadIdx.x) / LANES;
+    const int lane = threadIdx.x % LANES;
     if (s >= n_rows) return;
     const int cell = sorted_lin[s];
     if (cell < 0 || seg_rank[s] != 0) return;
-    for (int ch = lane; ch < c; ch += 32) {
+    for (int ch = lane; ch < c; ch += LANES) {
         float acc = 0.f;
         for (long j = s; j < n_rows && sorted_lin[j] == cell; j += kChunk) acc += partial[(size_t)j * c + ch];
         grad_grid[(size_t)cell * c + ch] = acc;
@@ -123,10 +127,16 @@ int liso_bev_gather_bwd_f32(const float* grad_out, const int* sorted_lin, const 
     if (n_rows < 0 || c < 1) return LISO_EINVAL;
     if (n_rows == 0) return LISO_OK;
     if (!grad_out || !sorted_lin || !order || !seg_rank || !partial || !grad_grid) return LISO_EINVAL;
-    const unsigned blocks = (unsigned)((n_rows * 32 + 255) / 256);
     hipStream_t st = (hipStream_t)stream;
-    bev_gather_bwd_chunk_kernel<<<blocks, 256, 0, st>>>(grad_out, sorted_lin, order, seg_rank, n_rows, c, partial);
-    bev_gather_bwd_segment_kernel<<<blocks, 256, 0, st>>>(partial, sorted_lin, seg_rank, n_rows, c, grad_grid);
+    if (c <= 8) {
+        const unsigned blocks = (unsigned)((n_rows * 8 + 255) / 256);
+        bev_gather_bwd_chunk_kernel<8><<<blocks, 256, 0, st>>>(grad_out, sorted_lin, order, seg_rank, n_rows, c, partial);
+        bev_gather_bwd_segment_kernel<8><<<blocks, 256, 0, st>>>(partial, sorted_lin, seg_rank, n_rows, c, grad_grid);
+    } else {
+        const unsigned blocks = (unsigned)((n_rows * 32 + 255) / 256);
+        bev_gather_bwd_chunk_kernel<32><<<blocks, 256, 0, st>>>(grad_out, sorted_lin, order, seg_rank, n_rows, c, partial);
+        bev_gather_bwd_segment_kernel<32><<<blocks, 256, 0, st>>>(partial, sorted_lin, seg_rank, n_rows, c, grad_grid);
+    }
     return check_launch();
 }
 

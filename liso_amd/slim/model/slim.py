@@ -103,9 +103,8 @@ class SLIM(nn.Module):
         B = pa["pcl"].shape[0]
         fs = self.slim_cfg.model.u_net.final_scale
         cat = lambda a, b: torch.cat([a.to(dev), b.to(dev)], dim=0)  # noqa: E731
-        tile = lambda t: torch.cat([t[:B]] * n_it + [t[B:]] * n_it, dim=0)  # noqa: E731
-        valid_all, coors_all = tile(cat(pa["pcl_is_valid"], pb["pcl_is_valid"])), tile(cat(pa["pillar_coors"], pb["pillar_coors"]))
-        return BevGatherPlan(torch.div(coors_all, fs, rounding_mode="trunc"), valid_all, grid_hw).prepare_backward()
+        valid, coors = cat(pa["pcl_is_valid"], pb["pcl_is_valid"]), cat(pa["pillar_coors"], pb["pillar_coors"])
+        return BevGatherPlan.tiled(torch.div(coors, fs, rounding_mode="trunc"), valid, grid_hw, n_it, B).prepare_backward()
 
     def forward(self, sample_data_t0, sample_data_t1, summaries=None, canvases=None, gather_plan=None):
         """`canvases` (extension): the pillar canvases of both sweeps, `raft_network.encode_pillars(...)`, computed by the caller;
@@ -148,8 +147,8 @@ class SLIM(nn.Module):
             tile = lambda t: torch.cat([t[:B]] * n_it + [t[B:]] * n_it, dim=0)  # noqa: E731
             pc_all, valid_all, coors_all = tile(pc), tile(valid), tile(coors)
             self.gather_plan_meta = (n_it, tuple(int(v) for v in out_fw[0].shape[1:3]))
-            plan = gather_plan if gather_plan is not None else BevGatherPlan(torch.div(coors_all, fs, rounding_mode="trunc"), valid_all,
-                                                                             out_fw[0].shape[1:3])
+            plan = gather_plan if gather_plan is not None else BevGatherPlan.tiled(torch.div(coors, fs, rounding_mode="trunc"), valid,
+                                                                                   out_fw[0].shape[1:3], n_it, B)
             out_all = self.head_decoder_fw(net_all, pointwise_valid_mask=valid_all, pointwise_voxel_coordinates=coors_all, pc=pc_all,
                                            filled_pillar_mask=tile(filled), odom=tile(odom), inv_odom=tile(inv_odom),
                                            gather_plan=plan, pointwise_only=self.training and getattr(self, "pointwise_decoding", True),

@@ -28,8 +28,40 @@ class BevGatherPlan:
         self.shape = (B, N, H, W)
         self._sorted = None
 
+    @classmethod
+    def tiled(cls, pointwise_voxel_coordinates_fs, pointwise_valid_mask, grid_hw, n_it, half):
+        """The plan of the batch [samples[:half]] * n_it + [samples[half:]] * n_it -- what the decoder sees when the network outputs of
+        all RAFT iterations and both flow directions are decoded at once (slim.py: forward) -- from the 2 * half DISTINCT samples: the
+        same cloud repeated n_it times has the same cells, so one segmented sort of the distinct clouds (2 x 120k keys instead of
+        2.9 M) is expanded with per-copy offsets.  Rows of one cell stay consecutive and in point order inside every copy's block,
+        which is all the segmented-sum adjoint asks for (liso_bev_gather_bwd_f32): its sums are bit for bit those of the flat sort."""
+        small = cls(pointwise_voxel_coordinates_fs, pointwise_valid_mask, grid_hw)
+        n2, N = pointwise_valid_mask.shape
+        H, W = int(grid_hw[0]), int(grid_hw[1])
+        assert 0 < half <= n2 and n_it >= 1
+        dev = small.lin.device
+        src = torch.cat([torch.arange(half, device=dev).repeat(n_it), torch.arange(half, n2, device=dev).repeat(n_it)])
+        off = ((torch.arange(src.numel(), device=dev) - src) * (H * W)).to(torch.int32)[:, None]
+        rows = small.lin.view(n2, N)
+        self = object.__new__(cls)
+        picked = rows[src]
+        self.lin = torch.where(picked >= 0, picked + off, picked).reshape(-1).contiguous()
+        self.shape = (int(src.numel()), N, H, W)
+        self._sorted = None
+        self._tile = (rows, src, off, N)
+        return self
+
     def _sort(self):
         """the cell-sorted view of the list: only the adjoint needs it (inference never builds it)"""
+        if self._sorted is None and getattr(self, "_tile", None) is not None:
+            rows, src, off, N = self._tile
+            s_rows, o_rows = torch.sort(rows, dim=1, stable=True)  # one segmented sort of the distinct samples
+            pos = torch.arange(N, device=rows.device, dtype=torch.int32)[None, :]
+            rank = (pos - torch.searchsorted(s_rows, s_rows, right=False).to(torch.int32))
+            picked = s_rows[src]
+            sorted_lin = torch.where(picked >= 0, picked + off, picked).reshape(-1).contiguous()
+            order = (o_rows.to(torch.int32)[src] + (torch.arange(src.numel(), device=rows.device, dtype=torch.int32) * N)[:, None])
+            self._sorted = (sorted_lin, order.reshape(-1).contiguous(), rank[src].reshape(-1).contiguous())
         if self._sorted is None:
             sorted_lin, order = torch.sort(self.lin, stable=True)
             pos = torch.arange(sorted_lin.numel(), device=self.lin.device, dtype=torch.int32)

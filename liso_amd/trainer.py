@@ -341,6 +341,8 @@ class DetectorTrainer:
                 if self._pack_jobs:  # the forward / data-gradient panels of every layer from ONE launch (recorded in the warm-up)
                     self._step_packs = MC.batched_pack(self._pack_jobs)
             MC.set_step_packs(getattr(self, "_step_packs", None))
+            det_cus = MC.roles_cus(getattr(self, "roles_cus", 0))  # (experiment knob of the pipelined loop: LisoLoopTrainer.detector_cus)
+            det_cus.__enter__()
             MC.set_direct_grads(True, keep_touched=part == 2)  # gradients of conv / BatchNorm parameters land in the flat buffer without an add each
             gathered = self._gather_params or []
             for p_, _ in gathered:  # (autograd then KEEPS the gradient tensor it is handed instead of adding it into the zeroed slice)
@@ -359,6 +361,7 @@ class DetectorTrainer:
                     with MC.wgrad_side(self._wgrad_stream):
                         cut.finish()
             finally:
+                det_cus.__exit__(None, None, None)
                 MC.set_step_packs(None)
                 MC.set_direct_grads(False, keep_touched=True)
                 self._gather_gradients(gathered, add=part == 2)
@@ -917,6 +920,8 @@ class LisoLoopTrainer:
         # compute units the captured SLIM inference's persistent 3x3 convolutions may take while the pipeline overlaps it with the
         # detector step (0 = all): half the chip by default, see _infer_flow_padded
         self.infer_cus = 0
+        if device.type == "cuda" and self.overlap and os.environ.get("LISO_DETECTOR_CUS"):
+            self.detector.roles_cus = int(os.environ["LISO_DETECTOR_CUS"])  # (experiment: the detector's persistent convolutions capped too)
         if device.type == "cuda" and self.overlap:
             n_cu = torch.cuda.get_device_properties(device).multi_processor_count
             self.infer_cus = int(os.environ.get("LISO_INFER_CUS", str(n_cu // 2)))
