@@ -55,13 +55,25 @@ class BevGatherPlan:
         """the cell-sorted view of the list: only the adjoint needs it (inference never builds it)"""
         if self._sorted is None and getattr(self, "_tile", None) is not None:
             rows, src, off, N = self._tile
-            s_rows, o_rows = torch.sort(rows, dim=1, stable=True)  # one segmented sort of the distinct samples
-            pos = torch.arange(N, device=rows.device, dtype=torch.int32)[None, :]
-            rank = (pos - torch.searchsorted(s_rows, s_rows, right=False).to(torch.int32))
-            picked = s_rows[src]
-            sorted_lin = torch.where(picked >= 0, picked + off, picked).reshape(-1).contiguous()
-            order = (o_rows.to(torch.int32)[src] + (torch.arange(src.numel(), device=rows.device, dtype=torch.int32) * N)[:, None])
-            self._sorted = (sorted_lin, order.reshape(-1).contiguous(), rank[src].reshape(-1).contiguous())
+            n2 = rows.shape[0]
+            dev = rows.device
+            # ONE flat (radix) sort of the distinct samples' keys (a per-row sort of two long rows takes torch's merge-sort path:
+            # 24 launches, 0.14 ms).  The flat order is [invalid rows of every sample | sample 0's cells | sample 1's cells | ...]:
+            # sample b's valid rows are the range [start_b, start_b + nv_b) of it; every copy's block is those rows followed by
+            # invalid padding up to N rows (the adjoint skips cell < 0), all index arithmetic on the device.
+            s_flat, o_flat = torch.sort(rows.reshape(-1), stable=True)
+            pos = torch.arange(s_flat.numel(), device=dev, dtype=torch.int32)
+            rank_flat = pos - torch.searchsorted(s_flat, s_flat, right=False).to(torch.int32)
+            nv = (rows >= 0).sum(dim=1)                                   # valid rows per distinct sample
+            start = (rows.numel() - nv.sum()) + torch.cumsum(nv, 0) - nv  # first valid row of sample b in the flat order
+            k = torch.arange(N, device=dev)[None, :]
+            idx = (start[src][:, None] + k).clamp(max=s_flat.numel() - 1)
+            ok = k < nv[src][:, None]
+            sorted_lin = torch.where(ok, s_flat[idx] + off, torch.full_like(off, -1)).reshape(-1).contiguous()
+            local = (o_flat[idx] - (src * N)[:, None]).to(torch.int32)   # row inside its sample
+            order = torch.where(ok, local + (torch.arange(src.numel(), device=dev, dtype=torch.int32) * N)[:, None], torch.zeros_like(local))
+            rank = torch.where(ok, rank_flat[idx], torch.zeros_like(local))
+            self._sorted = (sorted_lin, order.reshape(-1).contiguous(), rank.reshape(-1).contiguous())
         if self._sorted is None:
             sorted_lin, order = torch.sort(self.lin, stable=True)
             pos = torch.arange(sorted_lin.numel(), device=self.lin.device, dtype=torch.int32)
