@@ -150,3 +150,55 @@ def test_iou3d_nms_buffers():
         n = M.nms_gpu(tb, keep, 0.1)
         gd.check()
     assert 0 < n <= 3000
+
+
+def test_voxel_slots_at_the_largest_slot_count_and_crowded_pillars():
+    """max_points = 32, the largest the ABI takes (round-5 advisor finding on voxel_slots_kernel: on its crowded path, n > 64 points, the
+    rounds ran to max_points whatever n -- harmless while max_points <= 32 < 64 is enforced, bounded by n since round 6; a larger
+    max_points is refused).  Pillars of 3 .. 500 points against a host construction: the first min(n, 32) slots are the pillar's point
+    indices in ascending order, the slots behind them keep what the caller put there (-7)."""
+    import ctypes
+
+    import liso_amd.networks.pcl_to_feature_grid.pcl_to_feature_grid as P
+    from liso_amd import _lib as L
+
+    _, net = _pfn(64, 64.0)
+    net.max_num_points = 32
+    pcfg = net._pcfg(4)
+    g = torch.Generator().manual_seed(5)
+    sizes = [3, 31, 32, 33, 64, 65, 500]
+    pts = []
+    for k, n in enumerate(sizes):  # pillar k: cell (2 k + 1, 5), 1-m cells on [-32, 32)^2
+        pts.append(torch.rand(n, 4, generator=g) * torch.tensor([0.9, 0.9, 2.0, 1.0]) + torch.tensor([-32.0 + 2 * k + 1, -32.0 + 5, -1.0, 0.0]))
+    cloud = torch.cat(pts)[torch.randperm(sum(sizes), generator=g)].to(DEV).contiguous()
+    with guarded() as gd:
+        real_empty = torch.empty
+
+        def poisoned(*a, **k):  # the slots buffer starts as -7: untouched entries stay recognisable
+            t = real_empty(*a, **k)
+            if k.get("dtype") == torch.int32 and t.dim() == 2 and t.shape[1] == 32:
+                t.fill_(-7)
+            return t
+
+        P.torch.empty = poisoned
+        try:
+            coors, num_points, slots, num_voxels, _ = P.voxelize_raw(cloud, [0, cloud.shape[0]], pcfg)
+        finally:
+            P.torch.empty = real_empty
+        gd.check()
+    nv = int(num_voxels[0])
+    assert nv == len(sizes)
+    cell = ((cloud[:, 0] + 32).floor().long() * 64 + (cloud[:, 1] + 32).floor().long()).cpu()
+    for v in range(nv):
+        idx = torch.nonzero(cell == int(coors[v, 2]) * 64 + int(coors[v, 3])).flatten()
+        kept = min(idx.numel(), 32)
+        assert int(num_points[v]) == kept, (v, idx.numel(), int(num_points[v]))
+        got = slots[v].cpu()
+        assert torch.equal(got[:kept].long(), idx[:kept]), (v, idx.numel())
+        assert bool((got[kept:] == -7).all()), (v, idx.numel(), got[kept:kept + 5])
+    pcfg.max_points = 33  # beyond the one-wave-per-pillar mapping: refused, not truncated
+    off = (ctypes.c_int * 2)(0, cloud.shape[0])
+    ws = torch.empty(1 << 22, dtype=torch.uint8, device=DEV)
+    rc = L.lib().liso_pillars_voxelize_f32(L.ptr(cloud), off, 1, ctypes.byref(pcfg), L.ptr(coors), L.ptr(num_points), L.ptr(slots),
+                                           L.ptr(num_voxels), L.ptr(ws), L.ptr(ws), ws.numel(), L.stream_ptr())
+    assert rc != 0
