@@ -372,8 +372,8 @@ def child_leg(extra, steps=10, warmup=3, timeout_s=420):
 class PinnedLoader:
     """`--loader` ("separately with a pinned-memory loader"; the reference feeds its step from DataLoader workers,
     liso_cli.py:362-380): the ring of sweep pairs lives in PINNED HOST memory.  Every step uploads the pairs that enter the pipeline's
-    announcement window at the NEXT step -- fresh device tensors, H2D copies on a copy stream -- and the step that first announces them
-    waits for that upload's event on its own stream (the trainer orders its side streams behind the head of the step).  Device
+    announcement window at the NEXT step -- fresh device tensors, H2D copies on a copy stream -- and hands the upload's event to the step
+    that first announces them (`step_batch(..., inputs_ready=event)`: every stream of the pipeline that reads them waits for it).  Device
     tensors of a pair are dropped once its detector step is enqueued.  Nothing of a pair is resident before its upload."""
 
     def __init__(self, pairs, dev, torch):
@@ -440,19 +440,18 @@ class PinnedLoader:
             i = step.count * batch
             step.count += 1
             need = range(i, i + batch + n_up)
+            ready = None  # the copy stream's event behind the newest upload that this step announces: every pipeline stream waits for it
             if self.pending is not None:  # uploaded during the previous step
-                got, done = self.pending
-                cur.wait_event(done)
+                got, ready = self.pending
                 self.window.update(got)
                 self.pending = None
             missing = [j for j in need if j not in self.window]
             if missing:  # (first step only: nothing was announced before it)
-                got, done = self._upload(missing)
-                cur.wait_event(done)
+                got, ready = self._upload(missing)
                 self.window.update(got)
             self.pending = self._upload(range(i + batch + n_up, i + 2 * batch + n_up))  # enters the window at the next step
             loss = trainer.step_batch([self.window[j] for j in range(i, i + batch)],
-                                      upcoming=tuple(self.window[j] for j in range(i + batch, i + batch + n_up)))
+                                      upcoming=tuple(self.window[j] for j in range(i + batch, i + batch + n_up)), inputs_ready=ready)
             for j in range(i, i + batch):
                 del self.window[j]
             return loss

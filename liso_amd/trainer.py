@@ -1354,6 +1354,11 @@ class LisoLoopTrainer:
         m = self._take(self._mined, pair)
         if m is None:
             return None
+        if os.environ.get("LISO_NO_COUNT_WAIT") == "1":  # (experiment: what does the host's wait for the cluster count cost?  scripts/loop_floor.py)
+            cur.wait_event(m.done)
+            for t in list(m.targets.values()) + [v for v in m.boxes.__dict__.values() if torch.is_tensor(v)]:
+                t.record_stream(cur)
+            return m.targets, m.boxes
         m.done.synchronize()  # (stage B of this pair was enqueued one or two steps ago)
         cur.wait_event(m.done)
         if int(m.cluster_count[0]) > self.box_capacity:  # more clusters than slots: the exact, reference-shaped call
@@ -1371,28 +1376,33 @@ class LisoLoopTrainer:
         Prefetched results are matched by object identity; anything announced but not requested next is dropped."""
         return self.step_batch([(sample_t0, sample_t1)], upcoming)
 
-    def step_batch(self, pairs, upcoming=()):
+    def step_batch(self, pairs, upcoming=(), inputs_ready=None):
         """`_step_batch` with the convolution plans of a shared GPU (the three pipeline stages run next to each other)"""
         if self.device.type != "cuda":
             return self._step_batch(pairs, upcoming)
         from liso_amd.utils import mfma_conv as MC
 
         with MC.shared_gpu():
-            return self._step_batch(pairs, upcoming)
+            return self._step_batch(pairs, upcoming, inputs_ready)
 
-    def _step_batch(self, pairs, upcoming=()):
+    def _step_batch(self, pairs, upcoming=(), inputs_ready=None):
         """one iteration on a BATCH of sweep pairs (each a (sample_t0, sample_t1) with batch size 1): boxes are mined per pair, the
         detector takes ONE train step on the batch of len(pairs) clouds and target maps -- the reference's `batch_size` (2 in
         liso_config.yml:121, 4 in the README commands :637-639), BatchNorm statistics over that batch like the reference's.
         `upcoming`: the pairs of the following calls in order (flat list); the pipeline keeps stage B two batches ahead."""
         cuda = self.device.type == "cuda"
         cur = torch.cuda.current_stream(self.device) if cuda else None
-        if cuda and self.overlap:
-            # whatever the caller enqueued on ITS stream before this call (host -> device uploads of the announced clouds, a device-side
-            # data pipeline) is ordered in front of the side streams' reads of `upcoming`: an event recorded here, BEFORE this step's
-            # detector work, so that the side streams do not queue behind that work (a wait_stream at their point of use would)
-            self._inputs_ready = torch.cuda.Event()
-            self._inputs_ready.record(cur)
+        if cuda:
+            # `inputs_ready`: an event the CALLER recorded on the stream that produced / uploaded the announced samples (a DataLoader's
+            # copy stream: bench.py --loader).  Every stream of the pipeline that reads them waits for it.  Without it the samples
+            # must be complete when they are announced.  (An event recorded HERE on the caller's stream -- the first form of this,
+            # early in round 6 -- sits behind the previous step's whole detector work in that stream: the side stages of step i then
+            # start only when detector step i - 1 has finished, the host blocks on their results ~2 ms per step and the detector's
+            # stream runs dry while the host enqueues the next step: 4.26 instead of 4.10 ms per step, 3.16 instead of 2.72 with both
+            # side stages cached; scripts/loop_floor.py.)
+            self._inputs_ready = inputs_ready
+            if inputs_ready is not None:
+                cur.wait_event(inputs_ready)
         mined = []
         for pair in pairs:
             sample_t0, sample_t1 = pair
@@ -1440,7 +1450,8 @@ class LisoLoopTrainer:
             # pipeline's critical path, and these launches sat at the head of every step of it
             nxt = [c for p_ in upcoming[:len(pairs)] for c in p_[0]["pcl_full_no_ground_ta"]]
             side = self._mine_stream
-            side.wait_event(self._inputs_ready)
+            if self._inputs_ready is not None:
+                side.wait_event(self._inputs_ready)
             with torch.cuda.stream(side):
                 got_prep = self.detector.net.model.pfn.prepare(nxt)
                 done = torch.cuda.Event()
