@@ -7,7 +7,10 @@ the own kernels -- `mfma_conv.on_device` (-> False: the modules take their host 
 that forward accepts device tensors) -- and then runs bench.py's main() with --eager.  Round 2's numbers of this comparison are in
 profiles/r02_compare/.
 
-    python scripts/compare_backends.py --workload detector --steps 10 --warmup 3 --no-cpu-baseline --no-iou3d
+    python scripts/compare_backends.py --steps 10 --warmup 3 --no-cpu-baseline --no-iou3d        (the detector train step, configs[2])
+
+Only the DETECTOR's modules have a host forward to fall back on (rpn.py / center_head.py gate on `mfma_conv.on_device`); SLIM's encoders
+and update block call the kernels' entry points directly, so the comparison is the detector workload.
 """
 import os
 import sys
@@ -24,6 +27,9 @@ MC.supported = lambda *a, **k: False
 
 import bench  # noqa: E402
 
+if "--workload" not in sys.argv:
+    sys.argv += ["--workload", "detector"]
+assert sys.argv[sys.argv.index("--workload") + 1] == "detector", "the library-backed comparison covers the detector workload"
 if "--eager" not in sys.argv:
     sys.argv.append("--eager")
 for flag in ("--no-fp32-leg", "--no-legs"):
