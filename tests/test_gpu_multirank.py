@@ -161,6 +161,13 @@ def test_bench_ranks_on_one_gpu_reports_world_and_identical_replicas(workload, w
         assert line["config"]["dist"]["gradient_buckets"] == 2 and line["config"]["dist"]["world_size"] == world
     assert line["replicas_identical"] is True
     assert line["value"] > 0 and line["final_loss"] == line["final_loss"]
+    # round 6: the line itself shows how many ranks the process group spanned and what the gradient collective cost a step
+    assert line["config"]["dist"]["ranks_seen"] == world and line["config"]["dist"]["devices_visible"] >= 1
+    if workload != "slim":
+        dc = line["dist_cost"]
+        assert dc["allreduce_bytes"] > 1 << 20 and dc["allreduce_alone_ms"] > 0 and dc["ms_per_step_without_collective"] > 0
+        assert abs(dc["exposed_allreduce_ms_per_step"] - (line["ms_per_step"] - dc["ms_per_step_without_collective"])) < 1e-9
+    assert line["step_times"]["median_ms"] > 0 and line["step_roofline"]["algorithmic_flop_per_step"] > 0
 
 
 def test_rccl_process_group_next_to_graph_captures_and_replays():
