@@ -263,12 +263,15 @@ def cpu_baseline_loop(cfg, trainer, s0, s1, torch):
     from oracle.liso_loop import timed_loop_step
 
     torch.set_num_threads(min(os.cpu_count() or 1, 32))
-    secs, stages, n = timed_loop_step(cfg, {k: v.detach().float().cpu() for k, v in trainer.slim.state_dict().items()},
-                                      trainer.detector.net.state_dict(), s0, s1, GRID, BEV_RANGE)
+    slim_sd = {k: v.detach().float().cpu() for k, v in trainer.slim.state_dict().items()}
+    runs = [timed_loop_step(cfg, slim_sd, trainer.detector.net.state_dict(), s0, s1, GRID, BEV_RANGE) for _ in range(3)]  # (~2 s each)
+    runs.sort(key=lambda r_: r_[0])
+    secs, stages, n = runs[1]  # the median of three samples (one sample moved 1.0-1.3 frames/s between runs of round 5)
     return {"value": 2.0 / secs, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"1 sweep pair = 2 frames ({N_POINTS} pts each, {GRID}x{GRID} BEV), one fused LISO iteration (SLIM fwd, "
-                      f"sklearn DBSCAN + moments + Kabsch, NMS, targets, detector fwd+bwd), fp32 torch-CPU port, {secs:.2f} s, "
-                      f"{n} mined boxes", "stage_seconds": {k: round(v, 4) for k, v in stages.items()}}
+                      f"sklearn DBSCAN + moments + Kabsch, NMS, targets, detector fwd+bwd), fp32 torch-CPU port, median of 3 runs "
+                      f"({', '.join(f'{r_[0]:.2f}' for r_ in runs)} s), {n} mined boxes",
+            "stage_seconds": {k: round(v, 4) for k, v in stages.items()}}
 
 
 def bench_iou3d(dev, torch, with_cpu=True):
