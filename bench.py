@@ -547,7 +547,7 @@ def main():
         overlap = not (args.eager or args.no_overlap)
         # --dtype fp32 = every convolution (SLIM and detector) on the native fp32 MFMA; --dtype f32x3 = fp32 tensors everywhere,
         # three bf16 MFMAs per product (the parity-conformant configuration with the highest throughput)
-        trainer = LisoLoopTrainer(cfg, dev, compute_dtype=dtype, total_steps=args.steps + args.warmup + 8, use_graph=not args.eager,
+        trainer = LisoLoopTrainer(cfg, dev, compute_dtype=dtype, total_steps=2 * (args.steps + args.warmup) + 64, use_graph=not args.eager,
                                   overlap=overlap, infer_batch=max(1, args.lookahead - 1 - args.flow_ahead), flow_ahead=args.flow_ahead,
                                   exact={"fp32": True, "f32x3": False}.get(args.dtype))
         # a ring of different sweep pairs; step i trains on pair i while (overlap) pairs i+1 / i+2 are in the mining stages.  Like real
@@ -617,6 +617,16 @@ def main():
         torch.cuda.synchronize()
         main_stream = torch.cuda.Stream(device=dev, priority=int(os.environ["LISO_MAIN_PRIORITY"]))
         torch.cuda.set_stream(main_stream)
+    precapture_steps = 0
+    if args.workload == "loop" and not args.eager:
+        # hipGraph captures are one-time setup, not steady state: the inference graph has one signature per (pairs per replay, largest
+        # point-count bucket of the batch), the box-mining graph one per bucket, and the ring of 16 sweep pairs of 16 different sizes
+        # meets them all within one round -- more steps than the driver's --warmup.  One round (+ the pipeline's depth) of untimed steps
+        # in front of the W warm-up steps, the same number on every rank (the steps hold collectives), reported in
+        # config.graph_captures; `inside_timed_region` shows that none was left for the timed steps.
+        precapture_steps = n_pairs // batch + 2 + trainer.infer_batch
+        for _ in range(precapture_steps):
+            step()
     for _ in range(args.warmup):
         step()
     captures_after_warmup = None
@@ -849,7 +859,8 @@ def main():
                            "graph_captures": {"inference": len(trainer._infer_graphs), "box_mining": trainer.mine_captures,
                                               "inside_timed_region": (len(trainer._infer_graphs) - captures_after_warmup[0]) +
                                               (trainer.mine_captures - captures_after_warmup[1]),
-                                              "box_mining_eager_fallbacks": trainer.mine_eager_fallbacks}}
+                                              "box_mining_eager_fallbacks": trainer.mine_eager_fallbacks,
+                                              "precapture_steps": precapture_steps}}
                           if args.workload == "loop" else {}),
                        "launch": ("eager" if not graphed else "hipGraph replay of fwd+loss+bwd, eager RMSprop" if args.workload == "slim"
                                   else "hipGraph replays (SLIM inference; detector backbone+head+loss fwd/bwd), eager pillar encoder / "
