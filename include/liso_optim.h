@@ -60,6 +60,15 @@ int liso_gather_f32(int count, const void* const* src, void* const* dst, const s
 #define LISO_MULTI_COPY_MAX 24
 int liso_multi_copy(int n, void* const* dst, const void* const* src, const size_t* bytes, void* stream);
 
+/* `n` 2-D copies in one launch per LISO_MULTI_COPY_ROWS_MAX jobs: job k copies rows[k] rows of row_bytes[k] contiguous bytes,
+ * dst_stride[k] / src_stride[k] bytes between consecutive rows (everything a multiple of 4).  The merged filters of parallel
+ * convolutions (block-diagonal / concatenated / channel-permuted: liso/slim/model/update.py:29-164 and
+ * liso/networks/centerpoint/center_head.py:60-117 run their parallel branches as single launches) are assembled from the modules' own
+ * parameters -- and their gradients handed back -- by one such launch instead of one framework copy per block. */
+#define LISO_MULTI_COPY_ROWS_MAX 32
+int liso_multi_copy_rows(int n, void* const* dst, const void* const* src, const unsigned* rows, const unsigned* row_bytes,
+                         const size_t* dst_stride, const size_t* src_stride, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -85,6 +85,44 @@ def multi_copy(pairs):
             check(lib().liso_multi_copy(n, dst, src, nb, stream_ptr()), "multi_copy")
 
 
+def copy_blocks(jobs):
+    """`jobs`: (dst, src) pairs of fp32 tensors that are 2-D "rows" views -- dst[i] <- src[i] where both index the same logical block
+    [rows, cols...] with the trailing dimensions contiguous and one stride between rows (a filter block inside a merged filter, a
+    column range of a matrix, a whole contiguous tensor) -- as ONE launch (include/liso_optim.h: liso_multi_copy_rows)."""
+    import torch
+
+    n = len(jobs)
+    if n == 0:
+        return
+    dst = (ctypes.c_void_p * n)()
+    src = (ctypes.c_void_p * n)()
+    rows = (ctypes.c_uint * n)()
+    rb = (ctypes.c_uint * n)()
+    ds = (ctypes.c_size_t * n)()
+    ss = (ctypes.c_size_t * n)()
+
+    def rows_view(t):
+        # -> (rows, elements per row, row stride in elements): dim 0 = rows, the rest one contiguous run
+        assert t.dtype == torch.float32 and t.is_cuda
+        if t.dim() == 1:
+            assert t.stride(0) == 1 or t.numel() <= 1
+            return 1, t.numel(), t.numel()
+        inner = 1
+        for k in range(t.dim() - 1, 0, -1):
+            assert t.shape[k] == 1 or t.stride(k) == inner, (tuple(t.shape), t.stride())
+            inner *= t.shape[k]
+        return t.shape[0], inner, (t.stride(0) if t.shape[0] > 1 else inner)
+
+    for i, (d, s_) in enumerate(jobs):
+        assert tuple(d.shape) == tuple(s_.shape), (tuple(d.shape), tuple(s_.shape))
+        r, c, dstr = rows_view(d)
+        r2, c2, sstr = rows_view(s_)
+        assert (r, c) == (r2, c2)
+        dst[i], src[i], rows[i], rb[i], ds[i], ss[i] = d.data_ptr(), s_.data_ptr(), r, 4 * c, 4 * dstr, 4 * sstr
+    with torch.cuda.device(jobs[0][0].device):
+        check(lib().liso_multi_copy_rows(n, dst, src, rows, rb, ds, ss, stream_ptr()), "multi_copy_rows")
+
+
 def require_cuda(*tensors):
     for t in tensors:
         if not t.is_cuda:
@@ -193,6 +231,7 @@ SIGNATURES = {
     "liso_adamw_step_f32": (_i, [_vp, _vp, _vp, _vp, _sz] + [ctypes.c_double] * 5 + [ctypes.c_long, _vp]),
     "liso_adamw_step_scaled_f32": (_i, [_vp, _vp, _vp, _vp, _sz] + [ctypes.c_double] * 6 + [ctypes.c_long, _vp]),
     "liso_rmsprop_step_f32": (_i, [_vp, _vp, _vp, _sz] + [ctypes.c_double] * 4 + [_vp]),
+    "liso_multi_copy_rows": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "liso_gather_f32": (_i, [_i, _vp, _vp, _vp, _vp]),
     # include/liso_bn.h
     "liso_bn_workspace_bytes": (_sz, [_i]),

@@ -22,16 +22,38 @@ class _BlockDiagonalFilters(torch.autograd.Function):
         co = [w.shape[0] for w in ws]
         ci = [w.shape[1] for w in ws]
         W = ws[0].new_zeros((sum(co), sum(ci)) + tuple(ws[0].shape[2:]))
+        ctx.co, ctx.ci = co, ci
+        ctx.device_blocks = W.is_cuda and W.dtype == torch.float32
+        if ctx.device_blocks:  # every block and bias by one launch (include/liso_optim.h: liso_multi_copy_rows)
+            from liso_amd import _lib as L
+
+            bias = bs[0].new_empty(sum(co))
+            jobs, o, c = [], 0, 0
+            for w, b_, a, b in zip(ws, bs, co, ci):
+                jobs += [(W[o:o + a, c:c + b], w.detach()), (bias[o:o + a], b_.detach())]
+                o, c = o + a, c + b
+            L.copy_blocks(jobs)
+            return W, bias
         o = c = 0
         for w, a, b in zip(ws, co, ci):
             W[o:o + a, c:c + b] = w
             o, c = o + a, c + b
-        ctx.co, ctx.ci = co, ci
         return W, torch.cat(bs)
 
     @staticmethod
     def backward(ctx, gW, gb):
         gws, gbs, o, c = [], [], 0, 0
+        if ctx.device_blocks and gW is not None and gW.dtype == torch.float32:
+            from liso_amd import _lib as L
+
+            jobs = []
+            for a, b in zip(ctx.co, ctx.ci):
+                gws.append(gW.new_empty((a, b) + tuple(gW.shape[2:])))
+                jobs.append((gws[-1], gW[o:o + a, c:c + b]))
+                gbs.append(gb[o:o + a] if gb is not None else None)
+                o, c = o + a, c + b
+            L.copy_blocks(jobs)
+            return (None, *gws, *gbs)
         for a, b in zip(ctx.co, ctx.ci):
             gws.append(gW[o:o + a, c:c + b].contiguous() if gW is not None else None)
             gbs.append(gb[o:o + a] if gb is not None else None)

@@ -75,38 +75,62 @@ def _params(ub):
 _S1, _S3, _S7 = MC.ConvSpec(1, 1, 1, 0), MC.ConvSpec(3, 3, 1, 1), MC.ConvSpec(7, 7, 1, 3)
 
 
-def _merged_weights(ub, ci):
-    """the loop's filters from the modules' parameters (detached): permuted / concatenated / block-diagonal, see the module docstring"""
+def _merged_buffers(ub):
+    """the loop's merged filters as persistent buffers on the update block (allocated and zeroed once per device / dtype: the
+    off-diagonal blocks of the block-diagonal ones are never written again)"""
     me, gru, fh, hd = ub.motion_encoder, ub.gru, ub.static_flow_head, ub.classification_head
     d = _dims(ub)
     ch, co, cc, cf, cq, k1c, k1f, hf, hc = (d[k] for k in ("ch", "co", "cc", "cf", "cq", "k1c", "k1f", "hf", "hc"))
     dev = me.conv.weight.device
+    hit = getattr(ub, "_raft_loop_buffers", None)
+    if hit is not None and hit["dev"] == dev:
+        return hit
     z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)  # noqa: E731
-    with torch.no_grad():
-        wc, wq = me.conv.weight, gru.convq.weight
-        w71 = z(k1c + k1f, 8, 7, 7)
-        w71[:k1c, 0:4] = me.conv_class1.weight
-        w71[k1c:, 4:6] = me.conv_flow1.weight
-        wcf = z(cc + cf, k1c + k1f, 3, 3)
-        wcf[:cc, :k1c] = me.conv_class2.weight
-        wcf[cc:, k1c:] = me.conv_flow2.weight
-        whd = z(8, hf + hc, 3, 3)
-        whd[0:4, hf:] = hd.conv2.weight
-        whd[4:6, :hf] = fh.conv2.weight
-        bhd = z(8)
-        bhd[0:4] = hd.conv2.bias
-        bhd[4:6] = fh.conv2.bias
-        return {
-            "corr1": (me.conv_stat_corr1.weight.detach(), me.conv_stat_corr1.bias.detach(), _S1),
-            "c71": (w71, torch.cat([me.conv_class1.bias, me.conv_flow1.bias]), _S7),
-            "cf": (wcf, torch.cat([me.conv_class2.bias, me.conv_flow2.bias]), _S3),
-            # `conv` reads (corr, class, flow) instead of the reference's (corr, flow, class); `convq` reads (x, r*h) instead of (r*h, x)
-            "conv": (torch.cat([wc[:, :cq], wc[:, cq + cf:cq + cf + cc], wc[:, cq:cq + cf]], dim=1).contiguous(), me.conv.bias.detach(), _S3),
-            "zr": (torch.cat([gru.convz.weight, gru.convr.weight], dim=0), torch.cat([gru.convz.bias, gru.convr.bias]), _S3),
-            "q": (torch.cat([wq[:, ch:], wq[:, :ch]], dim=1).contiguous(), gru.convq.bias.detach(), _S3),
-            "pair": (torch.cat([fh.conv1.weight, hd.conv1.weight], dim=0), torch.cat([fh.conv1.bias, hd.conv1.bias]), _S3),
-            "hd": (whd, bhd, _S3),
-        }
+    cin = gru.convz.in_channels
+    hit = {"dev": dev,
+           "c71": (z(k1c + k1f, 8, 7, 7), z(k1c + k1f)), "cf": (z(cc + cf, k1c + k1f, 3, 3), z(cc + cf)),
+           "conv": (z(co, cq + cc + cf, 3, 3), None), "zr": (z(2 * ch, cin, 3, 3), z(2 * ch)), "q": (z(ch, cin, 3, 3), None),
+           "pair": (z(hf + hc, ch, 3, 3), z(hf + hc)), "hd": (z(8, hf + hc, 3, 3), z(8))}
+    ub._raft_loop_buffers = hit
+    return hit
+
+
+def _merged_weights(ub, ci):
+    """the loop's filters from the modules' parameters (detached): permuted / concatenated / block-diagonal, see the module docstring.
+    ONE launch places every block (liso_multi_copy_rows) into the persistent buffers of `_merged_buffers`."""
+    me, gru, fh, hd = ub.motion_encoder, ub.gru, ub.static_flow_head, ub.classification_head
+    d = _dims(ub)
+    ch, co, cc, cf, cq, k1c, k1f, hf, hc = (d[k] for k in ("ch", "co", "cc", "cf", "cq", "k1c", "k1f", "hf", "hc"))
+    B = _merged_buffers(ub)
+    w71, b71 = B["c71"]
+    wcf, bcf = B["cf"]
+    wcv, _ = B["conv"]
+    wzr, bzr = B["zr"]
+    wq, _ = B["q"]
+    wpr, bpr = B["pair"]
+    whd, bhd = B["hd"]
+    P = lambda m: (m.weight.detach(), m.bias.detach())  # noqa: E731
+    (wc1, bc1), (wf1, bf1), (wc2, bc2), (wf2, bf2) = P(me.conv_class1), P(me.conv_flow1), P(me.conv_class2), P(me.conv_flow2)
+    wc, _ = P(me.conv)
+    (wz, bz), (wr, br), (wqq, _) = P(gru.convz), P(gru.convr), P(gru.convq)
+    (wh1f, bh1f), (wh1c, bh1c), (wh2f, bh2f), (wh2c, bh2c) = P(fh.conv1), P(hd.conv1), P(fh.conv2), P(hd.conv2)
+    cx = wqq.shape[1] - ch
+    jobs = [
+        (w71[:k1c, 0:4], wc1), (w71[k1c:, 4:6], wf1), (b71[:k1c], bc1), (b71[k1c:], bf1),
+        (wcf[:cc, :k1c], wc2), (wcf[cc:, k1c:], wf2), (bcf[:cc], bc2), (bcf[cc:], bf2),
+        # `conv` reads (corr, class, flow) instead of the reference's (corr, flow, class); `convq` reads (x, r*h) instead of (r*h, x)
+        (wcv[:, :cq], wc[:, :cq]), (wcv[:, cq:cq + cc], wc[:, cq + cf:cq + cf + cc]), (wcv[:, cq + cc:], wc[:, cq:cq + cf]),
+        (wzr[:ch], wz), (wzr[ch:], wr), (bzr[:ch], bz), (bzr[ch:], br),
+        (wq[:, :cx], wqq[:, ch:]), (wq[:, cx:], wqq[:, :ch]),
+        (wpr[:hf], wh1f), (wpr[hf:], wh1c), (bpr[:hf], bh1f), (bpr[hf:], bh1c),
+        (whd[0:4, hf:], wh2c), (whd[4:6, :hf], wh2f), (bhd[0:4], bh2c), (bhd[4:6], bh2f),
+    ]
+    L.copy_blocks(jobs)
+    return {
+        "corr1": (me.conv_stat_corr1.weight.detach(), me.conv_stat_corr1.bias.detach(), _S1),
+        "c71": (w71, b71, _S7), "cf": (wcf, bcf, _S3), "conv": (wcv, me.conv.bias.detach(), _S3), "zr": (wzr, bzr, _S3),
+        "q": (wq, gru.convq.bias.detach(), _S3), "pair": (wpr, bpr, _S3), "hd": (whd, bhd, _S3),
+    }
 
 
 def _nchw(t):
@@ -279,14 +303,21 @@ class _RaftLoop(torch.autograd.Function):
         w_c1, b_c1 = wgrad(F8[:N][..., 0:4], D_C1[..., :k1c], (k1c, 4, 7, 7), _S7)
         w_f1, b_f1 = wgrad(F8[:N][..., 4:8], D_C1[..., k1c:], (k1f, 4, 7, 7), _S7)
         w_co, b_co = wgrad(CORR, D_CORRF, (cq, P, 1, 1), _S1)
+        # the merged / permuted gradients back to the modules' own layouts: row ranges are views, the column blocks are placed by ONE launch
+        like = lambda p_: torch.empty(p_.shape, dtype=torch.float32, device=p_.device)  # noqa: E731
+        g_f1, g_c2, g_f2, g_cv, g_q, g_fh2, g_hd2 = (like(m.weight) for m in (me.conv_flow1, me.conv_class2, me.conv_flow2, me.conv, gru.convq,
+                                                                                fh.conv2, hd.conv2))
+        L.copy_blocks([
+            (g_f1, w_f1[:, :2]), (g_c2, w_cf[:cc, :k1c]), (g_f2, w_cf[cc:, k1c:]),
+            (g_cv[:, :cq], w_cv[:, :cq]), (g_cv[:, cq:cq + cf], w_cv[:, cq + cc:]), (g_cv[:, cq + cf:], w_cv[:, cq:cq + cc]),
+            (g_q[:, :ch], w_q[:, cx:]), (g_q[:, ch:], w_q[:, :cx]), (g_fh2, w_hd[4:6, :hf]), (g_hd2, w_hd[0:4, hf:]),
+        ])
         grads = {
-            me.conv_stat_corr1: (w_co, b_co), me.conv_class1: (w_c1, b_c1), me.conv_flow1: (w_f1[:, :2].contiguous(), b_f1),
-            me.conv_class2: (w_cf[:cc, :k1c].contiguous(), b_cf[:cc]), me.conv_flow2: (w_cf[cc:, k1c:].contiguous(), b_cf[cc:]),
-            me.conv: (torch.cat([w_cv[:, :cq], w_cv[:, cq + cc:], w_cv[:, cq:cq + cc]], dim=1), b_cv),
-            gru.convz: (w_zr[:ch], b_zr[:ch]), gru.convr: (w_zr[ch:], b_zr[ch:]),
-            gru.convq: (torch.cat([w_q[:, cx:], w_q[:, :cx]], dim=1), b_q),
+            me.conv_stat_corr1: (w_co, b_co), me.conv_class1: (w_c1, b_c1), me.conv_flow1: (g_f1, b_f1),
+            me.conv_class2: (g_c2, b_cf[:cc]), me.conv_flow2: (g_f2, b_cf[cc:]), me.conv: (g_cv, b_cv),
+            gru.convz: (w_zr[:ch], b_zr[:ch]), gru.convr: (w_zr[ch:], b_zr[ch:]), gru.convq: (g_q, b_q),
             fh.conv1: (w_pair[:hf], b_pair[:hf]), hd.conv1: (w_pair[hf:], b_pair[hf:]),
-            fh.conv2: (w_hd[4:6, :hf].contiguous(), b_hd[4:6]), hd.conv2: (w_hd[0:4, hf:].contiguous(), b_hd[0:4]),
+            fh.conv2: (g_fh2, b_hd[4:6]), hd.conv2: (g_hd2, b_hd[0:4]),
         }
         layers, _ = _params(ub)
         flat = [g for m in layers for g in grads[m]]

@@ -158,6 +158,41 @@ def test_multi_copy_equals_tensor_copies():
 
 
 @pytest.mark.gpu
+def test_copy_blocks_places_filter_blocks_like_slice_assignments():
+    """_lib.copy_blocks (include/liso_optim.h: liso_multi_copy_rows): blocks of merged filters -- row ranges, column ranges, both,
+    1-D biases, more jobs than one launch takes -- land where slice assignments put them and nothing else is touched."""
+    import torch
+
+    from liso_amd import _lib as L
+
+    g = torch.Generator().manual_seed(1)
+    R = lambda *s: torch.rand(*s, generator=g).cuda()  # noqa: E731
+    jobs, checks = [], []
+    for k in range(45):
+        co, ci, kk = [1, 2, 4, 64, 96][k % 5], [2, 8, 64, 33][k % 4], [1, 3, 7][k % 3]
+        big = R(co + 5, ci + 7, kk, kk)
+        ref = big.clone()
+        blk = R(co, ci, kk, kk)
+        jobs.append((big[2:2 + co, 3:3 + ci], blk))
+        ref[2:2 + co, 3:3 + ci] = blk
+        checks.append((big, ref))
+        out = torch.zeros(co, ci, kk, kk, device="cuda")
+        other = R(co + 3, ci + 2, kk, kk)
+        jobs.append((out, other[1:1 + co, 2:2 + ci]))  # strided source
+        checks.append((out, other[1:1 + co, 2:2 + ci].clone()))
+    bias = torch.zeros(13, device="cuda")
+    b1, b2 = R(5), R(8)
+    jobs += [(bias[:5], b1), (bias[5:], b2)]
+    L.copy_blocks(jobs)
+    torch.cuda.synchronize()
+    for (got, exp) in checks:
+        assert torch.equal(got, exp)
+    assert torch.equal(bias, torch.cat([b1, b2]))
+    with pytest.raises(AssertionError):
+        L.copy_blocks([(torch.zeros(4, 3, device="cuda")[:, :2], torch.zeros(4, 2, 2, device="cuda")[:, :, 0])])  # inner stride 2
+
+
+@pytest.mark.gpu
 def test_flat_rmsprop_follows_torch_rmsprop():
     """FlatRMSprop (one liso_rmsprop_step_f32 launch over flat buffers) against torch.optim.RMSprop with the reference's settings
     (liso/slim/experiment.py:200-219: defaults + a LambdaLR schedule): 20 steps on tensors of odd sizes and channels-last filters,
