@@ -1569,9 +1569,15 @@ __global__ __launch_bounds__(1024) void conv_bn_finalize_kernel(const float* __r
     const int c = blockIdx.x * 8 + (col & 7), s = col >> 3;
     double acc = 0.0;
     if (c < co) {
-        float v[4];
+        float v[16];
         int row = rg;
-        for (; row + 3 * kFinGroups < rows; row += 4 * kFinGroups) {  // 4 independent loads in flight per thread
+        for (; row + 15 * kFinGroups < rows; row += 16 * kFinGroups) {  // 16 independent loads in flight per thread, summed in row order
+#pragma unroll
+            for (int u = 0; u < 16; u++) v[u] = partial[((long)(row + u * kFinGroups) * 2 + s) * co_pad + c];
+#pragma unroll
+            for (int u = 0; u < 16; u++) acc += (double)v[u];
+        }
+        for (; row + 3 * kFinGroups < rows; row += 4 * kFinGroups) {
 #pragma unroll
             for (int u = 0; u < 4; u++) v[u] = partial[((long)(row + u * kFinGroups) * 2 + s) * co_pad + c];
 #pragma unroll
@@ -1581,11 +1587,24 @@ __global__ __launch_bounds__(1024) void conv_bn_finalize_kernel(const float* __r
     }
     red[rg][col] = acc;
     __syncthreads();
-    if (threadIdx.x < 16) {  // one thread per (channel, sum): the 64 group sums in group order
-        double q = 0.0;
-        for (int g = 0; g < kFinGroups; g++) q += red[g][threadIdx.x];
-        red[0][threadIdx.x] = q;
+    // the 64 group sums per (channel, sum) as a fixed two-level tree: 8 runs of 8 consecutive groups, then the 8 run sums in order (64
+    // dependent LDS reads + fp64 adds in ONE thread were ~3 us of this 5.6-us launch)
+    double q = 0.0;
+    if (threadIdx.x < 128) {
+        const int run = threadIdx.x >> 4;
+#pragma unroll
+        for (int g = 0; g < 8; g++) q += red[run * 8 + g][col];
     }
+    __syncthreads();
+    if (threadIdx.x < 128) red[threadIdx.x >> 4][col] = q;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        q = 0.0;
+#pragma unroll
+        for (int g = 0; g < 8; g++) q += red[g][threadIdx.x];
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) red[0][threadIdx.x] = q;
     __syncthreads();
     if (threadIdx.x < 8) {
         const int cc = blockIdx.x * 8 + threadIdx.x;
