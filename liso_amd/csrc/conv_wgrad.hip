@@ -56,6 +56,9 @@ struct WgArgs {
     int pipelined;      // bf16: the halo tile fits one register batch -> tile k+1 is loaded during the MFMAs of tile k
     int compact;        // strided convolution whose tap groups each sit in ONE kernel row: the LDS tile holds only the input rows that
                         // group reads (row r of the tile = input row iy0 + (group's dy) + r * isy) instead of the class's dense halo
+#ifdef LISO_WGRAD_STAMPS
+    unsigned long long* stamps;  // diagnostic build (make STAMPS=1): 16 counters per block of conv_wgrad_rs3_kernel, scripts/wgrad_stamps.py
+#endif
 };
 
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
@@ -683,19 +686,41 @@ __global__ __launch_bounds__(kRsThreads, 1) void conv_wgrad_rs3_kernel(const lis
                 }
             }
         };
+#ifdef LISO_WGRAD_STAMPS
+        unsigned long long ws_store = 0, ws_load = 0, ws_bar = 0, ws_t;
+        const unsigned long long ws_k0 = __builtin_amdgcn_s_memtime();
+#define WSTAMP_BEGIN ws_t = __builtin_amdgcn_s_memtime();
+#define WSTAMP_END(acc) { const unsigned long long ws_n = __builtin_amdgcn_s_memtime(); acc += ws_n - ws_t; ws_t = ws_n; }
+#else
+#define WSTAMP_BEGIN
+#define WSTAMP_END(acc)
+#endif
         if (n_mine > 0) {
             load_tile(split);
             store_tile(smem);
             if (n_mine > 1) load_tile(split + a.splits);
         }
         __syncthreads();  // (A) buffer 0 is ready
+#ifdef LISO_WGRAD_STAMPS
+        const unsigned long long ws_k1 = __builtin_amdgcn_s_memtime();
+#endif
         for (int k = 0; k < n_mine; k++) {
+            WSTAMP_BEGIN
             if (k + 1 < n_mine) {
                 store_tile(smem + ((k + 1) & 1) * BUF);  // the tile the MFMA waves take next (they left this buffer at barrier k - 1)
+                WSTAMP_END(ws_store)
                 if (k + 2 < n_mine) load_tile(split + (k + 2) * a.splits);
+                WSTAMP_END(ws_load)
             }
             __syncthreads();  // (B k)
+            WSTAMP_END(ws_bar)
         }
+#ifdef LISO_WGRAD_STAMPS
+        if (ltid == 0 && a.stamps) {
+            unsigned long long* o = a.stamps + (size_t)blockIdx.x * 16 + 8;
+            o[0] = ws_k1 - ws_k0; o[1] = ws_store; o[2] = ws_load; o[3] = ws_bar; o[4] = (unsigned long long)n_mine;
+        }
+#endif
         if (want_bias) {  // (the MFMA waves are past their last LDS read: barrier B of the last tile)
             float* red = reinterpret_cast<float*>(smem);
 #pragma unroll
@@ -742,7 +767,15 @@ __global__ __launch_bounds__(kRsThreads, 1) void conv_wgrad_rs3_kernel(const lis
         acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i], 0, 0, 0);
     };
 
+#ifdef LISO_WGRAD_STAMPS
+    unsigned long long ms_mul = 0, ms_bar = 0, ms_t;
+    const unsigned long long ms_k0 = __builtin_amdgcn_s_memtime();
+#endif
     __syncthreads();  // (A)
+#ifdef LISO_WGRAD_STAMPS
+    const unsigned long long ms_k1 = __builtin_amdgcn_s_memtime();
+    ms_t = ms_k1;
+#endif
     for (int k = 0; k < n_mine; k++) {
         const unsigned char* xs = smem + (k & 1) * BUF;
         const unsigned char* ys = xs + X_BYTES;
@@ -778,9 +811,18 @@ __global__ __launch_bounds__(kRsThreads, 1) void conv_wgrad_rs3_kernel(const lis
                 }
             }
         }
+#ifdef LISO_WGRAD_STAMPS
+        { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); ms_mul += n_ - ms_t; ms_t = n_; }
+#endif
         __syncthreads();  // (B k)
+#ifdef LISO_WGRAD_STAMPS
+        { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); ms_bar += n_ - ms_t; ms_t = n_; }
+#endif
     }
     __syncthreads();  // (C)
+#ifdef LISO_WGRAD_STAMPS
+    const unsigned long long ms_k2 = __builtin_amdgcn_s_memtime();
+#endif
     // ---- slab: D[row = ci][col = co]; col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5) ---------------------------------
     const int r = lane & 31, h = lane >> 5;
 #pragma unroll
@@ -796,6 +838,14 @@ __global__ __launch_bounds__(kRsThreads, 1) void conv_wgrad_rs3_kernel(const lis
             }
         }
     }
+#ifdef LISO_WGRAD_STAMPS
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the slab stores have left
+    if (tid == 0 && a.stamps) {
+        unsigned long long* o = a.stamps + (size_t)blockIdx.x * 16;
+        const unsigned long long ms_k3 = __builtin_amdgcn_s_memtime();
+        o[0] = ms_k1 - ms_k0; o[1] = ms_mul; o[2] = ms_bar; o[3] = ms_k2 - ms_k0; o[4] = ms_k3 - ms_k2; o[5] = ms_k3 - ms_k0;
+    }
+#endif
 }
 
 // dw (torch layout) = sum over splits of the slabs, in a fixed order.  PARTS = 16: block = one (tap, k) row x 64 output channels;
@@ -1281,10 +1331,22 @@ bool make_rs3_plan(const liso_conv_desc& d, Rs3Plan* p) {
     return true;
 }
 
+#ifdef LISO_WGRAD_STAMPS
+unsigned long long* g_wgrad_stamps = nullptr;  // 4096 blocks x 16 counters
+#endif
+
 template <int MODE, int TH, int S>
 int launch_rs3(const liso_conv_desc& d, const Rs3Plan& p, hipStream_t st) {
     static liso_dev::PerDeviceFlag attr_set;
     if (!liso_dev::lds_opt_in(attr_set, (const void*)conv_wgrad_rs3_kernel<MODE, TH, S>, 160 * 1024)) return LISO_ELAUNCH;
+#ifdef LISO_WGRAD_STAMPS
+    if (!g_wgrad_stamps && hipMalloc((void**)&g_wgrad_stamps, 4096 * 16 * 8) != hipSuccess) return LISO_ELAUNCH;
+    (void)hipMemsetAsync(g_wgrad_stamps, 0, 4096 * 16 * 8, st);
+    Rs3Plan q = p;
+    q.a.stamps = p.blocks <= 4096 ? g_wgrad_stamps : nullptr;
+    conv_wgrad_rs3_kernel<MODE, TH, S><<<q.blocks, kRsThreads, q.lds, st>>>(d, q.a);
+    return hipGetLastError() == hipSuccess ? LISO_OK : LISO_ELAUNCH;
+#endif
     conv_wgrad_rs3_kernel<MODE, TH, S><<<p.blocks, kRsThreads, p.lds, st>>>(d, p.a);
     return hipGetLastError() == hipSuccess ? LISO_OK : LISO_ELAUNCH;
 }
@@ -1561,3 +1623,11 @@ int liso_conv_wgrad_smallci_f32(const float* x, long x_pix_stride, const float* 
 }
 
 }  // extern "C"
+
+#ifdef LISO_WGRAD_STAMPS
+// diagnostic build only: the counters of the last conv_wgrad_rs3_kernel launch -> host (16 x uint64 per block)
+extern "C" int liso_wgrad_stamps_read(unsigned long long* host_out, int blocks) {
+    if (!g_wgrad_stamps || blocks > 4096) return LISO_EINVAL;
+    return hipMemcpy(host_out, g_wgrad_stamps, (size_t)blocks * 16 * 8, hipMemcpyDeviceToHost) == hipSuccess ? LISO_OK : LISO_ELAUNCH;
+}
+#endif
