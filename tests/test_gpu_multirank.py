@@ -170,6 +170,30 @@ def test_bench_ranks_on_one_gpu_reports_world_and_identical_replicas(workload, w
     assert line["step_times"]["median_ms"] > 0 and line["step_roofline"]["algorithmic_flop_per_step"] > 0
 
 
+@pytest.mark.timeout(600)
+def test_bench_loader_run_trains_like_the_resident_run():
+    """`bench.py --loader` (SURVEY 8d's second measurement mode): the sweep pairs live in pinned host memory, every pair is one collated
+    buffer uploaded on a copy stream into a ring of device staging slots, and the step waits for the upload's event
+    (`step_batch(..., inputs_ready=...)`).  Same iteration, same data: the loss after the same number of steps equals the resident
+    run's, and the line reports the uploads."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    out = []
+    for extra in ([], ["--loader"]):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "6", "--warmup", "3", "--no-cpu-baseline", "--no-iou3d",
+                            "--no-legs"] + extra, env=env, capture_output=True, text=True, timeout=280)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out.append(json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1]))
+    resident, fed = out
+    assert "loader" not in resident and fed["loader"]["uploads"] > 0 and fed["loader"]["h2d_bytes_per_step"] > 1 << 20
+    assert fed["final_loss"] == resident["final_loss"], (fed["final_loss"], resident["final_loss"])
+    assert fed["mined_boxes_last_step"] == resident["mined_boxes_last_step"]
+
+
 def test_rccl_process_group_next_to_graph_captures_and_replays():
     """RCCL itself (backend "nccl"), one rank on the one GPU there is: a live process group (communicator + watchdog thread) while the
     loop captures and replays its three hipGraphs, and an all-reduce of the detector's flat gradient buffer between replays -- the calls
