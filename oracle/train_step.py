@@ -54,4 +54,4 @@ def timed_detector_step(sd, pcls, targets, grid, bev_range_m):
     t0 = time.perf_counter()
     total, _, _ = detector_forward_loss(sd, pcls, targets, grid, bev_range_m)
     total.backward()
-    return time.perf_counter() - t0, float(total)
+    return time.perf_counter() - t0, float(total.detach())

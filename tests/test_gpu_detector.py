@@ -45,7 +45,7 @@ def test_train_step_matches_cpu_oracle_fp32():
     sd64 = prepare_state(sd0, torch.float64)
     ref64, _, _ = detector_forward_loss(sd64, cpu_pcls, t_cpu, 128, 100.0, dtype=torch.float64)
     ref64.backward()
-    assert abs(float(total) - float(ref64)) <= 1e-3 * abs(float(ref64))
+    assert abs(float(total.detach()) - float(ref64.detach())) <= 1e-3 * abs(float(ref64.detach()))
     names = dict(tr.net.named_parameters())
     keys = [k for k, p in names.items() if p.grad is not None and sd64[k].grad is not None
             and float(sd64[k].grad.abs().max()) >= 1e-6]  # conv biases in front of a BatchNorm: true gradient == 0
