@@ -1020,7 +1020,12 @@ bool make_plan_impl(const liso_conv_desc& d, WgPlan* p, bool compact) {
     long slab_mb = 24;
     if (const char* e = getenv("LISO_WGRAD_SLAB_MB")) slab_mb = atol(e) > 0 ? atol(e) : slab_mb;  // experiments
     long split_cap = (slab_mb << 20) / slab_per_split;
-    const long by_tiles = a.n_tiles >= 4 ? a.n_tiles / 4 : 1;
+    // tiles per block at least (the first tile's load is exposed).  fp32 tensors: 2 -- the SLIM encoders' 1x1 / strided layers have 256
+    // tiles in all: at 4 per block 64 of the 256 CUs worked, each through four unpipelined load -> multiply rounds (28 us per launch);
+    // measured on the SLIM train step: weight-gradient family 2.10-2.13 -> 2.00-2.05 ms (1 tile per block: no better, 4x the slabs)
+    long min_tiles = x3 ? 2 : 4;
+    if (const char* e = getenv("LISO_WGRAD_MIN_TILES")) min_tiles = atol(e) > 0 ? atol(e) : min_tiles;  // experiments
+    const long by_tiles = a.n_tiles >= min_tiles ? a.n_tiles / min_tiles : 1;
     split_cap = split_cap < 1 ? 1 : (split_cap > by_tiles ? by_tiles : split_cap);
     long target = 512;  // ~2 blocks per CU
     if (const char* e = getenv("LISO_WGRAD_BLOCKS")) target = atol(e) > 0 ? atol(e) : target;  // experiments
