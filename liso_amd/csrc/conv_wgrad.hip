@@ -1322,7 +1322,11 @@ bool make_rs3_plan(const liso_conv_desc& d, Rs3Plan* p) {
     a.th = th;
     a.tiles_y = (d.ho + th - 1) / th;
     a.n_tiles = d.batch * a.tiles_y * a.tiles_x;
-    long s = a.n_tiles / 4;  // >= 4 tiles per block: the first tile's load is exposed, the others hide behind MFMAs
+    long min_tiles = 4;  // >= 4 tiles per block: the first tile's load is exposed, the others hide behind MFMAs
+    // (experiments; 2 tiles per block on the SLIM encoders' 64 -> 64 / 96 -> 96 layers -- 172 blocks instead of 86 -- measured no change:
+    // SLIM step 10.81-11.06 vs 10.66-11.05 ms, twice the slabs)
+    if (const char* e = getenv("LISO_WGRAD_RS3_MIN_TILES")) min_tiles = atol(e) > 0 ? atol(e) : min_tiles;
+    long s = a.n_tiles / min_tiles;
     s = s > want ? want : s;
     s = s < 1 ? 1 : s;
     a.splits = (int)s;
