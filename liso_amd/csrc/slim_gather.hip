@@ -28,8 +28,7 @@ __global__ void bev_gather_fwd_kernel(const float* __restrict__ grid, const int*
 // up its chunk heads (<= len / kChunk steps) and write the cell's gradient row.  Fixed order, no atomics.
 constexpr int kChunk = 16;
 
-// LANES lanes per sorted row (32, or 8 for maps of <= 8 channels -- the decoder's 8-channel network output and 3-channel flow | weight
-// maps: with 32 lanes per row three quarters of every wave idled through the index loads): the row's cell / rank are read once per
+// LANES lanes per sorted row (32; maps of <= 8 channels take the row-per-thread kernels below): the row's cell / rank are read once per
 // lane group (not once per channel), lanes = channels.
 template <int LANES>
 __global__ __launch_bounds__(256) void bev_gather_bwd_chunk_kernel(const float* __restrict__ grad_out, const int* __restrict__ sorted_lin,
@@ -78,6 +77,93 @@ __global__ __launch_bounds__(256) void bev_gather_bwd_segment_kernel(const float
         for (long j = s; j < n_rows && sorted_lin[j] == cell; j += kChunk) acc += partial[(size_t)j * c + ch];
         grad_grid[(size_t)cell * c + ch] = acc;
     }
+}
+
+// ---- maps of <= 8 channels (the decoder's 8-channel network output, the 3-channel flow | weight maps): a thread per sorted row ----
+// The chunk / segment pair above keeps one lane group per sorted row, of which only the chunk heads (one row in ~10) do anything, each
+// through a chain of dependent global loads: 189 + 106 us for the 1.44 M rows of a SLIM step (0.3 TB/s).  Here EVERY thread gathers its
+// row (<= 32 bytes) in one round trip, and the sums run in LDS:
+//   rows kernel      block = 256 consecutive sorted rows.  Level 1: rows whose index is a multiple of 16 or that start a run of equal
+//                    cells sum forward to the next such row; level 2: run starts add the level-1 sums of their run (<= 16 + 16 steps, all
+//                    in LDS).  A run that starts (rank 0) and ends inside the block writes its cell's gradient row; otherwise the
+//                    block's share goes to partial[first row of the share].
+//   boundary kernel  a thread per block boundary: the run that crosses it FIRST there (its start lies in the block in front) adds the
+//                    shares of all blocks it touches, in block order, and writes the cell's row.
+// Fixed order, no atomics: bit reproducible.
+constexpr int kRowsBlock = 256;
+
+__global__ __launch_bounds__(kRowsBlock) void bev_gather_bwd_rows_kernel(const float* __restrict__ grad_out, const int* __restrict__ sorted_lin,
+                                                                         const int* __restrict__ order, const int* __restrict__ seg_rank,
+                                                                         long n_rows, int c, float* __restrict__ partial,
+                                                                         float* __restrict__ grad_grid) {
+    __shared__ float val[kRowsBlock][9];  // (row stride 9: neighbouring rows of one channel fall into different banks)
+    __shared__ int cells[kRowsBlock + 1];
+    const int tid = threadIdx.x;
+    const long s = (long)blockIdx.x * kRowsBlock + tid;
+    int cell = -1;
+    float v[8];
+#pragma unroll
+    for (int ch = 0; ch < 8; ch++) v[ch] = 0.f;
+    if (s < n_rows) {
+        cell = sorted_lin[s];
+        if (cell >= 0) {
+            const float* g = grad_out + (size_t)order[s] * c;
+            if (c == 8) {
+                const float4 a = *reinterpret_cast<const float4*>(g), b = *reinterpret_cast<const float4*>(g + 4);
+                v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+            } else {
+#pragma unroll
+                for (int ch = 0; ch < 8; ch++)
+                    if (ch < c) v[ch] = g[ch];
+            }
+        }
+    }
+#pragma unroll
+    for (int ch = 0; ch < 8; ch++) val[tid][ch] = v[ch];
+    cells[tid] = cell;
+    if (tid == kRowsBlock - 1) cells[kRowsBlock] = s + 1 < n_rows ? sorted_lin[s + 1] : -2;
+    __syncthreads();
+    const bool head = cell >= 0 && (tid == 0 || cells[tid - 1] != cell);
+    if (cell >= 0 && (head || (tid & 15) == 0)) {  // level 1: forward to the next multiple of 16 / the end of the run
+        for (int k = tid + 1; k < kRowsBlock && (k & 15) != 0 && cells[k] == cell; k++)
+#pragma unroll
+            for (int ch = 0; ch < 8; ch++) v[ch] += val[k][ch];
+    }
+    __syncthreads();  // (level 1 only read rows that nobody overwrites: a row is written by its own thread)
+    if (cell >= 0 && (head || (tid & 15) == 0))
+#pragma unroll
+        for (int ch = 0; ch < 8; ch++) val[tid][ch] = v[ch];
+    __syncthreads();
+    if (!head) return;
+    for (int k = (tid | 15) + 1; k < kRowsBlock && cells[k] == cell; k += 16)  // level 2: the run's level-1 sums, in row order
+#pragma unroll
+        for (int ch = 0; ch < 8; ch++) v[ch] += val[k][ch];
+    const bool ends_here = !(cells[kRowsBlock - 1] == cell && cells[kRowsBlock] == cell);
+    float* dst = (ends_here && seg_rank[s] == 0) ? grad_grid + (size_t)cell * c : partial + (size_t)s * c;
+#pragma unroll
+    for (int ch = 0; ch < 8; ch++)
+        if (ch < c) dst[ch] = v[ch];
+}
+
+__global__ __launch_bounds__(256) void bev_gather_bwd_boundary_kernel(const float* __restrict__ partial, const int* __restrict__ sorted_lin,
+                                                                      const int* __restrict__ seg_rank, long n_rows, int c,
+                                                                      float* __restrict__ grad_grid) {
+    const long b = (long)blockIdx.x * blockDim.x + threadIdx.x + 1;  // boundary in front of block b
+    const long r = b * kRowsBlock;
+    if (r >= n_rows) return;
+    const int cell = sorted_lin[r];
+    if (cell < 0) return;
+    const int rank = seg_rank[r];
+    const long h = r - rank;  // where the run starts
+    if (rank == 0 || h / kRowsBlock != b - 1) return;  // no run crosses here, or it crossed an earlier boundary first
+    float v[8];
+#pragma unroll
+    for (int ch = 0; ch < 8; ch++) v[ch] = ch < c ? partial[(size_t)h * c + ch] : 0.f;
+    for (long q = r; q < n_rows && sorted_lin[q] == cell; q += kRowsBlock)
+#pragma unroll
+        for (int ch = 0; ch < 8; ch++)
+            if (ch < c) v[ch] += partial[(size_t)q * c + ch];
+    for (int ch = 0; ch < c; ch++) grad_grid[(size_t)cell * c + ch] = v[ch];
 }
 
 // BevGatherPlan's list (liso/slim/slim_loss/static_aggregation.py:69-84 indexes grid[b, row, col] per valid point): the flattened
@@ -129,9 +215,10 @@ int liso_bev_gather_bwd_f32(const float* grad_out, const int* sorted_lin, const 
     if (!grad_out || !sorted_lin || !order || !seg_rank || !partial || !grad_grid) return LISO_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     if (c <= 8) {
-        const unsigned blocks = (unsigned)((n_rows * 8 + 255) / 256);
-        bev_gather_bwd_chunk_kernel<8><<<blocks, 256, 0, st>>>(grad_out, sorted_lin, order, seg_rank, n_rows, c, partial);
-        bev_gather_bwd_segment_kernel<8><<<blocks, 256, 0, st>>>(partial, sorted_lin, seg_rank, n_rows, c, grad_grid);
+        const long nblk = (n_rows + kRowsBlock - 1) / kRowsBlock;
+        bev_gather_bwd_rows_kernel<<<(unsigned)nblk, kRowsBlock, 0, st>>>(grad_out, sorted_lin, order, seg_rank, n_rows, c, partial, grad_grid);
+        if (nblk > 1)
+            bev_gather_bwd_boundary_kernel<<<(unsigned)((nblk - 1 + 255) / 256), 256, 0, st>>>(partial, sorted_lin, seg_rank, n_rows, c, grad_grid);
     } else {
         const unsigned blocks = (unsigned)((n_rows * 32 + 255) / 256);
         bev_gather_bwd_chunk_kernel<32><<<blocks, 256, 0, st>>>(grad_out, sorted_lin, order, seg_rank, n_rows, c, partial);

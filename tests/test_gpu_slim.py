@@ -372,6 +372,36 @@ def test_bev_gather_forward_backward_vs_torch_indexing():
     assert torch.equal(pb, flags[bi, coors[..., 0].long(), coors[..., 1].long()] & valid[..., None])
 
 
+@pytest.mark.parametrize("C,N", [(8, 60000), (3, 20000), (1, 700), (8, 255), (8, 256), (8, 257)])
+def test_bev_gather_backward_row_kernels_vs_torch_indexing(C, N):
+    """maps of <= 8 channels take bev_gather_bwd_rows_kernel + bev_gather_bwd_boundary_kernel (a thread per sorted row, sums in LDS, runs
+    that cross the 256-row blocks finished per boundary): against torch's index_put adjoint, with a pillar that holds thousands of
+    points (a run across ~20 blocks), pillars of every small size, invalid rows, row counts around the block size; bit reproducible."""
+    from liso_amd.slim.slim_loss.static_aggregation import BevGatherPlan, batched_grid_data_to_pointwise_data
+
+    B, H, W = 2, 40, 56
+    g = torch.Generator().manual_seed(100 + C + N)
+    grid = torch.randn(B, H, W, C, generator=g).cuda().requires_grad_(True)
+    coors = torch.stack([torch.randint(0, H, (B, N), generator=g), torch.randint(0, W, (B, N), generator=g)], -1).int().cuda()
+    coors[0, : N // 6] = torch.tensor([7, 9], dtype=torch.int32)            # a crowded pillar
+    coors[1, N // 2: N // 2 + min(300, N // 3)] = torch.tensor([39, 55], dtype=torch.int32)  # the last cell of the map
+    valid = (torch.rand(B, N, generator=g) > 0.1).cuda()
+    go = torch.randn(B, N, C, generator=g).cuda()
+    plan = BevGatherPlan(coors, valid, (H, W))
+    out = batched_grid_data_to_pointwise_data(grid, coors, valid, 0.5, plan=plan)
+    bi = torch.arange(B, device="cuda")[:, None].expand(-1, N)
+    ref = torch.where(valid[..., None], grid[bi, coors[..., 0].long(), coors[..., 1].long()], 0.5)
+    assert torch.equal(out, ref)
+    (g1,) = torch.autograd.grad((out * go).sum(), grid)
+    (g1b,) = torch.autograd.grad((batched_grid_data_to_pointwise_data(grid, coors, valid, 0.5) * go).sum(), grid)
+    (g2,) = torch.autograd.grad((ref.double() * go.double()).sum(), grid)
+    assert torch.equal(g1, g1b)
+    empty = torch.ones(B, H, W, dtype=torch.bool, device="cuda")
+    empty[bi[valid], coors[..., 0].long()[valid], coors[..., 1].long()[valid]] = False
+    assert float(g1[empty].abs().sum()) == 0  # cells without points keep their zeros
+    assert _rel(g1, g2.cpu().numpy()) < 2e-6
+
+
 def _slim_cfg(tag):
     from liso_amd.utils.config import apply_slim_simple_knn_training, default_cfg
 
