@@ -196,15 +196,34 @@ __global__ __launch_bounds__(kScanTile) void cell_scan_block_kernel(const int* _
 
 // one block: exclusive prefix of the block totals (<= 4096 blocks = 4 M cells)
 __global__ __launch_bounds__(1024) void cell_scan_tot_kernel(int* __restrict__ block_tot, int nblk) {
-    __shared__ int s[4096];
-    for (int q = threadIdx.x; q < 4096; q += 1024) s[q] = q < nblk ? block_tot[q] : 0;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int run = 0;
-        for (int q = 0; q < nblk; q++) { const int t = s[q]; s[q] = run; run += t; }
+    // exclusive scan of <= 4096 block totals: 4 consecutive values per thread, wave scan, scan of the 16 wave totals (one thread walking
+    // all totals took 12 us at 1024 of them)
+    __shared__ int wsum[16];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    int v[4], tot = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int q = t * 4 + k;
+        v[k] = q < nblk ? block_tot[q] : 0;
+        tot += v[k];
     }
+    int incl = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(incl, o);
+        if (lane >= o) incl += up;
+    }
+    if (lane == 63) wsum[wave] = incl;
     __syncthreads();
-    for (int q = threadIdx.x; q < nblk; q += 1024) block_tot[q] = s[q];
+    int base = 0;
+    for (int w = 0; w < wave; w++) base += wsum[w];
+    int run = base + incl - tot;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int q = t * 4 + k;
+        if (q < nblk) block_tot[q] = run;
+        run += v[k];
+    }
 }
 
 __global__ __launch_bounds__(256) void seg_fill_kernel(const int* __restrict__ cell_of_point, int n_total, const int* __restrict__ seg_off,
@@ -222,13 +241,11 @@ __global__ __launch_bounds__(256) void seg_fill_kernel(const int* __restrict__ c
 // over the whole segment (coalesced re-reads of a cached segment; 1 000 points: 16 loads per lane and round).  (A thread per POINT that
 // walks its cell's segment -- the first form of this kernel -- took 144-165 us on the bench's clouds: the few pillars next to the sensor
 // hold hundreds of points and every lane of their waves walks them all.)
-__global__ __launch_bounds__(256) void voxel_slots_kernel(const int* __restrict__ coors, const int* __restrict__ num_voxels, int max_voxels,
-                                                          int batch, int gx, int gy, const int* __restrict__ seg_off,
-                                                          const int* __restrict__ block_tot, const int* __restrict__ count,
-                                                          const int* __restrict__ seg, int max_points, int* __restrict__ slots) {
-    const int lane = threadIdx.x & 63;
-    const long v = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (v >= (long)batch * max_voxels) return;
+constexpr int kSlotRegs = 16;  // voxel_slots_kernel: pillars of up to 1024 points are ranked from registers
+__device__ __forceinline__ void voxel_slots_one(const int* __restrict__ coors, const int* __restrict__ num_voxels, int max_voxels, int gx, int gy,
+                                                const int* __restrict__ seg_off, const int* __restrict__ block_tot,
+                                                const int* __restrict__ count, const int* __restrict__ seg, int max_points,
+                                                int* __restrict__ slots, long v, int lane) {
     const int b = (int)(v / max_voxels), ord = (int)(v % max_voxels);
     if (ord >= num_voxels[b]) return;
     const int c = (b * gx + coors[v * 4 + 2]) * gy + coors[v * 4 + 3];
@@ -243,6 +260,24 @@ __global__ __launch_bounds__(256) void voxel_slots_kernel(const int* __restrict_
     }
     int last = -1;
     const int rounds = min(max_points, n);  // (max_points > n: the slots behind the n-th stay untouched, as on the n <= 64 path)
+    if (n <= 64 * kSlotRegs) {
+        // a crowded pillar (a wall stacks hundreds of returns into one pillar): the point indices are fetched ONCE into registers, the
+        // `max_points` selection rounds run on them (the loop below re-reads the whole segment per round through a chain of dependent
+        // global loads: ~0.5 us per round and 64 points -- one such wave set the launch's duration, 33 us)
+        int x[kSlotRegs];
+#pragma unroll
+        for (int u = 0; u < kSlotRegs; u++) x[u] = lane + 64 * u < n ? seg[off + lane + 64 * u] : 0x7fffffff;
+        for (int r = 0; r < rounds; r++) {
+            int m = 0x7fffffff;
+#pragma unroll
+            for (int u = 0; u < kSlotRegs; u++) m = (x[u] > last && x[u] < m) ? x[u] : m;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) m = min(m, __shfl_xor(m, o));
+            if (lane == 0) out[r] = m;
+            last = m;
+        }
+        return;
+    }
     for (int r = 0; r < rounds; r++) {
         int m = 0x7fffffff;
         for (int j = lane; j < n; j += 64) {
@@ -254,6 +289,17 @@ __global__ __launch_bounds__(256) void voxel_slots_kernel(const int* __restrict_
         if (lane == 0) out[r] = m;
         last = m;
     }
+}
+
+// a wave per pillar slot (most of the [batch, max_voxels] slots hold no pillar and exit at once; a capped grid whose waves walk the
+// slots was measured slower: 35.7 vs 29.6 us at B = 4)
+__global__ __launch_bounds__(256) void voxel_slots_kernel(const int* __restrict__ coors, const int* __restrict__ num_voxels, int max_voxels,
+                                                          int batch, int gx, int gy, const int* __restrict__ seg_off,
+                                                          const int* __restrict__ block_tot, const int* __restrict__ count,
+                                                          const int* __restrict__ seg, int max_points, int* __restrict__ slots) {
+    const int lane = threadIdx.x & 63;
+    for (long v = (long)blockIdx.x * 4 + (threadIdx.x >> 6); v < (long)batch * max_voxels; v += (long)gridDim.x * 4)
+        voxel_slots_one(coors, num_voxels, max_voxels, gx, gy, seg_off, block_tot, count, seg, max_points, slots, v, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -458,30 +504,46 @@ __global__ __launch_bounds__(1024) void pfn_bn_finalize_kernel(const double* __r
                                                                float eps, float* __restrict__ bn_out,
                                                                double* __restrict__ moments) {
     constexpr int F = C + 6, D = F + 1;
-    __shared__ double part[8][128];
-    __shared__ double mom[LISO_PFN_STATS_DOUBLES];
-    const int e = threadIdx.x & 127, chunk = threadIdx.x >> 7;  // 8 chunks of blocks
-    double s = 0.0;
-    if (e < LISO_PFN_STATS_DOUBLES) {
-        const int per = (nblocks + 7) / 8;
+    constexpr int NS = LISO_PFN_STATS_DOUBLES, CH = 1024 / NS;  // 13 chunks of blocks x 78 sums (8 x 128 left 50 lanes of every chunk idle)
+    __shared__ double part[CH][NS];
+    __shared__ double mom[NS];
+    const int e = threadIdx.x % NS, chunk = threadIdx.x / NS;
+    if (chunk < CH) {
+        double s = 0.0;
+        const int per = (nblocks + CH - 1) / CH;
         const int lo = chunk * per, hi = lo + per < nblocks ? lo + per : nblocks;
         int blk = lo;
-        for (; blk + 8 <= hi; blk += 8) {  // 8 independent loads in flight, original summation order
-            double v[8];
+        for (; blk + 16 <= hi; blk += 16) {  // 16 independent loads in flight, summed in block order
+            double v[16];
 #pragma unroll
-            for (int j = 0; j < 8; j++) v[j] = partials[(size_t)(blk + j) * LISO_PFN_STATS_DOUBLES + e];
+            for (int j = 0; j < 16; j++) v[j] = partials[(size_t)(blk + j) * NS + e];
 #pragma unroll
-            for (int j = 0; j < 8; j++) s += v[j];
+            for (int j = 0; j < 16; j++) s += v[j];
         }
-        for (; blk < hi; blk++) s += partials[(size_t)blk * LISO_PFN_STATS_DOUBLES + e];
+        for (; blk < hi; blk++) s += partials[(size_t)blk * NS + e];
+        part[chunk][e] = s;
     }
-    part[chunk][e] = s;
     __syncthreads();
-    if (threadIdx.x < LISO_PFN_STATS_DOUBLES) {
+    if (threadIdx.x < NS) {
         double t = 0.0;
-        for (int c = 0; c < 8; c++) t += part[c][threadIdx.x];
+        for (int c = 0; c < CH; c++) t += part[c][threadIdx.x];
         mom[threadIdx.x] = t;
         moments[threadIdx.x] = t;
+    }
+    __syncthreads();
+    // the quadratic form w^T M w of every output channel: thread (channel, j) takes row j (F products), the F row sums of a channel are
+    // added in row order (one thread per channel walking all F x F products through LDS took ~10 us of this launch)
+    __shared__ double rows_sq[kOut][F + 1], rows_sum[kOut][F + 1];
+    if (threadIdx.x < kOut * F) {
+        const int c = threadIdx.x / F, j = threadIdx.x % F;
+        const double wj = (double)weight[c * F + j];
+        double q = 0.0;
+        for (int k = 0; k < F; k++) {
+            const int a = j <= k ? j : k, bb = j <= k ? k : j;
+            q += wj * (double)weight[c * F + k] * mom[pair_index(a, bb, D)];
+        }
+        rows_sq[c][j] = q;
+        rows_sum[c][j] = wj * mom[pair_index(j, D - 1, D)];
     }
     __syncthreads();
     if (threadIdx.x < kOut) {
@@ -489,15 +551,10 @@ __global__ __launch_bounds__(1024) void pfn_bn_finalize_kernel(const double* __r
         long long P = 0;
         for (int b = 0; b < batch; b++) P += num_voxels[b];
         const double M = (double)P * (double)max_points;  // BatchNorm1d sees [P, 64, 20]: padded rows count
-        double w[F];
-        for (int k = 0; k < F; k++) w[k] = (double)weight[c * F + k];
         double sum = 0.0, sq = 0.0;
         for (int j = 0; j < F; j++) {
-            sum += w[j] * mom[pair_index(j, D - 1, D)];
-            for (int k = 0; k < F; k++) {
-                const int a = j <= k ? j : k, bb = j <= k ? k : j;
-                sq += w[j] * w[k] * mom[pair_index(a, bb, D)];
-            }
+            sum += rows_sum[c][j];
+            sq += rows_sq[c][j];
         }
         double mean = 0.0, var = 0.0;
         if (M > 0.0) {
