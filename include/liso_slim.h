@@ -157,6 +157,19 @@ int liso_bev_gather_fwd_f32(const float* grid, const int* lin, long n_rows, int 
  * [batch, n] -> lin int32 [batch * n] = (b h + row) w + col, -1 for invalid points. */
 int liso_bev_lin_index(const void* coors, int coors_are_int64, const unsigned char* valid, int batch, long n, int h, int w, int* lin,
                        void* stream);
+
+/* The gather plan's index arithmetic (BevGatherPlan.tiled / _sort, liso_amd/slim/slim_loss/static_aggregation.py; the reference indexes
+ * grid[b, row, col] per point and lets autograd scatter: liso/slim/slim_loss/static_aggregation.py:69-84).
+ * tile_lin: lin of the tiled batch [samples[:half]] * n_it + [samples[half:]] * n_it from the distinct samples' rows [n2, n] (cells of copy j
+ *   shifted by (j - its sample) * h * w, invalid rows stay -1).
+ * rank: rank[i] = i - (first index of sorted_lin[i] in the ascending list); order32 (optional) = order64 narrowed.
+ * expand: the cell-sorted view (sorted_lin, order, rank: [n2 * n_it * n] each) of the tiled batch from ONE stable sort of the distinct
+ *   samples' flat list (s_flat ascending: invalid rows first, then sample 0's cells, sample 1's, ...; o_flat its permutation; rank_flat
+ *   from `rank`): every copy's block holds its sample's valid rows in sorted order, then -1 padding. */
+int liso_bev_plan_tile_lin(const int* rows, int n2, long n, int n_it, int half, int h, int w, int* lin, void* stream);
+int liso_bev_plan_rank(const int* sorted_lin, const long long* order64, long n, int* rank, int* order32, void* stream);
+int liso_bev_plan_expand(const int* s_flat, const long long* o_flat, const int* rank_flat, int n2, long n, int n_it, int half, int h, int w,
+                         int* sorted_lin, int* order, int* rank, void* stream);
 int liso_bev_gather_bwd_f32(const float* grad_out, const int* sorted_lin, const int* order, const int* seg_rank, long n_rows,
                             int c, float* partial, float* grad_grid, void* stream);
 

@@ -206,6 +206,9 @@ SIGNATURES = {
     "liso_gru_out_rows_f32": (_i, [ctypes.c_long, _i, _vp, ctypes.c_long, _vp, _vp, ctypes.c_long, _vp]),
     "liso_multi_copy": (_i, [_i, _vp, _vp, _vp, _vp]),
     "liso_bev_lin_index": (_i, [_vp, _i, _vp, _i, ctypes.c_long, _i, _i, _vp, _vp]),
+    "liso_bev_plan_tile_lin": (_i, [_vp, _i, ctypes.c_long, _i, _i, _i, _i, _vp, _vp]),
+    "liso_bev_plan_rank": (_i, [_vp, _vp, ctypes.c_long, _vp, _vp, _vp]),
+    "liso_bev_plan_expand": (_i, [_vp, _vp, _vp, _i, ctypes.c_long, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "liso_raft_state_step_f32": (_i, [_i, _i, _vp, ctypes.c_long, _vp, _vp, _vp, _vp]),
     "liso_raft_upsample_scratch_bytes": (_sz, [_vp]),
     "liso_raft_upsample_outputs_fwd_f32": (_i, [_vp] * 5),

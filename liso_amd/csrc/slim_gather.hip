@@ -178,6 +178,69 @@ __global__ __launch_bounds__(256) void bev_lin_index_kernel(const T* __restrict_
     lin[i] = valid[i] ? (int)v : -1;
 }
 
+// ---- the plan's index arithmetic as three launches (BevGatherPlan.tiled / _sort: 48 framework launches per SLIM step before) ----------
+// copy j of the tiled batch [samples[:half]] * n_it + [samples[half:]] * n_it shows distinct sample src(j); its cells are shifted by
+// (j - src) * H * W
+__device__ __forceinline__ int tiled_src(int j, int n2, int n_it, int half) {
+    return j < half * n_it ? j % half : half + (j - half * n_it) % (n2 - half);
+}
+
+__global__ __launch_bounds__(256) void bev_plan_tile_lin_kernel(const int* __restrict__ rows, int n2, long n, int n_it, int half, int hw,
+                                                                int* __restrict__ lin) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)n2 * n_it * n) return;
+    const int j = (int)(i / n);
+    const long k = i - (long)j * n;
+    const int src = tiled_src(j, n2, n_it, half);
+    const int v = rows[(long)src * n + k];
+    lin[i] = v >= 0 ? v + (j - src) * hw : v;
+}
+
+// first index whose value is >= key in the ascending list s[0, n)
+__device__ __forceinline__ long lower_bound(const int* __restrict__ s, long n, int key) {
+    long lo = 0, hi = n;
+    while (lo < hi) {
+        const long mid = (lo + hi) >> 1;
+        if (s[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// rank of every row inside its run of equal cells = position - first position of the value; `order` narrowed to int32 on the way
+__global__ __launch_bounds__(256) void bev_plan_rank_kernel(const int* __restrict__ sorted_lin, const long long* __restrict__ order64, long n,
+                                                            int* __restrict__ rank, int* __restrict__ order32) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    rank[i] = (int)(i - lower_bound(sorted_lin, n, sorted_lin[i]));
+    if (order32) order32[i] = (int)order64[i];
+}
+
+// the sorted view of the tiled batch from the flat sort of the distinct samples ([invalid rows | sample 0's cells | sample 1's cells | ...]):
+// copy j's block = its sample's valid rows in sorted order, cells shifted, then invalid padding up to n rows.  One block = 256 rows of one copy.
+__global__ __launch_bounds__(256) void bev_plan_expand_kernel(const int* __restrict__ s_flat, const long long* __restrict__ o_flat,
+                                                              const int* __restrict__ rank_flat, int n2, long n, int n_it, int half, int hw,
+                                                              int* __restrict__ sorted_lin, int* __restrict__ order, int* __restrict__ rank) {
+    __shared__ long se[2];
+    const int j = blockIdx.y;
+    const int src = tiled_src(j, n2, n_it, half);
+    if (threadIdx.x < 2) se[threadIdx.x] = lower_bound(s_flat, (long)n2 * n, (src + (int)threadIdx.x) * hw);
+    __syncthreads();
+    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const long start = se[0], nv = se[1] - se[0];
+    const long o = (long)j * n + k;
+    if (k < nv) {
+        const long idx = start + k;
+        sorted_lin[o] = s_flat[idx] + (j - src) * hw;
+        order[o] = (int)(o_flat[idx] - (long)src * n + (long)j * n);
+        rank[o] = rank_flat[idx];
+    } else {
+        sorted_lin[o] = -1;
+        order[o] = 0;
+        rank[o] = 0;
+    }
+}
+
 inline int check_launch() { return hipGetLastError() == hipSuccess ? LISO_OK : LISO_ELAUNCH; }
 
 }  // namespace
@@ -205,6 +268,33 @@ int liso_bev_lin_index(const void* coors, int coors_are_int64, const unsigned ch
         bev_lin_index_kernel<long long><<<blocks, 256, 0, (hipStream_t)stream>>>((const long long*)coors, valid, rows, n, h, w, lin);
     else
         bev_lin_index_kernel<int><<<blocks, 256, 0, (hipStream_t)stream>>>((const int*)coors, valid, rows, n, h, w, lin);
+    return check_launch();
+}
+
+int liso_bev_plan_tile_lin(const int* rows, int n2, long n, int n_it, int half, int h, int w, int* lin, void* stream) {
+    if (n2 <= 0 || n < 0 || n_it < 1 || half <= 0 || half > n2 || h <= 0 || w <= 0) return LISO_EINVAL;
+    const long total = (long)n2 * n_it * n;
+    if (total == 0) return LISO_OK;
+    if (!rows || !lin) return LISO_EINVAL;
+    bev_plan_tile_lin_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(rows, n2, n, n_it, half, h * w, lin);
+    return check_launch();
+}
+
+int liso_bev_plan_rank(const int* sorted_lin, const long long* order64, long n, int* rank, int* order32, void* stream) {
+    if (n < 0) return LISO_EINVAL;
+    if (n == 0) return LISO_OK;
+    if (!sorted_lin || !rank || (order32 && !order64)) return LISO_EINVAL;
+    bev_plan_rank_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(sorted_lin, order64, n, rank, order32);
+    return check_launch();
+}
+
+int liso_bev_plan_expand(const int* s_flat, const long long* o_flat, const int* rank_flat, int n2, long n, int n_it, int half, int h, int w,
+                         int* sorted_lin, int* order, int* rank, void* stream) {
+    if (n2 <= 0 || n < 0 || n_it < 1 || half <= 0 || half > n2 || h <= 0 || w <= 0 || (long)n2 * h * w > 0x7fffffffL) return LISO_EINVAL;
+    if (n == 0) return LISO_OK;
+    if (!s_flat || !o_flat || !rank_flat || !sorted_lin || !order || !rank) return LISO_EINVAL;
+    const dim3 grid((unsigned)((n + 255) / 256), (unsigned)(n2 * n_it));
+    bev_plan_expand_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(s_flat, o_flat, rank_flat, n2, n, n_it, half, h * w, sorted_lin, order, rank);
     return check_launch();
 }
 

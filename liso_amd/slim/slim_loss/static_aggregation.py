@@ -40,6 +40,17 @@ class BevGatherPlan:
         H, W = int(grid_hw[0]), int(grid_hw[1])
         assert 0 < half <= n2 and n_it >= 1
         dev = small.lin.device
+        if small.lin.is_cuda:  # one launch (include/liso_slim.h: liso_bev_plan_tile_lin); the sorted view: _sort, two more
+            assert n2 * H * W * n_it < 2 ** 31
+            self = object.__new__(cls)
+            self.lin = torch.empty(n2 * n_it * N, dtype=torch.int32, device=dev)
+            with torch.cuda.device(dev):
+                L.check(L.lib().liso_bev_plan_tile_lin(L.ptr(small.lin), n2, N, n_it, half, H, W, L.ptr(self.lin), L.stream_ptr()),
+                        "bev_plan_tile_lin")
+            self.shape = (n2 * n_it, N, H, W)
+            self._sorted = None
+            self._tile_dev = (small.lin, n2, N, n_it, half, H, W)
+            return self
         src = torch.cat([torch.arange(half, device=dev).repeat(n_it), torch.arange(half, n2, device=dev).repeat(n_it)])
         off = ((torch.arange(src.numel(), device=dev) - src) * (H * W)).to(torch.int32)[:, None]
         rows = small.lin.view(n2, N)
@@ -53,6 +64,21 @@ class BevGatherPlan:
 
     def _sort(self):
         """the cell-sorted view of the list: only the adjoint needs it (inference never builds it)"""
+        if self._sorted is None and getattr(self, "_tile_dev", None) is not None:
+            # device tensors: ONE flat (radix) sort of the distinct samples' keys + two launches (rank inside the runs; expansion to the
+            # tiled batch with per-copy offsets) -- include/liso_slim.h: liso_bev_plan_rank / liso_bev_plan_expand
+            rows, n2, N, n_it, half, H, W = self._tile_dev
+            dev = rows.device
+            s_flat, o_flat = torch.sort(rows, stable=True)
+            rank_flat = torch.empty_like(s_flat)
+            total = n2 * n_it * N
+            sorted_lin, order, rank = (torch.empty(total, dtype=torch.int32, device=dev) for _ in range(3))
+            with torch.cuda.device(dev):
+                lib = L.lib()
+                L.check(lib.liso_bev_plan_rank(L.ptr(s_flat), None, s_flat.numel(), L.ptr(rank_flat), None, L.stream_ptr()), "bev_plan_rank")
+                L.check(lib.liso_bev_plan_expand(L.ptr(s_flat), L.ptr(o_flat), L.ptr(rank_flat), n2, N, n_it, half, H, W, L.ptr(sorted_lin),
+                                                 L.ptr(order), L.ptr(rank), L.stream_ptr()), "bev_plan_expand")
+            self._sorted = (sorted_lin, order, rank)
         if self._sorted is None and getattr(self, "_tile", None) is not None:
             rows, src, off, N = self._tile
             n2 = rows.shape[0]
@@ -74,6 +100,13 @@ class BevGatherPlan:
             order = torch.where(ok, local + (torch.arange(src.numel(), device=dev, dtype=torch.int32) * N)[:, None], torch.zeros_like(local))
             rank = torch.where(ok, rank_flat[idx], torch.zeros_like(local))
             self._sorted = (sorted_lin, order.reshape(-1).contiguous(), rank.reshape(-1).contiguous())
+        if self._sorted is None and self.lin.is_cuda:
+            sorted_lin, order64 = torch.sort(self.lin, stable=True)
+            seg_rank, order = torch.empty_like(sorted_lin), torch.empty_like(sorted_lin)
+            with torch.cuda.device(self.lin.device):
+                L.check(L.lib().liso_bev_plan_rank(L.ptr(sorted_lin), L.ptr(order64), sorted_lin.numel(), L.ptr(seg_rank), L.ptr(order),
+                                                   L.stream_ptr()), "bev_plan_rank")
+            self._sorted = (sorted_lin, order, seg_rank)
         if self._sorted is None:
             sorted_lin, order = torch.sort(self.lin, stable=True)
             pos = torch.arange(sorted_lin.numel(), device=self.lin.device, dtype=torch.int32)

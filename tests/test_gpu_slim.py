@@ -402,6 +402,28 @@ def test_bev_gather_backward_row_kernels_vs_torch_indexing(C, N):
     assert _rel(g1, g2.cpu().numpy()) < 2e-6
 
 
+@pytest.mark.parametrize("n2,N,H,W,n_it,half,p_valid", [(4, 500, 16, 16, 3, 2, 0.8), (2, 3000, 8, 8, 6, 1, 0.5), (2, 64, 4, 4, 2, 1, 1.0),
+                                                         (2, 40, 4, 4, 3, 1, 0.0), (2, 120000, 512, 512, 6, 1, 0.9), (3, 257, 5, 7, 2, 2, 0.7)])
+def test_gather_plan_on_the_device_equals_the_host_construction(n2, N, H, W, n_it, half, p_valid):
+    """BevGatherPlan / BevGatherPlan.tiled on device tensors (liso_bev_lin_index, liso_bev_plan_tile_lin, one radix sort,
+    liso_bev_plan_rank, liso_bev_plan_expand) against the same plans built by the torch path on host tensors: every array equal."""
+    from liso_amd.slim.slim_loss.static_aggregation import BevGatherPlan
+
+    g = torch.Generator().manual_seed(N + H)
+    coors = torch.randint(0, H, (n2, N, 2), generator=g)
+    coors[..., 1] = torch.randint(0, W, (n2, N), generator=g)
+    coors[0, : N // 3] = torch.tensor([H - 1, W - 1])  # a crowded cell
+    valid = torch.rand(n2, N, generator=g) < p_valid
+    host_t = BevGatherPlan.tiled(coors, valid, (H, W), n_it, half)
+    dev_t = BevGatherPlan.tiled(coors.cuda(), valid.cuda(), (H, W), n_it, half)
+    host_f = BevGatherPlan(coors, valid, (H, W))
+    dev_f = BevGatherPlan(coors.cuda().int(), valid.cuda(), (H, W))
+    for h_, d_ in ((host_t, dev_t), (host_f, dev_f)):
+        assert h_.shape == d_.shape and torch.equal(h_.lin, d_.lin.cpu())
+        for a, b in ((h_.sorted_lin, d_.sorted_lin), (h_.order, d_.order), (h_.seg_rank, d_.seg_rank)):
+            assert b.dtype == torch.int32 and b.is_contiguous() and torch.equal(a, b.cpu())
+
+
 def _slim_cfg(tag):
     from liso_amd.utils.config import apply_slim_simple_knn_training, default_cfg
 
