@@ -85,6 +85,13 @@ int liso_slim_decode_points_bwd(const liso_slim_decode_cfg* cfg, const float* ra
  * l = mean_c(weight * (est_c - flow_c)^2); out[0] = sum of l over valid rows / number of valid rows (0 rows -> NaN, as torch).
  *   valid uint8 [S,N]; flow [S,N,3]; weight [S,N]; trafo float64 [S,4,4]; workspace >= liso_slim_loss_workspace_bytes().
  * Backward: grad_out float32 [1] -> grad_flow [S,N,3], grad_weight [S,N] (either may be NULL). */
+/* Per-channel maxima and minima of the first c <= 4 channels of a [rows, stride] fp32 map in one pass: out = [max_0..max_{c-1} |
+ * min_0..min_{c-1}], NaN propagating like torch.amax / amin.  The decoder's global logit extrema of the True / False output modes
+ * (liso/slim/model/head_decoder.py:779-955 takes torch.max / torch.min over the batch it is given): two launches instead of the two
+ * staged framework reductions that read the strided logit channels twice. */
+size_t liso_channel_extrema_workspace_bytes(void);
+int liso_channel_extrema_f32(const float* x, long rows, int stride, int c, float* out, void* workspace, size_t workspace_bytes, void* stream);
+
 size_t liso_slim_loss_workspace_bytes(void);
 int liso_slim_static_points_loss_fwd(int samples, long n, const float* pc, int pc_stride, const uint8_t* valid, const float* flow,
                                      const float* weight, const double* trafo, float* out, void* workspace, size_t workspace_bytes,

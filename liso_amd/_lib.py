@@ -206,6 +206,8 @@ SIGNATURES = {
     "liso_gru_out_rows_f32": (_i, [ctypes.c_long, _i, _vp, ctypes.c_long, _vp, _vp, ctypes.c_long, _vp]),
     "liso_multi_copy": (_i, [_i, _vp, _vp, _vp, _vp]),
     "liso_bev_lin_index": (_i, [_vp, _i, _vp, _i, ctypes.c_long, _i, _i, _vp, _vp]),
+    "liso_channel_extrema_workspace_bytes": (_sz, []),
+    "liso_channel_extrema_f32": (_i, [_vp, ctypes.c_long, _i, _i, _vp, _vp, _sz, _vp]),
     "liso_bev_plan_tile_lin": (_i, [_vp, _i, ctypes.c_long, _i, _i, _i, _i, _vp, _vp]),
     "liso_bev_plan_rank": (_i, [_vp, _vp, ctypes.c_long, _vp, _vp, _vp]),
     "liso_bev_plan_expand": (_i, [_vp, _vp, _vp, _i, ctypes.c_long, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),

@@ -502,6 +502,62 @@ __global__ __launch_bounds__(kThreads) void nploss_masked_bwd_kernel(liso_slim_n
     gflow[3 * row] = g[0]; gflow[3 * row + 1] = g[1]; gflow[3 * row + 2] = g[2];
 }
 
+// ---- per-channel extrema of a [rows, stride] map's first c <= 4 channels (the decoder's global logit extrema, head_decoder.py:779-955) ----
+// max / min are exact in any order: block partials, one final block.  NaN propagates like torch.amax / amin.
+constexpr int kExtBlocks = 512;
+__device__ __forceinline__ float nan_max(float m, float v) { return (v > m || v != v) ? v : m; }
+__device__ __forceinline__ float nan_min(float m, float v) { return (v < m || v != v) ? v : m; }
+
+__global__ __launch_bounds__(256) void channel_extrema_partial_kernel(const float* __restrict__ x, long rows, int stride, int c,
+                                                                      float* __restrict__ partial) {
+    float hi[4], lo[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { hi[k] = -INFINITY; lo[k] = INFINITY; }
+    const bool vec = c == 4 && (stride & 3) == 0 && (((uintptr_t)x) & 15) == 0;
+    for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < rows; r += (long)gridDim.x * 256) {
+        float v[4];
+        if (vec) {
+            const float4 q = *reinterpret_cast<const float4*>(x + r * stride);
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[k] = k < c ? x[r * stride + k] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) { hi[k] = nan_max(hi[k], v[k]); lo[k] = nan_min(lo[k], v[k]); }
+    }
+    __shared__ float red[4][8];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { hi[k] = nan_max(hi[k], __shfl_xor(hi[k], o)); lo[k] = nan_min(lo[k], __shfl_xor(lo[k], o)); }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int k = 0; k < 4; k++) { red[wave][k] = hi[k]; red[wave][4 + k] = lo[k]; }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        const bool is_hi = threadIdx.x < 4;
+        float m = red[0][threadIdx.x];
+        for (int w = 1; w < 4; w++) m = is_hi ? nan_max(m, red[w][threadIdx.x]) : nan_min(m, red[w][threadIdx.x]);
+        partial[(long)blockIdx.x * 8 + threadIdx.x] = m;
+    }
+}
+
+__global__ __launch_bounds__(256) void channel_extrema_final_kernel(const float* __restrict__ partial, int nblk, int c, float* __restrict__ out) {
+    __shared__ float red[32][8];
+    const int col = threadIdx.x & 7, grp = threadIdx.x >> 3;  // 32 groups x 8 columns (4 maxima | 4 minima)
+    const bool is_hi = col < 4;
+    float m = is_hi ? -INFINITY : INFINITY;
+    for (int b = grp; b < nblk; b += 32) m = is_hi ? nan_max(m, partial[(long)b * 8 + col]) : nan_min(m, partial[(long)b * 8 + col]);
+    red[grp][col] = m;
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        for (int g = 1; g < 32; g++) m = is_hi ? nan_max(m, red[g][col]) : nan_min(m, red[g][col]);
+        if ((col & 3) < c) out[(is_hi ? 0 : c) + (col & 3)] = m;
+    }
+}
+
 inline bool cfg_ok(const liso_slim_decode_cfg* c) {
     if (!c || c->samples < 1 || c->n < 0 || c->h < 1 || c->w < 1) return false;
     for (int i = 0; i < 4; i++)
@@ -635,6 +691,21 @@ int liso_slim_nearest_point_loss_bwd(const liso_slim_nploss_cfg* cfg, const floa
                                                                                     (const long long*)order, grad_out, grad_dist_sqr,
                                                                                     (const double*)workspace, grad_flow);
     return check_launch();
+}
+
+
+size_t liso_channel_extrema_workspace_bytes(void) { return (size_t)kExtBlocks * 8 * sizeof(float); }
+
+int liso_channel_extrema_f32(const float* x, long rows, int stride, int c, float* out, void* workspace, size_t workspace_bytes, void* stream) {
+    if (rows <= 0 || c < 1 || c > 4 || stride < c) return LISO_EINVAL;
+    if (!x || !out || !workspace) return LISO_EINVAL;
+    if (workspace_bytes < liso_channel_extrema_workspace_bytes()) return LISO_EWORKSPACE;
+    long nb = (rows + 255) / 256;
+    nb = nb > kExtBlocks ? kExtBlocks : nb;
+    hipStream_t st = (hipStream_t)stream;
+    channel_extrema_partial_kernel<<<(unsigned)nb, 256, 0, st>>>(x, rows, stride, c, (float*)workspace);
+    channel_extrema_final_kernel<<<1, 256, 0, st>>>((const float*)workspace, (int)nb, c, out);
+    return hipGetLastError() == hipSuccess ? LISO_OK : LISO_ELAUNCH;
 }
 
 }  // extern "C"

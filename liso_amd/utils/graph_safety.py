@@ -78,8 +78,29 @@ def two_stage_sum(t):
 
 
 def channel_extrema(maps):
-    """(amax, amin) over all but the last dimension of [..., C], staged like two_stage_*"""
+    """(amax, amin) over all but the last dimension of [..., C]; device fp32 maps of <= 4 channels whose pixels are regular rows (a channel
+    slice of a channels-last tensor): one pass, two launches (include/liso_slim_decode.h: liso_channel_extrema_f32); else staged like
+    two_stage_*"""
     C = maps.shape[-1]
+    m = maps.detach()
+    if m.is_cuda and m.dtype == torch.float32 and 1 <= C <= 4 and m.numel() > 0 and m.stride(-1) == 1:
+        rows, st, regular = m.numel() // C, m.stride(-2) if m.dim() > 1 else C, True
+        acc = st
+        for d in range(m.dim() - 2, -1, -1):  # rows st floats apart throughout
+            if m.shape[d] != 1 and m.stride(d) != acc:
+                regular = False
+                break
+            acc *= m.shape[d]
+        if regular and st >= C:
+            from liso_amd import _lib as L
+
+            lib = L.lib()
+            nbytes = lib.liso_channel_extrema_workspace_bytes()
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=m.device)
+            out = torch.empty(2 * C, dtype=torch.float32, device=m.device)
+            with torch.cuda.device(m.device):
+                L.check(lib.liso_channel_extrema_f32(L.ptr(m), rows, st, C, L.ptr(out), L.ptr(ws), nbytes, L.stream_ptr()), "channel_extrema")
+            return out[:C], out[C:]
     f = maps.detach().reshape(-1, C)
     hi = lo = f
     while hi.shape[0] > 2048:

@@ -424,6 +424,23 @@ def test_gather_plan_on_the_device_equals_the_host_construction(n2, N, H, W, n_i
             assert b.dtype == torch.int32 and b.is_contiguous() and torch.equal(a, b.cpu())
 
 
+@pytest.mark.parametrize("shape,C,off", [((12, 64, 64, 8), 4, 0), ((2, 33, 17, 8), 4, 0), ((3, 50, 6), 3, 1), ((5, 7, 4), 4, 0), ((1, 1, 8), 2, 5)])
+def test_channel_extrema_equals_amax_amin(shape, C, off):
+    """graph_safety.channel_extrema on a channel slice of a channels-last map (liso_channel_extrema_f32: one pass, block partials):
+    the maxima / minima torch.amax / amin give, NaN propagating"""
+    from liso_amd.utils.graph_safety import channel_extrema
+
+    g = torch.Generator().manual_seed(sum(shape))
+    base = (torch.randn(*shape, generator=g) * 50).cuda()
+    m = base[..., off:off + C]
+    hi, lo = channel_extrema(m)
+    f = m.reshape(-1, C)
+    assert torch.equal(hi, f.amax(dim=0)) and torch.equal(lo, f.amin(dim=0))
+    base[tuple(0 for _ in shape[:-1]) + (off,)] = float("nan")
+    hi, lo = channel_extrema(m)
+    assert bool(torch.isnan(hi[0])) and bool(torch.isnan(lo[0])) and torch.equal(hi[1:], f.amax(dim=0)[1:]) and torch.equal(lo[1:], f.amin(dim=0)[1:])
+
+
 def _slim_cfg(tag):
     from liso_amd.utils.config import apply_slim_simple_knn_training, default_cfg
 
