@@ -24,5 +24,7 @@ timeout 400 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU
 find $OUT -name "*_kernel_trace.csv" -delete
 find $OUT -name "*.db" -delete
 python3 $R/scripts/pmc_summary.py $OUT > $OUT/pmc_summary.txt 2>&1
+# (the per-dispatch counter files are summarised into pmc_<PASS>.csv above: drop them, gpurun_out/ is capped at 64 MiB for the WHOLE call)
+find $OUT -name "*counter_collection.csv" -delete
 du -sh $OUT | tail -1
 tail -c 600 $OUT/bench_line.json
