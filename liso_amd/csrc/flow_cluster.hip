@@ -18,36 +18,64 @@ namespace {
 
 constexpr double kFix = 16777216.0;  // 2^24 fixed-point scale: 6e-8 m resolution, |sum| < 5e11 m fits int64
 
-__global__ void bev_scatter_kernel(const float* __restrict__ points, int ps, const uint8_t* __restrict__ valid,
+__global__ __launch_bounds__(256) void bev_scatter_kernel(const float* __restrict__ points, int ps, const uint8_t* __restrict__ valid,
                                    const int32_t* __restrict__ coors, const float* __restrict__ flow, int fs,
                                    const double* __restrict__ ome, int batch, int n, int h, int w,
                                    long long* __restrict__ sums, int* __restrict__ counts) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)batch * n) return;
-    if (!valid[i]) return;  // masked_scatter_mean_2d only scatters valid rows (:63-66)
-    const int b = (int)(i / n);
-    const int r = coors[i * 2 + 0], c = coors[i * 2 + 1];
-    if (r < 0 || r >= h || c < 0 || c >= w) return;
-    const float* p = points + i * ps;
-    const float* f = flow + i * fs;
-    const double* M = ome + (size_t)b * 16;
-    const double x = p[0], y = p[1], z = p[2];
-    float nr[3];
+    const int lane = threadIdx.x & 63;
+    long long cell = -1;
+    long long q[4] = {0, 0, 0, 0};
+    if (i < (size_t)batch * n && valid[i]) {  // masked_scatter_mean_2d only scatters valid rows (:63-66)
+        const int b = (int)(i / n);
+        const int r = coors[i * 2 + 0], c = coors[i * 2 + 1];
+        if (r >= 0 && r < h && c >= 0 && c < w) {
+            const float* p = points + i * ps;
+            const float* f = flow + i * fs;
+            const double* M = ome + (size_t)b * 16;
+            const double x = p[0], y = p[1], z = p[2];
+            float nr[3];
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        // bev_flow_utils.py:28-41: static flow = ((inv(odom) - I) [x y z 1])[:3] in fp64, cast to fp32, subtracted in fp32
-        const float stat = (float)(M[k * 4 + 0] * x + M[k * 4 + 1] * y + M[k * 4 + 2] * z + M[k * 4 + 3]);
-        nr[k] = f[k] - stat;
+            for (int k = 0; k < 3; k++) {
+                // bev_flow_utils.py:28-41: static flow = ((inv(odom) - I) [x y z 1])[:3] in fp64, cast to fp32, subtracted in fp32
+                const float stat = (float)(M[k * 4 + 0] * x + M[k * 4 + 1] * y + M[k * 4 + 2] * z + M[k * 4 + 3]);
+                nr[k] = f[k] - stat;
+            }
+            // torch.linalg.norm (fp32)
+            const float len = sqrtf(nr[0] * nr[0] + nr[1] * nr[1] + nr[2] * nr[2]);
+            cell = (long long)(((size_t)b * h + r) * w + c);
+            q[0] = llrint((double)len * kFix);
+            q[1] = llrint((double)nr[0] * kFix);
+            q[2] = llrint((double)nr[1] * kFix);
+            q[3] = llrint((double)nr[2] * kFix);
+        }
     }
-    // torch.linalg.norm (fp32)
-    const float len = sqrtf(nr[0] * nr[0] + nr[1] * nr[1] + nr[2] * nr[2]);
-    const size_t cell = ((size_t)b * h + r) * w + c;
+    // consecutive returns of one ring fall into the same pillar: the lanes of a RUN of equal cells add up in the wave (integer sums:
+    // any grouping gives the same bits) and the run's first lane issues the five atomics for all of them
+    const long long prev = __shfl_up(cell, 1);
+    const bool head = lane == 0 || prev != cell;
+    const unsigned long long heads = __ballot(head);
+    const int run = __popcll(heads & ((2ull << lane) - 1ull));  // run index of this lane (1-based)
+    int cnt = cell >= 0 ? 1 : 0;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int other_run = __shfl_down(run, o);
+        const bool take = lane + o < 64 && other_run == run;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const long long v = __shfl_down(q[k], o);
+            if (take) q[k] += v;
+        }
+        const int vc = __shfl_down(cnt, o);
+        if (take) cnt += vc;
+    }
+    if (!head || cell < 0) return;
     unsigned long long* s = (unsigned long long*)(sums + cell * 4);
-    atomicAdd(s + 0, (unsigned long long)(long long)llrint((double)len * kFix));
-    atomicAdd(s + 1, (unsigned long long)(long long)llrint((double)nr[0] * kFix));
-    atomicAdd(s + 2, (unsigned long long)(long long)llrint((double)nr[1] * kFix));
-    atomicAdd(s + 3, (unsigned long long)(long long)llrint((double)nr[2] * kFix));
-    atomicAdd(&counts[cell], 1);
+    atomicAdd(s + 0, (unsigned long long)q[0]);
+    atomicAdd(s + 1, (unsigned long long)q[1]);
+    atomicAdd(s + 2, (unsigned long long)q[2]);
+    atomicAdd(s + 3, (unsigned long long)q[3]);
+    atomicAdd(&counts[cell], cnt);
 }
 
 __global__ void bev_mean_kernel(const long long* __restrict__ sums, const int* __restrict__ counts, size_t cells,
