@@ -53,6 +53,7 @@ struct WgArgs {
     int x_plane_bytes;  // multiple of 16
     int psx;            // LDS bytes per x pixel
     int th;             // tile rows
+    int ci_w;           // conv_wgrad_rs3_kernel: input channels per block (64, or 32: half the accumulators, half the slab per block)
     int pipelined;      // bf16: the halo tile fits one register batch -> tile k+1 is loaded during the MFMAs of tile k
     int compact;        // strided convolution whose tap groups each sit in ONE kernel row: the LDS tile holds only the input rows that
                         // group reads (row r of the tile = input row iy0 + (group's dy) + r * isy) instead of the class's dense halo
@@ -509,16 +510,23 @@ constexpr int RPS = 128;  // LDS bytes per pixel and plane (64 bf16 channels)
 // pixels are every second pixel of a row, so pixel pairs (2, 3), (6, 7), ... swap their LDS slots and the 64-B half swap follows bit 2
 // (the four pixels of a transposing read then again fall into four different 16-bank ranges); input rows 2o and 2o + 2 of the tile
 // serve kernel rows 0 and 2 of neighbouring output rows from the same fragments.
-template <int MODE, int TH, int S>
+// CIW = 64 | 32 input channels per block.  32: the four MFMA waves are (output-channel half, 16-pixel column half) instead of (input half,
+// output half) -- every wave multiplies one column half of every tile row, the two column halves' sums are added through LDS behind the
+// pixel loop (fixed order) and a block writes 9 x 32 x 64 sums: half the slab bytes per launch and per reduction, twice the tiles per
+// block.  At B = 2-4 a block has only 4 tiles of work and its slab (147 KB, written and read once more by the reduction) costs more
+// memory time than its inputs: profiles/r06_wgrad_stamps.txt.
+template <int MODE, int TH, int S, int CIW>
 __global__ __launch_bounds__(kRsThreads, 1) void conv_wgrad_rs3_kernel(const liso_conv_desc d, const WgArgs a) {
     constexpr bool X3 = MODE == LISO_CONV_F32X3;
     constexpr int PLANES = X3 ? 2 : 1;
     constexpr int IW = (TW - 1) * S + 3, IH = (TH - 1) * S + 3;  // halo tile (padding 1)
     constexpr int NPX = IH * IW;                     // halo pixels
     constexpr int NSLOT = (NPX + 3) / 4 * 4;         // LDS pixel slots (S = 2 swaps pixel pairs: the last pair may reach NPX)
-    constexpr int CPP = X3 ? 16 : 8;                 // 16-B global chunks per pixel (64 channels)
-    constexpr int PSL = 256 / CPP;                   // pixel slots of the 256 loader threads
-    constexpr int XB = (NPX + PSL - 1) / PSL;        // chunks per loader thread
+    constexpr int CPP = X3 ? 16 : 8;                 // 16-B global chunks per pixel (64 channels): dy
+    constexpr int PSL = 256 / CPP;                   // pixel slots of the 256 loader threads: dy
+    constexpr int CPPX = CPP * CIW / 64;             // ... of the x tile (CIW channels)
+    constexpr int PSLX = 256 / CPPX;
+    constexpr int XB = (NPX + PSLX - 1) / PSLX;      // chunks per loader thread
     constexpr int YB = TH * TW / PSL;                // dy: TH x 32 pixels
     constexpr int X_PLANE = NSLOT * RPS, Y_PLANE = TH * TW * RPS;
     constexpr int X_BYTES = PLANES * X_PLANE;
@@ -531,14 +539,15 @@ __global__ __launch_bounds__(kRsThreads, 1) void conv_wgrad_rs3_kernel(const lis
     t /= a.splits;
     const int cot = t % a.co_t;
     const int cit = t / a.co_t;
-    const int ci0 = cit * CT, co0 = cot * CT;
-    const long cip = (long)a.ci_t * CT, cop = (long)a.co_t * CT;
+    const int ci0 = cit * CIW, co0 = cot * CT;
+    const long cip = (long)a.ci_t * CIW, cop = (long)a.co_t * CT;
     const int n_mine = split < a.n_tiles ? (a.n_tiles - split + a.splits - 1) / a.splits : 0;  // tiles of this block
 
     if (wave >= 4) {
         // ================================ loader waves ================================
         const int ltid = tid - 256;
-        const int cc = ltid % CPP, p0 = ltid / CPP;
+        const int cc = ltid % CPP, p0 = ltid / CPP;      // dy: chunk of the pixel, first pixel slot
+        const int ccx = ltid % CPPX, p0x = ltid / CPPX;  // x
         uint4 xv[XB], yv[YB];
         unsigned xok = 0u, yok = 0u;
         float sc[NE], sh[NE];
@@ -547,7 +556,7 @@ __global__ __launch_bounds__(kRsThreads, 1) void conv_wgrad_rs3_kernel(const lis
         for (int e = 0; e < NE; e++) bsum[e] = 0.0f;
         const bool want_bias = a.bias_slab != nullptr && cit == 0;
         const bool pro = a.in_scale != nullptr;
-        const int ch = ci0 + cc * NE, chy = co0 + cc * NE;
+        const int ch = ci0 + ccx * NE, chy = co0 + cc * NE;
         const bool ch_ok = ch < d.ci, chy_ok = chy < d.co;
         if (pro) {
 #pragma unroll
@@ -561,7 +570,7 @@ __global__ __launch_bounds__(kRsThreads, 1) void conv_wgrad_rs3_kernel(const lis
         unsigned lyx[XB];
 #pragma unroll
         for (int u = 0; u < XB; u++) {
-            const int pix = p0 + u * PSL;
+            const int pix = p0x + u * PSLX;
             const int ly = pix / IW, lx = pix - ly * IW;
             rel[u] = (ly * d.wi + lx) * d.x_pix_stride;
             lyx[u] = (unsigned)ly | ((unsigned)lx << 8) | (pix < NPX && ch_ok ? 0x10000u : 0u);
@@ -609,7 +618,7 @@ __global__ __launch_bounds__(kRsThreads, 1) void conv_wgrad_rs3_kernel(const lis
             unsigned char* ys = buf + X_BYTES;
 #pragma unroll
             for (int u = 0; u < XB; u++) {
-                const int pix = p0 + u * PSL;
+                const int pix = p0x + u * PSLX;
                 if (pix >= NPX) continue;
                 const int swz = S == 1 ? ((pix >> 1) & 1) << 6 : ((pix >> 2) & 1) << 6;
                 const int slot = S == 1 ? pix : pix ^ ((pix >> 1) & 1);
@@ -630,8 +639,8 @@ __global__ __launch_bounds__(kRsThreads, 1) void conv_wgrad_rs3_kernel(const lis
                         hi2[e] = pack_bf16(h0, h1);
                         lo2[e] = pack_bf16(f[2 * e] - h0, f[2 * e + 1] - h1);
                     }
-                    *reinterpret_cast<uint2*>(xs + slot * RPS + ((cc * 8) ^ swz)) = make_uint2(hi2[0], hi2[1]);
-                    *reinterpret_cast<uint2*>(xs + X_PLANE + slot * RPS + ((cc * 8) ^ swz)) = make_uint2(lo2[0], lo2[1]);
+                    *reinterpret_cast<uint2*>(xs + slot * RPS + ((ccx * 8) ^ swz)) = make_uint2(hi2[0], hi2[1]);
+                    *reinterpret_cast<uint2*>(xs + X_PLANE + slot * RPS + ((ccx * 8) ^ swz)) = make_uint2(lo2[0], lo2[1]);
                 } else {
                     uint4 o = xv[u];
                     if (pro) {
@@ -649,7 +658,7 @@ __global__ __launch_bounds__(kRsThreads, 1) void conv_wgrad_rs3_kernel(const lis
                         o = make_uint4(w[0], w[1], w[2], w[3]);
                     }
                     if (!((xok >> u) & 1u)) o = make_uint4(0u, 0u, 0u, 0u);
-                    *reinterpret_cast<uint4*>(xs + slot * RPS + ((cc * 16) ^ swz)) = o;
+                    *reinterpret_cast<uint4*>(xs + slot * RPS + ((ccx * 16) ^ swz)) = o;
                 }
             }
 #pragma unroll
@@ -734,11 +743,15 @@ __global__ __launch_bounds__(kRsThreads, 1) void conv_wgrad_rs3_kernel(const lis
             for (int pp = 0; pp < PSL; pp++) s_ += red[(pp * CPP + grp_c) * NE + e];
             a.bias_slab[(long)split * cop + co0 + ltid] = s_;
         }
+        if constexpr (CIW == 32) __syncthreads();  // (D) the MFMA waves' hand-over below
         return;
     }
     // ================================ MFMA waves ================================
     const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
-    const int ci_half = wave >> 1, co_half = wave & 1;
+    // CIW = 64: wave = (input-channel half, output-channel half), both 16-pixel column halves of a tile row.
+    // CIW = 32: wave = (column half, output-channel half), the block's 32 input channels.
+    const int ci_half = CIW == 64 ? wave >> 1 : 0, co_half = wave & 1;
+    const int c_lo = CIW == 64 ? 0 : wave >> 1, c_hi = CIW == 64 ? 2 : (wave >> 1) + 1;
     // lane offsets of the transposing reads, relative to the fragment's first pixel `base`, for every alignment of `base` that changes
     // them.  S = 1: pixel base + 8 (g >> 1) + q, the half swap follows bit 1 (4 alignments; + 4 or + 8 pixels never change it).
     // S = 2: pixel base + 2 (8 (g >> 1) + q), slot = pixel ^ bit 1, half swap on bit 2 (8 alignments; + 8 or + 16 change neither).
@@ -780,7 +793,7 @@ __global__ __launch_bounds__(kRsThreads, 1) void conv_wgrad_rs3_kernel(const lis
         const unsigned char* xs = smem + (k & 1) * BUF;
         const unsigned char* ys = xs + X_BYTES;
 #pragma unroll
-        for (int c = 0; c < 2; c++) {
+        for (int c = c_lo; c < c_hi; c++) {
             bf8 bf[3], bl[3];
 #pragma unroll
             for (int r = 0; r < IH; r++) {
@@ -823,6 +836,23 @@ __global__ __launch_bounds__(kRsThreads, 1) void conv_wgrad_rs3_kernel(const lis
 #ifdef LISO_WGRAD_STAMPS
     const unsigned long long ms_k2 = __builtin_amdgcn_s_memtime();
 #endif
+    if constexpr (CIW == 32) {
+        // the two column halves' sums: waves 2 | 3 hand theirs over through LDS ([wave][tap][register][lane]: 256-B rows), waves 0 | 1 add
+        // them to their own (own + other: a fixed order) and write the slab.  (The first 8 KB hold the loader waves' bias rows.)
+        float* hand = reinterpret_cast<float*>(smem + 8192) + (size_t)(wave & 1) * 9 * 16 * 64;
+        if (wave >= 2) {
+#pragma unroll
+            for (int i = 0; i < 9; i++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) hand[(i * 16 + e) * 64 + lane] = acc[i][e];
+        }
+        __syncthreads();  // (D)
+        if (wave >= 2) return;
+#pragma unroll
+        for (int i = 0; i < 9; i++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][e] += hand[(i * 16 + e) * 64 + lane];
+    }
     // ---- slab: D[row = ci][col = co]; col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5) ---------------------------------
     const int r = lane & 31, h = lane >> 5;
 #pragma unroll
@@ -1343,7 +1373,14 @@ bool make_rs3_plan(const liso_conv_desc& d, Rs3Plan* p) {
     for (int t = 0; t < 9; t++)
         if (d.tap_dy[t] != t / 3 - 1 || d.tap_dx[t] != t % 3 - 1 || d.tap_w[t] < 0 || d.tap_w[t] >= 9) return false;
     WgArgs& a = p->a;
-    a.ci_t = (d.ci + CT - 1) / CT;
+    // 32 input channels per block (half the slab per launch and block, twice the tiles per block) -- only where the layer HAS no more than
+    // 32 (the SLIM encoders' first stage: 42.4 -> 38.5 us).  Measured (scripts/wgrad_time.py, wgrad + reduction): bf16 4 x 128 -> 128 at
+    // 128^2 39.3 -> 49.1 us, B = 2 32.3 -> 45.9, 64 -> 64 at 256^2 39.4 -> 48.5, 256 -> 256 at 64^2 40.8 -> 51.1; fp32 64 -> 64 35.7 ->
+    // 37.3, 304 -> 192 x 12 maps 192.7 -> 227.8: a wave that multiplies one column half per tile row pays the tile's barrier and the
+    // priming of its row-stationary fragments for half the products -- the slab bytes it saves are worth less.  LISO_WGRAD_CIW: experiments
+    a.ci_w = (S == 1 && d.ci <= 32) ? 32 : CT;
+    if (const char* e = getenv("LISO_WGRAD_CIW")) a.ci_w = (atoi(e) == 32 && S == 1) ? 32 : CT;
+    a.ci_t = (d.ci + a.ci_w - 1) / a.ci_w;
     a.co_t = (d.co + CT - 1) / CT;
     const long cc = (long)a.ci_t * a.co_t;
     long want = 256 / cc;  // one block per CU
@@ -1371,7 +1408,7 @@ bool make_rs3_plan(const liso_conv_desc& d, Rs3Plan* p) {
     p->blocks = (int)(cc * s);
     const int npx = ((th - 1) * S + 3) * ((TW - 1) * S + 3);
     p->lds = 2 * (x3 ? 2 : 1) * ((npx + 3) / 4 * 4 + th * TW) * RPS;  // two tile buffers (of two planes each for F32X3)
-    p->slab_bytes = (size_t)s * 9 * a.ci_t * CT * a.co_t * CT * sizeof(float);
+    p->slab_bytes = (size_t)s * 9 * a.ci_t * a.ci_w * a.co_t * CT * sizeof(float);
     p->bias_bytes = (size_t)s * a.co_t * CT * sizeof(float);
     return true;
 }
@@ -1380,19 +1417,19 @@ bool make_rs3_plan(const liso_conv_desc& d, Rs3Plan* p) {
 unsigned long long* g_wgrad_stamps = nullptr;  // 4096 blocks x 16 counters
 #endif
 
-template <int MODE, int TH, int S>
+template <int MODE, int TH, int S, int CIW = 64>
 int launch_rs3(const liso_conv_desc& d, const Rs3Plan& p, hipStream_t st) {
     static liso_dev::PerDeviceFlag attr_set;
-    if (!liso_dev::lds_opt_in(attr_set, (const void*)conv_wgrad_rs3_kernel<MODE, TH, S>, 160 * 1024)) return LISO_ELAUNCH;
+    if (!liso_dev::lds_opt_in(attr_set, (const void*)conv_wgrad_rs3_kernel<MODE, TH, S, CIW>, 160 * 1024)) return LISO_ELAUNCH;
 #ifdef LISO_WGRAD_STAMPS
     if (!g_wgrad_stamps && hipMalloc((void**)&g_wgrad_stamps, 4096 * 16 * 8) != hipSuccess) return LISO_ELAUNCH;
     (void)hipMemsetAsync(g_wgrad_stamps, 0, 4096 * 16 * 8, st);
     Rs3Plan q = p;
     q.a.stamps = p.blocks <= 4096 ? g_wgrad_stamps : nullptr;
-    conv_wgrad_rs3_kernel<MODE, TH, S><<<q.blocks, kRsThreads, q.lds, st>>>(d, q.a);
+    conv_wgrad_rs3_kernel<MODE, TH, S, CIW><<<q.blocks, kRsThreads, q.lds, st>>>(d, q.a);
     return hipGetLastError() == hipSuccess ? LISO_OK : LISO_ELAUNCH;
 #endif
-    conv_wgrad_rs3_kernel<MODE, TH, S><<<p.blocks, kRsThreads, p.lds, st>>>(d, p.a);
+    conv_wgrad_rs3_kernel<MODE, TH, S, CIW><<<p.blocks, kRsThreads, p.lds, st>>>(d, p.a);
     return hipGetLastError() == hipSuccess ? LISO_OK : LISO_ELAUNCH;
 }
 
@@ -1597,13 +1634,19 @@ int liso_conv_wgrad(const liso_conv_desc* d, const void* x, const float* in_scal
         r3.a.slab = (float*)workspace;
         r3.a.bias_slab = dbias ? (float*)((char*)workspace + r3.slab_bytes) : nullptr;
         hipStream_t st3 = (hipStream_t)stream;
-        const int rc3 = d->mode == LISO_CONV_F32X3 ? launch_rs3<LISO_CONV_F32X3, 3, 1>(*d, r3, st3)
-                        : r3.stride == 2       ? launch_rs3<LISO_CONV_BF16, 3, 2>(*d, r3, st3)
-                        : r3.th == 8           ? launch_rs3<LISO_CONV_BF16, 8, 1>(*d, r3, st3)
-                                               : launch_rs3<LISO_CONV_BF16, 4, 1>(*d, r3, st3);
+        int rc3;
+        if (r3.a.ci_w == 32)
+            rc3 = d->mode == LISO_CONV_F32X3 ? launch_rs3<LISO_CONV_F32X3, 3, 1, 32>(*d, r3, st3)
+                  : r3.th == 8           ? launch_rs3<LISO_CONV_BF16, 8, 1, 32>(*d, r3, st3)
+                                         : launch_rs3<LISO_CONV_BF16, 4, 1, 32>(*d, r3, st3);
+        else
+            rc3 = d->mode == LISO_CONV_F32X3 ? launch_rs3<LISO_CONV_F32X3, 3, 1>(*d, r3, st3)
+                  : r3.stride == 2       ? launch_rs3<LISO_CONV_BF16, 3, 2>(*d, r3, st3)
+                  : r3.th == 8           ? launch_rs3<LISO_CONV_BF16, 8, 1>(*d, r3, st3)
+                                         : launch_rs3<LISO_CONV_BF16, 4, 1>(*d, r3, st3);
         if (rc3 != LISO_OK) return rc3;
         const int co_w3 = d->wgrad_co > 0 ? d->wgrad_co : d->co;
-        return launch_reduce(r3.a.slab, r3.a.bias_slab, r3.a.splits, r3.a.splits, d->w_taps, d->ci, co_w3, (long)r3.a.ci_t * CT,
+        return launch_reduce(r3.a.slab, r3.a.bias_slab, r3.a.splits, r3.a.splits, d->w_taps, d->ci, co_w3, (long)r3.a.ci_t * r3.a.ci_w,
                              (long)r3.a.co_t * CT, transposed, dw, dbias, st3);
     }
     WgPlan p;
