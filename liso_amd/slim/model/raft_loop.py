@@ -78,7 +78,7 @@ _S1, _S3, _S7 = MC.ConvSpec(1, 1, 1, 0), MC.ConvSpec(3, 3, 1, 1), MC.ConvSpec(7,
 def _merged_buffers(ub):
     """the loop's merged filters as persistent buffers on the update block (allocated and zeroed once per device / dtype: the
     off-diagonal blocks of the block-diagonal ones are never written again)"""
-    me, gru, fh, hd = ub.motion_encoder, ub.gru, ub.static_flow_head, ub.classification_head
+    me, gru = ub.motion_encoder, ub.gru
     d = _dims(ub)
     ch, co, cc, cf, cq, k1c, k1f, hf, hc = (d[k] for k in ("ch", "co", "cc", "cf", "cq", "k1c", "k1f", "hf", "hc"))
     dev = me.conv.weight.device
@@ -100,7 +100,7 @@ def _merged_weights(ub, ci):
     ONE launch places every block (liso_multi_copy_rows) into the persistent buffers of `_merged_buffers`."""
     me, gru, fh, hd = ub.motion_encoder, ub.gru, ub.static_flow_head, ub.classification_head
     d = _dims(ub)
-    ch, co, cc, cf, cq, k1c, k1f, hf, hc = (d[k] for k in ("ch", "co", "cc", "cf", "cq", "k1c", "k1f", "hf", "hc"))
+    ch, cc, cf, cq, k1c, hf = (d[k] for k in ("ch", "cc", "cf", "cq", "k1c", "hf"))
     B = _merged_buffers(ub)
     w71, b71 = B["c71"]
     wcf, bcf = B["cf"]
